@@ -1,0 +1,221 @@
+/*
+ * srk.h — C ABI of libsrk.so, the MI355X (gfx950 / CDNA4) kernel library behind the
+ * convolutional super-resolution hot path.
+ *
+ * The reference (togheppi/pytorch-super-resolution-model-collection) has no FFI layer: its
+ * hot path is the set of torch.nn calls made by base_networks.py and the per-model Net
+ * classes.  Each entry point below names the reference call site (file:line under
+ * /root/reference) whose arithmetic it replaces.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data owned by the caller; the library never
+ *     allocates, frees or retains a pointer past the call;
+ *   - activations are dense NHWC ("channels_last"): x[n][h][w][c];
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); no call
+ *     synchronises the device; calls are re-entrant (no global mutable state besides the
+ *     thread-local last-error string);
+ *   - return value: SRK_OK (0) or a negative srk_status; no exception crosses the ABI.
+ */
+#ifndef SRK_H_
+#define SRK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRK_VERSION 100 /* major*10000 + minor*100 + patch */
+
+typedef enum srk_status {
+  SRK_OK = 0,
+  SRK_ERR_BAD_ARG = -1,     /* null pointer, non-positive dim, inconsistent shapes        */
+  SRK_ERR_UNSUPPORTED = -2, /* legal request that no kernel in this build covers          */
+  SRK_ERR_LAUNCH = -3,      /* hipGetLastError() != hipSuccess after a launch             */
+  SRK_ERR_WORKSPACE = -4    /* caller-provided workspace smaller than srk_*_workspace_bytes */
+} srk_status;
+
+/* Activation kinds: base_networks.py:50-60 (ReLU / PReLU / LeakyReLU(0.2) / Tanh / Sigmoid). */
+typedef enum srk_act {
+  SRK_ACT_NONE = 0,
+  SRK_ACT_RELU = 1,
+  SRK_ACT_PRELU = 2, /* slope(s) read from device memory (learnable, base_networks.py:54) */
+  SRK_ACT_LRELU = 3, /* slope passed by value (0.2 in the reference, base_networks.py:56)  */
+  SRK_ACT_TANH = 4,
+  SRK_ACT_SIGMOID = 5
+} srk_act;
+
+/* Which implementation a conv call may use.  AUTO picks the fastest kernel that covers the
+ * shape; GENERIC forces the plain gather kernel (used by the tests to cross-check). */
+typedef enum srk_algo { SRK_ALGO_AUTO = 0, SRK_ALGO_GENERIC = 1, SRK_ALGO_MFMA = 2, SRK_ALGO_DIRECT = 3 } srk_algo;
+
+/* Geometry of one torch.nn.Conv2d / ConvTranspose2d call.
+ *   conv       (base_networks.py:42,112-113,156): y[n,oy,ox,co] = sum x[n,oy*s-p+kh,ox*s-p+kw,ci] * w
+ *   transposed (base_networks.py:77, fsrcnn.py:33):  y[n,oy,ox,co] = sum x[n,(oy+p-kh)/s,(ox+p-kw)/s,ci] * w
+ * (H,W,Cin) describe x and (OH,OW,Cout) describe y in both cases; OH/OW must equal
+ * srk_conv_out_dim(). */
+typedef struct srk_conv_desc {
+  int32_t N, H, W, Cin;
+  int32_t OH, OW, Cout;
+  int32_t KH, KW;
+  int32_t stride, pad;
+  int32_t transposed; /* 0: Conv2d, 1: ConvTranspose2d */
+  int32_t out_pad;    /* ConvTranspose2d output_padding (fsrcnn.py:33 uses 1) */
+  int32_t algo;       /* srk_algo */
+} srk_conv_desc;
+
+/* Fused epilogue of a forward conv:  y = PS_r( act(conv + bias) ) + residual
+ *   bias     : Conv2d bias (may be NULL — vdsr.py:17-24 and lapsrn.py are bias-free)
+ *   act      : ConvBlock activation (base_networks.py:67-70)
+ *   residual : torch.add(out, residual) of ResnetBlock / VDSR / EDSR / SRGAN
+ *              (base_networks.py:149, vdsr.py:31, edsr.py:42, srgan.py:39); indexed like y
+ *   ps_r     : PSBlock's PixelShuffle(r) fused into the store (base_networks.py:157,179-181);
+ *              0 or 1 = none.  With ps_r>1, y is [N, OH*r, OW*r, Cout/r^2]. */
+typedef struct srk_epilogue {
+  const float* bias;
+  const float* prelu_weight; /* SRK_ACT_PRELU: device slopes */
+  const float* residual;
+  float slope;               /* SRK_ACT_LRELU */
+  int32_t act;               /* srk_act */
+  int32_t prelu_n;           /* 1 (nn.PReLU() default) or number of output channels */
+  int32_t ps_r;
+} srk_epilogue;
+
+/* Activation-gradient prologue of the backward kernels: the incoming gradient dy is
+ * multiplied by act'(.) while it is loaded, using the SAVED FORWARD OUTPUT `y`
+ * (post-activation; valid for ReLU and positive-slope LeakyReLU, which is what
+ * ReLU(True)/LeakyReLU(0.2, True) in base_networks.py:52,56 keep alive). */
+typedef struct srk_bwd_mask {
+  const float* y; /* NULL = no mask */
+  float slope;    /* 0 for ReLU */
+} srk_bwd_mask;
+
+/* ---- queries --------------------------------------------------------------------------- */
+int srk_version(void);
+const char* srk_status_string(int status);
+const char* srk_last_error_string(void); /* thread-local, valid until the next failing call */
+/* Output spatial size of a conv / transposed conv along one axis (torch semantics). */
+int srk_conv_out_dim(int in, int k, int stride, int pad, int transposed, int out_pad);
+
+/* ---- layout ---------------------------------------------------------------------------- */
+/* NCHW <-> NHWC copies at the module boundary (the reference feeds NCHW tensors:
+ * edsr.py:146-152). */
+int srk_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, void* stream);
+int srk_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream);
+
+/* Weight repacks.  `w` is the state_dict tensor exactly as torch stores it:
+ *   Conv2d          [Cout][Cin][KH][KW]   (transposed = 0)
+ *   ConvTranspose2d [Cin][Cout][KH][KW]   (transposed = 1)
+ * Packed layout consumed by srk_conv2d_forward:        wp[kh][kw][ci][co]
+ * Packed layout consumed by srk_conv2d_backward_data:  wp[kh][kw][co][ci]
+ *   (for the data gradient the roles of the channel axes swap; the spatial flip is handled by
+ *   the kernels' index arithmetic, not by the packing).
+ * ps_r > 1 (forward only) additionally permutes the output channels to (i, j, c) order so a
+ * fused pixel-shuffle store is contiguous; bias must then be packed with srk_pack_bias_ps. */
+int srk_pack_weight_fwd(const float* w, float* wp, int Cout, int Cin, int KH, int KW, int transposed, int ps_r,
+                        void* stream);
+int srk_pack_weight_bwd(const float* w, float* wp, int Cout, int Cin, int KH, int KW, int transposed,
+                        void* stream);
+int srk_pack_bias_ps(const float* b, float* bp, int Cout, int ps_r, void* stream);
+
+/* ---- convolution (Conv2d / ConvTranspose2d: base_networks.py:42,77,112-113,156; fsrcnn.py:33) */
+int srk_conv2d_forward(const srk_conv_desc* d, const float* x, const float* w_packed_fwd, float* y,
+                       const srk_epilogue* ep, void* stream);
+/* dx = d(loss)/dx given dy; optional act-grad prologue on dy; optional fused "+ add_to"
+ * (gradient fan-in of a residual connection).  Replaces aten::convolution_backward (input
+ * gradient) as dispatched from loss.backward() — edsr.py:154, vdsr.py:146, srgan.py:286,309. */
+int srk_conv2d_backward_data(const srk_conv_desc* d, const float* dy, const float* w_packed_bwd, float* dx,
+                             const srk_bwd_mask* mask, const float* add_to, void* stream);
+/* dw (torch layout, see srk_pack_weight_*) and db (may be NULL).  beta = 0 overwrites,
+ * beta = 1 accumulates into dw/db (shared weights: lapsrn.py:40,44).  `workspace` holds the
+ * split-K partial sums; size from srk_conv2d_backward_weight_workspace_bytes. */
+size_t srk_conv2d_backward_weight_workspace_bytes(const srk_conv_desc* d);
+int srk_conv2d_backward_weight(const srk_conv_desc* d, const float* x, const float* dy, const srk_bwd_mask* mask,
+                               float* dw, float* db, float beta, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
+/* ---- pixel shuffle (torch.nn.PixelShuffle: base_networks.py:157,179-181) ----------------- */
+/* x [N,H,W,C*r*r] -> y [N,H*r,W*r,C];  channel c*r*r + i*r + j -> (c, h*r+i, w*r+j). */
+int srk_pixel_shuffle_forward(const float* x, float* y, int N, int H, int W, int C, int r, void* stream);
+/* dy [N,H*r,W*r,C] -> dx [N,H,W,C*r*r]  (aten::pixel_unshuffle in backward). */
+int srk_pixel_shuffle_backward(const float* dy, float* dx, int N, int H, int W, int C, int r, void* stream);
+
+/* ---- pointwise (base_networks.py:50-60,149; vdsr.py:31; edsr.py:42) ------------------------ */
+/* y = act(x); channels = innermost (NHWC) extent, used only by per-channel PReLU. */
+int srk_act_forward(const float* x, float* y, size_t n, int channels, int act, float slope,
+                    const float* prelu_weight, int prelu_n, void* stream);
+/* dx = dy * act'(.).  `saved` is the forward INPUT x for PReLU and the forward OUTPUT y for
+ * every other kind.  PReLU also accumulates d(slope) into dprelu (+=, caller zeroes). */
+int srk_act_backward(const float* dy, const float* saved, float* dx, size_t n, int channels, int act, float slope,
+                     const float* prelu_weight, int prelu_n, float* dprelu, void* stream);
+/* out = alpha*a + beta*b  (torch.add and autograd's gradient fan-in) */
+int srk_axpby(const float* a, const float* b, float* out, size_t n, float alpha, float beta, void* stream);
+/* out = x * (*alpha_dev): chain-rule scaling by an upstream scalar gradient that lives on the device
+ * (e.g. the 1e-3 weight of the adversarial term, srgan.py:308). */
+int srk_scale_dev(const float* x, const float* alpha_dev, float* out, size_t n, void* stream);
+
+/* ---- losses, reduction='mean' (srcnn.py:84-86,129; edsr.py:98-100,153; lapsrn.py:75-85;
+ *      srgan.py:157,276-297).  One pass: *loss = mean(...), dpred = d(loss)/d(pred)*grad_scale.
+ * pred/dpred are NHWC-dense; target is addressed through explicit element strides
+ * (n,c,h,w) so an NCHW target batch needs no copy.  dpred may be NULL (evaluation).
+ * `partials` is a caller-provided scratch of srk_loss_workspace_bytes(). */
+typedef enum srk_loss { SRK_LOSS_MSE = 0, SRK_LOSS_L1 = 1, SRK_LOSS_CHARBONNIER = 2, SRK_LOSS_BCE = 3 } srk_loss;
+size_t srk_loss_workspace_bytes(void);
+int srk_loss_forward_backward(int kind, const float* pred, const float* target, const int64_t* target_strides,
+                              int N, int C, int H, int W, float eps, float grad_scale, float* loss, float* dpred,
+                              void* workspace, void* stream);
+
+/* ---- optimizers over flat fp32 buffers (srcnn.py:79; fsrcnn.py:105-106; vdsr.py:86-90,149;
+ *      espcn.py:79; edsr.py:93; srgan.py:147-149) --------------------------------------------- */
+/* torch.optim.SGD: g += wd*p; buf = mom*buf + g (first step: buf = g); p -= lr*(nesterov ? g+mom*buf : buf).
+ * `first_step` selects the buf = g initialisation. lr/scale are read from device memory when the
+ * *_dev pointers are non-NULL (keeps a captured hipGraph valid across LR decay / grad clipping). */
+int srk_sgd_step(float* p, const float* g, float* momentum_buf, size_t n, float lr, float momentum,
+                 float weight_decay, int nesterov, int first_step, const float* lr_dev, const float* grad_scale_dev,
+                 void* stream);
+/* torch.optim.Adam (betas, eps, no amsgrad): `step_dev` is a device int32 step counter that the
+ * kernel launch increments (bias correction uses the incremented value). */
+int srk_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int32_t* step_dev, const float* lr_dev,
+                  const float* grad_scale_dev, void* stream);
+/* torch.nn.utils.clip_grad_norm (vdsr.py:149): *norm_out = ||g||_2; *scale_out = min(1, max_norm/(norm+1e-6)). */
+size_t srk_grad_norm_workspace_bytes(void);
+int srk_grad_norm_clip(const float* g, size_t n, float max_norm, float* norm_out, float* scale_out, void* workspace,
+                       void* stream);
+
+/* ---- BatchNorm2d, train/eval (base_networks.py:46,117,161; live in srgan.py only) ---------- */
+/* Training forward: batch statistics over (N,H,W) per channel, y = (x-mean)*rstd*gamma+beta,
+ * running stats updated with `momentum` (unbiased variance), save_mean/save_rstd kept for
+ * backward.  sum/sumsq partials are exposed through `stats` ([2*C] doubles: sum, sumsq) so a
+ * data-parallel caller can all-reduce them (SyncBN) between the two phases. */
+int srk_bn_stats(const float* x, double* stats, size_t rows, int C, void* workspace, void* stream);
+size_t srk_bn_workspace_bytes(int C);
+int srk_bn_finalize(const double* stats, double count, float* save_mean, float* save_rstd, float* running_mean,
+                    float* running_var, float momentum, float eps, int C, void* stream);
+int srk_bn_apply(const float* x, float* y, const float* mean, const float* rstd, const float* gamma,
+                 const float* beta, size_t rows, int C, int act, float slope, void* stream);
+int srk_bn_eval_params(const float* running_mean, const float* running_var, float eps, float* mean, float* rstd,
+                       int C, void* stream);
+/* Backward: `dstats` [2*C] doubles = (sum dy, sum dy*xhat) (all-reducible for SyncBN);
+ * srk_bn_backward_apply writes dx = gamma*rstd*(dy - dstats[c]/count - xhat*dstats[C+c]/count)
+ * (pass zeros for eval-mode BN); srk_bn_param_grads accumulates dbeta += dstats[c],
+ * dgamma += dstats[C+c]. */
+int srk_bn_backward_stats(const float* dy, const float* x, const float* mean, const float* rstd, double* dstats,
+                          size_t rows, int C, void* workspace, void* stream);
+int srk_bn_backward_apply(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                          const double* dstats, double count, float* dx, size_t rows, int C, void* stream);
+int srk_bn_param_grads(const double* dstats, float* dgamma, float* dbeta, int C, void* stream);
+
+/* ---- Linear (DenseBlock: base_networks.py:7; srgan.py:66-70) -------------------------------- */
+/* y[B,Out] = act(x[B,In] @ w[Out,In]^T + b) */
+int srk_linear_forward(const float* x, const float* w, const float* b, float* y, int B, int In, int Out, int act,
+                       float slope, void* stream);
+int srk_linear_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B,
+                        int In, int Out, float beta, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRK_H_ */

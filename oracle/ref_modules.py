@@ -1,0 +1,416 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  CPU restatement (stock torch.nn, fp32) of the reference's
+hot path: the block library (/root/reference/base_networks.py:4-214), the Net / Generator /
+Discriminator topologies (srcnn.py:13-29, espcn.py:13-29, fsrcnn.py:13-55, vdsr.py:13-36,
+edsr.py:13-45, lapsrn.py:14-85, srgan.py:14-81) and the transcribed train-step bodies
+(srcnn.py:116-131, vdsr.py:133-150, edsr.py:137-155, lapsrn.py:179-199, srgan.py:249-310).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package; the
+product package (pytorch_super_resolution_model_collection_amd/) never does.
+
+Parity pinning: the reference ships NO tests or golden vectors, so the oracle is
+pinned against the reference ITSELF: tests/golden/make_golden.py imports the reference's classes
+in the build container, loads identical weights into these classes and asserts BIT-EQUAL outputs
+and gradients (same torch build => same ATen/oneDNN kernels), then freezes the vectors under
+tests/golden/*.npz.  tests/test_oracle_golden.py re-checks the oracle against those vectors.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+def _act(name):
+    # base_networks.py:49-60
+    return {None: None, 'relu': lambda: nn.ReLU(True), 'prelu': nn.PReLU, 'lrelu': lambda: nn.LeakyReLU(0.2, True),
+            'tanh': nn.Tanh, 'sigmoid': nn.Sigmoid}[name]
+
+
+class _Blk(nn.Module):
+    def _tail(self, ch, activation, norm, one_d=False):
+        self.norm, self.activation = norm, activation
+        if norm == 'batch':
+            self.bn = (nn.BatchNorm1d if one_d else nn.BatchNorm2d)(ch)
+        elif norm == 'instance':
+            self.bn = (nn.InstanceNorm1d if one_d else nn.InstanceNorm2d)(ch)
+        if _act(activation) is not None:
+            self.act = _act(activation)()
+
+    def _finish(self, out):
+        if self.norm is not None:
+            out = self.bn(out)
+        if self.activation is not None:
+            out = self.act(out)
+        return out
+
+
+class DenseBlock(_Blk):  # base_networks.py:4-36
+    def __init__(self, input_size, output_size, bias=True, activation='relu', norm='batch'):
+        super().__init__()
+        self.fc = nn.Linear(input_size, output_size, bias=bias)
+        self._tail(output_size, activation, norm, one_d=True)
+
+    def forward(self, x):
+        return self._finish(self.fc(x))
+
+
+class ConvBlock(_Blk):  # base_networks.py:39-71
+    def __init__(self, input_size, output_size, kernel_size=4, stride=2, padding=1, bias=True, activation='relu',
+                 norm='batch'):
+        super().__init__()
+        self.conv = nn.Conv2d(input_size, output_size, kernel_size, stride, padding, bias=bias)
+        self._tail(output_size, activation, norm)
+
+    def forward(self, x):
+        return self._finish(self.conv(x))
+
+
+class DeconvBlock(_Blk):  # base_networks.py:74-106
+    def __init__(self, input_size, output_size, kernel_size=4, stride=2, padding=1, bias=True, activation='relu',
+                 norm='batch'):
+        super().__init__()
+        self.deconv = nn.ConvTranspose2d(input_size, output_size, kernel_size, stride, padding, bias=bias)
+        self._tail(output_size, activation, norm)
+
+    def forward(self, x):
+        return self._finish(self.deconv(x))
+
+
+class ResnetBlock(_Blk):  # base_networks.py:109-150 (ONE bn / act shared by both convs)
+    def __init__(self, num_filter, kernel_size=3, stride=1, padding=1, bias=True, activation='relu', norm='batch'):
+        super().__init__()
+        self.conv1 = nn.Conv2d(num_filter, num_filter, kernel_size, stride, padding, bias=bias)
+        self.conv2 = nn.Conv2d(num_filter, num_filter, kernel_size, stride, padding, bias=bias)
+        self._tail(num_filter, activation, norm)
+
+    def forward(self, x):
+        out = self.conv1(x)
+        if self.norm is not None:
+            out = self.bn(out)
+        if self.activation is not None:
+            out = self.act(out)
+        out = self.conv2(out)
+        if self.norm is not None:
+            out = self.bn(out)
+        return torch.add(out, x)
+
+
+class PSBlock(_Blk):  # base_networks.py:153-185
+    def __init__(self, input_size, output_size, scale_factor, kernel_size=3, stride=1, padding=1, bias=True,
+                 activation='relu', norm='batch'):
+        super().__init__()
+        self.conv = nn.Conv2d(input_size, output_size * scale_factor ** 2, kernel_size, stride, padding, bias=bias)
+        self.ps = nn.PixelShuffle(scale_factor)
+        self._tail(output_size, activation, norm)
+
+    def forward(self, x):
+        return self._finish(self.ps(self.conv(x)))
+
+
+class Upsample2xBlock(nn.Module):  # base_networks.py:188-214
+    def __init__(self, input_size, output_size, bias=True, upsample='deconv', activation='relu', norm='batch'):
+        super().__init__()
+        if upsample == 'deconv':
+            self.upsample = DeconvBlock(input_size, output_size, 4, 2, 1, bias=bias, activation=activation, norm=norm)
+        elif upsample == 'ps':
+            self.upsample = PSBlock(input_size, output_size, 2, bias=bias, activation=activation, norm=norm)
+        else:
+            self.upsample = nn.Sequential(nn.Upsample(scale_factor=2, mode='nearest'),
+                                          ConvBlock(input_size, output_size, 3, 1, 1, bias=bias,
+                                                    activation=activation, norm=norm))
+
+    def forward(self, x):
+        return self.upsample(x)
+
+
+def weights_init_normal(m, mean=0.0, std=0.02):  # utils.py:76-93
+    n = m.__class__.__name__
+    if n.find('Linear') != -1 or n.find('Conv2d') != -1 or n.find('ConvTranspose2d') != -1:
+        m.weight.data.normal_(mean, std)
+        if m.bias is not None:
+            m.bias.data.zero_()
+    elif n.find('Norm') != -1:
+        m.weight.data.normal_(1.0, 0.02)
+        if m.bias is not None:
+            m.bias.data.zero_()
+
+
+def weights_init_kaming(m):  # utils.py:96-113
+    n = m.__class__.__name__
+    if n.find('Linear') != -1 or n.find('Conv2d') != -1 or n.find('ConvTranspose2d') != -1:
+        nn.init.kaiming_normal_(m.weight)
+        if m.bias is not None:
+            m.bias.data.zero_()
+    elif n.find('Norm') != -1:
+        m.weight.data.normal_(1.0, 0.02)
+        if m.bias is not None:
+            m.bias.data.zero_()
+
+
+class SRCNN(nn.Module):  # srcnn.py:13-29
+    def __init__(self, num_channels, base_filter):
+        super().__init__()
+        self.layers = nn.Sequential(ConvBlock(num_channels, base_filter, 9, 1, 0, norm=None),
+                                    ConvBlock(base_filter, base_filter // 2, 5, 1, 0, norm=None),
+                                    ConvBlock(base_filter // 2, num_channels, 5, 1, 0, activation=None, norm=None))
+
+    def forward(self, x):
+        return self.layers(x)
+
+    def weight_init(self, mean=0.0, std=0.001):
+        for m in self.modules():
+            weights_init_normal(m, mean, std)
+
+
+class ESPCN(nn.Module):  # espcn.py:13-29
+    def __init__(self, num_channels, base_filter, scale_factor):
+        super().__init__()
+        self.layers = nn.Sequential(
+            ConvBlock(num_channels, base_filter, 5, 1, 0, activation='relu', norm=None),
+            ConvBlock(base_filter, base_filter // 2, 3, 1, 0, activation='relu', norm=None),
+            PSBlock(base_filter // 2, num_channels, scale_factor, 3, 1, 0, activation=None, norm=None))
+
+    def forward(self, x):
+        return self.layers(x)
+
+    def weight_init(self):
+        for m in self.modules():
+            weights_init_normal(m)
+
+
+class FSRCNN(nn.Module):  # fsrcnn.py:13-55
+    def __init__(self, num_channels, scale_factor, d, s, m):
+        super().__init__()
+        self.first_part = ConvBlock(num_channels, d, 5, 1, 0, activation='prelu', norm=None)
+        layers = [ConvBlock(d, s, 1, 1, 0, activation='prelu', norm=None)]
+        layers += [ConvBlock(s, s, 3, 1, 1, activation=None, norm=None) for _ in range(m)]
+        layers += [nn.PReLU(), ConvBlock(s, d, 1, 1, 0, activation='prelu', norm=None)]
+        self.mid_part = nn.Sequential(*layers)
+        self.last_part = nn.ConvTranspose2d(d, num_channels, 9, scale_factor, 3, output_padding=1)
+
+    def forward(self, x):
+        return self.last_part(self.mid_part(self.first_part(x)))
+
+    def weight_init(self, mean=0.0, std=0.02):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                m.weight.data.normal_(mean, std)
+                if m.bias is not None:
+                    m.bias.data.zero_()
+            if isinstance(m, nn.ConvTranspose2d):
+                m.weight.data.normal_(0.0, 0.0001)
+                if m.bias is not None:
+                    m.bias.data.zero_()
+
+
+class VDSR(nn.Module):  # vdsr.py:13-36
+    def __init__(self, num_channels, base_filter, num_residuals):
+        super().__init__()
+        self.input_conv = ConvBlock(num_channels, base_filter, 3, 1, 1, norm=None, bias=False)
+        self.residual_layers = nn.Sequential(*[ConvBlock(base_filter, base_filter, 3, 1, 1, norm=None, bias=False)
+                                               for _ in range(num_residuals)])
+        self.output_conv = ConvBlock(base_filter, num_channels, 3, 1, 1, activation=None, norm=None, bias=False)
+
+    def forward(self, x):
+        return torch.add(self.output_conv(self.residual_layers(self.input_conv(x))), x)
+
+    def weight_init(self):
+        for m in self.modules():
+            weights_init_kaming(m)
+
+
+class EDSR(nn.Module):  # edsr.py:13-45
+    def __init__(self, num_channels, base_filter, num_residuals):
+        super().__init__()
+        self.input_conv = ConvBlock(num_channels, base_filter, 3, 1, 1, activation=None, norm=None)
+        self.residual_layers = nn.Sequential(*[ResnetBlock(base_filter, norm=None) for _ in range(num_residuals)])
+        self.mid_conv = ConvBlock(base_filter, base_filter, 3, 1, 1, activation=None, norm=None)
+        self.upscale4x = nn.Sequential(
+            Upsample2xBlock(base_filter, base_filter, upsample='ps', activation=None, norm=None),
+            Upsample2xBlock(base_filter, base_filter, upsample='ps', activation=None, norm=None))
+        self.output_conv = ConvBlock(base_filter, num_channels, 3, 1, 1, activation=None, norm=None)
+
+    def weight_init(self, mean=0.0, std=0.02):
+        for m in self.modules():
+            weights_init_normal(m, mean, std)
+
+    def forward(self, x):
+        out = self.input_conv(x)
+        out = torch.add(self.mid_conv(self.residual_layers(out)), out)
+        return self.output_conv(self.upscale4x(out))
+
+
+def get_upsample_filter(size):  # lapsrn.py:14-24
+    factor = (size + 1) // 2
+    center = factor - 1 if size % 2 == 1 else factor - 0.5
+    og = np.ogrid[:size, :size]
+    filt = (1 - abs(og[0] - center) / factor) * (1 - abs(og[1] - center) / factor)
+    return torch.from_numpy(filt).float()
+
+
+class LapSRN(nn.Module):  # lapsrn.py:27-72
+    def __init__(self, num_channels, base_filter, num_convs):
+        super().__init__()
+        self.input_conv = ConvBlock(num_channels, base_filter, 3, 1, 1, activation='lrelu', norm=None, bias=False)
+        blocks = [ConvBlock(base_filter, base_filter, 3, 1, 1, activation='lrelu', norm=None, bias=False)
+                  for _ in range(num_convs)]
+        blocks.append(DeconvBlock(base_filter, base_filter, 4, 2, 1, activation='lrelu', norm=None, bias=False))
+        self.convt_I1 = DeconvBlock(num_channels, num_channels, 4, 2, 1, activation=None, norm=None, bias=False)
+        self.convt_R1 = ConvBlock(base_filter, num_channels, 3, 1, 1, activation=None, norm=None, bias=False)
+        self.convt_F1 = nn.Sequential(*blocks)
+        self.convt_I2 = DeconvBlock(num_channels, num_channels, 4, 2, 1, activation=None, norm=None, bias=False)
+        self.convt_R2 = ConvBlock(base_filter, num_channels, 3, 1, 1, activation=None, norm=None, bias=False)
+        self.convt_F2 = nn.Sequential(*blocks)
+
+    def weight_init(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2. / n))
+                if m.bias is not None:
+                    m.bias.data.zero_()
+            if isinstance(m, nn.ConvTranspose2d):
+                c1, c2, h, w = m.weight.data.size()
+                m.weight.data = get_upsample_filter(h).view(1, 1, h, w).repeat(c1, c2, 1, 1)
+                if m.bias is not None:
+                    m.bias.data.zero_()
+
+    def forward(self, x):
+        out = self.input_conv(x)
+        f1 = self.convt_F1(out)
+        x_coarse = self.convt_I1(x) + self.convt_R1(f1)
+        f2 = self.convt_F2(f1)
+        x_finer = self.convt_I2(x_coarse) + self.convt_R2(f2)
+        return x_coarse, x_finer
+
+
+class L1_Charbonnier_loss(nn.Module):  # lapsrn.py:75-85
+    def __init__(self):
+        super().__init__()
+        self.eps = 1e-6
+
+    def forward(self, x, y):
+        diff = torch.add(x, -y)
+        return torch.mean(torch.sqrt(diff * diff + self.eps))
+
+
+class Generator(nn.Module):  # srgan.py:14-46
+    def __init__(self, num_channels, base_filter, num_residuals):
+        super().__init__()
+        self.input_conv = ConvBlock(num_channels, base_filter, 9, 1, 4, activation='prelu', norm=None)
+        self.residual_layers = nn.Sequential(*[ResnetBlock(base_filter, activation='prelu')
+                                               for _ in range(num_residuals)])
+        self.mid_conv = ConvBlock(base_filter, base_filter, 3, 1, 1, activation=None)
+        self.upscale4x = nn.Sequential(
+            Upsample2xBlock(base_filter, base_filter, upsample='ps', activation='prelu', norm=None),
+            Upsample2xBlock(base_filter, base_filter, upsample='ps', activation='prelu', norm=None))
+        self.output_conv = ConvBlock(base_filter, num_channels, 9, 1, 4, activation=None, norm=None)
+
+    def forward(self, x):
+        out = self.input_conv(x)
+        out = torch.add(self.mid_conv(self.residual_layers(out)), out)
+        return self.output_conv(self.upscale4x(out))
+
+    def weight_init(self, mean=0.0, std=0.02):
+        for m in self.modules():
+            weights_init_normal(m, mean, std)
+
+
+class Discriminator(nn.Module):  # srgan.py:49-81
+    def __init__(self, num_channels, base_filter, image_size):
+        super().__init__()
+        self.image_size = image_size
+        bf = base_filter
+        self.input_conv = ConvBlock(num_channels, bf, 3, 1, 1, activation='lrelu', norm=None)
+        self.conv_blocks = nn.Sequential(
+            ConvBlock(bf, bf, 3, 2, 1, activation='lrelu'), ConvBlock(bf, bf * 2, 3, 1, 1, activation='lrelu'),
+            ConvBlock(bf * 2, bf * 2, 3, 2, 1, activation='lrelu'), ConvBlock(bf * 2, bf * 4, 3, 1, 1, activation='lrelu'),
+            ConvBlock(bf * 4, bf * 4, 3, 2, 1, activation='lrelu'), ConvBlock(bf * 4, bf * 8, 3, 1, 1, activation='lrelu'),
+            ConvBlock(bf * 8, bf * 8, 3, 2, 1, activation='lrelu'))
+        self.dense_layers = nn.Sequential(
+            DenseBlock(bf * 8 * image_size // 16 * image_size // 16, bf * 16, activation='lrelu', norm=None),
+            DenseBlock(bf * 16, 1, activation='sigmoid', norm=None))
+
+    def forward(self, x):
+        out = self.conv_blocks(self.input_conv(x))
+        return self.dense_layers(out.view(out.size()[0], -1))
+
+    def weight_init(self, mean=0.0, std=0.02):
+        for m in self.modules():
+            weights_init_normal(m, mean, std)
+
+
+# ---------------------------------------------------------------------------------------------
+# Transcribed train-step bodies (stock torch losses / optimizers with the reference's
+# hyper-parameters).  Each returns the scalar loss of the step as a python float.
+# ---------------------------------------------------------------------------------------------
+def make_optimizer(kind, params, lr):
+    if kind == 'srcnn':     # srcnn.py:79
+        return torch.optim.SGD(params, lr=lr)
+    if kind == 'fsrcnn':    # fsrcnn.py:105-106
+        return torch.optim.SGD(params, lr=lr, momentum=0.9)
+    if kind == 'vdsr':      # vdsr.py:86-90
+        return torch.optim.SGD(params, lr=lr, momentum=0.9, weight_decay=1e-4)
+    if kind in ('espcn', 'lapsrn'):  # espcn.py:79, lapsrn.py:135
+        return torch.optim.Adam(params, lr=lr)
+    if kind in ('edsr', 'srgan_g'):  # edsr.py:93, srgan.py:147
+        return torch.optim.Adam(params, lr=lr, betas=(0.9, 0.999), eps=1e-8)
+    if kind == 'srgan_d':   # srgan.py:149
+        return torch.optim.SGD(params, lr=lr / 100, momentum=0.9, nesterov=True)
+    raise ValueError(kind)
+
+
+def step_mse(model, opt, inp, target, clip=None):
+    """srcnn.py:127-131 / fsrcnn.py:153-157 / vdsr.py:143-150 (clip=0.4)."""
+    opt.zero_grad()
+    loss = nn.functional.mse_loss(model(inp), target)
+    loss.backward()
+    if clip is not None:
+        nn.utils.clip_grad_norm_(model.parameters(), clip)
+    opt.step()
+    return float(loss)
+
+
+def step_l1(model, opt, inp, target):
+    """edsr.py:151-155"""
+    opt.zero_grad()
+    loss = nn.functional.l1_loss(model(inp), target)
+    loss.backward()
+    opt.step()
+    return float(loss)
+
+
+def step_lapsrn(model, opt, inp, target2x, target4x):
+    """lapsrn.py:190-199: two Charbonnier losses, two backward calls, one step."""
+    crit = L1_Charbonnier_loss()
+    opt.zero_grad()
+    hr2, hr4 = model(inp)
+    l1, l2 = crit(hr2, target2x), crit(hr4, target4x)
+    l1.backward(retain_graph=True)
+    l2.backward()
+    opt.step()
+    return float(l1), float(l2)
+
+
+def step_srgan(G, D, g_opt, d_opt, lr_img, hr_img):
+    """srgan.py:249-310 with labels shaped [B,1] and the (zero-gradient) VGG term omitted
+    (SURVEY.md App. B-6/B-7).  Returns (D_loss, G_loss)."""
+    bce, mse = nn.BCELoss(), nn.MSELoss()
+    b = lr_img.shape[0]
+    real, fake = torch.ones(b, 1), torch.zeros(b, 1)
+    # D step (srgan.py:272-287) — G is NOT detached in the reference
+    d_opt.zero_grad()
+    d_real_loss = bce(D(hr_img), real)
+    recon = G(lr_img)
+    d_fake_loss = bce(D(recon), fake)
+    d_loss = d_real_loss + d_fake_loss
+    d_loss.backward()
+    d_opt.step()
+    # G step (srgan.py:290-310)
+    g_opt.zero_grad()
+    recon = G(lr_img)
+    gan_loss = bce(D(recon), real)
+    g_loss = mse(recon, hr_img) + 1e-3 * gan_loss
+    g_loss.backward()
+    g_opt.step()
+    return float(d_loss), float(g_loss)

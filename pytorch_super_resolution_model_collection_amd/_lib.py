@@ -1,0 +1,145 @@
+"""ctypes binding of libsrk.so (the C ABI declared in include/srk.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, a RuntimeError is
+raised.  torch is used only for device memory, streams and autograd bookkeeping; every number on
+the hot path is produced by a kernel in csrc/.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrk.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "srk.h")
+
+# enums mirrored from include/srk.h
+ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = range(6)
+ALGO_AUTO, ALGO_GENERIC, ALGO_MFMA, ALGO_DIRECT = range(4)
+LOSS_MSE, LOSS_L1, LOSS_CHARBONNIER, LOSS_BCE = range(4)
+ACT_BY_NAME = {None: ACT_NONE, "relu": ACT_RELU, "prelu": ACT_PRELU, "lrelu": ACT_LRELU, "tanh": ACT_TANH,
+               "sigmoid": ACT_SIGMOID}
+
+c_f = ctypes.c_void_p  # device float*
+c_vp = ctypes.c_void_p
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_size = ctypes.c_size_t
+
+
+class ConvDesc(ctypes.Structure):
+    """struct srk_conv_desc"""
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("N", "H", "W", "Cin", "OH", "OW", "Cout", "KH", "KW", "stride", "pad", "transposed", "out_pad",
+                 "algo")]
+
+
+class Epilogue(ctypes.Structure):
+    """struct srk_epilogue"""
+    _fields_ = [("bias", c_vp), ("prelu_weight", c_vp), ("residual", c_vp), ("slope", c_float),
+                ("act", ctypes.c_int32), ("prelu_n", ctypes.c_int32), ("ps_r", ctypes.c_int32)]
+
+
+class BwdMask(ctypes.Structure):
+    """struct srk_bwd_mask"""
+    _fields_ = [("y", c_vp), ("slope", c_float)]
+
+
+_PROTOTYPES = {
+    "srk_version": (c_int, []),
+    "srk_status_string": (ctypes.c_char_p, [c_int]),
+    "srk_last_error_string": (ctypes.c_char_p, []),
+    "srk_conv_out_dim": (c_int, [c_int] * 6),
+    "srk_nchw_to_nhwc": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_vp]),
+    "srk_nhwc_to_nchw": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_vp]),
+    "srk_pack_weight_fwd": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "srk_pack_weight_bwd": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "srk_pack_bias_ps": (c_int, [c_f, c_f, c_int, c_int, c_vp]),
+    "srk_conv2d_forward": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, c_f, ctypes.POINTER(Epilogue), c_vp]),
+    "srk_conv2d_backward_data": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, c_f, ctypes.POINTER(BwdMask), c_f,
+                                         c_vp]),
+    "srk_conv2d_backward_weight_workspace_bytes": (c_size, [ctypes.POINTER(ConvDesc)]),
+    "srk_conv2d_backward_weight": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, ctypes.POINTER(BwdMask), c_f, c_f,
+                                           c_float, c_vp, c_size, c_vp]),
+    "srk_pixel_shuffle_forward": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "srk_pixel_shuffle_backward": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "srk_act_forward": (c_int, [c_f, c_f, c_size, c_int, c_int, c_float, c_f, c_int, c_vp]),
+    "srk_act_backward": (c_int, [c_f, c_f, c_f, c_size, c_int, c_int, c_float, c_f, c_int, c_f, c_vp]),
+    "srk_axpby": (c_int, [c_f, c_f, c_f, c_size, c_float, c_float, c_vp]),
+    "srk_loss_workspace_bytes": (c_size, []),
+    "srk_loss_forward_backward": (c_int, [c_int, c_f, c_f, ctypes.POINTER(ctypes.c_int64), c_int, c_int, c_int,
+                                          c_int, c_float, c_float, c_f, c_f, c_vp, c_vp]),
+    "srk_sgd_step": (c_int, [c_f, c_f, c_f, c_size, c_float, c_float, c_float, c_int, c_int, c_f, c_f, c_vp]),
+    "srk_adam_step": (c_int, [c_f, c_f, c_f, c_f, c_size, c_float, c_float, c_float, c_float, c_float, c_vp, c_f,
+                              c_f, c_vp]),
+    "srk_grad_norm_workspace_bytes": (c_size, []),
+    "srk_grad_norm_clip": (c_int, [c_f, c_size, c_float, c_f, c_f, c_vp, c_vp]),
+    "srk_bn_stats": (c_int, [c_f, c_vp, c_size, c_int, c_vp, c_vp]),
+    "srk_bn_workspace_bytes": (c_size, [c_int]),
+    "srk_bn_finalize": (c_int, [c_vp, ctypes.c_double, c_f, c_f, c_f, c_f, c_float, c_float, c_int, c_vp]),
+    "srk_bn_apply": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_size, c_int, c_int, c_float, c_vp]),
+    "srk_bn_eval_params": (c_int, [c_f, c_f, c_float, c_f, c_f, c_int, c_vp]),
+    "srk_bn_backward_stats": (c_int, [c_f, c_f, c_f, c_f, c_vp, c_size, c_int, c_vp, c_vp]),
+    "srk_bn_backward_apply": (c_int, [c_f, c_f, c_f, c_f, c_f, c_vp, ctypes.c_double, c_f, c_size, c_int, c_vp]),
+    "srk_bn_param_grads": (c_int, [c_vp, c_f, c_f, c_int, c_vp]),
+    "srk_scale_dev": (c_int, [c_f, c_f, c_f, c_size, c_vp]),
+    "srk_linear_forward": (c_int, [c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int, c_float, c_vp]),
+    "srk_linear_backward": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_float, c_vp]),
+}
+
+_lib = None
+
+
+def header_symbols():
+    """Every function name declared in include/srk.h (used by the CPU-side export test)."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(srk_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """Load libsrk.so (building it is __graft_entry__.build()'s job). Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libsrk.so not found at %s — run `python __graft_entry__.py build` (hipcc --offload-arch=gfx950). "
+            "There is no CPU/eager fallback for the hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        lib = load()
+        raise RuntimeError("%s failed: %s (%s)" % (what, lib.srk_status_string(rc).decode(),
+                                                   lib.srk_last_error_string().decode()))
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "the MI355X hot path only runs on GPU tensors (got a %s tensor); there is no CPU fallback — "
+                "use oracle/ for a CPU reference" % t.device)
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError("the hot path is fp32 (got %s)" % t.dtype)

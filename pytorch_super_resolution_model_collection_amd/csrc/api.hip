@@ -1,0 +1,160 @@
+// extern "C" entry points of the convolution family + library queries.  Validates arguments,
+// maps Conv2d / ConvTranspose2d forward / data-gradient onto the gather problem, dispatches to
+// the MFMA, direct or generic kernels.
+#include "srk_common.h"
+#include "conv_problem.h"
+#include <string.h>
+#include <stdlib.h>
+
+namespace srk {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// conv_direct.hip
+bool conv_direct_gather_supported(const GatherConv& g, const Epi& ep);
+int conv_direct_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
+                       const float* mask_y, float mask_slope, hipStream_t s);
+// conv_generic.hip
+size_t conv_generic_wgrad_ws(const srk_conv_desc& d);
+int conv_generic_wgrad(const srk_conv_desc& d, const float* x, const float* dy, const srk_bwd_mask* mask, float* dw,
+                       float* db, float beta, void* ws, size_t ws_bytes, hipStream_t s);
+// conv_wgrad_mfma.hip
+bool conv_wgrad_mfma_supported(const srk_conv_desc& d);
+size_t conv_wgrad_mfma_ws(const srk_conv_desc& d);
+int conv_wgrad_mfma(const srk_conv_desc& d, const float* x, const float* dy, const srk_bwd_mask* mask, float* dw,
+                    float* db, float beta, void* ws, size_t ws_bytes, hipStream_t s);
+
+static int validate_desc(const srk_conv_desc* d, const char* who) {
+  SRK_REQUIRE(d, "%s: null descriptor", who);
+  SRK_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "%s: non-positive tensor dims", who);
+  SRK_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "%s: bad kernel/stride/pad", who);
+  SRK_REQUIRE(d->transposed == 0 || d->transposed == 1, "%s: transposed must be 0/1", who);
+  SRK_REQUIRE(d->out_pad >= 0 && (d->out_pad == 0 || (d->transposed && d->out_pad < d->stride)),
+              "%s: bad output_padding %d", who, d->out_pad);
+  const int oh = srk_conv_out_dim(d->H, d->KH, d->stride, d->pad, d->transposed, d->out_pad);
+  const int ow = srk_conv_out_dim(d->W, d->KW, d->stride, d->pad, d->transposed, d->out_pad);
+  SRK_REQUIRE(oh > 0 && ow > 0, "%s: empty output (%d x %d)", who, oh, ow);
+  SRK_REQUIRE(d->OH == oh && d->OW == ow, "%s: OH/OW (%d,%d) != expected (%d,%d)", who, d->OH, d->OW, oh, ow);
+  SRK_REQUIRE(d->algo >= SRK_ALGO_AUTO && d->algo <= SRK_ALGO_DIRECT, "%s: unknown algo %d", who, d->algo);
+  return SRK_OK;
+}
+
+static int forced_algo(int algo) {
+  if (algo != SRK_ALGO_AUTO) return algo;
+  const char* e = getenv("SRK_FORCE_ALGO");  // debugging aid: generic|mfma|direct
+  if (!e) return SRK_ALGO_AUTO;
+  if (!strcmp(e, "generic")) return SRK_ALGO_GENERIC;
+  if (!strcmp(e, "mfma")) return SRK_ALGO_MFMA;
+  if (!strcmp(e, "direct")) return SRK_ALGO_DIRECT;
+  return SRK_ALGO_AUTO;
+}
+
+static int run_gather(const GatherConv& g, int algo, const float* in, const float* wp, float* out, const Epi& ep,
+                      const float* mask_y, float mask_slope, hipStream_t s, const char* who) {
+  algo = forced_algo(algo);
+  const bool direct_ok = conv_direct_gather_supported(g, ep);
+  const bool mfma_ok = conv_mfma_gather_supported(g, ep);
+  if (algo == SRK_ALGO_DIRECT && !direct_ok) {
+    set_error("%s: direct kernel does not cover this shape", who);
+    return SRK_ERR_UNSUPPORTED;
+  }
+  if (algo == SRK_ALGO_MFMA && !mfma_ok) {
+    set_error("%s: MFMA kernel does not cover this shape", who);
+    return SRK_ERR_UNSUPPORTED;
+  }
+  if (algo == SRK_ALGO_DIRECT || (algo == SRK_ALGO_AUTO && direct_ok))
+    return conv_direct_gather(g, in, wp, out, ep, mask_y, mask_slope, s);
+  if (algo == SRK_ALGO_MFMA || (algo == SRK_ALGO_AUTO && mfma_ok))
+    return conv_mfma_gather(g, in, wp, out, ep, mask_y, mask_slope, s);
+  return conv_generic_gather(g, in, wp, out, ep, mask_y, mask_slope, s);
+}
+
+}  // namespace srk
+
+using namespace srk;
+
+extern "C" int srk_version(void) { return SRK_VERSION; }
+
+extern "C" const char* srk_status_string(int status) {
+  switch (status) {
+    case SRK_OK: return "ok";
+    case SRK_ERR_BAD_ARG: return "bad argument";
+    case SRK_ERR_UNSUPPORTED: return "unsupported configuration";
+    case SRK_ERR_LAUNCH: return "kernel launch failure";
+    case SRK_ERR_WORKSPACE: return "workspace too small";
+    default: return "unknown status";
+  }
+}
+
+extern "C" const char* srk_last_error_string(void) { return g_err; }
+
+extern "C" int srk_conv_out_dim(int in, int k, int stride, int pad, int transposed, int out_pad) {
+  if (in <= 0 || k <= 0 || stride <= 0 || pad < 0) return -1;
+  if (!transposed) return (in + 2 * pad - k) / stride + 1;
+  return (in - 1) * stride - 2 * pad + k + out_pad;
+}
+
+extern "C" int srk_conv2d_forward(const srk_conv_desc* d, const float* x, const float* w_packed_fwd, float* y,
+                                  const srk_epilogue* ep_in, void* stream) {
+  int rc = validate_desc(d, "conv2d_forward");
+  if (rc) return rc;
+  SRK_REQUIRE(x && w_packed_fwd && y, "conv2d_forward: null tensor pointer");
+  Epi ep = make_epi(ep_in);
+  SRK_REQUIRE(ep.act >= SRK_ACT_NONE && ep.act <= SRK_ACT_SIGMOID, "conv2d_forward: unknown act %d", ep.act);
+  SRK_REQUIRE(ep.act != SRK_ACT_PRELU || (ep.prelu_w && ep.prelu_n >= 1), "conv2d_forward: PReLU needs its weight");
+  if (ep.ps_r > 1) {
+    SRK_REQUIRE(d->Cout % (ep.ps_r * ep.ps_r) == 0, "conv2d_forward: Cout %d not divisible by r^2", d->Cout);
+    SRK_REQUIRE(ep.act != SRK_ACT_PRELU || ep.prelu_n == 1 || ep.prelu_n == d->Cout / (ep.ps_r * ep.ps_r),
+                "conv2d_forward: PReLU after pixel-shuffle must have 1 or Cout/r^2 slopes");
+  } else {
+    SRK_REQUIRE(ep.act != SRK_ACT_PRELU || ep.prelu_n == 1 || ep.prelu_n == d->Cout,
+                "conv2d_forward: PReLU must have 1 or Cout slopes");
+  }
+  GatherConv g{d->N, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->pad, d->transposed};
+  return run_gather(g, d->algo, x, w_packed_fwd, y, ep, nullptr, 0.f, (hipStream_t)stream, "conv2d_forward");
+}
+
+extern "C" int srk_conv2d_backward_data(const srk_conv_desc* d, const float* dy, const float* w_packed_bwd, float* dx,
+                                        const srk_bwd_mask* mask, const float* add_to, void* stream) {
+  int rc = validate_desc(d, "conv2d_backward_data");
+  if (rc) return rc;
+  SRK_REQUIRE(dy && w_packed_bwd && dx, "conv2d_backward_data: null tensor pointer");
+  // dx is a gather over dy with the channel roles swapped and the opposite gather kind.
+  GatherConv g{d->N, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad, !d->transposed};
+  Epi ep{};
+  ep.residual = add_to;
+  return run_gather(g, d->algo, dy, w_packed_bwd, dx, ep, mask ? mask->y : nullptr, mask ? mask->slope : 0.f,
+                    (hipStream_t)stream, "conv2d_backward_data");
+}
+
+extern "C" size_t srk_conv2d_backward_weight_workspace_bytes(const srk_conv_desc* d) {
+  if (!d) return 0;
+  size_t a = conv_generic_wgrad_ws(*d);
+  size_t b = conv_wgrad_mfma_supported(*d) ? conv_wgrad_mfma_ws(*d) : 0;
+  return a > b ? a : b;
+}
+
+extern "C" int srk_conv2d_backward_weight(const srk_conv_desc* d, const float* x, const float* dy,
+                                          const srk_bwd_mask* mask, float* dw, float* db, float beta, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  int rc = validate_desc(d, "conv2d_backward_weight");
+  if (rc) return rc;
+  SRK_REQUIRE(x && dy && dw, "conv2d_backward_weight: null tensor pointer");
+  SRK_REQUIRE(beta == 0.f || beta == 1.f, "conv2d_backward_weight: beta must be 0 or 1");
+  int algo = forced_algo(d->algo);
+  const bool mfma_ok = conv_wgrad_mfma_supported(*d);
+  if (algo == SRK_ALGO_MFMA && !mfma_ok) {
+    set_error("conv2d_backward_weight: MFMA kernel does not cover this shape");
+    return SRK_ERR_UNSUPPORTED;
+  }
+  if (algo == SRK_ALGO_MFMA || ((algo == SRK_ALGO_AUTO || algo == SRK_ALGO_DIRECT) && mfma_ok))
+    return conv_wgrad_mfma(*d, x, dy, mask, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);
+  return conv_generic_wgrad(*d, x, dy, mask, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);
+}

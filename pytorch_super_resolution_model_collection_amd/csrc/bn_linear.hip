@@ -1,0 +1,315 @@
+// BatchNorm2d (train / eval) and Linear — the SRGAN-only pieces of the hot path
+// (base_networks.py:7,46,117,161; srgan.py:49-81).  NHWC: a tensor is [rows][C] with
+// rows = N*H*W, so per-channel statistics are column sums with lanes = channels (coalesced rows).
+#include "srk_common.h"
+
+namespace srk {
+
+constexpr int kBnRowSplits = 512;
+
+// partial[split][2][C] (double): sum(a), sum(a*b') where the second operand depends on MODE:
+//   MODE 0: a = x,  second = x*x                      (forward statistics)
+//   MODE 1: a = dy, second = dy * (x-mean)*rstd       (backward statistics)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bn_colsum(const float* __restrict__ a, const float* __restrict__ x,
+                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                   double* __restrict__ partial, size_t rows, int C,
+                                                   size_t rows_per_split) {
+  __shared__ double sm[2][4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  size_t r0 = (size_t)blockIdx.y * rows_per_split, r1 = r0 + rows_per_split;
+  if (r1 > rows) r1 = rows;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C) {
+    float mu = 0.f, rs = 1.f;
+    if (MODE == 1) {
+      mu = mean[c];
+      rs = rstd[c];
+    }
+    float f0 = 0.f, f1 = 0.f;
+    int cnt = 0;
+    for (size_t r = r0 + w; r < r1; r += 4) {
+      const float v = a[r * C + c];
+      if (MODE == 0) {
+        f0 += v;
+        f1 += v * v;
+      } else {
+        f0 += v;
+        f1 += v * ((x[r * C + c] - mu) * rs);
+      }
+      if (++cnt == 64) {  // flush the fp32 running sums into double to bound rounding growth
+        s0 += f0; s1 += f1; f0 = 0.f; f1 = 0.f; cnt = 0;
+      }
+    }
+    s0 += f0;
+    s1 += f1;
+  }
+  sm[0][w][lane] = s0;
+  sm[1][w][lane] = s1;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    double* p = partial + (size_t)blockIdx.y * 2 * C;
+    p[c] = sm[0][0][lane] + sm[0][1][lane] + sm[0][2][lane] + sm[0][3][lane];
+    p[C + c] = sm[1][0][lane] + sm[1][1][lane] + sm[1][2][lane] + sm[1][3][lane];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bn_reduce(const double* __restrict__ partial, double* __restrict__ stats,
+                                                   int nsplit, int C2) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= C2) return;
+  double s = 0.0;
+  for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * C2 + i];
+  stats[i] = s;
+}
+
+__global__ __launch_bounds__(256) void k_bn_finalize(const double* __restrict__ stats, double count,
+                                                     float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                     float* __restrict__ rm, float* __restrict__ rv, float momentum,
+                                                     float eps, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double mean = stats[c] / count;
+  double var = stats[C + c] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  save_mean[c] = (float)mean;
+  save_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rm) rm[c] = (1.f - momentum) * rm[c] + momentum * (float)mean;
+  if (rv) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bn_eval_params(const float* __restrict__ rm, const float* __restrict__ rv,
+                                                        float eps, float* __restrict__ mean, float* __restrict__ rstd,
+                                                        int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = rm[c];
+  rstd[c] = 1.f / sqrtf(rv[c] + eps);
+}
+
+__global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, float* __restrict__ y,
+                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  size_t total, int C, int act, float slope) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    float v = (x[i] - mean[c]) * rstd[c];
+    v = v * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
+    y[i] = act_apply(v, act, slope);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ gamma,
+                                                      const double* __restrict__ dstats, double count,
+                                                      float* __restrict__ dx, size_t total, int C) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const float rs = rstd[c];
+    const float xhat = (x[i] - mean[c]) * rs;
+    const float m1 = (float)(dstats[c] / count);
+    const float m2 = (float)(dstats[C + c] / count);
+    const float g = gamma ? gamma[c] : 1.f;
+    dx[i] = g * rs * (dy[i] - m1 - xhat * m2);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bn_param_grads(const double* __restrict__ dstats, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  if (dbeta) dbeta[c] += (float)dstats[c];
+  if (dgamma) dgamma[c] += (float)dstats[C + c];
+}
+
+static int bn_colsum(int mode, const float* a, const float* x, const float* mean, const float* rstd, double* out,
+                     size_t rows, int C, void* ws, hipStream_t s) {
+  int splits = (int)((rows + 255) / 256);
+  if (splits > kBnRowSplits) splits = kBnRowSplits;
+  if (splits < 1) splits = 1;
+  const size_t rps = (rows + splits - 1) / splits;
+  dim3 grid(cdiv(C, 64), splits);
+  if (mode == 0)
+    hipLaunchKernelGGL(k_bn_colsum<0>, grid, dim3(256), 0, s, a, x, mean, rstd, (double*)ws, rows, C, rps);
+  else
+    hipLaunchKernelGGL(k_bn_colsum<1>, grid, dim3(256), 0, s, a, x, mean, rstd, (double*)ws, rows, C, rps);
+  hipLaunchKernelGGL(k_bn_reduce, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, (const double*)ws, out, splits, 2 * C);
+  return check_launch("bn_colsum");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Linear.  y[B,Out] = act(x[B,In] @ w[Out,In]^T + b).  Weight-streaming (B is small): a block
+// owns 4 output neurons and up to 8 batch rows; lanes stride the In axis with float4 loads.
+// ---------------------------------------------------------------------------------------------
+constexpr int LIN_BT = 8;
+
+__global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ b, float* __restrict__ y, int B, int In,
+                                                    int Out, int act, float slope) {
+  __shared__ float sm[4];
+  const int o0 = blockIdx.x * 4;
+  const int b0 = blockIdx.y * LIN_BT;
+  float acc[4][LIN_BT];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int r = 0; r < LIN_BT; ++r) acc[k][r] = 0.f;
+  for (int i = threadIdx.x; i < In; i += 256) {
+    float wv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wv[k] = (o0 + k < Out) ? w[(size_t)(o0 + k) * In + i] : 0.f;
+#pragma unroll
+    for (int r = 0; r < LIN_BT; ++r) {
+      const float xv = (b0 + r < B) ? x[(size_t)(b0 + r) * In + i] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k][r] = fmaf(wv[k], xv, acc[k][r]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int r = 0; r < LIN_BT; ++r) {
+      const float t = block_sum_256(acc[k][r], sm);
+      if (threadIdx.x == 0 && o0 + k < Out && b0 + r < B) {
+        float v = t + (b ? b[o0 + k] : 0.f);
+        y[(size_t)(b0 + r) * Out + o0 + k] = act_apply(v, act, slope);
+      }
+    }
+  }
+}
+
+// dx[b][i] = sum_o dy[b][o] * w[o][i]   (thread per i, up to 8 batch rows per pass)
+__global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dy, const float* __restrict__ w,
+                                                   float* __restrict__ dx, int B, int In, int Out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int b0 = blockIdx.y * LIN_BT;
+  if (i >= In) return;
+  float acc[LIN_BT];
+#pragma unroll
+  for (int r = 0; r < LIN_BT; ++r) acc[r] = 0.f;
+  for (int o = 0; o < Out; ++o) {
+    const float wv = w[(size_t)o * In + i];
+#pragma unroll
+    for (int r = 0; r < LIN_BT; ++r) {
+      const float g = (b0 + r < B) ? dy[(size_t)(b0 + r) * Out + o] : 0.f;
+      acc[r] = fmaf(g, wv, acc[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < LIN_BT; ++r)
+    if (b0 + r < B) dx[(size_t)(b0 + r) * In + i] = acc[r];
+}
+
+// dw[o][i] = beta*dw + sum_b dy[b][o]*x[b][i]
+__global__ __launch_bounds__(256) void k_linear_dw(const float* __restrict__ dy, const float* __restrict__ x,
+                                                   float* __restrict__ dw, int B, int In, int Out, float beta) {
+  const size_t total = (size_t)Out * In;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int i = (int)(e % In);
+    const int o = (int)(e / In);
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc = fmaf(dy[(size_t)b * Out + o], x[(size_t)b * In + i], acc);
+    dw[e] = beta != 0.f ? beta * dw[e] + acc : acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_linear_db(const float* __restrict__ dy, float* __restrict__ db, int B,
+                                                   int Out, float beta) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= Out) return;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) acc += dy[(size_t)b * Out + o];
+  db[o] = beta != 0.f ? beta * db[o] + acc : acc;
+}
+
+}  // namespace srk
+
+using namespace srk;
+
+extern "C" size_t srk_bn_workspace_bytes(int C) { return (size_t)kBnRowSplits * 2 * (size_t)(C > 0 ? C : 0) * sizeof(double); }
+
+extern "C" int srk_bn_stats(const float* x, double* stats, size_t rows, int C, void* workspace, void* stream) {
+  SRK_REQUIRE(x && stats && workspace && rows > 0 && C > 0, "bn_stats: bad args");
+  return bn_colsum(0, x, nullptr, nullptr, nullptr, stats, rows, C, workspace, (hipStream_t)stream);
+}
+
+extern "C" int srk_bn_finalize(const double* stats, double count, float* save_mean, float* save_rstd,
+                               float* running_mean, float* running_var, float momentum, float eps, int C,
+                               void* stream) {
+  SRK_REQUIRE(stats && save_mean && save_rstd && C > 0 && count > 0, "bn_finalize: bad args");
+  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, count, save_mean,
+                     save_rstd, running_mean, running_var, momentum, eps, C);
+  return check_launch("bn_finalize");
+}
+
+extern "C" int srk_bn_eval_params(const float* running_mean, const float* running_var, float eps, float* mean,
+                                  float* rstd, int C, void* stream) {
+  SRK_REQUIRE(running_mean && running_var && mean && rstd && C > 0, "bn_eval_params: bad args");
+  hipLaunchKernelGGL(k_bn_eval_params, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, running_mean,
+                     running_var, eps, mean, rstd, C);
+  return check_launch("bn_eval_params");
+}
+
+extern "C" int srk_bn_apply(const float* x, float* y, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, size_t rows, int C, int act, float slope, void* stream) {
+  SRK_REQUIRE(x && y && mean && rstd && rows > 0 && C > 0, "bn_apply: bad args");
+  SRK_REQUIRE(act != SRK_ACT_PRELU, "bn_apply: PReLU is not fused here (use srk_act_forward)");
+  const size_t total = rows * (size_t)C;
+  size_t nb = (total + 256 * 4 - 1) / (256 * 4);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, y, mean, rstd, gamma, beta,
+                     total, C, act, slope);
+  return check_launch("bn_apply");
+}
+
+extern "C" int srk_bn_backward_stats(const float* dy, const float* x, const float* mean, const float* rstd,
+                                     double* dstats, size_t rows, int C, void* workspace, void* stream) {
+  SRK_REQUIRE(dy && x && mean && rstd && dstats && workspace && rows > 0 && C > 0, "bn_backward_stats: bad args");
+  return bn_colsum(1, dy, x, mean, rstd, dstats, rows, C, workspace, (hipStream_t)stream);
+}
+
+extern "C" int srk_bn_backward_apply(const float* dy, const float* x, const float* mean, const float* rstd,
+                                     const float* gamma, const double* dstats, double count, float* dx, size_t rows,
+                                     int C, void* stream) {
+  SRK_REQUIRE(dy && x && mean && rstd && dstats && dx && rows > 0 && C > 0 && count > 0, "bn_backward_apply: bad args");
+  const size_t total = rows * (size_t)C;
+  size_t nb = (total + 256 * 4 - 1) / (256 * 4);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma,
+                     dstats, count, dx, total, C);
+  return check_launch("bn_backward_apply");
+}
+
+extern "C" int srk_bn_param_grads(const double* dstats, float* dgamma, float* dbeta, int C, void* stream) {
+  SRK_REQUIRE(dstats && C > 0, "bn_param_grads: bad args");
+  hipLaunchKernelGGL(k_bn_param_grads, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dstats, dgamma, dbeta, C);
+  return check_launch("bn_param_grads");
+}
+
+extern "C" int srk_linear_forward(const float* x, const float* w, const float* b, float* y, int B, int In, int Out,
+                                  int act, float slope, void* stream) {
+  SRK_REQUIRE(x && w && y && B > 0 && In > 0 && Out > 0, "linear_forward: bad args");
+  SRK_REQUIRE(act != SRK_ACT_PRELU, "linear_forward: PReLU is not fused here");
+  dim3 grid(cdiv(Out, 4), cdiv(B, LIN_BT));
+  hipLaunchKernelGGL(k_linear_fwd, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, y, B, In, Out, act, slope);
+  return check_launch("linear_forward");
+}
+
+extern "C" int srk_linear_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                                   int B, int In, int Out, float beta, void* stream) {
+  SRK_REQUIRE(x && w && dy && B > 0 && In > 0 && Out > 0, "linear_backward: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  if (dx) hipLaunchKernelGGL(k_linear_dx, dim3(cdiv(In, 256), cdiv(B, LIN_BT)), dim3(256), 0, s, dy, w, dx, B, In, Out);
+  if (dw) {
+    size_t nb = ((size_t)Out * In + 256 * 4 - 1) / (256 * 4);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(k_linear_dw, dim3((unsigned)nb), dim3(256), 0, s, dy, x, dw, B, In, Out, beta);
+  }
+  if (db) hipLaunchKernelGGL(k_linear_db, dim3(cdiv(Out, 256)), dim3(256), 0, s, dy, db, B, Out, beta);
+  return check_launch("linear_backward");
+}

@@ -1,0 +1,620 @@
+// Implicit-GEMM convolution on the CDNA4 matrix cores, exact fp32 (v_mfma_f32_16x16x4_f32).
+//
+// GEMM view: M = output pixels, N = output channels, K = taps x input channels.
+// One 256-thread block (4 waves) owns a tile of <=128 output pixels x <=64 output channels:
+//   * the NHWC input halo of the tile ((TH-1)*is+KH) x ((TW-1)*is+KW) pixels x CK channels is
+//     staged ONCE in LDS with coalesced 16-byte global reads (zero-filled outside the image, the
+//     activation-gradient mask applied on the fly for backward-data); every tap then re-reads it
+//     from LDS — HBM sees each input element ~once (+halo overlap, L2-absorbed);
+//   * the filter slice of the current tap [CK][<=64] is staged in LDS, the next tap's slice is
+//     prefetched into registers while the current one is being multiplied;
+//   * each wave owns 32 pixels x 64 channels = 2 x 4 MFMA tiles (32 accumulator VGPRs); per
+//     16-channel K step a lane issues 2 ds_read_b128 (A) + 16 ds_read_b32 (B) for 32 MFMAs;
+//   * epilogue: bias + activation + residual add + optional pixel-shuffle scatter, straight
+//     from the accumulators (C/D layout: col = lane&15, row = (lane>>4)*4 + reg).
+//
+// One kernel serves Conv2d forward (any stride), its data gradient (stride 1: flipped taps;
+// stride s: s*s phase launches), ConvTranspose2d forward and its data gradient, through the
+// "phase space" parametrisation below.  Input-channel counts <= 4 (first layers of the forward
+// nets, last layers in backward-data) use the tap-group variant, which packs 4 taps x 4 padded
+// channels into each 16-deep K step instead of wasting 13/16 of the MFMA on zero channels.
+#include "srk_common.h"
+#include "conv_problem.h"
+
+namespace srk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MfmaConvParams {
+  const float* in;
+  const float* wp;
+  float* out;
+  const float* mask_y;
+  float mask_slope;
+  Epi ep;
+  int N, IH, IW, IC;
+  int OH, OW, OC;
+  // phase space: this launch produces outputs (oy0 + r*os, ox0 + c*os), r < PH, c < PW;
+  // virtual tap (u,v) reads input (r*is + iy0 + u, c*is + ix0 + v) and weight tap
+  // (wh0 + wdh*u, ww0 + wdw*v).
+  int PH, PW, oy0, ox0, os;
+  int iy0, ix0, is;
+  int KHv, KWv, wh0, wdh, ww0, wdw, KW_full;
+  int TH, TW, tiles_y, tiles_x, HH, HW;
+  int CK;   // input-channel chunk staged per pass (multiple of 16, <= 64)
+  int PSA;  // halo pixel stride in floats (CK + 4, or 4 for the tap-group variant)
+  int BNp;  // LDS filter row stride in floats (NT*16 + 4)
+  int halo_floats;
+  int vec_in, vec_w;
+};
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Halo staging: global NHWC -> LDS [pixel][PSA], channels [cb, cb+ck) zero-padded to ckp.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_halo(const MfmaConvParams& P, float* halo, int n, int r0, int c0, int cb, int ck,
+                                          int ckp) {
+  const int nvec = ckp >> 2;  // float4 slots per pixel
+  const int items = P.HH * P.HW * nvec;
+  const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int hp = it / nvec, q = it - hp * nvec;
+    const int hy = hp / P.HW, hx = hp - hy * P.HW;
+    const int iy = iyb + hy, ix = ixb + hx;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const int ch = q * 4;
+    if (iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW && ch < ck) {
+      const size_t off = (((size_t)n * P.IH + iy) * P.IW + ix) * P.IC + cb + ch;
+      if (P.vec_in && ch + 3 < ck) {
+        v = *reinterpret_cast<const f32x4*>(P.in + off);
+        if (P.mask_y) {
+          const f32x4 m = *reinterpret_cast<const f32x4*>(P.mask_y + off);
+          v.x = m.x > 0.f ? v.x : v.x * P.mask_slope;
+          v.y = m.y > 0.f ? v.y : v.y * P.mask_slope;
+          v.z = m.z > 0.f ? v.z : v.z * P.mask_slope;
+          v.w = m.w > 0.f ? v.w : v.w * P.mask_slope;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (ch + e < ck) {
+            float x = P.in[off + e];
+            if (P.mask_y) x = P.mask_y[off + e] > 0.f ? x : x * P.mask_slope;
+            v[e] = x;
+          }
+        }
+      }
+    }
+    *reinterpret_cast<f32x4*>(halo + (size_t)hp * P.PSA + ch) = v;
+  }
+}
+
+// Epilogue shared by both variants.
+template <int NT>
+__device__ __forceinline__ void store_tile(const MfmaConvParams& P, const f32x4 (&acc)[2][NT], int n, int r0, int c0,
+                                           int ocb, int wave, int j, int kq) {
+  GatherConv g{};
+  g.OH = P.OH; g.OW = P.OW; g.OC = P.OC;
+  const int npx = P.TH * P.TW;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int m = wave * 32 + mt * 16 + kq * 4 + reg;
+      if (m >= npx) continue;
+      const int r = m / P.TW, c = m - r * P.TW;
+      const int pr = r0 + r, pc = c0 + c;
+      if (pr >= P.PH || pc >= P.PW) continue;
+      const int oy = P.oy0 + pr * P.os, ox = P.ox0 + pc * P.os;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int oc = ocb + nt * 16 + j;
+        if (oc < P.OC) epi_store(P.ep, g, acc[mt][nt][reg], n, oy, ox, oc, P.out);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Main variant: IC >= 5 (channels padded to 16 inside LDS).
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_conv_mfma(MfmaConvParams P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* halo = smem;
+  float* wl = smem + P.halo_floats;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  int b = blockIdx.x;
+  const int txi = b % P.tiles_x;
+  b /= P.tiles_x;
+  const int tyi = b % P.tiles_y;
+  const int n = b / P.tiles_y;
+  const int r0 = tyi * P.TH, c0 = txi * P.TW;
+  const int ocb = blockIdx.y * 64;
+  const int npx = P.TH * P.TW;
+
+  int aoff[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    int m = wave * 32 + mt * 16 + j;
+    if (m >= npx) m = 0;
+    const int r = m / P.TW, c = m - r * P.TW;
+    aoff[mt] = ((r * P.is) * P.HW + c * P.is) * P.PSA + 4 * kq;
+  }
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int T = P.KHv * P.KWv;
+  const int BNp = P.BNp;
+  constexpr int WV = NT * 4;  // float4 slots per filter row
+
+  if (T > 0) {
+    for (int cb = 0; cb < P.IC; cb += P.CK) {
+      const int ck = (P.IC - cb) < P.CK ? (P.IC - cb) : P.CK;
+      const int ckp = (ck + 15) & ~15;
+      const int witems = ckp * WV;
+      __syncthreads();  // previous chunk fully consumed
+      load_halo(P, halo, n, r0, c0, cb, ck, ckp);
+
+      f32x4 wr[4];
+      auto fetch_w = [&](int t) {
+        const int u = t / P.KWv, v = t - u * P.KWv;
+        const int tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
+        const float* base = P.wp + ((size_t)tapw * P.IC + cb) * P.OC + ocb;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int item = tid + it * 256;
+          f32x4 w = {0.f, 0.f, 0.f, 0.f};
+          if (item < witems) {
+            const int ci = item / WV, co = (item - ci * WV) * 4;
+            if (ci < ck) {
+              const float* p = base + (size_t)ci * P.OC + co;
+              if (P.vec_w && ocb + co + 3 < P.OC) {
+                w = *reinterpret_cast<const f32x4*>(p);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (ocb + co + e < P.OC) w[e] = p[e];
+              }
+            }
+          }
+          wr[it] = w;
+        }
+      };
+      auto stash_w = [&]() {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int item = tid + it * 256;
+          if (item < witems) {
+            const int ci = item / WV, co = (item - ci * WV) * 4;
+            *reinterpret_cast<f32x4*>(wl + ci * BNp + co) = wr[it];
+          }
+        }
+      };
+
+      fetch_w(0);
+      for (int t = 0; t < T; ++t) {
+        __syncthreads();  // previous tap's reads of wl done (and halo stores visible for t == 0)
+        stash_w();
+        if (t + 1 < T) fetch_w(t + 1);  // in flight while this tap is multiplied
+        __syncthreads();
+        const int u = t / P.KWv, v = t - u * P.KWv;
+        const int toff = (u * P.HW + v) * P.PSA;
+        const float* ha0 = halo + aoff[0] + toff;
+        const float* ha1 = halo + aoff[1] + toff;
+        for (int c16 = 0; c16 < ckp; c16 += 16) {
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(ha0 + c16);
+          const f32x4 a1 = *reinterpret_cast<const f32x4*>(ha1 + c16);
+          float bq[NT][4];
+          const float* wrow = wl + (c16 + 4 * kq) * BNp + j;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[nt][q] = wrow[q * BNp + nt * 16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              acc[0][nt] = mfma16(a0[q], bq[nt][q], acc[0][nt]);
+              acc[1][nt] = mfma16(a1[q], bq[nt][q], acc[1][nt]);
+            }
+          }
+        }
+      }
+    }
+  }
+  store_tile<NT>(P, acc, n, r0, c0, ocb, wave, j, kq);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tap-group variant: IC <= 4.  LDS halo is [pixel][4] (channels zero-padded); a 16-deep K step
+// covers 4 taps x 4 channels: k-slot kq <-> tap 4*tg + kq, element q <-> channel q.
+// The filter for up to TG_STAGE tap groups is staged per pass as rows (tap_local*4 + ci).
+// ---------------------------------------------------------------------------------------------
+constexpr int TG_STAGE = 8;  // 32 taps per filter stage
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_conv_mfma_tg(MfmaConvParams P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* halo = smem;
+  float* wl = smem + P.halo_floats;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  int b = blockIdx.x;
+  const int txi = b % P.tiles_x;
+  b /= P.tiles_x;
+  const int tyi = b % P.tiles_y;
+  const int n = b / P.tiles_y;
+  const int r0 = tyi * P.TH, c0 = txi * P.TW;
+  const int ocb = blockIdx.y * 64;
+  const int npx = P.TH * P.TW;
+
+  int aoff[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    int m = wave * 32 + mt * 16 + j;
+    if (m >= npx) m = 0;
+    const int r = m / P.TW, c = m - r * P.TW;
+    aoff[mt] = ((r * P.is) * P.HW + c * P.is) * 4;
+  }
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int T = P.KHv * P.KWv;
+  const int BNp = P.BNp;
+  constexpr int WV = NT * 4;
+
+  if (T > 0) {
+    load_halo(P, halo, n, r0, c0, 0, P.IC, 4);
+    const int ngroups = (T + 3) >> 2;
+    for (int g0 = 0; g0 < ngroups; g0 += TG_STAGE) {
+      const int ng = (ngroups - g0) < TG_STAGE ? (ngroups - g0) : TG_STAGE;
+      const int rows = ng * 16;  // (tap_local*4 + ci)
+      __syncthreads();           // previous stage consumed (halo visible on first pass)
+      for (int item = tid; item < rows * WV; item += 256) {
+        const int row = item / WV, co = (item - row * WV) * 4;
+        const int t = g0 * 4 + (row >> 2), ci = row & 3;
+        f32x4 w = {0.f, 0.f, 0.f, 0.f};
+        if (t < T && ci < P.IC) {
+          const int u = t / P.KWv, v = t - u * P.KWv;
+          const int tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
+          const float* p = P.wp + ((size_t)tapw * P.IC + ci) * P.OC + ocb + co;
+          if (P.vec_w && ocb + co + 3 < P.OC) {
+            w = *reinterpret_cast<const f32x4*>(p);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (ocb + co + e < P.OC) w[e] = p[e];
+          }
+        }
+        *reinterpret_cast<f32x4*>(wl + row * BNp + co) = w;
+      }
+      __syncthreads();
+      for (int tg = 0; tg < ng; ++tg) {
+        int t = (g0 + tg) * 4 + kq;
+        if (t >= T) t = 0;  // its filter rows are zero
+        const int u = t / P.KWv, v = t - u * P.KWv;
+        const int toff = (u * P.HW + v) * 4;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(halo + aoff[0] + toff);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(halo + aoff[1] + toff);
+        float bq[NT][4];
+        const float* wrow = wl + ((tg * 4 + kq) * 4) * BNp + j;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bq[nt][q] = wrow[q * BNp + nt * 16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[0][nt] = mfma16(a0[q], bq[nt][q], acc[0][nt]);
+            acc[1][nt] = mfma16(a1[q], bq[nt][q], acc[1][nt]);
+          }
+        }
+      }
+    }
+  }
+  store_tile<NT>(P, acc, n, r0, c0, ocb, wave, j, kq);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Direct variant: OC <= 4 (the 64->3 output convs; 3->3 LapSRN image deconvs).  An MFMA tile
+// would be >= 75% padding, so this is plain VALU: one thread per output pixel (<=256 per block),
+// the input halo staged in LDS exactly as above, the filter read through the scalar cache
+// (its address is wave-uniform), OC fp32 FMAs per LDS element.
+// ---------------------------------------------------------------------------------------------
+template <int OCT>
+__global__ __launch_bounds__(256, 2) void k_conv_direct(MfmaConvParams P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* halo = smem;
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  const int txi = b % P.tiles_x;
+  b /= P.tiles_x;
+  const int tyi = b % P.tiles_y;
+  const int n = b / P.tiles_y;
+  const int r0 = tyi * P.TH, c0 = txi * P.TW;
+  const int npx = P.TH * P.TW;
+  const bool live = tid < npx;
+  const int m = live ? tid : 0;
+  const int r = m / P.TW, c = m - r * P.TW;
+  const int aoff = ((r * P.is) * P.HW + c * P.is) * P.PSA;
+  float acc[OCT];
+#pragma unroll
+  for (int o = 0; o < OCT; ++o) acc[o] = 0.f;
+  const int T = P.KHv * P.KWv;
+  const float* __restrict__ wp = P.wp;
+  if (T > 0) {
+    for (int cb = 0; cb < P.IC; cb += P.CK) {
+      const int ck = (P.IC - cb) < P.CK ? (P.IC - cb) : P.CK;
+      const int ckp = (ck + 3) & ~3;
+      __syncthreads();
+      load_halo(P, halo, n, r0, c0, cb, ck, ckp);
+      __syncthreads();
+      for (int t = 0; t < T; ++t) {
+        const int u = t / P.KWv, v = t - u * P.KWv;
+        const int tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
+        const float* __restrict__ wt = wp + ((size_t)tapw * P.IC + cb) * P.OC;
+        const float* hp = halo + aoff + (u * P.HW + v) * P.PSA;
+        const int full = ck & ~3;
+        for (int c4 = 0; c4 < full; c4 += 4) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(hp + c4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int o = 0; o < OCT; ++o) acc[o] = fmaf(a[e], wt[(c4 + e) * OCT + o], acc[o]);
+        }
+        if (full < ck) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(hp + full);
+#pragma unroll
+          for (int e = 0; e < 3; ++e)
+            if (full + e < ck) {
+#pragma unroll
+              for (int o = 0; o < OCT; ++o) acc[o] = fmaf(a[e], wt[(full + e) * OCT + o], acc[o]);
+            }
+        }
+      }
+    }
+  }
+  if (!live) return;
+  const int pr = r0 + r, pc = c0 + c;
+  if (pr >= P.PH || pc >= P.PW) return;
+  GatherConv g{};
+  g.OH = P.OH; g.OW = P.OW; g.OC = P.OC;
+  const int oy = P.oy0 + pr * P.os, ox = P.ox0 + pc * P.os;
+#pragma unroll
+  for (int o = 0; o < OCT; ++o) epi_store(P.ep, g, acc[o], n, oy, ox, o, P.out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------
+static constexpr int kLdsBudgetBytes = 78 * 1024;  // 2 blocks per CU out of 160 KiB
+
+struct TilePick {
+  int TH, TW, tiles_y, tiles_x, HH, HW;
+  double eff;
+};
+
+// Choose the <=128-pixel tile (any aspect, any width) that covers PH x PW with the fewest tiles
+// under the LDS budget; ties -> smaller halo.
+static bool pick_tile(int maxpix, int PH, int PW, int is, int KHv, int KWv, int psa, int budget_floats,
+                      TilePick& best) {
+  bool found = false;
+  long best_tiles = 0, best_halo = 0;
+  const int maxTW = PW < maxpix ? PW : maxpix;
+  for (int TW = 1; TW <= maxTW; ++TW) {
+    int TH = maxpix / TW;
+    if (TH > PH) TH = PH;
+    for (; TH >= 1; --TH) {
+      const int HH = (TH - 1) * is + KHv, HWd = (TW - 1) * is + KWv;
+      if ((long)HH * HWd * psa <= budget_floats) {
+        const long tiles = (long)cdiv(PH, TH) * cdiv(PW, TW);
+        const long halo = (long)HH * HWd * tiles;
+        if (!found || tiles < best_tiles || (tiles == best_tiles && halo < best_halo)) {
+          found = true;
+          best_tiles = tiles;
+          best_halo = halo;
+          best = TilePick{TH, TW, (int)cdiv(PH, TH), (int)cdiv(PW, TW), HH, HWd,
+                          (double)PH * PW / ((double)tiles * (double)maxpix)};
+        }
+        break;  // smaller TH only gets worse for this TW
+      }
+    }
+  }
+  return found;
+}
+
+bool conv_mfma_gather_supported(const GatherConv& g, const Epi& ep) {
+  (void)ep;
+  if (g.OC < 8) return false;                       // <=4: direct variant; 5..7: generic kernel
+  if (g.KH * g.KW > 32 * 32) return false;
+  if ((long)g.N * g.OH * g.OW > (1L << 30)) return false;
+  return true;
+}
+
+// Raise the dynamic-LDS limit of a kernel once per size (host call, not a stream op).
+static void ensure_lds(const void* fn, int& cur, size_t lds) {
+  if ((int)lds > cur) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    cur = (int)lds;
+  }
+}
+
+template <int NT>
+static void launch_variant(bool tapgroup, const MfmaConvParams& P, dim3 grid, size_t lds, hipStream_t s) {
+  static int cur_tg = 0, cur_main = 0;
+  if (tapgroup) {
+    ensure_lds(reinterpret_cast<const void*>(&k_conv_mfma_tg<NT>), cur_tg, lds);
+    hipLaunchKernelGGL(k_conv_mfma_tg<NT>, grid, dim3(256), lds, s, P);
+  } else {
+    ensure_lds(reinterpret_cast<const void*>(&k_conv_mfma<NT>), cur_main, lds);
+    hipLaunchKernelGGL(k_conv_mfma<NT>, grid, dim3(256), lds, s, P);
+  }
+}
+
+static void apply_pick(MfmaConvParams& P, const TilePick& t) {
+  P.TH = t.TH; P.TW = t.TW; P.tiles_y = t.tiles_y; P.tiles_x = t.tiles_x; P.HH = t.HH; P.HW = t.HW;
+}
+
+template <int OCT>
+static void launch_direct(const MfmaConvParams& P, dim3 grid, size_t lds, hipStream_t s) {
+  static int cur = 0;
+  ensure_lds(reinterpret_cast<const void*>(&k_conv_direct<OCT>), cur, lds);
+  hipLaunchKernelGGL(k_conv_direct<OCT>, grid, dim3(256), lds, s, P);
+}
+
+// Channel-chunk / tile choice for the variants that stage [pixel][CK+4] halos: try chunks of
+// 64 / 32 / 16 channels, keep the largest unless a smaller one tiles the phase grid >15% more
+// efficiently (strided convs and 9x9 kernels have large halos).
+static bool pick_chunk(int maxpix, const MfmaConvParams& P, int icp, int wfloats_per_ci, int& CKout, TilePick& out) {
+  int bestCK = 0;
+  for (int CK = 64; CK >= 16; CK >>= 1) {
+    const int ck = icp < CK ? icp : CK;
+    if (ck == bestCK) continue;
+    TilePick tp{};
+    if (!pick_tile(maxpix, P.PH, P.PW, P.is, P.KHv > 0 ? P.KHv : 1, P.KWv > 0 ? P.KWv : 1, ck + 4,
+                   kLdsBudgetBytes / 4 - ck * wfloats_per_ci, tp))
+      continue;
+    if (bestCK == 0 || tp.eff > out.eff * 1.15) {
+      bestCK = ck;
+      out = tp;
+    }
+  }
+  CKout = bestCK;
+  return bestCK != 0;
+}
+
+static int launch_phase(MfmaConvParams P, hipStream_t s) {
+  const int T = P.KHv * P.KWv;
+  TilePick best{};
+  if (P.OC <= 4) {  // direct VALU variant
+    const int icp = (P.IC + 3) & ~3;
+    int CK = 0;
+    if (!pick_chunk(256, P, icp, 0, CK, best)) {
+      set_error("conv_direct: no tile fits LDS");
+      return SRK_ERR_UNSUPPORTED;
+    }
+    P.CK = CK;
+    P.PSA = CK + 4;
+    apply_pick(P, best);
+    P.halo_floats = best.HH * best.HW * P.PSA;
+    const size_t lds = (size_t)P.halo_floats * 4;
+    dim3 grid((unsigned)((size_t)P.tiles_x * P.tiles_y * P.N), 1);
+    switch (P.OC) {
+      case 1: launch_direct<1>(P, grid, lds, s); break;
+      case 2: launch_direct<2>(P, grid, lds, s); break;
+      case 3: launch_direct<3>(P, grid, lds, s); break;
+      default: launch_direct<4>(P, grid, lds, s); break;
+    }
+    return check_launch("conv_direct");
+  }
+  const bool tapgroup = P.IC <= 4;
+  const int NT = P.OC >= 64 ? 4 : (P.OC + 15) / 16;
+  P.BNp = NT * 16 + 4;
+  size_t lds;
+  if (tapgroup) {
+    P.CK = 4;
+    P.PSA = 4;
+    int ng = (T + 3) / 4;
+    if (ng > TG_STAGE) ng = TG_STAGE;
+    if (ng < 1) ng = 1;
+    const int wfloats = ng * 16 * P.BNp;
+    if (!pick_tile(128, P.PH, P.PW, P.is, P.KHv > 0 ? P.KHv : 1, P.KWv > 0 ? P.KWv : 1, 4,
+                   kLdsBudgetBytes / 4 - wfloats, best)) {
+      set_error("conv_mfma: no tile fits LDS (tap-group)");
+      return SRK_ERR_UNSUPPORTED;
+    }
+    apply_pick(P, best);
+    P.halo_floats = best.HH * best.HW * 4;
+    lds = ((size_t)P.halo_floats + wfloats) * 4;
+  } else {
+    const int icp = (P.IC + 15) & ~15;
+    int CK = 0;
+    if (!pick_chunk(128, P, icp, P.BNp, CK, best)) {
+      set_error("conv_mfma: no tile fits LDS");
+      return SRK_ERR_UNSUPPORTED;
+    }
+    P.CK = CK;
+    P.PSA = CK + 4;
+    apply_pick(P, best);
+    P.halo_floats = best.HH * best.HW * P.PSA;
+    lds = ((size_t)P.halo_floats + (size_t)P.CK * P.BNp) * 4;
+  }
+  dim3 grid((unsigned)((size_t)P.tiles_x * P.tiles_y * P.N), cdiv(P.OC, 64));
+  switch (NT) {
+    case 1: launch_variant<1>(tapgroup, P, grid, lds, s); break;
+    case 2: launch_variant<2>(tapgroup, P, grid, lds, s); break;
+    case 3: launch_variant<3>(tapgroup, P, grid, lds, s); break;
+    default: launch_variant<4>(tapgroup, P, grid, lds, s); break;
+  }
+  return check_launch(tapgroup ? "conv_mfma_tg" : "conv_mfma");
+}
+
+// The direct variant is reached through the same gather entry (OC <= 4).
+bool conv_direct_gather_supported(const GatherConv& g, const Epi& ep) {
+  (void)ep;
+  return g.OC <= 4 && g.KH * g.KW <= 32 * 32;
+}
+int conv_direct_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
+                       const float* mask_y, float mask_slope, hipStream_t s) {
+  return conv_mfma_gather(g, in, wp, out, ep, mask_y, mask_slope, s);
+}
+
+int conv_mfma_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
+                     const float* mask_y, float mask_slope, hipStream_t s) {
+  MfmaConvParams P{};
+  P.in = in; P.wp = wp; P.out = out; P.mask_y = mask_y; P.mask_slope = mask_slope; P.ep = ep;
+  P.N = g.N; P.IH = g.IH; P.IW = g.IW; P.IC = g.IC; P.OH = g.OH; P.OW = g.OW; P.OC = g.OC;
+  P.KW_full = g.KW;
+  P.vec_in = (g.IC % 4 == 0) && ((uintptr_t)in % 16 == 0) && (!mask_y || (uintptr_t)mask_y % 16 == 0);
+  P.vec_w = (g.OC % 4 == 0) && ((uintptr_t)wp % 16 == 0);
+  if (!g.trans) {
+    P.PH = g.OH; P.PW = g.OW; P.oy0 = 0; P.ox0 = 0; P.os = 1;
+    P.iy0 = -g.pad; P.ix0 = -g.pad; P.is = g.stride;
+    P.KHv = g.KH; P.KWv = g.KW; P.wh0 = 0; P.wdh = 1; P.ww0 = 0; P.wdw = 1;
+    return launch_phase(P, s);
+  }
+  // TRANS gather: iy = (oy + p - kh)/s.  One launch per output phase (py,px) = ((oy+p)%s, (ox+p)%s).
+  const int st = g.stride;
+  for (int py = 0; py < st; ++py) {
+    const int oy0 = (((py - g.pad) % st) + st) % st;
+    if (oy0 >= g.OH) continue;
+    const int KHv = py < g.KH ? (g.KH - py + st - 1) / st : 0;
+    const int by = (oy0 + g.pad - py) / st;
+    for (int px = 0; px < st; ++px) {
+      const int ox0 = (((px - g.pad) % st) + st) % st;
+      if (ox0 >= g.OW) continue;
+      const int KWv = px < g.KW ? (g.KW - px + st - 1) / st : 0;
+      const int bx = (ox0 + g.pad - px) / st;
+      MfmaConvParams Q = P;
+      Q.PH = (g.OH - oy0 + st - 1) / st;
+      Q.PW = (g.OW - ox0 + st - 1) / st;
+      Q.oy0 = oy0; Q.ox0 = ox0; Q.os = st; Q.is = 1;
+      if (KHv == 0 || KWv == 0) {
+        Q.KHv = 0; Q.KWv = 0; Q.iy0 = 0; Q.ix0 = 0; Q.wh0 = 0; Q.wdh = 0; Q.ww0 = 0; Q.wdw = 0;
+      } else {
+        Q.KHv = KHv; Q.KWv = KWv;
+        Q.iy0 = by - (KHv - 1); Q.ix0 = bx - (KWv - 1);
+        Q.wh0 = py + st * (KHv - 1); Q.wdh = -st;
+        Q.ww0 = px + st * (KWv - 1); Q.wdw = -st;
+      }
+      const int rc = launch_phase(Q, s);
+      if (rc) return rc;
+    }
+  }
+  return SRK_OK;
+}
+
+}  // namespace srk

@@ -1,0 +1,86 @@
+// Internal description of one "gather convolution" launch plus the fused epilogue, shared by the
+// generic, direct and MFMA kernels.
+#pragma once
+#include "srk_common.h"
+
+namespace srk {
+
+// out[n,oy,ox,oc] = sum in[n,iy,ix,ic] * W[kh][kw][ic][oc]; see conv_generic.hip for iy(oy,kh).
+struct GatherConv {
+  int N, IH, IW, IC;
+  int OH, OW, OC;
+  int KH, KW, stride, pad, trans;
+};
+
+// Device-side epilogue: out = PS_r(act(acc + bias)) + residual
+struct Epi {
+  const float* bias;
+  const float* prelu_w;
+  const float* residual;
+  float slope;
+  int act;
+  int prelu_n;
+  int ps_r;
+};
+
+inline Epi make_epi(const srk_epilogue* e) {
+  Epi r{};
+  if (e) {
+    r.bias = e->bias;
+    r.prelu_w = e->prelu_weight;
+    r.residual = e->residual;
+    r.slope = e->slope;
+    r.act = e->act;
+    r.prelu_n = e->prelu_n;
+    r.ps_r = e->ps_r > 1 ? e->ps_r : 0;
+  }
+  return r;
+}
+
+// Address of output element (n, oy, ox, oc) after the optional fused pixel shuffle.
+// With ps_r > 1 the packed channel order is (i, j, c): oc = (i*r + j)*C + c, and `c_out`
+// receives the post-shuffle channel c (the index a per-channel PReLU of PSBlock uses).
+__device__ __forceinline__ size_t epi_out_index(int ps_r, int OH, int OW, int OC, int n, int oy, int ox, int oc,
+                                                int& c_out) {
+  if (ps_r > 1) {
+    const int C = OC / (ps_r * ps_r);
+    const int q = oc / C, c = oc - q * C;
+    const int i = q / ps_r, j = q - i * ps_r;
+    c_out = c;
+    return (((size_t)n * OH * ps_r + (size_t)oy * ps_r + i) * ((size_t)OW * ps_r) + (size_t)ox * ps_r + j) * C + c;
+  }
+  c_out = oc;
+  return (((size_t)n * OH + oy) * OW + ox) * OC + oc;
+}
+
+__device__ __forceinline__ float epi_value(const Epi& ep, float acc, int oc, int c_act) {
+  if (ep.bias) acc += ep.bias[oc];
+  if (ep.act != SRK_ACT_NONE) {
+    float a = ep.slope;
+    if (ep.act == SRK_ACT_PRELU) a = ep.prelu_n > 1 ? ep.prelu_w[c_act] : ep.prelu_w[0];
+    acc = act_apply(acc, ep.act, a);
+  }
+  return acc;
+}
+
+__device__ __forceinline__ void epi_store(const Epi& ep, const GatherConv& g, float acc, int n, int oy, int ox, int oc,
+                                          float* __restrict__ out) {
+  int c_act;
+  const size_t o = epi_out_index(ep.ps_r, g.OH, g.OW, g.OC, n, oy, ox, oc, c_act);
+  float v = epi_value(ep, acc, oc, c_act);
+  if (ep.residual) v += ep.residual[o];
+  out[o] = v;
+}
+
+// Implemented in conv_generic.hip
+int conv_generic_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
+                        const float* mask_y, float mask_slope, hipStream_t s);
+int conv_bias_grad(const srk_conv_desc& d, const float* dy, const srk_bwd_mask* mask, float* db, float beta,
+                   hipStream_t s);
+int conv_wgrad_finalize(const srk_conv_desc& d, const float* ws, float* dw, float beta, hipStream_t s);
+// Implemented in conv_mfma.hip
+bool conv_mfma_gather_supported(const GatherConv& g, const Epi& ep);
+int conv_mfma_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
+                     const float* mask_y, float mask_slope, hipStream_t s);
+
+}  // namespace srk

@@ -1,0 +1,264 @@
+// Pointwise / permutation kernels: layout copies, pixel shuffle, activations, axpby.
+// All HBM-bound: 16-byte accesses where the layout allows, grid capped at ~2048 blocks with a
+// grid-stride loop (cdna_hip_programming.md Guideline 11/13).
+#include "srk_common.h"
+
+namespace srk {
+
+static inline unsigned ew_grid(size_t work_items, int per_block) {
+  size_t b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > 256 * 16) b = 256 * 16;
+  return (unsigned)b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NCHW <-> NHWC: per image a [C][HW] <-> [HW][C] transpose through a padded LDS tile.
+// ---------------------------------------------------------------------------------------------
+template <bool TO_NHWC>
+__global__ __launch_bounds__(256) void k_layout(const float* __restrict__ x, float* __restrict__ y, int C, int HW) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* xi = x + (size_t)n * C * HW;
+  float* yo = y + (size_t)n * C * HW;
+  if (TO_NHWC) {
+    // read x[c][p] with p fastest; write y[p][c] with c fastest
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+      int c = c0 + ty + k, p = p0 + tx;
+      if (c < C && p < HW) tile[ty + k][tx] = xi[(size_t)c * HW + p];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+      int p = p0 + ty + k, c = c0 + tx;
+      if (c < C && p < HW) yo[(size_t)p * C + c] = tile[tx][ty + k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+      int p = p0 + ty + k, c = c0 + tx;
+      if (c < C && p < HW) tile[ty + k][tx] = xi[(size_t)p * C + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+      int c = c0 + ty + k, p = p0 + tx;
+      if (c < C && p < HW) yo[(size_t)c * HW + p] = tile[tx][ty + k];
+    }
+  }
+}
+
+static int layout_launch(bool to_nhwc, const float* x, float* y, int N, int C, int H, int W, hipStream_t s) {
+  SRK_REQUIRE(x && y, "layout: null pointer");
+  SRK_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "layout: bad dims %d %d %d %d", N, C, H, W);
+  SRK_REQUIRE(N <= 65535 && cdiv(C, 32) <= 65535, "layout: N or C too large for the grid");
+  const int HW = H * W;
+  dim3 grid(cdiv(HW, 32), cdiv(C, 32), N);
+  if (to_nhwc)
+    hipLaunchKernelGGL(k_layout<true>, grid, dim3(256), 0, s, x, y, C, HW);
+  else
+    hipLaunchKernelGGL(k_layout<false>, grid, dim3(256), 0, s, x, y, C, HW);
+  return check_launch("layout");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pixel shuffle (NHWC).  x[n,h,w, c*r*r + i*r + j]  <->  y[n, h*r+i, w*r+j, c]
+// One thread per OUTPUT element of the direction being computed so that stores are coalesced;
+// the gather side stays inside one 4*C*r*r-byte input pixel (L1/L2-resident).
+// ---------------------------------------------------------------------------------------------
+template <bool FWD>
+__global__ __launch_bounds__(256) void k_pixel_shuffle(const float* __restrict__ src, float* __restrict__ dst, int H,
+                                                       int W, int C, int r, size_t total) {
+  const int rr = r * r;
+  const int Cin = C * rr;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    if (FWD) {
+      // e indexes y[n][oy][ox][c]
+      const int c = (int)(e % C);
+      size_t t = e / C;
+      const int ox = (int)(t % ((size_t)W * r));
+      t /= (size_t)W * r;
+      const int oy = (int)(t % ((size_t)H * r));
+      const size_t n = t / ((size_t)H * r);
+      const int h = oy / r, i = oy - h * r, w = ox / r, j = ox - w * r;
+      dst[e] = src[((n * H + h) * W + w) * Cin + c * rr + i * r + j];
+    } else {
+      // e indexes dx[n][h][w][c*rr + i*r + j]
+      const int ch = (int)(e % Cin);
+      size_t t = e / Cin;
+      const int w = (int)(t % W);
+      t /= W;
+      const int h = (int)(t % H);
+      const size_t n = t / H;
+      const int c = ch / rr, q = ch - c * rr, i = q / r, j = q - i * r;
+      dst[e] = src[((n * (size_t)H * r + (size_t)h * r + i) * ((size_t)W * r) + (size_t)w * r + j) * C + c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Activations
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_act_fwd(const float* __restrict__ x, float* __restrict__ y, size_t n,
+                                                 int channels, int act, float slope, const float* __restrict__ pw,
+                                                 int pn) {
+  const bool per_ch = (act == SRK_ACT_PRELU && pn > 1);
+  float a = slope;
+  if (act == SRK_ACT_PRELU && !per_ch) a = pw[0];
+  const size_t n4 = n / 4;
+  const bool vec_ok = (channels % 4 == 0) || !per_ch;
+  if (vec_ok) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+      float4 v = reinterpret_cast<const float4*>(x)[i];
+      float a0 = a, a1 = a, a2 = a, a3 = a;
+      if (per_ch) {
+        const int c = (int)((i * 4) % channels);
+        a0 = pw[c]; a1 = pw[c + 1]; a2 = pw[c + 2]; a3 = pw[c + 3];
+      }
+      v.x = act_apply(v.x, act, a0);
+      v.y = act_apply(v.y, act, a1);
+      v.z = act_apply(v.z, act, a2);
+      v.w = act_apply(v.w, act, a3);
+      reinterpret_cast<float4*>(y)[i] = v;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+      y[i] = act_apply(x[i], act, per_ch ? pw[i % channels] : a);
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+      y[i] = act_apply(x[i], act, pw[i % channels]);
+  }
+}
+
+// dx = dy * act'(.) ; PReLU slope gradient reduced per block then atomically added.
+__global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ dy, const float* __restrict__ saved,
+                                                 float* __restrict__ dx, size_t n, int channels, int act, float slope,
+                                                 const float* __restrict__ pw, int pn, float* __restrict__ dpw) {
+  __shared__ float sm[4];
+  const bool per_ch = (act == SRK_ACT_PRELU && pn > 1);
+  float a = slope;
+  if (act == SRK_ACT_PRELU && !per_ch) a = pw[0];
+  float dslope = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float g = dy[i], s = saved[i];
+    float d;
+    switch (act) {
+      case SRK_ACT_RELU: d = s > 0.f ? g : 0.f; break;
+      case SRK_ACT_LRELU: d = s > 0.f ? g : g * slope; break;
+      case SRK_ACT_PRELU: {
+        const float ai = per_ch ? pw[i % channels] : a;
+        d = s > 0.f ? g : g * ai;
+        const float ds = s > 0.f ? 0.f : g * s;
+        if (per_ch) {
+          if (ds != 0.f) atomicAdd(&dpw[i % channels], ds);
+        } else {
+          dslope += ds;
+        }
+        break;
+      }
+      case SRK_ACT_TANH: d = g * (1.f - s * s); break;
+      case SRK_ACT_SIGMOID: d = g * s * (1.f - s); break;
+      default: d = g;
+    }
+    dx[i] = d;
+  }
+  if (act == SRK_ACT_PRELU && !per_ch && dpw) {
+    const float tot = block_sum_256(dslope, sm);
+    if (threadIdx.x == 0 && tot != 0.f) atomicAdd(dpw, tot);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_axpby(const float* __restrict__ a, const float* __restrict__ b,
+                                               float* __restrict__ out, size_t n, float alpha, float beta) {
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 u = reinterpret_cast<const float4*>(a)[i];
+    const float4 v = reinterpret_cast<const float4*>(b)[i];
+    float4 o;
+    o.x = alpha * u.x + beta * v.x;
+    o.y = alpha * u.y + beta * v.y;
+    o.z = alpha * u.z + beta * v.z;
+    o.w = alpha * u.w + beta * v.w;
+    reinterpret_cast<float4*>(out)[i] = o;
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    out[i] = alpha * a[i] + beta * b[i];
+}
+
+__global__ __launch_bounds__(256) void k_scale_dev(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                   float* __restrict__ out, size_t n) {
+  const float a = *alpha;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = a * x[i];
+}
+
+}  // namespace srk
+
+using namespace srk;
+
+extern "C" int srk_scale_dev(const float* x, const float* alpha_dev, float* out, size_t n, void* stream) {
+  SRK_REQUIRE(x && alpha_dev && out && n > 0, "scale_dev: null pointer or empty");
+  hipLaunchKernelGGL(k_scale_dev, dim3(ew_grid(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, x, alpha_dev, out, n);
+  return check_launch("scale_dev");
+}
+
+extern "C" int srk_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, void* stream) {
+  return layout_launch(true, x, y, N, C, H, W, (hipStream_t)stream);
+}
+extern "C" int srk_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream) {
+  return layout_launch(false, x, y, N, C, H, W, (hipStream_t)stream);
+}
+
+extern "C" int srk_pixel_shuffle_forward(const float* x, float* y, int N, int H, int W, int C, int r, void* stream) {
+  SRK_REQUIRE(x && y, "pixel_shuffle_forward: null pointer");
+  SRK_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && r >= 1, "pixel_shuffle_forward: bad dims");
+  const size_t total = (size_t)N * H * W * C * r * r;
+  hipLaunchKernelGGL(k_pixel_shuffle<true>, dim3(ew_grid(total, 256 * 4)), dim3(256), 0, (hipStream_t)stream, x, y, H,
+                     W, C, r, total);
+  return check_launch("pixel_shuffle_forward");
+}
+extern "C" int srk_pixel_shuffle_backward(const float* dy, float* dx, int N, int H, int W, int C, int r,
+                                          void* stream) {
+  SRK_REQUIRE(dy && dx, "pixel_shuffle_backward: null pointer");
+  SRK_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && r >= 1, "pixel_shuffle_backward: bad dims");
+  const size_t total = (size_t)N * H * W * C * r * r;
+  hipLaunchKernelGGL(k_pixel_shuffle<false>, dim3(ew_grid(total, 256 * 4)), dim3(256), 0, (hipStream_t)stream, dy, dx,
+                     H, W, C, r, total);
+  return check_launch("pixel_shuffle_backward");
+}
+
+extern "C" int srk_act_forward(const float* x, float* y, size_t n, int channels, int act, float slope,
+                               const float* prelu_weight, int prelu_n, void* stream) {
+  SRK_REQUIRE(x && y && n > 0, "act_forward: null pointer or empty");
+  SRK_REQUIRE(act >= SRK_ACT_NONE && act <= SRK_ACT_SIGMOID, "act_forward: unknown act %d", act);
+  if (act == SRK_ACT_PRELU) {
+    SRK_REQUIRE(prelu_weight && prelu_n >= 1, "act_forward: PReLU needs its weight");
+    SRK_REQUIRE(prelu_n == 1 || prelu_n == channels, "act_forward: prelu_n %d != channels %d", prelu_n, channels);
+  }
+  SRK_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0), "act_forward: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(k_act_fwd, dim3(ew_grid(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, x, y, n, channels, act,
+                     slope, prelu_weight, prelu_n);
+  return check_launch("act_forward");
+}
+
+extern "C" int srk_act_backward(const float* dy, const float* saved, float* dx, size_t n, int channels, int act,
+                                float slope, const float* prelu_weight, int prelu_n, float* dprelu, void* stream) {
+  SRK_REQUIRE(dy && saved && dx && n > 0, "act_backward: null pointer or empty");
+  SRK_REQUIRE(act >= SRK_ACT_NONE && act <= SRK_ACT_SIGMOID, "act_backward: unknown act %d", act);
+  if (act == SRK_ACT_PRELU) {
+    SRK_REQUIRE(prelu_weight && prelu_n >= 1, "act_backward: PReLU needs its weight");
+    SRK_REQUIRE(prelu_n == 1 || prelu_n == channels, "act_backward: prelu_n %d != channels %d", prelu_n, channels);
+  }
+  hipLaunchKernelGGL(k_act_bwd, dim3(ew_grid(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, dy, saved, dx, n,
+                     channels, act, slope, prelu_weight, prelu_n, dprelu);
+  return check_launch("act_backward");
+}
+
+extern "C" int srk_axpby(const float* a, const float* b, float* out, size_t n, float alpha, float beta, void* stream) {
+  SRK_REQUIRE(a && b && out && n > 0, "axpby: null pointer or empty");
+  SRK_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0) && ((uintptr_t)out % 16 == 0),
+              "axpby: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(k_axpby, dim3(ew_grid(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, a, b, out, n, alpha, beta);
+  return check_launch("axpby");
+}

@@ -1,0 +1,78 @@
+// Shared helpers for the libsrk kernels (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/srk.h"
+
+namespace srk {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return SRK_ERR_LAUNCH;
+  }
+  return SRK_OK;
+}
+
+#define SRK_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      ::srk::set_error(__VA_ARGS__);    \
+      return SRK_ERR_BAD_ARG;           \
+    }                                   \
+  } while (0)
+
+constexpr int kWave = 64;
+constexpr int kNumCU = 256;
+
+inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+// Activation forward on a scalar. `a` is the negative-side slope for PReLU / LeakyReLU.
+__device__ __forceinline__ float act_apply(float v, int act, float a) {
+  switch (act) {
+    case SRK_ACT_RELU: return v > 0.f ? v : 0.f;
+    case SRK_ACT_PRELU:
+    case SRK_ACT_LRELU: return v > 0.f ? v : a * v;
+    case SRK_ACT_TANH: return tanhf(v);
+    case SRK_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+    default: return v;
+  }
+}
+
+// Sum over the 64 lanes of a wave; every lane gets the total.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum for blockDim.x == 256 (4 waves). `sm` needs 4 floats. All threads get the total.
+__device__ __forceinline__ float block_sum_256(float v, float* sm) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
+__device__ __forceinline__ double block_sum_256_d(double v, double* sm) {
+  v = wave_sum_d(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+}  // namespace srk
+

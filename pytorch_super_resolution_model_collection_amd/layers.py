@@ -1,0 +1,184 @@
+"""Leaf layers: parameter containers with torch's names, shapes and default initialisation
+(so state_dict files and utils.weights_init_* stay drop-in), whose forward runs the HIP kernels.
+
+They subclass the torch.nn classes ONLY for parameter registration / state_dict / class-name
+matching (the reference initialises by `classname.find('Conv2d')`, utils.py:76-113); the ATen
+forward is never called.
+"""
+import torch
+
+from . import ops
+from ._lib import ACT_BY_NAME, ACT_LRELU, ACT_NONE, ACT_PRELU, ACT_RELU
+
+# bumped by optim.step(); cached packed weights older than this are re-packed (inference cache)
+_WEIGHT_EPOCH = [0]
+
+
+def bump_weight_epoch():
+    _WEIGHT_EPOCH[0] += 1
+
+
+def _single(v):
+    if isinstance(v, (tuple, list)):
+        if len(set(v)) != 1:
+            raise NotImplementedError("only square kernels / isotropic stride & padding are supported, got %r" % (v,))
+        return int(v[0])
+    return int(v)
+
+
+def grad_mode(*tensors):
+    """True when autograd will need a backward for this call."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+class _PackCache(object):
+    """Packed-weight cache for no-grad execution, invalidated when the parameters change."""
+
+    def __init__(self):
+        self.key = None
+        self.val = None
+
+    def get(self, weight, bias, transposed, ps_r):
+        key = (weight.data_ptr(), weight._version, None if bias is None else (bias.data_ptr(), bias._version),
+               transposed, ps_r, _WEIGHT_EPOCH[0], str(weight.device))
+        if key != self.key:
+            self.val = (ops.pack_weight_fwd(weight.detach(), transposed, ps_r),
+                        ops.pack_bias_ps(None if bias is None else bias.detach(), ps_r))
+            self.key = key
+        return self.val
+
+
+class Conv2d(torch.nn.Conv2d):
+    """torch.nn.Conv2d surface (base_networks.py:42,112-113,156) on srk_conv2d_*."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+        super(Conv2d, self).__init__(in_channels, out_channels, kernel_size, stride, padding, bias=bias)
+        self._k, self._s, self._p = _single(self.kernel_size), _single(self.stride), _single(self.padding)
+        self._cache = _PackCache()
+
+    def run(self, x, act=ACT_NONE, slope=0.0, prelu_w=None, residual=None, ps_r=0):
+        """conv (+ fused epilogue).  In grad mode only none/relu/lrelu are fused (see ops.conv2d);
+        the caller applies other activations unfused."""
+        cfg = ops.ConvCfg(self._s, self._p, False, 0, act, slope, ps_r)
+        if grad_mode(x, self.weight, self.bias, residual, prelu_w):
+            return ops.conv2d(x, self.weight, self.bias, residual, cfg)
+        packed = self._cache.get(self.weight, self.bias, False, ps_r)
+        return ops.conv2d_infer(x, self.weight, self.bias, residual, cfg, prelu_w, packed)
+
+    def forward(self, x):
+        return self.run(x)
+
+
+class ConvTranspose2d(torch.nn.ConvTranspose2d):
+    """torch.nn.ConvTranspose2d surface (base_networks.py:77; fsrcnn.py:33)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, bias=True):
+        super(ConvTranspose2d, self).__init__(in_channels, out_channels, kernel_size, stride, padding,
+                                              output_padding, bias=bias)
+        self._k, self._s, self._p = _single(self.kernel_size), _single(self.stride), _single(self.padding)
+        self._op = _single(self.output_padding)
+        self._cache = _PackCache()
+
+    def run(self, x, act=ACT_NONE, slope=0.0, prelu_w=None):
+        cfg = ops.ConvCfg(self._s, self._p, True, self._op, act, slope, 0)
+        if grad_mode(x, self.weight, self.bias, prelu_w):
+            return ops.conv2d(x, self.weight, self.bias, None, cfg)
+        packed = self._cache.get(self.weight, self.bias, True, 0)
+        return ops.conv2d_infer(x, self.weight, self.bias, None, cfg, prelu_w, packed)
+
+    def forward(self, x, output_size=None):
+        if output_size is not None:
+            raise NotImplementedError("output_size is not supported")
+        return self.run(x)
+
+
+class PixelShuffle(torch.nn.PixelShuffle):
+    """torch.nn.PixelShuffle surface (base_networks.py:157)."""
+
+    def forward(self, x):
+        return ops.pixel_shuffle(x, self.upscale_factor)
+
+
+class BatchNorm2d(torch.nn.BatchNorm2d):
+    """torch.nn.BatchNorm2d surface (base_networks.py:46,117,161). `sync_group` (a
+    torch.distributed group) turns the batch statistics into SyncBN sums over the DP ranks."""
+
+    sync_group = None
+
+    def forward(self, x):
+        training = self.training or self.running_mean is None
+        if training and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)  # bookkeeping counter, not arithmetic on the path
+        momentum = 0.1 if self.momentum is None else self.momentum
+        return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, training, momentum,
+                              self.eps, self.sync_group if training else None)
+
+
+class Linear(torch.nn.Linear):
+    """torch.nn.Linear surface (base_networks.py:7)."""
+
+    def run(self, x, act=ACT_NONE, slope=0.0):
+        return ops.linear(x, self.weight, self.bias, act, slope)
+
+    def forward(self, x):
+        return self.run(x)
+
+
+class ReLU(torch.nn.ReLU):
+    kind, slope = ACT_RELU, 0.0
+
+    def forward(self, x):
+        return ops.activation(x, ACT_RELU)
+
+
+class LeakyReLU(torch.nn.LeakyReLU):
+    kind = ACT_LRELU
+
+    @property
+    def slope(self):
+        return float(self.negative_slope)
+
+    def forward(self, x):
+        return ops.activation(x, ACT_LRELU, self.negative_slope)
+
+
+class PReLU(torch.nn.PReLU):
+    kind, slope = ACT_PRELU, 0.0
+
+    def forward(self, x):
+        return ops.activation(x, ACT_PRELU, 0.0, self.weight)
+
+
+class Tanh(torch.nn.Tanh):
+    kind, slope = ACT_BY_NAME["tanh"], 0.0
+
+    def forward(self, x):
+        return ops.activation(x, self.kind)
+
+
+class Sigmoid(torch.nn.Sigmoid):
+    kind, slope = ACT_BY_NAME["sigmoid"], 0.0
+
+    def forward(self, x):
+        return ops.activation(x, self.kind)
+
+
+def make_activation(name):
+    """The if-chain of base_networks.py:49-60 as a table."""
+    if name is None:
+        return None
+    table = {"relu": lambda: ReLU(True), "prelu": PReLU, "lrelu": lambda: LeakyReLU(0.2, True), "tanh": Tanh,
+             "sigmoid": Sigmoid}
+    if name not in table:
+        return None  # the reference silently builds no activation for unknown names
+    return table[name]()
+
+
+def make_norm2d(norm, channels):
+    if norm is None:
+        return None
+    if norm == "batch":
+        return BatchNorm2d(channels)
+    if norm == "instance":
+        raise NotImplementedError("norm='instance' is never used by the reference nets and is not implemented")
+    return None

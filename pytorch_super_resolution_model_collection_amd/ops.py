@@ -1,0 +1,555 @@
+"""autograd.Function wrappers around the C ABI (include/srk.h).
+
+Every function here enqueues hand-written HIP kernels on torch's current stream and returns
+torch tensors that merely OWN the device memory.  Activations are logically NCHW (the reference's
+module surface, e.g. edsr.py:146-152) but stored channels_last (= dense NHWC, the kernels'
+layout).  Nothing in this file computes on the CPU and nothing falls back to ATen operators.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_BY_NAME, ACT_LRELU, ACT_NONE, ACT_PRELU, ACT_RELU, ALGO_AUTO, BwdMask, ConvDesc, Epilogue,
+                   check, ptr, require_cuda, stream_ptr)
+
+CL = torch.channels_last
+
+
+def _empty_cl(n, c, h, w, like):
+    return torch.empty((n, c, h, w), dtype=torch.float32, device=like.device, memory_format=CL)
+
+
+def _is_nhwc_dense(x):
+    n, c, h, w = x.shape
+    return x.stride() == (h * w * c, 1, w * c, c) or (x.is_contiguous(memory_format=CL) and (c == 1 or h * w == 1))
+
+
+def to_nhwc(x):
+    """Logical NCHW tensor -> same values, channels_last storage (srk_nchw_to_nhwc if a copy is needed)."""
+    require_cuda(x)
+    if x.dim() != 4:
+        raise RuntimeError("expected a 4-D NCHW tensor, got shape %s" % (tuple(x.shape),))
+    if _is_nhwc_dense(x):
+        return x
+    n, c, h, w = x.shape
+    if not x.is_contiguous():
+        raise RuntimeError("input must be NCHW-contiguous or channels_last")
+    y = _empty_cl(n, c, h, w, x)
+    lib = _lib.load()
+    check(lib.srk_nchw_to_nhwc(ptr(x), ptr(y), n, c, h, w, stream_ptr()), "srk_nchw_to_nhwc")
+    return y
+
+
+def to_nchw(x):
+    """channels_last tensor -> NCHW-contiguous copy (srk_nhwc_to_nchw). Used before Linear layers."""
+    require_cuda(x)
+    n, c, h, w = x.shape
+    if x.is_contiguous() and not (_is_nhwc_dense(x) and c > 1 and h * w > 1):
+        return x
+    x = to_nhwc(x)
+    y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    check(lib.srk_nhwc_to_nchw(ptr(x), ptr(y), n, c, h, w, stream_ptr()), "srk_nhwc_to_nchw")
+    return y
+
+
+class _ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return to_nchw(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return to_nhwc(g.contiguous() if not (g.is_contiguous() or _is_nhwc_dense(g)) else g)
+
+
+def flatten_nchw(x):
+    """out.view(B, -1) of the reference (srgan.py:75) — flatten in (C,H,W) order."""
+    y = _ToNCHW.apply(x)
+    return y.reshape(y.shape[0], -1)
+
+
+# ------------------------------------------------------------------------------------------------
+# Convolution
+# ------------------------------------------------------------------------------------------------
+class ConvCfg(object):
+    """Static configuration of one Conv2d / ConvTranspose2d call."""
+    __slots__ = ("stride", "pad", "transposed", "out_pad", "act", "slope", "ps_r", "algo")
+
+    def __init__(self, stride=1, pad=0, transposed=False, out_pad=0, act=ACT_NONE, slope=0.0, ps_r=0,
+                 algo=ALGO_AUTO):
+        self.stride, self.pad, self.transposed, self.out_pad = int(stride), int(pad), bool(transposed), int(out_pad)
+        self.act, self.slope, self.ps_r, self.algo = int(act), float(slope), int(ps_r), int(algo)
+
+
+def _weight_dims(weight, transposed):
+    if transposed:
+        cin, cout, kh, kw = weight.shape
+    else:
+        cout, cin, kh, kw = weight.shape
+    return cout, cin, kh, kw
+
+
+def _make_desc(x_shape, weight, cfg):
+    lib = _lib.load()
+    n, c, h, w = x_shape
+    cout, cin, kh, kw = _weight_dims(weight, cfg.transposed)
+    if c != cin:
+        raise RuntimeError("conv: input has %d channels, weight expects %d" % (c, cin))
+    oh = lib.srk_conv_out_dim(h, kh, cfg.stride, cfg.pad, int(cfg.transposed), cfg.out_pad)
+    ow = lib.srk_conv_out_dim(w, kw, cfg.stride, cfg.pad, int(cfg.transposed), cfg.out_pad)
+    if oh <= 0 or ow <= 0:
+        raise RuntimeError("conv: empty output for input %s kernel %dx%d" % (tuple(x_shape), kh, kw))
+    return ConvDesc(n, h, w, cin, oh, ow, cout, kh, kw, cfg.stride, cfg.pad, int(cfg.transposed), cfg.out_pad,
+                    cfg.algo)
+
+
+def pack_weight_fwd(weight, transposed, ps_r):
+    lib = _lib.load()
+    cout, cin, kh, kw = _weight_dims(weight, transposed)
+    wp = torch.empty(kh * kw * cin * cout, dtype=torch.float32, device=weight.device)
+    check(lib.srk_pack_weight_fwd(ptr(weight), ptr(wp), cout, cin, kh, kw, int(transposed), int(ps_r), stream_ptr()),
+          "srk_pack_weight_fwd")
+    return wp
+
+
+def pack_weight_bwd(weight, transposed):
+    lib = _lib.load()
+    cout, cin, kh, kw = _weight_dims(weight, transposed)
+    wp = torch.empty(kh * kw * cin * cout, dtype=torch.float32, device=weight.device)
+    check(lib.srk_pack_weight_bwd(ptr(weight), ptr(wp), cout, cin, kh, kw, int(transposed), stream_ptr()),
+          "srk_pack_weight_bwd")
+    return wp
+
+
+def pack_bias_ps(bias, ps_r):
+    if bias is None or ps_r <= 1:
+        return bias
+    lib = _lib.load()
+    bp = torch.empty_like(bias)
+    check(lib.srk_pack_bias_ps(ptr(bias), ptr(bp), bias.numel(), int(ps_r), stream_ptr()), "srk_pack_bias_ps")
+    return bp
+
+
+def conv_forward_raw(x, wp, bias_p, weight_shape_src, cfg, prelu_w=None, residual=None):
+    """Launch srk_conv2d_forward on already-packed weights. x must be NHWC-dense."""
+    lib = _lib.load()
+    d = _make_desc(x.shape, weight_shape_src, cfg)
+    r = cfg.ps_r if cfg.ps_r > 1 else 1
+    y = _empty_cl(d.N, d.Cout // (r * r), d.OH * r, d.OW * r, x)
+    if residual is not None and tuple(residual.shape) != tuple(y.shape):
+        raise RuntimeError("conv: residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
+    ep = Epilogue(ptr(bias_p), ptr(prelu_w), ptr(residual), cfg.slope, cfg.act,
+                  0 if prelu_w is None else prelu_w.numel(), cfg.ps_r)
+    check(lib.srk_conv2d_forward(ctypes.byref(d), ptr(x), ptr(wp), ptr(y), ctypes.byref(ep), stream_ptr()),
+          "srk_conv2d_forward")
+    return y
+
+
+class _Conv2d(torch.autograd.Function):
+    """y = PS_r(act(conv(x, w) + b)) + residual, training-capable for act in {none, relu, lrelu}."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, cfg, packed):
+        require_cuda(x, weight, bias, residual)
+        x = to_nhwc(x)
+        if residual is not None:
+            residual = to_nhwc(residual)
+        if packed is not None:
+            wp, bp = packed
+        else:
+            wp = pack_weight_fwd(weight, cfg.transposed, cfg.ps_r)
+            bp = pack_bias_ps(bias, cfg.ps_r)
+        y = conv_forward_raw(x, wp, bp, weight, cfg, None, residual)
+        ctx.cfg = cfg
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.weight_ref = weight
+        ctx.bias_ref = bias
+        need_mask = cfg.act in (ACT_RELU, ACT_LRELU)
+        ctx.save_for_backward(x, weight, y if need_mask else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        cfg = ctx.cfg
+        x, weight, y = ctx.saved_tensors
+        dy = to_nhwc(dy if (dy.is_contiguous() or _is_nhwc_dense(dy)) else dy.contiguous())
+        d = _make_desc(x.shape, weight, cfg)
+        dres = dy if ctx.has_res else None
+        dyc = dy
+        if cfg.ps_r > 1:
+            r = cfg.ps_r
+            dyc = _empty_cl(d.N, d.Cout, d.OH, d.OW, dy)
+            check(lib.srk_pixel_shuffle_backward(ptr(dy), ptr(dyc), d.N, d.OH, d.OW, d.Cout // (r * r), r,
+                                                 stream_ptr()), "srk_pixel_shuffle_backward")
+        mask = None
+        if y is not None:
+            mask = BwdMask(ptr(y), cfg.slope if cfg.act == ACT_LRELU else 0.0)
+        mref = ctypes.byref(mask) if mask is not None else None
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wpb = pack_weight_bwd(weight, cfg.transposed)
+            dx = _empty_cl(d.N, d.Cin, d.H, d.W, dy)
+            check(lib.srk_conv2d_backward_data(ctypes.byref(d), ptr(dyc), ptr(wpb), ptr(dx), mref, None,
+                                               stream_ptr()), "srk_conv2d_backward_data")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            ws_bytes = lib.srk_conv2d_backward_weight_workspace_bytes(ctypes.byref(d))
+            ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=dy.device)
+            wref, bref = ctx.weight_ref, ctx.bias_ref
+            wacc = getattr(wref, "_srk_grad", None)
+            bacc = getattr(bref, "_srk_grad", None) if ctx.has_bias else None
+            if wacc is not None and (not ctx.has_bias or bacc is not None):
+                # flat-buffer mode: accumulate straight into the (pre-zeroed) gradient views
+                check(lib.srk_conv2d_backward_weight(ctypes.byref(d), ptr(x), ptr(dyc), mref, ptr(wacc), ptr(bacc),
+                                                     1.0, ptr(ws), ws.numel(), stream_ptr()),
+                      "srk_conv2d_backward_weight")
+            else:
+                dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+                db = torch.empty(d.Cout, dtype=torch.float32, device=dy.device) if ctx.has_bias else None
+                check(lib.srk_conv2d_backward_weight(ctypes.byref(d), ptr(x), ptr(dyc), mref, ptr(dw), ptr(db), 0.0,
+                                                     ptr(ws), ws.numel(), stream_ptr()),
+                      "srk_conv2d_backward_weight")
+        return dx, dw, db, dres, None, None
+
+
+def conv2d(x, weight, bias=None, residual=None, cfg=None, packed=None):
+    """Fused conv for training (act limited to none/relu/lrelu; no act together with residual/ps)."""
+    cfg = cfg or ConvCfg()
+    if cfg.act not in (ACT_NONE, ACT_RELU, ACT_LRELU):
+        raise RuntimeError("conv2d (autograd path) fuses only none/relu/lrelu; use conv2d_infer or an unfused act")
+    if cfg.act != ACT_NONE and (residual is not None or cfg.ps_r > 1):
+        raise RuntimeError("conv2d (autograd path): activation cannot be fused together with residual/pixel-shuffle")
+    return _Conv2d.apply(x, weight, bias, residual, cfg, packed)
+
+
+def conv2d_infer(x, weight, bias=None, residual=None, cfg=None, prelu_w=None, packed=None):
+    """No-grad fully fused conv: any activation + residual + pixel shuffle in one kernel."""
+    cfg = cfg or ConvCfg()
+    require_cuda(x, weight, bias, residual, prelu_w)
+    x = to_nhwc(x)
+    if residual is not None:
+        residual = to_nhwc(residual)
+    if packed is not None:
+        wp, bp = packed
+    else:
+        wp = pack_weight_fwd(weight, cfg.transposed, cfg.ps_r)
+        bp = pack_bias_ps(bias, cfg.ps_r)
+    return conv_forward_raw(x, wp, bp, weight, cfg, prelu_w, residual)
+
+
+# ------------------------------------------------------------------------------------------------
+# Pixel shuffle, activations, add / fork
+# ------------------------------------------------------------------------------------------------
+class _PixelShuffle(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, r):
+        lib = _lib.load()
+        require_cuda(x)
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        if c % (r * r):
+            raise RuntimeError("pixel_shuffle: %d channels not divisible by r^2=%d" % (c, r * r))
+        y = _empty_cl(n, c // (r * r), h * r, w * r, x)
+        check(lib.srk_pixel_shuffle_forward(ptr(x), ptr(y), n, h, w, c // (r * r), r, stream_ptr()),
+              "srk_pixel_shuffle_forward")
+        ctx.r = r
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        r = ctx.r
+        dy = to_nhwc(dy if (dy.is_contiguous() or _is_nhwc_dense(dy)) else dy.contiguous())
+        n, c, hr, wr = dy.shape
+        dx = _empty_cl(n, c * r * r, hr // r, wr // r, dy)
+        check(lib.srk_pixel_shuffle_backward(ptr(dy), ptr(dx), n, hr // r, wr // r, c, r, stream_ptr()),
+              "srk_pixel_shuffle_backward")
+        return dx, None
+
+
+def pixel_shuffle(x, r):
+    return _PixelShuffle.apply(x, int(r))
+
+
+def _channels_inner(x):
+    """Innermost (fastest) extent used for per-channel PReLU: C for NHWC 4-D, last dim for 2-D."""
+    return x.shape[1] if x.dim() == 4 else x.shape[-1]
+
+
+def _dense(x):
+    if x.dim() == 4:
+        return to_nhwc(x if (x.is_contiguous() or _is_nhwc_dense(x)) else x.contiguous())
+    return x.contiguous()
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kind, slope, prelu_w):
+        lib = _lib.load()
+        require_cuda(x, prelu_w)
+        x = _dense(x)
+        y = torch.empty_like(x)
+        check(lib.srk_act_forward(ptr(x), ptr(y), x.numel(), _channels_inner(x), kind, slope, ptr(prelu_w),
+                                  0 if prelu_w is None else prelu_w.numel(), stream_ptr()), "srk_act_forward")
+        ctx.kind, ctx.slope = kind, slope
+        ctx.prelu_ref = prelu_w
+        ctx.save_for_backward(x if kind == ACT_PRELU else y, prelu_w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        saved, prelu_w = ctx.saved_tensors
+        dy = _dense(dy)
+        dx = torch.empty_like(dy)
+        dpw = ret_dpw = None
+        if prelu_w is not None:
+            dpw = getattr(ctx.prelu_ref, "_srk_grad", None)
+            if dpw is None:
+                dpw = ret_dpw = torch.zeros_like(prelu_w)
+        check(lib.srk_act_backward(ptr(dy), ptr(saved), ptr(dx), dy.numel(), _channels_inner(dy), ctx.kind,
+                                   ctx.slope, ptr(prelu_w), 0 if prelu_w is None else prelu_w.numel(), ptr(dpw),
+                                   stream_ptr()), "srk_act_backward")
+        return dx, None, None, ret_dpw
+
+
+def activation(x, kind, slope=0.0, prelu_w=None):
+    if isinstance(kind, str) or kind is None:
+        kind = ACT_BY_NAME[kind]
+    if kind == ACT_NONE:
+        return x
+    return _Act.apply(x, int(kind), float(slope), prelu_w)
+
+
+def _axpby(a, b, alpha, beta):
+    lib = _lib.load()
+    out = torch.empty_like(a)
+    check(lib.srk_axpby(ptr(a), ptr(b), ptr(out), a.numel(), alpha, beta, stream_ptr()), "srk_axpby")
+    return out
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        require_cuda(a, b)
+        if a.shape != b.shape:
+            raise RuntimeError("add: shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        a, b = _dense(a), _dense(b)
+        return _axpby(a, b, 1.0, 1.0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    """torch.add(out, residual) of the reference (base_networks.py:149, vdsr.py:31, edsr.py:42)."""
+    return _Add.apply(a, b)
+
+
+class _Fork(torch.autograd.Function):
+    """Use a tensor twice (trunk + skip) with the gradient fan-in summed by srk_axpby instead of
+    autograd's internal ATen add."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None:
+            return g2
+        if g2 is None:
+            return g1
+        return _axpby(_dense(g1), _dense(g2), 1.0, 1.0)
+
+
+def fork(x):
+    return _Fork.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# Losses (mean reduction), forward + gradient in one pass
+# ------------------------------------------------------------------------------------------------
+class _Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, kind, eps):
+        lib = _lib.load()
+        require_cuda(pred, target)
+        if pred.shape != target.shape:
+            raise RuntimeError("loss: pred %s vs target %s" % (tuple(pred.shape), tuple(target.shape)))
+        if pred.dim() == 4:
+            pred = _dense(pred)
+            n, c, h, w = pred.shape
+            ts = target.stride()
+        else:  # [B, F] (BCE on the discriminator output): treat as N=B, C=F, H=W=1
+            pred = pred.contiguous()
+            n, c = pred.shape[0], pred.numel() // pred.shape[0]
+            h = w = 1
+            target = target.contiguous()
+            ts = (c, 1, 1, 1)
+        strides = (ctypes.c_int64 * 4)(*[int(s) for s in ts])
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        need_grad = ctx.needs_input_grad[0]
+        dpred = torch.empty_like(pred) if need_grad else None
+        ws = torch.empty(int(lib.srk_loss_workspace_bytes()), dtype=torch.uint8, device=pred.device)
+        check(lib.srk_loss_forward_backward(kind, ptr(pred), ptr(target), strides, n, c, h, w, eps, 1.0, ptr(loss),
+                                            ptr(dpred), ptr(ws), stream_ptr()), "srk_loss_forward_backward")
+        ctx.dpred = dpred
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dpred = ctx.dpred
+        ctx.dpred = None
+        if dpred is None:
+            return None, None, None, None
+        lib = _lib.load()
+        out = torch.empty_like(dpred)
+        check(lib.srk_scale_dev(ptr(dpred), ptr(g.contiguous()), ptr(out), dpred.numel(), stream_ptr()),
+              "srk_scale_dev")
+        return out, None, None, None
+
+
+def mse_loss(pred, target):
+    """nn.MSELoss() (srcnn.py:84-86,129; vdsr.py:145; srgan.py:205,300)."""
+    return _Loss.apply(pred, target, _lib.LOSS_MSE, 0.0)
+
+
+def l1_loss(pred, target):
+    """nn.L1Loss() (edsr.py:98-100,153)."""
+    return _Loss.apply(pred, target, _lib.LOSS_L1, 0.0)
+
+
+def charbonnier_loss(pred, target, eps=1e-6):
+    """L1_Charbonnier_loss (lapsrn.py:75-85)."""
+    return _Loss.apply(pred, target, _lib.LOSS_CHARBONNIER, float(eps))
+
+
+def bce_loss(pred, target):
+    """nn.BCELoss() (srgan.py:157,276-297)."""
+    return _Loss.apply(pred, target, _lib.LOSS_BCE, 0.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm2d / Linear (SRGAN)
+# ------------------------------------------------------------------------------------------------
+class _BatchNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, sync_group):
+        lib = _lib.load()
+        require_cuda(x, gamma, beta)
+        x = _dense(x)
+        n, c, h, w = x.shape
+        rows = n * h * w
+        mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(c, dtype=torch.float32, device=x.device)
+        count = float(rows)
+        if training:
+            stats = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+            ws = torch.empty(int(lib.srk_bn_workspace_bytes(c)), dtype=torch.uint8, device=x.device)
+            check(lib.srk_bn_stats(ptr(x), ptr(stats), rows, c, ptr(ws), stream_ptr()), "srk_bn_stats")
+            if sync_group is not None:
+                import torch.distributed as dist
+                dist.all_reduce(stats, group=sync_group)
+                count *= dist.get_world_size(sync_group)
+            check(lib.srk_bn_finalize(ptr(stats), count, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
+                                      momentum, eps, c, stream_ptr()), "srk_bn_finalize")
+        else:
+            check(lib.srk_bn_eval_params(ptr(running_mean), ptr(running_var), eps, ptr(mean), ptr(rstd), c,
+                                         stream_ptr()), "srk_bn_eval_params")
+        y = torch.empty_like(x)
+        check(lib.srk_bn_apply(ptr(x), ptr(y), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), rows, c, ACT_NONE, 0.0,
+                               stream_ptr()), "srk_bn_apply")
+        ctx.training, ctx.count, ctx.sync_group = training, count, sync_group
+        ctx.gamma_ref, ctx.beta_ref = gamma, beta
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dy = _dense(dy)
+        n, c, h, w = x.shape
+        rows = n * h * w
+        dstats = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+        ws = torch.empty(int(lib.srk_bn_workspace_bytes(c)), dtype=torch.uint8, device=x.device)
+        check(lib.srk_bn_backward_stats(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(dstats), rows, c, ptr(ws),
+                                        stream_ptr()), "srk_bn_backward_stats")
+        local = dstats
+        if ctx.training and ctx.sync_group is not None:
+            import torch.distributed as dist
+            local = dstats.clone()
+            dist.all_reduce(dstats, group=ctx.sync_group)
+        dx = torch.empty_like(dy)
+        dgamma = getattr(ctx.gamma_ref, "_srk_grad", None)
+        dbeta = getattr(ctx.beta_ref, "_srk_grad", None)
+        ret_g = ret_b = None
+        if dgamma is None or dbeta is None:
+            dgamma = ret_g = torch.zeros(c, dtype=torch.float32, device=x.device)
+            dbeta = ret_b = torch.zeros(c, dtype=torch.float32, device=x.device)
+        # eval-mode BN: statistics are constants -> no mean/projection terms in dx
+        use = dstats if ctx.training else torch.zeros_like(dstats)
+        check(lib.srk_bn_backward_apply(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(use), ctx.count,
+                                        ptr(dx), rows, c, stream_ptr()), "srk_bn_backward_apply")
+        # parameter gradients use the LOCAL sums (the DP gradient all-reduce happens later)
+        check(lib.srk_bn_param_grads(ptr(local), ptr(dgamma), ptr(dbeta), c, stream_ptr()), "srk_bn_param_grads")
+        return dx, ret_g, ret_b, None, None, None, None, None, None
+
+
+def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, sync_group=None):
+    """nn.BatchNorm2d (base_networks.py:46,117,161)."""
+    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, bool(training), float(momentum), float(eps),
+                            sync_group)
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, slope):
+        lib = _lib.load()
+        require_cuda(x, weight, bias)
+        x = x.contiguous()
+        b, fin = x.shape
+        fout = weight.shape[0]
+        y = torch.empty((b, fout), dtype=torch.float32, device=x.device)
+        check(lib.srk_linear_forward(ptr(x), ptr(weight), ptr(bias), ptr(y), b, fin, fout, act, slope, stream_ptr()),
+              "srk_linear_forward")
+        ctx.act, ctx.slope = act, slope
+        ctx.weight_ref, ctx.bias_ref = weight, bias
+        ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, weight, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        b, fin = x.shape
+        fout = weight.shape[0]
+        if y is not None:
+            dz = torch.empty_like(dy)
+            check(lib.srk_act_backward(ptr(dy), ptr(y), ptr(dz), dy.numel(), fout, ctx.act, ctx.slope, None, 0, None,
+                                       stream_ptr()), "srk_act_backward")
+            dy = dz
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        has_bias = ctx.bias_ref is not None
+        wacc = getattr(ctx.weight_ref, "_srk_grad", None)
+        bacc = getattr(ctx.bias_ref, "_srk_grad", None) if has_bias else None
+        if wacc is not None and (not has_bias or bacc is not None):
+            check(lib.srk_linear_backward(ptr(x), ptr(weight), ptr(dy), ptr(dx), ptr(wacc), ptr(bacc), b, fin, fout,
+                                          1.0, stream_ptr()), "srk_linear_backward")
+            return dx, None, None, None, None
+        dw = torch.empty_like(weight)
+        db = torch.empty(fout, dtype=torch.float32, device=x.device) if has_bias else None
+        check(lib.srk_linear_backward(ptr(x), ptr(weight), ptr(dy), ptr(dx), ptr(dw), ptr(db), b, fin, fout, 0.0,
+                                      stream_ptr()), "srk_linear_backward")
+        return dx, dw, db, None, None
+
+
+def linear(x, weight, bias=None, act=ACT_NONE, slope=0.0):
+    """nn.Linear + activation of DenseBlock (base_networks.py:7,26-35). PReLU is applied unfused."""
+    return _Linear.apply(x, weight, bias, int(act), float(slope))

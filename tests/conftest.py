@@ -1,0 +1,62 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# north_star tolerance: outputs within 1e-3 (relative, fp32) of the reference's CPU path.
+TOL_CONTRACT = 1e-3
+# what the exact-fp32 MFMA path actually delivers (only summation order differs from oneDNN)
+TOL_TIGHT = 2e-5
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def ops_kat():
+    return _load("ops_kat.npz")
+
+
+@pytest.fixture(scope="session")
+def nets_golden():
+    return _load("nets.npz")
+
+
+@pytest.fixture(scope="session")
+def train_golden():
+    return _load("train_traj.npz")
+
+
+def rel_err(a, b):
+    """max |a-b| / max(|b|, tiny) on numpy arrays / tensors."""
+    import torch
+    if isinstance(a, torch.Tensor):
+        a = a.detach().float().cpu().numpy()
+    if isinstance(b, torch.Tensor):
+        b = b.detach().float().cpu().numpy()
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    denom = max(float(np.abs(b).max()), 1e-30)
+    return float(np.abs(a - b).max()) / denom
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__
+    __graft_entry__.build()
+    return torch.device("cuda:0")

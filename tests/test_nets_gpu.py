@@ -1,0 +1,92 @@
+"""Whole-network parity on the MI355X: every reference net (forward, input gradient and all
+parameter gradients) against the golden vectors produced by the reference's own classes."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import fill, ref_modules as R
+
+pytestmark = pytest.mark.gpu
+
+# name: (product class name, ctor args, input shape, fill gain) — mirrors tests/golden/make_golden.py NETS
+CASES = {
+    "srcnn": ("SRCNNNet", (3, 64), (2, 3, 20, 20), 1.0),
+    "espcn": ("ESPCNNet", (3, 64, 4), (2, 3, 16, 16), 1.0),
+    "fsrcnn": ("FSRCNNNet", (3, 4, 56, 12, 4), (2, 3, 12, 12), 1.0),
+    "vdsr": ("VDSRNet", (3, 64, 18), (2, 3, 13, 13), 1.0),
+    "edsr": ("EDSRNet", (3, 64, 16), (2, 3, 8, 8), 0.5),
+    "lapsrn": ("LapSRNNet", (3, 64, 10), (1, 3, 8, 8), 1.0),
+    "srgan_g": ("SRGANGenerator", (3, 64, 16), (2, 3, 8, 8), 0.7),
+    "srgan_d": ("SRGANDiscriminator", (3, 64, 32), (2, 3, 32, 32), 1.0),
+}
+TOL_FWD = 1e-4   # contract: 1e-3
+TOL_GRAD = 5e-4  # contract: 1e-3
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_net_forward_backward(gpu, nets_golden, name):
+    import pytorch_super_resolution_model_collection_amd as pkg
+    cls, args, ishape, gain = CASES[name]
+    net = getattr(pkg, cls)(*args)
+    fill.fill_module(net, 1234, gain)
+    net.to(gpu).train()
+    x = fill.rand(ishape, 4321).to(gpu).requires_grad_(True)
+    out = net(x)
+    outs = out if isinstance(out, (tuple, list)) else (out,)
+    for i, o in enumerate(outs):
+        assert rel_err(o, nets_golden["%s.out%d" % (name, i)]) < TOL_FWD, "forward output %d" % i
+    grads = [fill.randn(tuple(o.shape), 77 + i).to(gpu) / o.numel() for i, o in enumerate(outs)]
+    torch.autograd.backward(list(outs), grads)
+    assert rel_err(x.grad, nets_golden[name + ".dx"]) < TOL_GRAD
+    names = [str(n) for n in nets_golden[name + ".grad_names"]]
+    sums = nets_golden[name + ".grad_sums"]
+    params = dict(net.named_parameters())
+    for n, (s, l2) in zip(names, sums):
+        g = params[n].grad.detach().double().cpu()
+        assert abs(float(g.pow(2).sum().sqrt()) - l2) <= TOL_GRAD * max(l2, 1e-12), "grad L2 of " + n
+        assert abs(float(g.sum()) - s) <= 10 * TOL_GRAD * max(l2, 1e-12), "grad sum of " + n
+    assert rel_err(params[names[0]].grad, nets_golden[name + ".grad_first"]) < TOL_GRAD
+    assert rel_err(params[names[-1]].grad, nets_golden[name + ".grad_last"]) < TOL_GRAD
+    if name.startswith("srgan"):
+        sd = net.state_dict()
+        for n, (s, l2) in zip([str(k) for k in nets_golden[name + ".bn_names"]], nets_golden[name + ".bn_sums"]):
+            t = sd[n].double().cpu()
+            assert abs(float(t.pow(2).sum().sqrt()) - l2) <= 1e-4 * max(l2, 1e-12), "running stat " + n
+        net.eval()
+        with torch.no_grad():
+            assert rel_err(net(x.detach()), nets_golden[name + ".eval_out"]) < TOL_FWD
+
+
+@pytest.mark.parametrize("name", ["espcn", "vdsr", "edsr", "srgan_g", "lapsrn", "fsrcnn"])
+def test_net_inference_matches_training_forward(gpu, name):
+    """The fused no-grad path (cached packed weights, fused PReLU/residual epilogues) must equal
+    the autograd path's forward."""
+    import pytorch_super_resolution_model_collection_amd as pkg
+    cls, args, ishape, gain = CASES[name]
+    net = getattr(pkg, cls)(*args)
+    fill.fill_module(net, 1234, gain)
+    net.to(gpu).eval()
+    x = fill.rand(ishape, 99).to(gpu)
+    a = net(x.clone().requires_grad_(True))
+    with torch.no_grad():
+        b = net(x)
+    a = a if isinstance(a, (tuple, list)) else (a,)
+    b = b if isinstance(b, (tuple, list)) else (b,)
+    for u, v in zip(a, b):
+        assert rel_err(u, v) < 1e-6
+
+
+def test_state_dict_roundtrip_with_oracle(gpu):
+    """Checkpoints are interchangeable with the reference layout: oracle -> product -> oracle."""
+    import pytorch_super_resolution_model_collection_amd as pkg
+    ora = fill.fill_module(R.EDSR(3, 64, 16), 7, 0.5)
+    net = pkg.EDSRNet(3, 64, 16)
+    net.load_state_dict(ora.state_dict())
+    net.to(gpu)
+    back = R.EDSR(3, 64, 16)
+    back.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    x = fill.rand((1, 3, 9, 7), 3)
+    with torch.no_grad():
+        assert torch.equal(back(x), ora(x))
+        assert rel_err(net(x.to(gpu)), ora(x)) < TOL_FWD

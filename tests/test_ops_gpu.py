@@ -1,0 +1,215 @@
+"""Op-level parity on the MI355X, through the C ABI: every kernel family against the committed
+golden vectors (generated from the torch.nn classes the reference instantiates).  Tolerance: the
+contract is 1e-3 relative (BASELINE.json north_star); the exact-fp32 kernels are held to 2e-5."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import TOL_TIGHT, rel_err
+from oracle import fill
+from oracle.kat_table import CONV_KATS, conv_case_inputs
+
+pytestmark = pytest.mark.gpu
+
+ALGOS = {"auto": 0, "generic": 1}
+ACTS = {None: 0, "relu": 1, "lrelu": 3}
+
+
+def _pkg():
+    import pytorch_super_resolution_model_collection_amd as pkg
+    return pkg
+
+
+@pytest.mark.parametrize("algo", ["auto", "generic"])
+@pytest.mark.parametrize("idx", range(len(CONV_KATS)), ids=[c[0] for c in CONV_KATS])
+def test_conv_forward_backward(gpu, ops_kat, idx, algo):
+    pkg = _pkg()
+    ops = pkg.ops
+    tag, cin, cout, k, s, p, tr, op, H, W, N, act = CONV_KATS[idx]
+    x, w, b, g = conv_case_inputs(idx)
+    xg = x.to(gpu).requires_grad_(True)
+    wg = w.to(gpu).requires_grad_(True)
+    bg = b.to(gpu).requires_grad_(True)
+    cfg = ops.ConvCfg(s, p, bool(tr), op, ACTS[act], 0.2 if act == "lrelu" else 0.0, 0, ALGOS[algo])
+    y = ops.conv2d(xg, wg, bg, None, cfg)
+    assert tuple(y.shape) == tuple(g.shape)
+    assert rel_err(y, ops_kat["conv.%s.y" % tag]) < TOL_TIGHT
+    y.backward(g.to(gpu))
+    assert rel_err(xg.grad, ops_kat["conv.%s.dx" % tag]) < TOL_TIGHT
+    assert rel_err(wg.grad, ops_kat["conv.%s.dw" % tag]) < TOL_TIGHT
+    assert rel_err(bg.grad, ops_kat["conv.%s.db" % tag]) < TOL_TIGHT
+
+
+@pytest.mark.parametrize("idx", [0, 3, 9, 10], ids=lambda i: CONV_KATS[i][0])
+def test_conv_infer_fused_epilogue(gpu, idx):
+    """Fully fused no-grad path: bias + PReLU + residual in one launch vs torch CPU."""
+    pkg = _pkg()
+    ops = pkg.ops
+    tag, cin, cout, k, s, p, tr, op, H, W, N, act = CONV_KATS[idx]
+    x, w, b, g = conv_case_inputs(idx)
+    slope = torch.tensor([0.3])
+    res = fill.randn(tuple(g.shape), 555)
+    ref = torch.nn.functional.prelu(torch.nn.functional.conv2d(x, w, b, s, p), slope) + res
+    cfg = ops.ConvCfg(s, p, False, 0, pkg._lib.ACT_PRELU)
+    with torch.no_grad():
+        y = ops.conv2d_infer(x.to(gpu), w.to(gpu), b.to(gpu), res.to(gpu), cfg, slope.to(gpu))
+    assert rel_err(y, ref) < TOL_TIGHT
+
+
+@pytest.mark.parametrize("r,C", [(2, 64), (4, 3), (3, 2)])
+def test_conv_fused_pixel_shuffle(gpu, r, C):
+    """conv + PixelShuffle store (PSBlock, base_networks.py:179-181), forward and backward."""
+    pkg = _pkg()
+    ops = pkg.ops
+    cin = 16
+    x, w = fill.randn((2, cin, 7, 9), 1), fill.randn((C * r * r, cin, 3, 3), 2, 0.1)
+    b = fill.randn((C * r * r,), 3, 0.1)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.pixel_shuffle(torch.nn.functional.conv2d(xr, wr, br, 1, 1), r)
+    g = fill.randn(tuple(ref.shape), 4)
+    ref.backward(g)
+    xg, wg, bg = (t.to(gpu).requires_grad_(True) for t in (x, w, b))
+    y = ops.conv2d(xg, wg, bg, None, ops.ConvCfg(1, 1, False, 0, 0, 0.0, r))
+    assert rel_err(y, ref) < TOL_TIGHT
+    y.backward(g.to(gpu))
+    assert rel_err(xg.grad, xr.grad) < TOL_TIGHT
+    assert rel_err(wg.grad, wr.grad) < TOL_TIGHT
+    assert rel_err(bg.grad, br.grad) < TOL_TIGHT
+
+
+@pytest.mark.parametrize("r", [2, 4, 3])
+def test_pixel_shuffle(gpu, ops_kat, r):
+    pkg = _pkg()
+    x = torch.from_numpy(ops_kat["ps.r%d.x" % r]).to(gpu).requires_grad_(True)
+    y = pkg.ops.pixel_shuffle(x, r)
+    assert rel_err(y, ops_kat["ps.r%d.y" % r]) == 0.0  # pure permutation: bit-exact
+    y.backward(torch.from_numpy(ops_kat["ps.r%d.g" % r]).to(gpu))
+    assert rel_err(x.grad, ops_kat["ps.r%d.dx" % r]) == 0.0
+
+
+@pytest.mark.parametrize("name", ["relu", "prelu", "prelu_c", "lrelu", "tanh", "sigmoid"])
+def test_activation(gpu, ops_kat, name):
+    pkg = _pkg()
+    kinds = {"relu": 1, "prelu": 2, "prelu_c": 2, "lrelu": 3, "tanh": 4, "sigmoid": 5}
+    x = torch.from_numpy(ops_kat["act.%s.x" % name]).to(gpu).requires_grad_(True)
+    pw = None
+    if name.startswith("prelu"):
+        pw = torch.from_numpy(ops_kat["act.%s.w" % name]).to(gpu).requires_grad_(True)
+    y = pkg.ops.activation(x, kinds[name], 0.2, pw)
+    assert rel_err(y, ops_kat["act.%s.y" % name]) < 1e-6
+    y.backward(torch.from_numpy(ops_kat["act.%s.g" % name]).to(gpu))
+    assert rel_err(x.grad, ops_kat["act.%s.dx" % name]) < 1e-6
+    if pw is not None:
+        assert rel_err(pw.grad, ops_kat["act.%s.dw" % name]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["mse", "l1", "charbonnier", "bce"])
+@pytest.mark.parametrize("target_layout", ["nchw", "nhwc"])
+def test_losses(gpu, ops_kat, name, target_layout):
+    pkg = _pkg()
+    fn = {"mse": pkg.ops.mse_loss, "l1": pkg.ops.l1_loss, "charbonnier": pkg.ops.charbonnier_loss,
+          "bce": pkg.ops.bce_loss}[name]
+    p = torch.from_numpy(ops_kat["loss.pred"]).to(gpu).requires_grad_(True)
+    t = torch.from_numpy(ops_kat["loss.target"]).to(gpu)
+    if target_layout == "nhwc":
+        t = pkg.ops.to_nhwc(t)
+    l = fn(p, t)
+    assert rel_err(l, ops_kat["loss.%s.value" % name]) < 1e-6
+    l.backward()
+    assert rel_err(p.grad, ops_kat["loss.%s.dpred" % name]) < 1e-6
+
+
+def test_add_and_fork(gpu):
+    pkg = _pkg()
+    a, b = fill.randn((2, 5, 6, 7), 1), fill.randn((2, 5, 6, 7), 2)
+    ag, bg = a.to(gpu).requires_grad_(True), b.to(gpu).requires_grad_(True)
+    y = pkg.ops.add(ag, bg)
+    assert rel_err(y, a + b) == 0.0
+    u, v = pkg.ops.fork(ag)
+    z = pkg.ops.add(pkg.ops.activation(u, 1), pkg.ops.activation(v, 4))
+    z.backward(torch.ones_like(z))
+    ar = a.clone().requires_grad_(True)
+    (torch.relu(ar) + torch.tanh(ar)).sum().backward()
+    assert rel_err(ag.grad, ar.grad) < 1e-6
+
+
+def test_batchnorm_shared_double_call(gpu, ops_kat):
+    """One BN applied twice in a forward (ResnetBlock's shared bn, base_networks.py:117,137,145):
+    outputs, gradients and the twice-updated running statistics."""
+    pkg = _pkg()
+    bn = pkg.layers.BatchNorm2d(16)
+    bn.weight.data.copy_(torch.from_numpy(ops_kat["bn.gamma"]))
+    bn.bias.data.copy_(torch.from_numpy(ops_kat["bn.beta"]))
+    bn.to(gpu).train()
+    x = torch.from_numpy(ops_kat["bn.x"]).to(gpu).requires_grad_(True)
+    y1 = bn(x)
+    y2 = bn(_affine(pkg, y1))
+    assert rel_err(y1, ops_kat["bn.y1"]) < TOL_TIGHT
+    assert rel_err(y2, ops_kat["bn.y2"]) < TOL_TIGHT
+    y2.backward(torch.from_numpy(ops_kat["bn.g"]).to(gpu))
+    assert rel_err(x.grad, ops_kat["bn.dx"]) < 1e-4
+    assert rel_err(bn.weight.grad, ops_kat["bn.dgamma"]) < 1e-4
+    assert rel_err(bn.bias.grad, ops_kat["bn.dbeta"]) < 1e-4
+    assert rel_err(bn.running_mean, ops_kat["bn.running_mean"]) < 1e-5
+    assert rel_err(bn.running_var, ops_kat["bn.running_var"]) < 1e-5
+    assert int(bn.num_batches_tracked) == 2
+    bn.eval()
+    with torch.no_grad():
+        assert rel_err(bn(x), ops_kat["bn.eval_y"]) < TOL_TIGHT
+
+
+class _Affine(torch.autograd.Function):
+    """y = 0.5*x + 0.1 built from srk_axpby (test helper; keeps the graph on our kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, pkg):
+        ctx.pkg = pkg
+        return pkg.ops._axpby(x, torch.full_like(x, 0.1), 0.5, 1.0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.pkg.ops._axpby(g, g, 0.5, 0.0), None
+
+
+def _affine(pkg, x):
+    return _Affine.apply(x, pkg)
+
+
+def test_linear(gpu, ops_kat):
+    pkg = _pkg()
+    x = torch.from_numpy(ops_kat["fc.x"]).to(gpu).requires_grad_(True)
+    w = torch.from_numpy(ops_kat["fc.w"]).to(gpu).requires_grad_(True)
+    b = torch.from_numpy(ops_kat["fc.b"]).to(gpu).requires_grad_(True)
+    y = pkg.ops.linear(x, w, b, 3, 0.2)
+    assert rel_err(y, ops_kat["fc.y"]) < TOL_TIGHT
+    y.backward(torch.from_numpy(ops_kat["fc.g"]).to(gpu))
+    assert rel_err(x.grad, ops_kat["fc.dx"]) < TOL_TIGHT
+    assert rel_err(w.grad, ops_kat["fc.dw"]) < TOL_TIGHT
+    assert rel_err(b.grad, ops_kat["fc.db"]) < TOL_TIGHT
+
+
+def test_layout_roundtrip_and_ragged(gpu):
+    """NCHW<->NHWC copies at ragged sizes (non multiples of the 32x32 transpose tile)."""
+    pkg = _pkg()
+    for shape in ((1, 1, 1, 1), (2, 3, 5, 7), (3, 33, 9, 31), (1, 64, 41, 41)):
+        x = fill.randn(shape, 11).to(gpu)
+        y = pkg.ops.to_nhwc(x)
+        assert torch.equal(y.cpu(), x.cpu())
+        assert y.stride() == x.contiguous(memory_format=torch.channels_last).stride() or shape[1] == 1 or shape[2] * shape[3] == 1
+        z = pkg.ops.to_nchw(y)
+        assert z.is_contiguous() and torch.equal(z.cpu(), x.cpu())
+
+
+def test_errors_are_loud(gpu):
+    pkg = _pkg()
+    with pytest.raises(RuntimeError):
+        pkg.ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3))  # CPU tensors: no fallback
+    with pytest.raises(RuntimeError):
+        pkg.ops.conv2d(torch.zeros(1, 3, 2, 2, device=gpu), torch.zeros(4, 3, 5, 5, device=gpu))  # empty output
+    with pytest.raises(RuntimeError):
+        pkg.ops.pixel_shuffle(torch.zeros(1, 6, 2, 2, device=gpu), 2)
+    lib = pkg._lib.load()
+    assert lib.srk_axpby(None, None, None, 0, 1.0, 1.0, None) == -1
+    assert b"null" in lib.srk_last_error_string()
