@@ -1,12 +1,486 @@
-// placeholder until the MFMA weight-gradient kernel lands (see below in this round)
+// Weight gradient of Conv2d / ConvTranspose2d on the CDNA4 matrix cores (exact fp32,
+// v_mfma_f32_16x16x4_f32).
+//
+//   dW[tap][ci][co] = sum over pixels q of  X[.][ci] * dY[.][co]
+//     Conv2d:          X at q*s - p + tap (shifted, "big"),  dY at q (anchor, "small")
+//     ConvTranspose2d: X at q (anchor),  dY at q*s - p + tap (shifted)
+//
+// GEMM view per tap: M = ci, N = co, K = pixels (hundreds of thousands) -> split-K:
+//   * persistent blocks (2 per CU) walk spatial tiles of <=64 anchor pixels; for each tile the
+//     anchor tile and the shifted halo are staged in LDS once (coalesced 16-byte reads, zero
+//     fill, ReLU/LeakyReLU gradient mask applied to dY on the fly);
+//   * wave w owns the 16 input channels [16w,16w+16) of the block's 64-channel chunk and all
+//     (<=9 taps) x (<=4 co tiles) 16x16 accumulators of the current tap group (<=144 VGPRs), so a
+//     4-pixel K step costs <=13 ds_read_b32 for 36 MFMAs;
+//   * accumulators live in registers across ALL tiles of the block; each block writes one
+//     partial slab, a second kernel reduces the slabs in a fixed order (deterministic) into the
+//     torch layout with beta-accumulate.
+// Cin <= 4 (first layers) uses the flattened variant: M = (tap, ci) dense, so a 3x3x3 filter is
+// 2 MFMA row tiles instead of 9 mostly-empty ones.
 #include "srk_common.h"
+#include "conv_problem.h"
+
 namespace srk {
-bool conv_wgrad_mfma_supported(const srk_conv_desc& d) { (void)d; return false; }
-size_t conv_wgrad_mfma_ws(const srk_conv_desc& d) { (void)d; return 0; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WG_TP = 64;       // anchor pixels per tile
+constexpr int WG_TAPS = 9;      // taps per register pass
+constexpr int WG_MAXBLOCKS = 512;
+
+struct WgradParams {
+  const float* x;
+  const float* dy;
+  const float* mask_y;
+  float mask_slope;
+  float* ws;  // [G][T][Cin][Cout]
+  int N, Cin, Cout;
+  int XH, XW, YH, YW;  // spatial dims of x and dy
+  int KH, KW, stride, pad, transposed;
+  int AH, AW;          // anchor spatial dims (dy for conv, x for transposed)
+  int BH, BW;          // shifted spatial dims
+  int TH, TW, tiles_y, tiles_x, HH, HW;
+  int ntiles, G;
+  int PSX, PSY;        // LDS pixel strides (floats) of the x / dy regions
+  int xs_floats;       // size of the x region (dy region follows)
+  int vec_x, vec_y;
+};
+
+__device__ __forceinline__ f32x4 mfma16w(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Stage rows [y0,y0+ny) x cols [x0,x0+nx) x channels [cb,cb+cc) of an NHWC tensor into
+// lds[pixel][ps] (channels zero-padded to ccp, OOB pixels zero). `rows_total` >= ny*nx rows are
+// written (extra rows zero) so K can be padded to a multiple of 4.
+__device__ __forceinline__ void stage_region(const float* __restrict__ src, const float* __restrict__ mask,
+                                             float mslope, float* lds, int ps, int n, int TH_, int TW_, int C, int y0,
+                                             int x0, int ny, int nx, int rows_total, int cb, int cc, int ccp, int vec) {
+  const int nvec = ccp >> 2;
+  const int items = rows_total * nvec;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int hp = it / nvec, q = it - hp * nvec;
+    const int hy = hp / nx, hx = hp - hy * nx;
+    const int iy = y0 + hy, ix = x0 + hx;
+    const int ch = q * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (hy < ny && iy >= 0 && iy < TH_ && ix >= 0 && ix < TW_ && ch < cc) {
+      const size_t off = (((size_t)n * TH_ + iy) * TW_ + ix) * C + cb + ch;
+      if (vec && ch + 3 < cc) {
+        v = *reinterpret_cast<const f32x4*>(src + off);
+        if (mask) {
+          const f32x4 m = *reinterpret_cast<const f32x4*>(mask + off);
+          v.x = m.x > 0.f ? v.x : v.x * mslope;
+          v.y = m.y > 0.f ? v.y : v.y * mslope;
+          v.z = m.z > 0.f ? v.z : v.z * mslope;
+          v.w = m.w > 0.f ? v.w : v.w * mslope;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (ch + e < cc) {
+            float t = src[off + e];
+            if (mask) t = mask[off + e] > 0.f ? t : t * mslope;
+            v[e] = t;
+          }
+      }
+    }
+    *reinterpret_cast<f32x4*>(lds + (size_t)hp * ps + ch) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// W1: general channel counts.  grid = (G, ci chunks of 64, co chunks of NTC*16).
+// ---------------------------------------------------------------------------------------------
+template <int NTC, bool TRANS>
+__global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WgradParams P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;
+  float* ys = smem + P.xs_floats;
+  __shared__ int hoff[WG_TP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int cib = blockIdx.y * 64;
+  const int cob = blockIdx.z * (NTC * 16);
+  const int cic = (P.Cin - cib) < 64 ? (P.Cin - cib) : 64;
+  const int cicp = (cic + 15) & ~15;
+  const int coc = (P.Cout - cob) < NTC * 16 ? (P.Cout - cob) : NTC * 16;
+  const int cocp = NTC * 16;
+  const int T = P.KH * P.KW;
+  const int npx = P.TH * P.TW;
+  const int npx4 = (npx + 3) & ~3;
+  const bool wave_live = wave * 16 < cicp;
+
+  for (int p = tid; p < WG_TP; p += 256) {
+    int h = 0;
+    if (p < npx) {
+      const int r = p / P.TW, c = p - r * P.TW;
+      h = (r * P.stride) * P.HW + c * P.stride;
+    }
+    hoff[p] = h;
+  }
+
+  for (int t0 = 0; t0 < T; t0 += WG_TAPS) {
+    const int tg = (T - t0) < WG_TAPS ? (T - t0) : WG_TAPS;
+    int toff[WG_TAPS];
+#pragma unroll
+    for (int t = 0; t < WG_TAPS; ++t) {
+      const int tt = (t < tg) ? (t0 + t) : t0;
+      const int u = tt / P.KW, v = tt - u * P.KW;
+      toff[t] = (u * P.HW + v) * (TRANS ? P.PSY : P.PSX);
+    }
+    f32x4 acc[WG_TAPS][NTC];
+#pragma unroll
+    for (int t = 0; t < WG_TAPS; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < P.ntiles; tile += P.G) {
+      int b = tile;
+      const int txi = b % P.tiles_x;
+      b /= P.tiles_x;
+      const int tyi = b % P.tiles_y;
+      const int n = b / P.tiles_y;
+      const int r0 = tyi * P.TH, c0 = txi * P.TW;
+      // anchor rows actually inside the tensor for this tile (ragged last tiles)
+      __syncthreads();  // previous tile fully consumed (and hoff visible on the first pass)
+      const int by0 = r0 * P.stride - P.pad, bx0 = c0 * P.stride - P.pad;
+      if (!TRANS) {
+        stage_region(P.x, nullptr, 0.f, xs, P.PSX, n, P.XH, P.XW, P.Cin, by0, bx0, P.HH, P.HW, P.HH * P.HW, cib, cic,
+                     cicp, P.vec_x);
+        stage_region(P.dy, P.mask_y, P.mask_slope, ys, P.PSY, n, P.YH, P.YW, P.Cout, r0, c0, P.TH, P.TW, npx4, cob,
+                     coc, cocp, P.vec_y);
+      } else {
+        stage_region(P.x, nullptr, 0.f, xs, P.PSX, n, P.XH, P.XW, P.Cin, r0, c0, P.TH, P.TW, npx4, cib, cic, cicp,
+                     P.vec_x);
+        stage_region(P.dy, P.mask_y, P.mask_slope, ys, P.PSY, n, P.YH, P.YW, P.Cout, by0, bx0, P.HH, P.HW,
+                     P.HH * P.HW, cob, coc, cocp, P.vec_y);
+      }
+      __syncthreads();
+      if (wave_live) {
+        for (int k4 = 0; k4 < npx4; k4 += 4) {
+          const int p = k4 + kq;
+          const int ho = hoff[p];
+          if (!TRANS) {
+            const float* ap = xs + ho * P.PSX + wave * 16 + i;
+            const float* bp = ys + p * P.PSY + i;
+            float bq[NTC];
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt) bq[nt] = bp[nt * 16];
+#pragma unroll
+            for (int t = 0; t < WG_TAPS; ++t) {
+              if (t < tg) {
+                const float a = ap[toff[t]];
+#pragma unroll
+                for (int nt = 0; nt < NTC; ++nt) acc[t][nt] = mfma16w(a, bq[nt], acc[t][nt]);
+              }
+            }
+          } else {
+            const float a = xs[p * P.PSX + wave * 16 + i];
+            const float* bp = ys + ho * P.PSY + i;
+#pragma unroll
+            for (int t = 0; t < WG_TAPS; ++t) {
+              if (t < tg) {
+#pragma unroll
+                for (int nt = 0; nt < NTC; ++nt) acc[t][nt] = mfma16w(a, bp[toff[t] + nt * 16], acc[t][nt]);
+              }
+            }
+          }
+        }
+      }
+    }
+    // partial slab: ws[g][t][ci][co]; C/D layout col = lane&15 (co), row = (lane>>4)*4 + reg (ci)
+    if (wave_live) {
+      float* slab = P.ws + (size_t)blockIdx.x * T * P.Cin * P.Cout;
+#pragma unroll
+      for (int t = 0; t < WG_TAPS; ++t) {
+        if (t < tg) {
+#pragma unroll
+          for (int nt = 0; nt < NTC; ++nt) {
+            const int co = cob + nt * 16 + i;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+              const int ci = cib + wave * 16 + kq * 4 + reg;
+              if (ci < P.Cin && co < P.Cout) slab[((size_t)(t0 + t) * P.Cin + ci) * P.Cout + co] = acc[t][nt][reg];
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// W2: Cin <= 4 (Conv2d only).  M = (tap, ci) flattened dense: m = tap*Cin + ci, MT row tiles.
+// Wave w owns output-channel tile w of a 64-channel chunk and all MT row tiles.
+// LDS: x halo [pixel][4], dy tile [pixel][PSY].
+// ---------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256, 2) void k_wgrad_mfma_smallcin(WgradParams P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;
+  float* ys = smem + P.xs_floats;
+  __shared__ int hoff[WG_TP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int cob = blockIdx.z * 64;
+  const int coc = (P.Cout - cob) < 64 ? (P.Cout - cob) : 64;
+  const int T = P.KH * P.KW;
+  const int M = T * P.Cin;
+  const int npx = P.TH * P.TW;
+  const int npx4 = (npx + 3) & ~3;
+  const bool wave_live = wave * 16 < coc;
+
+  for (int p = tid; p < WG_TP; p += 256) {
+    int h = 0;
+    if (p < npx) {
+      const int r = p / P.TW, c = p - r * P.TW;
+      h = ((r * P.stride) * P.HW + c * P.stride) * 4;
+    }
+    hoff[p] = h;
+  }
+  // per-lane gather offset of row m = mt*16 + i inside the halo: tap shift * 4 + ci
+  int moff[MT];
+  bool mval[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mt * 16 + i;
+    mval[mt] = m < M;
+    const int mm = mval[mt] ? m : 0;
+    const int t = mm / P.Cin, ci = mm - t * P.Cin;
+    const int u = t / P.KW, v = t - u * P.KW;
+    moff[mt] = (u * P.HW + v) * 4 + ci;
+  }
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < P.ntiles; tile += P.G) {
+    int b = tile;
+    const int txi = b % P.tiles_x;
+    b /= P.tiles_x;
+    const int tyi = b % P.tiles_y;
+    const int n = b / P.tiles_y;
+    const int r0 = tyi * P.TH, c0 = txi * P.TW;
+    __syncthreads();
+    stage_region(P.x, nullptr, 0.f, xs, 4, n, P.XH, P.XW, P.Cin, r0 * P.stride - P.pad, c0 * P.stride - P.pad, P.HH,
+                 P.HW, P.HH * P.HW, 0, P.Cin, 4, P.vec_x);
+    stage_region(P.dy, P.mask_y, P.mask_slope, ys, P.PSY, n, P.YH, P.YW, P.Cout, r0, c0, P.TH, P.TW, npx4, cob, coc,
+                 64, P.vec_y);
+    __syncthreads();
+    if (wave_live) {
+      for (int k4 = 0; k4 < npx4; k4 += 4) {
+        const int p = k4 + kq;
+        const float bv = ys[p * P.PSY + wave * 16 + i];
+        const float* ap = xs + hoff[p];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float a = mval[mt] ? ap[moff[mt]] : 0.f;
+          acc[mt] = mfma16w(a, bv, acc[mt]);
+        }
+      }
+    }
+  }
+  if (wave_live) {
+    float* slab = P.ws + (size_t)blockIdx.x * T * P.Cin * P.Cout;
+    const int co = cob + wave * 16 + i;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int m = mt * 16 + kq * 4 + reg;  // = tap*Cin + ci -> ws index (tap*Cin + ci)*Cout + co
+        if (m < M && co < P.Cout) slab[(size_t)m * P.Cout + co] = acc[mt][reg];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Deterministic slab reduction + layout change:  dw(torch layout) = beta*dw + sum_g ws[g][t][ci][co]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw, int G,
+                                                      int Cout, int Cin, int KH, int KW, int transposed, float beta) {
+  const int elems = KH * KW * Cin * Cout;
+  const int e = blockIdx.x * 256 + threadIdx.x;  // slab index (coalesced slab reads)
+  if (e >= elems) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int g = 0;
+  for (; g + 3 < G; g += 4) {
+    s0 += ws[(size_t)g * elems + e];
+    s1 += ws[(size_t)(g + 1) * elems + e];
+    s2 += ws[(size_t)(g + 2) * elems + e];
+    s3 += ws[(size_t)(g + 3) * elems + e];
+  }
+  for (; g < G; ++g) s0 += ws[(size_t)g * elems + e];
+  const float v = (s0 + s1) + (s2 + s3);
+  const int co = e % Cout;
+  const int ci = (e / Cout) % Cin;
+  const int tap = e / (Cout * Cin);
+  const int kh = tap / KW, kw = tap - kh * KW;
+  const size_t o = transposed ? ((((size_t)ci * Cout + co) * KH + kh) * KW + kw)
+                              : ((((size_t)co * Cin + ci) * KH + kh) * KW + kw);
+  dw[o] = beta != 0.f ? beta * dw[o] + v : v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host
+// ---------------------------------------------------------------------------------------------
+static constexpr int kWgLdsBudget = 78 * 1024;
+
+struct WgPlan {
+  bool ok;
+  bool smallcin;
+  int NTC;
+  int TH, TW, tiles_y, tiles_x, HH, HW;
+  int PSX, PSY, xs_floats;
+  size_t lds;
+  int G, ntiles;
+};
+
+static WgPlan plan(const srk_conv_desc& d) {
+  WgPlan pl{};
+  pl.ok = false;
+  const int T = d.KH * d.KW;
+  if (T > 32 * 32 || d.Cout < 1) return pl;
+  pl.smallcin = (d.Cin <= 4) && !d.transposed && (T * d.Cin <= 256);
+  if (!pl.smallcin && d.Cin <= 4) return pl;  // transposed / huge kernels with tiny Cin: generic kernel
+  const int AH = d.transposed ? d.H : d.OH, AW = d.transposed ? d.W : d.OW;
+  int ntc = (d.Cout + 15) / 16;
+  if (ntc > 4) ntc = 4;
+  pl.NTC = pl.smallcin ? 4 : ntc;
+  // LDS pixel strides: lanes of one half-wave (kq = 0,1) must land on disjoint banks -> stride = 16 (mod 32)
+  const int cip = pl.smallcin ? 4 : (d.Cin >= 64 ? 64 : ((d.Cin + 15) & ~15));
+  const int psx_full = pl.smallcin ? 4 : (((cip % 32) == 16) ? cip : cip + 16);
+  const int cop = pl.NTC * 16;
+  const int psy_full = ((cop % 32) == 16) ? cop : cop + 16;
+  // conv: x is the halo, dy the tile; transposed: the other way round
+  const int ps_halo = d.transposed ? psy_full : psx_full;
+  const int ps_tile = d.transposed ? psx_full : psy_full;
+  bool found = false;
+  long best_tiles = 0, best_halo = 0;
+  for (int TW = 1; TW <= (AW < WG_TP ? AW : WG_TP); ++TW) {
+    int TH = WG_TP / TW;
+    if (TH > AH) TH = AH;
+    for (; TH >= 1; --TH) {
+      const int HH = (TH - 1) * d.stride + d.KH, HW = (TW - 1) * d.stride + d.KW;
+      const int tile_rows = (TH * TW + 3) & ~3;
+      const long floats = (long)HH * HW * ps_halo + (long)tile_rows * ps_tile;
+      if (floats * 4 <= kWgLdsBudget) {
+        const long tiles = (long)cdiv(AH, TH) * cdiv(AW, TW);
+        const long halo = (long)HH * HW * tiles;
+        if (!found || tiles < best_tiles || (tiles == best_tiles && halo < best_halo)) {
+          found = true;
+          best_tiles = tiles;
+          best_halo = halo;
+          pl.TH = TH; pl.TW = TW; pl.tiles_y = cdiv(AH, TH); pl.tiles_x = cdiv(AW, TW); pl.HH = HH; pl.HW = HW;
+        }
+        break;
+      }
+    }
+  }
+  if (!found) return pl;
+  pl.PSX = psx_full;
+  pl.PSY = psy_full;
+  const int tile_rows = (pl.TH * pl.TW + 3) & ~3;
+  pl.xs_floats = d.transposed ? tile_rows * psx_full : pl.HH * pl.HW * psx_full;
+  const int ys_floats = d.transposed ? pl.HH * pl.HW * psy_full : tile_rows * psy_full;
+  pl.lds = ((size_t)pl.xs_floats + ys_floats) * 4;
+  const long nt = (long)d.N * pl.tiles_y * pl.tiles_x;
+  if (nt > (1L << 30)) return pl;
+  pl.ntiles = (int)nt;
+  pl.G = pl.ntiles < WG_MAXBLOCKS ? pl.ntiles : WG_MAXBLOCKS;
+  pl.ok = true;
+  return pl;
+}
+
+bool conv_wgrad_mfma_supported(const srk_conv_desc& d) { return plan(d).ok; }
+
+size_t conv_wgrad_mfma_ws(const srk_conv_desc& d) {
+  WgPlan pl = plan(d);
+  if (!pl.ok) return 0;
+  return (size_t)pl.G * d.KH * d.KW * d.Cin * d.Cout * sizeof(float);
+}
+
+template <typename K>
+static void wg_set_lds(K kern, int& cur, size_t lds) {
+  if ((int)lds > cur) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    cur = (int)lds;
+  }
+}
+
+template <int NTC, bool TRANS>
+static void launch_w1(const WgradParams& P, dim3 grid, size_t lds, hipStream_t s) {
+  static int cur = 0;
+  wg_set_lds(&k_wgrad_mfma<NTC, TRANS>, cur, lds);
+  hipLaunchKernelGGL((k_wgrad_mfma<NTC, TRANS>), grid, dim3(256), lds, s, P);
+}
+template <int MT>
+static void launch_w2(const WgradParams& P, dim3 grid, size_t lds, hipStream_t s) {
+  static int cur = 0;
+  wg_set_lds(&k_wgrad_mfma_smallcin<MT>, cur, lds);
+  hipLaunchKernelGGL((k_wgrad_mfma_smallcin<MT>), grid, dim3(256), lds, s, P);
+}
+
 int conv_wgrad_mfma(const srk_conv_desc& d, const float* x, const float* dy, const srk_bwd_mask* mask, float* dw,
                     float* db, float beta, void* ws, size_t ws_bytes, hipStream_t s) {
-  (void)d; (void)x; (void)dy; (void)mask; (void)dw; (void)db; (void)beta; (void)ws; (void)ws_bytes; (void)s;
-  set_error("conv_wgrad_mfma: not built");
-  return SRK_ERR_UNSUPPORTED;
+  WgPlan pl = plan(d);
+  if (!pl.ok) {
+    set_error("conv_wgrad_mfma: shape not covered");
+    return SRK_ERR_UNSUPPORTED;
+  }
+  const size_t need = (size_t)pl.G * d.KH * d.KW * d.Cin * d.Cout * sizeof(float);
+  if (!ws || ws_bytes < need) {
+    set_error("conv_wgrad_mfma: workspace %zu < %zu", ws_bytes, need);
+    return SRK_ERR_WORKSPACE;
+  }
+  WgradParams P{};
+  P.x = x; P.dy = dy; P.mask_y = mask ? mask->y : nullptr; P.mask_slope = mask ? mask->slope : 0.f;
+  P.ws = (float*)ws;
+  P.N = d.N; P.Cin = d.Cin; P.Cout = d.Cout;
+  P.XH = d.H; P.XW = d.W; P.YH = d.OH; P.YW = d.OW;
+  P.KH = d.KH; P.KW = d.KW; P.stride = d.stride; P.pad = d.pad; P.transposed = d.transposed;
+  P.AH = d.transposed ? d.H : d.OH; P.AW = d.transposed ? d.W : d.OW;
+  P.BH = d.transposed ? d.OH : d.H; P.BW = d.transposed ? d.OW : d.W;
+  P.TH = pl.TH; P.TW = pl.TW; P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x; P.HH = pl.HH; P.HW = pl.HW;
+  P.ntiles = pl.ntiles; P.G = pl.G; P.PSX = pl.PSX; P.PSY = pl.PSY; P.xs_floats = pl.xs_floats;
+  P.vec_x = (d.Cin % 4 == 0) && ((uintptr_t)x % 16 == 0);
+  P.vec_y = (d.Cout % 4 == 0) && ((uintptr_t)dy % 16 == 0) && (!P.mask_y || (uintptr_t)P.mask_y % 16 == 0);
+  // every (t, ci, co) of every slab is written exactly once by exactly one block => no memset needed
+  if (pl.smallcin) {
+    const int MT = (d.KH * d.KW * d.Cin + 15) / 16;
+    dim3 grid(pl.G, 1, cdiv(d.Cout, 64));
+    if (MT <= 2) launch_w2<2>(P, grid, pl.lds, s);
+    else if (MT <= 5) launch_w2<5>(P, grid, pl.lds, s);
+    else launch_w2<16>(P, grid, pl.lds, s);
+  } else {
+    dim3 grid(pl.G, cdiv(d.Cin, 64), cdiv(d.Cout, pl.NTC * 16));
+    if (!d.transposed) {
+      switch (pl.NTC) {
+        case 1: launch_w1<1, false>(P, grid, pl.lds, s); break;
+        case 2: launch_w1<2, false>(P, grid, pl.lds, s); break;
+        case 3: launch_w1<3, false>(P, grid, pl.lds, s); break;
+        default: launch_w1<4, false>(P, grid, pl.lds, s); break;
+      }
+    } else {
+      switch (pl.NTC) {
+        case 1: launch_w1<1, true>(P, grid, pl.lds, s); break;
+        case 2: launch_w1<2, true>(P, grid, pl.lds, s); break;
+        case 3: launch_w1<3, true>(P, grid, pl.lds, s); break;
+        default: launch_w1<4, true>(P, grid, pl.lds, s); break;
+      }
+    }
+  }
+  int rc = check_launch("conv_wgrad_mfma");
+  if (rc) return rc;
+  const int elems = d.KH * d.KW * d.Cin * d.Cout;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(elems, 256)), dim3(256), 0, s, (const float*)ws, dw, pl.G, d.Cout,
+                     d.Cin, d.KH, d.KW, d.transposed, beta);
+  rc = check_launch("conv_wgrad_reduce");
+  if (rc) return rc;
+  if (db) rc = conv_bias_grad(d, dy, mask, db, beta, s);
+  return rc;
 }
+
 }  // namespace srk

@@ -21,8 +21,16 @@ def _empty_cl(n, c, h, w, like):
 
 
 def _is_nhwc_dense(x):
+    """Memory is dense NHWC (strides of size-1 dims are irrelevant — views may rewrite them)."""
     n, c, h, w = x.shape
-    return x.stride() == (h * w * c, 1, w * c, c) or (x.is_contiguous(memory_format=CL) and (c == 1 or h * w == 1))
+    want = (h * w * c, 1, w * c, c)
+    return all(sz == 1 or st == e for sz, st, e in zip(x.shape, x.stride(), want))
+
+
+def _is_nchw_dense(x):
+    n, c, h, w = x.shape
+    want = (c * h * w, h * w, w, 1)
+    return all(sz == 1 or st == e for sz, st, e in zip(x.shape, x.stride(), want))
 
 
 def to_nhwc(x):
@@ -33,8 +41,8 @@ def to_nhwc(x):
     if _is_nhwc_dense(x):
         return x
     n, c, h, w = x.shape
-    if not x.is_contiguous():
-        raise RuntimeError("input must be NCHW-contiguous or channels_last")
+    if not _is_nchw_dense(x):
+        raise RuntimeError("input must be NCHW-contiguous or channels_last (got strides %s)" % (x.stride(),))
     y = _empty_cl(n, c, h, w, x)
     lib = _lib.load()
     check(lib.srk_nchw_to_nhwc(ptr(x), ptr(y), n, c, h, w, stream_ptr()), "srk_nchw_to_nhwc")
@@ -45,8 +53,8 @@ def to_nchw(x):
     """channels_last tensor -> NCHW-contiguous copy (srk_nhwc_to_nchw). Used before Linear layers."""
     require_cuda(x)
     n, c, h, w = x.shape
-    if x.is_contiguous() and not (_is_nhwc_dense(x) and c > 1 and h * w > 1):
-        return x
+    if _is_nchw_dense(x):
+        return x if x.is_contiguous() else x.contiguous()
     x = to_nhwc(x)
     y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
     lib = _lib.load()
@@ -61,7 +69,7 @@ class _ToNCHW(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return to_nhwc(g.contiguous() if not (g.is_contiguous() or _is_nhwc_dense(g)) else g)
+        return to_nhwc(g if (_is_nchw_dense(g) or _is_nhwc_dense(g)) else g.contiguous())
 
 
 def flatten_nchw(x):
@@ -176,7 +184,7 @@ class _Conv2d(torch.autograd.Function):
         lib = _lib.load()
         cfg = ctx.cfg
         x, weight, y = ctx.saved_tensors
-        dy = to_nhwc(dy if (dy.is_contiguous() or _is_nhwc_dense(dy)) else dy.contiguous())
+        dy = to_nhwc(dy if (_is_nchw_dense(dy) or _is_nhwc_dense(dy)) else dy.contiguous())
         d = _make_desc(x.shape, weight, cfg)
         dres = dy if ctx.has_res else None
         dyc = dy
@@ -262,7 +270,7 @@ class _PixelShuffle(torch.autograd.Function):
     def backward(ctx, dy):
         lib = _lib.load()
         r = ctx.r
-        dy = to_nhwc(dy if (dy.is_contiguous() or _is_nhwc_dense(dy)) else dy.contiguous())
+        dy = to_nhwc(dy if (_is_nchw_dense(dy) or _is_nhwc_dense(dy)) else dy.contiguous())
         n, c, hr, wr = dy.shape
         dx = _empty_cl(n, c * r * r, hr // r, wr // r, dy)
         check(lib.srk_pixel_shuffle_backward(ptr(dy), ptr(dx), n, hr // r, wr // r, c, r, stream_ptr()),
@@ -281,7 +289,7 @@ def _channels_inner(x):
 
 def _dense(x):
     if x.dim() == 4:
-        return to_nhwc(x if (x.is_contiguous() or _is_nhwc_dense(x)) else x.contiguous())
+        return to_nhwc(x if (_is_nchw_dense(x) or _is_nhwc_dense(x)) else x.contiguous())
     return x.contiguous()
 
 

@@ -1,0 +1,164 @@
+"""Flat fp32 parameter / gradient storage and the optimizers of the reference's trainers
+(torch.optim.SGD / Adam call sites: srcnn.py:79, fsrcnn.py:105-106, vdsr.py:86-90, espcn.py:79,
+edsr.py:93, lapsrn.py:135, srgan.py:147-149; clip_grad_norm: vdsr.py:149) on srk_sgd_step /
+srk_adam_step / srk_grad_norm_clip.
+
+MI355X-first layout: all parameters of a model live in ONE contiguous fp32 buffer and all
+gradients in another (288 GB of HBM make replication free), so
+  * zero_grad is one memset, the optimizer is one kernel launch over the whole model,
+  * the data-parallel gradient exchange is one (or a few large) RCCL all-reduce(s) on the flat
+    gradient buffer instead of 74 small ones (EDSR),
+  * the weight-gradient kernels accumulate straight into the gradient buffer (`_srk_grad` views),
+    so autograd never launches an ATen add for parameter gradients.
+nn.Parameter objects stay in place (their .data / .grad become views), so state_dict() and the
+reference's checkpoint files keep working.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+from .layers import bump_weight_epoch
+
+_ALIGN = 4  # floats (16 bytes) — keeps every parameter view 16-byte aligned for the vector kernels
+
+
+class FlatParams(object):
+    """Re-homes the (unique) parameters of `module` into flat `data` / `grad` buffers."""
+
+    def __init__(self, module):
+        seen, params, names = set(), [], []
+        for name, p in module.named_parameters():
+            if id(p) in seen:
+                continue
+            seen.add(id(p))
+            params.append(p)
+            names.append(name)
+        if not params:
+            raise ValueError("module has no parameters")
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatParams: move the module to the GPU first (module.to('cuda'))")
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.module, self.params, self.names, self.offsets, self.numel = module, params, names, offs, total
+        self.data = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, o in zip(params, offs):
+            v = self.data[o:o + p.numel()].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+            g = self.grad[o:o + p.numel()].view(p.shape)
+            p._srk_grad = g      # kernels accumulate here (ops._Conv2d.backward etc.)
+            p.grad = g           # what user code / hooks see
+        bump_weight_epoch()
+
+    def zero_grad(self):
+        self.grad.zero_()  # one memset node
+
+    def named_grads(self):
+        return {n: p._srk_grad for n, p in zip(self.names, self.params)}
+
+
+class _Group(dict):
+    """param_groups entry: `group['lr'] /= 2` (edsr.py:131-133) must reach the device scalar."""
+
+    def __init__(self, owner, **kw):
+        super(_Group, self).__init__(**kw)
+        self._owner = owner
+
+    def __setitem__(self, k, v):
+        super(_Group, self).__setitem__(k, v)
+        if k == "lr":
+            self._owner._set_lr(v)
+
+
+class _FlatOptimizer(object):
+    def __init__(self, params, lr):
+        if not isinstance(params, FlatParams):
+            params = FlatParams(params)
+        self.flat = params
+        dev = params.data.device
+        self.lr_dev = torch.tensor([float(lr)], dtype=torch.float32, device=dev)
+        self.scale_dev = torch.ones(1, dtype=torch.float32, device=dev)   # gradient scale (clip / DP average)
+        self.norm_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._norm_ws = None
+        self.param_groups = [_Group(self, lr=float(lr))]
+
+    def _set_lr(self, v):
+        self.lr_dev.fill_(float(v))
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()
+
+    def clip_grad_norm(self, max_norm):
+        """torch.nn.utils.clip_grad_norm(params, max_norm) (vdsr.py:149): computes the global L2
+        norm on the device and stores min(1, max_norm/(norm+1e-6)) where the next step() reads it
+        (the flat gradient buffer itself is left unscaled). Returns the device norm tensor."""
+        lib = _lib.load()
+        if self._norm_ws is None:
+            self._norm_ws = torch.empty(int(lib.srk_grad_norm_workspace_bytes()), dtype=torch.uint8,
+                                        device=self.flat.data.device)
+        check(lib.srk_grad_norm_clip(ptr(self.flat.grad), self.flat.numel, float(max_norm), ptr(self.norm_dev),
+                                     ptr(self.scale_dev), ptr(self._norm_ws), stream_ptr()), "srk_grad_norm_clip")
+        return self.norm_dev
+
+    def reset_grad_scale(self):
+        self.scale_dev.fill_(1.0)
+
+
+class SGD(_FlatOptimizer):
+    """torch.optim.SGD(lr, momentum, weight_decay, nesterov) — dampening 0 as in every reference call."""
+
+    def __init__(self, params, lr, momentum=0.0, weight_decay=0.0, nesterov=False):
+        super(SGD, self).__init__(params, lr)
+        self.momentum, self.weight_decay, self.nesterov = float(momentum), float(weight_decay), bool(nesterov)
+        # zero-initialised buffer: mom*0 + g == g, i.e. torch's "buf = clone(grad)" first step
+        self.buf = torch.zeros_like(self.flat.data) if momentum != 0.0 else None
+
+    def step(self):
+        lib = _lib.load()
+        f = self.flat
+        check(lib.srk_sgd_step(ptr(f.data), ptr(f.grad), ptr(self.buf), f.numel, 0.0, self.momentum,
+                               self.weight_decay, int(self.nesterov), 0, ptr(self.lr_dev), ptr(self.scale_dev),
+                               stream_ptr()), "srk_sgd_step")
+        bump_weight_epoch()
+
+
+class Adam(_FlatOptimizer):
+    """torch.optim.Adam(lr, betas, eps, weight_decay) without amsgrad."""
+
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super(Adam, self).__init__(params, lr)
+        self.betas, self.eps, self.weight_decay = (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.exp_avg = torch.zeros_like(self.flat.data)
+        self.exp_avg_sq = torch.zeros_like(self.flat.data)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.flat.data.device)
+
+    def step(self):
+        lib = _lib.load()
+        f = self.flat
+        check(lib.srk_adam_step(ptr(f.data), ptr(f.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), f.numel, 0.0,
+                                self.betas[0], self.betas[1], self.eps, self.weight_decay, ptr(self.step_dev),
+                                ptr(self.lr_dev), ptr(self.scale_dev), stream_ptr()), "srk_adam_step")
+        bump_weight_epoch()
+
+
+def make_optimizer(kind, flat, lr):
+    """The reference's per-model optimizer choices."""
+    if kind == "srcnn":      # srcnn.py:79
+        return SGD(flat, lr)
+    if kind == "fsrcnn":     # fsrcnn.py:105-106
+        return SGD(flat, lr, momentum=0.9)
+    if kind == "vdsr":       # vdsr.py:86-90
+        return SGD(flat, lr, momentum=0.9, weight_decay=1e-4)
+    if kind in ("espcn", "lapsrn"):   # espcn.py:79, lapsrn.py:135
+        return Adam(flat, lr)
+    if kind in ("edsr", "srgan_g"):   # edsr.py:93, srgan.py:147
+        return Adam(flat, lr, betas=(0.9, 0.999), eps=1e-8)
+    if kind == "srgan_d":    # srgan.py:149
+        return SGD(flat, lr / 100, momentum=0.9, nesterov=True)
+    raise ValueError("unknown optimizer kind %r" % (kind,))

@@ -1,0 +1,168 @@
+"""Train-step bodies of the reference's trainers on the MI355X path.
+
+Each `*_step` builder returns a closure step(*batch) -> device loss tensor(s) that performs
+    zero_grad -> forward -> loss -> backward -> [RCCL all-reduce] -> [clip] -> optimizer step
+with the same op order, loss and hyper-parameters as the cited reference lines, and with NO host
+synchronisation (the reference syncs every iteration through loss.data[0], edsr.py:158).
+`GraphedStep` captures the forward+backward and the optimizer parts into hipGraphs so a step is
+two graph launches (+ the all-reduce) instead of ~200 kernel launches from Python.
+"""
+import torch
+
+from . import ops
+from .optim import FlatParams, make_optimizer
+
+
+def _backward(loss, dp):
+    if dp is not None and dp.world > 1:
+        loss.backward(dp.loss_seed)
+    else:
+        loss.backward()
+
+
+def mse_step(model, opt, dp=None, clip=None):
+    """srcnn.py:127-131 / fsrcnn.py:153-157 / vdsr.py:143-150 (clip = 0.4)."""
+    def step(inp, target):
+        opt.zero_grad()
+        loss = ops.mse_loss(model(inp), target)
+        _backward(loss, dp)
+        if dp is not None:
+            dp.allreduce_grads()
+        if clip is not None:
+            opt.clip_grad_norm(clip)
+        opt.step()
+        return loss
+    return step
+
+
+def l1_step(model, opt, dp=None):
+    """edsr.py:151-155"""
+    def step(inp, target):
+        opt.zero_grad()
+        loss = ops.l1_loss(model(inp), target)
+        _backward(loss, dp)
+        if dp is not None:
+            dp.allreduce_grads()
+        opt.step()
+        return loss
+    return step
+
+
+def lapsrn_step(model, opt, dp=None):
+    """lapsrn.py:190-199: two Charbonnier losses, two backward calls into the same gradients."""
+    def step(inp, target2x, target4x):
+        opt.zero_grad()
+        hr2, hr4 = model(inp)
+        l1 = ops.charbonnier_loss(hr2, target2x)
+        l2 = ops.charbonnier_loss(hr4, target4x)
+        seed = dp.loss_seed if (dp is not None and dp.world > 1) else None
+        torch.autograd.backward([l1, l2], [seed, seed] if seed is not None else None)
+        if dp is not None:
+            dp.allreduce_grads()
+        opt.step()
+        return l1, l2
+    return step
+
+
+def srgan_step(G, D, g_opt, d_opt, g_dp=None, d_dp=None):
+    """srgan.py:249-310 with [B,1] labels; the VGG term is omitted (it has zero gradient in the
+    reference).  As in the reference the D step back-propagates through G
+    (G is not detached, srgan.py:279) and the G step accumulates into D's gradients, which the
+    next D step's zero_grad discards."""
+    def step(lr_img, hr_img):
+        b = lr_img.shape[0]
+        real = torch.ones(b, 1, device=lr_img.device)
+        fake = torch.zeros(b, 1, device=lr_img.device)
+        d_opt.zero_grad()
+        d_loss = ops.bce_loss(D(hr_img), real) + ops.bce_loss(D(G(lr_img)), fake)
+        _backward(d_loss, d_dp)
+        if d_dp is not None:
+            d_dp.allreduce_grads()
+        d_opt.step()
+        g_opt.zero_grad()
+        recon = G(lr_img)
+        gan_loss = ops.bce_loss(D(recon), real)
+        g_loss = ops.mse_loss(recon, hr_img) + 1e-3 * gan_loss
+        _backward(g_loss, g_dp)
+        if g_dp is not None:
+            g_dp.allreduce_grads()
+        g_opt.step()
+        return d_loss, g_loss
+    return step
+
+
+def build(kind, model, lr, dp_group=None, use_dp=False):
+    """(flat, optimizer, dp, step) for one of 'srcnn' | 'fsrcnn' | 'vdsr' | 'edsr' | 'lapsrn' | 'espcn'."""
+    from .dp import DataParallel
+    flat = FlatParams(model)
+    opt = make_optimizer(kind, flat, lr)
+    dp = DataParallel(flat, dp_group) if use_dp else None
+    if dp is not None:
+        dp.broadcast_params()
+    if kind == "edsr":
+        step = l1_step(model, opt, dp)
+    elif kind == "lapsrn":
+        step = lapsrn_step(model, opt, dp)
+    elif kind == "vdsr":
+        step = mse_step(model, opt, dp, clip=0.4)
+    else:
+        step = mse_step(model, opt, dp)
+    return flat, opt, dp, step
+
+
+class GraphedStep(object):
+    """hipGraph capture of a train step with static input buffers.
+
+    The step is split at the gradient all-reduce: graph A = zero_grad + forward + loss + backward,
+    then the (eager) RCCL all-reduce, then graph B = [clip] + optimizer.  Without data parallelism
+    everything is one graph.  Call with new batches; they are copied into the static buffers.
+    """
+
+    def __init__(self, model, opt, loss_fn, example_inputs, dp=None, clip=None, warmup=3):
+        self.model, self.opt, self.dp, self.clip = model, opt, dp, clip
+        self.static = [torch.empty_like(t).copy_(t) for t in example_inputs]
+        self.loss_fn = loss_fn
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._fwd_bwd()
+                self._exchange()
+                self._update()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_a):
+            self.loss = self._fwd_bwd()
+            if dp is None or dp.world == 1:
+                self._update()
+        self.graph_b = None
+        if dp is not None and dp.world > 1:
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b):
+                self._update()
+
+    def _fwd_bwd(self):
+        self.opt.zero_grad()
+        loss = self.loss_fn(self.model(self.static[0]), *self.static[1:])
+        _backward(loss, self.dp)
+        return loss
+
+    def _exchange(self):
+        if self.dp is not None:
+            self.dp.allreduce_grads()
+
+    def _update(self):
+        if self.clip is not None:
+            self.opt.clip_grad_norm(self.clip)
+        self.opt.step()
+
+    def __call__(self, *batch):
+        for s, b in zip(self.static, batch):
+            if b is not s:
+                s.copy_(b, non_blocking=True)
+        self.graph_a.replay()
+        if self.graph_b is not None:
+            self._exchange()
+            self.graph_b.replay()
+        return self.loss

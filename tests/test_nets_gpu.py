@@ -42,10 +42,13 @@ def test_net_forward_backward(gpu, nets_golden, name):
     names = [str(n) for n in nets_golden[name + ".grad_names"]]
     sums = nets_golden[name + ".grad_sums"]
     params = dict(net.named_parameters())
+    # conv biases that feed a BatchNorm have an exactly-zero gradient in exact arithmetic; both
+    # sides then hold rounding noise, so tolerances are floored relative to the largest gradient.
+    floor = 1e-4 * float(sums[:, 1].max())
     for n, (s, l2) in zip(names, sums):
         g = params[n].grad.detach().double().cpu()
-        assert abs(float(g.pow(2).sum().sqrt()) - l2) <= TOL_GRAD * max(l2, 1e-12), "grad L2 of " + n
-        assert abs(float(g.sum()) - s) <= 10 * TOL_GRAD * max(l2, 1e-12), "grad sum of " + n
+        assert abs(float(g.pow(2).sum().sqrt()) - l2) <= TOL_GRAD * max(l2, floor), "grad L2 of " + n
+        assert abs(float(g.sum()) - s) <= 10 * TOL_GRAD * max(l2, floor), "grad sum of " + n
     assert rel_err(params[names[0]].grad, nets_golden[name + ".grad_first"]) < TOL_GRAD
     assert rel_err(params[names[-1]].grad, nets_golden[name + ".grad_last"]) < TOL_GRAD
     if name.startswith("srgan"):
