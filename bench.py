@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): LR->HR images/s of ESPCN x4 inference (config c2:
+256x256 LR, batch 64 per GPU, fp32) on N MI355X GPUs, printed as ONE JSON line by rank 0.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one forward pass of the hot path over one synthetic batch that is already resident in
+HBM.  Inference replicas share nothing, so N GPUs = N independent shards of the image stream
+(weak scaling, no data-path collective).  The same JSON line also carries
+  * roofline      — the dominant kernel (conv 64->32, 3x3) timed live with HIP events on the launch
+                    stream, against the fp32 MFMA peak, plus the whole-net HBM-roofline fraction
+                    the north star quotes (61.11 MB compulsory traffic per image);
+  * cpu_baseline  — the oracle (stock torch.nn = the arithmetic the reference invokes) timed on this
+                    box's host cores on a bounded sample of the same workload;
+  * extra         — training throughput of configs c3 (VDSR, 1 GPU) and c4 (EDSR, global batch 128
+                    sharded over the N ranks with the RCCL gradient all-reduce; strong scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 peak
+ESPCN_BYTES_PER_IMG = 61.11e6  # per-layer compulsory activation traffic, 256x256 LR
+ESPCN_FLOP_PER_IMG = 4.614e9
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="LR images per GPU per step (c2: 64)")
+    ap.add_argument("--lr-size", type=int, default=256)
+    ap.add_argument("--no-extra", action="store_true", help="skip the c3/c4 training side metrics")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def barrier_sync(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(seconds, world, dev):
+    if world == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return float(t.item())
+
+
+def time_steps(fn, steps, warmup, world, dev):
+    for _ in range(warmup):
+        fn()
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    barrier_sync(world)
+    return max_over_ranks(time.perf_counter() - t0, world, dev)
+
+
+def espcn_layer_events(net, x, steps):
+    """HIP events on the launch stream around each of the three fused kernels (conv5+ReLU,
+    conv3+ReLU, conv3+pixel-shuffle store). Returns average ms per layer."""
+    import pytorch_super_resolution_model_collection_amd as pkg
+    xs = pkg.ops.to_nhwc(x)
+    evs = []
+    with torch.no_grad():
+        for _ in range(steps):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            h = xs
+            e[0].record()
+            for i, layer in enumerate(net.layers):
+                h = layer(h)
+                e[i + 1].record()
+            evs.append(e)
+    torch.cuda.synchronize()
+    return [sum(e[i].elapsed_time(e[i + 1]) for e in evs) / len(evs) for i in range(3)]
+
+
+def cpu_baseline(batch_cap=8, lr_size=256):
+    """Oracle ESPCN x4 forward on the host cores (bounded sample: B=8, best of 5 after 2 warm-ups)."""
+    from oracle import fill, ref_modules as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = fill.fill_module(R.ESPCN(3, 64, 4)).eval()
+    x = fill.rand((batch_cap, 3, lr_size, lr_size), 1234)
+    best = None
+    with torch.no_grad():
+        for i in range(7):
+            t0 = time.perf_counter()
+            net(x)
+            dt = time.perf_counter() - t0
+            if i >= 2:
+                best = dt if best is None else min(best, dt)
+    return {"value": round(batch_cap / best, 2), "unit": "images/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "oracle ESPCN x4 forward (stock torch.nn CPU fp32), batch %d of %dx%d LR, best of 5"
+                      % (batch_cap, lr_size, lr_size)}
+
+
+def train_extra(pkg, dev, rank, world):
+    """Side metrics: c3 VDSR x4 training (41x41, batch 256, one GPU's worth per rank is NOT sharded —
+    reported from rank 0 only at N=1) and c4 EDSR x4 training with global batch 128 sharded over the ranks."""
+    from oracle import fill
+    out = {}
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+
+    def run(kind, net, inp, tgt, loss_fn, clip, use_dp, steps=6, warmup=3):
+        net.to(dev).train()
+        flat = pkg.optim.FlatParams(net)
+        opt = pkg.optim.make_optimizer(kind, flat, 1e-5)
+        dp = None
+        if use_dp and world > 1:
+            dp = pkg.dp.DataParallel(flat)
+            dp.broadcast_params()
+        step = pkg.trainers.GraphedStep(net, opt, loss_fn, (inp, tgt), dp=dp, clip=clip, warmup=2)
+        return time_steps(lambda: step(inp, tgt), steps, warmup, world if use_dp else 1, dev), steps
+
+    if world == 1:
+        net = pkg.VDSRNet(3, 64, 18)
+        net.weight_init()
+        x = torch.rand(256, 3, 41, 41, generator=g).to(dev)
+        t = torch.rand(256, 3, 41, 41, generator=g).to(dev)
+        sec, k = run("vdsr", net, x, t, pkg.ops.mse_loss, 0.4, False)
+        out["c3_vdsr_x4_train_patches_per_s"] = round(256 * k / sec, 1)
+        out["c3_vdsr_ms_per_step"] = round(1e3 * sec / k, 3)
+        out["c3_vdsr_frac_fp32_mfma_peak"] = round(256 * k / sec * 6.72e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
+    gb = 128
+    lo, hi = pkg.dp.shard_range(gb, rank, world)
+    net = pkg.EDSRNet(3, 64, 16)
+    torch.manual_seed(1234)
+    net.weight_init()
+    x = torch.rand(gb, 3, 32, 32, generator=torch.Generator().manual_seed(99))[lo:hi].to(dev)
+    t = torch.rand(gb, 3, 128, 128, generator=torch.Generator().manual_seed(98))[lo:hi].to(dev)
+    sec, k = run("edsr", net, x, t, pkg.ops.l1_loss, None, True)
+    out["c4_edsr_x4_train_patches_per_s_global_batch_128"] = round(gb * k / sec, 1)
+    out["c4_edsr_ms_per_step"] = round(1e3 * sec / k, 3)
+    out["c4_scaling"] = "strong (global batch 128 sharded over %d rank(s), RCCL all-reduce of 6.07 MB grads)" % world
+    return out
+
+
+def main():
+    args = parse()
+    import __graft_entry__
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        __graft_entry__.build()
+    import pytorch_super_resolution_model_collection_amd as pkg
+    rank, world, local = pkg.dp.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        torch.distributed.barrier()
+    pkg._lib.load()
+
+    # ---- c2: ESPCN x4 inference, random-init weights of the reference's distribution, synthetic LR batch
+    torch.manual_seed(1234)
+    net = pkg.ESPCNNet(3, 64, 4)
+    net.weight_init()
+    net.to(dev).eval()
+    x = torch.rand(args.batch, 3, args.lr_size, args.lr_size, generator=torch.Generator().manual_seed(1234 + rank))
+    x = x.to(dev)
+
+    def step():
+        with torch.no_grad():
+            return net(x)
+
+    y = step()
+    assert tuple(y.shape) == (args.batch, 3, 4 * (args.lr_size - 8), 4 * (args.lr_size - 8))
+    sec = time_steps(step, args.steps, args.warmup, world, dev)
+    imgs_per_s = world * args.batch * args.steps / sec
+    layer_ms = espcn_layer_events(net, x, max(3, min(args.steps, 10)))
+
+    result = None
+    if rank == 0:
+        H = args.lr_size
+        flop_l2 = 2.0 * args.batch * (H - 6) ** 2 * 32 * 64 * 9
+        dom = max(range(3), key=lambda i: layer_ms[i])
+        names = ["k_conv_mfma_tg<4> conv5x5 3->64 + ReLU", "k_conv_mfma<2> conv3x3 64->32 + ReLU",
+                 "k_conv_mfma<3> conv3x3 32->48 + pixel-shuffle store"]
+        flops = [2.0 * args.batch * (H - 4) ** 2 * 64 * 3 * 25, flop_l2, 2.0 * args.batch * (H - 8) ** 2 * 48 * 32 * 9]
+        achieved = flops[dom] / (layer_ms[dom] * 1e-3) / 1e12
+        scale = (H / 256.0) ** 2
+        result = {
+            "metric": "ESPCN x4 LR->HR images/sec (infer)", "value": round(imgs_per_s, 1), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * sec / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "c2: ESPCN x4 inference, %dx%d LR, batch %d per GPU, fp32, random-init N(0,0.02)"
+                                   % (H, H, args.batch),
+                       "parallelism": "replicas x%d (no collective)" % world},
+            "roofline": {"bound": "mfma", "kernel": names[dom], "achieved": round(achieved, 2),
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel_ms": round(layer_ms[dom], 4),
+                         "layer_ms": [round(m, 4) for m in layer_ms],
+                         "whole_net_hbm": {
+                             "achieved_GBps": round(ESPCN_BYTES_PER_IMG * scale * imgs_per_s / world / 1e9, 1),
+                             "peak_GBps": HBM_PEAK_GBS,
+                             "frac": round(ESPCN_BYTES_PER_IMG * scale * imgs_per_s / world / 1e9 / HBM_PEAK_GBS, 4),
+                             "note": "61.11 MB/img per-layer compulsory traffic (SURVEY.md 8d); north-star target 0.30"},
+                         "whole_net_fp32_flop_frac": round(
+                             ESPCN_FLOP_PER_IMG * scale * imgs_per_s / world / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
+        }
+    extra = {}
+    if not args.no_extra:
+        extra = train_extra(pkg, dev, rank, world)
+    if rank == 0:
+        if extra:
+            result["extra"] = extra
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(lr_size=args.lr_size)
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

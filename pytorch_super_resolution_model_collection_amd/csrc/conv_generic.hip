@@ -145,17 +145,21 @@ __global__ __launch_bounds__(256) void k_wgrad_finalize(const float* __restrict_
   dw[e] = beta != 0.f ? beta * dw[e] + v : v;
 }
 
-// db[co] = beta*db + sum over pixels of (masked) dy[pix][co].  One block per channel group of
-// 64 channels; 4 waves stride over pixels; lanes = channels (coalesced 256-byte rows).
-__global__ __launch_bounds__(256) void k_bias_grad(const float* __restrict__ dy, const float* __restrict__ mask_y,
-                                                   float mask_slope, float* __restrict__ db, size_t npix, int Cout,
-                                                   float beta) {
+// db[co] = beta*db + sum over pixels of (masked) dy[pix][co].  Two deterministic stages:
+// grid (channel groups of 64, pixel splits): lanes = channels (coalesced 256-byte rows), the 4
+// waves stride the split's pixels; partial[split][co] then a fixed-order reduction.
+__global__ __launch_bounds__(256) void k_bias_grad_partial(const float* __restrict__ dy,
+                                                           const float* __restrict__ mask_y, float mask_slope,
+                                                           float* __restrict__ partial, size_t npix, int Cout,
+                                                           size_t pix_per_split) {
   __shared__ float sm[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int co = blockIdx.x * 64 + lane;
+  size_t p0 = (size_t)blockIdx.y * pix_per_split, p1 = p0 + pix_per_split;
+  if (p1 > npix) p1 = npix;
   float acc = 0.f;
   if (co < Cout) {
-    for (size_t p = w; p < npix; p += 4) {
+    for (size_t p = p0 + w; p < p1; p += 4) {
       float g = dy[p * Cout + co];
       if (mask_y) g = mask_y[p * Cout + co] > 0.f ? g : g * mask_slope;
       acc += g;
@@ -163,19 +167,38 @@ __global__ __launch_bounds__(256) void k_bias_grad(const float* __restrict__ dy,
   }
   sm[w][lane] = acc;
   __syncthreads();
-  if (w == 0 && co < Cout) {
-    const float t = sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane];
-    db[co] = beta != 0.f ? beta * db[co] + t : t;
-  }
+  if (w == 0 && co < Cout)
+    partial[(size_t)blockIdx.y * Cout + co] = sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane];
 }
 
-size_t conv_generic_wgrad_ws(const srk_conv_desc& d) { return (size_t)d.KH * d.KW * d.Cin * d.Cout * sizeof(float); }
+__global__ __launch_bounds__(256) void k_bias_grad_final(const float* __restrict__ partial, float* __restrict__ db,
+                                                         int splits, int Cout, float beta) {
+  const int co = blockIdx.x * 256 + threadIdx.x;
+  if (co >= Cout) return;
+  float t = 0.f;
+  for (int s = 0; s < splits; ++s) t += partial[(size_t)s * Cout + co];
+  db[co] = beta != 0.f ? beta * db[co] + t : t;
+}
 
-int conv_bias_grad(const srk_conv_desc& d, const float* dy, const srk_bwd_mask* mask, float* db, float beta,
+constexpr int kBiasSplits = 1024;
+
+size_t conv_bias_grad_ws(const srk_conv_desc& d) { return (size_t)kBiasSplits * d.Cout * sizeof(float); }
+
+size_t conv_generic_wgrad_ws(const srk_conv_desc& d) {
+  return (size_t)d.KH * d.KW * d.Cin * d.Cout * sizeof(float) + conv_bias_grad_ws(d);
+}
+
+int conv_bias_grad(const srk_conv_desc& d, const float* dy, const srk_bwd_mask* mask, float* db, float beta, void* ws,
                    hipStream_t s) {
   const size_t npix = (size_t)d.N * d.OH * d.OW;
-  hipLaunchKernelGGL(k_bias_grad, dim3(cdiv(d.Cout, 64)), dim3(256), 0, s, dy, mask ? mask->y : nullptr,
-                     mask ? mask->slope : 0.f, db, npix, d.Cout, beta);
+  int splits = (int)((npix + 255) / 256);
+  if (splits > kBiasSplits) splits = kBiasSplits;
+  if (splits < 1) splits = 1;
+  const size_t pps = (npix + splits - 1) / splits;
+  hipLaunchKernelGGL(k_bias_grad_partial, dim3(cdiv(d.Cout, 64), splits), dim3(256), 0, s, dy,
+                     mask ? mask->y : nullptr, mask ? mask->slope : 0.f, (float*)ws, npix, d.Cout, pps);
+  hipLaunchKernelGGL(k_bias_grad_final, dim3(cdiv(d.Cout, 256)), dim3(256), 0, s, (const float*)ws, db, splits,
+                     d.Cout, beta);
   return check_launch("conv_bias_grad");
 }
 
@@ -193,7 +216,8 @@ int conv_generic_wgrad(const srk_conv_desc& d, const float* x, const float* dy, 
     set_error("conv_generic_wgrad: workspace %zu < %zu", ws_bytes, need);
     return SRK_ERR_WORKSPACE;
   }
-  hipError_t me = hipMemsetAsync(ws, 0, need, s);
+  const size_t wbytes = (size_t)d.KH * d.KW * d.Cin * d.Cout * sizeof(float);
+  hipError_t me = hipMemsetAsync(ws, 0, wbytes, s);
   if (me != hipSuccess) {
     set_error("conv_generic_wgrad: memset failed: %s", hipGetErrorString(me));
     return SRK_ERR_LAUNCH;
@@ -213,7 +237,7 @@ int conv_generic_wgrad(const srk_conv_desc& d, const float* x, const float* dy, 
   if (rc) return rc;
   rc = conv_wgrad_finalize(d, (const float*)ws, dw, beta, s);
   if (rc) return rc;
-  if (db) rc = conv_bias_grad(d, dy, mask, db, beta, s);
+  if (db) rc = conv_bias_grad(d, dy, mask, db, beta, (char*)ws + wbytes, s);
   return rc;
 }
 

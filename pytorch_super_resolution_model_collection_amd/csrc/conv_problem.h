@@ -75,7 +75,8 @@ __device__ __forceinline__ void epi_store(const Epi& ep, const GatherConv& g, fl
 // Implemented in conv_generic.hip
 int conv_generic_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
                         const float* mask_y, float mask_slope, hipStream_t s);
-int conv_bias_grad(const srk_conv_desc& d, const float* dy, const srk_bwd_mask* mask, float* db, float beta,
+size_t conv_bias_grad_ws(const srk_conv_desc& d);
+int conv_bias_grad(const srk_conv_desc& d, const float* dy, const srk_bwd_mask* mask, float* db, float beta, void* ws,
                    hipStream_t s);
 int conv_wgrad_finalize(const srk_conv_desc& d, const float* ws, float* dw, float beta, hipStream_t s);
 // Implemented in conv_mfma.hip

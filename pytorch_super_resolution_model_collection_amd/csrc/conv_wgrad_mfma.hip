@@ -398,7 +398,7 @@ bool conv_wgrad_mfma_supported(const srk_conv_desc& d) { return plan(d).ok; }
 size_t conv_wgrad_mfma_ws(const srk_conv_desc& d) {
   WgPlan pl = plan(d);
   if (!pl.ok) return 0;
-  return (size_t)pl.G * d.KH * d.KW * d.Cin * d.Cout * sizeof(float);
+  return (size_t)pl.G * d.KH * d.KW * d.Cin * d.Cout * sizeof(float) + conv_bias_grad_ws(d);
 }
 
 template <typename K>
@@ -430,7 +430,8 @@ int conv_wgrad_mfma(const srk_conv_desc& d, const float* x, const float* dy, con
     set_error("conv_wgrad_mfma: shape not covered");
     return SRK_ERR_UNSUPPORTED;
   }
-  const size_t need = (size_t)pl.G * d.KH * d.KW * d.Cin * d.Cout * sizeof(float);
+  const size_t slab_bytes = (size_t)pl.G * d.KH * d.KW * d.Cin * d.Cout * sizeof(float);
+  const size_t need = slab_bytes + conv_bias_grad_ws(d);
   if (!ws || ws_bytes < need) {
     set_error("conv_wgrad_mfma: workspace %zu < %zu", ws_bytes, need);
     return SRK_ERR_WORKSPACE;
@@ -479,7 +480,7 @@ int conv_wgrad_mfma(const srk_conv_desc& d, const float* x, const float* dy, con
                      d.Cin, d.KH, d.KW, d.transposed, beta);
   rc = check_launch("conv_wgrad_reduce");
   if (rc) return rc;
-  if (db) rc = conv_bias_grad(d, dy, mask, db, beta, s);
+  if (db) rc = conv_bias_grad(d, dy, mask, db, beta, (char*)ws + slab_bytes, s);
   return rc;
 }
 
