@@ -48,8 +48,16 @@ typedef enum srk_act {
 } srk_act;
 
 /* Which implementation a conv call may use.  AUTO picks the fastest kernel that covers the
- * shape; GENERIC forces the plain gather kernel (used by the tests to cross-check). */
-typedef enum srk_algo { SRK_ALGO_AUTO = 0, SRK_ALGO_GENERIC = 1, SRK_ALGO_MFMA = 2, SRK_ALGO_DIRECT = 3 } srk_algo;
+ * shape; GENERIC forces the plain gather kernel (used by the tests to cross-check).  The environment
+ * variable SRK_FORCE_ALGO=generic|mfma|direct|bf16x3 overrides AUTO (SRK_FORCE_ALGO=mfma gives the
+ * exact-fp32 MFMA path everywhere). */
+typedef enum srk_algo {
+  SRK_ALGO_AUTO = 0,        /* bf16x3 MFMA where it applies, else fp32 MFMA / direct / generic            */
+  SRK_ALGO_GENERIC = 1,     /* plain fp32 gather kernel (any shape)                                       */
+  SRK_ALGO_MFMA = 2,        /* exact fp32 MFMA (v_mfma_f32_16x16x4_f32)                                    */
+  SRK_ALGO_DIRECT = 3,      /* fp32 VALU kernel for Cout <= 4                                              */
+  SRK_ALGO_MFMA_BF16X3 = 4  /* 3-term bf16 split on v_mfma_f32_16x16x32_bf16, fp32 accumulate (~1e-5 rel) */
+} srk_algo;
 
 /* Geometry of one torch.nn.Conv2d / ConvTranspose2d call.
  *   conv       (base_networks.py:42,112-113,156): y[n,oy,ox,co] = sum x[n,oy*s-p+kh,ox*s-p+kw,ci] * w
@@ -113,7 +121,10 @@ int srk_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, void*
  *   (for the data gradient the roles of the channel axes swap; the spatial flip is handled by
  *   the kernels' index arithmetic, not by the packing).
  * ps_r > 1 (forward only) additionally permutes the output channels to (i, j, c) order so a
- * fused pixel-shuffle store is contiguous; bias must then be packed with srk_pack_bias_ps. */
+ * fused pixel-shuffle store is contiguous; bias must then be packed with srk_pack_bias_ps.
+ * A packed buffer is srk_packed_weight_bytes() long: the fp32 layout above followed (256-byte
+ * aligned) by the same filter pre-split into bf16 hi/lo planes for the bf16x3 MFMA kernel. */
+size_t srk_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int bwd);
 int srk_pack_weight_fwd(const float* w, float* wp, int Cout, int Cin, int KH, int KW, int transposed, int ps_r,
                         void* stream);
 int srk_pack_weight_bwd(const float* w, float* wp, int Cout, int Cin, int KH, int KW, int transposed,

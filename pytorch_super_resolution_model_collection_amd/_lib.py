@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "srk.h")
 
 # enums mirrored from include/srk.h
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = range(6)
-ALGO_AUTO, ALGO_GENERIC, ALGO_MFMA, ALGO_DIRECT = range(4)
+ALGO_AUTO, ALGO_GENERIC, ALGO_MFMA, ALGO_DIRECT, ALGO_MFMA_BF16X3 = range(5)
 LOSS_MSE, LOSS_L1, LOSS_CHARBONNIER, LOSS_BCE = range(4)
 ACT_BY_NAME = {None: ACT_NONE, "relu": ACT_RELU, "prelu": ACT_PRELU, "lrelu": ACT_LRELU, "tanh": ACT_TANH,
                "sigmoid": ACT_SIGMOID}
@@ -56,6 +56,7 @@ _PROTOTYPES = {
     "srk_pack_weight_fwd": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "srk_pack_weight_bwd": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "srk_pack_bias_ps": (c_int, [c_f, c_f, c_int, c_int, c_vp]),
+    "srk_packed_weight_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
     "srk_conv2d_forward": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, c_f, ctypes.POINTER(Epilogue), c_vp]),
     "srk_conv2d_backward_data": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, c_f, ctypes.POINTER(BwdMask), c_f,
                                          c_vp]),

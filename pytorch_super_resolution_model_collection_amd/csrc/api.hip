@@ -42,7 +42,7 @@ static int validate_desc(const srk_conv_desc* d, const char* who) {
   const int ow = srk_conv_out_dim(d->W, d->KW, d->stride, d->pad, d->transposed, d->out_pad);
   SRK_REQUIRE(oh > 0 && ow > 0, "%s: empty output (%d x %d)", who, oh, ow);
   SRK_REQUIRE(d->OH == oh && d->OW == ow, "%s: OH/OW (%d,%d) != expected (%d,%d)", who, d->OH, d->OW, oh, ow);
-  SRK_REQUIRE(d->algo >= SRK_ALGO_AUTO && d->algo <= SRK_ALGO_DIRECT, "%s: unknown algo %d", who, d->algo);
+  SRK_REQUIRE(d->algo >= SRK_ALGO_AUTO && d->algo <= SRK_ALGO_MFMA_BF16X3, "%s: unknown algo %d", who, d->algo);
   return SRK_OK;
 }
 
@@ -53,6 +53,7 @@ static int forced_algo(int algo) {
   if (!strcmp(e, "generic")) return SRK_ALGO_GENERIC;
   if (!strcmp(e, "mfma")) return SRK_ALGO_MFMA;
   if (!strcmp(e, "direct")) return SRK_ALGO_DIRECT;
+  if (!strcmp(e, "bf16x3")) return SRK_ALGO_MFMA_BF16X3;
   return SRK_ALGO_AUTO;
 }
 
@@ -65,12 +66,19 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
     set_error("%s: direct kernel does not cover this shape", who);
     return SRK_ERR_UNSUPPORTED;
   }
-  if (algo == SRK_ALGO_MFMA && !mfma_ok) {
+  if (algo == SRK_ALGO_MFMA && !mfma_ok && !direct_ok) {
     set_error("%s: MFMA kernel does not cover this shape", who);
     return SRK_ERR_UNSUPPORTED;
   }
-  if (algo == SRK_ALGO_DIRECT || (algo == SRK_ALGO_AUTO && direct_ok))
+  const bool bf3_ok = conv_bf3_gather_supported(g, ep);
+  if (algo == SRK_ALGO_MFMA_BF16X3 && !bf3_ok) {
+    set_error("%s: bf16x3 MFMA kernel does not cover this shape", who);
+    return SRK_ERR_UNSUPPORTED;
+  }
+  if (algo == SRK_ALGO_DIRECT || ((algo == SRK_ALGO_AUTO || (algo == SRK_ALGO_MFMA && !mfma_ok)) && direct_ok))
     return conv_direct_gather(g, in, wp, out, ep, mask_y, mask_slope, s);
+  if (algo == SRK_ALGO_MFMA_BF16X3 || (algo == SRK_ALGO_AUTO && bf3_ok))
+    return conv_bf3_gather(g, in, wp, out, ep, mask_y, mask_slope, s);
   if (algo == SRK_ALGO_MFMA || (algo == SRK_ALGO_AUTO && mfma_ok))
     return conv_mfma_gather(g, in, wp, out, ep, mask_y, mask_slope, s);
   return conv_generic_gather(g, in, wp, out, ep, mask_y, mask_slope, s);
@@ -148,13 +156,9 @@ extern "C" int srk_conv2d_backward_weight(const srk_conv_desc* d, const float* x
   if (rc) return rc;
   SRK_REQUIRE(x && dy && dw, "conv2d_backward_weight: null tensor pointer");
   SRK_REQUIRE(beta == 0.f || beta == 1.f, "conv2d_backward_weight: beta must be 0 or 1");
-  int algo = forced_algo(d->algo);
-  const bool mfma_ok = conv_wgrad_mfma_supported(*d);
-  if (algo == SRK_ALGO_MFMA && !mfma_ok) {
-    set_error("conv2d_backward_weight: MFMA kernel does not cover this shape");
-    return SRK_ERR_UNSUPPORTED;
-  }
-  if (algo == SRK_ALGO_MFMA || ((algo == SRK_ALGO_AUTO || algo == SRK_ALGO_DIRECT) && mfma_ok))
+  // the weight gradient has one fast kernel (fp32 MFMA); every algo except GENERIC uses it where it applies
+  const int algo = forced_algo(d->algo);
+  if (algo != SRK_ALGO_GENERIC && conv_wgrad_mfma_supported(*d))
     return conv_wgrad_mfma(*d, x, dy, mask, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);
   return conv_generic_wgrad(*d, x, dy, mask, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -294,7 +294,14 @@ extern "C" int srk_pack_weight_fwd(const float* w, float* wp, int Cout, int Cin,
   const int elems = KH * KW * Cin * Cout;
   hipLaunchKernelGGL(k_pack_weight, dim3(cdiv(elems, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, KH,
                      KW, transposed, ps_r, 0);
-  return check_launch("pack_weight_fwd");
+  int rc = check_launch("pack_weight_fwd");
+  if (rc) return rc;
+  return bf3_pack_prepared(w, wp, Cout, Cin, KH, KW, transposed, ps_r, 0, (hipStream_t)stream);
+}
+extern "C" size_t srk_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int bwd) {
+  if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 0;
+  const size_t elems = (size_t)KH * KW * Cin * Cout;
+  return bf3_prepared_offset(elems) + bf3_prepared_bytes(bwd ? Cout : Cin, bwd ? Cin : Cout, KH * KW);
 }
 extern "C" int srk_pack_weight_bwd(const float* w, float* wp, int Cout, int Cin, int KH, int KW, int transposed,
                                    void* stream) {
@@ -303,7 +310,9 @@ extern "C" int srk_pack_weight_bwd(const float* w, float* wp, int Cout, int Cin,
   const int elems = KH * KW * Cin * Cout;
   hipLaunchKernelGGL(k_pack_weight, dim3(cdiv(elems, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, KH,
                      KW, transposed, 0, 1);
-  return check_launch("pack_weight_bwd");
+  int rc = check_launch("pack_weight_bwd");
+  if (rc) return rc;
+  return bf3_pack_prepared(w, wp, Cout, Cin, KH, KW, transposed, 0, 1, (hipStream_t)stream);
 }
 extern "C" int srk_pack_bias_ps(const float* b, float* bp, int Cout, int ps_r, void* stream) {
   SRK_REQUIRE(b && bp && Cout > 0 && ps_r >= 1, "pack_bias_ps: bad args");

@@ -1,0 +1,421 @@
+// Implicit-GEMM convolution on the bf16 matrix cores with a 3-term split ("bf16x3"):
+//
+//     a = a_hi + a_lo,  b = b_hi + b_lo   (hi = bf16(x) round-to-nearest, lo = bf16(x - hi))
+//     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (dropped a_lo*b_lo <= 2^-16 |a*b|)
+//
+// accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  Three bf16 MFMAs (each 16x the fp32 MFMA
+// rate) replace one fp32 MFMA: ~5.3x the fp32 ceiling (157 TF -> ~830 TF effective) at an error of
+// ~1e-5 relative — two orders inside the 1e-3 contract (tests hold this path to 1e-4).  This is
+// what lifts the FLOP-bound nets (ESPCN forward: 75 FLOP/B) towards the HBM roofline.
+//
+// Structure (one 256-thread block = <=256 output pixels x <=64 output channels):
+//   * the NHWC fp32 halo of the tile is read ONCE from HBM (coalesced 16-byte loads), split into
+//     hi/lo bf16 on the fly and staged in LDS as [plane][8-channel group][pixel][8 x bf16]: the 16
+//     lanes of an MFMA row group read 16 consecutive pixels x 16 B = 256 contiguous bytes
+//     (bank-conflict-free ds_read_b128), 32 channels per pass;
+//   * filters are pre-split at pack time into the same [plane][group][co][8] layout, so the
+//     per-tap slice (8 KB) is a linear copy into a double-buffered LDS slot (next tap prefetched
+//     into registers during the MFMAs) — one barrier per tap;
+//   * each wave owns 64 pixels x 64 channels = 4 x 4 MFMA tiles (64 accumulator VGPRs); per tap
+//     and 32-channel chunk it issues 16 ds_read_b128 for 48 MFMAs;
+//   * epilogue identical to the fp32 kernel (bias / activation / residual / pixel-shuffle store).
+#include "srk_common.h"
+#include "conv_problem.h"
+#include "conv_tile.h"
+
+namespace srk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Bf3Params {
+  MfmaConvParams P;
+  const uint4* wq;  // prepared filters
+  int ICc;          // 32-channel chunks
+  int OCb;          // 64-channel output blocks
+  int NB;           // output channels per block in the prepared layout (NT*16)
+  int NPIXp;        // halo pixels rounded up to 16
+};
+
+__device__ __forceinline__ void split8(const float (&f)[8], uint4& hi, uint4& lo) {
+  bf16x8 h, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 hh = (__bf16)f[e];
+    h[e] = hh;
+    l[e] = (__bf16)(f[e] - (float)hh);
+  }
+  hi = __builtin_bit_cast(uint4, h);
+  lo = __builtin_bit_cast(uint4, l);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Filter preparation: torch-layout fp32 weights -> [tap][chunk][ocb][plane][group][co][8] bf16
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bf3_pack(const float* __restrict__ w, uint4* __restrict__ dst, int Cout,
+                                                  int Cin, int KH, int KW, int transposed, int ps_r, int bwd, int IC,
+                                                  int OC, int ICc, int OCb, int NB) {
+  const int T = KH * KW;
+  const long items = (long)T * ICc * OCb * 4 * NB;
+  const long it = (long)blockIdx.x * 256 + threadIdx.x;
+  if (it >= items) return;
+  const int col = (int)(it % NB);
+  long r = it / NB;
+  const int g = (int)(r % 4);
+  r /= 4;
+  const int ocb = (int)(r % OCb);
+  r /= OCb;
+  const int cc = (int)(r % ICc);
+  const int tap = (int)(r / ICc);
+  const int kh = tap / KW, kw = tap - kh * KW;
+  const int oc = ocb * 64 + col;
+  float f[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ic = cc * 32 + g * 8 + e;
+    float v = 0.f;
+    if (ic < IC && oc < OC) {
+      int ci, co;
+      if (!bwd) {
+        ci = ic;
+        co = oc;
+        if (ps_r > 1) {  // packed order (i, j, c) -> torch order c*r*r + i*r + j
+          const int C = Cout / (ps_r * ps_r);
+          const int q = oc / C, c = oc - q * C;
+          co = c * ps_r * ps_r + q;
+        }
+      } else {
+        ci = oc;
+        co = ic;
+      }
+      const size_t src = transposed ? ((((size_t)ci * Cout + co) * KH + kh) * KW + kw)
+                                    : ((((size_t)co * Cin + ci) * KH + kh) * KW + kw);
+      v = w[src];
+    }
+    f[e] = v;
+  }
+  uint4 hi, lo;
+  split8(f, hi, lo);
+  uint4* blk = dst + ((size_t)(tap * ICc + cc) * OCb + ocb) * (size_t)(8 * NB);
+  blk[(0 * 4 + g) * NB + col] = hi;
+  blk[(1 * 4 + g) * NB + col] = lo;
+}
+
+static inline int bf3_nb(int OC) { return OC >= 64 ? 64 : ((OC + 15) / 16) * 16; }
+
+size_t bf3_prepared_offset(size_t elems) { return (elems * sizeof(float) + 255) & ~(size_t)255; }
+
+size_t bf3_prepared_bytes(int IC, int OC, int T) {
+  const int ICc = (IC + 31) / 32, OCb = (OC + 63) / 64, NB = bf3_nb(OC);
+  return (size_t)T * ICc * OCb * 8 * NB * sizeof(uint4);
+}
+
+int bf3_pack_prepared(const float* w, void* packed_base, int Cout, int Cin, int KH, int KW, int transposed, int ps_r,
+                      int bwd, hipStream_t s) {
+  const int IC = bwd ? Cout : Cin, OC = bwd ? Cin : Cout;
+  const int ICc = (IC + 31) / 32, OCb = (OC + 63) / 64, NB = bf3_nb(OC);
+  const size_t elems = (size_t)KH * KW * Cin * Cout;
+  uint4* dst = reinterpret_cast<uint4*>(static_cast<char*>(packed_base) + bf3_prepared_offset(elems));
+  const long items = (long)KH * KW * ICc * OCb * 4 * NB;
+  hipLaunchKernelGGL(k_bf3_pack, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, w, dst, Cout, Cin, KH, KW,
+                     transposed, ps_r, bwd, IC, OC, ICc, OCb, NB);
+  return check_launch("bf3_pack_prepared");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
+                                                 0);
+}
+
+// halo chunk: channels [cb, cb+32) of every halo pixel -> hi/lo planes.
+// thread -> (8-channel group g = tid&3, pixel slot tid>>2); pixels advance by 64 per pass with an
+// incremental (row, col) update instead of a division per item.
+__device__ __forceinline__ void bf3_stage_halo(const Bf3Params& B, uint4* hal, int n, int r0, int c0, int cb) {
+  const MfmaConvParams& P = B.P;
+  const int npix = P.HH * P.HW;
+  const int g = threadIdx.x & 3;
+  int hp = threadIdx.x >> 2;
+  int hy = hp / P.HW, hx = hp - hy * P.HW;
+  const int dy64 = 64 / P.HW, dx64 = 64 - dy64 * P.HW;
+  const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
+  const int ch = cb + g * 8;
+  const bool ch_any = ch < P.IC, ch_vec = P.vec_in && ch + 7 < P.IC;
+  const size_t img = (size_t)n * P.IH;
+  for (; hp < npix; hp += 64) {
+    const int iy = iyb + hy, ix = ixb + hx;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = 0.f;
+    if (ch_any && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) {
+      const size_t off = ((img + iy) * P.IW + ix) * P.IC + ch;
+      if (ch_vec) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(P.in + off);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(P.in + off + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f[e] = v0[e];
+          f[4 + e] = v1[e];
+        }
+        if (P.mask_y) {
+          const f32x4 m0 = *reinterpret_cast<const f32x4*>(P.mask_y + off);
+          const f32x4 m1 = *reinterpret_cast<const f32x4*>(P.mask_y + off + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            f[e] = m0[e] > 0.f ? f[e] : f[e] * P.mask_slope;
+            f[4 + e] = m1[e] > 0.f ? f[4 + e] : f[4 + e] * P.mask_slope;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (ch + e < P.IC) {
+            float x = P.in[off + e];
+            if (P.mask_y) x = P.mask_y[off + e] > 0.f ? x : x * P.mask_slope;
+            f[e] = x;
+          }
+        }
+      }
+    }
+    uint4 hi, lo;
+    split8(f, hi, lo);
+    hal[(0 * 4 + g) * B.NPIXp + hp] = hi;
+    hal[(1 * 4 + g) * B.NPIXp + hp] = lo;
+    hy += dy64;
+    hx += dx64;
+    if (hx >= P.HW) {
+      hx -= P.HW;
+      ++hy;
+    }
+  }
+}
+
+constexpr int BF3_MAXTAPS = 128;   // taps with precomputed tables (larger kernels: computed on the fly)
+constexpr int BF3_EPI_STRIDE = 68; // floats per staged output row (64 + 4: conflict-free float4 rows)
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_conv_bf3(Bf3Params B) {
+  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+  __shared__ int tap_toff[BF3_MAXTAPS];
+  __shared__ int tap_wtap[BF3_MAXTAPS];
+  const MfmaConvParams& P = B.P;
+  uint4* hal = smem4;                       // [2][4][NPIXp]
+  uint4* wl = smem4 + 8 * B.NPIXp;          // [2 bufs][2][4][NB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  int b = blockIdx.x;
+  const int txi = b % P.tiles_x;
+  b /= P.tiles_x;
+  const int tyi = b % P.tiles_y;
+  const int n = b / P.tiles_y;
+  const int r0 = tyi * P.TH, c0 = txi * P.TW;
+  const int ocbi = blockIdx.y;
+  const int ocb = ocbi * 64;
+  const int npx = P.TH * P.TW;
+  const int NB = B.NB;
+  const int wslot = 8 * NB;  // uint4 per weight buffer
+  const int T = P.KHv * P.KWv;
+
+  for (int t = tid; t < T && t < BF3_MAXTAPS; t += 256) {
+    const int u = t / P.KWv, v = t - u * P.KWv;
+    tap_toff[t] = u * P.HW + v;
+    tap_wtap[t] = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
+  }
+
+  int hp[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    int m = wave * 64 + mt * 16 + j;
+    if (m >= npx) m = 0;
+    const int r = m / P.TW, c = m - r * P.TW;
+    hp[mt] = (r * P.is) * P.HW + c * P.is + kq * B.NPIXp;
+  }
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const bool wave_live = wave * 64 < npx;
+  const bool w0_ok = tid < wslot, w1_ok = tid + 256 < wslot;
+  const int lo_plane = 4 * B.NPIXp;
+  const int wlane = kq * NB + j;
+
+  if (T > 0) {
+    for (int cc = 0; cc < B.ICc; ++cc) {
+      __syncthreads();  // previous chunk fully consumed (and the tap tables visible)
+      auto wsrc = [&](int t) -> const uint4* {
+        int tapw;
+        if (t < BF3_MAXTAPS) {
+          tapw = tap_wtap[t];
+        } else {
+          const int u = t / P.KWv, v = t - u * P.KWv;
+          tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
+        }
+        return B.wq + ((size_t)(tapw * B.ICc + cc) * B.OCb + ocbi) * (size_t)wslot;
+      };
+      bf3_stage_halo(B, hal, n, r0, c0, cc * 32);
+      {
+        const uint4* src = wsrc(0);
+        if (w0_ok) wl[tid] = src[tid];
+        if (w1_ok) wl[tid + 256] = src[tid + 256];
+      }
+      __syncthreads();
+      for (int t = 0; t < T; ++t) {
+        uint4 wr0 = {0, 0, 0, 0}, wr1 = {0, 0, 0, 0};
+        if (t + 1 < T) {  // prefetch the next tap's slice; lands while the MFMAs below run
+          const uint4* src = wsrc(t + 1);
+          if (w0_ok) wr0 = src[tid];
+          if (w1_ok) wr1 = src[tid + 256];
+        }
+        if (wave_live) {
+          int toff;
+          if (t < BF3_MAXTAPS) {
+            toff = tap_toff[t];
+          } else {
+            const int u = t / P.KWv, v = t - u * P.KWv;
+            toff = u * P.HW + v;
+          }
+          const uint4* wb = wl + (t & 1) * wslot + wlane;
+          const uint4* hb = hal + toff;
+          uint4 ah[4], al[4];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            ah[mt] = hb[hp[mt]];
+            al[mt] = hb[hp[mt] + lo_plane];
+          }
+          uint4 bh[NT], bl[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            bh[nt] = wb[nt * 16];
+            bl[nt] = wb[4 * NB + nt * 16];
+          }
+          // three passes, each over 4*NT independent accumulators (no back-to-back dependency)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_bf16(al[mt], bh[nt], acc[mt][nt]);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_bf16(ah[mt], bl[nt], acc[mt][nt]);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_bf16(ah[mt], bh[nt], acc[mt][nt]);
+        }
+        if (t + 1 < T) {
+          uint4* wn = wl + ((t + 1) & 1) * wslot;
+          if (w0_ok) wn[tid] = wr0;
+          if (w1_ok) wn[tid + 256] = wr1;
+        }
+        __syncthreads();
+      }
+    }
+  }
+  // ---- epilogue: accumulators -> LDS (wave-private 32 x 64 slab, two halves) -> 16-byte stores.
+  // C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
+  __syncthreads();
+  float* st = reinterpret_cast<float*>(smem4) + wave * (32 * BF3_EPI_STRIDE);
+  constexpr int Q4 = NT * 4;  // float4 columns per row
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+          st[(mh * 16 + kq * 4 + reg) * BF3_EPI_STRIDE + nt * 16 + j] = acc[2 * h + mh][nt][reg];
+    __syncthreads();
+    for (int it = lane; it < 32 * Q4; it += 64) {
+      const int row = it / Q4, q4 = it - row * Q4;
+      const int m = wave * 64 + h * 32 + row;
+      if (m < npx) {
+        const int r = m / P.TW, c = m - r * P.TW;
+        const int pr = r0 + r, pc = c0 + c;
+        const int oc = ocb + q4 * 4;
+        if (pr < P.PH && pc < P.PW && oc < P.OC) {
+          const epi_f4 v = *reinterpret_cast<const epi_f4*>(st + row * BF3_EPI_STRIDE + q4 * 4);
+          epi_store4(P.ep, P.OH, P.OW, P.OC, n, P.oy0 + pr * P.os, P.ox0 + pc * P.os, oc, v, P.out);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+static void bf3_launch(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s) {
+  static int cur = 0;
+  if ((int)lds > cur) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bf3<NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    cur = (int)lds;
+  }
+  hipLaunchKernelGGL(k_conv_bf3<NT>, grid, dim3(256), lds, s, B);
+}
+
+bool conv_bf3_gather_supported(const GatherConv& g, const Epi& ep) {
+  (void)ep;
+  if (g.IC < 8 || g.OC < 8) return false;  // tiny channel counts: tap-group / direct / fp32 kernels
+  if (g.KH * g.KW > 32 * 32) return false;
+  if ((long)g.N * g.OH * g.OW > (1L << 30)) return false;
+  return true;
+}
+
+static int bf3_launch_phase(MfmaConvParams P, const uint4* wq, hipStream_t s) {
+  Bf3Params B{};
+  const int NT = P.OC >= 64 ? 4 : (P.OC + 15) / 16;
+  B.NB = NT * 16;
+  B.ICc = (P.IC + 31) / 32;
+  B.OCb = (P.OC + 63) / 64;
+  B.wq = wq;
+  const int wbytes = 2 * 8 * B.NB * 16;
+  // halo pixel = 128 B (2 planes x 4 groups x 16 B); try 2 blocks/CU first, fall back to 1 block/CU
+  TilePick best{};
+  bool ok = pick_tile(256, P.PH, P.PW, P.is, P.KHv > 0 ? P.KHv : 1, P.KWv > 0 ? P.KWv : 1, 32,
+                      (kLdsBudgetBytes - wbytes) / 4 - 16 * 32, best);
+  if (!ok || best.eff < 0.6) {
+    TilePick big{};
+    if (pick_tile(256, P.PH, P.PW, P.is, P.KHv > 0 ? P.KHv : 1, P.KWv > 0 ? P.KWv : 1, 32,
+                  (156 * 1024 - wbytes) / 4 - 16 * 32, big) &&
+        (!ok || big.eff > best.eff * 1.2)) {
+      best = big;
+      ok = true;
+    }
+  }
+  if (!ok) {
+    set_error("conv_bf3: no tile fits LDS");
+    return SRK_ERR_UNSUPPORTED;
+  }
+  P.TH = best.TH; P.TW = best.TW; P.tiles_y = best.tiles_y; P.tiles_x = best.tiles_x; P.HH = best.HH; P.HW = best.HW;
+  B.NPIXp = (best.HH * best.HW + 15) & ~15;
+  B.P = P;
+  size_t lds = (size_t)8 * B.NPIXp * 16 + wbytes;
+  const size_t epi_bytes = (size_t)4 * 32 * BF3_EPI_STRIDE * sizeof(float);
+  if (lds < epi_bytes) lds = epi_bytes;
+  dim3 grid((unsigned)((size_t)P.tiles_x * P.tiles_y * P.N), B.OCb);
+  switch (NT) {
+    case 1: bf3_launch<1>(B, grid, lds, s); break;
+    case 2: bf3_launch<2>(B, grid, lds, s); break;
+    case 3: bf3_launch<3>(B, grid, lds, s); break;
+    default: bf3_launch<4>(B, grid, lds, s); break;
+  }
+  return check_launch("conv_bf3");
+}
+
+int conv_bf3_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
+                    const float* mask_y, float mask_slope, hipStream_t s) {
+  const size_t elems = (size_t)g.KH * g.KW * g.IC * g.OC;
+  const uint4* wq = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wp) + bf3_prepared_offset(elems));
+  return for_each_phase(g, in, wp, out, ep, mask_y, mask_slope,
+                        [&](const MfmaConvParams& P) { return bf3_launch_phase(P, wq, s); });
+}
+
+}  // namespace srk

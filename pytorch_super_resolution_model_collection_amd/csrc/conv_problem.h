@@ -84,4 +84,13 @@ bool conv_mfma_gather_supported(const GatherConv& g, const Epi& ep);
 int conv_mfma_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
                      const float* mask_y, float mask_slope, hipStream_t s);
 
+// Implemented in conv_mfma_bf16.hip
+size_t bf3_prepared_offset(size_t elems);
+size_t bf3_prepared_bytes(int IC, int OC, int T);
+int bf3_pack_prepared(const float* w, void* packed_base, int Cout, int Cin, int KH, int KW, int transposed, int ps_r,
+                      int bwd, hipStream_t s);
+bool conv_bf3_gather_supported(const GatherConv& g, const Epi& ep);
+int conv_bf3_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
+                    const float* mask_y, float mask_slope, hipStream_t s);
+
 }  // namespace srk

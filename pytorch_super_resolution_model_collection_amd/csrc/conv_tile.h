@@ -1,0 +1,168 @@
+// Shared host/device definitions of the halo-tiled convolution kernels (fp32 MFMA, bf16x3 MFMA,
+// direct): launch parameters, the tile picker and the phase decomposition of strided gathers.
+#pragma once
+#include "srk_common.h"
+#include "conv_problem.h"
+
+namespace srk {
+
+struct MfmaConvParams {
+  const float* in;
+  const float* wp;
+  float* out;
+  const float* mask_y;
+  float mask_slope;
+  Epi ep;
+  int N, IH, IW, IC;
+  int OH, OW, OC;
+  // phase space: this launch produces outputs (oy0 + r*os, ox0 + c*os), r < PH, c < PW;
+  // virtual tap (u,v) reads input (r*is + iy0 + u, c*is + ix0 + v) and weight tap
+  // (wh0 + wdh*u, ww0 + wdw*v).
+  int PH, PW, oy0, ox0, os;
+  int iy0, ix0, is;
+  int KHv, KWv, wh0, wdh, ww0, wdw, KW_full;
+  int TH, TW, tiles_y, tiles_x, HH, HW;
+  int CK;   // input-channel chunk staged per pass (multiple of 16, <= 64)
+  int PSA;  // halo pixel stride in floats (CK + 4, or 4 for the tap-group variant)
+  int BNp;  // LDS filter row stride in floats (NT*16 + 4)
+  int halo_floats;
+  int vec_in, vec_w;
+};
+
+static constexpr int kLdsBudgetBytes = 78 * 1024;  // 2 blocks per CU out of 160 KiB
+
+struct TilePick {
+  int TH, TW, tiles_y, tiles_x, HH, HW;
+  double eff;
+};
+
+// Choose the <=128-pixel tile (any aspect, any width) that covers PH x PW with the fewest tiles
+// under the LDS budget; ties -> smaller halo.
+static inline bool pick_tile(int maxpix, int PH, int PW, int is, int KHv, int KWv, int psa, int budget_floats,
+                      TilePick& best) {
+  bool found = false;
+  long best_tiles = 0, best_halo = 0;
+  const int maxTW = PW < maxpix ? PW : maxpix;
+  for (int TW = 1; TW <= maxTW; ++TW) {
+    int TH = maxpix / TW;
+    if (TH > PH) TH = PH;
+    for (; TH >= 1; --TH) {
+      const int HH = (TH - 1) * is + KHv, HWd = (TW - 1) * is + KWv;
+      if ((long)HH * HWd * psa <= budget_floats) {
+        const long tiles = (long)cdiv(PH, TH) * cdiv(PW, TW);
+        const long halo = (long)HH * HWd * tiles;
+        if (!found || tiles < best_tiles || (tiles == best_tiles && halo < best_halo)) {
+          found = true;
+          best_tiles = tiles;
+          best_halo = halo;
+          best = TilePick{TH, TW, (int)cdiv(PH, TH), (int)cdiv(PW, TW), HH, HWd,
+                          (double)PH * PW / ((double)tiles * (double)maxpix)};
+        }
+        break;  // smaller TH only gets worse for this TW
+      }
+    }
+  }
+  return found;
+}
+
+
+// Fills the geometry of `P` from the gather problem and calls launch(P) once (CONV gather, TRANS
+// gather with stride 1) or once per output phase (TRANS gather with stride s: s*s launches).
+template <typename Launch>
+static inline int for_each_phase(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
+                                 const float* mask_y, float mask_slope, Launch launch) {
+  MfmaConvParams P{};
+  P.in = in; P.wp = wp; P.out = out; P.mask_y = mask_y; P.mask_slope = mask_slope; P.ep = ep;
+  P.N = g.N; P.IH = g.IH; P.IW = g.IW; P.IC = g.IC; P.OH = g.OH; P.OW = g.OW; P.OC = g.OC;
+  P.KW_full = g.KW;
+  P.vec_in = (g.IC % 4 == 0) && ((uintptr_t)in % 16 == 0) && (!mask_y || (uintptr_t)mask_y % 16 == 0);
+  P.vec_w = (g.OC % 4 == 0) && ((uintptr_t)wp % 16 == 0);
+  if (!g.trans) {
+    P.PH = g.OH; P.PW = g.OW; P.oy0 = 0; P.ox0 = 0; P.os = 1;
+    P.iy0 = -g.pad; P.ix0 = -g.pad; P.is = g.stride;
+    P.KHv = g.KH; P.KWv = g.KW; P.wh0 = 0; P.wdh = 1; P.ww0 = 0; P.wdw = 1;
+    return launch(P);
+  }
+  // TRANS gather: iy = (oy + p - kh)/s.  One launch per output phase (py,px) = ((oy+p)%s, (ox+p)%s).
+  const int st = g.stride;
+  for (int py = 0; py < st; ++py) {
+    const int oy0 = (((py - g.pad) % st) + st) % st;
+    if (oy0 >= g.OH) continue;
+    const int KHv = py < g.KH ? (g.KH - py + st - 1) / st : 0;
+    const int by = (oy0 + g.pad - py) / st;
+    for (int px = 0; px < st; ++px) {
+      const int ox0 = (((px - g.pad) % st) + st) % st;
+      if (ox0 >= g.OW) continue;
+      const int KWv = px < g.KW ? (g.KW - px + st - 1) / st : 0;
+      const int bx = (ox0 + g.pad - px) / st;
+      MfmaConvParams Q = P;
+      Q.PH = (g.OH - oy0 + st - 1) / st;
+      Q.PW = (g.OW - ox0 + st - 1) / st;
+      Q.oy0 = oy0; Q.ox0 = ox0; Q.os = st; Q.is = 1;
+      if (KHv == 0 || KWv == 0) {
+        Q.KHv = 0; Q.KWv = 0; Q.iy0 = 0; Q.ix0 = 0; Q.wh0 = 0; Q.wdh = 0; Q.ww0 = 0; Q.wdw = 0;
+      } else {
+        Q.KHv = KHv; Q.KWv = KWv;
+        Q.iy0 = by - (KHv - 1); Q.ix0 = bx - (KWv - 1);
+        Q.wh0 = py + st * (KHv - 1); Q.wdh = -st;
+        Q.ww0 = px + st * (KWv - 1); Q.wdw = -st;
+      }
+      const int rc = launch(Q);
+      if (rc) return rc;
+    }
+  }
+  return SRK_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Vector epilogue: 4 consecutive packed output channels [oc, oc+4) of output pixel (n, oy, ox).
+// Used by the LDS-staged epilogues (each lane owns 16 bytes of one pixel -> coalesced stores).
+//   out = PS_r(act(v + bias)) + residual, see struct Epi.
+// ---------------------------------------------------------------------------------------------
+typedef float epi_f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void epi_store4(const Epi& ep, int OH, int OW, int OC, int n, int oy, int ox, int oc,
+                                           epi_f4 v, float* __restrict__ out) {
+  size_t off;
+  int c_first;
+  bool run_ok;
+  if (ep.ps_r > 1) {
+    const int r = ep.ps_r;
+    const int C = OC / (r * r);
+    const int RL = r * C;  // (j, c) run: contiguous floats of one output row segment
+    const int i = oc / RL, rem = oc - i * RL;
+    off = (((size_t)n * OH * r + (size_t)oy * r + i) * ((size_t)OW * r) + (size_t)ox * r) * C + rem;
+    c_first = rem % C;
+    run_ok = rem + 3 < RL;
+  } else {
+    off = (((size_t)n * OH + oy) * OW + ox) * OC + oc;
+    c_first = oc;
+    run_ok = true;
+  }
+  const bool full = oc + 3 < OC && run_ok;
+  const bool simple_act = !(ep.act == SRK_ACT_PRELU && ep.prelu_n > 1);
+  if (full && simple_act && (off & 3) == 0 && (!ep.bias || (oc & 3) == 0)) {
+    if (ep.bias) {
+      const epi_f4 b = *reinterpret_cast<const epi_f4*>(ep.bias + oc);
+      v += b;
+    }
+    if (ep.act != SRK_ACT_NONE) {
+      const float a = ep.act == SRK_ACT_PRELU ? ep.prelu_w[0] : ep.slope;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], ep.act, a);
+    }
+    if (ep.residual) v += *reinterpret_cast<const epi_f4*>(ep.residual + off);
+    *reinterpret_cast<epi_f4*>(out + off) = v;
+    return;
+  }
+  // ragged / unaligned / per-channel-PReLU tail: element-wise through the scalar path
+  GatherConv g{};
+  g.OH = OH; g.OW = OW; g.OC = OC;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (oc + e < OC) epi_store(ep, g, v[e], n, oy, ox, oc + e, out);
+  (void)c_first;
+}
+
+}  // namespace srk

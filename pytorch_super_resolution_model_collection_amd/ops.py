@@ -15,6 +15,39 @@ from ._lib import (ACT_BY_NAME, ACT_LRELU, ACT_NONE, ACT_PRELU, ACT_RELU, ALGO_A
 
 CL = torch.channels_last
 
+# Convolution arithmetic used when a ConvCfg leaves algo = AUTO, per role:
+#   infer     forward under torch.no_grad()
+#   train_fwd forward that will be differentiated
+#   bwd       data gradient
+# Modes:
+#   "mixed"  (default) infer = bf16x3, train_fwd = exact fp32 MFMA, bwd = bf16x3.
+#            The training forward stays exact so that ReLU / LeakyReLU masks are decided on fp32
+#            values (a 5e-6 forward perturbation flips ~1e-5 of the units of a bias-free ReLU net, and
+#            one flipped unit moves that layer's gradient by ~1/sqrt(units) ~ 1e-2); gradients then
+#            only carry the ~5e-6 arithmetic error of the bf16x3 data-gradient kernels.
+#   "bf16x3" everything on the 3-term bf16 split (fastest; forward error ~1e-5, gradients subject to
+#            the mask-flip sensitivity above).
+#   "fp32"   everything exact fp32 (summation-order-level agreement with ATen/oneDNN).
+_MODES = {"mixed": {"infer": ALGO_AUTO, "train_fwd": _lib.ALGO_MFMA, "bwd": ALGO_AUTO},
+          "bf16x3": {"infer": ALGO_AUTO, "train_fwd": ALGO_AUTO, "bwd": ALGO_AUTO},
+          "fp32": {"infer": _lib.ALGO_MFMA, "train_fwd": _lib.ALGO_MFMA, "bwd": _lib.ALGO_MFMA}}
+_PRECISION = {"mode": "mixed"}
+
+
+def set_precision(mode):
+    """Select the convolution arithmetic: 'mixed' (default), 'bf16x3' or 'fp32' (see above)."""
+    if mode not in _MODES:
+        raise ValueError("precision must be one of %s" % sorted(_MODES))
+    _PRECISION["mode"] = mode
+
+
+def get_precision():
+    return _PRECISION["mode"]
+
+
+def _algo_for(cfg, role):
+    return cfg.algo if cfg.algo != ALGO_AUTO else _MODES[_PRECISION["mode"]][role]
+
 
 def _empty_cl(n, c, h, w, like):
     return torch.empty((n, c, h, w), dtype=torch.float32, device=like.device, memory_format=CL)
@@ -99,7 +132,7 @@ def _weight_dims(weight, transposed):
     return cout, cin, kh, kw
 
 
-def _make_desc(x_shape, weight, cfg):
+def _make_desc(x_shape, weight, cfg, role="infer"):
     lib = _lib.load()
     n, c, h, w = x_shape
     cout, cin, kh, kw = _weight_dims(weight, cfg.transposed)
@@ -109,14 +142,15 @@ def _make_desc(x_shape, weight, cfg):
     ow = lib.srk_conv_out_dim(w, kw, cfg.stride, cfg.pad, int(cfg.transposed), cfg.out_pad)
     if oh <= 0 or ow <= 0:
         raise RuntimeError("conv: empty output for input %s kernel %dx%d" % (tuple(x_shape), kh, kw))
-    return ConvDesc(n, h, w, cin, oh, ow, cout, kh, kw, cfg.stride, cfg.pad, int(cfg.transposed), cfg.out_pad,
-                    cfg.algo)
+    algo = _algo_for(cfg, role)
+    return ConvDesc(n, h, w, cin, oh, ow, cout, kh, kw, cfg.stride, cfg.pad, int(cfg.transposed), cfg.out_pad, algo)
 
 
 def pack_weight_fwd(weight, transposed, ps_r):
     lib = _lib.load()
     cout, cin, kh, kw = _weight_dims(weight, transposed)
-    wp = torch.empty(kh * kw * cin * cout, dtype=torch.float32, device=weight.device)
+    nbytes = int(lib.srk_packed_weight_bytes(cout, cin, kh, kw, 0))
+    wp = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=weight.device)
     check(lib.srk_pack_weight_fwd(ptr(weight), ptr(wp), cout, cin, kh, kw, int(transposed), int(ps_r), stream_ptr()),
           "srk_pack_weight_fwd")
     return wp
@@ -125,7 +159,8 @@ def pack_weight_fwd(weight, transposed, ps_r):
 def pack_weight_bwd(weight, transposed):
     lib = _lib.load()
     cout, cin, kh, kw = _weight_dims(weight, transposed)
-    wp = torch.empty(kh * kw * cin * cout, dtype=torch.float32, device=weight.device)
+    nbytes = int(lib.srk_packed_weight_bytes(cout, cin, kh, kw, 1))
+    wp = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=weight.device)
     check(lib.srk_pack_weight_bwd(ptr(weight), ptr(wp), cout, cin, kh, kw, int(transposed), stream_ptr()),
           "srk_pack_weight_bwd")
     return wp
@@ -140,10 +175,10 @@ def pack_bias_ps(bias, ps_r):
     return bp
 
 
-def conv_forward_raw(x, wp, bias_p, weight_shape_src, cfg, prelu_w=None, residual=None):
+def conv_forward_raw(x, wp, bias_p, weight_shape_src, cfg, prelu_w=None, residual=None, role="infer"):
     """Launch srk_conv2d_forward on already-packed weights. x must be NHWC-dense."""
     lib = _lib.load()
-    d = _make_desc(x.shape, weight_shape_src, cfg)
+    d = _make_desc(x.shape, weight_shape_src, cfg, role)
     r = cfg.ps_r if cfg.ps_r > 1 else 1
     y = _empty_cl(d.N, d.Cout // (r * r), d.OH * r, d.OW * r, x)
     if residual is not None and tuple(residual.shape) != tuple(y.shape):
@@ -169,7 +204,7 @@ class _Conv2d(torch.autograd.Function):
         else:
             wp = pack_weight_fwd(weight, cfg.transposed, cfg.ps_r)
             bp = pack_bias_ps(bias, cfg.ps_r)
-        y = conv_forward_raw(x, wp, bp, weight, cfg, None, residual)
+        y = conv_forward_raw(x, wp, bp, weight, cfg, None, residual, "train_fwd")
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
@@ -185,7 +220,7 @@ class _Conv2d(torch.autograd.Function):
         cfg = ctx.cfg
         x, weight, y = ctx.saved_tensors
         dy = to_nhwc(dy if (_is_nchw_dense(dy) or _is_nhwc_dense(dy)) else dy.contiguous())
-        d = _make_desc(x.shape, weight, cfg)
+        d = _make_desc(x.shape, weight, cfg, "bwd")
         dres = dy if ctx.has_res else None
         dyc = dy
         if cfg.ps_r > 1:

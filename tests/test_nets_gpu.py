@@ -24,9 +24,20 @@ TOL_FWD = 1e-4   # contract: 1e-3
 TOL_GRAD = 5e-4  # contract: 1e-3
 
 
-@pytest.mark.parametrize("name", list(CASES))
-def test_net_forward_backward(gpu, nets_golden, name):
+@pytest.fixture(autouse=True)
+def _restore_precision():
     import pytorch_super_resolution_model_collection_amd as pkg
+    yield
+    pkg.ops.set_precision("mixed")
+
+
+@pytest.mark.parametrize("precision", ["mixed", "fp32"])
+@pytest.mark.parametrize("name", list(CASES))
+def test_net_forward_backward(gpu, nets_golden, name, precision):
+    """Default ('mixed': exact-fp32 training forward, bf16x3 data gradients) and all-fp32 arithmetic:
+    forward, input gradient, every parameter gradient and BN running statistics."""
+    import pytorch_super_resolution_model_collection_amd as pkg
+    pkg.ops.set_precision(precision)
     cls, args, ishape, gain = CASES[name]
     net = getattr(pkg, cls)(*args)
     fill.fill_module(net, 1234, gain)
@@ -61,11 +72,38 @@ def test_net_forward_backward(gpu, nets_golden, name):
             assert rel_err(net(x.detach()), nets_golden[name + ".eval_out"]) < TOL_FWD
 
 
+@pytest.mark.parametrize("name", list(CASES))
+def test_net_inference_bf16x3_forward(gpu, nets_golden, name):
+    """Inference default: the bf16x3 split-MFMA kernels with fully fused epilogues, against the
+    reference vectors (eval-mode vectors for the BatchNorm nets)."""
+    import pytorch_super_resolution_model_collection_amd as pkg
+    cls, args, ishape, gain = CASES[name]
+    net = getattr(pkg, cls)(*args)
+    fill.fill_module(net, 1234, gain)
+    net.to(gpu)
+    x = fill.rand(ishape, 4321).to(gpu)
+    if name.startswith("srgan"):
+        # eval-mode golden outputs were taken after one training forward updated the running stats
+        net.train()
+        net(x.clone().requires_grad_(True))
+        net.eval()
+        with torch.no_grad():
+            assert rel_err(net(x), nets_golden[name + ".eval_out"]) < TOL_FWD
+        return
+    net.eval()
+    with torch.no_grad():
+        out = net(x)
+    outs = out if isinstance(out, (tuple, list)) else (out,)
+    for i, o in enumerate(outs):
+        assert rel_err(o, nets_golden["%s.out%d" % (name, i)]) < TOL_FWD
+
+
 @pytest.mark.parametrize("name", ["espcn", "vdsr", "edsr", "srgan_g", "lapsrn", "fsrcnn"])
 def test_net_inference_matches_training_forward(gpu, name):
     """The fused no-grad path (cached packed weights, fused PReLU/residual epilogues) must equal
     the autograd path's forward."""
     import pytorch_super_resolution_model_collection_amd as pkg
+    pkg.ops.set_precision("fp32")
     cls, args, ishape, gain = CASES[name]
     net = getattr(pkg, cls)(*args)
     fill.fill_module(net, 1234, gain)

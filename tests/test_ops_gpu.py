@@ -13,7 +13,9 @@ from oracle.kat_table import CONV_KATS, conv_case_inputs
 
 pytestmark = pytest.mark.gpu
 
-ALGOS = {"auto": 0, "generic": 1}
+ALGOS = {"auto": 0, "generic": 1, "mfma_fp32": 2}
+# AUTO runs the bf16x3 split-MFMA kernel where it applies (~1e-5 rel); the fp32 algos are exact-order fp32
+TOL_ALGO = {"auto": 1e-4, "generic": TOL_TIGHT, "mfma_fp32": TOL_TIGHT}
 ACTS = {None: 0, "relu": 1, "lrelu": 3}
 
 
@@ -22,7 +24,7 @@ def _pkg():
     return pkg
 
 
-@pytest.mark.parametrize("algo", ["auto", "generic"])
+@pytest.mark.parametrize("algo", ["auto", "generic", "mfma_fp32"])
 @pytest.mark.parametrize("idx", range(len(CONV_KATS)), ids=[c[0] for c in CONV_KATS])
 def test_conv_forward_backward(gpu, ops_kat, idx, algo):
     pkg = _pkg()
@@ -35,11 +37,12 @@ def test_conv_forward_backward(gpu, ops_kat, idx, algo):
     cfg = ops.ConvCfg(s, p, bool(tr), op, ACTS[act], 0.2 if act == "lrelu" else 0.0, 0, ALGOS[algo])
     y = ops.conv2d(xg, wg, bg, None, cfg)
     assert tuple(y.shape) == tuple(g.shape)
-    assert rel_err(y, ops_kat["conv.%s.y" % tag]) < TOL_TIGHT
+    tol = TOL_ALGO[algo]
+    assert rel_err(y, ops_kat["conv.%s.y" % tag]) < tol
     y.backward(g.to(gpu))
-    assert rel_err(xg.grad, ops_kat["conv.%s.dx" % tag]) < TOL_TIGHT
-    assert rel_err(wg.grad, ops_kat["conv.%s.dw" % tag]) < TOL_TIGHT
-    assert rel_err(bg.grad, ops_kat["conv.%s.db" % tag]) < TOL_TIGHT
+    assert rel_err(xg.grad, ops_kat["conv.%s.dx" % tag]) < tol
+    assert rel_err(wg.grad, ops_kat["conv.%s.dw" % tag]) < tol
+    assert rel_err(bg.grad, ops_kat["conv.%s.db" % tag]) < tol
 
 
 @pytest.mark.parametrize("idx", [0, 3, 9, 10], ids=lambda i: CONV_KATS[i][0])
@@ -55,7 +58,7 @@ def test_conv_infer_fused_epilogue(gpu, idx):
     cfg = ops.ConvCfg(s, p, False, 0, pkg._lib.ACT_PRELU)
     with torch.no_grad():
         y = ops.conv2d_infer(x.to(gpu), w.to(gpu), b.to(gpu), res.to(gpu), cfg, slope.to(gpu))
-    assert rel_err(y, ref) < TOL_TIGHT
+    assert rel_err(y, ref) < 1e-4
 
 
 @pytest.mark.parametrize("r,C", [(2, 64), (4, 3), (3, 2)])
@@ -72,11 +75,11 @@ def test_conv_fused_pixel_shuffle(gpu, r, C):
     ref.backward(g)
     xg, wg, bg = (t.to(gpu).requires_grad_(True) for t in (x, w, b))
     y = ops.conv2d(xg, wg, bg, None, ops.ConvCfg(1, 1, False, 0, 0, 0.0, r))
-    assert rel_err(y, ref) < TOL_TIGHT
+    assert rel_err(y, ref) < 1e-4
     y.backward(g.to(gpu))
-    assert rel_err(xg.grad, xr.grad) < TOL_TIGHT
-    assert rel_err(wg.grad, wr.grad) < TOL_TIGHT
-    assert rel_err(bg.grad, br.grad) < TOL_TIGHT
+    assert rel_err(xg.grad, xr.grad) < 1e-4
+    assert rel_err(wg.grad, wr.grad) < 1e-4
+    assert rel_err(bg.grad, br.grad) < 1e-4
 
 
 @pytest.mark.parametrize("r", [2, 4, 3])

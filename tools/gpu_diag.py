@@ -34,7 +34,7 @@ def kat_table():
     print("%-14s %-8s %10s %10s %10s %10s" % ("case", "algo", "y", "dx", "dw", "db"))
     for idx, c in enumerate(CONV_KATS):
         tag, cin, cout, k, s, p, tr, op, H, W, N, act = c
-        for algo_name, algo in (("auto", 0), ("generic", 1)):
+        for algo_name, algo in (("auto", 0), ("mfma32", 2), ("generic", 1)):
             x, w, b, g = conv_case_inputs(idx)
             xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x, w, b))
             try:
@@ -80,12 +80,15 @@ def timing():
         b = torch.randn(cout, device=dev)
         cfg = ops.ConvCfg(1, pad, False, 0, act, 0.0, ps)
         wp, bp = ops.pack_weight_fwd(w, False, ps), ops.pack_bias_ps(b, ps)
-        with torch.no_grad():
-            ms = time_fn(lambda: ops.conv2d_infer(x, w, b, None, cfg, None, (wp, bp)))
         oh, ow = H + 2 * pad - k + 1, W + 2 * pad - k + 1
         flop = 2.0 * N * oh * ow * cout * cin * k * k
         byts = 4.0 * (N * H * W * cin + N * oh * ow * cout)
-        print("%-32s %8.3f ms  %7.1f TFLOP/s  %7.1f GB/s (compulsory)" % (tag, ms, flop / ms / 1e9, byts / ms / 1e6))
+        for aname, algo in (("auto", 0), ("fp32", 2)):
+            cfg.algo = algo
+            with torch.no_grad():
+                ms = time_fn(lambda: ops.conv2d_infer(x, w, b, None, cfg, None, (wp, bp)))
+            print("%-32s %-5s %8.3f ms  %7.1f TFLOP/s  %7.1f GB/s (compulsory)" % (tag, aname, ms, flop / ms / 1e9,
+                                                                                 byts / ms / 1e6))
     # training-direction kernels on the VDSR body shape
     N, C, H, W = 256, 64, 41, 41
     x = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
