@@ -101,6 +101,9 @@ __global__ __launch_bounds__(256) void k_bf3_pack(const float* __restrict__ w, u
   blk[(1 * 4 + g) * NB + col] = lo;
 }
 
+__global__ void k_bf3_pack_rows(const float* __restrict__ w, uint4* __restrict__ dst, int Cout, int Cin, int KH, int KW,
+                                int transposed, int ps_r, int bwd, int IC, int OC, int KS, int OCb, int NB);
+
 static inline int bf3_nb(int OC) { return OC >= 64 ? 64 : ((OC + 15) / 16) * 16; }
 
 size_t bf3_prepared_offset(size_t elems) { return (elems * sizeof(float) + 255) & ~(size_t)255; }
@@ -116,6 +119,14 @@ int bf3_pack_prepared(const float* w, void* packed_base, int Cout, int Cin, int 
   const int ICc = (IC + 31) / 32, OCb = (OC + 63) / 64, NB = bf3_nb(OC);
   const size_t elems = (size_t)KH * KW * Cin * Cout;
   uint4* dst = reinterpret_cast<uint4*>(static_cast<char*>(packed_base) + bf3_prepared_offset(elems));
+  const int gather_trans = bwd ? !transposed : transposed;
+  if (IC <= 4 && !gather_trans) {  // row-packed layout of k_conv_bf3_rows
+    const int KS = (KW + 7) / 8;
+    const long items = (long)KH * KS * OCb * 4 * NB;
+    hipLaunchKernelGGL(k_bf3_pack_rows, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, w, dst, Cout, Cin, KH,
+                       KW, transposed, ps_r, bwd, IC, OC, KS, OCb, NB);
+    return check_launch("bf3_pack_prepared_rows");
+  }
   const long items = (long)KH * KW * ICc * OCb * 4 * NB;
   hipLaunchKernelGGL(k_bf3_pack, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, w, dst, Cout, Cin, KH, KW,
                      transposed, ps_r, bwd, IC, OC, ICc, OCb, NB);
@@ -194,6 +205,43 @@ __device__ __forceinline__ void bf3_stage_halo(const Bf3Params& B, uint4* hal, i
 
 constexpr int BF3_MAXTAPS = 128;   // taps with precomputed tables (larger kernels: computed on the fly)
 constexpr int BF3_EPI_STRIDE = 68; // floats per staged output row (64 + 4: conflict-free float4 rows)
+
+// Epilogue shared by the bf16x3 kernels: accumulators -> LDS (wave-private 32 x 64 slab, two halves)
+// -> 16-byte coalesced stores.  C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
+template <int NT>
+__device__ __forceinline__ void bf3_epilogue(const MfmaConvParams& P, float* smem_f, const f32x4 (&acc)[4][NT], int n,
+                                             int r0, int c0, int ocb, int wave, int lane) {
+  const int j = lane & 15, kq = lane >> 4;
+  const int npx = P.TH * P.TW;
+  __syncthreads();
+  float* st = smem_f + wave * (32 * BF3_EPI_STRIDE);
+  constexpr int Q4 = NT * 4;  // float4 columns per row
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+          st[(mh * 16 + kq * 4 + reg) * BF3_EPI_STRIDE + nt * 16 + j] = acc[2 * h + mh][nt][reg];
+    __syncthreads();
+    for (int it = lane; it < 32 * Q4; it += 64) {
+      const int row = it / Q4, q4 = it - row * Q4;
+      const int m = wave * 64 + h * 32 + row;
+      if (m < npx) {
+        const int r = m / P.TW, c = m - r * P.TW;
+        const int pr = r0 + r, pc = c0 + c;
+        const int oc = ocb + q4 * 4;
+        if (pr < P.PH && pc < P.PW && oc < P.OC) {
+          const epi_f4 v = *reinterpret_cast<const epi_f4*>(st + row * BF3_EPI_STRIDE + q4 * 4);
+          epi_store4(P.ep, P.OH, P.OW, P.OC, n, P.oy0 + pr * P.os, P.ox0 + pc * P.os, oc, v, P.out);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
 
 template <int NT>
 __global__ __launch_bounds__(256, 2) void k_conv_bf3(Bf3Params B) {
@@ -315,36 +363,189 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3(Bf3Params B) {
       }
     }
   }
-  // ---- epilogue: accumulators -> LDS (wave-private 32 x 64 slab, two halves) -> 16-byte stores.
-  // C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
-  __syncthreads();
-  float* st = reinterpret_cast<float*>(smem4) + wave * (32 * BF3_EPI_STRIDE);
-  constexpr int Q4 = NT * 4;  // float4 columns per row
+  bf3_epilogue<NT>(P, reinterpret_cast<float*>(smem4), acc, n, r0, c0, ocb, wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-packed variant for IC <= 4 (CONV gathers: the 3->64 first layers).  A K step of 32 is one
+// kernel row segment: 8 kw positions x 4 (zero-padded) channels; lane group kq supplies kw slots
+// 2kq, 2kq+1, i.e. 16 contiguous bytes of the [pixel][4 x bf16] halo planes.  A 5x5x3 filter is 5
+// K steps (47 % dense) instead of 25 mostly-empty channel-padded taps.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bf3_pack_rows(const float* __restrict__ w, uint4* __restrict__ dst, int Cout,
+                                                       int Cin, int KH, int KW, int transposed, int ps_r, int bwd,
+                                                       int IC, int OC, int KS, int OCb, int NB) {
+  const long items = (long)KH * KS * OCb * 4 * NB;
+  const long it = (long)blockIdx.x * 256 + threadIdx.x;
+  if (it >= items) return;
+  const int col = (int)(it % NB);
+  long r = it / NB;
+  const int g = (int)(r % 4);
+  r /= 4;
+  const int ocb = (int)(r % OCb);
+  r /= OCb;
+  const int ks = (int)(r % KS);
+  const int kh = (int)(r / KS);
+  const int oc = ocb * 64 + col;
+  float f[8];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int e = 0; e < 8; ++e) {
+    const int kw = ks * 8 + 2 * g + (e >> 2), ic = e & 3;
+    float v = 0.f;
+    if (kw < KW && ic < IC && oc < OC) {
+      int ci = ic, co = oc;
+      if (bwd) {
+        ci = oc;
+        co = ic;
+      } else if (ps_r > 1) {
+        const int C = Cout / (ps_r * ps_r);
+        const int q = oc / C, c = oc - q * C;
+        co = c * ps_r * ps_r + q;
+      }
+      const size_t src = transposed ? ((((size_t)ci * Cout + co) * KH + kh) * KW + kw)
+                                    : ((((size_t)co * Cin + ci) * KH + kh) * KW + kw);
+      v = w[src];
+    }
+    f[e] = v;
+  }
+  uint4 hi, lo;
+  split8(f, hi, lo);
+  uint4* blk = dst + ((size_t)(kh * KS + ks) * OCb + ocb) * (size_t)(8 * NB);
+  blk[(0 * 4 + g) * NB + col] = hi;
+  blk[(1 * 4 + g) * NB + col] = lo;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_conv_bf3_rows(Bf3Params B) {
+  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+  const MfmaConvParams& P = B.P;
+  uint2* hal = reinterpret_cast<uint2*>(smem4);   // [2 planes][NPIXp] x (4 bf16)
+  uint4* wl = smem4 + B.NPIXp;                    // 2 planes * NPIXp * 8 B = NPIXp uint4
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  int b = blockIdx.x;
+  const int txi = b % P.tiles_x;
+  b /= P.tiles_x;
+  const int tyi = b % P.tiles_y;
+  const int n = b / P.tiles_y;
+  const int r0 = tyi * P.TH, c0 = txi * P.TW;
+  const int ocbi = blockIdx.y;
+  const int ocb = ocbi * 64;
+  const int npx = P.TH * P.TW;
+  const int NB = B.NB;
+  const int wslot = 8 * NB;
+  const int KS = B.ICc;           // K steps per kernel row
+  const int Q = P.KHv * KS;       // total K steps
+  const int npix = P.HH * P.HW;
+
+  // stage the whole (<=4 channel) halo once: one thread per pixel; pad pixels are zeroed (they are
+  // multiplied by zero filter taps and must be finite)
+  {
+    const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
+    for (int hp = tid; hp < B.NPIXp; hp += 256) {
+      float f[4] = {0.f, 0.f, 0.f, 0.f};
+      if (hp < npix) {
+        const int hy = hp / P.HW, hx = hp - hy * P.HW;
+        const int iy = iyb + hy, ix = ixb + hx;
+        if (iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) {
+          const size_t off = (((size_t)n * P.IH + iy) * P.IW + ix) * P.IC;
 #pragma unroll
-    for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-          st[(mh * 16 + kq * 4 + reg) * BF3_EPI_STRIDE + nt * 16 + j] = acc[2 * h + mh][nt][reg];
-    __syncthreads();
-    for (int it = lane; it < 32 * Q4; it += 64) {
-      const int row = it / Q4, q4 = it - row * Q4;
-      const int m = wave * 64 + h * 32 + row;
-      if (m < npx) {
-        const int r = m / P.TW, c = m - r * P.TW;
-        const int pr = r0 + r, pc = c0 + c;
-        const int oc = ocb + q4 * 4;
-        if (pr < P.PH && pc < P.PW && oc < P.OC) {
-          const epi_f4 v = *reinterpret_cast<const epi_f4*>(st + row * BF3_EPI_STRIDE + q4 * 4);
-          epi_store4(P.ep, P.OH, P.OW, P.OC, n, P.oy0 + pr * P.os, P.ox0 + pc * P.os, oc, v, P.out);
+          for (int e = 0; e < 4; ++e)
+            if (e < P.IC) {
+              float x = P.in[off + e];
+              if (P.mask_y) x = P.mask_y[off + e] > 0.f ? x : x * P.mask_slope;
+              f[e] = x;
+            }
         }
       }
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const __bf16 hh = (__bf16)f[e];
+        h[e] = hh;
+        l[e] = (__bf16)(f[e] - (float)hh);
+      }
+      hal[hp] = __builtin_bit_cast(uint2, h);
+      hal[B.NPIXp + hp] = __builtin_bit_cast(uint2, l);
+    }
+  }
+  int hp[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    int m = wave * 64 + mt * 16 + j;
+    if (m >= npx) m = 0;
+    const int r = m / P.TW, c = m - r * P.TW;
+    hp[mt] = (r * P.is) * P.HW + c * P.is + 2 * kq;
+  }
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool wave_live = wave * 64 < npx;
+  const bool w0_ok = tid < wslot, w1_ok = tid + 256 < wslot;
+  const int wlane = kq * NB + j;
+  auto wsrc = [&](int q) -> const uint4* { return B.wq + ((size_t)q * B.OCb + ocbi) * (size_t)wslot; };
+  if (Q > 0) {
+    {
+      const uint4* src = wsrc(0);
+      if (w0_ok) wl[tid] = src[tid];
+      if (w1_ok) wl[tid + 256] = src[tid + 256];
     }
     __syncthreads();
+    int u = 0, ks = 0;
+    for (int q = 0; q < Q; ++q) {
+      uint4 wr0 = {0, 0, 0, 0}, wr1 = {0, 0, 0, 0};
+      if (q + 1 < Q) {
+        const uint4* src = wsrc(q + 1);
+        if (w0_ok) wr0 = src[tid];
+        if (w1_ok) wr1 = src[tid + 256];
+      }
+      if (wave_live) {
+        const int toff = u * P.HW + ks * 8;
+        const uint4* wb = wl + (q & 1) * wslot + wlane;
+        uint4 ah[4], al[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const uint2* p = hal + hp[mt] + toff;
+          const uint2 h0 = p[0], h1 = p[1];
+          const uint2 l0 = p[B.NPIXp], l1 = p[B.NPIXp + 1];
+          ah[mt] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+          al[mt] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
+        uint4 bh[NT], bl[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          bh[nt] = wb[nt * 16];
+          bl[nt] = wb[4 * NB + nt * 16];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_bf16(al[mt], bh[nt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_bf16(ah[mt], bl[nt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_bf16(ah[mt], bh[nt], acc[mt][nt]);
+      }
+      if (q + 1 < Q) {
+        uint4* wn = wl + ((q + 1) & 1) * wslot;
+        if (w0_ok) wn[tid] = wr0;
+        if (w1_ok) wn[tid + 256] = wr1;
+      }
+      __syncthreads();
+      if (++ks == KS) {
+        ks = 0;
+        ++u;
+      }
+    }
   }
+  bf3_epilogue<NT>(P, reinterpret_cast<float*>(smem4), acc, n, r0, c0, ocb, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -363,13 +564,56 @@ static void bf3_launch(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s)
 
 bool conv_bf3_gather_supported(const GatherConv& g, const Epi& ep) {
   (void)ep;
-  if (g.IC < 8 || g.OC < 8) return false;  // tiny channel counts: tap-group / direct / fp32 kernels
+  if (g.OC < 8) return false;                        // <= 4: direct kernel; 5..7: fp32 kernels
+  if (g.IC < 8 && !(g.IC <= 4 && !g.trans)) return false;  // small IC: row-packed variant, CONV gathers only
   if (g.KH * g.KW > 32 * 32) return false;
   if ((long)g.N * g.OH * g.OW > (1L << 30)) return false;
   return true;
 }
 
+template <int NT>
+static void bf3_launch_rows(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s) {
+  static int cur = 0;
+  if ((int)lds > cur) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bf3_rows<NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    cur = (int)lds;
+  }
+  hipLaunchKernelGGL(k_conv_bf3_rows<NT>, grid, dim3(256), lds, s, B);
+}
+
+static int bf3_launch_rows_phase(MfmaConvParams P, const uint4* wq, hipStream_t s) {
+  Bf3Params B{};
+  const int NT = P.OC >= 64 ? 4 : (P.OC + 15) / 16;
+  B.NB = NT * 16;
+  B.ICc = (P.KWv + 7) / 8;  // K steps per kernel row
+  B.OCb = (P.OC + 63) / 64;
+  B.wq = wq;
+  const int wbytes = 2 * 8 * B.NB * 16;
+  TilePick best{};
+  if (!pick_tile(256, P.PH, P.PW, P.is, P.KHv > 0 ? P.KHv : 1, P.KWv > 0 ? P.KWv : 1, 4,
+                 (kLdsBudgetBytes - wbytes) / 4 - 32 * 4, best)) {
+    set_error("conv_bf3_rows: no tile fits LDS");
+    return SRK_ERR_UNSUPPORTED;
+  }
+  P.TH = best.TH; P.TW = best.TW; P.tiles_y = best.tiles_y; P.tiles_x = best.tiles_x; P.HH = best.HH; P.HW = best.HW;
+  B.NPIXp = (best.HH * best.HW + 16 + 15) & ~15;  // +16: the last row's padded kw slots read past the halo
+  B.P = P;
+  size_t lds = (size_t)B.NPIXp * 16 + wbytes;
+  const size_t epi_bytes = (size_t)4 * 32 * BF3_EPI_STRIDE * sizeof(float);
+  if (lds < epi_bytes) lds = epi_bytes;
+  dim3 grid((unsigned)((size_t)P.tiles_x * P.tiles_y * P.N), B.OCb);
+  switch (NT) {
+    case 1: bf3_launch_rows<1>(B, grid, lds, s); break;
+    case 2: bf3_launch_rows<2>(B, grid, lds, s); break;
+    case 3: bf3_launch_rows<3>(B, grid, lds, s); break;
+    default: bf3_launch_rows<4>(B, grid, lds, s); break;
+  }
+  return check_launch("conv_bf3_rows");
+}
+
 static int bf3_launch_phase(MfmaConvParams P, const uint4* wq, hipStream_t s) {
+  if (P.IC <= 4) return bf3_launch_rows_phase(P, wq, s);
   Bf3Params B{};
   const int NT = P.OC >= 64 ? 4 : (P.OC + 15) / 16;
   B.NB = NT * 16;

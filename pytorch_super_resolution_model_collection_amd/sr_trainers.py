@@ -1,0 +1,294 @@
+"""Trainer objects with the reference's surface — MODEL(args).train() / test() / test_single(fn) /
+save_model(epoch) / load_model() — for SRCNN, ESPCN, FSRCNN, VDSR, EDSR, LapSRN and SRGAN
+(srcnn.py:32-281, espcn.py:32-281, fsrcnn.py:58-307, vdsr.py:39-301, edsr.py:48-351,
+lapsrn.py:88-349, srgan.py:93-528), on the MI355X hot path.
+
+Kept from the reference: per-model hyper-parameters hard-coded in train() (e.g. EDSR base_filter 64 /
+16 residuals, edsr.py:87; VDSR momentum 0.9 / wd 1e-4 / clip 0.4, vdsr.py:86-90,149), the epoch-wise
+LR decay rules, the checkpoint file names and that checkpoints are weights-only state_dict pickles.
+Not kept (out of scope): the PIL/torchvision dataset pipeline, TF1 logging, PNG/plot
+side effects and the per-iteration host sync (`loss.data[0]`).  Training data comes from a
+`loader` argument (any iterable of tensor tuples in the reference's (lr, hr, bicubic) order) or, by
+default, from seeded synthetic patches of the configured crop size.
+"""
+import os
+
+import torch
+
+from . import dp as dpmod
+from . import models, ops, optim, trainers, utils
+
+
+def synthetic_loader(kind, args, steps, device, seed=1234):
+    """Seeded random (input, target...) batches with the shapes each reference train loop feeds."""
+    g = torch.Generator().manual_seed(seed)
+    b, c, r = args.batch_size, args.num_channels, args.scale_factor
+    hr = args.crop_size
+    lr = hr // r
+    for _ in range(steps):
+        if kind in ("srcnn",):          # bicubic-upsampled input, valid-conv target (srcnn.py:116-125)
+            yield torch.rand(b, c, hr, hr, generator=g).to(device), torch.rand(b, c, hr - 16, hr - 16, generator=g).to(device)
+        elif kind == "vdsr":            # vdsr.py:133-142
+            yield torch.rand(b, c, hr, hr, generator=g).to(device), torch.rand(b, c, hr, hr, generator=g).to(device)
+        elif kind == "fsrcnn":          # output r(H-5)+4 = target shaved by 2r (fsrcnn.py:143-150)
+            yield torch.rand(b, c, lr, lr, generator=g).to(device), torch.rand(b, c, r * (lr - 5) + 4, r * (lr - 5) + 4, generator=g).to(device)
+        elif kind == "espcn":           # net output r(H-8) (the reference's own target is inconsistent, App. B-2)
+            yield torch.rand(b, c, lr, lr, generator=g).to(device), torch.rand(b, c, r * (lr - 8), r * (lr - 8), generator=g).to(device)
+        elif kind == "lapsrn":          # lapsrn.py:179-188
+            yield (torch.rand(b, c, lr, lr, generator=g).to(device), torch.rand(b, c, 2 * lr, 2 * lr, generator=g).to(device),
+                   torch.rand(b, c, 4 * lr, 4 * lr, generator=g).to(device))
+        else:                           # edsr / srgan: (lr, hr)
+            yield torch.rand(b, c, lr, lr, generator=g).to(device), torch.rand(b, c, hr, hr, generator=g).to(device)
+
+
+class _Trainer(object):
+    kind = None
+
+    def __init__(self, args):
+        # the reference copies args field by field (edsr.py:49-65)
+        for k in ("model_name", "train_dataset", "test_dataset", "crop_size", "num_threads", "num_channels",
+                  "scale_factor", "num_epochs", "save_epochs", "batch_size", "test_batch_size", "lr", "data_dir",
+                  "save_dir", "gpu_mode"):
+            setattr(self, k, getattr(args, k, None))
+        self.args = args
+        self.steps_per_epoch = getattr(args, "steps_per_epoch", 8)
+        if not torch.cuda.is_available():
+            raise RuntimeError("the MI355X hot path needs a GPU (gpu_mode=False has no CPU fallback; see oracle/)")
+        self.rank, self.world, self.local = dpmod.init_from_env()
+        torch.cuda.set_device(self.local)
+        self.device = torch.device("cuda", self.local)
+        self.model = None
+
+    # -- overridables --------------------------------------------------------------------------
+    def build_model(self):
+        raise NotImplementedError
+
+    def lr_decay(self, epoch, opt):
+        pass
+
+    # -- reference surface ------------------------------------------------------------------------
+    def train(self, loader=None, log_every=0):
+        self.model = self.build_model()
+        self.model.weight_init()
+        self.model.to(self.device).train()
+        utils.print_network(self.model) if self.rank == 0 else None
+        self.flat, self.optimizer, self.dp, step = trainers.build(self.kind, self.model, self.lr,
+                                                                  use_dp=self.world > 1)
+        avg_loss = []
+        for epoch in range(self.num_epochs):
+            self.lr_decay(epoch, self.optimizer)
+            batches = loader if loader is not None else synthetic_loader(self.kind, self.args, self.steps_per_epoch,
+                                                                         self.device, 1234 + epoch * self.world + self.rank)
+            total, n = torch.zeros((), device=self.device), 0
+            for batch in batches:
+                out = step(*[t.to(self.device, non_blocking=True) for t in batch][:3 if self.kind == "lapsrn" else 2])
+                loss = sum(out) if isinstance(out, tuple) else out
+                total += loss.detach()   # device-side accumulation: no host sync inside the loop
+                n += 1
+            avg_loss.append(float(total) / max(n, 1))   # one sync per epoch
+            if self.rank == 0:
+                print('Epoch: [%2d] avg loss: %.8f' % (epoch + 1, avg_loss[-1]))
+                if (epoch + 1) % self.save_epochs == 0:
+                    self.save_model(epoch + 1)
+        if self.rank == 0:
+            self.save_model(epoch=None)
+        return avg_loss
+
+    def _infer(self, x):
+        self.model.eval()
+        with torch.no_grad():
+            return self.model(x.to(self.device))
+
+    def test(self, loader=None):
+        """Evaluation loop (espcn.py:173-215): forward + PSNR per image; returns the list of PSNRs."""
+        if self.model is None:
+            self.model = self.build_model().to(self.device)
+            self.load_model()
+        psnrs = []
+        batches = loader if loader is not None else synthetic_loader(self.kind, self.args, 2, self.device, 4321)
+        for batch in batches:
+            out = self._infer(batch[0])
+            out = out[-1] if isinstance(out, tuple) else out
+            tgt = batch[-1]
+            if out.shape == tgt.shape:
+                psnrs.append(utils.PSNR(out, tgt))
+        return psnrs
+
+    def test_single(self, img):
+        """Super-resolve one [C,H,W] (or [1,C,H,W]) tensor (the reference reads an image file with PIL)."""
+        if self.model is None:
+            self.model = self.build_model().to(self.device)
+            self.load_model()
+        x = img if img.dim() == 4 else img.unsqueeze(0)
+        out = self._infer(x)
+        return (out[-1] if isinstance(out, tuple) else out).cpu()
+
+    def _ckpt_name(self, epoch):
+        # srcnn.py:260-269 style for the simple trainers, edsr.py:324-337 style (ch/batch/epoch/lr) for EDSR / SRGAN
+        model_dir = os.path.join(self.save_dir, 'model')
+        os.makedirs(model_dir, exist_ok=True)
+        if self.kind in ("edsr",):
+            return model_dir + '/' + self.model_name + '_param_ch%d_batch%d_epoch%d_lr%.g.pkl' % (
+                self.num_channels, self.batch_size, self.num_epochs if epoch is None else epoch, self.lr)
+        if epoch is not None:
+            return model_dir + '/' + self.model_name + '_param_epoch_%d.pkl' % epoch
+        return model_dir + '/' + self.model_name + '_param.pkl'
+
+    def save_model(self, epoch=None):
+        sd = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
+        torch.save(sd, self._ckpt_name(epoch))
+        print('Trained model is saved.')
+
+    def load_model(self):
+        name = self._ckpt_name(None)
+        if os.path.exists(name):
+            self.model.load_state_dict(torch.load(name))
+            print('Trained model is loaded.')
+            return True
+        print('No model exists to load.')
+        return False
+
+
+class SRCNN(_Trainer):
+    kind = "srcnn"
+
+    def build_model(self):
+        return models.SRCNNNet(self.num_channels, 64)   # srcnn.py:73
+
+
+class ESPCN(_Trainer):
+    kind = "espcn"
+
+    def build_model(self):
+        return models.ESPCNNet(self.num_channels, 64, self.scale_factor)   # espcn.py:73
+
+
+class FSRCNN(_Trainer):
+    kind = "fsrcnn"
+
+    def build_model(self):
+        return models.FSRCNNNet(self.num_channels, self.scale_factor, 56, 12, 4)   # fsrcnn.py:99
+
+
+class VDSR(_Trainer):
+    kind = "vdsr"
+
+    def build_model(self):
+        return models.VDSRNet(self.num_channels, 64, 18)   # vdsr.py:80
+
+    def lr_decay(self, epoch, opt):   # vdsr.py:127-129: /10 every 20 epochs
+        if (epoch + 1) % 20 == 0:
+            for g in opt.param_groups:
+                g['lr'] = g['lr'] / 10.0
+
+
+class EDSR(_Trainer):
+    kind = "edsr"
+
+    def build_model(self):
+        return models.EDSRNet(self.num_channels, 64, 16)   # edsr.py:87
+
+    def lr_decay(self, epoch, opt):   # edsr.py:131-133: /2 every 40 epochs
+        if (epoch + 1) % 40 == 0:
+            for g in opt.param_groups:
+                g['lr'] = g['lr'] / 2.0
+
+
+class LapSRN(_Trainer):
+    kind = "lapsrn"
+
+    def build_model(self):
+        return models.LapSRNNet(self.num_channels, 64, 10)   # lapsrn.py:129
+
+    def lr_decay(self, epoch, opt):   # lapsrn.py:173-175: /2 every 50 epochs
+        if (epoch + 1) % 50 == 0:
+            for g in opt.param_groups:
+                g['lr'] = g['lr'] / 2.0
+
+
+class SRGAN(_Trainer):
+    """srgan.py:93-528: generator pre-training with MSE, then the adversarial loop."""
+    kind = "srgan"
+
+    def build_model(self):
+        self.G = models.SRGANGenerator(self.num_channels, 64, 16)                 # srgan.py:136
+        self.D = models.SRGANDiscriminator(self.num_channels, 64, self.crop_size)  # srgan.py:137
+        return self.G
+
+    def train(self, loader=None, pretrain_epochs=None, log_every=0):
+        self.model = self.build_model()
+        self.G.weight_init(mean=0.0, std=0.02)
+        self.D.weight_init(mean=0.0, std=0.02)
+        self.G.to(self.device).train()
+        self.D.to(self.device).train()
+        g_flat, d_flat = optim.FlatParams(self.G), optim.FlatParams(self.D)
+        g_opt = optim.make_optimizer("srgan_g", g_flat, self.lr)
+        d_opt = optim.make_optimizer("srgan_d", d_flat, self.lr)
+        g_dp = d_dp = None
+        if self.world > 1:
+            g_dp, d_dp = dpmod.DataParallel(g_flat), dpmod.DataParallel(d_flat)
+            g_dp.broadcast_params()
+            d_dp.broadcast_params()
+        norm = lambda t: utils.norm(t, vgg=True)   # srgan.py:193-194,257-258
+        # generator pre-training (srgan.py:179-219; 50 epochs in the reference)
+        pre = 1 if pretrain_epochs is None else pretrain_epochs
+        pre_step = trainers.mse_step(self.G, g_opt, g_dp)
+        for epoch in range(pre):
+            for lr_img, hr_img in (loader or synthetic_loader("srgan", self.args, self.steps_per_epoch, self.device,
+                                                              77 + epoch)):
+                pre_step(norm(lr_img.to(self.device)), norm(hr_img.to(self.device)))
+        if self.rank == 0:
+            self.save_model(is_pretrain=True)
+        step = trainers.srgan_step(self.G, self.D, g_opt, d_opt, g_dp, d_dp)
+        hist = []
+        for epoch in range(self.num_epochs):
+            if (epoch + 1) % 20 == 0:   # srgan.py:239-244: both learning rates /2 every 20 epochs
+                for o in (g_opt, d_opt):
+                    for g in o.param_groups:
+                        g['lr'] = g['lr'] / 2.0
+            d_tot, g_tot, n = torch.zeros((), device=self.device), torch.zeros((), device=self.device), 0
+            for lr_img, hr_img in (loader or synthetic_loader("srgan", self.args, self.steps_per_epoch, self.device,
+                                                              1234 + epoch)):
+                d_loss, g_loss = step(norm(lr_img.to(self.device)), norm(hr_img.to(self.device)))
+                d_tot += d_loss.detach()
+                g_tot += g_loss.detach()
+                n += 1
+            hist.append((float(d_tot) / max(n, 1), float(g_tot) / max(n, 1)))
+            if self.rank == 0:
+                print('Epoch: [%2d] D_loss: %.8f G_loss: %.8f' % ((epoch + 1,) + hist[-1]))
+                if (epoch + 1) % self.save_epochs == 0:
+                    self.save_model(epoch + 1)
+        if self.rank == 0:
+            self.save_model(epoch=None)
+        return hist
+
+    def _names(self, epoch):
+        model_dir = os.path.join(self.save_dir, 'model')
+        os.makedirs(model_dir, exist_ok=True)
+        tail = '_param_ch%d_batch%d_epoch%d_lr%.g.pkl' % (self.num_channels, self.batch_size,
+                                                           self.num_epochs if epoch is None else epoch, self.lr)
+        return (model_dir + '/' + self.model_name + '_G' + tail, model_dir + '/' + self.model_name + '_D' + tail,
+                model_dir + '/' + self.model_name + '_G_param_pretrain.pkl')
+
+    def save_model(self, epoch=None, is_pretrain=False):   # srgan.py:483-506
+        g_name, d_name, pre = self._names(epoch)
+        cpu = lambda m: {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        if is_pretrain:
+            torch.save(cpu(self.G), pre)
+            print('Pre-trained generator model is saved.')
+        else:
+            torch.save(cpu(self.G), g_name)
+            torch.save(cpu(self.D), d_name)
+            print('Trained models are saved.')
+
+    def load_model(self, is_pretrain=False):   # srgan.py:508-526
+        g_name, _, pre = self._names(None)
+        name = pre if is_pretrain else g_name
+        if os.path.exists(name):
+            self.G.load_state_dict(torch.load(name))
+            print('Trained generator model is loaded.')
+            return True
+        return False
+
+
+TRAINERS = {"SRCNN": SRCNN, "VDSR": VDSR, "ESPCN": ESPCN, "FSRCNN": FSRCNN, "SRGAN": SRGAN, "LapSRN": LapSRN, "EDSR": EDSR}
