@@ -171,13 +171,30 @@ __global__ __launch_bounds__(256) void k_bias_grad_partial(const float* __restri
     partial[(size_t)blockIdx.y * Cout + co] = sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane];
 }
 
+// one block per 64 channels: lanes = channels, the 4 waves stride the splits with 4 independent
+// accumulators each (loads stay in flight), fixed combination order => deterministic.
 __global__ __launch_bounds__(256) void k_bias_grad_final(const float* __restrict__ partial, float* __restrict__ db,
                                                          int splits, int Cout, float beta) {
-  const int co = blockIdx.x * 256 + threadIdx.x;
-  if (co >= Cout) return;
-  float t = 0.f;
-  for (int s = 0; s < splits; ++s) t += partial[(size_t)s * Cout + co];
-  db[co] = beta != 0.f ? beta * db[co] + t : t;
+  __shared__ float sm[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int co = blockIdx.x * 64 + lane;
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  if (co < Cout) {
+    int s = w;
+    for (; s + 12 < splits; s += 16) {
+      t0 += partial[(size_t)s * Cout + co];
+      t1 += partial[(size_t)(s + 4) * Cout + co];
+      t2 += partial[(size_t)(s + 8) * Cout + co];
+      t3 += partial[(size_t)(s + 12) * Cout + co];
+    }
+    for (; s < splits; s += 4) t0 += partial[(size_t)s * Cout + co];
+  }
+  sm[w][lane] = (t0 + t1) + (t2 + t3);
+  __syncthreads();
+  if (w == 0 && co < Cout) {
+    const float t = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+    db[co] = beta != 0.f ? beta * db[co] + t : t;
+  }
 }
 
 constexpr int kBiasSplits = 1024;
@@ -197,9 +214,16 @@ int conv_bias_grad(const srk_conv_desc& d, const float* dy, const srk_bwd_mask* 
   const size_t pps = (npix + splits - 1) / splits;
   hipLaunchKernelGGL(k_bias_grad_partial, dim3(cdiv(d.Cout, 64), splits), dim3(256), 0, s, dy,
                      mask ? mask->y : nullptr, mask ? mask->slope : 0.f, (float*)ws, npix, d.Cout, pps);
-  hipLaunchKernelGGL(k_bias_grad_final, dim3(cdiv(d.Cout, 256)), dim3(256), 0, s, (const float*)ws, db, splits,
+  hipLaunchKernelGGL(k_bias_grad_final, dim3(cdiv(d.Cout, 64)), dim3(256), 0, s, (const float*)ws, db, splits,
                      d.Cout, beta);
   return check_launch("conv_bias_grad");
+}
+
+// Final stage only: partial[splits][Cout] was produced by another kernel (the MFMA weight-gradient
+// kernel sums its LDS-resident dY tiles on the side).
+int conv_bias_grad_finish(const float* partial, int splits, float* db, int Cout, float beta, hipStream_t s) {
+  hipLaunchKernelGGL(k_bias_grad_final, dim3(cdiv(Cout, 64)), dim3(256), 0, s, partial, db, splits, Cout, beta);
+  return check_launch("conv_bias_grad_finish");
 }
 
 int conv_wgrad_finalize(const srk_conv_desc& d, const float* ws, float* dw, float beta, hipStream_t s) {

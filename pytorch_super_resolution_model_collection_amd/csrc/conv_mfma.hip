@@ -71,27 +71,36 @@ __device__ __forceinline__ void load_halo(const MfmaConvParams& P, float* halo, 
   }
 }
 
-// Epilogue shared by both variants.
+// Epilogue shared by both MFMA variants: accumulators -> wave-private LDS slab (32 pixels x 64
+// channels, row stride 68 floats) -> 16-byte coalesced stores with the fused bias / activation /
+// residual / pixel-shuffle (epi_store4).  C/D layout: col = lane&15, row = (lane>>4)*4 + reg.
+constexpr int EPI_STRIDE = 68;
+
 template <int NT>
-__device__ __forceinline__ void store_tile(const MfmaConvParams& P, const f32x4 (&acc)[2][NT], int n, int r0, int c0,
-                                           int ocb, int wave, int j, int kq) {
-  GatherConv g{};
-  g.OH = P.OH; g.OW = P.OW; g.OC = P.OC;
+__device__ __forceinline__ void store_tile(const MfmaConvParams& P, float* smem_f, const f32x4 (&acc)[2][NT], int n,
+                                           int r0, int c0, int ocb, int wave, int lane) {
+  const int j = lane & 15, kq = lane >> 4;
   const int npx = P.TH * P.TW;
+  constexpr int Q4 = NT * 4;
+  __syncthreads();  // every wave is done reading the halo / filter regions that the slab overlays
+  float* st = smem_f + wave * (32 * EPI_STRIDE);
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int m = wave * 32 + mt * 16 + kq * 4 + reg;
-      if (m >= npx) continue;
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) st[(mt * 16 + kq * 4 + reg) * EPI_STRIDE + nt * 16 + j] = acc[mt][nt][reg];
+  __syncthreads();
+  for (int it = lane; it < 32 * Q4; it += 64) {
+    const int row = it / Q4, q4 = it - row * Q4;
+    const int m = wave * 32 + row;
+    if (m < npx) {
       const int r = m / P.TW, c = m - r * P.TW;
       const int pr = r0 + r, pc = c0 + c;
-      if (pr >= P.PH || pc >= P.PW) continue;
-      const int oy = P.oy0 + pr * P.os, ox = P.ox0 + pc * P.os;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int oc = ocb + nt * 16 + j;
-        if (oc < P.OC) epi_store(P.ep, g, acc[mt][nt][reg], n, oy, ox, oc, P.out);
+      const int oc = ocb + q4 * 4;
+      if (pr < P.PH && pc < P.PW && oc < P.OC) {
+        const epi_f4 v = *reinterpret_cast<const epi_f4*>(st + row * EPI_STRIDE + q4 * 4);
+        epi_store4(P.ep, P.OH, P.OW, P.OC, n, P.oy0 + pr * P.os, P.ox0 + pc * P.os, oc, v, P.out);
       }
     }
   }
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(MfmaConvParams P) {
       }
     }
   }
-  store_tile<NT>(P, acc, n, r0, c0, ocb, wave, j, kq);
+  store_tile<NT>(P, smem, acc, n, r0, c0, ocb, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_tg(MfmaConvParams P) {
       }
     }
   }
-  store_tile<NT>(P, acc, n, r0, c0, ocb, wave, j, kq);
+  store_tile<NT>(P, smem, acc, n, r0, c0, ocb, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -495,6 +504,7 @@ static int launch_phase(MfmaConvParams P, hipStream_t s) {
     P.halo_floats = best.HH * best.HW * P.PSA;
     lds = ((size_t)P.halo_floats + (size_t)P.CK * P.BNp) * 4;
   }
+  if (lds < (size_t)4 * 32 * EPI_STRIDE * sizeof(float)) lds = (size_t)4 * 32 * EPI_STRIDE * sizeof(float);
   dim3 grid((unsigned)((size_t)P.tiles_x * P.tiles_y * P.N), cdiv(P.OC, 64));
   switch (NT) {
     case 1: launch_variant<1>(tapgroup, P, grid, lds, s); break;

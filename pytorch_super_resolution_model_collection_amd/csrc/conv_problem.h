@@ -78,6 +78,7 @@ int conv_generic_gather(const GatherConv& g, const float* in, const float* wp, f
 size_t conv_bias_grad_ws(const srk_conv_desc& d);
 int conv_bias_grad(const srk_conv_desc& d, const float* dy, const srk_bwd_mask* mask, float* db, float beta, void* ws,
                    hipStream_t s);
+int conv_bias_grad_finish(const float* partial, int splits, float* db, int Cout, float beta, hipStream_t s);
 int conv_wgrad_finalize(const srk_conv_desc& d, const float* ws, float* dw, float beta, hipStream_t s);
 // Implemented in conv_mfma.hip
 bool conv_mfma_gather_supported(const GatherConv& g, const Epi& ep);

@@ -34,6 +34,7 @@ struct WgradParams {
   const float* mask_y;
   float mask_slope;
   float* ws;  // [G][T][Cin][Cout]
+  float* bias_partial;  // [G][Cout] column sums of dY (NULL: not requested / transposed)
   int N, Cin, Cout;
   int XH, XW, YH, YW;  // spatial dims of x and dy
   int KH, KW, stride, pad, transposed;
@@ -110,6 +111,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WgradParams P) {
   const int npx = P.TH * P.TW;
   const int npx4 = (npx + 3) & ~3;
   const bool wave_live = wave * 16 < cicp;
+  const bool want_bias = P.bias_partial != nullptr && blockIdx.y == 0;
+  float bsum = 0.f;
 
   for (int p = tid; p < WG_TP; p += 256) {
     int h = 0;
@@ -157,6 +160,15 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WgradParams P) {
                      P.HH * P.HW, cob, coc, cocp, P.vec_y);
       }
       __syncthreads();
+      if (!TRANS && want_bias && t0 == 0 && tid < cocp) {
+        // db partial: column sums of the LDS-resident (masked) dY tile; zero rows pad the tile
+        float bs0 = 0.f, bs1 = 0.f;
+        for (int p = 0; p + 1 < npx4; p += 2) {
+          bs0 += ys[p * P.PSY + tid];
+          bs1 += ys[(p + 1) * P.PSY + tid];
+        }
+        bsum += bs0 + bs1;
+      }
       if (wave_live) {
         for (int k4 = 0; k4 < npx4; k4 += 4) {
           const int p = k4 + kq;
@@ -189,6 +201,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WgradParams P) {
         }
       }
     }
+    if (!TRANS && want_bias && t0 == 0 && tid < cocp && cob + tid < P.Cout)
+      P.bias_partial[(size_t)blockIdx.x * P.Cout + cob + tid] = bsum;
     // partial slab: ws[g][t][ci][co]; C/D layout col = lane&15 (co), row = (lane>>4)*4 + reg (ci)
     if (wave_live) {
       float* slab = P.ws + (size_t)blockIdx.x * T * P.Cin * P.Cout;
@@ -254,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_smallcin(WgradParams P) {
   f32x4 acc[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
 
   for (int tile = blockIdx.x; tile < P.ntiles; tile += P.G) {
     int b = tile;
@@ -268,6 +283,14 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_smallcin(WgradParams P) {
     stage_region(P.dy, P.mask_y, P.mask_slope, ys, P.PSY, n, P.YH, P.YW, P.Cout, r0, c0, P.TH, P.TW, npx4, cob, coc,
                  64, P.vec_y);
     __syncthreads();
+    if (P.bias_partial && tid < 64) {
+      float bs0 = 0.f, bs1 = 0.f;
+      for (int p = 0; p + 1 < npx4; p += 2) {
+        bs0 += ys[p * P.PSY + tid];
+        bs1 += ys[(p + 1) * P.PSY + tid];
+      }
+      bsum += bs0 + bs1;
+    }
     if (wave_live) {
       for (int k4 = 0; k4 < npx4; k4 += 4) {
         const int p = k4 + kq;
@@ -281,6 +304,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_smallcin(WgradParams P) {
       }
     }
   }
+  if (P.bias_partial && tid < 64 && cob + tid < P.Cout) P.bias_partial[(size_t)blockIdx.x * P.Cout + cob + tid] = bsum;
   if (wave_live) {
     float* slab = P.ws + (size_t)blockIdx.x * T * P.Cin * P.Cout;
     const int co = cob + wave * 16 + i;
@@ -439,6 +463,8 @@ int conv_wgrad_mfma(const srk_conv_desc& d, const float* x, const float* dy, con
   WgradParams P{};
   P.x = x; P.dy = dy; P.mask_y = mask ? mask->y : nullptr; P.mask_slope = mask ? mask->slope : 0.f;
   P.ws = (float*)ws;
+  float* bias_ws = reinterpret_cast<float*>(static_cast<char*>(ws) + slab_bytes);
+  P.bias_partial = (db && !d.transposed) ? bias_ws : nullptr;
   P.N = d.N; P.Cin = d.Cin; P.Cout = d.Cout;
   P.XH = d.H; P.XW = d.W; P.YH = d.OH; P.YW = d.OW;
   P.KH = d.KH; P.KW = d.KW; P.stride = d.stride; P.pad = d.pad; P.transposed = d.transposed;
@@ -480,7 +506,12 @@ int conv_wgrad_mfma(const srk_conv_desc& d, const float* x, const float* dy, con
                      d.Cin, d.KH, d.KW, d.transposed, beta);
   rc = check_launch("conv_wgrad_reduce");
   if (rc) return rc;
-  if (db) rc = conv_bias_grad(d, dy, mask, db, beta, (char*)ws + slab_bytes, s);
+  if (db) {
+    if (P.bias_partial)
+      rc = conv_bias_grad_finish(bias_ws, pl.G, db, d.Cout, beta, s);
+    else
+      rc = conv_bias_grad(d, dy, mask, db, beta, bias_ws, s);
+  }
   return rc;
 }
 
