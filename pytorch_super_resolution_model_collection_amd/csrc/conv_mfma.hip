@@ -21,6 +21,7 @@
 #include "srk_common.h"
 #include "conv_problem.h"
 #include "conv_tile.h"
+#include <type_traits>
 
 namespace srk {
 
@@ -34,46 +35,74 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // ---------------------------------------------------------------------------------------------
 // Halo staging: global NHWC -> LDS [pixel][PSA], channels [cb, cb+ck) zero-padded to ckp.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void load_halo(const MfmaConvParams& P, float* halo, int n, int r0, int c0, int cb, int ck,
-                                          int ckp) {
+// All loads of a batch (<= HALO_BATCH float4 per thread) are issued before the first LDS store, so
+// the HBM/L2 latency is paid once per batch, not once per element.
+constexpr int HALO_BATCH = 8;
+
+template <bool MASK>
+__device__ __forceinline__ void load_halo_t(const MfmaConvParams& P, float* halo, int n, int r0, int c0, int cb,
+                                            int ck, int ckp) {
   const int nvec = ckp >> 2;  // float4 slots per pixel
   const int items = P.HH * P.HW * nvec;
   const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
-  for (int it = threadIdx.x; it < items; it += 256) {
-    const int hp = it / nvec, q = it - hp * nvec;
-    const int hy = hp / P.HW, hx = hp - hy * P.HW;
-    const int iy = iyb + hy, ix = ixb + hx;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    const int ch = q * 4;
-    if (iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW && ch < ck) {
-      const size_t off = (((size_t)n * P.IH + iy) * P.IW + ix) * P.IC + cb + ch;
-      if (P.vec_in && ch + 3 < ck) {
-        v = *reinterpret_cast<const f32x4*>(P.in + off);
-        if (P.mask_y) {
-          const f32x4 m = *reinterpret_cast<const f32x4*>(P.mask_y + off);
-          v.x = m.x > 0.f ? v.x : v.x * P.mask_slope;
-          v.y = m.y > 0.f ? v.y : v.y * P.mask_slope;
-          v.z = m.z > 0.f ? v.z : v.z * P.mask_slope;
-          v.w = m.w > 0.f ? v.w : v.w * P.mask_slope;
-        }
-      } else {
+  for (int base = threadIdx.x; base < items; base += 256 * HALO_BATCH) {
+    f32x4 v[HALO_BATCH], m[HALO_BATCH];
+    int dst[HALO_BATCH];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (ch + e < ck) {
-            float x = P.in[off + e];
-            if (P.mask_y) x = P.mask_y[off + e] > 0.f ? x : x * P.mask_slope;
-            v[e] = x;
+    for (int k = 0; k < HALO_BATCH; ++k) {
+      const int it = base + 256 * k;
+      v[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (MASK) m[k] = (f32x4){1.f, 1.f, 1.f, 1.f};
+      dst[k] = -1;
+      if (it < items) {
+        const int hp = it / nvec, q = it - hp * nvec;
+        const int hy = hp / P.HW, hx = hp - hy * P.HW;
+        const int iy = iyb + hy, ix = ixb + hx;
+        const int ch = q * 4;
+        dst[k] = hp * P.PSA + ch;
+        if (iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW && ch < ck) {
+          const size_t off = (((size_t)n * P.IH + iy) * P.IW + ix) * P.IC + cb + ch;
+          if (P.vec_in && ch + 3 < ck) {
+            v[k] = *reinterpret_cast<const f32x4*>(P.in + off);
+            if (MASK) m[k] = *reinterpret_cast<const f32x4*>(P.mask_y + off);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (ch + e < ck) {
+                v[k][e] = P.in[off + e];
+                if (MASK) m[k][e] = P.mask_y[off + e];
+              }
+            }
           }
         }
       }
     }
-    *reinterpret_cast<f32x4*>(halo + (size_t)hp * P.PSA + ch) = v;
+#pragma unroll
+    for (int k = 0; k < HALO_BATCH; ++k) {
+      if (dst[k] >= 0) {
+        f32x4 x = v[k];
+        if (MASK) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = m[k][e] > 0.f ? x[e] : x[e] * P.mask_slope;
+        }
+        *reinterpret_cast<f32x4*>(halo + dst[k]) = x;
+      }
+    }
   }
 }
 
+__device__ __forceinline__ void load_halo(const MfmaConvParams& P, float* halo, int n, int r0, int c0, int cb, int ck,
+                                          int ckp) {
+  if (P.mask_y)
+    load_halo_t<true>(P, halo, n, r0, c0, cb, ck, ckp);
+  else
+    load_halo_t<false>(P, halo, n, r0, c0, cb, ck, ckp);
+}
+
 // Epilogue shared by both MFMA variants: accumulators -> wave-private LDS slab (32 pixels x 64
-// channels, row stride 68 floats) -> 16-byte coalesced stores with the fused bias / activation /
-// residual / pixel-shuffle (epi_store4).  C/D layout: col = lane&15, row = (lane>>4)*4 + reg.
+// channels, row stride 68 floats) -> 16-byte stores where a wave writes 4 pixels x 256 contiguous
+// bytes, with the fused bias / activation / residual / pixel-shuffle.  C/D layout: col = lane&15
+// (channel), row = (lane>>4)*4 + reg (pixel); per-channel-group math hoisted into EpiCol.
 constexpr int EPI_STRIDE = 68;
 
 template <int NT>
@@ -91,16 +120,22 @@ __device__ __forceinline__ void store_tile(const MfmaConvParams& P, float* smem_
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) st[(mt * 16 + kq * 4 + reg) * EPI_STRIDE + nt * 16 + j] = acc[mt][nt][reg];
   __syncthreads();
-  for (int it = lane; it < 32 * Q4; it += 64) {
-    const int row = it / Q4, q4 = it - row * Q4;
-    const int m = wave * 32 + row;
-    if (m < npx) {
-      const int r = m / P.TW, c = m - r * P.TW;
-      const int pr = r0 + r, pc = c0 + c;
-      const int oc = ocb + q4 * 4;
-      if (pr < P.PH && pc < P.PW && oc < P.OC) {
-        const epi_f4 v = *reinterpret_cast<const epi_f4*>(st + row * EPI_STRIDE + q4 * 4);
-        epi_store4(P.ep, P.OH, P.OW, P.OC, n, P.oy0 + pr * P.os, P.ox0 + pc * P.os, oc, v, P.out);
+  constexpr int RPI = 64 / Q4;
+  const int row0 = lane / Q4, q4 = lane - row0 * Q4;
+  const int oc4 = ocb + q4 * 4;
+  if (row0 < RPI && oc4 < P.OC) {
+    const int tw_magic = div_small_magic(P.TW);
+    const EpiCol col = epi_col_setup(P.ep, P.OW, P.OC, oc4);
+#pragma unroll 2
+    for (int row = row0; row < 32; row += RPI) {
+      const int m = wave * 32 + row;
+      if (m < npx) {
+        const int r = div_small(m, tw_magic), c = m - r * P.TW;
+        const int pr = r0 + r, pc = c0 + c;
+        if (pr < P.PH && pc < P.PW) {
+          const epi_f4 v = *reinterpret_cast<const epi_f4*>(st + row * EPI_STRIDE + q4 * 4);
+          epi_store4_col(P.ep, col, P.OH, P.OW, P.OC, n, P.oy0 + pr * P.os, P.ox0 + pc * P.os, v, P.out);
+        }
       }
     }
   }

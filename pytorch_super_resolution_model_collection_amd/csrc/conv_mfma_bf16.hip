@@ -22,6 +22,8 @@
 #include "srk_common.h"
 #include "conv_problem.h"
 #include "conv_tile.h"
+#include <type_traits>
+#include <stdlib.h>
 
 namespace srk {
 
@@ -35,6 +37,7 @@ struct Bf3Params {
   int OCb;          // 64-channel output blocks
   int NB;           // output channels per block in the prepared layout (NT*16)
   int NPIXp;        // halo pixels rounded up to 16
+  int dbg;          // ablation switches (SRK_DBG env): 1 skip halo loads, 2 skip epilogue, 4 skip MFMAs, 8 skip weight copies
 };
 
 __device__ __forceinline__ void split8(const float (&f)[8], uint4& hi, uint4& lo) {
@@ -143,71 +146,105 @@ __device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4
 
 // halo chunk: channels [cb, cb+32) of every halo pixel -> hi/lo planes.
 // thread -> (8-channel group g = tid&3, pixel slot tid>>2); pixels advance by 64 per pass with an
-// incremental (row, col) update instead of a division per item.
-__device__ __forceinline__ void bf3_stage_halo(const Bf3Params& B, uint4* hal, int n, int r0, int c0, int cb) {
+// incremental (row, col) update instead of a division per item.  All global loads of a thread
+// (<= BF3_STAGE_IT passes) are issued before the first conversion, so the HBM/L2 latency is paid
+// once per chunk instead of once per pass.
+constexpr int BF3_STAGE_IT = 6;  // covers halos of <= 384 pixels per batch; larger halos loop over batches
+
+template <bool MASK>
+__device__ __forceinline__ void bf3_stage_halo_t(const Bf3Params& B, uint4* hal, int n, int r0, int c0, int cb) {
   const MfmaConvParams& P = B.P;
   const int npix = P.HH * P.HW;
   const int g = threadIdx.x & 3;
-  int hp = threadIdx.x >> 2;
-  int hy = hp / P.HW, hx = hp - hy * P.HW;
+  const int hp0 = threadIdx.x >> 2;
+  int hy = hp0 / P.HW, hx = hp0 - hy * P.HW;
   const int dy64 = 64 / P.HW, dx64 = 64 - dy64 * P.HW;
   const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
   const int ch = cb + g * 8;
   const bool ch_any = ch < P.IC, ch_vec = P.vec_in && ch + 7 < P.IC;
   const size_t img = (size_t)n * P.IH;
-  for (; hp < npix; hp += 64) {
-    const int iy = iyb + hy, ix = ixb + hx;
-    float f[8];
+  for (int base = hp0; base < npix; base += 64 * BF3_STAGE_IT) {
+    f32x4 v0[BF3_STAGE_IT], v1[BF3_STAGE_IT], m0[BF3_STAGE_IT], m1[BF3_STAGE_IT];
+    // pass 1: issue every load of this batch
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = 0.f;
-    if (ch_any && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) {
-      const size_t off = ((img + iy) * P.IW + ix) * P.IC + ch;
-      if (ch_vec) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(P.in + off);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(P.in + off + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          f[e] = v0[e];
-          f[4 + e] = v1[e];
-        }
-        if (P.mask_y) {
-          const f32x4 m0 = *reinterpret_cast<const f32x4*>(P.mask_y + off);
-          const f32x4 m1 = *reinterpret_cast<const f32x4*>(P.mask_y + off + 4);
+    for (int k = 0; k < BF3_STAGE_IT; ++k) {
+      v0[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      v1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (MASK) {
+        m0[k] = (f32x4){1.f, 1.f, 1.f, 1.f};
+        m1[k] = (f32x4){1.f, 1.f, 1.f, 1.f};
+      }
+      const int hp = base + 64 * k;
+      const int iy = iyb + hy, ix = ixb + hx;
+      if (hp < npix && ch_any && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) {
+        const size_t off = ((img + iy) * P.IW + ix) * P.IC + ch;
+        if (ch_vec) {
+          v0[k] = *reinterpret_cast<const f32x4*>(P.in + off);
+          v1[k] = *reinterpret_cast<const f32x4*>(P.in + off + 4);
+          if (MASK) {
+            m0[k] = *reinterpret_cast<const f32x4*>(P.mask_y + off);
+            m1[k] = *reinterpret_cast<const f32x4*>(P.mask_y + off + 4);
+          }
+        } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            f[e] = m0[e] > 0.f ? f[e] : f[e] * P.mask_slope;
-            f[4 + e] = m1[e] > 0.f ? f[4 + e] : f[4 + e] * P.mask_slope;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          if (ch + e < P.IC) {
-            float x = P.in[off + e];
-            if (P.mask_y) x = P.mask_y[off + e] > 0.f ? x : x * P.mask_slope;
-            f[e] = x;
+            if (ch + e < P.IC) {
+              v0[k][e] = P.in[off + e];
+              if (MASK) m0[k][e] = P.mask_y[off + e];
+            }
+            if (ch + 4 + e < P.IC) {
+              v1[k][e] = P.in[off + 4 + e];
+              if (MASK) m1[k][e] = P.mask_y[off + 4 + e];
+            }
           }
         }
       }
+      hy += dy64;
+      hx += dx64;
+      if (hx >= P.HW) {
+        hx -= P.HW;
+        ++hy;
+      }
     }
-    uint4 hi, lo;
-    split8(f, hi, lo);
-    hal[(0 * 4 + g) * B.NPIXp + hp] = hi;
-    hal[(1 * 4 + g) * B.NPIXp + hp] = lo;
-    hy += dy64;
-    hx += dx64;
-    if (hx >= P.HW) {
-      hx -= P.HW;
-      ++hy;
+    // pass 2: mask, split, store
+#pragma unroll
+    for (int k = 0; k < BF3_STAGE_IT; ++k) {
+      const int hp = base + 64 * k;
+      if (hp < npix) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f[e] = v0[k][e];
+          f[4 + e] = v1[k][e];
+          if (MASK) {
+            f[e] = m0[k][e] > 0.f ? f[e] : f[e] * P.mask_slope;
+            f[4 + e] = m1[k][e] > 0.f ? f[4 + e] : f[4 + e] * P.mask_slope;
+          }
+        }
+        uint4 hi, lo;
+        split8(f, hi, lo);
+        hal[(0 * 4 + g) * B.NPIXp + hp] = hi;
+        hal[(1 * 4 + g) * B.NPIXp + hp] = lo;
+      }
     }
   }
+}
+
+__device__ __forceinline__ void bf3_stage_halo(const Bf3Params& B, uint4* hal, int n, int r0, int c0, int cb) {
+  if (B.P.mask_y)
+    bf3_stage_halo_t<true>(B, hal, n, r0, c0, cb);
+  else
+    bf3_stage_halo_t<false>(B, hal, n, r0, c0, cb);
 }
 
 constexpr int BF3_MAXTAPS = 128;   // taps with precomputed tables (larger kernels: computed on the fly)
 constexpr int BF3_EPI_STRIDE = 68; // floats per staged output row (64 + 4: conflict-free float4 rows)
 
 // Epilogue shared by the bf16x3 kernels: accumulators -> LDS (wave-private 32 x 64 slab, two halves)
-// -> 16-byte coalesced stores.  C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
+// -> 16-byte stores in which a wave writes 4 pixels x 256 contiguous bytes.  (Storing straight from
+// the MFMA layout — 64-byte segments of 16 different pixels per instruction — measured 2x slower on
+// the epilogue: partial-line HBM writes.)  C/D layout: col = lane&15 (channel), row = (lane>>4)*4+reg
+// (pixel).  Everything that depends only on the lane's channel group is hoisted (EpiCol).
 template <int NT>
 __device__ __forceinline__ void bf3_epilogue(const MfmaConvParams& P, float* smem_f, const f32x4 (&acc)[4][NT], int n,
                                              int r0, int c0, int ocb, int wave, int lane) {
@@ -215,7 +252,14 @@ __device__ __forceinline__ void bf3_epilogue(const MfmaConvParams& P, float* sme
   const int npx = P.TH * P.TW;
   __syncthreads();
   float* st = smem_f + wave * (32 * BF3_EPI_STRIDE);
-  constexpr int Q4 = NT * 4;  // float4 columns per row
+  constexpr int Q4 = NT * 4;        // float4 columns per row
+  constexpr int RPI = 64 / Q4;      // rows per wave pass (NT = 3 leaves 4 lanes idle)
+  const int row0 = lane / Q4, q4 = lane - row0 * Q4;
+  const int oc4 = ocb + q4 * 4;
+  const bool lane_on = row0 < RPI && oc4 < P.OC;
+  const int tw_magic = div_small_magic(P.TW);
+  EpiCol col{};
+  if (lane_on) col = epi_col_setup(P.ep, P.OW, P.OC, oc4);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -226,16 +270,17 @@ __device__ __forceinline__ void bf3_epilogue(const MfmaConvParams& P, float* sme
         for (int reg = 0; reg < 4; ++reg)
           st[(mh * 16 + kq * 4 + reg) * BF3_EPI_STRIDE + nt * 16 + j] = acc[2 * h + mh][nt][reg];
     __syncthreads();
-    for (int it = lane; it < 32 * Q4; it += 64) {
-      const int row = it / Q4, q4 = it - row * Q4;
-      const int m = wave * 64 + h * 32 + row;
-      if (m < npx) {
-        const int r = m / P.TW, c = m - r * P.TW;
-        const int pr = r0 + r, pc = c0 + c;
-        const int oc = ocb + q4 * 4;
-        if (pr < P.PH && pc < P.PW && oc < P.OC) {
-          const epi_f4 v = *reinterpret_cast<const epi_f4*>(st + row * BF3_EPI_STRIDE + q4 * 4);
-          epi_store4(P.ep, P.OH, P.OW, P.OC, n, P.oy0 + pr * P.os, P.ox0 + pc * P.os, oc, v, P.out);
+    if (lane_on) {
+#pragma unroll 2
+      for (int row = row0; row < 32; row += RPI) {
+        const int m = wave * 64 + h * 32 + row;
+        if (m < npx) {
+          const int r = div_small(m, tw_magic), c = m - r * P.TW;
+          const int pr = r0 + r, pc = c0 + c;
+          if (pr < P.PH && pc < P.PW) {
+            const epi_f4 v = *reinterpret_cast<const epi_f4*>(st + row * BF3_EPI_STRIDE + q4 * 4);
+            epi_store4_col(P.ep, col, P.OH, P.OW, P.OC, n, P.oy0 + pr * P.os, P.ox0 + pc * P.os, v, P.out);
+          }
         }
       }
     }
@@ -304,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3(Bf3Params B) {
         }
         return B.wq + ((size_t)(tapw * B.ICc + cc) * B.OCb + ocbi) * (size_t)wslot;
       };
-      bf3_stage_halo(B, hal, n, r0, c0, cc * 32);
+      if (!(B.dbg & 1)) bf3_stage_halo(B, hal, n, r0, c0, cc * 32);
       {
         const uint4* src = wsrc(0);
         if (w0_ok) wl[tid] = src[tid];
@@ -313,12 +358,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3(Bf3Params B) {
       __syncthreads();
       for (int t = 0; t < T; ++t) {
         uint4 wr0 = {0, 0, 0, 0}, wr1 = {0, 0, 0, 0};
-        if (t + 1 < T) {  // prefetch the next tap's slice; lands while the MFMAs below run
+        if (t + 1 < T && !(B.dbg & 8)) {  // prefetch the next tap's slice; lands while the MFMAs below run
           const uint4* src = wsrc(t + 1);
           if (w0_ok) wr0 = src[tid];
           if (w1_ok) wr1 = src[tid + 256];
         }
-        if (wave_live) {
+        if (wave_live && !(B.dbg & 4)) {
           int toff;
           if (t < BF3_MAXTAPS) {
             toff = tap_toff[t];
@@ -362,6 +407,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3(Bf3Params B) {
         __syncthreads();
       }
     }
+  }
+  if (B.dbg & 2) {
+    if (acc[0][0][0] == 123.456f) P.out[0] = 1.f;  // keep the accumulators live
+    return;
   }
   bf3_epilogue<NT>(P, reinterpret_cast<float*>(smem4), acc, n, r0, c0, ocb, wave, lane);
 }
@@ -641,6 +690,14 @@ static int bf3_launch_phase(MfmaConvParams P, const uint4* wq, hipStream_t s) {
   P.TH = best.TH; P.TW = best.TW; P.tiles_y = best.tiles_y; P.tiles_x = best.tiles_x; P.HH = best.HH; P.HW = best.HW;
   B.NPIXp = (best.HH * best.HW + 15) & ~15;
   B.P = P;
+  {
+    static int dbg = -1;
+    if (dbg < 0) {
+      const char* e = getenv("SRK_DBG");
+      dbg = e ? atoi(e) : 0;
+    }
+    B.dbg = dbg;
+  }
   size_t lds = (size_t)8 * B.NPIXp * 16 + wbytes;
   const size_t epi_bytes = (size_t)4 * 32 * BF3_EPI_STRIDE * sizeof(float);
   if (lds < epi_bytes) lds = epi_bytes;

@@ -165,4 +165,71 @@ __device__ __forceinline__ void epi_store4(const Epi& ep, int OH, int OW, int OC
   (void)c_first;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Column-hoisted form of epi_store4 for the LDS-staged epilogues: everything that depends only on
+// the lane's 4 output channels is computed once (EpiCol), the per-pixel part is a handful of
+// multiplies (no divisions in the store loop).
+// ---------------------------------------------------------------------------------------------
+struct EpiCol {
+  size_t off_oc;   // offset of channel group inside the output pixel block
+  int oc;
+  int vec;         // 16-byte path legal for this column group
+  int i_row;       // pixel-shuffle sub-row (0 without PS)
+  epi_f4 bias;
+  float slope;
+};
+
+__device__ __forceinline__ EpiCol epi_col_setup(const Epi& ep, int OW, int OC, int oc) {
+  EpiCol c;
+  c.oc = oc;
+  c.bias = (epi_f4){0.f, 0.f, 0.f, 0.f};
+  c.slope = ep.act == SRK_ACT_PRELU ? ep.prelu_w[0] : ep.slope;
+  const bool simple_act = !(ep.act == SRK_ACT_PRELU && ep.prelu_n > 1);
+  bool ok = oc + 3 < OC && (oc & 3) == 0 && simple_act;
+  if (ep.ps_r > 1) {
+    const int r = ep.ps_r;
+    const int C = OC / (r * r);
+    const int RL = r * C;
+    const int i = oc / RL, rem = oc - i * RL;
+    c.i_row = i;
+    c.off_oc = (size_t)i * ((size_t)OW * r) * C + rem;
+    ok = ok && rem + 3 < RL && (RL & 3) == 0 && (rem & 3) == 0;
+  } else {
+    c.i_row = 0;
+    c.off_oc = oc;
+    ok = ok && (OC & 3) == 0;
+  }
+  c.vec = ok;
+  if (ok && ep.bias) c.bias = *reinterpret_cast<const epi_f4*>(ep.bias + oc);
+  return c;
+}
+
+__device__ __forceinline__ void epi_store4_col(const Epi& ep, const EpiCol& col, int OH, int OW, int OC, int n, int oy,
+                                               int ox, epi_f4 v, float* __restrict__ out) {
+  if (col.vec) {
+    size_t base;
+    if (ep.ps_r > 1) {
+      const int r = ep.ps_r;
+      const int C = OC / (r * r);
+      base = (((size_t)n * OH * r + (size_t)oy * r) * ((size_t)OW * r) + (size_t)ox * r) * C;
+    } else {
+      base = (((size_t)n * OH + oy) * OW + ox) * OC;
+    }
+    const size_t off = base + col.off_oc;
+    v += col.bias;
+    if (ep.act != SRK_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], ep.act, col.slope);
+    }
+    if (ep.residual) v += *reinterpret_cast<const epi_f4*>(ep.residual + off);
+    *reinterpret_cast<epi_f4*>(out + off) = v;
+  } else {
+    epi_store4(ep, OH, OW, OC, n, oy, ox, col.oc, v, out);
+  }
+}
+
+// Exact floor(m / d) for 0 <= m < 256, 1 <= d <= 256 with one multiply (magic = ceil(65536 / d)).
+__host__ __device__ __forceinline__ int div_small_magic(int d) { return (65536 + d - 1) / d; }
+__device__ __forceinline__ int div_small(int m, int magic) { return (m * magic) >> 16; }
+
 }  // namespace srk
