@@ -28,7 +28,10 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # SRK_DIST_BACKEND=gloo lets the multi-rank code path be exercised on a single-GPU box
+            backend = os.environ.get("SRK_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available() and os.environ.get("SRK_SINGLE_GPU"):
+            local = 0  # test mode: every rank shares device 0
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
