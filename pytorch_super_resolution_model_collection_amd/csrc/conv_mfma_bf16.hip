@@ -608,6 +608,12 @@ static void bf3_launch(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s)
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     cur = (int)lds;
   }
+  if (B.dbg & 32) {
+    int nb = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_conv_bf3<NT>), 256, lds);
+    fprintf(stderr, "[srk] k_conv_bf3<%d>: lds %zu B, grid %u x %u, occupancy %d blocks/CU, tile %dx%d halo %dx%d\n", NT,
+            lds, grid.x, grid.y, nb, B.P.TH, B.P.TW, B.P.HH, B.P.HW);
+  }
   hipLaunchKernelGGL(k_conv_bf3<NT>, grid, dim3(256), lds, s, B);
 }
 
@@ -697,6 +703,8 @@ static int bf3_launch_phase(MfmaConvParams P, const uint4* wq, hipStream_t s) {
       dbg = e ? atoi(e) : 0;
     }
     B.dbg = dbg;
+  }
+    B.stagger = stag;
   }
   size_t lds = (size_t)8 * B.NPIXp * 16 + wbytes;
   const size_t epi_bytes = (size_t)4 * 32 * BF3_EPI_STRIDE * sizeof(float);

@@ -51,7 +51,14 @@ static inline bool pick_tile(int maxpix, int PH, int PW, int is, int KHv, int KW
       if ((long)HH * HWd * psa <= budget_floats) {
         const long tiles = (long)cdiv(PH, TH) * cdiv(PW, TW);
         const long halo = (long)HH * HWd * tiles;
-        if (!found || tiles < best_tiles || (tiles == best_tiles && halo < best_halo)) {
+        // fewest tiles; then (within 6 %) the WIDEST tile: wave lanes map to consecutive pixels of a
+        // row, so wide rows keep the 16-lane fragment reads contiguous in LDS (conflict-free) and the
+        // global halo loads / output stores long and coalesced; then the smallest halo.
+        const bool fewer = tiles < best_tiles;
+        const bool same = tiles == best_tiles;
+        const bool wider = same && halo * 100 <= best_halo * 106 && TW > best.TW;
+        const bool smaller = same && halo < best_halo && TW >= best.TW;
+        if (!found || fewer || wider || smaller) {
           found = true;
           best_tiles = tiles;
           best_halo = halo;
