@@ -704,8 +704,6 @@ static int bf3_launch_phase(MfmaConvParams P, const uint4* wq, hipStream_t s) {
     }
     B.dbg = dbg;
   }
-    B.stagger = stag;
-  }
   size_t lds = (size_t)8 * B.NPIXp * 16 + wbytes;
   const size_t epi_bytes = (size_t)4 * 32 * BF3_EPI_STRIDE * sizeof(float);
   if (lds < epi_bytes) lds = epi_bytes;
