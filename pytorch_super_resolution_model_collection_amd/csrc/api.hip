@@ -31,6 +31,10 @@ size_t conv_wgrad_mfma_ws(const srk_conv_desc& d);
 int conv_wgrad_mfma(const srk_conv_desc& d, const float* x, const float* dy, const srk_bwd_mask* mask, float* dw,
                     float* db, float beta, void* ws, size_t ws_bytes, hipStream_t s);
 
+// conv_fused2_bf16.hip
+int conv_fused2_forward(const srk_conv_desc& d1, const srk_conv_desc& d2, const float* x, int x_nchw,
+                        const float* wp1, const float* wp2, float* y, const Epi& ep1, const Epi& ep2, hipStream_t s);
+
 static int validate_desc(const srk_conv_desc* d, const char* who) {
   SRK_REQUIRE(d, "%s: null descriptor", who);
   SRK_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "%s: non-positive tensor dims", who);
@@ -161,4 +165,18 @@ extern "C" int srk_conv2d_backward_weight(const srk_conv_desc* d, const float* x
   if (algo != SRK_ALGO_GENERIC && conv_wgrad_mfma_supported(*d))
     return conv_wgrad_mfma(*d, x, dy, mask, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);
   return conv_generic_wgrad(*d, x, dy, mask, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int srk_conv2d_fused2_forward(const srk_conv_desc* d1, const srk_conv_desc* d2, const float* x,
+                                         int x_is_nchw, const float* w1_packed_fwd, const float* w2_packed_fwd,
+                                         float* y, const srk_epilogue* ep1, const srk_epilogue* ep2, void* stream) {
+  int rc = validate_desc(d1, "conv2d_fused2_forward(conv1)");
+  if (rc) return rc;
+  rc = validate_desc(d2, "conv2d_fused2_forward(conv2)");
+  if (rc) return rc;
+  SRK_REQUIRE(x && w1_packed_fwd && w2_packed_fwd && y, "conv2d_fused2_forward: null tensor pointer");
+  const Epi e1 = make_epi(ep1), e2 = make_epi(ep2);
+  SRK_REQUIRE(e2.act != SRK_ACT_PRELU || (e2.prelu_w && e2.prelu_n >= 1), "conv2d_fused2_forward: PReLU needs its weight");
+  return conv_fused2_forward(*d1, *d2, x, x_is_nchw ? 1 : 0, w1_packed_fwd, w2_packed_fwd, y, e1, e2,
+                             (hipStream_t)stream);
 }

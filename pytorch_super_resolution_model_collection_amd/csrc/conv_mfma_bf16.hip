@@ -151,19 +151,20 @@ __device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4
 // once per chunk instead of once per pass.
 constexpr int BF3_STAGE_IT = 6;  // covers halos of <= 384 pixels per batch; larger halos loop over batches
 
-template <bool MASK>
+template <bool MASK, int NTHR>
 __device__ __forceinline__ void bf3_stage_halo_t(const Bf3Params& B, uint4* hal, int n, int r0, int c0, int cb) {
   const MfmaConvParams& P = B.P;
   const int npix = P.HH * P.HW;
   const int g = threadIdx.x & 3;
   const int hp0 = threadIdx.x >> 2;
   int hy = hp0 / P.HW, hx = hp0 - hy * P.HW;
-  const int dy64 = 64 / P.HW, dx64 = 64 - dy64 * P.HW;
+  constexpr int PPP = NTHR / 4;  // pixels per pass
+  const int dy64 = PPP / P.HW, dx64 = PPP - dy64 * P.HW;
   const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
   const int ch = cb + g * 8;
   const bool ch_any = ch < P.IC, ch_vec = P.vec_in && ch + 7 < P.IC;
   const size_t img = (size_t)n * P.IH;
-  for (int base = hp0; base < npix; base += 64 * BF3_STAGE_IT) {
+  for (int base = hp0; base < npix; base += PPP * BF3_STAGE_IT) {
     f32x4 v0[BF3_STAGE_IT], v1[BF3_STAGE_IT], m0[BF3_STAGE_IT], m1[BF3_STAGE_IT];
     // pass 1: issue every load of this batch
 #pragma unroll
@@ -174,7 +175,7 @@ __device__ __forceinline__ void bf3_stage_halo_t(const Bf3Params& B, uint4* hal,
         m0[k] = (f32x4){1.f, 1.f, 1.f, 1.f};
         m1[k] = (f32x4){1.f, 1.f, 1.f, 1.f};
       }
-      const int hp = base + 64 * k;
+      const int hp = base + PPP * k;
       const int iy = iyb + hy, ix = ixb + hx;
       if (hp < npix && ch_any && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) {
         const size_t off = ((img + iy) * P.IW + ix) * P.IC + ch;
@@ -209,7 +210,7 @@ __device__ __forceinline__ void bf3_stage_halo_t(const Bf3Params& B, uint4* hal,
     // pass 2: mask, split, store
 #pragma unroll
     for (int k = 0; k < BF3_STAGE_IT; ++k) {
-      const int hp = base + 64 * k;
+      const int hp = base + PPP * k;
       if (hp < npix) {
         float f[8];
 #pragma unroll
@@ -230,11 +231,12 @@ __device__ __forceinline__ void bf3_stage_halo_t(const Bf3Params& B, uint4* hal,
   }
 }
 
+template <int NTHR>
 __device__ __forceinline__ void bf3_stage_halo(const Bf3Params& B, uint4* hal, int n, int r0, int c0, int cb) {
   if (B.P.mask_y)
-    bf3_stage_halo_t<true>(B, hal, n, r0, c0, cb);
+    bf3_stage_halo_t<true, NTHR>(B, hal, n, r0, c0, cb);
   else
-    bf3_stage_halo_t<false>(B, hal, n, r0, c0, cb);
+    bf3_stage_halo_t<false, NTHR>(B, hal, n, r0, c0, cb);
 }
 
 constexpr int BF3_MAXTAPS = 128;   // taps with precomputed tables (larger kernels: computed on the fly)
@@ -288,8 +290,9 @@ __device__ __forceinline__ void bf3_epilogue(const MfmaConvParams& P, float* sme
   }
 }
 
-template <int NT>
-__global__ __launch_bounds__(256, 2) void k_conv_bf3(Bf3Params B) {
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void k_conv_bf3(Bf3Params B) {
+  constexpr int NTHR = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   __shared__ int tap_toff[BF3_MAXTAPS];
   __shared__ int tap_wtap[BF3_MAXTAPS];
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3(Bf3Params B) {
   const int wslot = 8 * NB;  // uint4 per weight buffer
   const int T = P.KHv * P.KWv;
 
-  for (int t = tid; t < T && t < BF3_MAXTAPS; t += 256) {
+  for (int t = tid; t < T && t < BF3_MAXTAPS; t += NTHR) {
     const int u = t / P.KWv, v = t - u * P.KWv;
     tap_toff[t] = u * P.HW + v;
     tap_wtap[t] = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3(Bf3Params B) {
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const bool wave_live = wave * 64 < npx;
-  const bool w0_ok = tid < wslot, w1_ok = tid + 256 < wslot;
+  constexpr int WCP = 512 / NTHR;  // weight-slice uint4 per thread (wslot <= 512)
   const int lo_plane = 4 * B.NPIXp;
   const int wlane = kq * NB + j;
 
@@ -349,19 +352,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3(Bf3Params B) {
         }
         return B.wq + ((size_t)(tapw * B.ICc + cc) * B.OCb + ocbi) * (size_t)wslot;
       };
-      if (!(B.dbg & 1)) bf3_stage_halo(B, hal, n, r0, c0, cc * 32);
+      if (!(B.dbg & 1)) bf3_stage_halo<NTHR>(B, hal, n, r0, c0, cc * 32);
       {
         const uint4* src = wsrc(0);
-        if (w0_ok) wl[tid] = src[tid];
-        if (w1_ok) wl[tid + 256] = src[tid + 256];
+#pragma unroll
+        for (int c = 0; c < WCP; ++c)
+          if (tid + c * NTHR < wslot) wl[tid + c * NTHR] = src[tid + c * NTHR];
       }
       __syncthreads();
       for (int t = 0; t < T; ++t) {
-        uint4 wr0 = {0, 0, 0, 0}, wr1 = {0, 0, 0, 0};
+        uint4 wr[WCP];
+#pragma unroll
+        for (int c = 0; c < WCP; ++c) wr[c] = make_uint4(0, 0, 0, 0);
         if (t + 1 < T && !(B.dbg & 8)) {  // prefetch the next tap's slice; lands while the MFMAs below run
           const uint4* src = wsrc(t + 1);
-          if (w0_ok) wr0 = src[tid];
-          if (w1_ok) wr1 = src[tid + 256];
+#pragma unroll
+          for (int c = 0; c < WCP; ++c)
+            if (tid + c * NTHR < wslot) wr[c] = src[tid + c * NTHR];
         }
         if (wave_live && !(B.dbg & 4)) {
           int toff;
@@ -401,8 +408,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3(Bf3Params B) {
         }
         if (t + 1 < T) {
           uint4* wn = wl + ((t + 1) & 1) * wslot;
-          if (w0_ok) wn[tid] = wr0;
-          if (w1_ok) wn[tid + 256] = wr1;
+#pragma unroll
+          for (int c = 0; c < WCP; ++c)
+            if (tid + c * NTHR < wslot) wn[tid + c * NTHR] = wr[c];
         }
         __syncthreads();
       }
@@ -600,21 +608,22 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3_rows(Bf3Params B) {
 // ---------------------------------------------------------------------------------------------
 // Host
 // ---------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int NW>
 static void bf3_launch(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s) {
   static int cur = 0;
   if ((int)lds > cur) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bf3<NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bf3<NT, NW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     cur = (int)lds;
   }
   if (B.dbg & 32) {
     int nb = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_conv_bf3<NT>), 256, lds);
-    fprintf(stderr, "[srk] k_conv_bf3<%d>: lds %zu B, grid %u x %u, occupancy %d blocks/CU, tile %dx%d halo %dx%d\n", NT,
-            lds, grid.x, grid.y, nb, B.P.TH, B.P.TW, B.P.HH, B.P.HW);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_conv_bf3<NT, NW>), 64 * NW,
+                                                       lds);
+    fprintf(stderr, "[srk] k_conv_bf3<%d,%d>: lds %zu B, grid %u x %u, occupancy %d blocks/CU, tile %dx%d halo %dx%d\n", NT,
+            NW, lds, grid.x, grid.y, nb, B.P.TH, B.P.TW, B.P.HH, B.P.HW);
   }
-  hipLaunchKernelGGL(k_conv_bf3<NT>, grid, dim3(256), lds, s, B);
+  hipLaunchKernelGGL((k_conv_bf3<NT, NW>), grid, dim3(64 * NW), lds, s, B);
 }
 
 bool conv_bf3_gather_supported(const GatherConv& g, const Epi& ep) {
@@ -667,22 +676,19 @@ static int bf3_launch_rows_phase(MfmaConvParams P, const uint4* wq, hipStream_t 
   return check_launch("conv_bf3_rows");
 }
 
-static int bf3_launch_phase(MfmaConvParams P, const uint4* wq, hipStream_t s) {
-  if (P.IC <= 4) return bf3_launch_rows_phase(P, wq, s);
-  Bf3Params B{};
-  const int NT = P.OC >= 64 ? 4 : (P.OC + 15) / 16;
-  B.NB = NT * 16;
-  B.ICc = (P.IC + 31) / 32;
-  B.OCb = (P.OC + 63) / 64;
-  B.wq = wq;
+template <int NW>
+static int bf3_launch_phase_nw(MfmaConvParams P, Bf3Params B, int NT, int dbg, hipStream_t s) {
   const int wbytes = 2 * 8 * B.NB * 16;
-  // halo pixel = 128 B (2 planes x 4 groups x 16 B); try 2 blocks/CU first, fall back to 1 block/CU
+  const int maxpix = 64 * NW;
+  // LDS share that lets `blocks` blocks of this size be co-resident on a CU (160 KiB)
+  const int budget = NW == 4 ? kLdsBudgetBytes : (NW == 2 ? 39 * 1024 : 31 * 1024);
+  // halo pixel = 128 B (2 planes x 4 groups x 16 B); fall back to one block per CU for huge halos
   TilePick best{};
-  bool ok = pick_tile(256, P.PH, P.PW, P.is, P.KHv > 0 ? P.KHv : 1, P.KWv > 0 ? P.KWv : 1, 32,
-                      (kLdsBudgetBytes - wbytes) / 4 - 16 * 32, best);
+  bool ok = pick_tile(maxpix, P.PH, P.PW, P.is, P.KHv > 0 ? P.KHv : 1, P.KWv > 0 ? P.KWv : 1, 32,
+                      (budget - wbytes) / 4 - 16 * 32, best);
   if (!ok || best.eff < 0.6) {
     TilePick big{};
-    if (pick_tile(256, P.PH, P.PW, P.is, P.KHv > 0 ? P.KHv : 1, P.KWv > 0 ? P.KWv : 1, 32,
+    if (pick_tile(maxpix, P.PH, P.PW, P.is, P.KHv > 0 ? P.KHv : 1, P.KWv > 0 ? P.KWv : 1, 32,
                   (156 * 1024 - wbytes) / 4 - 16 * 32, big) &&
         (!ok || big.eff > best.eff * 1.2)) {
       best = big;
@@ -696,25 +702,39 @@ static int bf3_launch_phase(MfmaConvParams P, const uint4* wq, hipStream_t s) {
   P.TH = best.TH; P.TW = best.TW; P.tiles_y = best.tiles_y; P.tiles_x = best.tiles_x; P.HH = best.HH; P.HW = best.HW;
   B.NPIXp = (best.HH * best.HW + 15) & ~15;
   B.P = P;
-  {
-    static int dbg = -1;
-    if (dbg < 0) {
-      const char* e = getenv("SRK_DBG");
-      dbg = e ? atoi(e) : 0;
-    }
-    B.dbg = dbg;
-  }
+  B.dbg = dbg;
   size_t lds = (size_t)8 * B.NPIXp * 16 + wbytes;
-  const size_t epi_bytes = (size_t)4 * 32 * BF3_EPI_STRIDE * sizeof(float);
+  const size_t epi_bytes = (size_t)NW * 32 * BF3_EPI_STRIDE * sizeof(float);
   if (lds < epi_bytes) lds = epi_bytes;
+  if (dbg & 64) lds = 100 * 1024;  // experiment: force 1 block per CU
   dim3 grid((unsigned)((size_t)P.tiles_x * P.tiles_y * P.N), B.OCb);
   switch (NT) {
-    case 1: bf3_launch<1>(B, grid, lds, s); break;
-    case 2: bf3_launch<2>(B, grid, lds, s); break;
-    case 3: bf3_launch<3>(B, grid, lds, s); break;
-    default: bf3_launch<4>(B, grid, lds, s); break;
+    case 1: bf3_launch<1, NW>(B, grid, lds, s); break;
+    case 2: bf3_launch<2, NW>(B, grid, lds, s); break;
+    case 3: bf3_launch<3, NW>(B, grid, lds, s); break;
+    default: bf3_launch<4, NW>(B, grid, lds, s); break;
   }
   return check_launch("conv_bf3");
+}
+
+static int bf3_launch_phase(MfmaConvParams P, const uint4* wq, hipStream_t s) {
+  if (P.IC <= 4) return bf3_launch_rows_phase(P, wq, s);
+  Bf3Params B{};
+  const int NT = P.OC >= 64 ? 4 : (P.OC + 15) / 16;
+  B.NB = NT * 16;
+  B.ICc = (P.IC + 31) / 32;
+  B.OCb = (P.OC + 63) / 64;
+  B.wq = wq;
+  static int dbg = -1, nw = -1;
+  if (dbg < 0) {
+    const char* e = getenv("SRK_DBG");
+    dbg = e ? atoi(e) : 0;
+    const char* w = getenv("SRK_BF3_WAVES");  // waves per block: 4 (256-px tiles), 2 or 1 — more, smaller blocks per CU
+    nw = w ? atoi(w) : 4;
+  }
+  if (nw == 1) return bf3_launch_phase_nw<1>(P, B, NT, dbg, s);
+  if (nw == 2) return bf3_launch_phase_nw<2>(P, B, NT, dbg, s);
+  return bf3_launch_phase_nw<4>(P, B, NT, dbg, s);
 }
 
 int conv_bf3_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
