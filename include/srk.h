@@ -72,6 +72,8 @@ typedef struct srk_conv_desc {
   int32_t transposed; /* 0: Conv2d, 1: ConvTranspose2d */
   int32_t out_pad;    /* ConvTranspose2d output_padding (fsrcnn.py:33 uses 1) */
   int32_t algo;       /* srk_algo */
+  int32_t x_nchw;     /* forward only: x is the caller's NCHW tensor (read in place by the Cin <= 4 bf16x3
+                         first-layer kernel; SRK_ERR_UNSUPPORTED elsewhere) */
 } srk_conv_desc;
 
 /* Fused epilogue of a forward conv:  y = PS_r( act(conv + bias) ) + residual

@@ -32,7 +32,7 @@ class ConvDesc(ctypes.Structure):
     """struct srk_conv_desc"""
     _fields_ = [(n, ctypes.c_int32) for n in
                 ("N", "H", "W", "Cin", "OH", "OW", "Cout", "KH", "KW", "stride", "pad", "transposed", "out_pad",
-                 "algo")]
+                 "algo", "x_nchw")]
 
 
 class Epilogue(ctypes.Structure):

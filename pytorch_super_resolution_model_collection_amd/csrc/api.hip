@@ -129,7 +129,17 @@ extern "C" int srk_conv2d_forward(const srk_conv_desc* d, const float* x, const 
     SRK_REQUIRE(ep.act != SRK_ACT_PRELU || ep.prelu_n == 1 || ep.prelu_n == d->Cout,
                 "conv2d_forward: PReLU must have 1 or Cout slopes");
   }
-  GatherConv g{d->N, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->pad, d->transposed};
+  GatherConv g{d->N, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->pad, d->transposed, 0};
+  if (d->x_nchw) {
+    // only the row-packed bf16x3 first-layer kernel reads an NCHW input in place
+    const int algo = forced_algo(d->algo);
+    if (!(d->Cin <= 4 && !d->transposed && d->Cout >= 8 && (algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3) &&
+          conv_bf3_gather_supported(g, ep))) {
+      set_error("conv2d_forward: x_nchw is only supported by the Cin <= 4 bf16x3 kernel");
+      return SRK_ERR_UNSUPPORTED;
+    }
+    g.in_nchw = 1;
+  }
   return run_gather(g, d->algo, x, w_packed_fwd, y, ep, nullptr, 0.f, (hipStream_t)stream, "conv2d_forward");
 }
 
@@ -139,7 +149,7 @@ extern "C" int srk_conv2d_backward_data(const srk_conv_desc* d, const float* dy,
   if (rc) return rc;
   SRK_REQUIRE(dy && w_packed_bwd && dx, "conv2d_backward_data: null tensor pointer");
   // dx is a gather over dy with the channel roles swapped and the opposite gather kind.
-  GatherConv g{d->N, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad, !d->transposed};
+  GatherConv g{d->N, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad, !d->transposed, 0};
   Epi ep{};
   ep.residual = add_to;
   return run_gather(g, d->algo, dy, w_packed_bwd, dx, ep, mask ? mask->y : nullptr, mask ? mask->slope : 0.f,

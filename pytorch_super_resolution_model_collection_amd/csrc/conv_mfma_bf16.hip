@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3_rows(Bf3Params B) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (e < P.IC) {
-              float x = P.in[off + e];
+              float x = P.in_nchw ? P.in[(((size_t)n * P.IC + e) * P.IH + iy) * P.IW + ix] : P.in[off + e];
               if (P.mask_y) x = P.mask_y[off + e] > 0.f ? x : x * P.mask_slope;
               f[e] = x;
             }

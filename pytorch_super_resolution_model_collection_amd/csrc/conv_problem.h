@@ -10,6 +10,7 @@ struct GatherConv {
   int N, IH, IW, IC;
   int OH, OW, OC;
   int KH, KW, stride, pad, trans;
+  int in_nchw;  // input is NCHW (only the bf16x3 row-packed kernel reads it in place)
 };
 
 // Device-side epilogue: out = PS_r(act(acc + bias)) + residual

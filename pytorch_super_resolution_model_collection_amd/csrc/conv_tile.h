@@ -27,6 +27,7 @@ struct MfmaConvParams {
   int BNp;  // LDS filter row stride in floats (NT*16 + 4)
   int halo_floats;
   int vec_in, vec_w;
+  int in_nchw;  // input tensor is NCHW (row-packed Cin <= 4 kernel only)
 };
 
 static constexpr int kLdsBudgetBytes = 78 * 1024;  // 2 blocks per CU out of 160 KiB
@@ -82,6 +83,7 @@ static inline int for_each_phase(const GatherConv& g, const float* in, const flo
   P.in = in; P.wp = wp; P.out = out; P.mask_y = mask_y; P.mask_slope = mask_slope; P.ep = ep;
   P.N = g.N; P.IH = g.IH; P.IW = g.IW; P.IC = g.IC; P.OH = g.OH; P.OW = g.OW; P.OC = g.OC;
   P.KW_full = g.KW;
+  P.in_nchw = g.in_nchw;
   P.vec_in = (g.IC % 4 == 0) && ((uintptr_t)in % 16 == 0) && (!mask_y || (uintptr_t)mask_y % 16 == 0);
   P.vec_w = (g.OC % 4 == 0) && ((uintptr_t)wp % 16 == 0);
   if (!g.trans) {

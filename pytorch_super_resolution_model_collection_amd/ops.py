@@ -181,10 +181,11 @@ def pack_bias_ps(bias, ps_r):
     return bp
 
 
-def conv_forward_raw(x, wp, bias_p, weight_shape_src, cfg, prelu_w=None, residual=None, role="infer"):
-    """Launch srk_conv2d_forward on already-packed weights. x must be NHWC-dense."""
+def conv_forward_raw(x, wp, bias_p, weight_shape_src, cfg, prelu_w=None, residual=None, role="infer", x_nchw=False):
+    """Launch srk_conv2d_forward on already-packed weights. x must be NHWC-dense (or NCHW with x_nchw)."""
     lib = _lib.load()
     d = _make_desc(x.shape, weight_shape_src, cfg, role)
+    d.x_nchw = int(bool(x_nchw))
     r = cfg.ps_r if cfg.ps_r > 1 else 1
     y = _empty_cl(d.N, d.Cout // (r * r), d.OH * r, d.OW * r, x)
     if residual is not None and tuple(residual.shape) != tuple(y.shape):
@@ -278,7 +279,12 @@ def conv2d_infer(x, weight, bias=None, residual=None, cfg=None, prelu_w=None, pa
     """No-grad fully fused conv: any activation + residual + pixel shuffle in one kernel."""
     cfg = cfg or ConvCfg()
     require_cuda(x, weight, bias, residual, prelu_w)
-    x = to_nhwc(x)
+    cout, cin, _, _ = _weight_dims(weight, cfg.transposed)
+    # the Cin <= 4 bf16x3 first-layer kernel reads the caller's NCHW tensor in place (no layout copy)
+    x_nchw = (x.dim() == 4 and cin <= 4 and cout >= 8 and not cfg.transposed and not _is_nhwc_dense(x)
+              and _is_nchw_dense(x) and _algo_for(cfg, "infer") == ALGO_AUTO)
+    if not x_nchw:
+        x = to_nhwc(x)
     if residual is not None:
         residual = to_nhwc(residual)
     if packed is not None:
@@ -286,7 +292,7 @@ def conv2d_infer(x, weight, bias=None, residual=None, cfg=None, prelu_w=None, pa
     else:
         wp = pack_weight_fwd(weight, cfg.transposed, cfg.ps_r)
         bp = pack_bias_ps(bias, cfg.ps_r)
-    return conv_forward_raw(x, wp, bp, weight, cfg, prelu_w, residual)
+    return conv_forward_raw(x, wp, bp, weight, cfg, prelu_w, residual, "infer", x_nchw)
 
 
 def conv2d_fused2_infer(x, conv1, act1, slope1, conv2, act2, slope2, prelu2=None):
