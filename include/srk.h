@@ -132,6 +132,13 @@ int srk_pack_weight_fwd(const float* w, float* wp, int Cout, int Cin, int KH, in
 int srk_pack_weight_bwd(const float* w, float* wp, int Cout, int Cin, int KH, int KW, int transposed,
                         void* stream);
 int srk_pack_bias_ps(const float* b, float* bp, int Cout, int ps_r, void* stream);
+/* Whole-model packing in ONE launch (training: the weights change every step).  `params_base` is the
+ * flat fp32 parameter buffer, `packed_base` a caller-owned byte buffer, `table` a DEVICE array of
+ * n_layers rows x 12 int64: {w_off (floats), fwd_off (bytes, -1 skip), bwd_off (bytes, -1 skip), Cout,
+ * Cin, KH, KW, transposed, ps_r, bias_off (floats, -1), bias_ps_off (bytes, -1), 0}.  Every
+ * fwd_off / bwd_off region receives exactly what srk_pack_weight_fwd / _bwd would write there. */
+int srk_pack_weights_batched(const float* params_base, void* packed_base, const int64_t* table, int n_layers,
+                             int blocks_per_layer, void* stream);
 
 /* ---- convolution (Conv2d / ConvTranspose2d: base_networks.py:42,77,112-113,156; fsrcnn.py:33) */
 int srk_conv2d_forward(const srk_conv_desc* d, const float* x, const float* w_packed_fwd, float* y,

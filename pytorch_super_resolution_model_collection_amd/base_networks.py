@@ -159,6 +159,7 @@ class PSBlock(_Block):
         self.conv = Conv2d(input_size, output_size * scale_factor ** 2, kernel_size, stride, padding, bias=bias)
         self.ps = PixelShuffle(scale_factor)
         self._r = int(scale_factor)
+        self.conv._ps_r = self._r  # PackPlan packs this conv's filter in pixel-shuffle channel order
         self._setup(output_size, activation, norm)
 
     def forward(self, x):

@@ -35,6 +35,10 @@ int conv_wgrad_mfma(const srk_conv_desc& d, const float* x, const float* dy, con
 int conv_fused2_forward(const srk_conv_desc& d1, const srk_conv_desc& d2, const float* x, int x_nchw,
                         const float* wp1, const float* wp2, float* y, const Epi& ep1, const Epi& ep2, hipStream_t s);
 
+// conv_mfma_bf16.hip
+int pack_weights_batched(const float* params, void* packed, const long long* table, int n_layers, int blocks,
+                         hipStream_t s);
+
 static int validate_desc(const srk_conv_desc* d, const char* who) {
   SRK_REQUIRE(d, "%s: null descriptor", who);
   SRK_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "%s: non-positive tensor dims", who);
@@ -189,4 +193,12 @@ extern "C" int srk_conv2d_fused2_forward(const srk_conv_desc* d1, const srk_conv
   SRK_REQUIRE(e2.act != SRK_ACT_PRELU || (e2.prelu_w && e2.prelu_n >= 1), "conv2d_fused2_forward: PReLU needs its weight");
   return conv_fused2_forward(*d1, *d2, x, x_is_nchw ? 1 : 0, w1_packed_fwd, w2_packed_fwd, y, e1, e2,
                              (hipStream_t)stream);
+}
+
+extern "C" int srk_pack_weights_batched(const float* params_base, void* packed_base, const int64_t* table, int n_layers,
+                                        int blocks_per_layer, void* stream) {
+  SRK_REQUIRE(params_base && packed_base && table, "pack_weights_batched: null pointer");
+  SRK_REQUIRE(n_layers > 0 && n_layers <= 65535 && blocks_per_layer > 0, "pack_weights_batched: bad sizes");
+  return pack_weights_batched(params_base, packed_base, reinterpret_cast<const long long*>(table), n_layers,
+                              blocks_per_layer, (hipStream_t)stream);
 }

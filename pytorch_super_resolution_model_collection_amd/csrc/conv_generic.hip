@@ -12,6 +12,7 @@
 // gradient of each is the other gather with the channel roles swapped (see api.hip).
 #include "srk_common.h"
 #include "conv_problem.h"
+#include "pack_items.h"
 
 namespace srk {
 
@@ -275,27 +276,7 @@ __global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w
   const int elems = KH * KW * Cin * Cout;
   const int e = blockIdx.x * 256 + threadIdx.x;  // index in the PACKED layout (coalesced stores)
   if (e >= elems) return;
-  int ci, co_p, tap;
-  if (!bwd) {
-    co_p = e % Cout;
-    ci = (e / Cout) % Cin;
-    tap = e / (Cout * Cin);
-  } else {
-    ci = e % Cin;
-    co_p = (e / Cin) % Cout;
-    tap = e / (Cout * Cin);
-  }
-  const int kh = tap / KW, kw = tap % KW;
-  int co = co_p;
-  if (ps_r > 1) {
-    // packed order (i, j, c) -> torch order c*r*r + i*r + j
-    const int C = Cout / (ps_r * ps_r);
-    const int q = co_p / C, c = co_p % C;
-    co = c * ps_r * ps_r + q;
-  }
-  const size_t src = transposed ? ((((size_t)ci * Cout + co) * KH + kh) * KW + kw)
-                                : ((((size_t)co * Cin + ci) * KH + kh) * KW + kw);
-  wp[e] = w[src];
+  pack_f32_item(e, w, wp, Cout, Cin, KH, KW, transposed, ps_r, bwd);
 }
 
 __global__ void k_pack_bias_ps(const float* __restrict__ b, float* __restrict__ bp, int Cout, int ps_r) {

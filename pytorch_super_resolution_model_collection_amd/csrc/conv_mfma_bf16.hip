@@ -22,6 +22,7 @@
 #include "srk_common.h"
 #include "conv_problem.h"
 #include "conv_tile.h"
+#include "pack_items.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -58,50 +59,10 @@ __device__ __forceinline__ void split8(const float (&f)[8], uint4& hi, uint4& lo
 __global__ __launch_bounds__(256) void k_bf3_pack(const float* __restrict__ w, uint4* __restrict__ dst, int Cout,
                                                   int Cin, int KH, int KW, int transposed, int ps_r, int bwd, int IC,
                                                   int OC, int ICc, int OCb, int NB) {
-  const int T = KH * KW;
-  const long items = (long)T * ICc * OCb * 4 * NB;
+  const long items = (long)KH * KW * ICc * OCb * 4 * NB;
   const long it = (long)blockIdx.x * 256 + threadIdx.x;
   if (it >= items) return;
-  const int col = (int)(it % NB);
-  long r = it / NB;
-  const int g = (int)(r % 4);
-  r /= 4;
-  const int ocb = (int)(r % OCb);
-  r /= OCb;
-  const int cc = (int)(r % ICc);
-  const int tap = (int)(r / ICc);
-  const int kh = tap / KW, kw = tap - kh * KW;
-  const int oc = ocb * 64 + col;
-  float f[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int ic = cc * 32 + g * 8 + e;
-    float v = 0.f;
-    if (ic < IC && oc < OC) {
-      int ci, co;
-      if (!bwd) {
-        ci = ic;
-        co = oc;
-        if (ps_r > 1) {  // packed order (i, j, c) -> torch order c*r*r + i*r + j
-          const int C = Cout / (ps_r * ps_r);
-          const int q = oc / C, c = oc - q * C;
-          co = c * ps_r * ps_r + q;
-        }
-      } else {
-        ci = oc;
-        co = ic;
-      }
-      const size_t src = transposed ? ((((size_t)ci * Cout + co) * KH + kh) * KW + kw)
-                                    : ((((size_t)co * Cin + ci) * KH + kh) * KW + kw);
-      v = w[src];
-    }
-    f[e] = v;
-  }
-  uint4 hi, lo;
-  split8(f, hi, lo);
-  uint4* blk = dst + ((size_t)(tap * ICc + cc) * OCb + ocb) * (size_t)(8 * NB);
-  blk[(0 * 4 + g) * NB + col] = hi;
-  blk[(1 * 4 + g) * NB + col] = lo;
+  pack_bf3_item(it, w, dst, Cout, Cin, KH, KW, transposed, ps_r, bwd, IC, OC, ICc, OCb, NB);
 }
 
 __global__ void k_bf3_pack_rows(const float* __restrict__ w, uint4* __restrict__ dst, int Cout, int Cin, int KH, int KW,
@@ -435,41 +396,63 @@ __global__ __launch_bounds__(256) void k_bf3_pack_rows(const float* __restrict__
   const long items = (long)KH * KS * OCb * 4 * NB;
   const long it = (long)blockIdx.x * 256 + threadIdx.x;
   if (it >= items) return;
-  const int col = (int)(it % NB);
-  long r = it / NB;
-  const int g = (int)(r % 4);
-  r /= 4;
-  const int ocb = (int)(r % OCb);
-  r /= OCb;
-  const int ks = (int)(r % KS);
-  const int kh = (int)(r / KS);
-  const int oc = ocb * 64 + col;
-  float f[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int kw = ks * 8 + 2 * g + (e >> 2), ic = e & 3;
-    float v = 0.f;
-    if (kw < KW && ic < IC && oc < OC) {
-      int ci = ic, co = oc;
-      if (bwd) {
-        ci = oc;
-        co = ic;
-      } else if (ps_r > 1) {
-        const int C = Cout / (ps_r * ps_r);
-        const int q = oc / C, c = oc - q * C;
-        co = c * ps_r * ps_r + q;
-      }
-      const size_t src = transposed ? ((((size_t)ci * Cout + co) * KH + kh) * KW + kw)
-                                    : ((((size_t)co * Cin + ci) * KH + kh) * KW + kw);
-      v = w[src];
-    }
-    f[e] = v;
+  pack_bf3_rows_item(it, w, dst, Cout, Cin, KH, KW, transposed, ps_r, bwd, IC, OC, KS, OCb, NB);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Whole-model packing in ONE launch: grid = (blocks, layers).  Table row (int64 x 12) per layer:
+//   0 w_off (floats from params_base)   1 fwd_off (bytes from packed_base)   2 bwd_off (bytes)
+//   3 Cout  4 Cin  5 KH  6 KW  7 transposed  8 ps_r  9 bias_off (floats, -1 none)
+//   10 bias_ps_off (bytes, -1 none)  11 reserved
+// Each packed buffer has the srk_pack_weight_fwd / _bwd format (fp32 layout + bf16x3 planes).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pack_one_dir(const float* w, char* dst, int Cout, int Cin, int KH, int KW,
+                                             int transposed, int ps_r, int bwd, long tid0, long stride) {
+  const long elems = (long)KH * KW * Cin * Cout;
+  float* wp = reinterpret_cast<float*>(dst);
+  for (long e = tid0; e < elems; e += stride) pack_f32_item((int)e, w, wp, Cout, Cin, KH, KW, transposed, ps_r, bwd);
+  const int IC = bwd ? Cout : Cin, OC = bwd ? Cin : Cout;
+  const int OCb = (OC + 63) / 64, NB = OC >= 64 ? 64 : ((OC + 15) / 16) * 16;
+  uint4* q = reinterpret_cast<uint4*>(dst + ((elems * 4 + 255) & ~255L));
+  const int gather_trans = bwd ? !transposed : transposed;
+  if (IC <= 4 && !gather_trans) {
+    const int KS = (KW + 7) / 8;
+    const long items = (long)KH * KS * OCb * 4 * NB;
+    for (long it = tid0; it < items; it += stride)
+      pack_bf3_rows_item(it, w, q, Cout, Cin, KH, KW, transposed, ps_r, bwd, IC, OC, KS, OCb, NB);
+  } else {
+    const int ICc = (IC + 31) / 32;
+    const long items = (long)KH * KW * ICc * OCb * 4 * NB;
+    for (long it = tid0; it < items; it += stride)
+      pack_bf3_item(it, w, q, Cout, Cin, KH, KW, transposed, ps_r, bwd, IC, OC, ICc, OCb, NB);
   }
-  uint4 hi, lo;
-  split8(f, hi, lo);
-  uint4* blk = dst + ((size_t)(kh * KS + ks) * OCb + ocb) * (size_t)(8 * NB);
-  blk[(0 * 4 + g) * NB + col] = hi;
-  blk[(1 * 4 + g) * NB + col] = lo;
+}
+
+__global__ __launch_bounds__(256) void k_pack_batched(const float* __restrict__ params, char* __restrict__ packed,
+                                                      const long long* __restrict__ table) {
+  const long long* row = table + (size_t)blockIdx.y * 12;
+  const float* w = params + row[0];
+  const int Cout = (int)row[3], Cin = (int)row[4], KH = (int)row[5], KW = (int)row[6];
+  const int transposed = (int)row[7], ps_r = (int)row[8];
+  const long tid0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+  if (row[1] >= 0) pack_one_dir(w, packed + row[1], Cout, Cin, KH, KW, transposed, ps_r, 0, tid0, stride);
+  if (row[2] >= 0) pack_one_dir(w, packed + row[2], Cout, Cin, KH, KW, transposed, 0, 1, tid0, stride);
+  if (row[9] >= 0 && row[10] >= 0 && ps_r > 1) {
+    const float* b = params + row[9];
+    float* bp = reinterpret_cast<float*>(packed + row[10]);
+    const int C = Cout / (ps_r * ps_r);
+    for (long e = tid0; e < Cout; e += stride) {
+      const int q = (int)e / C, c = (int)e % C;
+      bp[e] = b[c * ps_r * ps_r + q];
+    }
+  }
+}
+
+int pack_weights_batched(const float* params, void* packed, const long long* table, int n_layers, int blocks,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(k_pack_batched, dim3((unsigned)blocks, (unsigned)n_layers), dim3(256), 0, s, params,
+                     static_cast<char*>(packed), table);
+  return check_launch("pack_weights_batched");
 }
 
 template <int NT>
@@ -730,10 +713,17 @@ static int bf3_launch_phase(MfmaConvParams P, const uint4* wq, hipStream_t s) {
     const char* e = getenv("SRK_DBG");
     dbg = e ? atoi(e) : 0;
     const char* w = getenv("SRK_BF3_WAVES");  // waves per block: 4 (256-px tiles), 2 or 1 — more, smaller blocks per CU
-    nw = w ? atoi(w) : 4;
+    nw = w ? atoi(w) : 0;  // 0 = automatic
   }
-  if (nw == 1) return bf3_launch_phase_nw<1>(P, B, NT, dbg, s);
-  if (nw == 2) return bf3_launch_phase_nw<2>(P, B, NT, dbg, s);
+  int use = nw;
+  if (nw <= 0) {
+    // small problems (strong-scaled shards): fewer pixels than 2 resident 256-pixel tiles per CU ->
+    // smaller blocks so every CU gets work (measured: 256-px tiles win whenever the chip is full)
+    const long px = (long)P.N * P.PH * P.PW * B.OCb;
+    use = px >= 256L * 2 * kNumCU ? 4 : (px >= 128L * 2 * kNumCU ? 2 : 1);
+  }
+  if (use == 1) return bf3_launch_phase_nw<1>(P, B, NT, dbg, s);
+  if (use == 2) return bf3_launch_phase_nw<2>(P, B, NT, dbg, s);
   return bf3_launch_phase_nw<4>(P, B, NT, dbg, s);
 }
 

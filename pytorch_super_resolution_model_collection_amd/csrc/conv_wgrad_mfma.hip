@@ -324,19 +324,28 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_smallcin(WgradParams P) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw, int G,
                                                       int Cout, int Cin, int KH, int KW, int transposed, float beta) {
+  // 64 consecutive slab elements per block (coalesced 256-byte rows); the 4 waves each sum a quarter
+  // of the G slabs with 4 independent accumulators (16 loads in flight per lane), combined through
+  // LDS in a fixed order => deterministic.
+  __shared__ float sm[4][64];
   const int elems = KH * KW * Cin * Cout;
-  const int e = blockIdx.x * 256 + threadIdx.x;  // slab index (coalesced slab reads)
-  if (e >= elems) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int g = 0;
-  for (; g + 3 < G; g += 4) {
-    s0 += ws[(size_t)g * elems + e];
-    s1 += ws[(size_t)(g + 1) * elems + e];
-    s2 += ws[(size_t)(g + 2) * elems + e];
-    s3 += ws[(size_t)(g + 3) * elems + e];
+  if (e < elems) {
+    int g = w;
+    for (; g + 12 < G; g += 16) {
+      s0 += ws[(size_t)g * elems + e];
+      s1 += ws[(size_t)(g + 4) * elems + e];
+      s2 += ws[(size_t)(g + 8) * elems + e];
+      s3 += ws[(size_t)(g + 12) * elems + e];
+    }
+    for (; g < G; g += 4) s0 += ws[(size_t)g * elems + e];
   }
-  for (; g < G; ++g) s0 += ws[(size_t)g * elems + e];
-  const float v = (s0 + s1) + (s2 + s3);
+  sm[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w != 0 || e >= elems) return;
+  const float v = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
   const int co = e % Cout;
   const int ci = (e / Cout) % Cin;
   const int tap = e / (Cout * Cin);
@@ -502,7 +511,7 @@ int conv_wgrad_mfma(const srk_conv_desc& d, const float* x, const float* dy, con
   int rc = check_launch("conv_wgrad_mfma");
   if (rc) return rc;
   const int elems = d.KH * d.KW * d.Cin * d.Cout;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(elems, 256)), dim3(256), 0, s, (const float*)ws, dw, pl.G, d.Cout,
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(elems, 64)), dim3(256), 0, s, (const float*)ws, dw, pl.G, d.Cout,
                      d.Cin, d.KH, d.KW, d.transposed, beta);
   rc = check_launch("conv_wgrad_reduce");
   if (rc) return rc;

@@ -48,6 +48,19 @@ class _PackCache(object):
         return self.val
 
 
+def _plan_views(m, ps_r):
+    """(wp_fwd, bias_packed, wp_bwd) from the model's PackPlan when it is current for this step."""
+    plan = getattr(m, "_plan", None)
+    if plan is None:
+        return None
+    owner, plan_ps, wpf, bp, wpb, wver, bver = plan
+    if not owner.current() or (plan_ps if plan_ps > 1 else 0) != (ps_r if ps_r > 1 else 0):
+        return None
+    if m.weight._version != wver or (m.bias is not None and m.bias._version != bver):
+        return None
+    return (wpf, bp if (ps_r > 1 and m.bias is not None) else m.bias, wpb)
+
+
 class Conv2d(torch.nn.Conv2d):
     """torch.nn.Conv2d surface (base_networks.py:42,112-113,156) on srk_conv2d_*."""
 
@@ -61,7 +74,7 @@ class Conv2d(torch.nn.Conv2d):
         the caller applies other activations unfused."""
         cfg = ops.ConvCfg(self._s, self._p, False, 0, act, slope, ps_r)
         if grad_mode(x, self.weight, self.bias, residual, prelu_w):
-            return ops.conv2d(x, self.weight, self.bias, residual, cfg)
+            return ops.conv2d(x, self.weight, self.bias, residual, cfg, _plan_views(self, ps_r))
         packed = self._cache.get(self.weight, self.bias, False, ps_r)
         return ops.conv2d_infer(x, self.weight, self.bias, residual, cfg, prelu_w, packed)
 
@@ -82,7 +95,7 @@ class ConvTranspose2d(torch.nn.ConvTranspose2d):
     def run(self, x, act=ACT_NONE, slope=0.0, prelu_w=None):
         cfg = ops.ConvCfg(self._s, self._p, True, self._op, act, slope, 0)
         if grad_mode(x, self.weight, self.bias, prelu_w):
-            return ops.conv2d(x, self.weight, self.bias, None, cfg)
+            return ops.conv2d(x, self.weight, self.bias, None, cfg, _plan_views(self, 0))
         packed = self._cache.get(self.weight, self.bias, True, 0)
         return ops.conv2d_infer(x, self.weight, self.bias, None, cfg, prelu_w, packed)
 

@@ -206,8 +206,11 @@ class _Conv2d(torch.autograd.Function):
         x = to_nhwc(x)
         if residual is not None:
             residual = to_nhwc(residual)
+        ctx.wpb = None
         if packed is not None:
-            wp, bp = packed
+            wp, bp = packed[0], packed[1]
+            if len(packed) > 2:
+                ctx.wpb = packed[2]  # data-gradient layout already packed by the model's PackPlan
         else:
             wp = pack_weight_fwd(weight, cfg.transposed, cfg.ps_r)
             bp = pack_bias_ps(bias, cfg.ps_r)
@@ -241,7 +244,7 @@ class _Conv2d(torch.autograd.Function):
         mref = ctypes.byref(mask) if mask is not None else None
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wpb = pack_weight_bwd(weight, cfg.transposed)
+            wpb = ctx.wpb if ctx.wpb is not None else pack_weight_bwd(weight, cfg.transposed)
             dx = _empty_cl(d.N, d.Cin, d.H, d.W, dy)
             check(lib.srk_conv2d_backward_data(ctypes.byref(d), ptr(dyc), ptr(wpb), ptr(dx), mref, None,
                                                stream_ptr()), "srk_conv2d_backward_data")

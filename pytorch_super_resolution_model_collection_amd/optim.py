@@ -55,12 +55,83 @@ class FlatParams(object):
             p._srk_grad = g      # kernels accumulate here (ops._Conv2d.backward etc.)
             p.grad = g           # what user code / hooks see
         bump_weight_epoch()
+        self.epoch = 0           # bumped whenever the flat parameters change (optimizer step, load_state_dict)
+        self.plan = PackPlan(module, self)
 
     def zero_grad(self):
         self.grad.zero_()  # one memset node
 
     def named_grads(self):
         return {n: p._srk_grad for n, p in zip(self.names, self.params)}
+
+
+class PackPlan(object):
+    """Packs the filters of EVERY conv layer of a model (forward + data-gradient layouts, fp32 +
+    bf16x3 planes, pixel-shuffle bias permutation) with ONE kernel launch per training step
+    (srk_pack_weights_batched) instead of four small launches per layer.  Layers pick their views up
+    in layers.Conv2d.run when the plan is current (`flat.epoch`)."""
+
+    def __init__(self, module, flat):
+        from .layers import Conv2d, ConvTranspose2d
+        lib = _lib.load()
+        self.flat = flat
+        base = flat.data.data_ptr()
+        rows, self.layers, off = [], [], 0
+
+        def take(nbytes):
+            nonlocal off
+            o = off
+            off += (int(nbytes) + 255) // 256 * 256
+            return o
+
+        seen = set()
+        for m in module.modules():
+            if not isinstance(m, (Conv2d, ConvTranspose2d)) or id(m.weight) in seen:
+                continue
+            seen.add(id(m.weight))
+            tr = isinstance(m, ConvTranspose2d)
+            cin, cout = (m.weight.shape[0], m.weight.shape[1]) if tr else (m.weight.shape[1], m.weight.shape[0])
+            kh, kw = m.weight.shape[2], m.weight.shape[3]
+            ps_r = int(getattr(m, "_ps_r", 0))
+            nf = int(lib.srk_packed_weight_bytes(cout, cin, kh, kw, 0))
+            nb = int(lib.srk_packed_weight_bytes(cout, cin, kh, kw, 1))
+            fo, bo = take(nf), take(nb)
+            w_off = (m.weight.data_ptr() - base) // 4
+            b_off, bp_off = -1, -1
+            if m.bias is not None and ps_r > 1:
+                b_off = (m.bias.data_ptr() - base) // 4
+                bp_off = take(cout * 4)
+            rows.append([w_off, fo, bo, cout, cin, kh, kw, int(tr), ps_r, b_off, bp_off, 0])
+            self.layers.append((m, fo, nf, bo, nb, bp_off, cout, ps_r))
+        self.n = len(rows)
+        if self.n == 0:
+            return
+        dev = flat.data.device
+        self.buf = torch.empty(max(off, 256), dtype=torch.uint8, device=dev)
+        self.table = torch.tensor(rows, dtype=torch.int64, device=dev)
+        self.epoch = -1
+        biggest = max(r[3] * r[4] * r[5] * r[6] for r in rows)
+        self.blocks = max(1, min(64, (biggest + 255) // 256))
+        for m, fo, nf, bo, nb, bp_off, cout, ps_r in self.layers:
+            wpf = self.buf[fo:fo + (nf + 3) // 4 * 4].view(torch.float32)
+            wpb = self.buf[bo:bo + (nb + 3) // 4 * 4].view(torch.float32)
+            bp = self.buf[bp_off:bp_off + cout * 4].view(torch.float32) if bp_off >= 0 else None
+            m._plan = [self, ps_r, wpf, bp, wpb, -1, -1]
+
+    def pack(self):
+        if self.n == 0:
+            return
+        lib = _lib.load()
+        check(lib.srk_pack_weights_batched(ptr(self.flat.data), ptr(self.buf), ptr(self.table), self.n, self.blocks,
+                                           stream_ptr()), "srk_pack_weights_batched")
+        self.epoch = self.flat.epoch
+        for lay in self.layers:  # host-side edits of a parameter (load_state_dict, init) invalidate its views
+            m = lay[0]
+            m._plan[5] = m.weight._version
+            m._plan[6] = -1 if m.bias is None else m.bias._version
+
+    def current(self):
+        return self.n > 0 and self.epoch == self.flat.epoch
 
 
 class _Group(dict):
@@ -92,7 +163,10 @@ class _FlatOptimizer(object):
         self.lr_dev.fill_(float(v))
 
     def zero_grad(self, set_to_none=False):
+        """Start of a train step: clear the flat gradient buffer (one memset) and re-pack every conv
+        filter of the model for this step's forward/backward (one launch)."""
         self.flat.zero_grad()
+        self.flat.plan.pack()
 
     def clip_grad_norm(self, max_norm):
         """torch.nn.utils.clip_grad_norm(params, max_norm) (vdsr.py:149): computes the global L2
@@ -126,6 +200,7 @@ class SGD(_FlatOptimizer):
                                self.weight_decay, int(self.nesterov), 0, ptr(self.lr_dev), ptr(self.scale_dev),
                                stream_ptr()), "srk_sgd_step")
         bump_weight_epoch()
+        f.epoch += 1
 
 
 class Adam(_FlatOptimizer):
@@ -145,6 +220,7 @@ class Adam(_FlatOptimizer):
                                 self.betas[0], self.betas[1], self.eps, self.weight_decay, ptr(self.step_dev),
                                 ptr(self.lr_dev), ptr(self.scale_dev), stream_ptr()), "srk_adam_step")
         bump_weight_epoch()
+        f.epoch += 1
 
 
 def make_optimizer(kind, flat, lr):

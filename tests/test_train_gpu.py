@@ -138,6 +138,49 @@ def test_graphed_step_equals_eager(gpu):
     assert rel_err(opt_b.flat.data, opt_a.flat.data) < 1e-5
 
 
+@pytest.mark.parametrize("model", ["edsr", "fsrcnn", "espcn", "lapsrn", "srgan_g"])
+def test_pack_plan_equals_per_layer_pack(gpu, model):
+    """One srk_pack_weights_batched launch writes byte-for-byte what the per-layer pack calls write
+    (fp32 + bf16x3 layouts, forward + data-gradient, pixel-shuffle filter/bias order, deconv)."""
+    pkg = _pkg()
+    net = {"edsr": lambda: pkg.EDSRNet(3, 64, 4), "fsrcnn": lambda: pkg.FSRCNNNet(1, 3, 56, 12, 4),
+           "espcn": lambda: pkg.ESPCNNet(3, 64, 4), "lapsrn": lambda: pkg.LapSRNNet(1, 64, 4),
+           "srgan_g": lambda: pkg.SRGANGenerator(3, 64, 2)}[model]()
+    fill.fill_module(net, 11, 1.0)
+    net.to(gpu)
+    from pytorch_super_resolution_model_collection_amd._lib import check, load, ptr, stream_ptr
+    lib = load()
+    flat = pkg.optim.FlatParams(net)
+    plan = flat.plan
+    assert plan.n > 0 and not plan.current()
+    plan.buf.zero_()
+    plan.pack()
+    torch.cuda.synchronize()
+    assert plan.current()
+    for m, fo, nf, bo, nb, bp_off, cout, ps_r in plan.layers:
+        tr = isinstance(m, pkg.layers.ConvTranspose2d)
+        cin, kh, kw = m.weight.shape[0 if tr else 1], m.weight.shape[2], m.weight.shape[3]
+        _, _, wpf, bp, wpb, _, _ = m._plan
+        # per-layer packs into zeroed buffers (the layouts have alignment gaps no kernel writes)
+        ref_f, ref_b = torch.zeros_like(wpf), torch.zeros_like(wpb)
+        w = m.weight.detach()
+        check(lib.srk_pack_weight_fwd(ptr(w), ptr(ref_f), cout, cin, kh, kw, int(tr), ps_r, stream_ptr()), "fwd")
+        check(lib.srk_pack_weight_bwd(ptr(w), ptr(ref_b), cout, cin, kh, kw, int(tr), stream_ptr()), "bwd")
+        assert torch.equal(wpf.view(torch.int32), ref_f.view(torch.int32)), (model, tuple(m.weight.shape), "fwd")
+        assert torch.equal(wpb.view(torch.int32), ref_b.view(torch.int32)), (model, tuple(m.weight.shape), "bwd")
+        if bp is not None:
+            assert torch.equal(bp, pkg.ops.pack_bias_ps(m.bias.detach(), ps_r))
+        views = pkg.layers._plan_views(m, ps_r)
+        assert views is not None and views[0].data_ptr() == wpf.data_ptr()
+    # a host-side edit of one parameter invalidates just that layer's views; an optimizer step all of them
+    first = plan.layers[0][0]
+    with torch.no_grad():
+        first.weight.mul_(1.0)
+    assert pkg.layers._plan_views(first, plan.layers[0][7]) is None
+    flat.epoch += 1
+    assert not plan.current()
+
+
 def test_flat_params_keep_state_dict_and_grads(gpu):
     pkg = _pkg()
     net = pkg.ESPCNNet(3, 64, 4)
