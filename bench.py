@@ -94,6 +94,26 @@ def espcn_layer_events(net, x, steps):
     return [sum(e[i].elapsed_time(e[i + 1]) for e in evs) / len(evs) for i in range(3)]
 
 
+def pmc_traffic(kernel_label, batch, lr_size):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_c2_pmc_traffic.json,
+    written by tools/profile_round.sh + tools/summarize_prof.py: rocprofv3 counters cannot be collected from
+    inside this process).  Only valid for the default c2 shape the passes were taken on."""
+    import glob
+    if batch != 64 or lr_size != 256:
+        return None
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_c2_pmc_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        kernels = json.load(fh).get("kernels", {})
+    short = kernel_label.split(" ")[0].rstrip(">")      # "k_conv_bf3<2" matches "srk::k_conv_bf3<2, 4>(...)"
+    for name, rec in kernels.items():
+        i = name.find("::" + short)
+        if i >= 0 and name[i + 2 + len(short)] in ">," and rec.get("hbm_bytes"):
+            return int(rec["hbm_bytes"])
+    return None
+
+
 def cpu_baseline(batch_cap=8, lr_size=256):
     """Oracle ESPCN x4 forward on the host cores (bounded sample: B=8, best of 5 after 2 warm-ups)."""
     from oracle import fill, ref_modules as R
@@ -218,7 +238,8 @@ def main():
                        "parallelism": "replicas x%d (no collective)" % world},
             "roofline": {"bound": "mfma", "kernel": names[dom], "achieved": round(achieved, 2),
                          "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "frac": round(achieved / peak, 4),
+                         "traffic": pmc_traffic(names[dom], args.batch, H),
                          "note": "achieved = algorithmic conv FLOPs / live HIP-event kernel time; peak = bf16 dense "
                                  "MFMA peak / 3 (three bf16 MFMAs per fp32-equivalent product)" if bf3 else
                                  "achieved = algorithmic conv FLOPs / live HIP-event kernel time; peak = fp32 MFMA",

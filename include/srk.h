@@ -49,14 +49,16 @@ typedef enum srk_act {
 
 /* Which implementation a conv call may use.  AUTO picks the fastest kernel that covers the
  * shape; GENERIC forces the plain gather kernel (used by the tests to cross-check).  The environment
- * variable SRK_FORCE_ALGO=generic|mfma|direct|bf16x3 overrides AUTO (SRK_FORCE_ALGO=mfma gives the
+ * variable SRK_FORCE_ALGO=generic|mfma|direct|bf16x3|bf16x6 overrides AUTO (SRK_FORCE_ALGO=mfma gives the
  * exact-fp32 MFMA path everywhere). */
 typedef enum srk_algo {
   SRK_ALGO_AUTO = 0,        /* bf16x3 MFMA where it applies, else fp32 MFMA / direct / generic            */
   SRK_ALGO_GENERIC = 1,     /* plain fp32 gather kernel (any shape)                                       */
   SRK_ALGO_MFMA = 2,        /* exact fp32 MFMA (v_mfma_f32_16x16x4_f32)                                    */
   SRK_ALGO_DIRECT = 3,      /* fp32 VALU kernel for Cout <= 4                                              */
-  SRK_ALGO_MFMA_BF16X3 = 4  /* 3-term bf16 split on v_mfma_f32_16x16x32_bf16, fp32 accumulate (~1e-5 rel) */
+  SRK_ALGO_MFMA_BF16X3 = 4, /* 3-term bf16 split on v_mfma_f32_16x16x32_bf16, fp32 accumulate (~1e-5 rel) */
+  SRK_ALGO_MFMA_BF16X6 = 5  /* exact 3-way operand split, 6 bf16 MFMAs per product: fp32-faithful (~1e-7
+                               rel) at 2.7x the fp32-MFMA rate; shapes it does not cover run SRK_ALGO_MFMA */
 } srk_algo;
 
 /* Geometry of one torch.nn.Conv2d / ConvTranspose2d call.

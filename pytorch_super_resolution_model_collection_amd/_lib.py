@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "srk.h")
 
 # enums mirrored from include/srk.h
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = range(6)
-ALGO_AUTO, ALGO_GENERIC, ALGO_MFMA, ALGO_DIRECT, ALGO_MFMA_BF16X3 = range(5)
+ALGO_AUTO, ALGO_GENERIC, ALGO_MFMA, ALGO_DIRECT, ALGO_MFMA_BF16X3, ALGO_MFMA_BF16X6 = range(6)
 LOSS_MSE, LOSS_L1, LOSS_CHARBONNIER, LOSS_BCE = range(4)
 ACT_BY_NAME = {None: ACT_NONE, "relu": ACT_RELU, "prelu": ACT_PRELU, "lrelu": ACT_LRELU, "tanh": ACT_TANH,
                "sigmoid": ACT_SIGMOID}

@@ -50,7 +50,7 @@ static int validate_desc(const srk_conv_desc* d, const char* who) {
   const int ow = srk_conv_out_dim(d->W, d->KW, d->stride, d->pad, d->transposed, d->out_pad);
   SRK_REQUIRE(oh > 0 && ow > 0, "%s: empty output (%d x %d)", who, oh, ow);
   SRK_REQUIRE(d->OH == oh && d->OW == ow, "%s: OH/OW (%d,%d) != expected (%d,%d)", who, d->OH, d->OW, oh, ow);
-  SRK_REQUIRE(d->algo >= SRK_ALGO_AUTO && d->algo <= SRK_ALGO_MFMA_BF16X3, "%s: unknown algo %d", who, d->algo);
+  SRK_REQUIRE(d->algo >= SRK_ALGO_AUTO && d->algo <= SRK_ALGO_MFMA_BF16X6, "%s: unknown algo %d", who, d->algo);
   return SRK_OK;
 }
 
@@ -62,6 +62,7 @@ static int forced_algo(int algo) {
   if (!strcmp(e, "mfma")) return SRK_ALGO_MFMA;
   if (!strcmp(e, "direct")) return SRK_ALGO_DIRECT;
   if (!strcmp(e, "bf16x3")) return SRK_ALGO_MFMA_BF16X3;
+  if (!strcmp(e, "bf16x6")) return SRK_ALGO_MFMA_BF16X6;
   return SRK_ALGO_AUTO;
 }
 
@@ -78,6 +79,11 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
     set_error("%s: MFMA kernel does not cover this shape", who);
     return SRK_ERR_UNSUPPORTED;
   }
+  const bool bfd_ok = conv_bfd_gather_supported(g, ep);
+  if (algo == SRK_ALGO_MFMA_BF16X6) {  // fp32-faithful class: bf16x6 where it applies, else the exact fp32 kernels
+    if (bfd_ok && !direct_ok) return conv_bfd_gather(g, in, wp, out, ep, mask_y, mask_slope, 3, s);
+    algo = SRK_ALGO_MFMA;
+  }
   const bool bf3_ok = conv_bf3_gather_supported(g, ep);
   if (algo == SRK_ALGO_MFMA_BF16X3 && !bf3_ok) {
     set_error("%s: bf16x3 MFMA kernel does not cover this shape", who);
@@ -85,8 +91,14 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
   }
   if (algo == SRK_ALGO_DIRECT || ((algo == SRK_ALGO_AUTO || (algo == SRK_ALGO_MFMA && !mfma_ok)) && direct_ok))
     return conv_direct_gather(g, in, wp, out, ep, mask_y, mask_slope, s);
-  if (algo == SRK_ALGO_MFMA_BF16X3 || (algo == SRK_ALGO_AUTO && bf3_ok))
+  if (algo == SRK_ALGO_MFMA_BF16X3 || (algo == SRK_ALGO_AUTO && bf3_ok)) {
+    // filters-from-global variant: small problems (channel-split 64-pixel blocks), or on request
+    const char* e = getenv("SRK_BF3_DIRECT");  // 0 = never, 1 = always, unset = small problems only
+    const int direct_w = e ? (atoi(e) ? 1 : 0) : 2;
+    if (bfd_ok && (direct_w == 1 || (direct_w == 2 && conv_bfd_small_problem(g))))
+      return conv_bfd_gather(g, in, wp, out, ep, mask_y, mask_slope, 2, s);
     return conv_bf3_gather(g, in, wp, out, ep, mask_y, mask_slope, s);
+  }
   if (algo == SRK_ALGO_MFMA || (algo == SRK_ALGO_AUTO && mfma_ok))
     return conv_mfma_gather(g, in, wp, out, ep, mask_y, mask_slope, s);
   return conv_generic_gather(g, in, wp, out, ep, mask_y, mask_slope, s);

@@ -1,0 +1,467 @@
+// Implicit-GEMM convolution on the bf16 matrix cores, filters straight from global memory ("bfd").
+//
+// Same arithmetic family as conv_mfma_bf16.hip — fp32 operands split into bf16 planes, products on
+// v_mfma_f32_16x16x32_bf16, fp32 accumulation — in two precisions:
+//
+//   NP = 2 (bf16x3)  a = h + m            a*b ~= m*h + h*m + h*h               (~5e-6 rel, 3 MFMAs)
+//   NP = 3 (bf16x6)  a = h + m + l EXACT  a*b ~= l*h + h*l + m*m + m*h + h*m + h*h
+//                    (dropped m*l, l*m, l*l <= 2^-23 |a*b|, typically ~1e-8: fp32-faithful, 6 MFMAs —
+//                     2.7x the fp32-MFMA rate.  This is the training-forward path of the default
+//                     "mixed" precision: ReLU masks must match the fp32 reference's.)
+//
+// Structure:
+//   * the prepared filter layout [tap][chunk][ocb][plane][group][co][8 x bf16] IS the MFMA
+//     B-operand layout, so every lane loads its own 16-byte fragments of the NEXT taps into
+//     registers (prefetch depth PF) while the MFMAs of the current tap run.  Filters of a layer
+//     are <= 221 KB and shared by every block: L1/L2 hits.  No weight LDS slots and NO barrier in
+//     the tap loop — the waves of a block drift apart and overlap each other's loads and MFMAs;
+//   * the fp32 NHWC halo of the block's pixel tile is read once, split into planes and staged in
+//     LDS as [plane][8-channel group][pixel][8 x bf16] (conflict-free ds_read_b128 A fragments);
+//   * a block is NPW pixel-waves x NOW channel-waves: wave (pw, ow) owns 64 pixels x NTW*16 output
+//     channels.  Large problems use NOW = 1 (64 x 64 per wave: fewest LDS bytes per MFMA); small
+//     problems (a strong-scaled shard of a batch) use 64-pixel blocks whose waves split the output
+//     channels, so that 4x more SIMDs share the serial MFMA chain of a tile;
+//   * epilogue through an LDS slab shared by the channel-waves of a pixel group: 16-byte stores,
+//     a pixel's channels contiguous (bias / activation / residual / pixel-shuffle as everywhere).
+#include "srk_common.h"
+#include "conv_problem.h"
+#include "conv_tile.h"
+#include <stdlib.h>
+
+namespace srk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct BfdParams {
+  MfmaConvParams P;
+  const uint4* wq;   // prepared filters, planes h, m
+  const uint4* wq3;  // third plane (l) [tap][chunk][ocb][group][co]
+  int ICc;           // 32-channel chunks
+  int OCb;           // 64-channel output blocks
+  int NB;            // output channels per block in the prepared layout
+  int NPIXp;         // halo pixels rounded up to 16
+  int dbg;
+};
+
+template <int NP>
+__device__ __forceinline__ void split8n(const float (&f)[8], uint4 (&pl)[NP]) {
+  bf16x8 h, m, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 hh = (__bf16)f[e];
+    const float r1 = f[e] - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    h[e] = hh;
+    m[e] = mm;
+    if (NP == 3) l[e] = (__bf16)(r1 - (float)mm);
+  }
+  pl[0] = __builtin_bit_cast(uint4, h);
+  pl[1] = __builtin_bit_cast(uint4, m);
+  if (NP == 3) pl[NP - 1] = __builtin_bit_cast(uint4, l);
+}
+
+__device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
+                                                 0);
+}
+
+// halo chunk: channels [cb, cb+32) of every halo pixel -> NP planes.  thread -> (8-channel group
+// g = tid&3, pixel slot tid>>2); all global loads of a batch are issued before the first conversion.
+constexpr int BFD_STAGE_IT = 6;
+
+template <bool MASK, int NTHR, int NP>
+__device__ __forceinline__ void bfd_stage_halo_t(const BfdParams& B, uint4* hal, int n, int r0, int c0, int cb) {
+  const MfmaConvParams& P = B.P;
+  const int npix = P.HH * P.HW;
+  const int g = threadIdx.x & 3;
+  const int hp0 = threadIdx.x >> 2;
+  int hy = hp0 / P.HW, hx = hp0 - hy * P.HW;
+  constexpr int PPP = NTHR / 4;  // pixels per pass
+  const int dyp = PPP / P.HW, dxp = PPP - dyp * P.HW;
+  const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
+  const int ch = cb + g * 8;
+  const bool ch_any = ch < P.IC, ch_vec = P.vec_in && ch + 7 < P.IC;
+  const size_t img = (size_t)n * P.IH;
+  for (int base = hp0; base < npix; base += PPP * BFD_STAGE_IT) {
+    f32x4 v0[BFD_STAGE_IT], v1[BFD_STAGE_IT], m0[BFD_STAGE_IT], m1[BFD_STAGE_IT];
+#pragma unroll
+    for (int k = 0; k < BFD_STAGE_IT; ++k) {
+      v0[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      v1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (MASK) {
+        m0[k] = (f32x4){1.f, 1.f, 1.f, 1.f};
+        m1[k] = (f32x4){1.f, 1.f, 1.f, 1.f};
+      }
+      const int hp = base + PPP * k;
+      const int iy = iyb + hy, ix = ixb + hx;
+      if (hp < npix && ch_any && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) {
+        const size_t off = ((img + iy) * P.IW + ix) * P.IC + ch;
+        if (ch_vec) {
+          v0[k] = *reinterpret_cast<const f32x4*>(P.in + off);
+          v1[k] = *reinterpret_cast<const f32x4*>(P.in + off + 4);
+          if (MASK) {
+            m0[k] = *reinterpret_cast<const f32x4*>(P.mask_y + off);
+            m1[k] = *reinterpret_cast<const f32x4*>(P.mask_y + off + 4);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (ch + e < P.IC) {
+              v0[k][e] = P.in[off + e];
+              if (MASK) m0[k][e] = P.mask_y[off + e];
+            }
+            if (ch + 4 + e < P.IC) {
+              v1[k][e] = P.in[off + 4 + e];
+              if (MASK) m1[k][e] = P.mask_y[off + 4 + e];
+            }
+          }
+        }
+      }
+      hy += dyp;
+      hx += dxp;
+      if (hx >= P.HW) {
+        hx -= P.HW;
+        ++hy;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < BFD_STAGE_IT; ++k) {
+      const int hp = base + PPP * k;
+      if (hp < npix) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f[e] = v0[k][e];
+          f[4 + e] = v1[k][e];
+          if (MASK) {
+            f[e] = m0[k][e] > 0.f ? f[e] : f[e] * P.mask_slope;
+            f[4 + e] = m1[k][e] > 0.f ? f[4 + e] : f[4 + e] * P.mask_slope;
+          }
+        }
+        uint4 pl[NP];
+        split8n<NP>(f, pl);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) hal[(p * 4 + g) * B.NPIXp + hp] = pl[p];
+      }
+    }
+  }
+}
+
+constexpr int BFD_MAXTAPS = 128;
+constexpr int BFD_EPI_STRIDE = 68;  // floats per staged output row (64 + 4: conflict-free float4 rows)
+
+// accumulators -> LDS slab of the pixel group (32 pixels x block channels, two halves) -> 16-byte
+// stores by all NOW waves of the group.  C/D layout: col = lane&15 (channel), row = (lane>>4)*4+reg.
+template <int NTW, int NPW, int NOW>
+__device__ __forceinline__ void bfd_epilogue(const MfmaConvParams& P, float* smem_f, const f32x4 (&acc)[4][NTW], int n,
+                                             int r0, int c0, int ocb, int pw, int ow, int lane) {
+  const int j = lane & 15, kq = lane >> 4;
+  const int npx = P.TH * P.TW;
+  __syncthreads();
+  float* st = smem_f + pw * (32 * BFD_EPI_STRIDE);
+  constexpr int Q4 = NTW * NOW * 4;   // float4 columns per row
+  constexpr int RPI = (64 * NOW) / Q4;  // rows per pass of the group
+  const int gi = ow * 64 + lane;
+  const int row0 = gi / Q4, q4 = gi - row0 * Q4;
+  const int oc4 = ocb + q4 * 4;
+  const bool lane_on = row0 < RPI && oc4 < P.OC;
+  const int tw_magic = div_small_magic(P.TW);
+  EpiCol col{};
+  if (lane_on) col = epi_col_setup(P.ep, P.OW, P.OC, oc4);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+          st[(mh * 16 + kq * 4 + reg) * BFD_EPI_STRIDE + (ow * NTW + nt) * 16 + j] = acc[2 * h + mh][nt][reg];
+    __syncthreads();
+    if (lane_on) {
+#pragma unroll 2
+      for (int row = row0; row < 32; row += RPI) {
+        const int m = pw * 64 + h * 32 + row;
+        if (m < npx) {
+          const int r = div_small(m, tw_magic), c = m - r * P.TW;
+          const int pr = r0 + r, pc = c0 + c;
+          if (pr < P.PH && pc < P.PW) {
+            const epi_f4 v = *reinterpret_cast<const epi_f4*>(st + row * BFD_EPI_STRIDE + q4 * 4);
+            epi_store4_col(P.ep, col, P.OH, P.OW, P.OC, n, P.oy0 + pr * P.os, P.ox0 + pc * P.os, v, P.out);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int NTW, int NPW, int NOW, int NP, int PF>
+__global__ __launch_bounds__(64 * NPW * NOW, 2) void k_conv_bfd(
+    BfdParams B) {
+  constexpr int NTHR = 64 * NPW * NOW;
+  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+  __shared__ int tap_toff[BFD_MAXTAPS];
+  __shared__ int tap_wtap[BFD_MAXTAPS];
+  const MfmaConvParams& P = B.P;
+  uint4* hal = smem4;  // [NP][4][NPIXp]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pw = wave % NPW, ow = wave / NPW;
+  const int j = lane & 15, kq = lane >> 4;
+  int b = blockIdx.x;
+  const int txi = b % P.tiles_x;
+  b /= P.tiles_x;
+  const int tyi = b % P.tiles_y;
+  const int n = b / P.tiles_y;
+  const int r0 = tyi * P.TH, c0 = txi * P.TW;
+  const int ocbi = blockIdx.y;
+  const int ocb = ocbi * 64;
+  const int npx = P.TH * P.TW;
+  const int NB = B.NB;
+  const int T = P.KHv * P.KWv;
+
+  for (int t = tid; t < T && t < BFD_MAXTAPS; t += NTHR) {
+    const int u = t / P.KWv, v = t - u * P.KWv;
+    tap_toff[t] = u * P.HW + v;
+    tap_wtap[t] = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
+  }
+  int hp[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    int m = pw * 64 + mt * 16 + j;
+    if (m >= npx) m = 0;
+    const int r = m / P.TW, c = m - r * P.TW;
+    hp[mt] = (r * P.is) * P.HW + c * P.is + kq * B.NPIXp;
+  }
+  f32x4 acc[4][NTW];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const bool wave_live = pw * 64 < npx;
+  const int plane = 4 * B.NPIXp;
+  const int wlane = kq * NB + j + ow * NTW * 16;
+
+  // filter fragments of flat iteration (chunk cc, tap t) -> registers
+  auto load_b = [&](int cc, int t, uint4 (&dst)[NP][NTW]) {
+    if (cc < B.ICc) {
+      int tapw;
+      if (t < BFD_MAXTAPS) {
+        tapw = tap_wtap[t];
+      } else {
+        const int u = t / P.KWv, v = t - u * P.KWv;
+        tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
+      }
+      const size_t slot = (size_t)(tapw * B.ICc + cc) * B.OCb + ocbi;
+      const uint4* w = B.wq + slot * (size_t)(8 * NB) + wlane;
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        dst[0][nt] = w[nt * 16];
+        dst[1][nt] = w[4 * NB + nt * 16];
+      }
+      if (NP == 3) {
+        const uint4* w3 = B.wq3 + slot * (size_t)(4 * NB) + wlane;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) dst[NP - 1][nt] = w3[nt * 16];
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) dst[p][nt] = make_uint4(0, 0, 0, 0);
+    }
+  };
+
+  if (T > 0) {
+    __syncthreads();  // tap tables
+    uint4 bq[PF][NP][NTW];
+    int hcc = 0, ht = 0;  // prefetch head (chunk, tap)
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+      load_b(hcc, ht, bq[d]);
+      if (++ht == T) {
+        ht = 0;
+        ++hcc;
+      }
+    }
+    for (int cc = 0; cc < B.ICc; ++cc) {
+      if (cc) __syncthreads();  // previous chunk's halo fully consumed
+      if (!(B.dbg & 1)) {
+        if (P.mask_y)
+          bfd_stage_halo_t<true, NTHR, NP>(B, hal, n, r0, c0, cc * 32);
+        else
+          bfd_stage_halo_t<false, NTHR, NP>(B, hal, n, r0, c0, cc * 32);
+      }
+      __syncthreads();
+      for (int t = 0; t < T; ++t) {
+        uint4 nb[NP][NTW];
+        load_b(hcc, ht, nb);
+        if (++ht == T) {
+          ht = 0;
+          ++hcc;
+        }
+        if (wave_live && !(B.dbg & 4)) {
+          int toff;
+          if (t < BFD_MAXTAPS) {
+            toff = tap_toff[t];
+          } else {
+            const int u = t / P.KWv, v = t - u * P.KWv;
+            toff = u * P.HW + v;
+          }
+          const uint4* hb = hal + toff;
+          uint4 a[NP][4];
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) a[p][mt] = hb[hp[mt] + p * plane];
+          // smallest products first; every pass runs over 4*NTW independent accumulators
+#define SRK_BFD_PASS(pa, pb)                                                              \
+  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = \
+      mfma16(a[pa][mt], bq[0][pb][nt], acc[mt][nt]);
+          if (NP == 3) {
+            SRK_BFD_PASS(NP - 1, 0)
+            SRK_BFD_PASS(0, NP - 1)
+            SRK_BFD_PASS(1, 1)
+          }
+          SRK_BFD_PASS(1, 0)
+          SRK_BFD_PASS(0, 1)
+          SRK_BFD_PASS(0, 0)
+#undef SRK_BFD_PASS
+        }
+#pragma unroll
+        for (int d = 0; d + 1 < PF; ++d)
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) bq[d][p][nt] = bq[d + 1][p][nt];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) bq[PF - 1][p][nt] = nb[p][nt];
+      }
+    }
+  }
+  if (B.dbg & 2) {
+    if (acc[0][0][0] == 123.456f) P.out[0] = 1.f;  // keep the accumulators live
+    return;
+  }
+  bfd_epilogue<NTW, NPW, NOW>(P, reinterpret_cast<float*>(smem4), acc, n, r0, c0, ocb, pw, ow, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host
+// ---------------------------------------------------------------------------------------------
+template <int NTW, int NPW, int NOW, int NP, int PF>
+static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
+  MfmaConvParams& P = B.P;
+  const int maxpix = 64 * NPW;
+  TilePick best{};
+  const int kh = P.KHv > 0 ? P.KHv : 1, kw = P.KWv > 0 ? P.KWv : 1;
+  bool ok = pick_tile(maxpix, P.PH, P.PW, P.is, kh, kw, NP * 16, budget_bytes / 4 - 16 * NP * 16, best);
+  if (!ok || best.eff < 0.6) {  // huge halos (large kernels / strides): one block per CU
+    TilePick big{};
+    if (pick_tile(maxpix, P.PH, P.PW, P.is, kh, kw, NP * 16, (156 * 1024) / 4 - 16 * NP * 16, big) &&
+        (!ok || big.eff > best.eff * 1.2)) {
+      best = big;
+      ok = true;
+    }
+  }
+  if (!ok) {
+    set_error("conv_bfd: no tile fits LDS");
+    return SRK_ERR_UNSUPPORTED;
+  }
+  P.TH = best.TH; P.TW = best.TW; P.tiles_y = best.tiles_y; P.tiles_x = best.tiles_x; P.HH = best.HH; P.HW = best.HW;
+  B.NPIXp = (best.HH * best.HW + 15) & ~15;
+  size_t lds = (size_t)NP * 4 * B.NPIXp * 16;
+  const size_t epi_bytes = (size_t)NPW * 32 * BFD_EPI_STRIDE * sizeof(float);
+  if (lds < epi_bytes) lds = epi_bytes;
+  static int cur = 0;
+  const void* fn = reinterpret_cast<const void*>(&k_conv_bfd<NTW, NPW, NOW, NP, PF>);
+  if ((int)lds > cur) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    cur = (int)lds;
+  }
+  dim3 grid((unsigned)((size_t)P.tiles_x * P.tiles_y * P.N), B.OCb);
+  if (B.dbg & 32) {
+    int nb = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * NPW * NOW, lds);
+    fprintf(stderr, "[srk] k_conv_bfd<%d,%d,%d,%d,%d>: lds %zu B, grid %u x %u, occupancy %d blocks/CU, tile %dx%d halo %dx%d\n",
+            NTW, NPW, NOW, NP, PF, lds, grid.x, grid.y, nb, P.TH, P.TW, P.HH, P.HW);
+  }
+  hipLaunchKernelGGL((k_conv_bfd<NTW, NPW, NOW, NP, PF>), grid, dim3(64 * NPW * NOW), lds, s, B);
+  return check_launch("conv_bfd");
+}
+
+bool conv_bfd_gather_supported(const GatherConv& g, const Epi& ep) {
+  (void)ep;
+  if (g.OC < 8 || g.IC < 8) return false;
+  if (g.KH * g.KW > 32 * 32) return false;
+  if ((long)g.N * g.OH * g.OW > (1L << 30)) return false;
+  return true;
+}
+
+static int bfd_dbg() {
+  static int dbg = -1;
+  if (dbg < 0) {
+    const char* e = getenv("SRK_DBG");
+    dbg = e ? atoi(e) : 0;
+  }
+  return dbg;
+}
+
+// small problem: fewer pixels than two resident 256-pixel tiles per CU -> 64-pixel blocks whose waves
+// split the output channels
+bool conv_bfd_small_problem(const GatherConv& g) {
+  const char* e = getenv("SRK_BFD_SMALL");  // tests: 0 / 1 force the large / small block configuration
+  if (e) return atoi(e) != 0;
+  const int st = g.trans ? g.stride : 1;
+  const long px = (long)g.N * ((g.OH + st - 1) / st) * ((g.OW + st - 1) / st) * ((g.OC + 63) / 64);
+  return px < 256L * 2 * kNumCU;
+}
+
+template <int NP>
+static int bfd_launch_phase(MfmaConvParams P, const uint4* wq, const uint4* wq3, bool small, hipStream_t s) {
+  BfdParams B{};
+  const int NT = P.OC >= 64 ? 4 : (P.OC + 15) / 16;
+  B.NB = NT * 16;
+  B.ICc = (P.IC + 31) / 32;
+  B.OCb = (P.OC + 63) / 64;
+  B.wq = wq;
+  B.wq3 = wq3;
+  B.dbg = bfd_dbg();
+  B.P = P;
+  constexpr int BIG = kLdsBudgetBytes, SMALL = 36 * 1024;
+  if (small) {
+    switch (NT) {
+      case 1: return bfd_launch<1, 1, 1, NP, 2>(B, SMALL, s);
+      case 2: return bfd_launch<1, 1, 2, NP, 2>(B, SMALL, s);
+      case 3: return bfd_launch<1, 1, 3, NP, 2>(B, SMALL, s);
+      default: return bfd_launch<1, 1, 4, NP, 2>(B, SMALL, s);
+    }
+  }
+  switch (NT) {
+    case 1: return bfd_launch<1, 4, 1, NP, 2>(B, BIG, s);
+    case 2: return bfd_launch<2, 4, 1, NP, 2>(B, BIG, s);
+    case 3: return bfd_launch<3, 4, 1, NP, 1>(B, BIG, s);
+    default:
+      if (NP == 3) return bfd_launch<2, 2, 2, NP, 1>(B, BIG, s);
+      return bfd_launch<4, 4, 1, NP, 1>(B, BIG, s);
+  }
+}
+
+// planes = 2: bf16x3, planes = 3: bf16x6.  `wp` is the packed filter buffer of srk_pack_weight_*.
+int conv_bfd_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
+                    const float* mask_y, float mask_slope, int planes, hipStream_t s) {
+  const size_t elems = (size_t)g.KH * g.KW * g.IC * g.OC;
+  const char* base = reinterpret_cast<const char*>(wp) + bf3_prepared_offset(elems);
+  const uint4* wq = reinterpret_cast<const uint4*>(base);
+  const uint4* wq3 = reinterpret_cast<const uint4*>(base + bf3_main_bytes(g.IC, g.OC, g.KH * g.KW));
+  const bool small = conv_bfd_small_problem(g);
+  return for_each_phase(g, in, wp, out, ep, mask_y, mask_slope, [&](const MfmaConvParams& P) {
+    return planes == 3 ? bfd_launch_phase<3>(P, wq, wq3, small, s) : bfd_launch_phase<2>(P, wq, wq3, small, s);
+  });
+}
+
+}  // namespace srk

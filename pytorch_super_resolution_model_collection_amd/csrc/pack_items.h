@@ -19,6 +19,23 @@ __device__ __forceinline__ void pk_split8(const float (&f)[8], uint4& hi, uint4&
   lo = __builtin_bit_cast(uint4, l);
 }
 
+// exact 3-way split x = h + m + l (h, m as in pk_split8; l = bf16(x - h - m) is exact)
+__device__ __forceinline__ void pk_split8x3(const float (&f)[8], uint4& hi, uint4& mid, uint4& lo) {
+  pk_bf16x8 h, m, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 hh = (__bf16)f[e];
+    const float r1 = f[e] - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    h[e] = hh;
+    m[e] = mm;
+    l[e] = (__bf16)(r1 - (float)mm);
+  }
+  hi = __builtin_bit_cast(uint4, h);
+  mid = __builtin_bit_cast(uint4, m);
+  lo = __builtin_bit_cast(uint4, l);
+}
+
 __device__ __forceinline__ size_t pk_src(int ci, int co, int kh, int kw, int Cout, int Cin, int KH, int KW, int transposed) {
   return transposed ? ((((size_t)ci * Cout + co) * KH + kh) * KW + kw) : ((((size_t)co * Cin + ci) * KH + kh) * KW + kw);
 }
@@ -46,7 +63,8 @@ __device__ __forceinline__ void pack_f32_item(int e, const float* __restrict__ w
   wp[e] = w[pk_src(ci, co, kh, kw, Cout, Cin, KH, KW, transposed)];
 }
 
-// bf16x3 main layout [tap][chunk][ocb][plane][group][co][8]
+// bf16 main layout [tap][chunk][ocb][plane h|m][group][co][8], followed by the third plane (bf16x6
+// kernels) [tap][chunk][ocb][group][co][8]
 __device__ __forceinline__ void pack_bf3_item(long it, const float* __restrict__ w, uint4* __restrict__ dst, int Cout,
                                               int Cin, int KH, int KW, int transposed, int ps_r, int bwd, int IC, int OC,
                                               int ICc, int OCb, int NB) {
@@ -83,11 +101,14 @@ __device__ __forceinline__ void pack_bf3_item(long it, const float* __restrict__
     }
     f[e] = v;
   }
-  uint4 hi, lo;
-  pk_split8(f, hi, lo);
-  uint4* blk = dst + ((size_t)(tap * ICc + cc) * OCb + ocb) * (size_t)(8 * NB);
+  uint4 hi, mid, lo;
+  pk_split8x3(f, hi, mid, lo);
+  const size_t slot = (size_t)(tap * ICc + cc) * OCb + ocb;
+  uint4* blk = dst + slot * (size_t)(8 * NB);
   blk[(0 * 4 + g) * NB + col] = hi;
-  blk[(1 * 4 + g) * NB + col] = lo;
+  blk[(1 * 4 + g) * NB + col] = mid;
+  uint4* third = dst + (size_t)KH * KW * ICc * OCb * (size_t)(8 * NB);
+  third[slot * (size_t)(4 * NB) + g * NB + col] = lo;
 }
 
 // bf16x3 row-packed layout (gather IC <= 4) [kh][ks][ocb][plane][group][co][8]

@@ -26,15 +26,18 @@ FUSE_ESPCN_HEAD = False
 #   train_fwd forward that will be differentiated
 #   bwd       data gradient
 # Modes:
-#   "mixed"  (default) infer = bf16x3, train_fwd = exact fp32 MFMA, bwd = bf16x3.
-#            The training forward stays exact so that ReLU / LeakyReLU masks are decided on fp32
-#            values (a 5e-6 forward perturbation flips ~1e-5 of the units of a bias-free ReLU net, and
-#            one flipped unit moves that layer's gradient by ~1/sqrt(units) ~ 1e-2); gradients then
-#            only carry the ~5e-6 arithmetic error of the bf16x3 data-gradient kernels.
+#   "mixed"  (default) infer = bf16x3, train_fwd = bf16x6 (exact 3-way operand split, 6 bf16 MFMAs per
+#            product: measured 3.5e-7 rms / 8.8e-7 max error vs fp64 — tighter than the fp32 MFMA
+#            kernel's 4.3e-7 / 1.2e-6 — at 1.5-2x its speed; shapes it does not cover run exact fp32),
+#            bwd = bf16x3.  The training forward stays fp32-faithful so that ReLU / LeakyReLU masks are
+#            decided on fp32-accurate values (a 5e-6 forward perturbation flips ~1e-5 of the units of
+#            a bias-free ReLU net, and one flipped unit moves that layer's gradient by
+#            ~1/sqrt(units) ~ 1e-2); gradients then only carry the ~5e-6 arithmetic error of the
+#            bf16x3 data-gradient kernels.
 #   "bf16x3" everything on the 3-term bf16 split (fastest; forward error ~1e-5, gradients subject to
 #            the mask-flip sensitivity above).
 #   "fp32"   everything exact fp32 (summation-order-level agreement with ATen/oneDNN).
-_MODES = {"mixed": {"infer": ALGO_AUTO, "train_fwd": _lib.ALGO_MFMA, "bwd": ALGO_AUTO},
+_MODES = {"mixed": {"infer": ALGO_AUTO, "train_fwd": _lib.ALGO_MFMA_BF16X6, "bwd": ALGO_AUTO},
           "bf16x3": {"infer": ALGO_AUTO, "train_fwd": ALGO_AUTO, "bwd": ALGO_AUTO},
           "fp32": {"infer": _lib.ALGO_MFMA, "train_fwd": _lib.ALGO_MFMA, "bwd": _lib.ALGO_MFMA}}
 _PRECISION = {"mode": "mixed"}

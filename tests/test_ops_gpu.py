@@ -13,9 +13,16 @@ from oracle.kat_table import CONV_KATS, conv_case_inputs
 
 pytestmark = pytest.mark.gpu
 
-ALGOS = {"auto": 0, "generic": 1, "mfma_fp32": 2}
-# AUTO runs the bf16x3 split-MFMA kernel where it applies (~1e-5 rel); the fp32 algos are exact-order fp32
-TOL_ALGO = {"auto": 1e-4, "generic": TOL_TIGHT, "mfma_fp32": TOL_TIGHT}
+ALGOS = {"auto": 0, "generic": 1, "mfma_fp32": 2, "bf16x6": 5}
+# AUTO runs the bf16x3 split-MFMA kernels where they apply (~1e-5 rel); generic / fp32 MFMA are exact-order fp32
+# and bf16x6 (exact 3-way operand split, 6 bf16 MFMAs) is held to the same tolerance as them.
+# variant -> (algo, env): the env switches pick the kernel family / block configuration that a problem of
+# benchmark size would get (the KAT shapes are all "small problems" for the automatic choice)
+VARIANTS = {"auto": ("auto", {}), "generic": ("generic", {}), "mfma_fp32": ("mfma_fp32", {}),
+            "auto_lds_weights": ("auto", {"SRK_BFD_SMALL": "0"}),
+            "auto_global_weights_big": ("auto", {"SRK_BF3_DIRECT": "1", "SRK_BFD_SMALL": "0"}),
+            "bf16x6": ("bf16x6", {}), "bf16x6_big": ("bf16x6", {"SRK_BFD_SMALL": "0"})}
+TOL_ALGO = {"auto": 1e-4, "generic": TOL_TIGHT, "mfma_fp32": TOL_TIGHT, "bf16x6": TOL_TIGHT}
 ACTS = {None: 0, "relu": 1, "lrelu": 3}
 
 
@@ -24,9 +31,12 @@ def _pkg():
     return pkg
 
 
-@pytest.mark.parametrize("algo", ["auto", "generic", "mfma_fp32"])
+@pytest.mark.parametrize("variant", list(VARIANTS))
 @pytest.mark.parametrize("idx", range(len(CONV_KATS)), ids=[c[0] for c in CONV_KATS])
-def test_conv_forward_backward(gpu, ops_kat, idx, algo):
+def test_conv_forward_backward(gpu, ops_kat, idx, variant, monkeypatch):
+    algo, env = VARIANTS[variant]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     pkg = _pkg()
     ops = pkg.ops
     tag, cin, cout, k, s, p, tr, op, H, W, N, act = CONV_KATS[idx]

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Run ON the MI355X box (through gpurun) from the repo root: collects the evidence committed under profiles/.
+#   1. rocprofv3 --kernel-trace --stats of the c2 bench command (per-kernel average durations)
+#   2. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE cannot share a pass: TCC has 4 slots, they cost 3+2)
+#   3. the same for one EDSR x4 training step (c4) so the train-path kernels are on record as well
+# Output: gpurun_out/prof_<tag>/...; tools/summarize_prof.py turns it into profiles/<tag>_*.{csv,json}.
+set -u
+TAG=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+C2="python $ROOT/bench.py --steps 10 --warmup 3 --no-extra --no-cpu-baseline"
+C4="python $ROOT/tools/edsr_b16.py 128"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2_kt -o c2 -- $C2 > $OUT/c2_kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/c2_fetch -o c2 -- $C2 > $OUT/c2_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/c2_write -o c2 -- $C2 > $OUT/c2_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_kt -o c4 -- $C4 > $OUT/c4_kt.log 2>&1
+cd $ROOT
+python tools/summarize_prof.py $TAG > $OUT/summary.log 2>&1
+cat $OUT/summary.log | tail -30
