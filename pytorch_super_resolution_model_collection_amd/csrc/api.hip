@@ -31,6 +31,12 @@ size_t conv_wgrad_mfma_ws(const srk_conv_desc& d);
 int conv_wgrad_mfma(const srk_conv_desc& d, const float* x, const float* dy, const srk_bwd_mask* mask, float* dw,
                     float* db, float beta, void* ws, size_t ws_bytes, hipStream_t s);
 
+// conv_wgrad_bf16.hip
+bool conv_wgrad_bf_supported(const srk_conv_desc& d);
+size_t conv_wgrad_bf_ws(const srk_conv_desc& d);
+int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const srk_bwd_mask* mask, float* dw,
+                  float* db, float beta, void* ws, size_t ws_bytes, hipStream_t s);
+
 // conv_fused2_bf16.hip
 int conv_fused2_forward(const srk_conv_desc& d1, const srk_conv_desc& d2, const float* x, int x_nchw,
                         const float* wp1, const float* wp2, float* y, const Epi& ep1, const Epi& ep2, hipStream_t s);
@@ -176,7 +182,9 @@ extern "C" size_t srk_conv2d_backward_weight_workspace_bytes(const srk_conv_desc
   if (!d) return 0;
   size_t a = conv_generic_wgrad_ws(*d);
   size_t b = conv_wgrad_mfma_supported(*d) ? conv_wgrad_mfma_ws(*d) : 0;
-  return a > b ? a : b;
+  size_t c = conv_wgrad_bf_supported(*d) ? conv_wgrad_bf_ws(*d) : 0;
+  if (b > a) a = b;
+  return a > c ? a : c;
 }
 
 extern "C" int srk_conv2d_backward_weight(const srk_conv_desc* d, const float* x, const float* dy,
@@ -186,8 +194,12 @@ extern "C" int srk_conv2d_backward_weight(const srk_conv_desc* d, const float* x
   if (rc) return rc;
   SRK_REQUIRE(x && dy && dw, "conv2d_backward_weight: null tensor pointer");
   SRK_REQUIRE(beta == 0.f || beta == 1.f, "conv2d_backward_weight: beta must be 0 or 1");
-  // the weight gradient has one fast kernel (fp32 MFMA); every algo except GENERIC uses it where it applies
+  // AUTO / BF16X3: bf16x3 MFMA kernel where it applies (stride-1 convs up to 3x3); MFMA / BF16X6 / DIRECT: the
+  // exact fp32 MFMA kernel; GENERIC: the plain kernel
   const int algo = forced_algo(d->algo);
+  const char* wb = getenv("SRK_WGRAD_BF16");  // 0 disables the bf16x3 weight-gradient kernel
+  if ((algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3) && !(wb && atoi(wb) == 0) && conv_wgrad_bf_supported(*d))
+    return conv_wgrad_bf(*d, x, dy, mask, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);
   if (algo != SRK_ALGO_GENERIC && conv_wgrad_mfma_supported(*d))
     return conv_wgrad_mfma(*d, x, dy, mask, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);
   return conv_generic_wgrad(*d, x, dy, mask, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);

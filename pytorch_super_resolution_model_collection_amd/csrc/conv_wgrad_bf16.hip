@@ -1,0 +1,396 @@
+// Weight gradient of stride-1 Conv2d on the bf16 matrix cores (3-term split, fp32 accumulate).
+//
+//   dW[tap][ci][co] = sum over output pixels q of  X[q - pad + tap][ci] * dY[q][co]
+//
+// GEMM view per tap: M = ci, N = co, K = pixels.  v_mfma_f32_16x16x32_bf16 wants, per lane, 8
+// consecutive K values of one row (A: channel ci of X) / column (B: channel co of dY): the NHWC
+// fp32 tiles are therefore staged TRANSPOSED in LDS as bf16 planes [hi|lo][channel][pixel], a K
+// step being 4 "octets" (8 consecutive pixels of one tile row, 16-byte aligned in LDS).
+//   * the tap's row shift u is a row offset in the X halo plane; the column shift v (0..2) would
+//     misalign the 16-byte fragment by v*2 bytes, so each lane reads the aligned octet plus the
+//     next two pixels (ds_read_b128 + ds_read_b32) ONCE per (u, plane) and derives the three
+//     shifted fragments in registers (v_alignbit_b32 by 16 bits for v = 1, a register rename for
+//     v = 2): 12 + 2*NTW LDS reads and 24 VALU ops feed 27*NTW MFMAs per K step;
+//   * a block owns a chunk of CIT*16 input channels x COW*NTW*16 output channels and ALL <= 9
+//     taps; wave (cit, cow) keeps its 9 x NTW accumulator tiles in registers across all pixel
+//     tiles the persistent block walks (split-K over blocks), then writes one partial slab; the
+//     deterministic slab reduction / bias-gradient finish are shared with the fp32 kernel;
+//   * dY is masked with the ReLU / LeakyReLU gradient on the fly and its column sums (bias
+//     gradient partials) are accumulated in fp32 registers while it is staged.
+// Arithmetic: x = h + m (bf16 each), products m*h + h*m + h*h -> ~5e-6 relative on dW.
+// Anything else (stride > 1, ConvTranspose2d, kernels larger than 3x3, Cin < 8) runs the exact fp32
+// kernels of conv_wgrad_mfma.hip.
+#include "srk_common.h"
+#include "conv_problem.h"
+#include <stdlib.h>
+
+namespace srk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// conv_wgrad_mfma.hip
+int conv_wgrad_reduce_launch(const float* ws, float* dw, int G, int Cout, int Cin, int KH, int KW, int transposed,
+                             float beta, hipStream_t s);
+
+constexpr int WB_MAXOCT = 64;  // octets per tile (<= 512 pixels)
+
+struct WgBfParams {
+  const float* x;
+  const float* dy;
+  const float* mask_y;
+  float mask_slope;
+  float* ws;            // [G][T][Cin][Cout]
+  float* bias_partial;  // [G][Cout] or NULL
+  int N, Cin, Cout;
+  int XH, XW, YH, YW;
+  int KH, KW, pad;
+  int TH, TW, TWo, tiles_y, tiles_x, HH, HWp;
+  int CS, DS;  // per-channel plane strides (bf16 elements) of the X halo / dY tile
+  int ntiles, G, nks;
+  int vec_x, vec_y;
+};
+
+__device__ __forceinline__ f32x4 wb_mfma(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
+                                                 0);
+}
+
+__device__ __forceinline__ unsigned short wb_bits(__bf16 v) { return __builtin_bit_cast(unsigned short, v); }
+
+// two horizontally adjacent pixels x 4 channels (fp32) -> 4 channels x {hi, lo} dwords (pixel pair packed)
+__device__ __forceinline__ void wb_split_pair(const f32x4& p0, const f32x4& p1, unsigned (&hi)[4], unsigned (&lo)[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const __bf16 h0 = (__bf16)p0[c], h1 = (__bf16)p1[c];
+    const __bf16 l0 = (__bf16)(p0[c] - (float)h0), l1 = (__bf16)(p1[c] - (float)h1);
+    hi[c] = (unsigned)wb_bits(h0) | ((unsigned)wb_bits(h1) << 16);
+    lo[c] = (unsigned)wb_bits(l0) | ((unsigned)wb_bits(l1) << 16);
+  }
+}
+
+// Load 4 channels [ch, ch+4) of pixel (n, iy, ix) of an NHWC tensor (zero outside the image / channel range),
+// optionally masked by the ReLU-family gradient of `mask`.
+__device__ __forceinline__ f32x4 wb_load4(const float* __restrict__ src, const float* __restrict__ mask, float mslope,
+                                          int n, int H, int W, int C, int iy, int ix, int ch, int vec) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (iy >= 0 && iy < H && ix >= 0 && ix < W && ch < C) {
+    const size_t off = (((size_t)n * H + iy) * W + ix) * C + ch;
+    if (vec && ch + 3 < C) {
+      v = *reinterpret_cast<const f32x4*>(src + off);
+      if (mask) {
+        const f32x4 m = *reinterpret_cast<const f32x4*>(mask + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : v[e] * mslope;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (ch + e < C) {
+          float t = src[off + e];
+          if (mask) t = mask[off + e] > 0.f ? t : t * mslope;
+          v[e] = t;
+        }
+    }
+  }
+  return v;
+}
+
+// CIT: 16-channel input tiles per block (one per wave row), COW: output-channel wave columns,
+// NTW: 16-channel output tiles per wave.  CIT * COW = 4 waves.
+template <int CIT, int COW, int NTW>
+__global__ __launch_bounds__(256, 2) void k_wgrad_bf(WgBfParams P) {
+  constexpr int CIB = CIT * 16, COB = COW * NTW * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+  __shared__ int oct_x[WB_MAXOCT], oct_y[WB_MAXOCT];
+  __shared__ float bred[256][4];
+  unsigned short* xs = smem16;                          // [2][CIB][CS]
+  unsigned short* ys = smem16 + (size_t)2 * CIB * P.CS;  // [2][COB][DS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int cit = wave % CIT, cow = wave / CIT;
+  const int cib = blockIdx.y * CIB, cob = blockIdx.z * COB;
+  const int noct = P.TH * P.TWo;
+  const bool want_bias = P.bias_partial != nullptr && blockIdx.y == 0;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+  for (int o = tid; o < P.nks * 4; o += 256) {
+    if (o < noct) {
+      const int orow = o / P.TWo, oc = o - orow * P.TWo;
+      oct_x[o] = orow * P.HWp + oc * 8;
+      oct_y[o] = o * 8;
+    } else {  // K padding: multiply by the zero octet appended to every dY plane
+      oct_x[o] = 0;
+      oct_y[o] = P.TH * P.TW;
+    }
+  }
+  for (int e = tid; e < 2 * COB * 4; e += 256) {  // zero octets (never overwritten by the staging)
+    const int pc = e >> 2, w = e & 3;
+    reinterpret_cast<unsigned*>(ys + (size_t)pc * P.DS + P.TH * P.TW)[w] = 0u;
+  }
+
+  f32x4 acc[3][3][NTW];
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) acc[u][v][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const unsigned short* xa_h = xs + (size_t)(cit * 16 + i) * P.CS;
+  const unsigned short* xa_l = xa_h + (size_t)CIB * P.CS;
+  const unsigned short* yb_h = ys + (size_t)(cow * NTW * 16 + i) * P.DS;
+  const unsigned short* yb_l = yb_h + (size_t)COB * P.DS;
+  const int hwp2 = P.HWp >> 1, tw2 = P.TW >> 1;
+
+  for (int tile = blockIdx.x; tile < P.ntiles; tile += P.G) {
+    int b = tile;
+    const int txi = b % P.tiles_x;
+    b /= P.tiles_x;
+    const int tyi = b % P.tiles_y;
+    const int n = b / P.tiles_y;
+    const int r0 = tyi * P.TH, c0 = txi * P.TW;
+    __syncthreads();  // previous tile fully consumed (tables / zero octets visible on the first pass)
+    {  // X halo: rows [r0-pad, +HH), cols [c0-pad, +HWp), channels [cib, cib+CIB) -> planes [ci][hy][hx]
+      constexpr int QN = CIB / 4;
+      const int items = P.HH * hwp2 * QN;
+      const int by0 = r0 - P.pad, bx0 = c0 - P.pad;
+      for (int it = tid; it < items; it += 256) {
+        const int q = it % QN, pp = it / QN;
+        const int hy = pp / hwp2, hx = (pp - hy * hwp2) * 2;
+        const int ch = cib + q * 4;
+        const f32x4 p0 = wb_load4(P.x, nullptr, 0.f, n, P.XH, P.XW, P.Cin, by0 + hy, bx0 + hx, ch, P.vec_x);
+        const f32x4 p1 = wb_load4(P.x, nullptr, 0.f, n, P.XH, P.XW, P.Cin, by0 + hy, bx0 + hx + 1, ch, P.vec_x);
+        unsigned hi[4], lo[4];
+        wb_split_pair(p0, p1, hi, lo);
+        const int po = hy * P.HWp + hx;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          *reinterpret_cast<unsigned*>(xs + (size_t)(q * 4 + c) * P.CS + po) = hi[c];
+          *reinterpret_cast<unsigned*>(xs + (size_t)(CIB + q * 4 + c) * P.CS + po) = lo[c];
+        }
+      }
+    }
+    {  // dY tile: rows [r0, +TH), cols [c0, +TW), channels [cob, cob+COB) -> planes [co][r][c] (masked)
+      constexpr int QN = COB / 4;
+      const int items = P.TH * tw2 * QN;
+      for (int it = tid; it < items; it += 256) {
+        const int q = it % QN, pp = it / QN;
+        const int r = pp / tw2, c = (pp - r * tw2) * 2;
+        const int ch = cob + q * 4;
+        const f32x4 p0 = wb_load4(P.dy, P.mask_y, P.mask_slope, n, P.YH, P.YW, P.Cout, r0 + r, c0 + c, ch, P.vec_y);
+        const f32x4 p1 =
+            wb_load4(P.dy, P.mask_y, P.mask_slope, n, P.YH, P.YW, P.Cout, r0 + r, c0 + c + 1, ch, P.vec_y);
+        bsum += p0 + p1;  // this thread's channel group is fixed (256 % QN == 0)
+        unsigned hi[4], lo[4];
+        wb_split_pair(p0, p1, hi, lo);
+        const int po = r * P.TW + c;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          *reinterpret_cast<unsigned*>(ys + (size_t)(q * 4 + cc) * P.DS + po) = hi[cc];
+          *reinterpret_cast<unsigned*>(ys + (size_t)(COB + q * 4 + cc) * P.DS + po) = lo[cc];
+        }
+      }
+    }
+    __syncthreads();
+    for (int ks = 0; ks < P.nks; ++ks) {
+      const int ox = oct_x[ks * 4 + kq], oy = oct_y[ks * 4 + kq];
+      uint4 bh[NTW], bl[NTW];
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        bh[nt] = *reinterpret_cast<const uint4*>(yb_h + (size_t)nt * 16 * P.DS + oy);
+        bl[nt] = *reinterpret_cast<const uint4*>(yb_l + (size_t)nt * 16 * P.DS + oy);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (u < P.KH) {
+          const unsigned short* ph = xa_h + ox + u * P.HWp;
+          const unsigned short* pl = xa_l + ox + u * P.HWp;
+          const uint4 qh = *reinterpret_cast<const uint4*>(ph);
+          const uint4 ql = *reinterpret_cast<const uint4*>(pl);
+          const unsigned eh = *reinterpret_cast<const unsigned*>(ph + 8);
+          const unsigned el = *reinterpret_cast<const unsigned*>(pl + 8);
+#pragma unroll
+          for (int v = 0; v < 3; ++v) {
+            if (v < P.KW) {
+              uint4 ah, al;
+              if (v == 0) {
+                ah = qh;
+                al = ql;
+              } else if (v == 1) {
+                ah = make_uint4(__builtin_amdgcn_alignbit(qh.y, qh.x, 16), __builtin_amdgcn_alignbit(qh.z, qh.y, 16),
+                                __builtin_amdgcn_alignbit(qh.w, qh.z, 16), __builtin_amdgcn_alignbit(eh, qh.w, 16));
+                al = make_uint4(__builtin_amdgcn_alignbit(ql.y, ql.x, 16), __builtin_amdgcn_alignbit(ql.z, ql.y, 16),
+                                __builtin_amdgcn_alignbit(ql.w, ql.z, 16), __builtin_amdgcn_alignbit(el, ql.w, 16));
+              } else {
+                ah = make_uint4(qh.y, qh.z, qh.w, eh);
+                al = make_uint4(ql.y, ql.z, ql.w, el);
+              }
+#pragma unroll
+              for (int nt = 0; nt < NTW; ++nt) acc[u][v][nt] = wb_mfma(al, bh[nt], acc[u][v][nt]);
+#pragma unroll
+              for (int nt = 0; nt < NTW; ++nt) acc[u][v][nt] = wb_mfma(ah, bl[nt], acc[u][v][nt]);
+#pragma unroll
+              for (int nt = 0; nt < NTW; ++nt) acc[u][v][nt] = wb_mfma(ah, bh[nt], acc[u][v][nt]);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (want_bias) {  // column sums of dY: combine the threads that staged the same channel group
+    constexpr int QN = COB / 4;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bred[tid][e] = bsum[e];
+    __syncthreads();
+    if (tid < COB && cob + tid < P.Cout) {
+      const int q = tid >> 2, e = tid & 3;
+      float s = 0.f;
+      for (int t = q; t < 256; t += QN) s += bred[t][e];
+      P.bias_partial[(size_t)blockIdx.x * P.Cout + cob + tid] = s;
+    }
+  }
+  // partial slab ws[g][t][ci][co]; C/D layout: col = lane&15 (co), row = (lane>>4)*4 + reg (ci)
+  float* slab = P.ws + (size_t)blockIdx.x * P.KH * P.KW * P.Cin * P.Cout;
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      if (u < P.KH && v < P.KW) {
+        const int t = u * P.KW + v;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const int co = cob + (cow * NTW + nt) * 16 + i;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int ci = cib + cit * 16 + kq * 4 + reg;
+            if (ci < P.Cin && co < P.Cout) slab[((size_t)t * P.Cin + ci) * P.Cout + co] = acc[u][v][nt][reg];
+          }
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host
+// ---------------------------------------------------------------------------------------------
+static constexpr int kWbLdsBudget = 74 * 1024;  // + ~4.6 KB static (tables, bias reduction): 2 blocks per CU
+
+struct WbPlan {
+  bool ok;
+  int cfg;  // 0: 32 ci x 64 co (CIT 2, COW 2, NTW 2); 1: 64 ci x 32 co (4,1,2); 2: 64 ci x 16 co (4,1,1)
+  int CIB, COB;
+  int TH, TW, TWo, tiles_y, tiles_x, HH, HWp, CS, DS, nks;
+  size_t lds;
+  int G, ntiles, gy, gz;
+};
+
+static inline int round_8odd(int v) {  // smallest multiple of 8 >= v whose quotient by 8 is odd
+  int q = (v + 7) / 8;
+  if ((q & 1) == 0) ++q;
+  return q * 8;
+}
+
+static WbPlan wb_plan(const srk_conv_desc& d) {
+  WbPlan pl{};
+  pl.ok = false;
+  if (d.transposed || d.stride != 1 || d.KH > 3 || d.KW > 3 || d.Cin < 8 || d.Cout < 1) return pl;
+  if (d.Cout > 32) {
+    pl.cfg = 0; pl.CIB = 32; pl.COB = 64;
+  } else if (d.Cout > 16) {
+    pl.cfg = 1; pl.CIB = 64; pl.COB = 32;
+  } else {
+    pl.cfg = 2; pl.CIB = 64; pl.COB = 16;
+  }
+  pl.TWo = (d.OW + 7) / 8;
+  if (pl.TWo > 4) pl.TWo = 4;
+  pl.TW = pl.TWo * 8;
+  pl.tiles_x = cdiv(d.OW, pl.TW);
+  int TH = 128 / pl.TW;
+  if (TH > d.OH) TH = d.OH;
+  for (; TH >= 1; --TH) {
+    const int HH = TH + d.KH - 1, HWp = pl.TW + 8;
+    const int CS = round_8odd(HH * HWp), DS = round_8odd(TH * pl.TW + 8);
+    const size_t lds = ((size_t)2 * pl.CIB * CS + (size_t)2 * pl.COB * DS) * 2;
+    if (lds <= (size_t)kWbLdsBudget && TH * pl.TWo <= WB_MAXOCT) {
+      pl.TH = TH; pl.HH = HH; pl.HWp = HWp; pl.CS = CS; pl.DS = DS; pl.lds = lds;
+      break;
+    }
+  }
+  if (TH < 1) return pl;
+  pl.tiles_y = cdiv(d.OH, pl.TH);
+  pl.nks = cdiv(pl.TH * pl.TWo, 4);
+  const long nt = (long)d.N * pl.tiles_y * pl.tiles_x;
+  if (nt > (1L << 30)) return pl;
+  pl.ntiles = (int)nt;
+  pl.gy = cdiv(d.Cin, pl.CIB);
+  pl.gz = cdiv(d.Cout, pl.COB);
+  int g = (2 * kNumCU) / (pl.gy * pl.gz);  // two resident blocks per CU in total
+  if (g < 1) g = 1;
+  pl.G = pl.ntiles < g ? pl.ntiles : g;
+  pl.ok = true;
+  return pl;
+}
+
+bool conv_wgrad_bf_supported(const srk_conv_desc& d) { return wb_plan(d).ok; }
+
+size_t conv_wgrad_bf_ws(const srk_conv_desc& d) {
+  WbPlan pl = wb_plan(d);
+  if (!pl.ok) return 0;
+  return (size_t)pl.G * d.KH * d.KW * d.Cin * d.Cout * sizeof(float) + conv_bias_grad_ws(d);
+}
+
+template <int CIT, int COW, int NTW>
+static void wb_launch(const WgBfParams& P, dim3 grid, size_t lds, hipStream_t s) {
+  static int cur = 0;
+  if ((int)lds > cur) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    cur = (int)lds;
+  }
+  hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW>), grid, dim3(256), lds, s, P);
+}
+
+int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const srk_bwd_mask* mask, float* dw,
+                  float* db, float beta, void* ws, size_t ws_bytes, hipStream_t s) {
+  WbPlan pl = wb_plan(d);
+  if (!pl.ok) {
+    set_error("conv_wgrad_bf: shape not covered");
+    return SRK_ERR_UNSUPPORTED;
+  }
+  const size_t slab_bytes = (size_t)pl.G * d.KH * d.KW * d.Cin * d.Cout * sizeof(float);
+  const size_t need = slab_bytes + conv_bias_grad_ws(d);
+  if (!ws || ws_bytes < need) {
+    set_error("conv_wgrad_bf: workspace %zu < %zu", ws_bytes, need);
+    return SRK_ERR_WORKSPACE;
+  }
+  WgBfParams P{};
+  P.x = x; P.dy = dy; P.mask_y = mask ? mask->y : nullptr; P.mask_slope = mask ? mask->slope : 0.f;
+  P.ws = (float*)ws;
+  float* bias_ws = reinterpret_cast<float*>(static_cast<char*>(ws) + slab_bytes);
+  P.bias_partial = db ? bias_ws : nullptr;
+  P.N = d.N; P.Cin = d.Cin; P.Cout = d.Cout;
+  P.XH = d.H; P.XW = d.W; P.YH = d.OH; P.YW = d.OW;
+  P.KH = d.KH; P.KW = d.KW; P.pad = d.pad;
+  P.TH = pl.TH; P.TW = pl.TW; P.TWo = pl.TWo; P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x;
+  P.HH = pl.HH; P.HWp = pl.HWp; P.CS = pl.CS; P.DS = pl.DS;
+  P.ntiles = pl.ntiles; P.G = pl.G; P.nks = pl.nks;
+  P.vec_x = (d.Cin % 4 == 0) && ((uintptr_t)x % 16 == 0);
+  P.vec_y = (d.Cout % 4 == 0) && ((uintptr_t)dy % 16 == 0) && (!P.mask_y || (uintptr_t)P.mask_y % 16 == 0);
+  dim3 grid(pl.G, pl.gy, pl.gz);
+  switch (pl.cfg) {
+    case 0: wb_launch<2, 2, 2>(P, grid, pl.lds, s); break;
+    case 1: wb_launch<4, 1, 2>(P, grid, pl.lds, s); break;
+    default: wb_launch<4, 1, 1>(P, grid, pl.lds, s); break;
+  }
+  int rc = check_launch("conv_wgrad_bf");
+  if (rc) return rc;
+  rc = conv_wgrad_reduce_launch((const float*)ws, dw, pl.G, d.Cout, d.Cin, d.KH, d.KW, 0, beta, s);
+  if (rc) return rc;
+  if (db) rc = conv_bias_grad_finish(bias_ws, pl.G, db, d.Cout, beta, s);
+  return rc;
+}
+
+}  // namespace srk

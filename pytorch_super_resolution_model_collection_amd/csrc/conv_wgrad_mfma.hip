@@ -355,6 +355,14 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   dw[o] = beta != 0.f ? beta * dw[o] + v : v;
 }
 
+int conv_wgrad_reduce_launch(const float* ws, float* dw, int G, int Cout, int Cin, int KH, int KW, int transposed,
+                             float beta, hipStream_t s) {
+  const int elems = KH * KW * Cin * Cout;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(elems, 64)), dim3(256), 0, s, ws, dw, G, Cout, Cin, KH, KW, transposed,
+                     beta);
+  return check_launch("conv_wgrad_reduce");
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host
 // ---------------------------------------------------------------------------------------------
@@ -510,10 +518,7 @@ int conv_wgrad_mfma(const srk_conv_desc& d, const float* x, const float* dy, con
   }
   int rc = check_launch("conv_wgrad_mfma");
   if (rc) return rc;
-  const int elems = d.KH * d.KW * d.Cin * d.Cout;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(elems, 64)), dim3(256), 0, s, (const float*)ws, dw, pl.G, d.Cout,
-                     d.Cin, d.KH, d.KW, d.transposed, beta);
-  rc = check_launch("conv_wgrad_reduce");
+  rc = conv_wgrad_reduce_launch((const float*)ws, dw, pl.G, d.Cout, d.Cin, d.KH, d.KW, d.transposed, beta, s);
   if (rc) return rc;
   if (db) {
     if (P.bias_partial)
