@@ -108,6 +108,7 @@ def pmc_traffic(kernel_label, batch, lr_size):
         kernels = json.load(fh).get("kernels", {})
     short = kernel_label.split(" ")[0].rstrip(">")      # "k_conv_bf3<2" matches "srk::k_conv_bf3<2, 4>(...)"
     for name, rec in kernels.items():
+        name = name.replace(" ", "")
         i = name.find("::" + short)
         if i >= 0 and name[i + 2 + len(short)] in ">," and rec.get("hbm_bytes"):
             return int(rec["hbm_bytes"])
@@ -219,7 +220,7 @@ def main():
         dom = max(range(3), key=lambda i: layer_ms[i])
         bf3 = pkg.ops.get_precision() != "fp32"
         names = ["k_conv_bf3_rows<4> conv5x5 3->64 + ReLU", "k_conv_bf3<2> conv3x3 64->32 + ReLU",
-                 "k_conv_bf3<3> conv3x3 32->48 + pixel-shuffle store"] if bf3 else [
+                 "k_conv_bfr<1,3> conv3x3 32->48 + pixel-shuffle store"] if bf3 else [
                  "k_conv_mfma_tg<4> conv5x5 3->64 + ReLU", "k_conv_mfma<2> conv3x3 64->32 + ReLU",
                  "k_conv_mfma<3> conv3x3 32->48 + pixel-shuffle store"]
         peak = BF16X3_PEAK_TFLOPS if bf3 else FP32_MFMA_PEAK_TFLOPS

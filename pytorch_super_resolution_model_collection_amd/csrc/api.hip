@@ -103,6 +103,10 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
     const int direct_w = e ? (atoi(e) ? 1 : 0) : 2;
     if (bfd_ok && (direct_w == 1 || (direct_w == 2 && conv_bfd_small_problem(g))))
       return conv_bfd_gather(g, in, wp, out, ep, mask_y, mask_slope, 2, s);
+    if (bfd_ok && conv_bfr_applicable(g, mask_y)) {  // filter resident in LDS, persistent blocks (ESPCN-size layers)
+      const int rc = conv_bfr_gather(g, in, wp, out, ep, s);
+      if (rc >= 0) return rc;
+    }
     return conv_bf3_gather(g, in, wp, out, ep, mask_y, mask_slope, s);
   }
   if (algo == SRK_ALGO_MFMA || (algo == SRK_ALGO_AUTO && mfma_ok))

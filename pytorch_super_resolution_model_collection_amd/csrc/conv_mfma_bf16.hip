@@ -388,147 +388,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_bf3(Bf3Params B) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Variant with the filter operand taken straight from global memory (L1/L2-resident: every block of
-// a layer reads the same <= 150 KB): the prepared layout IS the MFMA B-operand layout, so each lane
-// loads its 2*NT 16-byte fragments of the next tap into registers while the MFMAs of the current
-// tap run.  No weight LDS slots, no barrier inside the tap loop — the waves of a block drift apart
-// and overlap each other's loads and MFMAs; LDS traffic per tap halves (A fragments only).
-// ---------------------------------------------------------------------------------------------
-template <int NT, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void k_conv_bf3d(Bf3Params B) {
-  constexpr int NTHR = 64 * NW;
-  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
-  __shared__ int tap_toff[BF3_MAXTAPS];
-  __shared__ int tap_wtap[BF3_MAXTAPS];
-  const MfmaConvParams& P = B.P;
-  uint4* hal = smem4;  // [2][4][NPIXp]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j = lane & 15, kq = lane >> 4;
-  int b = blockIdx.x;
-  const int txi = b % P.tiles_x;
-  b /= P.tiles_x;
-  const int tyi = b % P.tiles_y;
-  const int n = b / P.tiles_y;
-  const int r0 = tyi * P.TH, c0 = txi * P.TW;
-  const int ocbi = blockIdx.y;
-  const int ocb = ocbi * 64;
-  const int npx = P.TH * P.TW;
-  const int NB = B.NB;
-  const int wslot = 8 * NB;
-  const int T = P.KHv * P.KWv;
-
-  for (int t = tid; t < T && t < BF3_MAXTAPS; t += NTHR) {
-    const int u = t / P.KWv, v = t - u * P.KWv;
-    tap_toff[t] = u * P.HW + v;
-    tap_wtap[t] = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
-  }
-  int hp[4];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    int m = wave * 64 + mt * 16 + j;
-    if (m >= npx) m = 0;
-    const int r = m / P.TW, c = m - r * P.TW;
-    hp[mt] = (r * P.is) * P.HW + c * P.is + kq * B.NPIXp;
-  }
-  f32x4 acc[4][NT];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const bool wave_live = wave * 64 < npx;
-  const int lo_plane = 4 * B.NPIXp;
-  const int wlane = kq * NB + j;
-  // flat (chunk, tap) -> this lane's fragment base
-  auto wsrc = [&](int cc, int t) -> const uint4* {
-    int tapw;
-    if (t < BF3_MAXTAPS) {
-      tapw = tap_wtap[t];
-    } else {
-      const int u = t / P.KWv, v = t - u * P.KWv;
-      tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
-    }
-    return B.wq + ((size_t)(tapw * B.ICc + cc) * B.OCb + ocbi) * (size_t)wslot + wlane;
-  };
-  uint4 bh[NT], bl[NT];
-  if (T > 0) {
-    __syncthreads();  // tap tables
-    {
-      const uint4* w0 = wsrc(0, 0);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        bh[nt] = w0[nt * 16];
-        bl[nt] = w0[4 * NB + nt * 16];
-      }
-    }
-    for (int cc = 0; cc < B.ICc; ++cc) {
-      if (cc) __syncthreads();  // previous chunk's halo fully consumed
-      if (!(B.dbg & 1)) bf3_stage_halo<NTHR>(B, hal, n, r0, c0, cc * 32);
-      __syncthreads();
-      for (int t = 0; t < T; ++t) {
-        uint4 nh[NT], nl[NT];
-        {
-          int nc = cc, ntp = t + 1;
-          if (ntp == T) {
-            ntp = 0;
-            ++nc;
-          }
-          if (nc < B.ICc) {
-            const uint4* wn = wsrc(nc, ntp);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              nh[nt] = wn[nt * 16];
-              nl[nt] = wn[4 * NB + nt * 16];
-            }
-          } else {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) nh[nt] = nl[nt] = make_uint4(0, 0, 0, 0);
-          }
-        }
-        if (wave_live && !(B.dbg & 4)) {
-          int toff;
-          if (t < BF3_MAXTAPS) {
-            toff = tap_toff[t];
-          } else {
-            const int u = t / P.KWv, v = t - u * P.KWv;
-            toff = u * P.HW + v;
-          }
-          const uint4* hb = hal + toff;
-          uint4 ah[4], al[4];
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) {
-            ah[mt] = hb[hp[mt]];
-            al[mt] = hb[hp[mt] + lo_plane];
-          }
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_bf16(al[mt], bh[nt], acc[mt][nt]);
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_bf16(ah[mt], bl[nt], acc[mt][nt]);
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_bf16(ah[mt], bh[nt], acc[mt][nt]);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          bh[nt] = nh[nt];
-          bl[nt] = nl[nt];
-        }
-      }
-    }
-  }
-  if (B.dbg & 2) {
-    if (acc[0][0][0] == 123.456f) P.out[0] = 1.f;
-    return;
-  }
-  bf3_epilogue<NT>(P, reinterpret_cast<float*>(smem4), acc, n, r0, c0, ocb, wave, lane);
-}
-
-// ---------------------------------------------------------------------------------------------
 // Row-packed variant for IC <= 4 (CONV gathers: the 3->64 first layers).  A K step of 32 is one
 // kernel row segment: 8 kw positions x 4 (zero-padded) channels; lane group kq supplies kw slots
 // 2kq, 2kq+1, i.e. 16 contiguous bytes of the [pixel][4 x bf16] halo planes.  A 5x5x3 filter is 5
@@ -753,24 +612,6 @@ static void bf3_launch(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s)
   hipLaunchKernelGGL((k_conv_bf3<NT, NW>), grid, dim3(64 * NW), lds, s, B);
 }
 
-template <int NT, int NW>
-static void bf3d_launch(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s) {
-  static int cur = 0;
-  if ((int)lds > cur) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bf3d<NT, NW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    cur = (int)lds;
-  }
-  if (B.dbg & 32) {
-    int nb = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_conv_bf3d<NT, NW>), 64 * NW,
-                                                       lds);
-    fprintf(stderr, "[srk] k_conv_bf3d<%d,%d>: lds %zu B, grid %u x %u, occupancy %d blocks/CU, tile %dx%d halo %dx%d\n", NT,
-            NW, lds, grid.x, grid.y, nb, B.P.TH, B.P.TW, B.P.HH, B.P.HW);
-  }
-  hipLaunchKernelGGL((k_conv_bf3d<NT, NW>), grid, dim3(64 * NW), lds, s, B);
-}
-
 bool conv_bf3_gather_supported(const GatherConv& g, const Epi& ep) {
   (void)ep;
   if (g.OC < 8) return false;                        // <= 4: direct kernel; 5..7: fp32 kernels
@@ -823,8 +664,7 @@ static int bf3_launch_rows_phase(MfmaConvParams P, const uint4* wq, hipStream_t 
 
 template <int NW>
 static int bf3_launch_phase_nw(MfmaConvParams P, Bf3Params B, int NT, int dbg, hipStream_t s) {
-  const bool direct_w = (dbg & 128) != 0;  // filters straight from global memory (k_conv_bf3d)
-  const int wbytes = direct_w ? 0 : 2 * 8 * B.NB * 16;
+  const int wbytes = 2 * 8 * B.NB * 16;
   const int maxpix = 64 * NW;
   // LDS share that lets `blocks` blocks of this size be co-resident on a CU (160 KiB)
   const int budget = NW == 4 ? kLdsBudgetBytes : (NW == 2 ? 39 * 1024 : 31 * 1024);
@@ -854,15 +694,6 @@ static int bf3_launch_phase_nw(MfmaConvParams P, Bf3Params B, int NT, int dbg, h
   if (lds < epi_bytes) lds = epi_bytes;
   if (dbg & 64) lds = 100 * 1024;  // experiment: force 1 block per CU
   dim3 grid((unsigned)((size_t)P.tiles_x * P.tiles_y * P.N), B.OCb);
-  if (direct_w) {
-    switch (NT) {
-      case 1: bf3d_launch<1, NW>(B, grid, lds, s); break;
-      case 2: bf3d_launch<2, NW>(B, grid, lds, s); break;
-      case 3: bf3d_launch<3, NW>(B, grid, lds, s); break;
-      default: bf3d_launch<4, NW>(B, grid, lds, s); break;
-    }
-    return check_launch("conv_bf3d");
-  }
   switch (NT) {
     case 1: bf3_launch<1, NW>(B, grid, lds, s); break;
     case 2: bf3_launch<2, NW>(B, grid, lds, s); break;
