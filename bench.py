@@ -174,6 +174,16 @@ def train_extra(pkg, dev, rank, world):
     out["c4_edsr_x4_train_patches_per_s_global_batch_128"] = round(gb * k / sec, 1)
     out["c4_edsr_ms_per_step"] = round(1e3 * sec / k, 3)
     out["c4_scaling"] = "strong (global batch 128 sharded over %d rank(s), RCCL all-reduce of 6.07 MB grads)" % world
+    if world > 1:
+        # the same step with the per-GPU batch held at 128 (weak scaling: global batch 128 * world)
+        net = pkg.EDSRNet(3, 64, 16)
+        torch.manual_seed(1234)
+        net.weight_init()
+        x = torch.rand(gb, 3, 32, 32, generator=g).to(dev)
+        t = torch.rand(gb, 3, 128, 128, generator=g).to(dev)
+        sec, k = run("edsr", net, x, t, pkg.ops.l1_loss, None, True)
+        out["c4_weak_edsr_x4_train_patches_per_s_batch_128_per_gpu"] = round(world * gb * k / sec, 1)
+        out["c4_weak_ms_per_step"] = round(1e3 * sec / k, 3)
     return out
 
 
