@@ -174,6 +174,27 @@ def train_extra(pkg, dev, rank, world):
     out["c4_edsr_x4_train_patches_per_s_global_batch_128"] = round(gb * k / sec, 1)
     out["c4_edsr_ms_per_step"] = round(1e3 * sec / k, 3)
     out["c4_scaling"] = "strong (global batch 128 sharded over %d rank(s), RCCL all-reduce of 6.07 MB grads)" % world
+    # c5: SRGAN x4 generator + discriminator adversarial step (srgan.py:249-310), reference default batch 16 per GPU,
+    # 32x32 LR -> 128x128 HR crops; eager (two models, two optimizers), both gradients all-reduced under DP
+    G, D = pkg.SRGANGenerator(3, 64, 16), pkg.SRGANDiscriminator(3, 64, 128)
+    torch.manual_seed(1234)
+    G.weight_init()
+    D.weight_init()
+    G.to(dev).train()
+    D.to(dev).train()
+    gflat, dflat = pkg.optim.FlatParams(G), pkg.optim.FlatParams(D)
+    g_opt, d_opt = pkg.optim.make_optimizer("srgan_g", gflat, 1e-4), pkg.optim.make_optimizer("srgan_d", dflat, 1e-4)
+    g_dp = d_dp = None
+    if world > 1:
+        g_dp, d_dp = pkg.dp.DataParallel(gflat), pkg.dp.DataParallel(dflat)
+        g_dp.broadcast_params()
+        d_dp.broadcast_params()
+    sstep = pkg.trainers.srgan_step(G, D, g_opt, d_opt, g_dp, d_dp)
+    lr_img = torch.rand(16, 3, 32, 32, generator=g).to(dev)
+    hr_img = torch.rand(16, 3, 128, 128, generator=g).to(dev)
+    sec = time_steps(lambda: sstep(lr_img, hr_img), 6, 3, world, dev)
+    out["c5_srgan_x4_adv_step_patches_per_s_batch_16_per_gpu"] = round(world * 16 * 6 / sec, 1)
+    out["c5_srgan_ms_per_step"] = round(1e3 * sec / 6, 3)
     if world > 1:
         # the same step with the per-GPU batch held at 128 (weak scaling: global batch 128 * world)
         net = pkg.EDSRNet(3, 64, 16)

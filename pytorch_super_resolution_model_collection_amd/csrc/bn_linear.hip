@@ -15,6 +15,8 @@ __global__ __launch_bounds__(256) void k_bn_colsum(const float* __restrict__ a, 
                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                                    double* __restrict__ partial, size_t rows, int C,
                                                    size_t rows_per_split) {
+  // lane = channel of a 64-channel slab (coalesced 256-byte rows), the 4 waves interleave rows; 8 rows per
+  // wave are loaded before the first add (8 independent fp32 accumulator pairs), flushed to double per batch
   __shared__ double sm[2][4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
@@ -27,23 +29,24 @@ __global__ __launch_bounds__(256) void k_bn_colsum(const float* __restrict__ a, 
       mu = mean[c];
       rs = rstd[c];
     }
-    float f0 = 0.f, f1 = 0.f;
-    int cnt = 0;
-    for (size_t r = r0 + w; r < r1; r += 4) {
-      const float v = a[r * C + c];
-      if (MODE == 0) {
-        f0 += v;
-        f1 += v * v;
-      } else {
-        f0 += v;
-        f1 += v * ((x[r * C + c] - mu) * rs);
+    constexpr int U = 8;
+    for (size_t rb = r0 + w; rb < r1; rb += 4 * U) {
+      float va[U], vx[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t r = rb + 4 * (size_t)u;
+        va[u] = r < r1 ? a[r * C + c] : 0.f;
+        if (MODE == 1) vx[u] = r < r1 ? x[r * C + c] : mu;
       }
-      if (++cnt == 64) {  // flush the fp32 running sums into double to bound rounding growth
-        s0 += f0; s1 += f1; f0 = 0.f; f1 = 0.f; cnt = 0;
+      float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        f0 += va[u];
+        f1 += MODE == 0 ? va[u] * va[u] : va[u] * ((vx[u] - mu) * rs);
       }
+      s0 += f0;
+      s1 += f1;
     }
-    s0 += f0;
-    s1 += f1;
   }
   sm[0][w][lane] = s0;
   sm[1][w][lane] = s1;
@@ -55,13 +58,27 @@ __global__ __launch_bounds__(256) void k_bn_colsum(const float* __restrict__ a, 
   }
 }
 
+// stats[i] = sum_k partial[k][i]: 64 columns per block, the 4 waves each take every 4th split with 4 independent
+// accumulators, combined through LDS in a fixed order (deterministic)
 __global__ __launch_bounds__(256) void k_bn_reduce(const double* __restrict__ partial, double* __restrict__ stats,
                                                    int nsplit, int C2) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= C2) return;
-  double s = 0.0;
-  for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * C2 + i];
-  stats[i] = s;
+  __shared__ double sm[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (i < C2) {
+    int k = w;
+    for (; k + 12 < nsplit; k += 16) {
+      s0 += partial[(size_t)k * C2 + i];
+      s1 += partial[(size_t)(k + 4) * C2 + i];
+      s2 += partial[(size_t)(k + 8) * C2 + i];
+      s3 += partial[(size_t)(k + 12) * C2 + i];
+    }
+    for (; k < nsplit; k += 4) s0 += partial[(size_t)k * C2 + i];
+  }
+  sm[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && i < C2) stats[i] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
 }
 
 __global__ __launch_bounds__(256) void k_bn_finalize(const double* __restrict__ stats, double count,
@@ -129,7 +146,7 @@ __global__ __launch_bounds__(256) void k_bn_param_grads(const double* __restrict
 
 static int bn_colsum(int mode, const float* a, const float* x, const float* mean, const float* rstd, double* out,
                      size_t rows, int C, void* ws, hipStream_t s) {
-  int splits = (int)((rows + 255) / 256);
+  int splits = (int)((rows + 127) / 128);
   if (splits > kBnRowSplits) splits = kBnRowSplits;
   if (splits < 1) splits = 1;
   const size_t rps = (rows + splits - 1) / splits;
@@ -138,7 +155,7 @@ static int bn_colsum(int mode, const float* a, const float* x, const float* mean
     hipLaunchKernelGGL(k_bn_colsum<0>, grid, dim3(256), 0, s, a, x, mean, rstd, (double*)ws, rows, C, rps);
   else
     hipLaunchKernelGGL(k_bn_colsum<1>, grid, dim3(256), 0, s, a, x, mean, rstd, (double*)ws, rows, C, rps);
-  hipLaunchKernelGGL(k_bn_reduce, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, (const double*)ws, out, splits, 2 * C);
+  hipLaunchKernelGGL(k_bn_reduce, dim3(cdiv(2 * C, 64)), dim3(256), 0, s, (const double*)ws, out, splits, 2 * C);
   return check_launch("bn_colsum");
 }
 
@@ -183,7 +200,7 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ x,
   }
 }
 
-// dx[b][i] = sum_o dy[b][o] * w[o][i]   (thread per i, up to 8 batch rows per pass)
+// dx[b][i] = sum_o dy[b][o] * w[o][i]   (thread per i, up to 8 batch rows per pass; 8 weight rows in flight)
 __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dy, const float* __restrict__ w,
                                                    float* __restrict__ dx, int B, int In, int Out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -192,7 +209,21 @@ __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dy,
   float acc[LIN_BT];
 #pragma unroll
   for (int r = 0; r < LIN_BT; ++r) acc[r] = 0.f;
-  for (int o = 0; o < Out; ++o) {
+  constexpr int U = 8;
+  int o = 0;
+  for (; o + U <= Out; o += U) {
+    float wv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) wv[u] = w[(size_t)(o + u) * In + i];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int r = 0; r < LIN_BT; ++r) {
+        const float g = (b0 + r < B) ? dy[(size_t)(b0 + r) * Out + o + u] : 0.f;
+        acc[r] = fmaf(g, wv[u], acc[r]);
+      }
+  }
+  for (; o < Out; ++o) {
     const float wv = w[(size_t)o * In + i];
 #pragma unroll
     for (int r = 0; r < LIN_BT; ++r) {
@@ -205,16 +236,42 @@ __global__ __launch_bounds__(256) void k_linear_dx(const float* __restrict__ dy,
     if (b0 + r < B) dx[(size_t)(b0 + r) * In + i] = acc[r];
 }
 
-// dw[o][i] = beta*dw + sum_b dy[b][o]*x[b][i]
+// dw[o][i] = beta*dw + sum_b dy[b][o]*x[b][i]: a streaming write of Out*In floats; a thread owns 4 consecutive i
+// of one o (16-byte loads/stores when In % 4 == 0), batch loop unrolled by 4
 __global__ __launch_bounds__(256) void k_linear_dw(const float* __restrict__ dy, const float* __restrict__ x,
                                                    float* __restrict__ dw, int B, int In, int Out, float beta) {
-  const size_t total = (size_t)Out * In;
+  typedef float lf4 __attribute__((ext_vector_type(4)));
+  const int in4 = (In + 3) >> 2;
+  const size_t total = (size_t)Out * in4;
+  const bool vec = (In & 3) == 0;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const int i = (int)(e % In);
-    const int o = (int)(e / In);
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc = fmaf(dy[(size_t)b * Out + o], x[(size_t)b * In + i], acc);
-    dw[e] = beta != 0.f ? beta * dw[e] + acc : acc;
+    const int i = (int)(e % in4) * 4;
+    const int o = (int)(e / in4);
+    lf4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+      int b = 0;
+      for (; b + 4 <= B; b += 4) {
+        lf4 xv[4];
+        float g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          xv[u] = *reinterpret_cast<const lf4*>(x + (size_t)(b + u) * In + i);
+          g[u] = dy[(size_t)(b + u) * Out + o];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += g[u] * xv[u];
+      }
+      for (; b < B; ++b) acc += dy[(size_t)b * Out + o] * *reinterpret_cast<const lf4*>(x + (size_t)b * In + i);
+      lf4* dst = reinterpret_cast<lf4*>(dw + (size_t)o * In + i);
+      *dst = beta != 0.f ? beta * *dst + acc : acc;
+    } else {
+      for (int k = 0; k < 4 && i + k < In; ++k) {
+        float a1 = 0.f;
+        for (int b = 0; b < B; ++b) a1 = fmaf(dy[(size_t)b * Out + o], x[(size_t)b * In + i + k], a1);
+        float* dst = dw + (size_t)o * In + i + k;
+        *dst = beta != 0.f ? beta * *dst + a1 : a1;
+      }
+    }
   }
 }
 
@@ -306,8 +363,8 @@ extern "C" int srk_linear_backward(const float* x, const float* w, const float* 
   hipStream_t s = (hipStream_t)stream;
   if (dx) hipLaunchKernelGGL(k_linear_dx, dim3(cdiv(In, 256), cdiv(B, LIN_BT)), dim3(256), 0, s, dy, w, dx, B, In, Out);
   if (dw) {
-    size_t nb = ((size_t)Out * In + 256 * 4 - 1) / (256 * 4);
-    if (nb > 8192) nb = 8192;
+    size_t nb = ((size_t)Out * ((In + 3) / 4) + 255) / 256;
+    if (nb > 16384) nb = 16384;
     hipLaunchKernelGGL(k_linear_dw, dim3((unsigned)nb), dim3(256), 0, s, dy, x, dw, B, In, Out, beta);
   }
   if (db) hipLaunchKernelGGL(k_linear_db, dim3(cdiv(Out, 256)), dim3(256), 0, s, dy, db, B, Out, beta);

@@ -19,6 +19,7 @@
 // 2 MFMA row tiles instead of 9 mostly-empty ones.
 #include "srk_common.h"
 #include "conv_problem.h"
+#include <stdlib.h>
 
 namespace srk {
 
@@ -350,8 +351,11 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   const int ci = (e / Cout) % Cin;
   const int tap = e / (Cout * Cin);
   const int kh = tap / KW, kw = tap - kh * KW;
-  const size_t o = transposed ? ((((size_t)ci * Cout + co) * KH + kh) * KW + kw)
-                              : ((((size_t)co * Cin + ci) * KH + kh) * KW + kw);
+  // transposed == 2: role-swapped small-Cout problem (see swap_small_cout): ConvTranspose-style index with the
+  // taps mirrored
+  const size_t o = transposed == 2 ? ((((size_t)ci * Cout + co) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw))
+                   : transposed    ? ((((size_t)ci * Cout + co) * KH + kh) * KW + kw)
+                                   : ((((size_t)co * Cin + ci) * KH + kh) * KW + kw);
   dw[o] = beta != 0.f ? beta * dw[o] + v : v;
 }
 
@@ -434,12 +438,37 @@ static WgPlan plan(const srk_conv_desc& d) {
   return pl;
 }
 
+// Small Cout (the 64->3 output layers: EDSR / VDSR / SRCNN / LapSRN tails, SRGAN's 9x9 64->3), stride 1:
+//   dW[tap][ci][co] = sum_q x[q + tap - p][ci] dy[q][co] = sum_q' dy[q' + (K-1-tap) - (K-1-p)][co] x[q'][ci]
+// i.e. the weight gradient of a convolution with input dy (Cout channels), output-gradient x (Cin channels), padding
+// K-1-p and mirrored taps.  That problem has a tiny channel count on its *input* side, which is exactly what the
+// flattened (tap, ci) kernel k_wgrad_mfma_smallcin is built for (one pass over the pixels instead of one pass per
+// group of 9 taps with a single 16-wide channel tile 3/16 full).  The reduce kernel undoes the swap (mode 2).
+static bool swap_small_cout(const srk_conv_desc& d, srk_conv_desc& ds) {
+  if (d.transposed || d.stride != 1 || d.Cout > 4 || d.Cin < 8 || d.KH != d.KW) return false;
+  if (d.KH * d.KW * d.Cout > 256 || d.KH - 1 - d.pad < 0) return false;
+  ds = d;
+  ds.H = d.OH; ds.W = d.OW; ds.Cin = d.Cout;
+  ds.OH = d.H; ds.OW = d.W; ds.Cout = d.Cin;
+  ds.pad = d.KH - 1 - d.pad;
+  return true;
+}
+
 bool conv_wgrad_mfma_supported(const srk_conv_desc& d) { return plan(d).ok; }
 
 size_t conv_wgrad_mfma_ws(const srk_conv_desc& d) {
   WgPlan pl = plan(d);
   if (!pl.ok) return 0;
-  return (size_t)pl.G * d.KH * d.KW * d.Cin * d.Cout * sizeof(float) + conv_bias_grad_ws(d);
+  size_t need = (size_t)pl.G * d.KH * d.KW * d.Cin * d.Cout * sizeof(float) + conv_bias_grad_ws(d);
+  srk_conv_desc ds;
+  if (swap_small_cout(d, ds)) {
+    WgPlan ps = plan(ds);
+    if (ps.ok) {
+      const size_t n2 = (size_t)ps.G * d.KH * d.KW * d.Cin * d.Cout * sizeof(float) + conv_bias_grad_ws(d);
+      if (n2 > need) need = n2;
+    }
+  }
+  return need;
 }
 
 template <typename K>
@@ -465,7 +494,51 @@ static void launch_w2(const WgradParams& P, dim3 grid, size_t lds, hipStream_t s
 }
 
 int conv_wgrad_mfma(const srk_conv_desc& d, const float* x, const float* dy, const srk_bwd_mask* mask, float* dw,
+                    float* db, float beta, void* ws, size_t ws_bytes, hipStream_t s);
+
+// role-swapped launch for small Cout (no activation mask on these layers)
+static int conv_wgrad_small_cout(const srk_conv_desc& d, const srk_conv_desc& ds, const float* x, const float* dy,
+                                 float* dw, float* db, float beta, void* ws, size_t ws_bytes, hipStream_t s) {
+  WgPlan pl = plan(ds);
+  const size_t slab_bytes = (size_t)pl.G * d.KH * d.KW * d.Cin * d.Cout * sizeof(float);
+  const size_t need = slab_bytes + conv_bias_grad_ws(d);
+  if (!ws || ws_bytes < need) {
+    set_error("conv_wgrad_mfma: workspace %zu < %zu", ws_bytes, need);
+    return SRK_ERR_WORKSPACE;
+  }
+  WgradParams P{};
+  P.x = dy; P.dy = x; P.mask_y = nullptr; P.mask_slope = 0.f;
+  P.ws = (float*)ws;
+  P.bias_partial = nullptr;
+  P.N = ds.N; P.Cin = ds.Cin; P.Cout = ds.Cout;
+  P.XH = ds.H; P.XW = ds.W; P.YH = ds.OH; P.YW = ds.OW;
+  P.KH = ds.KH; P.KW = ds.KW; P.stride = 1; P.pad = ds.pad; P.transposed = 0;
+  P.AH = ds.OH; P.AW = ds.OW; P.BH = ds.H; P.BW = ds.W;
+  P.TH = pl.TH; P.TW = pl.TW; P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x; P.HH = pl.HH; P.HW = pl.HW;
+  P.ntiles = pl.ntiles; P.G = pl.G; P.PSX = pl.PSX; P.PSY = pl.PSY; P.xs_floats = pl.xs_floats;
+  P.vec_x = (ds.Cin % 4 == 0) && ((uintptr_t)dy % 16 == 0);
+  P.vec_y = (ds.Cout % 4 == 0) && ((uintptr_t)x % 16 == 0);
+  const int MT = (ds.KH * ds.KW * ds.Cin + 15) / 16;
+  dim3 grid(pl.G, 1, cdiv(ds.Cout, 64));
+  if (MT <= 2) launch_w2<2>(P, grid, pl.lds, s);
+  else if (MT <= 5) launch_w2<5>(P, grid, pl.lds, s);
+  else launch_w2<16>(P, grid, pl.lds, s);
+  int rc = check_launch("conv_wgrad_small_cout");
+  if (rc) return rc;
+  rc = conv_wgrad_reduce_launch((const float*)ws, dw, pl.G, ds.Cout, ds.Cin, ds.KH, ds.KW, 2, beta, s);
+  if (rc) return rc;
+  if (db) rc = conv_bias_grad(d, dy, nullptr, db, beta, reinterpret_cast<float*>(static_cast<char*>(ws) + slab_bytes), s);
+  return rc;
+}
+
+int conv_wgrad_mfma(const srk_conv_desc& d, const float* x, const float* dy, const srk_bwd_mask* mask, float* dw,
                     float* db, float beta, void* ws, size_t ws_bytes, hipStream_t s) {
+  {
+    srk_conv_desc ds;
+    const char* e = getenv("SRK_WGRAD_SWAP");  // 0 disables the role-swapped small-Cout path
+    if (!(e && atoi(e) == 0) && !(mask && mask->y) && swap_small_cout(d, ds) && plan(ds).ok && plan(ds).smallcin)
+      return conv_wgrad_small_cout(d, ds, x, dy, dw, db, beta, ws, ws_bytes, s);
+  }
   WgPlan pl = plan(d);
   if (!pl.ok) {
     set_error("conv_wgrad_mfma: shape not covered");
