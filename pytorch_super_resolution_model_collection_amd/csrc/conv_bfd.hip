@@ -42,6 +42,7 @@ struct BfdParams {
   int NB;            // output channels per block in the prepared layout
   int NPIXp;         // halo pixels rounded up to 16
   int dbg;
+  int allc;          // small problems: every channel chunk of the halo staged up front (one load latency, one barrier)
 };
 
 template <int NP>
@@ -286,15 +287,27 @@ __global__ __launch_bounds__(64 * NPW * NOW, 2) void k_conv_bfd(
         ++hcc;
       }
     }
+    const int cstride = NP * 4 * B.NPIXp;  // uint4 per staged chunk
     for (int cc = 0; cc < B.ICc; ++cc) {
-      if (cc) __syncthreads();  // previous chunk's halo fully consumed
-      if (!(B.dbg & 1)) {
-        if (P.mask_y)
-          bfd_stage_halo_t<true, NTHR, NP>(B, hal, n, r0, c0, cc * 32);
-        else
-          bfd_stage_halo_t<false, NTHR, NP>(B, hal, n, r0, c0, cc * 32);
+      if (!B.allc) {
+        if (cc) __syncthreads();  // previous chunk's halo fully consumed
+        if (!(B.dbg & 1)) {
+          if (P.mask_y)
+            bfd_stage_halo_t<true, NTHR, NP>(B, hal, n, r0, c0, cc * 32);
+          else
+            bfd_stage_halo_t<false, NTHR, NP>(B, hal, n, r0, c0, cc * 32);
+        }
+        __syncthreads();
+      } else if (cc == 0) {
+        for (int c2 = 0; c2 < B.ICc; ++c2) {
+          if (P.mask_y)
+            bfd_stage_halo_t<true, NTHR, NP>(B, hal + c2 * cstride, n, r0, c0, c2 * 32);
+          else
+            bfd_stage_halo_t<false, NTHR, NP>(B, hal + c2 * cstride, n, r0, c0, c2 * 32);
+        }
+        __syncthreads();
       }
-      __syncthreads();
+      const uint4* halc = B.allc ? hal + cc * cstride : hal;
       for (int t = 0; t < T; ++t) {
         uint4 nb[NP][NTW];
         load_b(hcc, ht, nb);
@@ -310,7 +323,7 @@ __global__ __launch_bounds__(64 * NPW * NOW, 2) void k_conv_bfd(
             const int u = t / P.KWv, v = t - u * P.KWv;
             toff = u * P.HW + v;
           }
-          const uint4* hb = hal + toff;
+          const uint4* hb = halc + toff;
           uint4 a[NP][4];
 #pragma unroll
           for (int p = 0; p < NP; ++p)
@@ -602,6 +615,11 @@ static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
   P.TH = best.TH; P.TW = best.TW; P.tiles_y = best.tiles_y; P.tiles_x = best.tiles_x; P.HH = best.HH; P.HW = best.HW;
   B.NPIXp = (best.HH * best.HW + 15) & ~15;
   size_t lds = (size_t)NP * 4 * B.NPIXp * 16;
+  B.allc = 0;
+  if (NPW == 1 && B.ICc > 1 && lds * B.ICc <= 64 * 1024) {  // small-problem blocks: stage all chunks at once
+    B.allc = 1;
+    lds *= B.ICc;
+  }
   const size_t epi_bytes = (size_t)NPW * 32 * BFD_EPI_STRIDE * sizeof(float);
   if (lds < epi_bytes) lds = epi_bytes;
   static int cur = 0;

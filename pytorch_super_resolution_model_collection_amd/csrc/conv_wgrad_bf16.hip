@@ -31,7 +31,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // conv_wgrad_mfma.hip
 int conv_wgrad_reduce_launch(const float* ws, float* dw, int G, int Cout, int Cin, int KH, int KW, int transposed,
-                             float beta, hipStream_t s);
+                             float beta, const float* bias_partial, float* db, int bias_cout, hipStream_t s);
 
 constexpr int WB_MAXOCT = 64;  // octets per tile (<= 512 pixels)
 
@@ -387,10 +387,8 @@ int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const
   }
   int rc = check_launch("conv_wgrad_bf");
   if (rc) return rc;
-  rc = conv_wgrad_reduce_launch((const float*)ws, dw, pl.G, d.Cout, d.Cin, d.KH, d.KW, 0, beta, s);
-  if (rc) return rc;
-  if (db) rc = conv_bias_grad_finish(bias_ws, pl.G, db, d.Cout, beta, s);
-  return rc;
+  return conv_wgrad_reduce_launch((const float*)ws, dw, pl.G, d.Cout, d.Cin, d.KH, d.KW, 0, beta, db ? bias_ws : nullptr,
+                                  db, d.Cout, s);
 }
 
 }  // namespace srk

@@ -324,13 +324,38 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_smallcin(WgradParams P) {
 // Deterministic slab reduction + layout change:  dw(torch layout) = beta*dw + sum_g ws[g][t][ci][co]
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw, int G,
-                                                      int Cout, int Cin, int KH, int KW, int transposed, float beta) {
+                                                      int Cout, int Cin, int KH, int KW, int transposed, float beta,
+                                                      const float* __restrict__ bias_partial, float* __restrict__ db,
+                                                      int bias_cout) {
   // 64 consecutive slab elements per block (coalesced 256-byte rows); the 4 waves each sum a quarter
   // of the G slabs with 4 independent accumulators (16 loads in flight per lane), combined through
-  // LDS in a fixed order => deterministic.
+  // LDS in a fixed order => deterministic.  The blocks past the last slab element finish the bias
+  // gradient the same way (bias_partial[G][bias_cout] -> db), saving a launch per layer.
   __shared__ float sm[4][64];
   const int elems = KH * KW * Cin * Cout;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nwb = (elems + 63) / 64;
+  if ((int)blockIdx.x >= nwb) {
+    const int co = ((int)blockIdx.x - nwb) * 64 + lane;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    if (co < bias_cout) {
+      int g = w;
+      for (; g + 12 < G; g += 16) {
+        t0 += bias_partial[(size_t)g * bias_cout + co];
+        t1 += bias_partial[(size_t)(g + 4) * bias_cout + co];
+        t2 += bias_partial[(size_t)(g + 8) * bias_cout + co];
+        t3 += bias_partial[(size_t)(g + 12) * bias_cout + co];
+      }
+      for (; g < G; g += 4) t0 += bias_partial[(size_t)g * bias_cout + co];
+    }
+    sm[w][lane] = (t0 + t1) + (t2 + t3);
+    __syncthreads();
+    if (w == 0 && co < bias_cout) {
+      const float t = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+      db[co] = beta != 0.f ? beta * db[co] + t : t;
+    }
+    return;
+  }
   const int e = blockIdx.x * 64 + lane;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (e < elems) {
@@ -359,11 +384,13 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   dw[o] = beta != 0.f ? beta * dw[o] + v : v;
 }
 
+// bias_partial / db may be NULL (no bias, or the bias gradient is produced elsewhere); bias_cout = channels of db
 int conv_wgrad_reduce_launch(const float* ws, float* dw, int G, int Cout, int Cin, int KH, int KW, int transposed,
-                             float beta, hipStream_t s) {
+                             float beta, const float* bias_partial, float* db, int bias_cout, hipStream_t s) {
   const int elems = KH * KW * Cin * Cout;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(elems, 64)), dim3(256), 0, s, ws, dw, G, Cout, Cin, KH, KW, transposed,
-                     beta);
+  const int bias_blocks = (bias_partial && db) ? cdiv(bias_cout, 64) : 0;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(elems, 64) + bias_blocks), dim3(256), 0, s, ws, dw, G, Cout, Cin, KH, KW,
+                     transposed, beta, bias_partial, db, bias_cout);
   return check_launch("conv_wgrad_reduce");
 }
 
@@ -525,7 +552,7 @@ static int conv_wgrad_small_cout(const srk_conv_desc& d, const srk_conv_desc& ds
   else launch_w2<16>(P, grid, pl.lds, s);
   int rc = check_launch("conv_wgrad_small_cout");
   if (rc) return rc;
-  rc = conv_wgrad_reduce_launch((const float*)ws, dw, pl.G, ds.Cout, ds.Cin, ds.KH, ds.KW, 2, beta, s);
+  rc = conv_wgrad_reduce_launch((const float*)ws, dw, pl.G, ds.Cout, ds.Cin, ds.KH, ds.KW, 2, beta, nullptr, nullptr, 0, s);
   if (rc) return rc;
   if (db) rc = conv_bias_grad(d, dy, nullptr, db, beta, reinterpret_cast<float*>(static_cast<char*>(ws) + slab_bytes), s);
   return rc;
@@ -591,14 +618,11 @@ int conv_wgrad_mfma(const srk_conv_desc& d, const float* x, const float* dy, con
   }
   int rc = check_launch("conv_wgrad_mfma");
   if (rc) return rc;
-  rc = conv_wgrad_reduce_launch((const float*)ws, dw, pl.G, d.Cout, d.Cin, d.KH, d.KW, d.transposed, beta, s);
+  const bool fused_bias = db && P.bias_partial;
+  rc = conv_wgrad_reduce_launch((const float*)ws, dw, pl.G, d.Cout, d.Cin, d.KH, d.KW, d.transposed, beta,
+                                fused_bias ? bias_ws : nullptr, fused_bias ? db : nullptr, d.Cout, s);
   if (rc) return rc;
-  if (db) {
-    if (P.bias_partial)
-      rc = conv_bias_grad_finish(bias_ws, pl.G, db, d.Cout, beta, s);
-    else
-      rc = conv_bias_grad(d, dy, mask, db, beta, bias_ws, s);
-  }
+  if (db && !fused_bias) rc = conv_bias_grad(d, dy, mask, db, beta, bias_ws, s);
   return rc;
 }
 

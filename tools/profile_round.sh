@@ -16,6 +16,8 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2_kt -o c2 -- $C2 > $OUT/c2_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/c2_fetch -o c2 -- $C2 > $OUT/c2_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/c2_write -o c2 -- $C2 > $OUT/c2_write.log 2>&1
+# matrix-core and LDS activity of the same command (SQ counters share a pass: 8 SQ slots)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/c2_sq -o c2 -- $C2 > $OUT/c2_sq.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_kt -o c4 -- $C4 > $OUT/c4_kt.log 2>&1
 cd $ROOT
 python tools/summarize_prof.py $TAG > $OUT/summary.log 2>&1

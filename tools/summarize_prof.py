@@ -55,6 +55,26 @@ for k in sorted(set(fetch) | set(write)):
     out["kernels"][k] = {"launches": max(nf, nw), "fetch_KiB_raw": round(fk, 1), "write_KiB_raw": round(wk, 1),
                          "hbm_read_bytes": int(fk * 1024 * 2), "hbm_write_bytes": int(wk * 1024),
                          "hbm_bytes": int(fk * 1024 * 2 + wk * 1024)}
+# matrix-core / LDS activity (one SQ pass): per-kernel means per launch
+sq_names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_WAVE_CYCLES",
+            "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS", "GRBM_GUI_ACTIVE"]
+sq = {n: counter_means("c2_sq", n) for n in sq_names}
+sq_out = {"source": "rocprofv3 --pmc " + " ".join(sq_names) + " over the c2 bench command (own pass, no traces)",
+          "note": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 "
+                  "(the counter is summed over the 8 XCDs); SQ_VALU_MFMA_BUSY_CYCLES = 16 cycles per "
+                  "v_mfma_f32_16x16x32_bf16 summed over all SIMDs (checked against the instruction count of the layer)",
+          "kernels": {}}
+for k in sorted(set().union(*[set(v) for v in sq.values()])):
+    if "srk::k_conv" not in k:
+        continue
+    rec = {n: round(sq[n].get(k, (0.0, 0))[0], 1) for n in sq_names}
+    if rec["GRBM_GUI_ACTIVE"] > 0:
+        rec["mfma_util"] = round(rec["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * rec["GRBM_GUI_ACTIVE"] / 8.0), 4)
+    sq_out["kernels"][k] = rec
+if sq_out["kernels"]:
+    with open(os.path.join(dst, "%s_c2_pmc_mfma.json" % tag), "w") as fh:
+        json.dump(sq_out, fh, indent=1)
+    print(json.dumps(sq_out, indent=1))
 with open(os.path.join(dst, "%s_c2_pmc_traffic.json" % tag), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps(out, indent=1))
