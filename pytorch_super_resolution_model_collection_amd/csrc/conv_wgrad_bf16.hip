@@ -304,22 +304,33 @@ static WbPlan wb_plan(const srk_conv_desc& d) {
   } else {
     pl.cfg = 2; pl.CIB = 64; pl.COB = 16;
   }
-  pl.TWo = (d.OW + 7) / 8;
-  if (pl.TWo > 4) pl.TWo = 4;
-  pl.TW = pl.TWo * 8;
-  pl.tiles_x = cdiv(d.OW, pl.TW);
-  int TH = 128 / pl.TW;
-  if (TH > d.OH) TH = d.OH;
-  for (; TH >= 1; --TH) {
-    const int HH = TH + d.KH - 1, HWp = pl.TW + 8;
-    const int CS = round_8odd(HH * HWp), DS = round_8odd(TH * pl.TW + 8);
-    const size_t lds = ((size_t)2 * pl.CIB * CS + (size_t)2 * pl.COB * DS) * 2;
-    if (lds <= (size_t)kWbLdsBudget && TH * pl.TWo <= WB_MAXOCT) {
-      pl.TH = TH; pl.HH = HH; pl.HWp = HWp; pl.CS = CS; pl.DS = DS; pl.lds = lds;
-      break;
+  // tile = TH rows x TWo octets (8 pixels each).  Search the shapes that fit LDS for the one with the most useful
+  // pixels per padded K step (e.g. 41-wide VDSR patches: 2 x 48 -> 83 % instead of 4 x 32 -> 60 %); ties -> taller
+  // tiles (less halo per pixel).
+  double best_eff = -1.0;
+  for (int TWo = 1; TWo <= 6 && (TWo - 1) * 8 < d.OW; ++TWo) {
+    const int TW = TWo * 8;
+    int TH = 16 / TWo;  // <= 128 pixels per tile
+    if (TH > d.OH) TH = d.OH;
+    for (; TH >= 1; --TH) {
+      const int HH = TH + d.KH - 1, HWp = TW + 8;
+      const int CS = round_8odd(HH * HWp), DS = round_8odd(TH * TW + 8);
+      const size_t lds = ((size_t)2 * pl.CIB * CS + (size_t)2 * pl.COB * DS) * 2;
+      if (lds > (size_t)kWbLdsBudget || TH * TWo > WB_MAXOCT) continue;
+      const int nks = cdiv(TH * TWo, 4);
+      const double tiles = (double)cdiv(d.OH, TH) * cdiv(d.OW, TW);
+      // cost per tile: nks K steps + staging of the halo / tile (about one K step per 64 halo pixels)
+      const double cost = tiles * (nks + (double)(HH * HWp + TH * TW) / 128.0);
+      const double eff = (double)d.OH * d.OW / cost;
+      if (eff > best_eff * 1.02 || (eff > best_eff * 0.98 && eff > 0 && TH > pl.TH)) {
+        if (eff > best_eff) best_eff = eff;
+        pl.TWo = TWo; pl.TW = TW; pl.TH = TH; pl.HH = HH; pl.HWp = HWp; pl.CS = CS; pl.DS = DS; pl.lds = lds;
+      }
+      break;  // smaller TH only gets worse for this width
     }
   }
-  if (TH < 1) return pl;
+  if (best_eff < 0) return pl;
+  pl.tiles_x = cdiv(d.OW, pl.TW);
   pl.tiles_y = cdiv(d.OH, pl.TH);
   pl.nks = cdiv(pl.TH * pl.TWo, 4);
   const long nt = (long)d.N * pl.tiles_y * pl.tiles_x;
@@ -380,6 +391,16 @@ int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const
   P.vec_x = (d.Cin % 4 == 0) && ((uintptr_t)x % 16 == 0);
   P.vec_y = (d.Cout % 4 == 0) && ((uintptr_t)dy % 16 == 0) && (!P.mask_y || (uintptr_t)P.mask_y % 16 == 0);
   dim3 grid(pl.G, pl.gy, pl.gz);
+  {
+    static int dbg = -1;
+    if (dbg < 0) {
+      const char* e = getenv("SRK_DBG");
+      dbg = e ? atoi(e) : 0;
+    }
+    if (dbg & 32)
+      fprintf(stderr, "[srk] k_wgrad_bf cfg %d: tile %d x %d (%d K steps), %d tiles over %d x %d x %d blocks, lds %zu B\n",
+              pl.cfg, pl.TH, pl.TW, pl.nks, pl.ntiles, pl.G, pl.gy, pl.gz, pl.lds);
+  }
   switch (pl.cfg) {
     case 0: wb_launch<2, 2, 2>(P, grid, pl.lds, s); break;
     case 1: wb_launch<4, 1, 2>(P, grid, pl.lds, s); break;
