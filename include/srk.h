@@ -246,6 +246,15 @@ int srk_linear_forward(const float* x, const float* w, const float* b, float* y,
 int srk_linear_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B,
                         int In, int Out, float beta, void* stream);
 
+/* ---- utils.img_interp (utils.py:242-269): ToPILImage -> Image.resize -> ToTensor, bit-exact ---------------------
+ * x, y: dense NCHW fp32 (the reference's FloatTensor layout); values are quantised to uint8 by truncation of x*255
+ * (saturating outside [0,1]), resampled with Pillow's 8-bit two-pass algorithm and returned as uint8/255.
+ * SRCNN / VDSR / LapSRN call it every iteration (srcnn.py:119, vdsr.py:137, lapsrn.py:183). */
+typedef enum srk_interp { SRK_INTERP_NEAREST = 0, SRK_INTERP_BILINEAR = 2, SRK_INTERP_BICUBIC = 3 } srk_interp; /* PIL codes */
+size_t srk_img_interp_workspace_bytes(int N, int C, int H, int W, int OH, int OW, int filter);
+int srk_img_interp(const float* x_nchw, float* y_nchw, int N, int C, int H, int W, int OH, int OW, int filter,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

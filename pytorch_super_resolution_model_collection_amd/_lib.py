@@ -90,6 +90,8 @@ _PROTOTYPES = {
     "srk_scale_dev": (c_int, [c_f, c_f, c_f, c_size, c_vp]),
     "srk_linear_forward": (c_int, [c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int, c_float, c_vp]),
     "srk_linear_backward": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_float, c_vp]),
+    "srk_img_interp_workspace_bytes": (ctypes.c_size_t, [c_int] * 7),
+    "srk_img_interp": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, ctypes.c_size_t, c_vp]),
 }
 
 _lib = None

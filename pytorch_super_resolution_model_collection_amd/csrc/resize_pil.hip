@@ -1,0 +1,212 @@
+// utils.img_interp (utils.py:242-269) on the GPU, bit-exact with the reference's CPU path.
+//
+// The reference resizes every image of a batch in a Python loop through
+//     ToPILImage()            float [0,1] -> uint8 by  pic.mul(255).byte()        (truncation)
+//     Image.resize(BICUBIC)   Pillow's two-pass separable resampler on 8-bit pixels
+//     ToTensor()              uint8 -> float by  /255
+// and SRCNN / VDSR / LapSRN call it on every iteration (srcnn.py:119, vdsr.py:137, lapsrn.py:183).
+// Pillow's resampler (src/libImaging/Resample.c; the algorithm is unchanged since Pillow 4 and is the
+// one in the Pillow 12.2 of this image) is integer arithmetic on uint8 data:
+//   * per output coordinate xx: center = (xx + 0.5) * scale, support = filter_support * max(scale, 1),
+//     xmin = (int)(center - support + 0.5) clamped to 0, xmax = (int)(center + support + 0.5) clamped to
+//     the input size; weights w = filter((x + xmin - center + 0.5) / max(scale, 1)) in double,
+//     normalised by their sum, then quantised to 22-bit fixed point with round-half-away;
+//   * a pass accumulates  ss = 2^21 + sum pixel * k  in int32 and stores clip8(ss >> 22);
+//   * horizontal pass first (uint8 intermediate), then vertical.
+// The coefficient tables are produced on the device by k_resize_tables in IEEE double with
+// contraction off — the same operations in the same order as the C source — so they are identical
+// to Pillow's; everything after that is integer.  Result: bit-equal to the reference (tested against
+// Pillow itself).  Filters: bicubic (a = -0.5), bilinear; nearest uses Pillow's affine/nearest rule.
+#include "srk_common.h"
+#include <math.h>
+
+namespace srk {
+
+constexpr int kPrecisionBits = 32 - 8 - 2;
+
+__device__ __forceinline__ double pil_filter(int filter, double x) {
+#pragma clang fp contract(off)
+  if (x < 0.0) x = -x;
+  if (filter == SRK_INTERP_BILINEAR) return x < 1.0 ? 1.0 - x : 0.0;
+  const double a = -0.5;
+  if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+  if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+  return 0.0;
+}
+
+// precompute_coeffs + normalize_coeffs_8bpc of Resample.c for one axis; one thread per output index
+__global__ void k_resize_tables(int inSize, int outSize, int filter, int ksize, int* __restrict__ kk,
+                                int* __restrict__ bounds) {
+#pragma clang fp contract(off)
+  const int xx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (xx >= outSize) return;
+  const double fsupport = filter == SRK_INTERP_BILINEAR ? 1.0 : 2.0;
+  const double scale = (double)((float)inSize - 0.0f) / outSize;
+  double filterscale = scale;
+  if (filterscale < 1.0) filterscale = 1.0;
+  const double support = fsupport * filterscale;
+  const double center = 0.0 + (xx + 0.5) * scale;
+  const double ss = 1.0 / filterscale;
+  int xmin = (int)(center - support + 0.5);
+  if (xmin < 0) xmin = 0;
+  int xmax = (int)(center + support + 0.5);
+  if (xmax > inSize) xmax = inSize;
+  xmax -= xmin;
+  double ww = 0.0;
+  for (int x = 0; x < xmax; ++x) ww += pil_filter(filter, (x + xmin - center + 0.5) * ss);
+  int* k = kk + (size_t)xx * ksize;
+  for (int x = 0; x < ksize; ++x) {
+    double w = 0.0;
+    if (x < xmax) {
+      w = pil_filter(filter, (x + xmin - center + 0.5) * ss);
+      if (ww != 0.0) w /= ww;
+    }
+    k[x] = w < 0 ? (int)(-0.5 + w * (1 << kPrecisionBits)) : (int)(0.5 + w * (1 << kPrecisionBits));
+  }
+  bounds[2 * xx] = xmin;
+  bounds[2 * xx + 1] = xmax;
+}
+
+__device__ __forceinline__ unsigned char to_u8(float v) {  // pic.mul(255).byte(): fp32 multiply, truncation
+  const float s = v * 255.f;
+  return (unsigned char)(s <= 0.f ? 0 : (s >= 255.f ? 255 : (int)s));
+}
+
+__device__ __forceinline__ unsigned char clip8(int ss) {
+  const int v = ss >> kPrecisionBits;  // arithmetic shift, as Pillow's lookup index
+  return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+// horizontal pass: float NCHW rows -> uint8 rows of the output width
+__global__ __launch_bounds__(256) void k_resize_h(const float* __restrict__ x, unsigned char* __restrict__ tmp,
+                                                  size_t rows, int W, int OW, int ksize, const int* __restrict__ kk,
+                                                  const int* __restrict__ bounds) {
+  const size_t total = rows * (size_t)OW;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t row = e / OW;
+    const int ox = (int)(e - row * OW);
+    const int xmin = bounds[2 * ox], xmax = bounds[2 * ox + 1];
+    const int* k = kk + (size_t)ox * ksize;
+    const float* src = x + row * W + xmin;
+    int ss = 1 << (kPrecisionBits - 1);
+    for (int t = 0; t < xmax; ++t) ss += (int)to_u8(src[t]) * k[t];
+    tmp[e] = clip8(ss);
+  }
+}
+
+// vertical pass: uint8 [planes][H][OW] -> float [planes][OH][OW] (ToTensor: /255)
+__global__ __launch_bounds__(256) void k_resize_v(const unsigned char* __restrict__ tmp, float* __restrict__ y,
+                                                  size_t planes, int H, int OH, int OW, int ksize,
+                                                  const int* __restrict__ kk, const int* __restrict__ bounds) {
+  const size_t total = planes * (size_t)OH * OW;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int ox = (int)(e % OW);
+    const size_t r = e / OW;
+    const int oy = (int)(r % OH);
+    const size_t pl = r / OH;
+    const int ymin = bounds[2 * oy], ymax = bounds[2 * oy + 1];
+    const int* k = kk + (size_t)oy * ksize;
+    const unsigned char* src = tmp + (pl * H + ymin) * (size_t)OW + ox;
+    int ss = 1 << (kPrecisionBits - 1);
+    for (int t = 0; t < ymax; ++t) ss += (int)src[(size_t)t * OW] * k[t];
+    y[e] = (float)clip8(ss) / 255.f;
+  }
+}
+
+// Image.NEAREST: Pillow's ImagingScaleAffine — xo = scale * 0.5, then xo += scale per output column (a running
+// double sum, reproduced sequentially so that inexact scales round identically), xin = (int)xo.
+__global__ void k_nearest_tables(int W, int OW, int H, int OH, int* __restrict__ xtab, int* __restrict__ ytab) {
+#pragma clang fp contract(off)
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const double ax = (double)((float)W - 0.0f) / OW, ay = (double)((float)H - 0.0f) / OH;
+  double xo = 0.0 + ax * 0.5;
+  for (int x = 0; x < OW; ++x) {
+    int xin = xo < 0.0 ? -1 : (int)xo;
+    if (xin > W - 1) xin = W - 1;
+    xtab[x] = xin < 0 ? 0 : xin;
+    xo += ax;
+  }
+  double yo = 0.0 + ay * 0.5;
+  for (int y = 0; y < OH; ++y) {
+    int yin = yo < 0.0 ? -1 : (int)yo;
+    if (yin > H - 1) yin = H - 1;
+    ytab[y] = yin < 0 ? 0 : yin;
+    yo += ay;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_resize_nearest(const float* __restrict__ x, float* __restrict__ y,
+                                                        size_t planes, int H, int W, int OH, int OW,
+                                                        const int* __restrict__ xtab, const int* __restrict__ ytab) {
+  const size_t total = planes * (size_t)OH * OW;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int ox = (int)(e % OW);
+    const size_t r = e / OW;
+    const int oy = (int)(r % OH);
+    const size_t pl = r / OH;
+    y[e] = (float)to_u8(x[(pl * H + ytab[oy]) * (size_t)W + xtab[ox]]) / 255.f;
+  }
+}
+
+static int resize_ksize(int inSize, int outSize, int filter) {
+  const double fsupport = filter == SRK_INTERP_BILINEAR ? 1.0 : 2.0;
+  double filterscale = (double)((float)inSize) / outSize;
+  if (filterscale < 1.0) filterscale = 1.0;
+  return (int)ceil(fsupport * filterscale) * 2 + 1;
+}
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace srk
+
+using namespace srk;
+
+extern "C" size_t srk_img_interp_workspace_bytes(int N, int C, int H, int W, int OH, int OW, int filter) {
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return 0;
+  if (filter == SRK_INTERP_NEAREST) return align256((size_t)OW * 4) + align256((size_t)OH * 4);
+  const size_t kh = (size_t)resize_ksize(W, OW, filter), kv = (size_t)resize_ksize(H, OH, filter);
+  return align256((size_t)N * C * H * OW) + align256((size_t)OW * kh * 4) + align256((size_t)OW * 8) +
+         align256((size_t)OH * kv * 4) + align256((size_t)OH * 8);
+}
+
+extern "C" int srk_img_interp(const float* x_nchw, float* y_nchw, int N, int C, int H, int W, int OH, int OW, int filter,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  SRK_REQUIRE(x_nchw && y_nchw, "img_interp: null tensor pointer");
+  SRK_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "img_interp: non-positive dims");
+  SRK_REQUIRE(filter == SRK_INTERP_NEAREST || filter == SRK_INTERP_BILINEAR || filter == SRK_INTERP_BICUBIC,
+              "img_interp: unknown filter %d", filter);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t planes = (size_t)N * C;
+  const size_t need = srk_img_interp_workspace_bytes(N, C, H, W, OH, OW, filter);
+  SRK_REQUIRE(workspace && workspace_bytes >= need, "img_interp: workspace %zu < %zu", workspace_bytes, need);
+  if (filter == SRK_INTERP_NEAREST) {
+    int* xtab = static_cast<int*>(workspace);
+    int* ytab = reinterpret_cast<int*>(static_cast<char*>(workspace) + align256((size_t)OW * 4));
+    hipLaunchKernelGGL(k_nearest_tables, dim3(1), dim3(1), 0, s, W, OW, H, OH, xtab, ytab);
+    size_t nb = (planes * OH * OW + 255) / 256;
+    if (nb > 65535) nb = 65535;
+    hipLaunchKernelGGL(k_resize_nearest, dim3((unsigned)nb), dim3(256), 0, s, x_nchw, y_nchw, planes, H, W, OH, OW, xtab,
+                       ytab);
+    return check_launch("img_interp(nearest)");
+  }
+  const int kh = resize_ksize(W, OW, filter), kv = resize_ksize(H, OH, filter);
+  char* p = static_cast<char*>(workspace);
+  unsigned char* tmp = reinterpret_cast<unsigned char*>(p);
+  p += align256(planes * H * OW);
+  int* kkh = reinterpret_cast<int*>(p);
+  p += align256((size_t)OW * kh * 4);
+  int* bh = reinterpret_cast<int*>(p);
+  p += align256((size_t)OW * 8);
+  int* kkv = reinterpret_cast<int*>(p);
+  p += align256((size_t)OH * kv * 4);
+  int* bv = reinterpret_cast<int*>(p);
+  hipLaunchKernelGGL(k_resize_tables, dim3(cdiv(OW, 128)), dim3(128), 0, s, W, OW, filter, kh, kkh, bh);
+  hipLaunchKernelGGL(k_resize_tables, dim3(cdiv(OH, 128)), dim3(128), 0, s, H, OH, filter, kv, kkv, bv);
+  size_t nb = (planes * H * OW + 255) / 256;
+  if (nb > 65535) nb = 65535;
+  hipLaunchKernelGGL(k_resize_h, dim3((unsigned)nb), dim3(256), 0, s, x_nchw, tmp, planes * H, W, OW, kh, kkh, bh);
+  nb = (planes * OH * OW + 255) / 256;
+  if (nb > 65535) nb = 65535;
+  hipLaunchKernelGGL(k_resize_v, dim3((unsigned)nb), dim3(256), 0, s, tmp, y_nchw, planes, H, OH, OW, kv, kkv, bv);
+  return check_launch("img_interp");
+}

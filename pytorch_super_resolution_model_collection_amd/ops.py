@@ -648,3 +648,32 @@ class _Linear(torch.autograd.Function):
 def linear(x, weight, bias=None, act=ACT_NONE, slope=0.0):
     """nn.Linear + activation of DenseBlock (base_networks.py:7,26-35). PReLU is applied unfused."""
     return _Linear.apply(x, weight, bias, int(act), float(slope))
+
+
+_INTERP = {"nearest": 0, "bilinear": 2, "bicubic": 3}
+
+
+def img_interp(imgs, scale_factor, interpolation="bicubic"):
+    """utils.img_interp (utils.py:242-269) on the GPU: uint8 quantisation, Pillow's two-pass 8-bit resampling and
+    the /255 of ToTensor in three small kernels, bit-exact with the reference's PIL round trip.  `imgs` is a
+    [B,C,H,W] or [C,H,W] CUDA tensor; returns a dense NCHW tensor of size int(H*s) x int(W*s) like the reference."""
+    require_cuda(imgs)
+    if interpolation not in _INTERP:
+        raise ValueError("interpolation must be one of %s" % sorted(_INTERP))
+    squeeze = imgs.dim() == 3
+    x = imgs.unsqueeze(0) if squeeze else imgs
+    if x.dim() != 4:
+        raise RuntimeError("img_interp expects a [B,C,H,W] or [C,H,W] tensor, got shape %s" % (tuple(imgs.shape),))
+    x = x.detach().float().contiguous()
+    n, c, h, w = x.shape
+    oh, ow = int(h * scale_factor), int(w * scale_factor)
+    if oh <= 0 or ow <= 0:
+        raise RuntimeError("img_interp: empty output for scale %r" % (scale_factor,))
+    lib = _lib.load()
+    flt = _INTERP[interpolation]
+    y = torch.empty((n, c, oh, ow), dtype=torch.float32, device=x.device)
+    nbytes = int(lib.srk_img_interp_workspace_bytes(n, c, h, w, oh, ow, flt))
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=x.device)
+    check(lib.srk_img_interp(ptr(x), ptr(y), n, c, h, w, oh, ow, flt, ptr(ws), ws.numel(), stream_ptr()), "srk_img_interp")
+    return y[0] if squeeze else y
+

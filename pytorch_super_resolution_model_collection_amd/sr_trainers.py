@@ -23,21 +23,16 @@ def synthetic_loader(kind, args, steps, device, seed=1234):
     """Seeded random (input, target...) batches with the shapes each reference train loop feeds."""
     g = torch.Generator().manual_seed(seed)
     b, c, r = args.batch_size, args.num_channels, args.scale_factor
-    hr = args.crop_size
-    lr = hr // r
+    lr = args.crop_size // r
+    hr = lr * r  # the reference crops HR patches to a multiple of the scale (dataset.py calculate_valid_crop_size)
     for _ in range(steps):
-        if kind in ("srcnn",):          # bicubic-upsampled input, valid-conv target (srcnn.py:116-125)
-            yield torch.rand(b, c, hr, hr, generator=g).to(device), torch.rand(b, c, hr - 16, hr - 16, generator=g).to(device)
-        elif kind == "vdsr":            # vdsr.py:133-142
-            yield torch.rand(b, c, hr, hr, generator=g).to(device), torch.rand(b, c, hr, hr, generator=g).to(device)
-        elif kind == "fsrcnn":          # output r(H-5)+4 = target shaved by 2r (fsrcnn.py:143-150)
+        # every reference dataset yields (LR input, HR target) image batches in [0,1] (dataset.py:51-99); the
+        # per-model pre-steps (bicubic up/down-sampling, shaving) run on the device in _Trainer.prepare
+        if kind == "fsrcnn":            # output r(H-5)+4 = target shaved by 2r (fsrcnn.py:143-150)
             yield torch.rand(b, c, lr, lr, generator=g).to(device), torch.rand(b, c, r * (lr - 5) + 4, r * (lr - 5) + 4, generator=g).to(device)
         elif kind == "espcn":           # net output r(H-8) (the reference's own target is inconsistent, App. B-2)
             yield torch.rand(b, c, lr, lr, generator=g).to(device), torch.rand(b, c, r * (lr - 8), r * (lr - 8), generator=g).to(device)
-        elif kind == "lapsrn":          # lapsrn.py:179-188
-            yield (torch.rand(b, c, lr, lr, generator=g).to(device), torch.rand(b, c, 2 * lr, 2 * lr, generator=g).to(device),
-                   torch.rand(b, c, 4 * lr, 4 * lr, generator=g).to(device))
-        else:                           # edsr / srgan: (lr, hr)
+        else:                           # srcnn / vdsr / lapsrn / edsr / srgan: (lr, hr)
             yield torch.rand(b, c, lr, lr, generator=g).to(device), torch.rand(b, c, hr, hr, generator=g).to(device)
 
 
@@ -66,6 +61,20 @@ class _Trainer(object):
     def lr_decay(self, epoch, opt):
         pass
 
+    def prepare(self, inp, target):
+        """(input, target) of the data loader -> the tensors the train step consumes, on the device:
+          SRCNN   y = img_interp(input, r) (bicubic), x = shave(target, 8)               (srcnn.py:116-125)
+          VDSR    y = img_interp(input, r), x = target                                    (vdsr.py:133-142)
+          LapSRN  y = input, x_coarse = img_interp(target, 1/r*2), x_finer = target       (lapsrn.py:179-188)
+        utils.img_interp is the bit-exact GPU form of the reference's per-image PIL loop."""
+        if self.kind == "srcnn":
+            return utils.img_interp(inp, self.scale_factor), utils.shave(target, 8).contiguous()
+        if self.kind == "vdsr":
+            return utils.img_interp(inp, self.scale_factor), target
+        if self.kind == "lapsrn":
+            return inp, utils.img_interp(target, 1 / self.scale_factor * 2), target
+        return inp, target
+
     # -- reference surface ------------------------------------------------------------------------
     def train(self, loader=None, log_every=0):
         self.model = self.build_model()
@@ -81,7 +90,8 @@ class _Trainer(object):
                                                                          self.device, 1234 + epoch * self.world + self.rank)
             total, n = torch.zeros((), device=self.device), 0
             for batch in batches:
-                out = step(*[t.to(self.device, non_blocking=True) for t in batch][:3 if self.kind == "lapsrn" else 2])
+                inp, target = [t.to(self.device, non_blocking=True) for t in batch][:2]
+                out = step(*self.prepare(inp, target))
                 loss = sum(out) if isinstance(out, tuple) else out
                 total += loss.detach()   # device-side accumulation: no host sync inside the loop
                 n += 1
@@ -93,6 +103,10 @@ class _Trainer(object):
         if self.rank == 0:
             self.save_model(epoch=None)
         return avg_loss
+
+    def _net_input(self, x):
+        """SRCNN / VDSR feed the bicubic-upsampled image to the net (srcnn.py:145, vdsr.py:160)."""
+        return utils.img_interp(x, self.scale_factor) if self.kind in ("srcnn", "vdsr") else x
 
     def _infer(self, x):
         self.model.eval()
@@ -107,9 +121,11 @@ class _Trainer(object):
         psnrs = []
         batches = loader if loader is not None else synthetic_loader(self.kind, self.args, 2, self.device, 4321)
         for batch in batches:
-            out = self._infer(batch[0])
+            out = self._infer(self._net_input(batch[0].to(self.device)))
             out = out[-1] if isinstance(out, tuple) else out
-            tgt = batch[-1]
+            tgt = batch[-1].to(self.device)
+            if self.kind == "srcnn":     # srcnn.py:193-199: border pixels excluded
+                tgt = utils.shave(tgt, 8)
             if out.shape == tgt.shape:
                 psnrs.append(utils.PSNR(out, tgt))
         return psnrs
@@ -120,7 +136,7 @@ class _Trainer(object):
             self.model = self.build_model().to(self.device)
             self.load_model()
         x = img if img.dim() == 4 else img.unsqueeze(0)
-        out = self._infer(x)
+        out = self._infer(self._net_input(x.to(self.device)))
         return (out[-1] if isinstance(out, tuple) else out).cpu()
 
     def _ckpt_name(self, epoch):

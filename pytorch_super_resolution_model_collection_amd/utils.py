@@ -70,6 +70,13 @@ def denorm(img, vgg=False):
     return ((img + 1) / 2).clamp(0, 1)
 
 
+def img_interp(imgs, scale_factor, interpolation='bicubic'):
+    """utils.py:242-269 — the per-image PIL round trip (ToPILImage -> resize -> ToTensor) as GPU kernels,
+    bit-exact with it (ops.img_interp)."""
+    from . import ops
+    return ops.img_interp(imgs, scale_factor, interpolation)
+
+
 def print_network(net):
     """utils.py:14-20"""
     num_params = sum(p.numel() for p in net.parameters())

@@ -1,0 +1,84 @@
+"""utils.img_interp: the oracle (Pillow driven as the reference drives it) against the committed vectors on the
+CPU; the HIP kernels bit-exact against both on the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fill, img_interp as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+import importlib.util  # noqa: E402
+_spec = importlib.util.spec_from_file_location("make_golden_interp", os.path.join(HERE, "golden", "make_golden_interp.py"))
+_mg = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_mg)
+CASES = _mg.CASES
+
+
+@pytest.fixture(scope="module")
+def interp_golden():
+    return np.load(os.path.join(HERE, "golden", "img_interp.npz"))
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_oracle_matches_golden(interp_golden, case):
+    tag, shape, scale, interp, seed = case
+    y = O.img_interp(fill.rand(shape, seed), scale, interp)
+    assert np.array_equal(np.rint(y.numpy() * 255.0).astype(np.uint8), interp_golden[tag])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_hip_img_interp_bit_exact(gpu, interp_golden, case):
+    import pytorch_super_resolution_model_collection_amd as pkg
+    tag, shape, scale, interp, seed = case
+    x = fill.rand(shape, seed)
+    y = pkg.utils.img_interp(x.to(gpu), scale, interp)
+    ref = torch.from_numpy(interp_golden[tag].astype(np.float32)) / 255.0
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert torch.equal(y.cpu(), ref), "max diff %g" % float((y.cpu() - ref).abs().max())
+    # 3-D form (utils.py:262-269)
+    y3 = pkg.utils.img_interp(x[0].to(gpu), scale, interp)
+    assert torch.equal(y3.cpu(), ref[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,scale", [((16, 3, 32, 32), 2), ((4, 3, 41, 41), 4), ((2, 3, 37, 53), 3), ((2, 1, 64, 48), 2)])
+def test_hip_img_interp_bit_exact_vs_pillow_live(gpu, shape, scale):
+    """Larger seeded batches (SRCNN c1 / VDSR c3 patch sizes) against Pillow executed now."""
+    import pytorch_super_resolution_model_collection_amd as pkg
+    x = fill.rand(shape, 77)
+    for interp in ("bicubic", "bilinear", "nearest"):
+        y = pkg.ops.img_interp(x.to(gpu), scale, interp)
+        assert torch.equal(y.cpu(), O.img_interp(x, scale, interp)), interp
+    # values outside [0,1] saturate instead of wrapping (documented deviation from .byte() wrap-around)
+    y = pkg.ops.img_interp((x * 1.5 - 0.2).to(gpu), scale, "bicubic")
+    assert torch.equal(y.cpu(), O.img_interp((x * 1.5 - 0.2).clamp(0, 1), scale, "bicubic"))
+
+
+@pytest.mark.gpu
+def test_c1_srcnn_pipeline_with_bicubic_preprocessing(gpu):
+    """BASELINE c1 as the reference feeds it (srcnn.py:116-131): 16 LR patches of 32x32 -> utils.img_interp x2 (PIL
+    bicubic) -> SRCNN -> MSE against shave(target, 8); three SGD steps, product (GPU) vs oracle (CPU)."""
+    import pytorch_super_resolution_model_collection_amd as pkg
+    from oracle import ref_modules as R
+    net = pkg.SRCNNNet(3, 64)
+    fill.fill_module(net, 5, 1.0)
+    ora = fill.fill_module(R.SRCNN(3, 64), 5, 1.0)
+    net.to(gpu).train()
+    flat = pkg.optim.FlatParams(net)
+    opt = pkg.optim.make_optimizer("srcnn", flat, 1e-2)
+    step = pkg.trainers.mse_step(net, opt, None)
+    oopt = R.make_optimizer("srcnn", ora.parameters(), 1e-2)
+    for i in range(3):
+        inp, tgt = fill.rand((16, 3, 32, 32), 300 + i), fill.rand((16, 3, 64, 64), 400 + i)
+        y_gpu = pkg.utils.img_interp(inp.to(gpu), 2)
+        x_gpu = pkg.utils.shave(tgt.to(gpu), 8).contiguous()
+        y_cpu, x_cpu = O.img_interp(inp, 2), tgt[..., 8:-8, 8:-8]
+        assert torch.equal(y_gpu.cpu(), y_cpu)
+        loss = float(step(y_gpu, x_gpu))
+        oloss = R.step_mse(ora, oopt, y_cpu, x_cpu)
+        assert abs(loss - oloss) <= 2e-5 * abs(oloss)
+    for (n, p), (_, q) in zip(net.named_parameters(), ora.named_parameters()):
+        assert float((p.detach().cpu() - q.detach()).abs().max()) <= 2e-4 * float(q.detach().abs().max()) + 1e-7, n
