@@ -154,6 +154,41 @@ def train_extra(pkg, dev, rank, world):
         step = pkg.trainers.GraphedStep(net, opt, loss_fn, (inp, tgt), dp=dp, clip=clip, warmup=2)
         return time_steps(lambda: step(inp, tgt), steps, warmup, world if use_dp else 1, dev), steps
 
+    def c1():
+        # BASELINE c1: SRCNN x2, 16 LR patches 32x32 -> bicubic x2 (utils.img_interp, bit-exact PIL) -> 3x64x64 ->
+        # 3x48x48, MSE vs shave(target, 8), SGD (srcnn.py:116-131).  The pre-steps run inside the timed step.
+        net = pkg.SRCNNNet(3, 64)
+        net.weight_init()
+        net.to(dev).train()
+        flat = pkg.optim.FlatParams(net)
+        opt = pkg.optim.make_optimizer("srcnn", flat, 1e-5)
+        step = pkg.trainers.mse_step(net, opt, None)
+        inp = torch.rand(16, 3, 32, 32, generator=g).to(dev)
+        tgt = torch.rand(16, 3, 64, 64, generator=g).to(dev)
+
+        def one():
+            return step(pkg.utils.img_interp(inp, 2), pkg.utils.shave(tgt, 8).contiguous())
+
+        sec = time_steps(one, 20, 5, 1, dev)
+        out["c1_srcnn_x2_train_patches_per_s_batch_16"] = round(16 * 20 / sec, 1)
+        out["c1_srcnn_ms_per_step"] = round(1e3 * sec / 20, 3)
+        # the reference's CPU path for the same step on this box's host cores (oracle = stock torch + Pillow)
+        from oracle import ref_modules as R, img_interp as OI
+        onet = R.SRCNN(3, 64)
+        oopt = R.make_optimizer("srcnn", onet.parameters(), 1e-5)
+        ci, ct = inp.cpu(), tgt.cpu()
+        best, best_threads = None, 0
+        for nthr in sorted({os.cpu_count() or 1, 32, 8}):   # tiny tensors: all 256 host threads oversubscribe
+            torch.set_num_threads(nthr)
+            for i in range(5):
+                t0 = time.perf_counter()
+                R.step_mse(onet, oopt, OI.img_interp(ci, 2), ct[..., 8:-8, 8:-8])
+                dt = time.perf_counter() - t0
+                if i >= 2 and (best is None or dt < best):
+                    best, best_threads = dt, nthr
+        out["c1_cpu_oracle_patches_per_s"] = round(16 / best, 1)
+        out["c1_cpu_oracle_threads"] = best_threads
+
     def c3():
         net = pkg.VDSRNet(3, 64, 18)
         net.weight_init()
@@ -214,7 +249,7 @@ def train_extra(pkg, dev, rank, world):
         out["c5_srgan_ms_per_step"] = round(1e3 * sec / 6, 3)
 
     # every side metric is isolated: a failure is reported in the JSON instead of losing the headline line
-    sections = ([("c3", c3)] if world == 1 else []) + [("c4_strong", c4_strong)] + \
+    sections = ([("c1", c1), ("c3", c3)] if world == 1 else []) + [("c4_strong", c4_strong)] + \
                ([("c4_weak", c4_weak)] if world > 1 else []) + [("c5", c5)]
     for name, fn in sections:
         try:
@@ -261,6 +296,25 @@ def main():
     imgs_per_s = world * args.batch * args.steps / sec
     layer_ms = espcn_layer_events(net, x, max(3, min(args.steps, 10)))
 
+    # measured device-to-device copy bandwidth on this box (read + write bytes / time), beside the vendor peak
+    copy_gbps = None
+    try:
+        a = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=dev)
+        b = torch.empty_like(a)
+        for _ in range(2):
+            b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbps = round(2 * a.numel() * 4 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del a, b
+        torch.cuda.empty_cache()
+    except Exception:  # noqa: BLE001
+        pass
+
     result = None
     if rank == 0:
         H = args.lr_size
@@ -296,7 +350,7 @@ def main():
                          "layer_ms": [round(m, 4) for m in layer_ms],
                          "whole_net_hbm": {
                              "achieved_GBps": round(ESPCN_BYTES_PER_IMG * scale * imgs_per_s / world / 1e9, 1),
-                             "peak_GBps": HBM_PEAK_GBS,
+                             "peak_GBps": HBM_PEAK_GBS, "measured_copy_GBps": copy_gbps,
                              "frac": round(ESPCN_BYTES_PER_IMG * scale * imgs_per_s / world / 1e9 / HBM_PEAK_GBS, 4),
                              "note": "61.11 MB/img per-layer compulsory traffic (SURVEY.md 8d); north-star target 0.30"},
                          "whole_net_fp32_flop_frac": round(
