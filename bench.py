@@ -116,24 +116,28 @@ def pmc_traffic(kernel_label, batch, lr_size):
 
 
 def cpu_baseline(batch_cap=8, lr_size=256):
-    """Oracle ESPCN x4 forward on the host cores (bounded sample: B=8, best of 5 after 2 warm-ups)."""
+    """Oracle ESPCN x4 forward on the host cores (bounded sample: B=8; per thread count 2 warm-ups + best of 3; the
+    thread count that gives the best rate is the one reported — all hardware threads oversubscribe oneDNN here)."""
     from oracle import fill, ref_modules as R
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     net = fill.fill_module(R.ESPCN(3, 64, 4)).eval()
     x = fill.rand((batch_cap, 3, lr_size, lr_size), 1234)
-    best = None
+    best, best_threads = None, 0
+    ncpu = os.cpu_count() or 1
     with torch.no_grad():
-        for i in range(7):
-            t0 = time.perf_counter()
-            net(x)
-            dt = time.perf_counter() - t0
-            if i >= 2:
-                best = dt if best is None else min(best, dt)
-    return {"value": round(batch_cap / best, 2), "unit": "images/s", "cores": torch.get_num_threads(),
+        for nthr in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), 32, 16, 8}):
+            if nthr > ncpu:
+                continue
+            torch.set_num_threads(nthr)
+            for i in range(5):
+                t0 = time.perf_counter()
+                net(x)
+                dt = time.perf_counter() - t0
+                if i >= 2 and (best is None or dt < best):
+                    best, best_threads = dt, nthr
+    return {"value": round(batch_cap / best, 2), "unit": "images/s", "cores": best_threads, "host_threads": ncpu,
             "kind": "port",
-            "sample": "oracle ESPCN x4 forward (stock torch.nn CPU fp32), batch %d of %dx%d LR, best of 5"
-                      % (batch_cap, lr_size, lr_size)}
+            "sample": "oracle ESPCN x4 forward (stock torch.nn CPU fp32), batch %d of %dx%d LR, best of 3 at the best of "
+                      "%s threads" % (batch_cap, lr_size, lr_size, sorted({ncpu, ncpu // 2, ncpu // 4, 32, 16, 8}))}
 
 
 def train_extra(pkg, dev, rank, world):
