@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf(WgBfParams P) {
   const unsigned short* xa_l = xa_h + (size_t)CIB * P.CS;
   const unsigned short* yb_h = ys + (size_t)(cow * NTW * 16 + i) * P.DS;
   const unsigned short* yb_l = yb_h + (size_t)COB * P.DS;
-  const int hwp2 = P.HWp >> 1, tw2 = P.TW >> 1;
+  const int tw2 = P.TW >> 1;
 
   for (int tile = blockIdx.x; tile < P.ntiles; tile += P.G) {
     int b = tile;
@@ -153,11 +153,14 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf(WgBfParams P) {
     __syncthreads();  // previous tile fully consumed (tables / zero octets visible on the first pass)
     {  // X halo: rows [r0-pad, +HH), cols [c0-pad, +HWp), channels [cib, cib+CIB) -> planes [ci][hy][hx]
       constexpr int QN = CIB / 4;
-      const int items = P.HH * hwp2 * QN;
+      // only the TW + KW - 1 columns the fragments can touch are loaded (the plane row stride HWp = TW + 8 is for
+      // the 16-byte alignment of the octets)
+      const int need2 = (P.TW + P.KW) >> 1;
+      const int items = P.HH * need2 * QN;
       const int by0 = r0 - P.pad, bx0 = c0 - P.pad;
       for (int it = tid; it < items; it += 256) {
         const int q = it % QN, pp = it / QN;
-        const int hy = pp / hwp2, hx = (pp - hy * hwp2) * 2;
+        const int hy = pp / need2, hx = (pp - hy * need2) * 2;
         const int ch = cib + q * 4;
         const f32x4 p0 = wb_load4(P.x, nullptr, 0.f, n, P.XH, P.XW, P.Cin, by0 + hy, bx0 + hx, ch, P.vec_x);
         const f32x4 p1 = wb_load4(P.x, nullptr, 0.f, n, P.XH, P.XW, P.Cin, by0 + hy, bx0 + hx + 1, ch, P.vec_x);
