@@ -76,6 +76,10 @@ typedef struct srk_conv_desc {
   int32_t algo;       /* srk_algo */
   int32_t x_nchw;     /* forward only: x is the caller's NCHW tensor (read in place by the Cin <= 4 bf16x3
                          first-layer kernel; SRK_ERR_UNSUPPORTED elsewhere) */
+  int32_t dy_ps_r;    /* backward only: dy is handed over in the pixel-shuffled layout [N, OH*r, OW*r, Cout/r^2] that the
+                         fused conv + PixelShuffle forward produced (PSBlock, base_networks.py:179-181); the bf16x3
+                         data- and weight-gradient kernels un-shuffle while staging (SRK_ERR_UNSUPPORTED elsewhere:
+                         call srk_pixel_shuffle_backward first) */
 } srk_conv_desc;
 
 /* Fused epilogue of a forward conv:  y = PS_r( act(conv + bias) ) + residual
@@ -131,7 +135,9 @@ int srk_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, void*
 size_t srk_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int bwd);
 int srk_pack_weight_fwd(const float* w, float* wp, int Cout, int Cin, int KH, int KW, int transposed, int ps_r,
                         void* stream);
-int srk_pack_weight_bwd(const float* w, float* wp, int Cout, int Cin, int KH, int KW, int transposed,
+/* bwd, ps_r > 1: the contraction axis (Cout) is ordered (i, j, c) — the channel order of a pixel-shuffled dy, for
+ * srk_conv2d_backward_data with srk_conv_desc.dy_ps_r set */
+int srk_pack_weight_bwd(const float* w, float* wp, int Cout, int Cin, int KH, int KW, int transposed, int ps_r,
                         void* stream);
 int srk_pack_bias_ps(const float* b, float* bp, int Cout, int ps_r, void* stream);
 /* Whole-model packing in ONE launch (training: the weights change every step).  `params_base` is the

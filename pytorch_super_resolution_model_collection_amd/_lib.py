@@ -32,7 +32,7 @@ class ConvDesc(ctypes.Structure):
     """struct srk_conv_desc"""
     _fields_ = [(n, ctypes.c_int32) for n in
                 ("N", "H", "W", "Cin", "OH", "OW", "Cout", "KH", "KW", "stride", "pad", "transposed", "out_pad",
-                 "algo", "x_nchw")]
+                 "algo", "x_nchw", "dy_ps_r")]
 
 
 class Epilogue(ctypes.Structure):
@@ -54,7 +54,7 @@ _PROTOTYPES = {
     "srk_nchw_to_nhwc": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_vp]),
     "srk_nhwc_to_nchw": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_vp]),
     "srk_pack_weight_fwd": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
-    "srk_pack_weight_bwd": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "srk_pack_weight_bwd": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "srk_pack_bias_ps": (c_int, [c_f, c_f, c_int, c_int, c_vp]),
     "srk_pack_weights_batched": (c_int, [c_f, c_vp, c_vp, c_int, c_int, c_vp]),
     "srk_packed_weight_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),

@@ -75,6 +75,16 @@ static int forced_algo(int algo) {
 static int run_gather(const GatherConv& g, int algo, const float* in, const float* wp, float* out, const Epi& ep,
                       const float* mask_y, float mask_slope, hipStream_t s, const char* who) {
   algo = forced_algo(algo);
+  if (g.in_ps_r > 1) {  // pixel-shuffled input: only the bf16x3 kernels un-shuffle while staging
+    if ((algo != SRK_ALGO_AUTO && algo != SRK_ALGO_MFMA_BF16X3) || !conv_bf3_gather_supported(g, ep) || g.IC <= 4 ||
+        g.OC <= 4) {
+      set_error("%s: pixel-shuffled dy is only supported by the bf16x3 kernels (un-shuffle with srk_pixel_shuffle_backward)", who);
+      return SRK_ERR_UNSUPPORTED;
+    }
+    if (conv_bfd_gather_supported(g, ep) && conv_bfd_small_problem(g))
+      return conv_bfd_gather(g, in, wp, out, ep, mask_y, mask_slope, 2, s);
+    return conv_bf3_gather(g, in, wp, out, ep, mask_y, mask_slope, s);
+  }
   const bool direct_ok = conv_direct_gather_supported(g, ep);
   const bool mfma_ok = conv_mfma_gather_supported(g, ep);
   if (algo == SRK_ALGO_DIRECT && !direct_ok) {
@@ -156,6 +166,7 @@ extern "C" int srk_conv2d_forward(const srk_conv_desc* d, const float* x, const 
                 "conv2d_forward: PReLU must have 1 or Cout slopes");
   }
   GatherConv g{d->N, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->pad, d->transposed, 0};
+  SRK_REQUIRE(d->dy_ps_r == 0, "conv2d_forward: dy_ps_r is a backward-only field");
   if (d->x_nchw) {
     // only the row-packed bf16x3 first-layer kernel reads an NCHW input in place
     const int algo = forced_algo(d->algo);
@@ -175,7 +186,12 @@ extern "C" int srk_conv2d_backward_data(const srk_conv_desc* d, const float* dy,
   if (rc) return rc;
   SRK_REQUIRE(dy && w_packed_bwd && dx, "conv2d_backward_data: null tensor pointer");
   // dx is a gather over dy with the channel roles swapped and the opposite gather kind.
-  GatherConv g{d->N, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad, !d->transposed, 0};
+  GatherConv g{d->N, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad, !d->transposed, 0, 0};
+  if (d->dy_ps_r > 1) {
+    const int r2 = d->dy_ps_r * d->dy_ps_r;
+    SRK_REQUIRE(d->Cout % r2 == 0 && (d->Cout / r2) % 8 == 0, "conv2d_backward_data: dy_ps_r needs Cout/r^2 to be a multiple of 8");
+    g.in_ps_r = d->dy_ps_r;
+  }
   Epi ep{};
   ep.residual = add_to;
   return run_gather(g, d->algo, dy, w_packed_bwd, dx, ep, mask ? mask->y : nullptr, mask ? mask->slope : 0.f,
@@ -204,6 +220,11 @@ extern "C" int srk_conv2d_backward_weight(const srk_conv_desc* d, const float* x
   const char* wb = getenv("SRK_WGRAD_BF16");  // 0 disables the bf16x3 weight-gradient kernel
   if ((algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3) && !(wb && atoi(wb) == 0) && conv_wgrad_bf_supported(*d))
     return conv_wgrad_bf(*d, x, dy, mask, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);
+  if (d->dy_ps_r > 1) {
+    set_error("conv2d_backward_weight: pixel-shuffled dy is only supported by the bf16x3 kernel (un-shuffle with "
+              "srk_pixel_shuffle_backward)");
+    return SRK_ERR_UNSUPPORTED;
+  }
   if (algo != SRK_ALGO_GENERIC && conv_wgrad_mfma_supported(*d))
     return conv_wgrad_mfma(*d, x, dy, mask, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);
   return conv_generic_wgrad(*d, x, dy, mask, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);

@@ -309,15 +309,16 @@ extern "C" size_t srk_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int
   return bf3_prepared_offset(elems) + bf3_prepared_bytes(bwd ? Cout : Cin, bwd ? Cin : Cout, KH * KW);
 }
 extern "C" int srk_pack_weight_bwd(const float* w, float* wp, int Cout, int Cin, int KH, int KW, int transposed,
-                                   void* stream) {
+                                   int ps_r, void* stream) {
   SRK_REQUIRE(w && wp, "pack_weight_bwd: null pointer");
   SRK_REQUIRE(Cout > 0 && Cin > 0 && KH > 0 && KW > 0, "pack_weight_bwd: bad dims");
+  SRK_REQUIRE(ps_r <= 1 || Cout % (ps_r * ps_r) == 0, "pack_weight_bwd: Cout %d not divisible by r^2", Cout);
   const int elems = KH * KW * Cin * Cout;
   hipLaunchKernelGGL(k_pack_weight, dim3(cdiv(elems, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, KH,
-                     KW, transposed, 0, 1);
+                     KW, transposed, ps_r, 1);
   int rc = check_launch("pack_weight_bwd");
   if (rc) return rc;
-  return bf3_pack_prepared(w, wp, Cout, Cin, KH, KW, transposed, 0, 1, (hipStream_t)stream);
+  return bf3_pack_prepared(w, wp, Cout, Cin, KH, KW, transposed, ps_r, 1, (hipStream_t)stream);
 }
 extern "C" int srk_pack_bias_ps(const float* b, float* bp, int Cout, int ps_r, void* stream) {
   SRK_REQUIRE(b && bp && Cout > 0 && ps_r >= 1, "pack_bias_ps: bad args");

@@ -130,7 +130,6 @@ __device__ __forceinline__ void bf3_stage_halo_t(const Bf3Params& B, uint4* hal,
   const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
   const int ch = cb + g * 8;
   const bool ch_any = ch < P.IC, ch_vec = P.vec_in && ch + 7 < P.IC;
-  const size_t img = (size_t)n * P.IH;
   for (int base = hp0; base < npix; base += PPP * BF3_STAGE_IT) {
     f32x4 v0[BF3_STAGE_IT], v1[BF3_STAGE_IT], m0[BF3_STAGE_IT], m1[BF3_STAGE_IT];
     // pass 1: issue every load of this batch
@@ -145,7 +144,7 @@ __device__ __forceinline__ void bf3_stage_halo_t(const Bf3Params& B, uint4* hal,
       const int hp = base + PPP * k;
       const int iy = iyb + hy, ix = ixb + hx;
       if (hp < npix && ch_any && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) {
-        const size_t off = ((img + iy) * P.IW + ix) * P.IC + ch;
+        const size_t off = conv_in_offset(P, n, iy, ix, ch);
         if (ch_vec) {
           v0[k] = *reinterpret_cast<const f32x4*>(P.in + off);
           v1[k] = *reinterpret_cast<const f32x4*>(P.in + off + 4);
@@ -442,7 +441,7 @@ __global__ __launch_bounds__(256) void k_pack_batched(const float* __restrict__ 
   const int transposed = (int)row[7], ps_r = (int)row[8];
   const long tid0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
   if (row[1] >= 0) pack_one_dir(w, packed + row[1], Cout, Cin, KH, KW, transposed, ps_r, 0, tid0, stride);
-  if (row[2] >= 0) pack_one_dir(w, packed + row[2], Cout, Cin, KH, KW, transposed, 0, 1, tid0, stride);
+  if (row[2] >= 0) pack_one_dir(w, packed + row[2], Cout, Cin, KH, KW, transposed, ps_r, 1, tid0, stride);
   if (row[9] >= 0 && row[10] >= 0 && ps_r > 1) {
     const float* b = params + row[9];
     float* bp = reinterpret_cast<float*>(packed + row[10]);

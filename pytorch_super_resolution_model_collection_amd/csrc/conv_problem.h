@@ -11,6 +11,7 @@ struct GatherConv {
   int OH, OW, OC;
   int KH, KW, stride, pad, trans;
   int in_nchw;  // input is NCHW (only the bf16x3 row-packed kernel reads it in place)
+  int in_ps_r;  // input is stored pixel-shuffled [N, IH*r, IW*r, IC/r^2] (data gradient of a fused conv + PS forward)
 };
 
 // Device-side epilogue: out = PS_r(act(acc + bias)) + residual

@@ -28,7 +28,18 @@ struct MfmaConvParams {
   int halo_floats;
   int vec_in, vec_w;
   int in_nchw;  // input tensor is NCHW (row-packed Cin <= 4 kernel only)
+  int in_ps_r;  // input tensor is pixel-shuffled: packed channel (i, j, c) of pixel (y, x) lives at (y*r+i, x*r+j, c)
+  int in_ps_C;  // IC / r^2
 };
+
+// element offset of packed channel `ch` of input pixel (n, iy, ix)
+__device__ __forceinline__ size_t conv_in_offset(const MfmaConvParams& P, int n, int iy, int ix, int ch) {
+  if (P.in_ps_r <= 1) return (((size_t)n * P.IH + iy) * P.IW + ix) * P.IC + ch;
+  const int r = P.in_ps_r, C = P.in_ps_C;
+  const int q = ch / C, c = ch - q * C;
+  const int i = q / r, j = q - i * r;
+  return ((((size_t)n * P.IH + iy) * r + i) * ((size_t)P.IW * r) + (size_t)ix * r + j) * C + c;
+}
 
 static constexpr int kLdsBudgetBytes = 78 * 1024;  // 2 blocks per CU out of 160 KiB
 
@@ -84,6 +95,8 @@ static inline int for_each_phase(const GatherConv& g, const float* in, const flo
   P.N = g.N; P.IH = g.IH; P.IW = g.IW; P.IC = g.IC; P.OH = g.OH; P.OW = g.OW; P.OC = g.OC;
   P.KW_full = g.KW;
   P.in_nchw = g.in_nchw;
+  P.in_ps_r = g.in_ps_r;
+  P.in_ps_C = g.in_ps_r > 1 ? g.IC / (g.in_ps_r * g.in_ps_r) : g.IC;
   P.vec_in = (g.IC % 4 == 0) && ((uintptr_t)in % 16 == 0) && (!mask_y || (uintptr_t)mask_y % 16 == 0);
   P.vec_w = (g.OC % 4 == 0) && ((uintptr_t)wp % 16 == 0);
   if (!g.trans) {

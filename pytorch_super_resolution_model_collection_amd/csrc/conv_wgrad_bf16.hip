@@ -31,7 +31,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // conv_wgrad_mfma.hip
 int conv_wgrad_reduce_launch(const float* ws, float* dw, int G, int Cout, int Cin, int KH, int KW, int transposed,
-                             float beta, const float* bias_partial, float* db, int bias_cout, hipStream_t s);
+                             float beta, const float* bias_partial, float* db, int bias_cout, int out_ps_r,
+                             hipStream_t s);
 
 constexpr int WB_MAXOCT = 64;  // octets per tile (<= 512 pixels)
 
@@ -49,6 +50,7 @@ struct WgBfParams {
   int CS, DS;  // per-channel plane strides (bf16 elements) of the X halo / dY tile
   int ntiles, G, nks;
   int vec_x, vec_y;
+  int dy_ps_r, dy_ps_C;  // dY handed over pixel-shuffled [N, YH*r, YW*r, Cout/r^2]: un-shuffled while staging
 };
 
 __device__ __forceinline__ f32x4 wb_mfma(const uint4& a, const uint4& b, f32x4 c) {
@@ -72,10 +74,16 @@ __device__ __forceinline__ void wb_split_pair(const f32x4& p0, const f32x4& p1, 
 // Load 4 channels [ch, ch+4) of pixel (n, iy, ix) of an NHWC tensor (zero outside the image / channel range),
 // optionally masked by the ReLU-family gradient of `mask`.
 __device__ __forceinline__ f32x4 wb_load4(const float* __restrict__ src, const float* __restrict__ mask, float mslope,
-                                          int n, int H, int W, int C, int iy, int ix, int ch, int vec) {
+                                          int n, int H, int W, int C, int iy, int ix, int ch, int vec, int ps_r = 0,
+                                          int ps_C = 0) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if (iy >= 0 && iy < H && ix >= 0 && ix < W && ch < C) {
-    const size_t off = (((size_t)n * H + iy) * W + ix) * C + ch;
+    size_t off = (((size_t)n * H + iy) * W + ix) * C + ch;
+    if (ps_r > 1) {  // packed channel (i, j, c) of pixel (iy, ix) lives at (iy*r + i, ix*r + j, c)
+      const int q = ch / ps_C, c = ch - q * ps_C;
+      const int i = q / ps_r, j = q - i * ps_r;
+      off = ((((size_t)n * H + iy) * ps_r + i) * ((size_t)W * ps_r) + (size_t)ix * ps_r + j) * ps_C + c;
+    }
     if (vec && ch + 3 < C) {
       v = *reinterpret_cast<const f32x4*>(src + off);
       if (mask) {
@@ -181,9 +189,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf(WgBfParams P) {
         const int q = it % QN, pp = it / QN;
         const int r = pp / tw2, c = (pp - r * tw2) * 2;
         const int ch = cob + q * 4;
-        const f32x4 p0 = wb_load4(P.dy, P.mask_y, P.mask_slope, n, P.YH, P.YW, P.Cout, r0 + r, c0 + c, ch, P.vec_y);
+        const f32x4 p0 = wb_load4(P.dy, P.mask_y, P.mask_slope, n, P.YH, P.YW, P.Cout, r0 + r, c0 + c, ch, P.vec_y,
+                                  P.dy_ps_r, P.dy_ps_C);
         const f32x4 p1 =
-            wb_load4(P.dy, P.mask_y, P.mask_slope, n, P.YH, P.YW, P.Cout, r0 + r, c0 + c + 1, ch, P.vec_y);
+            wb_load4(P.dy, P.mask_y, P.mask_slope, n, P.YH, P.YW, P.Cout, r0 + r, c0 + c + 1, ch, P.vec_y, P.dy_ps_r,
+                     P.dy_ps_C);
         bsum += p0 + p1;  // this thread's channel group is fixed (256 % QN == 0)
         unsigned hi[4], lo[4];
         wb_split_pair(p0, p1, hi, lo);
@@ -300,6 +310,7 @@ static WbPlan wb_plan(const srk_conv_desc& d) {
   WbPlan pl{};
   pl.ok = false;
   if (d.transposed || d.stride != 1 || d.KH > 3 || d.KW > 3 || d.Cin < 8 || d.Cout < 1) return pl;
+  if (d.dy_ps_r > 1 && (d.Cout % (d.dy_ps_r * d.dy_ps_r) != 0 || (d.Cout / (d.dy_ps_r * d.dy_ps_r)) % 4 != 0)) return pl;
   if (d.Cout > 32) {
     pl.cfg = 0; pl.CIB = 32; pl.COB = 64;
   } else if (d.Cout > 16) {
@@ -393,6 +404,8 @@ int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const
   P.ntiles = pl.ntiles; P.G = pl.G; P.nks = pl.nks;
   P.vec_x = (d.Cin % 4 == 0) && ((uintptr_t)x % 16 == 0);
   P.vec_y = (d.Cout % 4 == 0) && ((uintptr_t)dy % 16 == 0) && (!P.mask_y || (uintptr_t)P.mask_y % 16 == 0);
+  P.dy_ps_r = d.dy_ps_r > 1 ? d.dy_ps_r : 0;
+  P.dy_ps_C = d.dy_ps_r > 1 ? d.Cout / (d.dy_ps_r * d.dy_ps_r) : d.Cout;
   dim3 grid(pl.G, pl.gy, pl.gz);
   {
     static int dbg = -1;
@@ -412,7 +425,7 @@ int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const
   int rc = check_launch("conv_wgrad_bf");
   if (rc) return rc;
   return conv_wgrad_reduce_launch((const float*)ws, dw, pl.G, d.Cout, d.Cin, d.KH, d.KW, 0, beta, db ? bias_ws : nullptr,
-                                  db, d.Cout, s);
+                                  db, d.Cout, d.dy_ps_r > 1 ? d.dy_ps_r : 0, s);
 }
 
 }  // namespace srk

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_smallcin(WgradParams P) {
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw, int G,
                                                       int Cout, int Cin, int KH, int KW, int transposed, float beta,
                                                       const float* __restrict__ bias_partial, float* __restrict__ db,
-                                                      int bias_cout) {
+                                                      int bias_cout, int out_ps_r) {
   // 64 consecutive slab elements per block (coalesced 256-byte rows); the 4 waves each sum a quarter
   // of the G slabs with 4 independent accumulators (16 loads in flight per lane), combined through
   // LDS in a fixed order => deterministic.  The blocks past the last slab element finish the bias
@@ -352,7 +352,13 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     __syncthreads();
     if (w == 0 && co < bias_cout) {
       const float t = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
-      db[co] = beta != 0.f ? beta * db[co] + t : t;
+      int cot = co;
+      if (out_ps_r > 1) {  // slab channel order (i, j, c) -> torch channel c*r*r + i*r + j
+        const int C = bias_cout / (out_ps_r * out_ps_r);
+        const int q = co / C, c = co - q * C;
+        cot = c * out_ps_r * out_ps_r + q;
+      }
+      db[cot] = beta != 0.f ? beta * db[cot] + t : t;
     }
     return;
   }
@@ -372,7 +378,12 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   __syncthreads();
   if (w != 0 || e >= elems) return;
   const float v = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
-  const int co = e % Cout;
+  int co = e % Cout;
+  if (out_ps_r > 1) {
+    const int C = Cout / (out_ps_r * out_ps_r);
+    const int q = co / C, c = co - q * C;
+    co = c * out_ps_r * out_ps_r + q;
+  }
   const int ci = (e / Cout) % Cin;
   const int tap = e / (Cout * Cin);
   const int kh = tap / KW, kw = tap - kh * KW;
@@ -386,11 +397,12 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 
 // bias_partial / db may be NULL (no bias, or the bias gradient is produced elsewhere); bias_cout = channels of db
 int conv_wgrad_reduce_launch(const float* ws, float* dw, int G, int Cout, int Cin, int KH, int KW, int transposed,
-                             float beta, const float* bias_partial, float* db, int bias_cout, hipStream_t s) {
+                             float beta, const float* bias_partial, float* db, int bias_cout, int out_ps_r,
+                             hipStream_t s) {
   const int elems = KH * KW * Cin * Cout;
   const int bias_blocks = (bias_partial && db) ? cdiv(bias_cout, 64) : 0;
   hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(elems, 64) + bias_blocks), dim3(256), 0, s, ws, dw, G, Cout, Cin, KH, KW,
-                     transposed, beta, bias_partial, db, bias_cout);
+                     transposed, beta, bias_partial, db, bias_cout, out_ps_r);
   return check_launch("conv_wgrad_reduce");
 }
 
@@ -552,7 +564,7 @@ static int conv_wgrad_small_cout(const srk_conv_desc& d, const srk_conv_desc& ds
   else launch_w2<16>(P, grid, pl.lds, s);
   int rc = check_launch("conv_wgrad_small_cout");
   if (rc) return rc;
-  rc = conv_wgrad_reduce_launch((const float*)ws, dw, pl.G, ds.Cout, ds.Cin, ds.KH, ds.KW, 2, beta, nullptr, nullptr, 0, s);
+  rc = conv_wgrad_reduce_launch((const float*)ws, dw, pl.G, ds.Cout, ds.Cin, ds.KH, ds.KW, 2, beta, nullptr, nullptr, 0, 0, s);
   if (rc) return rc;
   if (db) rc = conv_bias_grad(d, dy, nullptr, db, beta, reinterpret_cast<float*>(static_cast<char*>(ws) + slab_bytes), s);
   return rc;
@@ -620,7 +632,7 @@ int conv_wgrad_mfma(const srk_conv_desc& d, const float* x, const float* dy, con
   if (rc) return rc;
   const bool fused_bias = db && P.bias_partial;
   rc = conv_wgrad_reduce_launch((const float*)ws, dw, pl.G, d.Cout, d.Cin, d.KH, d.KW, d.transposed, beta,
-                                fused_bias ? bias_ws : nullptr, fused_bias ? db : nullptr, d.Cout, s);
+                                fused_bias ? bias_ws : nullptr, fused_bias ? db : nullptr, d.Cout, 0, s);
   if (rc) return rc;
   if (db && !fused_bias) rc = conv_bias_grad(d, dy, mask, db, beta, bias_ws, s);
   return rc;

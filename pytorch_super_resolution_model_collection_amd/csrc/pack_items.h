@@ -96,6 +96,11 @@ __device__ __forceinline__ void pack_bf3_item(long it, const float* __restrict__
       } else {
         ci = oc;
         co = ic;
+        if (ps_r > 1) {  // data gradient of a fused conv + pixel shuffle: K runs over dy's packed (i, j, c) channels
+          const int C = Cout / (ps_r * ps_r);
+          const int q = ic / C, c = ic - q * C;
+          co = c * ps_r * ps_r + q;
+        }
       }
       v = w[pk_src(ci, co, kh, kw, Cout, Cin, KH, KW, transposed)];
     }

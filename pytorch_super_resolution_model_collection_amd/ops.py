@@ -6,6 +6,7 @@ module surface, e.g. edsr.py:146-152) but stored channels_last (= dense NHWC, th
 layout).  Nothing in this file computes on the CPU and nothing falls back to ATen operators.
 """
 import ctypes
+import os
 
 import torch
 
@@ -165,12 +166,12 @@ def pack_weight_fwd(weight, transposed, ps_r):
     return wp
 
 
-def pack_weight_bwd(weight, transposed):
+def pack_weight_bwd(weight, transposed, ps_r=0):
     lib = _lib.load()
     cout, cin, kh, kw = _weight_dims(weight, transposed)
     nbytes = int(lib.srk_packed_weight_bytes(cout, cin, kh, kw, 1))
     wp = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=weight.device)
-    check(lib.srk_pack_weight_bwd(ptr(weight), ptr(wp), cout, cin, kh, kw, int(transposed), stream_ptr()),
+    check(lib.srk_pack_weight_bwd(ptr(weight), ptr(wp), cout, cin, kh, kw, int(transposed), int(ps_r), stream_ptr()),
           "srk_pack_weight_bwd")
     return wp
 
@@ -238,16 +239,27 @@ class _Conv2d(torch.autograd.Function):
         dyc = dy
         if cfg.ps_r > 1:
             r = cfg.ps_r
-            dyc = _empty_cl(d.N, d.Cout, d.OH, d.OW, dy)
-            check(lib.srk_pixel_shuffle_backward(ptr(dy), ptr(dyc), d.N, d.OH, d.OW, d.Cout // (r * r), r,
-                                                 stream_ptr()), "srk_pixel_shuffle_backward")
+            # the bf16x3 data- and weight-gradient kernels read the pixel-shuffled dy directly (they un-shuffle while
+            # staging their tiles); everything else gets an explicit depth-from-space pass first
+            fused_ps = (d.algo in (ALGO_AUTO, _lib.ALGO_MFMA_BF16X3) and not cfg.transposed and cfg.stride == 1
+                        and d.KH <= 3 and d.KW <= 3 and d.Cin >= 8 and (d.Cout // (r * r)) % 8 == 0
+                        and os.environ.get("SRK_FUSE_PS_BWD", "1") != "0")
+            ctx_wpb = ctx.wpb
+            if fused_ps:
+                d.dy_ps_r = r
+            else:
+                ctx_wpb = None  # the PackPlan packs PS layers for the fused path ((i, j, c) contraction order)
+                dyc = _empty_cl(d.N, d.Cout, d.OH, d.OW, dy)
+                check(lib.srk_pixel_shuffle_backward(ptr(dy), ptr(dyc), d.N, d.OH, d.OW, d.Cout // (r * r), r,
+                                                     stream_ptr()), "srk_pixel_shuffle_backward")
         mask = None
         if y is not None:
             mask = BwdMask(ptr(y), cfg.slope if cfg.act == ACT_LRELU else 0.0)
         mref = ctypes.byref(mask) if mask is not None else None
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wpb = ctx.wpb if ctx.wpb is not None else pack_weight_bwd(weight, cfg.transposed)
+            plan_wpb = ctx.wpb if cfg.ps_r <= 1 else ctx_wpb
+            wpb = plan_wpb if plan_wpb is not None else pack_weight_bwd(weight, cfg.transposed, d.dy_ps_r)
             dx = _empty_cl(d.N, d.Cin, d.H, d.W, dy)
             check(lib.srk_conv2d_backward_data(ctypes.byref(d), ptr(dyc), ptr(wpb), ptr(dx), mref, None,
                                                stream_ptr()), "srk_conv2d_backward_data")

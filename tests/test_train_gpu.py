@@ -165,7 +165,7 @@ def test_pack_plan_equals_per_layer_pack(gpu, model):
         ref_f, ref_b = torch.zeros_like(wpf), torch.zeros_like(wpb)
         w = m.weight.detach()
         check(lib.srk_pack_weight_fwd(ptr(w), ptr(ref_f), cout, cin, kh, kw, int(tr), ps_r, stream_ptr()), "fwd")
-        check(lib.srk_pack_weight_bwd(ptr(w), ptr(ref_b), cout, cin, kh, kw, int(tr), stream_ptr()), "bwd")
+        check(lib.srk_pack_weight_bwd(ptr(w), ptr(ref_b), cout, cin, kh, kw, int(tr), ps_r, stream_ptr()), "bwd")
         assert torch.equal(wpf.view(torch.int32), ref_f.view(torch.int32)), (model, tuple(m.weight.shape), "fwd")
         assert torch.equal(wpb.view(torch.int32), ref_b.view(torch.int32)), (model, tuple(m.weight.shape), "bwd")
         if bp is not None:
