@@ -397,7 +397,7 @@ def step_srgan(G, D, g_opt, d_opt, lr_img, hr_img):
     (SURVEY.md App. B-6/B-7).  Returns (D_loss, G_loss)."""
     bce, mse = nn.BCELoss(), nn.MSELoss()
     b = lr_img.shape[0]
-    real, fake = torch.ones(b, 1), torch.zeros(b, 1)
+    real, fake = torch.ones(b, 1, dtype=lr_img.dtype), torch.zeros(b, 1, dtype=lr_img.dtype)
     # D step (srgan.py:272-287) — G is NOT detached in the reference
     d_opt.zero_grad()
     d_real_loss = bce(D(hr_img), real)

@@ -131,3 +131,47 @@ def test_c4_shard_step_uses_small_problem_kernels_and_matches(gpu):
         full = net(x)
         part = net(x[48:64])
     assert rel_err(part, full[48:64]) < 5e-5
+
+
+def test_c5_srgan_full_size_adversarial_step(gpu):
+    """SRGAN x4 (c5) at the reference's default batch: 16 LR crops 32x32 -> 128x128, one full D step + G step
+    (srgan.py:249-310) against the oracle: both losses, and the updated parameters of G and D (the 9x9 convs at
+    128x128, the stride-2 discriminator convs, the 32768->1024 Linear and every BatchNorm run at full size here)."""
+    pkg = _pkg()
+    G, D = pkg.SRGANGenerator(3, 64, 16), pkg.SRGANDiscriminator(3, 64, 128)
+    fill.fill_module(G, 5, 0.7)
+    fill.fill_module(D, 6, 1.0)
+    oG = fill.fill_module(R.Generator(3, 64, 16), 5, 0.7)
+    oD = fill.fill_module(R.Discriminator(3, 64, 128), 6, 1.0)
+    G.to(gpu).train()
+    D.to(gpu).train()
+    g_opt = pkg.optim.make_optimizer("srgan_g", pkg.optim.FlatParams(G), 1e-4)
+    d_opt = pkg.optim.make_optimizer("srgan_d", pkg.optim.FlatParams(D), 1e-2)
+    step = pkg.trainers.srgan_step(G, D, g_opt, d_opt)
+    og_opt = R.make_optimizer("srgan_g", oG.parameters(), 1e-4)
+    od_opt = R.make_optimizer("srgan_d", oD.parameters(), 1e-2)
+    lr_img, hr_img = fill.rand((16, 3, 32, 32), 501), fill.rand((16, 3, 128, 128), 502)
+    d_loss, g_loss = step(lr_img.to(gpu), hr_img.to(gpu))
+    od_loss, og_loss = R.step_srgan(oG, oD, og_opt, od_opt, lr_img, hr_img)
+    assert abs(float(d_loss) - od_loss) <= 1e-4 * abs(od_loss)
+    assert abs(float(g_loss) - og_loss) <= 1e-4 * abs(og_loss)
+    # Gradients left in the buffers by the step (G: the G step's; D: D step + the G step's accumulation, a reference
+    # quirk both sides share), per tensor in the L2 norm.  At this size the problem is ill-conditioned in fp32: the
+    # backward sums of a BatchNorm that feeds another BatchNorm cancel to ~1e-4 of their mass, and stock torch fp32
+    # itself deviates from an fp64 run of the same oracle by ~2e-3 (tools/srgan_iso_err.py).  The yardstick is
+    # therefore the fp64 oracle, and the bar is a small multiple of the fp32 oracle's own deviation from it.
+    import copy
+    oG64 = fill.fill_module(R.Generator(3, 64, 16), 5, 0.7).double()
+    oD64 = fill.fill_module(R.Discriminator(3, 64, 128), 6, 1.0).double()
+    R.step_srgan(oG64, oD64, R.make_optimizer("srgan_g", oG64.parameters(), 1e-4),
+                 R.make_optimizer("srgan_d", oD64.parameters(), 1e-2), lr_img.double(), hr_img.double())
+    for net, ora, ora64 in ((G, oG, oG64), (D, oD, oD64)):
+        g32 = dict((n, p.grad.double()) for n, p in ora.named_parameters())
+        g64 = dict((n, p.grad) for n, p in ora64.named_parameters())
+        gmax = max(float(g.abs().max()) for g in g64.values())
+        worst_p, worst_o = 0.0, 0.0
+        for n, p in net.named_parameters():
+            den = max(float(g64[n].norm()), 1e-3 * gmax * g64[n].numel() ** 0.5)
+            worst_p = max(worst_p, float((p.grad.detach().cpu().double() - g64[n]).norm()) / den)
+            worst_o = max(worst_o, float((g32[n] - g64[n]).norm()) / den)
+        assert worst_p < max(1e-3, 4.0 * worst_o), (worst_p, worst_o)
