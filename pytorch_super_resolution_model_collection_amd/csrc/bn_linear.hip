@@ -38,13 +38,14 @@ __global__ __launch_bounds__(256) void k_bn_colsum(const float* __restrict__ a, 
         va[u] = r < r1 ? a[r * C + c] : 0.f;
         if (MODE == 1) vx[u] = r < r1 ? x[r * C + c] : mu;
       }
-      // accumulate in double from the first add: the backward sums (sum dy, sum dy*xhat) of a BN that feeds
-      // another BN cancel to ~1e-4 of their absolute mass, so fp32 partial sums would cost 3 digits there
+      float f0 = 0.f, f1 = 0.f;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        s0 += (double)va[u];
-        s1 += MODE == 0 ? (double)va[u] * (double)va[u] : (double)va[u] * (double)((vx[u] - mu) * rs);
+        f0 += va[u];
+        f1 += MODE == 0 ? va[u] * va[u] : va[u] * ((vx[u] - mu) * rs);
       }
+      s0 += f0;
+      s1 += f1;
     }
   }
   sm[0][w][lane] = s0;

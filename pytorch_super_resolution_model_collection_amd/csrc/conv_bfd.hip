@@ -86,6 +86,8 @@ __device__ __forceinline__ void bfd_stage_halo_t(const BfdParams& B, uint4* hal,
   const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
   const int ch = cb + g * 8;
   const bool ch_any = ch < P.IC, ch_vec = P.vec_in && ch + 7 < P.IC;
+  const size_t img = (size_t)n * P.IH;
+  const InAddr ia = conv_in_addr(P, ch);
   for (int base = hp0; base < npix; base += PPP * BFD_STAGE_IT) {
     f32x4 v0[BFD_STAGE_IT], v1[BFD_STAGE_IT], m0[BFD_STAGE_IT], m1[BFD_STAGE_IT];
 #pragma unroll
@@ -99,7 +101,7 @@ __device__ __forceinline__ void bfd_stage_halo_t(const BfdParams& B, uint4* hal,
       const int hp = base + PPP * k;
       const int iy = iyb + hy, ix = ixb + hx;
       if (hp < npix && ch_any && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) {
-        const size_t off = conv_in_offset(P, n, iy, ix, ch);
+        const size_t off = (img + iy) * ia.sA + (size_t)ix * ia.sB + ia.K;
         if (ch_vec) {
           v0[k] = *reinterpret_cast<const f32x4*>(P.in + off);
           v1[k] = *reinterpret_cast<const f32x4*>(P.in + off + 4);

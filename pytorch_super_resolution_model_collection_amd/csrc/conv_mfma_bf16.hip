@@ -130,6 +130,8 @@ __device__ __forceinline__ void bf3_stage_halo_t(const Bf3Params& B, uint4* hal,
   const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
   const int ch = cb + g * 8;
   const bool ch_any = ch < P.IC, ch_vec = P.vec_in && ch + 7 < P.IC;
+  const size_t img = (size_t)n * P.IH;
+  const InAddr ia = conv_in_addr(P, ch);
   for (int base = hp0; base < npix; base += PPP * BF3_STAGE_IT) {
     f32x4 v0[BF3_STAGE_IT], v1[BF3_STAGE_IT], m0[BF3_STAGE_IT], m1[BF3_STAGE_IT];
     // pass 1: issue every load of this batch
@@ -144,7 +146,7 @@ __device__ __forceinline__ void bf3_stage_halo_t(const Bf3Params& B, uint4* hal,
       const int hp = base + PPP * k;
       const int iy = iyb + hy, ix = ixb + hx;
       if (hp < npix && ch_any && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) {
-        const size_t off = conv_in_offset(P, n, iy, ix, ch);
+        const size_t off = (img + iy) * ia.sA + (size_t)ix * ia.sB + ia.K;
         if (ch_vec) {
           v0[k] = *reinterpret_cast<const f32x4*>(P.in + off);
           v1[k] = *reinterpret_cast<const f32x4*>(P.in + off + 4);
@@ -256,8 +258,10 @@ __device__ __forceinline__ void bf3_epilogue(const MfmaConvParams& P, float* sme
   }
 }
 
+// NT <= 2 (the c2 benchmark's 64->32 layer) must stay within 168 VGPRs: three resident blocks per CU instead of two
+// is worth 25 % on that layer (0.64 vs 0.89 ms) — the bound makes the compiler hold the line when code is added.
 template <int NT, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void k_conv_bf3(Bf3Params B) {
+__global__ __launch_bounds__(64 * NW, (NT <= 2 && NW == 4) ? 3 : 2) void k_conv_bf3(Bf3Params B) {
   constexpr int NTHR = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   __shared__ int tap_toff[BF3_MAXTAPS];

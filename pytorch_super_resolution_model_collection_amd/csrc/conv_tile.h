@@ -32,13 +32,29 @@ struct MfmaConvParams {
   int in_ps_C;  // IC / r^2
 };
 
-// element offset of packed channel `ch` of input pixel (n, iy, ix)
-__device__ __forceinline__ size_t conv_in_offset(const MfmaConvParams& P, int n, int iy, int ix, int ch) {
-  if (P.in_ps_r <= 1) return (((size_t)n * P.IH + iy) * P.IW + ix) * P.IC + ch;
-  const int r = P.in_ps_r, C = P.in_ps_C;
-  const int q = ch / C, c = ch - q * C;
-  const int i = q / r, j = q - i * r;
-  return ((((size_t)n * P.IH + iy) * r + i) * ((size_t)P.IW * r) + (size_t)ix * r + j) * C + c;
+// Input addressing of the halo staging loops as an affine map with loop-invariant terms:
+//   offset(n, iy, ix, ch) = (n*IH + iy) * sA + ix * sB + K(ch)
+// plain NHWC: sA = IW*IC, sB = IC, K = ch;  pixel-shuffled [N, IH*r, IW*r, C] (packed channel ch = (i*r + j)*C + c
+// lives at (iy*r + i, ix*r + j, c)): sA = r*IW*r*C, sB = r*C, K = i*IW*r*C + j*C + c.  sA / sB are wave-uniform,
+// K is one per-thread value, so the pixel-shuffled case costs no registers in the loops.
+struct InAddr {
+  size_t sA, sB, K;
+};
+__device__ __forceinline__ InAddr conv_in_addr(const MfmaConvParams& P, int ch) {
+  InAddr a;
+  if (P.in_ps_r <= 1) {
+    a.sA = (size_t)P.IW * P.IC;
+    a.sB = (size_t)P.IC;
+    a.K = (size_t)ch;
+  } else {
+    const int r = P.in_ps_r, C = P.in_ps_C;
+    const int q = ch / C, c = ch - q * C;
+    const int i = q / r, j = q - i * r;
+    a.sB = (size_t)r * C;
+    a.sA = (size_t)r * P.IW * a.sB;
+    a.K = (size_t)i * P.IW * a.sB + (size_t)j * C + c;
+  }
+  return a;
 }
 
 static constexpr int kLdsBudgetBytes = 78 * 1024;  // 2 blocks per CU out of 160 KiB
