@@ -174,6 +174,7 @@ __device__ __forceinline__ void bfd_epilogue(const MfmaConvParams& P, float* sme
   const int tw_magic = div_small_magic(P.TW);
   EpiCol col{};
   if (lane_on) col = epi_col_setup(P.ep, P.OW, P.OC, oc4);
+  const EpiTile et = epi_tile_setup(P, n, r0, c0);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -193,7 +194,10 @@ __device__ __forceinline__ void bfd_epilogue(const MfmaConvParams& P, float* sme
           const int pr = r0 + r, pc = c0 + c;
           if (pr < P.PH && pc < P.PW) {
             const epi_f4 v = *reinterpret_cast<const epi_f4*>(st + row * BFD_EPI_STRIDE + q4 * 4);
-            epi_store4_col(P.ep, col, P.OH, P.OW, P.OC, n, P.oy0 + pr * P.os, P.ox0 + pc * P.os, v, P.out);
+            if (col.vec)
+              epi_store4_tile(P.ep, col, et, r, c, v, P.out);
+            else
+              epi_store4_col(P.ep, col, P.OH, P.OW, P.OC, n, P.oy0 + pr * P.os, P.ox0 + pc * P.os, v, P.out);
           }
         }
       }

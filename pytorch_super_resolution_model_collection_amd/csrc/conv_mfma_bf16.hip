@@ -230,6 +230,7 @@ __device__ __forceinline__ void bf3_epilogue(const MfmaConvParams& P, float* sme
   const int tw_magic = div_small_magic(P.TW);
   EpiCol col{};
   if (lane_on) col = epi_col_setup(P.ep, P.OW, P.OC, oc4);
+  const EpiTile et = epi_tile_setup(P, n, r0, c0);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -249,7 +250,10 @@ __device__ __forceinline__ void bf3_epilogue(const MfmaConvParams& P, float* sme
           const int pr = r0 + r, pc = c0 + c;
           if (pr < P.PH && pc < P.PW) {
             const epi_f4 v = *reinterpret_cast<const epi_f4*>(st + row * BF3_EPI_STRIDE + q4 * 4);
-            epi_store4_col(P.ep, col, P.OH, P.OW, P.OC, n, P.oy0 + pr * P.os, P.ox0 + pc * P.os, v, P.out);
+            if (col.vec)
+              epi_store4_tile(P.ep, col, et, r, c, v, P.out);
+            else
+              epi_store4_col(P.ep, col, P.OH, P.OW, P.OC, n, P.oy0 + pr * P.os, P.ox0 + pc * P.os, v, P.out);
           }
         }
       }
@@ -264,8 +268,6 @@ template <int NT, int NW>
 __global__ __launch_bounds__(64 * NW, (NT <= 2 && NW == 4) ? 3 : 2) void k_conv_bf3(Bf3Params B) {
   constexpr int NTHR = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
-  __shared__ int tap_toff[BF3_MAXTAPS];
-  __shared__ int tap_wtap[BF3_MAXTAPS];
   const MfmaConvParams& P = B.P;
   uint4* hal = smem4;                       // [2][4][NPIXp]
   uint4* wl = smem4 + 8 * B.NPIXp;          // [2 bufs][2][4][NB]
@@ -284,19 +286,16 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 && NW == 4) ? 3 : 2) void k_conv_
   const int wslot = 8 * NB;  // uint4 per weight buffer
   const int T = P.KHv * P.KWv;
 
-  for (int t = tid; t < T && t < BF3_MAXTAPS; t += NTHR) {
-    const int u = t / P.KWv, v = t - u * P.KWv;
-    tap_toff[t] = u * P.HW + v;
-    tap_wtap[t] = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
-  }
-
   int hp[4];
+  {
+    const int tw_magic = div_small_magic(P.TW);
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    int m = wave * 64 + mt * 16 + j;
-    if (m >= npx) m = 0;
-    const int r = m / P.TW, c = m - r * P.TW;
-    hp[mt] = (r * P.is) * P.HW + c * P.is + kq * B.NPIXp;
+    for (int mt = 0; mt < 4; ++mt) {
+      int m = wave * 64 + mt * 16 + j;
+      if (m >= npx) m = 0;
+      const int r = div_small(m, tw_magic), c = m - r * P.TW;
+      hp[mt] = (r * P.is) * P.HW + c * P.is + kq * B.NPIXp;
+    }
   }
   f32x4 acc[4][NT];
 #pragma unroll
@@ -308,46 +307,38 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 && NW == 4) ? 3 : 2) void k_conv_
   constexpr int WCP = 512 / NTHR;  // weight-slice uint4 per thread (wslot <= 512)
   const int lo_plane = 4 * B.NPIXp;
   const int wlane = kq * NB + j;
+  // tap walk kept in scalar registers: (u, v) -> halo offset u*HW + v and weight tap (wh0 + wdh*u)*KW_full + ww0 + wdw*v
+  const int wtap_row = P.wdh * P.KW_full - P.wdw * P.KWv;  // weight-tap step at a row wrap (added to the +wdw step)
+  const size_t wtap_stride = (size_t)B.ICc * B.OCb * (size_t)wslot;
 
   if (T > 0) {
     for (int cc = 0; cc < B.ICc; ++cc) {
-      __syncthreads();  // previous chunk fully consumed (and the tap tables visible)
-      auto wsrc = [&](int t) -> const uint4* {
-        int tapw;
-        if (t < BF3_MAXTAPS) {
-          tapw = tap_wtap[t];
-        } else {
-          const int u = t / P.KWv, v = t - u * P.KWv;
-          tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
-        }
-        return B.wq + ((size_t)(tapw * B.ICc + cc) * B.OCb + ocbi) * (size_t)wslot;
-      };
+      __syncthreads();  // previous chunk fully consumed
+      const uint4* wbase = B.wq + ((size_t)cc * B.OCb + ocbi) * (size_t)wslot;
+      int wtap = P.wh0 * P.KW_full + P.ww0;  // weight tap of (u, v) = (0, 0)
       if (!(B.dbg & 1)) bf3_stage_halo<NTHR>(B, hal, n, r0, c0, cc * 32);
       {
-        const uint4* src = wsrc(0);
+        const uint4* src = wbase + (size_t)wtap * wtap_stride;
 #pragma unroll
         for (int c = 0; c < WCP; ++c)
           if (tid + c * NTHR < wslot) wl[tid + c * NTHR] = src[tid + c * NTHR];
       }
       __syncthreads();
+      int toff = 0, tv = 0;
       for (int t = 0; t < T; ++t) {
+        // next tap's weight index (row wrap when v reaches KWv)
+        int wnext = wtap + P.wdw;
+        if (tv + 1 == P.KWv) wnext += wtap_row;
         uint4 wr[WCP];
 #pragma unroll
         for (int c = 0; c < WCP; ++c) wr[c] = make_uint4(0, 0, 0, 0);
         if (t + 1 < T && !(B.dbg & 8)) {  // prefetch the next tap's slice; lands while the MFMAs below run
-          const uint4* src = wsrc(t + 1);
+          const uint4* src = wbase + (size_t)wnext * wtap_stride;
 #pragma unroll
           for (int c = 0; c < WCP; ++c)
             if (tid + c * NTHR < wslot) wr[c] = src[tid + c * NTHR];
         }
         if (wave_live && !(B.dbg & 4)) {
-          int toff;
-          if (t < BF3_MAXTAPS) {
-            toff = tap_toff[t];
-          } else {
-            const int u = t / P.KWv, v = t - u * P.KWv;
-            toff = u * P.HW + v;
-          }
           const uint4* wb = wl + (t & 1) * wslot + wlane;
           const uint4* hb = hal + toff;
           uint4 ah[4], al[4];
@@ -381,6 +372,13 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 && NW == 4) ? 3 : 2) void k_conv_
 #pragma unroll
           for (int c = 0; c < WCP; ++c)
             if (tid + c * NTHR < wslot) wn[tid + c * NTHR] = wr[c];
+        }
+        // advance the tap walk
+        wtap = wnext;
+        ++toff;
+        if (++tv == P.KWv) {
+          tv = 0;
+          toff += P.HW - P.KWv;
         }
         __syncthreads();
       }

@@ -266,6 +266,44 @@ __device__ __forceinline__ void epi_store4_col(const Epi& ep, const EpiCol& col,
   }
 }
 
+// Tile-affine output addressing for the LDS-staged epilogues: the element offset of output pixel (r, c) of the
+// block's tile is off0 + r*RS + c*CS (+ the lane's channel offset), with off0 computed once per tile from
+// wave-uniform values and RS / CS 32-bit — no 64-bit multiplies per store.
+struct EpiTile {
+  size_t off0;
+  int RS, CS;
+};
+
+__device__ __forceinline__ EpiTile epi_tile_setup(const MfmaConvParams& P, int n, int r0, int c0) {
+  EpiTile t;
+  const int oy = P.oy0 + r0 * P.os, ox = P.ox0 + c0 * P.os;
+  if (P.ep.ps_r > 1) {
+    const int r = P.ep.ps_r;
+    const int C = P.OC / (r * r);
+    t.off0 = ((((size_t)n * P.OH + oy) * r) * ((size_t)P.OW * r) + (size_t)ox * r) * C;
+    t.CS = P.os * r * C;
+    t.RS = P.os * r * P.OW * r * C;
+  } else {
+    t.off0 = (((size_t)n * P.OH + oy) * P.OW + ox) * P.OC;
+    t.CS = P.os * P.OC;
+    t.RS = P.os * P.OW * P.OC;
+  }
+  return t;
+}
+
+// vector path of epi_store4_col (col.vec must hold) for tile pixel (r, c)
+__device__ __forceinline__ void epi_store4_tile(const Epi& ep, const EpiCol& col, const EpiTile& t, int r, int c,
+                                                epi_f4 v, float* __restrict__ out) {
+  const size_t off = t.off0 + col.off_oc + (size_t)(unsigned)(r * t.RS + c * t.CS);
+  v += col.bias;
+  if (ep.act != SRK_ACT_NONE) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], ep.act, col.slope);
+  }
+  if (ep.residual) v += *reinterpret_cast<const epi_f4*>(ep.residual + off);
+  *reinterpret_cast<epi_f4*>(out + off) = v;
+}
+
 // Exact floor(m / d) for 0 <= m < 256, 1 <= d <= 256 with one multiply (magic = ceil(65536 / d)).
 __host__ __device__ __forceinline__ int div_small_magic(int d) { return (65536 + d - 1) / d; }
 __device__ __forceinline__ int div_small(int m, int magic) { return (m * magic) >> 16; }
