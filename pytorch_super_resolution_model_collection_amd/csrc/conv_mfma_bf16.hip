@@ -215,7 +215,10 @@ constexpr int BF3_EPI_STRIDE = 68; // floats per staged output row (64 + 4: conf
 // the MFMA layout — 64-byte segments of 16 different pixels per instruction — measured 2x slower on
 // the epilogue: partial-line HBM writes.)  C/D layout: col = lane&15 (channel), row = (lane>>4)*4+reg
 // (pixel).  Everything that depends only on the lane's channel group is hoisted (EpiCol).
-template <int NT>
+// VEC_ONLY: the host guarantees that every lane's 4-channel group takes the 16-byte store path (epi_all_vector), so
+// the scalar fallback — and the integer divisions of its index math that the compiler hoists in front of the store
+// loop — is not compiled into the kernel.
+template <int NT, bool VEC_ONLY = false>
 __device__ __forceinline__ void bf3_epilogue(const MfmaConvParams& P, float* smem_f, const f32x4 (&acc)[4][NT], int n,
                                              int r0, int c0, int ocb, int wave, int lane) {
   const int j = lane & 15, kq = lane >> 4;
@@ -250,7 +253,7 @@ __device__ __forceinline__ void bf3_epilogue(const MfmaConvParams& P, float* sme
           const int pr = r0 + r, pc = c0 + c;
           if (pr < P.PH && pc < P.PW) {
             const epi_f4 v = *reinterpret_cast<const epi_f4*>(st + row * BF3_EPI_STRIDE + q4 * 4);
-            if (col.vec)
+            if (VEC_ONLY || col.vec)
               epi_store4_tile(P.ep, col, et, r, c, v, P.out);
             else
               epi_store4_col(P.ep, col, P.OH, P.OW, P.OC, n, P.oy0 + pr * P.os, P.ox0 + pc * P.os, v, P.out);
@@ -264,7 +267,7 @@ __device__ __forceinline__ void bf3_epilogue(const MfmaConvParams& P, float* sme
 
 // NT <= 2 (the c2 benchmark's 64->32 layer) must stay within 168 VGPRs: three resident blocks per CU instead of two
 // is worth 25 % on that layer (0.64 vs 0.89 ms) — the bound makes the compiler hold the line when code is added.
-template <int NT, int NW>
+template <int NT, int NW, bool VEC_ONLY = false>
 __global__ __launch_bounds__(64 * NW, (NT <= 2 && NW == 4) ? 3 : 2) void k_conv_bf3(Bf3Params B) {
   constexpr int NTHR = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 && NW == 4) ? 3 : 2) void k_conv_
     if (acc[0][0][0] == 123.456f) P.out[0] = 1.f;  // keep the accumulators live
     return;
   }
-  bf3_epilogue<NT>(P, reinterpret_cast<float*>(smem4), acc, n, r0, c0, ocb, wave, lane);
+  bf3_epilogue<NT, VEC_ONLY>(P, reinterpret_cast<float*>(smem4), acc, n, r0, c0, ocb, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -598,6 +601,24 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3_rows(Bf3Params B) {
 // ---------------------------------------------------------------------------------------------
 // Host
 // ---------------------------------------------------------------------------------------------
+template <int NT>
+static void bf3_launch_vec(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s) {
+  static int cur = 0;
+  if ((int)lds > cur) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bf3<NT, 4, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    cur = (int)lds;
+  }
+  if (B.dbg & 32) {
+    int nb = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_conv_bf3<NT, 4, true>), 256,
+                                                       lds);
+    fprintf(stderr, "[srk] k_conv_bf3<%d,4,vec>: lds %zu B, grid %u x %u, occupancy %d blocks/CU, tile %dx%d halo %dx%d\n", NT,
+            lds, grid.x, grid.y, nb, B.P.TH, B.P.TW, B.P.HH, B.P.HW);
+  }
+  hipLaunchKernelGGL((k_conv_bf3<NT, 4, true>), grid, dim3(256), lds, s, B);
+}
+
 template <int NT, int NW>
 static void bf3_launch(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s) {
   static int cur = 0;
@@ -698,6 +719,14 @@ static int bf3_launch_phase_nw(MfmaConvParams P, Bf3Params B, int NT, int dbg, h
   if (lds < epi_bytes) lds = epi_bytes;
   if (dbg & 64) lds = 100 * 1024;  // experiment: force 1 block per CU
   dim3 grid((unsigned)((size_t)P.tiles_x * P.tiles_y * P.N), B.OCb);
+  if (NW == 4 && NT >= 2 && P.OC % 16 == 0 && epi_all_vector(P)) {  // full 16-channel tiles, vector stores everywhere
+    switch (NT) {
+      case 2: bf3_launch_vec<2>(B, grid, lds, s); break;
+      case 3: bf3_launch_vec<3>(B, grid, lds, s); break;
+      default: bf3_launch_vec<4>(B, grid, lds, s); break;
+    }
+    return check_launch("conv_bf3");
+  }
   switch (NT) {
     case 1: bf3_launch<1, NW>(B, grid, lds, s); break;
     case 2: bf3_launch<2, NW>(B, grid, lds, s); break;
