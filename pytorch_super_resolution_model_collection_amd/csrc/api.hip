@@ -81,7 +81,7 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
       set_error("%s: pixel-shuffled dy is only supported by the bf16x3 kernels (un-shuffle with srk_pixel_shuffle_backward)", who);
       return SRK_ERR_UNSUPPORTED;
     }
-    if (conv_bfd_gather_supported(g, ep) && conv_bfd_small_problem(g))
+    if (conv_bfd_gather_supported(g, ep) && conv_epi_all_vector(g.OC, ep, out) && conv_bfd_small_problem(g))
       return conv_bfd_gather(g, in, wp, out, ep, mask_y, mask_slope, 2, s);
     return conv_bf3_gather(g, in, wp, out, ep, mask_y, mask_slope, s);
   }
@@ -95,7 +95,8 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
     set_error("%s: MFMA kernel does not cover this shape", who);
     return SRK_ERR_UNSUPPORTED;
   }
-  const bool bfd_ok = conv_bfd_gather_supported(g, ep);
+  // the bfd / bfr kernels are compiled without the scalar store fallback
+  const bool bfd_ok = conv_bfd_gather_supported(g, ep) && conv_epi_all_vector(g.OC, ep, out);
   if (algo == SRK_ALGO_MFMA_BF16X6) {  // fp32-faithful class: bf16x6 where it applies, else the exact fp32 kernels
     if (bfd_ok && !direct_ok) return conv_bfd_gather(g, in, wp, out, ep, mask_y, mask_slope, 3, s);
     algo = SRK_ALGO_MFMA;

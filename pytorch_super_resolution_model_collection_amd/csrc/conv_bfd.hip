@@ -194,10 +194,9 @@ __device__ __forceinline__ void bfd_epilogue(const MfmaConvParams& P, float* sme
           const int pr = r0 + r, pc = c0 + c;
           if (pr < P.PH && pc < P.PW) {
             const epi_f4 v = *reinterpret_cast<const epi_f4*>(st + row * BFD_EPI_STRIDE + q4 * 4);
-            if (col.vec)
-              epi_store4_tile(P.ep, col, et, r, c, v, P.out);
-            else
-              epi_store4_col(P.ep, col, P.OH, P.OW, P.OC, n, P.oy0 + pr * P.os, P.ox0 + pc * P.os, v, P.out);
+            // vector path only: the host routes layers that could need the scalar fallback to other kernels
+            // (conv_epi_all_vector), which keeps its hoisted index divisions out of these kernels
+            epi_store4_tile(P.ep, col, et, r, c, v, P.out);
           }
         }
       }

@@ -91,6 +91,22 @@ int conv_mfma_gather(const GatherConv& g, const float* in, const float* wp, floa
 size_t bf3_prepared_offset(size_t elems);
 size_t bf3_prepared_bytes(int IC, int OC, int T);
 size_t bf3_main_bytes(int IC, int OC, int T);
+// True when every 4-channel group of the layer's output takes the 16-byte store path of the LDS-staged epilogues
+// (mirror of epi_col_setup's test): kernels compiled without the scalar store fallback require it.
+static inline bool conv_epi_all_vector(int OC, const Epi& ep, const float* out) {
+  if (OC % 4 != 0) return false;
+  if (ep.act == SRK_ACT_PRELU && ep.prelu_n > 1) return false;
+  if (((uintptr_t)out % 16) != 0 || (ep.bias && ((uintptr_t)ep.bias % 16) != 0) ||
+      (ep.residual && ((uintptr_t)ep.residual % 16) != 0))
+    return false;
+  if (ep.ps_r > 1) {
+    const int r = ep.ps_r;
+    if (OC % (r * r) != 0) return false;
+    if ((r * (OC / (r * r))) % 4 != 0) return false;
+  }
+  return true;
+}
+
 // conv_bfd.hip: filters straight from global memory; planes 2 = bf16x3, 3 = bf16x6 (fp32-faithful)
 bool conv_bfd_gather_supported(const GatherConv& g, const Epi& ep);
 bool conv_bfd_small_problem(const GatherConv& g);

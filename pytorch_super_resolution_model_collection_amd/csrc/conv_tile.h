@@ -268,21 +268,7 @@ __device__ __forceinline__ void epi_store4_col(const Epi& ep, const EpiCol& col,
 
 // Host-side mirror of epi_col_setup's `vec` test for EVERY 4-channel group of the layer: true when no lane can need
 // the scalar fallback (then kernels compiled without it may be used).
-static inline bool epi_all_vector(const MfmaConvParams& P) {
-  const Epi& ep = P.ep;
-  if (P.OC % 4 != 0) return false;
-  if (ep.act == SRK_ACT_PRELU && ep.prelu_n > 1) return false;
-  if (((uintptr_t)P.out % 16) != 0 || (ep.bias && ((uintptr_t)ep.bias % 16) != 0) ||
-      (ep.residual && ((uintptr_t)ep.residual % 16) != 0))
-    return false;
-  if (ep.ps_r > 1) {
-    const int r = ep.ps_r;
-    if (P.OC % (r * r) != 0) return false;
-    const int RL = r * (P.OC / (r * r));
-    if (RL % 4 != 0) return false;
-  }
-  return true;
-}
+static inline bool epi_all_vector(const MfmaConvParams& P) { return conv_epi_all_vector(P.OC, P.ep, P.out); }
 
 // Tile-affine output addressing for the LDS-staged epilogues: the element offset of output pixel (r, c) of the
 // block's tile is off0 + r*RS + c*CS (+ the lane's channel offset), with off0 computed once per tile from
