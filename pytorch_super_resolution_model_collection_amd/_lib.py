@@ -11,7 +11,7 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrk.so")
+LIB_PATH = os.environ.get("SRK_LIB_PATH") or os.path.join(_HERE, "libsrk.so")  # env override: A/B kernel builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "srk.h")
 
 # enums mirrored from include/srk.h

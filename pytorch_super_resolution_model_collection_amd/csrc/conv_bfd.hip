@@ -86,8 +86,10 @@ __device__ __forceinline__ void bfd_stage_halo_t(const BfdParams& B, uint4* hal,
   const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
   const int ch = cb + g * 8;
   const bool ch_any = ch < P.IC, ch_vec = P.vec_in && ch + 7 < P.IC;
-  const size_t img = (size_t)n * P.IH;
   const InAddr ia = conv_in_addr(P, ch);
+  const size_t img_off = (size_t)n * P.IH * ia.sA;  // wave-uniform: scalar base pointers
+  const float* __restrict__ inb = P.in + img_off;
+  const float* __restrict__ mkb = MASK ? P.mask_y + img_off : nullptr;
   for (int base = hp0; base < npix; base += PPP * BFD_STAGE_IT) {
     f32x4 v0[BFD_STAGE_IT], v1[BFD_STAGE_IT], m0[BFD_STAGE_IT], m1[BFD_STAGE_IT];
 #pragma unroll
@@ -100,25 +102,25 @@ __device__ __forceinline__ void bfd_stage_halo_t(const BfdParams& B, uint4* hal,
       }
       const int hp = base + PPP * k;
       const int iy = iyb + hy, ix = ixb + hx;
-      if (hp < npix && ch_any && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) {
-        const size_t off = (img + iy) * ia.sA + (size_t)ix * ia.sB + ia.K;
+      if (hp < npix && ch_any && (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW) {
+        const unsigned off = (unsigned)iy * ia.sA + (unsigned)ix * ia.sB + ia.K;
         if (ch_vec) {
-          v0[k] = *reinterpret_cast<const f32x4*>(P.in + off);
-          v1[k] = *reinterpret_cast<const f32x4*>(P.in + off + 4);
+          v0[k] = *reinterpret_cast<const f32x4*>(inb + off);
+          v1[k] = *reinterpret_cast<const f32x4*>(inb + off + 4);
           if (MASK) {
-            m0[k] = *reinterpret_cast<const f32x4*>(P.mask_y + off);
-            m1[k] = *reinterpret_cast<const f32x4*>(P.mask_y + off + 4);
+            m0[k] = *reinterpret_cast<const f32x4*>(mkb + off);
+            m1[k] = *reinterpret_cast<const f32x4*>(mkb + off + 4);
           }
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             if (ch + e < P.IC) {
-              v0[k][e] = P.in[off + e];
-              if (MASK) m0[k][e] = P.mask_y[off + e];
+              v0[k][e] = inb[off + e];
+              if (MASK) m0[k][e] = mkb[off + e];
             }
             if (ch + 4 + e < P.IC) {
-              v1[k][e] = P.in[off + 4 + e];
-              if (MASK) m1[k][e] = P.mask_y[off + 4 + e];
+              v1[k][e] = inb[off + 4 + e];
+              if (MASK) m1[k][e] = mkb[off + 4 + e];
             }
           }
         }
@@ -651,6 +653,7 @@ bool conv_bfd_gather_supported(const GatherConv& g, const Epi& ep) {
   if (g.OC < 8 || g.IC < 8) return false;
   if (g.KH * g.KW > 32 * 32) return false;
   if ((long)g.N * g.OH * g.OW > (1L << 30)) return false;
+  if ((long)g.IH * g.IW * g.IC >= (1L << 30)) return false;  // 32-bit in-image offsets in the staging loops
   return true;
 }
 

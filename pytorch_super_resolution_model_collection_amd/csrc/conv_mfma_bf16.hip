@@ -130,8 +130,10 @@ __device__ __forceinline__ void bf3_stage_halo_t(const Bf3Params& B, uint4* hal,
   const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
   const int ch = cb + g * 8;
   const bool ch_any = ch < P.IC, ch_vec = P.vec_in && ch + 7 < P.IC;
-  const size_t img = (size_t)n * P.IH;
   const InAddr ia = conv_in_addr(P, ch);
+  const size_t img_off = (size_t)n * P.IH * ia.sA;  // wave-uniform: scalar base pointers
+  const float* __restrict__ inb = P.in + img_off;
+  const float* __restrict__ mkb = MASK ? P.mask_y + img_off : nullptr;
   for (int base = hp0; base < npix; base += PPP * BF3_STAGE_IT) {
     f32x4 v0[BF3_STAGE_IT], v1[BF3_STAGE_IT], m0[BF3_STAGE_IT], m1[BF3_STAGE_IT];
     // pass 1: issue every load of this batch
@@ -145,25 +147,25 @@ __device__ __forceinline__ void bf3_stage_halo_t(const Bf3Params& B, uint4* hal,
       }
       const int hp = base + PPP * k;
       const int iy = iyb + hy, ix = ixb + hx;
-      if (hp < npix && ch_any && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) {
-        const size_t off = (img + iy) * ia.sA + (size_t)ix * ia.sB + ia.K;
+      if (hp < npix && ch_any && (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW) {
+        const unsigned off = (unsigned)iy * ia.sA + (unsigned)ix * ia.sB + ia.K;
         if (ch_vec) {
-          v0[k] = *reinterpret_cast<const f32x4*>(P.in + off);
-          v1[k] = *reinterpret_cast<const f32x4*>(P.in + off + 4);
+          v0[k] = *reinterpret_cast<const f32x4*>(inb + off);
+          v1[k] = *reinterpret_cast<const f32x4*>(inb + off + 4);
           if (MASK) {
-            m0[k] = *reinterpret_cast<const f32x4*>(P.mask_y + off);
-            m1[k] = *reinterpret_cast<const f32x4*>(P.mask_y + off + 4);
+            m0[k] = *reinterpret_cast<const f32x4*>(mkb + off);
+            m1[k] = *reinterpret_cast<const f32x4*>(mkb + off + 4);
           }
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             if (ch + e < P.IC) {
-              v0[k][e] = P.in[off + e];
-              if (MASK) m0[k][e] = P.mask_y[off + e];
+              v0[k][e] = inb[off + e];
+              if (MASK) m0[k][e] = mkb[off + e];
             }
             if (ch + 4 + e < P.IC) {
-              v1[k][e] = P.in[off + 4 + e];
-              if (MASK) m1[k][e] = P.mask_y[off + 4 + e];
+              v1[k][e] = inb[off + 4 + e];
+              if (MASK) m1[k][e] = mkb[off + 4 + e];
             }
           }
         }
@@ -465,7 +467,7 @@ int pack_weights_batched(const float* params, void* packed, const long long* tab
   return check_launch("pack_weights_batched");
 }
 
-template <int NT>
+template <int NT, bool VEC_ONLY = false>
 __global__ __launch_bounds__(256, 2) void k_conv_bf3_rows(Bf3Params B) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   const MfmaConvParams& P = B.P;
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3_rows(Bf3Params B) {
       }
     }
   }
-  bf3_epilogue<NT>(P, reinterpret_cast<float*>(smem4), acc, n, r0, c0, ocb, wave, lane);
+  bf3_epilogue<NT, VEC_ONLY>(P, reinterpret_cast<float*>(smem4), acc, n, r0, c0, ocb, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -643,18 +645,26 @@ bool conv_bf3_gather_supported(const GatherConv& g, const Epi& ep) {
   if (g.IC < 8 && !(g.IC <= 4 && !g.trans)) return false;  // small IC: row-packed variant, CONV gathers only
   if (g.KH * g.KW > 32 * 32) return false;
   if ((long)g.N * g.OH * g.OW > (1L << 30)) return false;
+  if ((long)g.IH * g.IW * g.IC >= (1L << 30)) return false;  // 32-bit in-image offsets in the staging loops
   return true;
 }
 
-template <int NT>
-static void bf3_launch_rows(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s) {
+template <int NT, bool VEC_ONLY>
+static void bf3_launch_rows_v(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s) {
   static int cur = 0;
   if ((int)lds > cur) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bf3_rows<NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bf3_rows<NT, VEC_ONLY>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     cur = (int)lds;
   }
-  hipLaunchKernelGGL(k_conv_bf3_rows<NT>, grid, dim3(256), lds, s, B);
+  hipLaunchKernelGGL((k_conv_bf3_rows<NT, VEC_ONLY>), grid, dim3(256), lds, s, B);
+}
+template <int NT>
+static void bf3_launch_rows(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s) {
+  if (B.P.OC % 16 == 0 && epi_all_vector(B.P))
+    bf3_launch_rows_v<NT, true>(B, grid, lds, s);
+  else
+    bf3_launch_rows_v<NT, false>(B, grid, lds, s);
 }
 
 static int bf3_launch_rows_phase(MfmaConvParams P, const uint4* wq, hipStream_t s) {

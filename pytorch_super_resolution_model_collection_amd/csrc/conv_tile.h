@@ -38,21 +38,21 @@ struct MfmaConvParams {
 // lives at (iy*r + i, ix*r + j, c)): sA = r*IW*r*C, sB = r*C, K = i*IW*r*C + j*C + c.  sA / sB are wave-uniform,
 // K is one per-thread value, so the pixel-shuffled case costs no registers in the loops.
 struct InAddr {
-  size_t sA, sB, K;
+  unsigned sA, sB, K;  // element units; one image holds < 2^30 elements (checked by the *_supported functions)
 };
 __device__ __forceinline__ InAddr conv_in_addr(const MfmaConvParams& P, int ch) {
   InAddr a;
   if (P.in_ps_r <= 1) {
-    a.sA = (size_t)P.IW * P.IC;
-    a.sB = (size_t)P.IC;
-    a.K = (size_t)ch;
+    a.sA = (unsigned)(P.IW * P.IC);
+    a.sB = (unsigned)P.IC;
+    a.K = (unsigned)ch;
   } else {
     const int r = P.in_ps_r, C = P.in_ps_C;
     const int q = ch / C, c = ch - q * C;
     const int i = q / r, j = q - i * r;
-    a.sB = (size_t)r * C;
-    a.sA = (size_t)r * P.IW * a.sB;
-    a.K = (size_t)i * P.IW * a.sB + (size_t)j * C + c;
+    a.sB = (unsigned)(r * C);
+    a.sA = (unsigned)(r * P.IW) * a.sB;
+    a.K = (unsigned)(i * P.IW) * a.sB + (unsigned)(j * C + c);
   }
   return a;
 }
