@@ -60,31 +60,34 @@ __device__ __forceinline__ f32x4 wb_mfma(const uint4& a, const uint4& b, f32x4 c
 
 __device__ __forceinline__ unsigned short wb_bits(__bf16 v) { return __builtin_bit_cast(unsigned short, v); }
 
-// two horizontally adjacent pixels x 4 channels (fp32) -> 4 channels x {hi, lo} dwords (pixel pair packed)
+// two horizontally adjacent pixels x 4 channels (fp32) -> 4 channels x {hi, lo} dwords (pixel pair packed):
+// one v_cvt_pk_bf16_f32 per (channel, plane) produces the packed pair directly
+typedef __bf16 wb_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float wb_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void wb_split_pair(const f32x4& p0, const f32x4& p1, unsigned (&hi)[4], unsigned (&lo)[4]) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const __bf16 h0 = (__bf16)p0[c], h1 = (__bf16)p1[c];
-    const __bf16 l0 = (__bf16)(p0[c] - (float)h0), l1 = (__bf16)(p1[c] - (float)h1);
-    hi[c] = (unsigned)wb_bits(h0) | ((unsigned)wb_bits(h1) << 16);
-    lo[c] = (unsigned)wb_bits(l0) | ((unsigned)wb_bits(l1) << 16);
+    const wb_f32x2 v = {p0[c], p1[c]};
+    const wb_bf16x2 h = __builtin_convertvector(v, wb_bf16x2);
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    const wb_f32x2 hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+    const wb_bf16x2 l = __builtin_convertvector(v - hf, wb_bf16x2);
+    hi[c] = hb;
+    lo[c] = __builtin_bit_cast(unsigned, l);
   }
 }
 
-// Load 4 channels [ch, ch+4) of pixel (n, iy, ix) of an NHWC tensor (zero outside the image / channel range),
-// optionally masked by the ReLU-family gradient of `mask`.
+// Exact floor(m / d) for 0 <= m < 2^20 / d with one multiply (magic = ceil(2^20 / d)): pixel-pair counters of a tile
+__host__ __device__ __forceinline__ unsigned wb_magic20(int d) { return (unsigned)(((1u << 20) + d - 1) / d); }
+__device__ __forceinline__ int wb_div20(int m, unsigned magic) { return (int)(((unsigned)m * magic) >> 20); }
+
+// Load 4 channels at element offset `off` from the (wave-uniform) image base `src`; `ok` = inside the image and
+// channel range.  `mask` (same offsets) applies the ReLU-family gradient.  vec = 16-byte path legal.
 __device__ __forceinline__ f32x4 wb_load4(const float* __restrict__ src, const float* __restrict__ mask, float mslope,
-                                          int n, int H, int W, int C, int iy, int ix, int ch, int vec, int ps_r = 0,
-                                          int ps_C = 0) {
+                                          unsigned off, bool ok, int nch, int vec) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (iy >= 0 && iy < H && ix >= 0 && ix < W && ch < C) {
-    size_t off = (((size_t)n * H + iy) * W + ix) * C + ch;
-    if (ps_r > 1) {  // packed channel (i, j, c) of pixel (iy, ix) lives at (iy*r + i, ix*r + j, c)
-      const int q = ch / ps_C, c = ch - q * ps_C;
-      const int i = q / ps_r, j = q - i * ps_r;
-      off = ((((size_t)n * H + iy) * ps_r + i) * ((size_t)W * ps_r) + (size_t)ix * ps_r + j) * ps_C + c;
-    }
-    if (vec && ch + 3 < C) {
+  if (ok) {
+    if (vec && nch >= 4) {
       v = *reinterpret_cast<const f32x4*>(src + off);
       if (mask) {
         const f32x4 m = *reinterpret_cast<const f32x4*>(mask + off);
@@ -94,7 +97,7 @@ __device__ __forceinline__ f32x4 wb_load4(const float* __restrict__ src, const f
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (ch + e < C) {
+        if (e < nch) {
           float t = src[off + e];
           if (mask) t = mask[off + e] > 0.f ? t : t * mslope;
           v[e] = t;
@@ -159,49 +162,78 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf(WgBfParams P) {
     const int n = b / P.tiles_y;
     const int r0 = tyi * P.TH, c0 = txi * P.TW;
     __syncthreads();  // previous tile fully consumed (tables / zero octets visible on the first pass)
-    {  // X halo: rows [r0-pad, +HH), cols [c0-pad, +HWp), channels [cib, cib+CIB) -> planes [ci][hy][hx]
-      constexpr int QN = CIB / 4;
+    {  // X halo: rows [r0-pad, +HH), cols [c0-pad, +TW+KW-1), channels [cib, cib+CIB) -> planes [ci][hy][hx]
+      // A thread's channel group q is fixed (256 % QN == 0): it walks pixel pairs pp, pp + 256/QN, ...
+      constexpr int QN = CIB / 4, PSTEP = 256 / QN;
       // only the TW + KW - 1 columns the fragments can touch are loaded (the plane row stride HWp = TW + 8 is for
       // the 16-byte alignment of the octets)
       const int need2 = (P.TW + P.KW) >> 1;
-      const int items = P.HH * need2 * QN;
+      const unsigned need2_magic = wb_magic20(need2);
+      const int npairs = P.HH * need2;
       const int by0 = r0 - P.pad, bx0 = c0 - P.pad;
-      for (int it = tid; it < items; it += 256) {
-        const int q = it % QN, pp = it / QN;
-        const int hy = pp / need2, hx = (pp - hy * need2) * 2;
-        const int ch = cib + q * 4;
-        const f32x4 p0 = wb_load4(P.x, nullptr, 0.f, n, P.XH, P.XW, P.Cin, by0 + hy, bx0 + hx, ch, P.vec_x);
-        const f32x4 p1 = wb_load4(P.x, nullptr, 0.f, n, P.XH, P.XW, P.Cin, by0 + hy, bx0 + hx + 1, ch, P.vec_x);
+      const int q = tid % QN, ch = cib + q * 4;
+      const int nch = P.Cin - ch;  // channels of this group that exist (<= 0: none)
+      const float* __restrict__ xb = P.x + (size_t)n * P.XH * P.XW * P.Cin;  // wave-uniform image base
+      unsigned short* xq = xs + (size_t)(q * 4) * P.CS;
+      for (int pp = tid / QN; pp < npairs; pp += PSTEP) {
+        const int hy = wb_div20(pp, need2_magic), hx = (pp - hy * need2) * 2;
+        const int iy = by0 + hy, ix = bx0 + hx;
+        const bool rowok = (unsigned)iy < (unsigned)P.XH && nch > 0;
+        const unsigned off = (unsigned)(iy * P.XW + ix) * (unsigned)P.Cin + (unsigned)ch;
+        const f32x4 p0 = wb_load4(xb, nullptr, 0.f, off, rowok && (unsigned)ix < (unsigned)P.XW, nch, P.vec_x);
+        const f32x4 p1 = wb_load4(xb, nullptr, 0.f, off + (unsigned)P.Cin, rowok && (unsigned)(ix + 1) < (unsigned)P.XW,
+                                  nch, P.vec_x);
         unsigned hi[4], lo[4];
         wb_split_pair(p0, p1, hi, lo);
-        const int po = hy * P.HWp + hx;
+        unsigned short* dst = xq + hy * P.HWp + hx;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          *reinterpret_cast<unsigned*>(xs + (size_t)(q * 4 + c) * P.CS + po) = hi[c];
-          *reinterpret_cast<unsigned*>(xs + (size_t)(CIB + q * 4 + c) * P.CS + po) = lo[c];
+          *reinterpret_cast<unsigned*>(dst + (size_t)c * P.CS) = hi[c];
+          *reinterpret_cast<unsigned*>(dst + (size_t)(CIB + c) * P.CS) = lo[c];
         }
       }
     }
     {  // dY tile: rows [r0, +TH), cols [c0, +TW), channels [cob, cob+COB) -> planes [co][r][c] (masked)
-      constexpr int QN = COB / 4;
-      const int items = P.TH * tw2 * QN;
-      for (int it = tid; it < items; it += 256) {
-        const int q = it % QN, pp = it / QN;
-        const int r = pp / tw2, c = (pp - r * tw2) * 2;
-        const int ch = cob + q * 4;
-        const f32x4 p0 = wb_load4(P.dy, P.mask_y, P.mask_slope, n, P.YH, P.YW, P.Cout, r0 + r, c0 + c, ch, P.vec_y,
-                                  P.dy_ps_r, P.dy_ps_C);
-        const f32x4 p1 =
-            wb_load4(P.dy, P.mask_y, P.mask_slope, n, P.YH, P.YW, P.Cout, r0 + r, c0 + c + 1, ch, P.vec_y, P.dy_ps_r,
-                     P.dy_ps_C);
-        bsum += p0 + p1;  // this thread's channel group is fixed (256 % QN == 0)
+      constexpr int QN = COB / 4, PSTEP = 256 / QN;
+      const unsigned tw2_magic = wb_magic20(tw2);
+      const int npairs = P.TH * tw2;
+      const int q = tid % QN, ch = cob + q * 4;
+      const int nch = P.Cout - ch;
+      // element strides of (row, col) and the channel-group offset inside a pixel; pixel-shuffled dY: packed channel
+      // (i, j, c) of pixel (y, x) lives at (y*r + i, x*r + j, c) of the [N, YH*r, YW*r, C] tensor
+      unsigned srow, scol, koff;
+      if (P.dy_ps_r > 1) {
+        const int r = P.dy_ps_r, C = P.dy_ps_C;
+        const int chc = ch < P.Cout ? ch : 0;
+        const int qq = chc / C, c = chc - qq * C;
+        const int i = qq / r, j = qq - i * r;
+        scol = (unsigned)(r * C);
+        srow = (unsigned)(r * P.YW) * scol;
+        koff = (unsigned)(i * P.YW) * scol + (unsigned)(j * C + c);
+      } else {
+        scol = (unsigned)P.Cout;
+        srow = (unsigned)P.YW * scol;
+        koff = (unsigned)ch;
+      }
+      const size_t img = (size_t)n * P.YH * srow;
+      const float* __restrict__ yb = P.dy + img;
+      const float* __restrict__ mb = P.mask_y ? P.mask_y + img : nullptr;
+      unsigned short* yq = ys + (size_t)(q * 4) * P.DS;
+      for (int pp = tid / QN; pp < npairs; pp += PSTEP) {
+        const int r = wb_div20(pp, tw2_magic), c = (pp - r * tw2) * 2;
+        const int iy = r0 + r, ix = c0 + c;
+        const bool rowok = iy < P.YH && nch > 0;
+        const unsigned off = (unsigned)iy * srow + (unsigned)ix * scol + koff;
+        const f32x4 p0 = wb_load4(yb, mb, P.mask_slope, off, rowok && ix < P.YW, nch, P.vec_y);
+        const f32x4 p1 = wb_load4(yb, mb, P.mask_slope, off + scol, rowok && ix + 1 < P.YW, nch, P.vec_y);
+        bsum += p0 + p1;  // this thread's channel group is fixed
         unsigned hi[4], lo[4];
         wb_split_pair(p0, p1, hi, lo);
-        const int po = r * P.TW + c;
+        unsigned short* dst = yq + r * P.TW + c;
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-          *reinterpret_cast<unsigned*>(ys + (size_t)(q * 4 + cc) * P.DS + po) = hi[cc];
-          *reinterpret_cast<unsigned*>(ys + (size_t)(COB + q * 4 + cc) * P.DS + po) = lo[cc];
+          *reinterpret_cast<unsigned*>(dst + (size_t)cc * P.DS) = hi[cc];
+          *reinterpret_cast<unsigned*>(dst + (size_t)(COB + cc) * P.DS) = lo[cc];
         }
       }
     }
@@ -310,6 +342,7 @@ static WbPlan wb_plan(const srk_conv_desc& d) {
   WbPlan pl{};
   pl.ok = false;
   if (d.transposed || d.stride != 1 || d.KH > 3 || d.KW > 3 || d.Cin < 8 || d.Cout < 1) return pl;
+  if ((long)d.H * d.W * d.Cin >= (1L << 30) || (long)d.OH * d.OW * d.Cout >= (1L << 30)) return pl;  // 32-bit in-image offsets
   if (d.dy_ps_r > 1 && (d.Cout % (d.dy_ps_r * d.dy_ps_r) != 0 || (d.Cout / (d.dy_ps_r * d.dy_ps_r)) % 4 != 0)) return pl;
   if (d.Cout > 32) {
     pl.cfg = 0; pl.CIB = 32; pl.COB = 64;
