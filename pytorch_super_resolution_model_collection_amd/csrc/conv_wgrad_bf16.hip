@@ -50,6 +50,7 @@ struct WgBfParams {
   int CS, DS;  // per-channel plane strides (bf16 elements) of the X halo / dY tile
   int ntiles, G, nks;
   int vec_x, vec_y;
+  int dbg;  // ablation (SRK_DBG): 2 skip the staging, 4 skip the K loop
   int dy_ps_r, dy_ps_C;  // dY handed over pixel-shuffled [N, YH*r, YW*r, Cout/r^2]: un-shuffled while staging
 };
 
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf(WgBfParams P) {
     const int n = b / P.tiles_y;
     const int r0 = tyi * P.TH, c0 = txi * P.TW;
     __syncthreads();  // previous tile fully consumed (tables / zero octets visible on the first pass)
-    {  // X halo: rows [r0-pad, +HH), cols [c0-pad, +TW+KW-1), channels [cib, cib+CIB) -> planes [ci][hy][hx]
+    if (!(P.dbg & 2)) {  // X halo: rows [r0-pad, +HH), cols [c0-pad, +TW+KW-1), channels [cib, cib+CIB) -> planes [ci][hy][hx]
       // A thread's channel group q is fixed (256 % QN == 0): it walks pixel pairs pp, pp + 256/QN, ...
       constexpr int QN = CIB / 4, PSTEP = 256 / QN;
       // only the TW + KW - 1 columns the fragments can touch are loaded (the plane row stride HWp = TW + 8 is for
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf(WgBfParams P) {
         }
       }
     }
-    {  // dY tile: rows [r0, +TH), cols [c0, +TW), channels [cob, cob+COB) -> planes [co][r][c] (masked)
+    if (!(P.dbg & 2)) {  // dY tile: rows [r0, +TH), cols [c0, +TW), channels [cob, cob+COB) -> planes [co][r][c] (masked)
       constexpr int QN = COB / 4, PSTEP = 256 / QN;
       const unsigned tw2_magic = wb_magic20(tw2);
       const int npairs = P.TH * tw2;
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf(WgBfParams P) {
       }
     }
     __syncthreads();
-    for (int ks = 0; ks < P.nks; ++ks) {
+    for (int ks = 0; ks < ((P.dbg & 4) ? 0 : P.nks); ++ks) {
       const int ox = oct_x[ks * 4 + kq], oy = oct_y[ks * 4 + kq];
       uint4 bh[NTW], bl[NTW];
 #pragma unroll
@@ -366,8 +367,9 @@ static WbPlan wb_plan(const srk_conv_desc& d) {
       if (lds > (size_t)kWbLdsBudget || TH * TWo > WB_MAXOCT) continue;
       const int nks = cdiv(TH * TWo, 4);
       const double tiles = (double)cdiv(d.OH, TH) * cdiv(d.OW, TW);
-      // cost per tile: nks K steps + staging of the halo / tile (about one K step per 64 halo pixels)
-      const double cost = tiles * (nks + (double)(HH * HWp + TH * TW) / 128.0);
+      // cost per tile: nks K steps + staging, calibrated on the VDSR / EDSR body layers (ablation: staging one
+      // channel-pixel costs 1/3136 of a K step; only TW + KW - 1 halo columns are loaded)
+      const double cost = tiles * (nks + ((double)HH * (TW + d.KW - 1) * pl.CIB + (double)TH * TW * pl.COB) / 3136.0);
       const double eff = (double)d.OH * d.OW / cost;
       if (eff > best_eff * 1.02 || (eff > best_eff * 0.98 && eff > 0 && TH > pl.TH)) {
         if (eff > best_eff) best_eff = eff;
@@ -385,7 +387,13 @@ static WbPlan wb_plan(const srk_conv_desc& d) {
   pl.ntiles = (int)nt;
   pl.gy = cdiv(d.Cin, pl.CIB);
   pl.gz = cdiv(d.Cout, pl.COB);
-  int g = (2 * kNumCU) / (pl.gy * pl.gz);  // two resident blocks per CU in total
+  static int blocks_per_cu = 0;
+  if (!blocks_per_cu) {
+    const char* e = getenv("SRK_WG_BLOCKS");  // experiment: resident blocks per CU (slab count vs overlap)
+    blocks_per_cu = e ? atoi(e) : 2;
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+  }
+  int g = (blocks_per_cu * kNumCU) / (pl.gy * pl.gz);
   if (g < 1) g = 1;
   pl.G = pl.ntiles < g ? pl.ntiles : g;
   pl.ok = true;
@@ -446,6 +454,7 @@ int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const
       const char* e = getenv("SRK_DBG");
       dbg = e ? atoi(e) : 0;
     }
+    P.dbg = dbg;
     if (dbg & 32)
       fprintf(stderr, "[srk] k_wgrad_bf cfg %d: tile %d x %d (%d K steps), %d tiles over %d x %d x %d blocks, lds %zu B\n",
               pl.cfg, pl.TH, pl.TW, pl.nks, pl.ntiles, pl.G, pl.gy, pl.gz, pl.lds);
