@@ -82,6 +82,8 @@ class DataParallel(object):
     def allreduce_grads(self):
         """SUM all-reduce of the flat gradient buffer, in a few multi-MB buckets issued
         back-to-back (async) so RCCL pipelines them over the xGMI links."""
+        from . import ops
+        ops.join_side_streams()  # weight gradients forked onto the side stream must have landed
         if self.world == 1:
             return
         g = self.flat.grad

@@ -201,6 +201,34 @@ def conv_forward_raw(x, wp, bias_p, weight_shape_src, cfg, prelu_w=None, residua
     return y
 
 
+# Weight gradients on a second HIP stream.  In flat-buffer mode (optim.FlatParams) the weight-gradient kernels
+# accumulate straight into the model's gradient buffer and autograd never looks at their result, so a layer's wgrad
+# (+ slab reduce) can run concurrently with the same layer's data-gradient kernel and with the backward of the layers
+# below it.  That matters when a layer cannot fill the chip by itself — a strong-scaled shard (EDSR x4, 16 patches per
+# GPU: 256 one-wave-group blocks per kernel) — and is neutral when it can.  Everything forked here is joined by
+# join_side_streams(), which FlatParams / the optimizers / DataParallel / trainers call before the gradients are read.
+WGRAD_SIDE_STREAM = os.environ.get("SRK_WGRAD_STREAM", "1") != "0"
+_SIDE = {}   # device index -> [stream, tensors kept alive until the join]
+
+
+def _side(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ent = _SIDE.get(idx)
+    if ent is None:
+        ent = [torch.cuda.Stream(device=idx), []]
+        _SIDE[idx] = ent
+    return ent
+
+
+def join_side_streams():
+    """Make the current stream wait for every weight gradient forked onto the side stream.  Runs automatically at
+    the end of every backward pass that forked (autograd engine callback), so `loss.backward(); p.grad...` is safe."""
+    for idx, ent in _SIDE.items():
+        if ent[1]:
+            torch.cuda.current_stream(idx).wait_stream(ent[0])
+            ent[1] = []
+
+
 class _Conv2d(torch.autograd.Function):
     """y = PS_r(act(conv(x, w) + b)) + residual, training-capable for act in {none, relu, lrelu}."""
 
@@ -257,29 +285,45 @@ class _Conv2d(torch.autograd.Function):
             mask = BwdMask(ptr(y), cfg.slope if cfg.act == ACT_LRELU else 0.0)
         mref = ctypes.byref(mask) if mask is not None else None
         dx = dw = db = None
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        wref, bref = ctx.weight_ref, ctx.bias_ref
+        wacc = getattr(wref, "_srk_grad", None)
+        bacc = getattr(bref, "_srk_grad", None) if ctx.has_bias else None
+        flat_mode = wacc is not None and (not ctx.has_bias or bacc is not None)
+        if need_w and flat_mode:
+            # flat-buffer mode: accumulate straight into the (pre-zeroed) gradient views — on the side stream, forked
+            # here (after dy / x are ready, before the data gradient is launched) so the two kernels overlap
+            ws_bytes = lib.srk_conv2d_backward_weight_workspace_bytes(ctypes.byref(d))
+            if WGRAD_SIDE_STREAM:
+                side, keep = _side(dy.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=dy.device)
+                    check(lib.srk_conv2d_backward_weight(ctypes.byref(d), ptr(x), ptr(dyc), mref, ptr(wacc), ptr(bacc),
+                                                         1.0, ptr(ws), ws.numel(), stream_ptr()),
+                          "srk_conv2d_backward_weight")
+                if not keep:  # first fork of this backward pass: join when the autograd engine finishes it
+                    torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+                keep.append((x, dyc, y, ws))  # the caching allocator must not recycle these before the join
+            else:
+                ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=dy.device)
+                check(lib.srk_conv2d_backward_weight(ctypes.byref(d), ptr(x), ptr(dyc), mref, ptr(wacc), ptr(bacc),
+                                                     1.0, ptr(ws), ws.numel(), stream_ptr()),
+                      "srk_conv2d_backward_weight")
         if ctx.needs_input_grad[0]:
             plan_wpb = ctx.wpb if cfg.ps_r <= 1 else ctx_wpb
             wpb = plan_wpb if plan_wpb is not None else pack_weight_bwd(weight, cfg.transposed, d.dy_ps_r)
             dx = _empty_cl(d.N, d.Cin, d.H, d.W, dy)
             check(lib.srk_conv2d_backward_data(ctypes.byref(d), ptr(dyc), ptr(wpb), ptr(dx), mref, None,
                                                stream_ptr()), "srk_conv2d_backward_data")
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        if need_w and not flat_mode:
             ws_bytes = lib.srk_conv2d_backward_weight_workspace_bytes(ctypes.byref(d))
             ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=dy.device)
-            wref, bref = ctx.weight_ref, ctx.bias_ref
-            wacc = getattr(wref, "_srk_grad", None)
-            bacc = getattr(bref, "_srk_grad", None) if ctx.has_bias else None
-            if wacc is not None and (not ctx.has_bias or bacc is not None):
-                # flat-buffer mode: accumulate straight into the (pre-zeroed) gradient views
-                check(lib.srk_conv2d_backward_weight(ctypes.byref(d), ptr(x), ptr(dyc), mref, ptr(wacc), ptr(bacc),
-                                                     1.0, ptr(ws), ws.numel(), stream_ptr()),
-                      "srk_conv2d_backward_weight")
-            else:
-                dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
-                db = torch.empty(d.Cout, dtype=torch.float32, device=dy.device) if ctx.has_bias else None
-                check(lib.srk_conv2d_backward_weight(ctypes.byref(d), ptr(x), ptr(dyc), mref, ptr(dw), ptr(db), 0.0,
-                                                     ptr(ws), ws.numel(), stream_ptr()),
-                      "srk_conv2d_backward_weight")
+            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            db = torch.empty(d.Cout, dtype=torch.float32, device=dy.device) if ctx.has_bias else None
+            check(lib.srk_conv2d_backward_weight(ctypes.byref(d), ptr(x), ptr(dyc), mref, ptr(dw), ptr(db), 0.0,
+                                                 ptr(ws), ws.numel(), stream_ptr()),
+                  "srk_conv2d_backward_weight")
         return dx, dw, db, dres, None, None
 
 

@@ -59,6 +59,8 @@ class FlatParams(object):
         self.plan = PackPlan(module, self)
 
     def zero_grad(self):
+        from . import ops
+        ops.join_side_streams()  # no weight gradient of the previous step may still be accumulating
         self.grad.zero_()  # one memset node
 
     def named_grads(self):
@@ -172,6 +174,8 @@ class _FlatOptimizer(object):
         """torch.nn.utils.clip_grad_norm(params, max_norm) (vdsr.py:149): computes the global L2
         norm on the device and stores min(1, max_norm/(norm+1e-6)) where the next step() reads it
         (the flat gradient buffer itself is left unscaled). Returns the device norm tensor."""
+        from . import ops
+        ops.join_side_streams()
         lib = _lib.load()
         if self._norm_ws is None:
             self._norm_ws = torch.empty(int(lib.srk_grad_norm_workspace_bytes()), dtype=torch.uint8,
@@ -194,6 +198,8 @@ class SGD(_FlatOptimizer):
         self.buf = torch.zeros_like(self.flat.data) if momentum != 0.0 else None
 
     def step(self):
+        from . import ops
+        ops.join_side_streams()  # weight gradients forked onto the side stream
         lib = _lib.load()
         f = self.flat
         check(lib.srk_sgd_step(ptr(f.data), ptr(f.grad), ptr(self.buf), f.numel, 0.0, self.momentum,
@@ -214,6 +220,8 @@ class Adam(_FlatOptimizer):
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.flat.data.device)
 
     def step(self):
+        from . import ops
+        ops.join_side_streams()  # weight gradients forked onto the side stream
         lib = _lib.load()
         f = self.flat
         check(lib.srk_adam_step(ptr(f.data), ptr(f.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), f.numel, 0.0,

@@ -18,6 +18,7 @@ def _backward(loss, dp):
         loss.backward(dp.loss_seed)
     else:
         loss.backward()
+    ops.join_side_streams()  # weight gradients run on a second stream (ops.WGRAD_SIDE_STREAM)
 
 
 def mse_step(model, opt, dp=None, clip=None):

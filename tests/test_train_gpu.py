@@ -218,3 +218,25 @@ def test_trainer_objects_and_cli(gpu, tmp_path):
     files = glob.glob(str(tmp_path / "EDSR" / "model" / "EDSR_param_ch3_batch2_epoch2_lr0.0001.pkl"))
     assert files, "EDSR checkpoint name does not follow edsr.py:329-335"
     R.EDSR(3, 64, 16).load_state_dict(torch.load(files[0]))
+
+
+def test_wgrad_side_stream_matches_single_stream(gpu):
+    """ops.WGRAD_SIDE_STREAM (weight gradients forked onto a second stream, joined by the autograd-engine callback):
+    same gradients as the single-stream path, readable right after loss.backward()."""
+    pkg = _pkg()
+    x, t = B((4, 3, 12, 12), 71).to(gpu), B((4, 3, 48, 48), 72).to(gpu)
+    grads = []
+    for side in (False, True):
+        pkg.ops.WGRAD_SIDE_STREAM = side
+        try:
+            net = pkg.EDSRNet(3, 64, 4)
+            fill.fill_module(net, 3, 0.5)
+            net.to(gpu).train()
+            flat = pkg.optim.FlatParams(net)
+            flat.zero_grad()
+            pkg.ops.l1_loss(net(x), t).backward()
+            grads.append(flat.grad.clone())
+        finally:
+            pkg.ops.WGRAD_SIDE_STREAM = False
+    assert float(grads[0].abs().max()) > 0
+    assert torch.equal(grads[0], grads[1])
