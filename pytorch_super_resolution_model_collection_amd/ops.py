@@ -204,10 +204,14 @@ def conv_forward_raw(x, wp, bias_p, weight_shape_src, cfg, prelu_w=None, residua
 # Weight gradients on a second HIP stream.  In flat-buffer mode (optim.FlatParams) the weight-gradient kernels
 # accumulate straight into the model's gradient buffer and autograd never looks at their result, so a layer's wgrad
 # (+ slab reduce) can run concurrently with the same layer's data-gradient kernel and with the backward of the layers
-# below it.  That matters when a layer cannot fill the chip by itself — a strong-scaled shard (EDSR x4, 16 patches per
-# GPU: 256 one-wave-group blocks per kernel) — and is neutral when it can.  Everything forked here is joined by
-# join_side_streams(), which FlatParams / the optimizers / DataParallel / trainers call before the gradients are read.
-WGRAD_SIDE_STREAM = os.environ.get("SRK_WGRAD_STREAM", "1") != "0"
+# below it.
+# Measured on MI355X / ROCm 7.2 (tools/edsr_small_batch.py, tools/graph_conc.py): hipGraph replay does not run the
+# forked branch concurrently (a two-branch graph of small kernels replays slower than the same kernels in one chain),
+# so the strong-scaled shard (EDSR x4, 16 patches per GPU) gains only 2 % (2.72 -> 2.65 ms) and the full batch loses
+# 8 % (9.04 -> 9.76 ms, two co-resident kernels fighting over LDS / cache).  OFF by default; SRK_WGRAD_STREAM=1 or
+# ops.WGRAD_SIDE_STREAM = True enables it.  Everything forked is joined by join_side_streams(), which runs at the end
+# of every backward pass (autograd engine callback) and in FlatParams / the optimizers / DataParallel.
+WGRAD_SIDE_STREAM = os.environ.get("SRK_WGRAD_STREAM", "0") == "1"
 _SIDE = {}   # device index -> [stream, tensors kept alive until the join]
 
 
