@@ -212,8 +212,6 @@ __global__ __launch_bounds__(64 * NPW * NOW, 2) void k_conv_bfd(
     BfdParams B) {
   constexpr int NTHR = 64 * NPW * NOW;
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
-  __shared__ int tap_toff[BFD_MAXTAPS];
-  __shared__ int tap_wtap[BFD_MAXTAPS];
   const MfmaConvParams& P = B.P;
   uint4* hal = smem4;  // [NP][4][NPIXp]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -231,18 +229,16 @@ __global__ __launch_bounds__(64 * NPW * NOW, 2) void k_conv_bfd(
   const int NB = B.NB;
   const int T = P.KHv * P.KWv;
 
-  for (int t = tid; t < T && t < BFD_MAXTAPS; t += NTHR) {
-    const int u = t / P.KWv, v = t - u * P.KWv;
-    tap_toff[t] = u * P.HW + v;
-    tap_wtap[t] = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
-  }
   int hp[4];
+  {
+    const int tw_magic = div_small_magic(P.TW);
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    int m = pw * 64 + mt * 16 + j;
-    if (m >= npx) m = 0;
-    const int r = m / P.TW, c = m - r * P.TW;
-    hp[mt] = (r * P.is) * P.HW + c * P.is + kq * B.NPIXp;
+    for (int mt = 0; mt < 4; ++mt) {
+      int m = pw * 64 + mt * 16 + j;
+      if (m >= npx) m = 0;
+      const int r = div_small(m, tw_magic), c = m - r * P.TW;
+      hp[mt] = (r * P.is) * P.HW + c * P.is + kq * B.NPIXp;
+    }
   }
   f32x4 acc[4][NTW];
 #pragma unroll
@@ -254,47 +250,76 @@ __global__ __launch_bounds__(64 * NPW * NOW, 2) void k_conv_bfd(
   const int plane = 4 * B.NPIXp;
   const int wlane = kq * NB + j + ow * NTW * 16;
 
-  // filter fragments of flat iteration (chunk cc, tap t) -> registers
-  auto load_b = [&](int cc, int t, uint4 (&dst)[NP][NTW]) {
-    if (cc < B.ICc) {
-      int tapw;
-      if (t < BFD_MAXTAPS) {
-        tapw = tap_wtap[t];
-      } else {
-        const int u = t / P.KWv, v = t - u * P.KWv;
-        tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
-      }
-      const size_t slot = (size_t)(tapw * B.ICc + cc) * B.OCb + ocbi;
-      const uint4* w = B.wq + slot * (size_t)(8 * NB) + wlane;
+  // Tap walks in scalar registers (no LDS tables, no per-tap division): virtual tap (u, v) reads halo offset
+  // u*HW + v and weight tap (wh0 + wdh*u)*KW_full + ww0 + wdw*v.  `Walk` is the prefetch head over the flat
+  // (chunk, tap) sequence; the compute loop keeps its own (toff, tv).
+  const int wtap0 = P.wh0 * P.KW_full + P.ww0;
+  const int wtap_row = P.wdh * P.KW_full - P.wdw * P.KWv;  // extra weight-tap step at a row wrap
+  struct Walk {
+    int cc, t, tv, wt;
+  };
+  auto walk_next = [&](Walk& h) {
+    h.wt += P.wdw;
+    if (++h.tv == P.KWv) {
+      h.tv = 0;
+      h.wt += wtap_row;
+    }
+    if (++h.t == T) {
+      h.t = 0;
+      h.tv = 0;
+      h.wt = wtap0;
+      ++h.cc;
+    }
+  };
+  // filter fragments of the head position -> registers (past the end the walk re-reads the last chunk: valid
+  // memory, never used)
+  auto load_b = [&](const Walk& h, uint4 (&dst)[NP][NTW]) {
+    const int hc = h.cc < B.ICc ? h.cc : B.ICc - 1;
+    const size_t slot = (size_t)(h.wt * B.ICc + hc) * B.OCb + ocbi;
+    const uint4* w = B.wq + slot * (size_t)(8 * NB) + wlane;
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) {
-        dst[0][nt] = w[nt * 16];
-        dst[1][nt] = w[4 * NB + nt * 16];
-      }
-      if (NP == 3) {
-        const uint4* w3 = B.wq3 + slot * (size_t)(4 * NB) + wlane;
+    for (int nt = 0; nt < NTW; ++nt) {
+      dst[0][nt] = w[nt * 16];
+      dst[1][nt] = w[4 * NB + nt * 16];
+    }
+    if (NP == 3) {
+      const uint4* w3 = B.wq3 + slot * (size_t)(4 * NB) + wlane;
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) dst[NP - 1][nt] = w3[nt * 16];
-      }
-    } else {
+      for (int nt = 0; nt < NTW; ++nt) dst[NP - 1][nt] = w3[nt * 16];
+    }
+  };
+  // one tap: A fragments from LDS, 3 or 6 MFMA passes against the given filter fragments
+  auto tap_mfma = [&](const uint4* halc, int toff, const uint4 (&bf)[NP][NTW]) {
+    if (wave_live && !(B.dbg & 4)) {
+      const uint4* hb = halc + toff;
+      uint4 a[NP][4];
 #pragma unroll
       for (int p = 0; p < NP; ++p)
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) dst[p][nt] = make_uint4(0, 0, 0, 0);
+        for (int mt = 0; mt < 4; ++mt) a[p][mt] = hb[hp[mt] + p * plane];
+      // smallest products first; every pass runs over 4*NTW independent accumulators
+#define SRK_BFD_PASS(pa, pb)                                                              \
+  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = \
+      mfma16(a[pa][mt], bf[pb][nt], acc[mt][nt]);
+      if (NP == 3) {
+        SRK_BFD_PASS(NP - 1, 0)
+        SRK_BFD_PASS(0, NP - 1)
+        SRK_BFD_PASS(1, 1)
+      }
+      SRK_BFD_PASS(1, 0)
+      SRK_BFD_PASS(0, 1)
+      SRK_BFD_PASS(0, 0)
+#undef SRK_BFD_PASS
     }
   };
 
   if (T > 0) {
-    __syncthreads();  // tap tables
-    uint4 bq[PF][NP][NTW];
-    int hcc = 0, ht = 0;  // prefetch head (chunk, tap)
+    uint4 bq[PF + 1][NP][NTW];  // bq[0] = current tap, bq[1..PF] = the following taps
+    Walk head{0, 0, 0, wtap0};
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
-      load_b(hcc, ht, bq[d]);
-      if (++ht == T) {
-        ht = 0;
-        ++hcc;
-      }
+      load_b(head, bq[d]);
+      walk_next(head);
     }
     const int cstride = NP * 4 * B.NPIXp;  // uint4 per staged chunk
     for (int cc = 0; cc < B.ICc; ++cc) {
@@ -317,51 +342,39 @@ __global__ __launch_bounds__(64 * NPW * NOW, 2) void k_conv_bfd(
         __syncthreads();
       }
       const uint4* halc = B.allc ? hal + cc * cstride : hal;
-      for (int t = 0; t < T; ++t) {
-        uint4 nb[NP][NTW];
-        load_b(hcc, ht, nb);
-        if (++ht == T) {
-          ht = 0;
-          ++hcc;
+      int toff = 0, tv = 0;
+      auto toff_next = [&]() {
+        ++toff;
+        if (++tv == P.KWv) {
+          tv = 0;
+          toff += P.HW - P.KWv;
         }
-        if (wave_live && !(B.dbg & 4)) {
-          int toff;
-          if (t < BFD_MAXTAPS) {
-            toff = tap_toff[t];
-          } else {
-            const int u = t / P.KWv, v = t - u * P.KWv;
-            toff = u * P.HW + v;
-          }
-          const uint4* hb = halc + toff;
-          uint4 a[NP][4];
+      };
+      int t = 0;
+      if (NTW * NP <= 6) {
+        // rotate through the PF+1 register sets instead of shifting them: after PF+1 taps the roles are back
+        // where they started (wider tiles spill when unrolled like this and take the shifting loop below)
+        for (; t + PF + 1 <= T; t += PF + 1) {
 #pragma unroll
-          for (int p = 0; p < NP; ++p)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) a[p][mt] = hb[hp[mt] + p * plane];
-          // smallest products first; every pass runs over 4*NTW independent accumulators
-#define SRK_BFD_PASS(pa, pb)                                                              \
-  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = \
-      mfma16(a[pa][mt], bq[0][pb][nt], acc[mt][nt]);
-          if (NP == 3) {
-            SRK_BFD_PASS(NP - 1, 0)
-            SRK_BFD_PASS(0, NP - 1)
-            SRK_BFD_PASS(1, 1)
+          for (int k = 0; k <= PF; ++k) {
+            load_b(head, bq[(k + PF) % (PF + 1)]);
+            walk_next(head);
+            tap_mfma(halc, toff, bq[k]);
+            toff_next();
           }
-          SRK_BFD_PASS(1, 0)
-          SRK_BFD_PASS(0, 1)
-          SRK_BFD_PASS(0, 0)
-#undef SRK_BFD_PASS
         }
+      }
+      for (; t < T; ++t) {
+        load_b(head, bq[PF]);
+        walk_next(head);
+        tap_mfma(halc, toff, bq[0]);
+        toff_next();
 #pragma unroll
-        for (int d = 0; d + 1 < PF; ++d)
+        for (int d = 0; d < PF; ++d)
 #pragma unroll
           for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) bq[d][p][nt] = bq[d + 1][p][nt];
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) bq[PF - 1][p][nt] = nb[p][nt];
       }
     }
   }
