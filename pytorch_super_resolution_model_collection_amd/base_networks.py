@@ -132,16 +132,22 @@ class ResnetBlock(_Block):
     def forward(self, x):
         kind, slope, pw = self._act_args()
         training = grad_mode(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, pw)
+        if self.norm is None:
+            fuse = self._fuse_act(x, self.conv1.weight)
+            # training: the skip gradient (= the block output gradient) is added by conv1's data-gradient kernel
+            # (ops.GradBox); it needs x itself to require grad, else there is no fan-in to sum
+            box = ops.GradBox() if (training and x.requires_grad and ops.FUSE_SKIP_GRAD) else None
+            residual = x
+            if training and box is None:
+                x, residual = ops.fork(x)  # unfused: gradient fan-in summed by srk_axpby
+            out = self.conv1.run(x, kind if fuse else ACT_NONE, slope, pw if fuse else None, add_box=box)
+            if not fuse:
+                out = self.act(out)
+            return self.conv2.run(out, ACT_NONE, 0.0, None, residual, res_box=box)  # conv2 + residual add, one kernel
         if training:
             x, residual = ops.fork(x)  # gradient fan-in summed by srk_axpby
         else:
             residual = x
-        if self.norm is None:
-            fuse = self._fuse_act(x, self.conv1.weight)
-            out = self.conv1.run(x, kind if fuse else ACT_NONE, slope, pw if fuse else None)
-            if not fuse:
-                out = self.act(out)
-            return self.conv2.run(out, ACT_NONE, 0.0, None, residual)  # conv2 + residual add, one kernel
         out = self.bn(self.conv1.run(x))
         if self.activation is not None:
             out = self.act(out)

@@ -17,6 +17,9 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// conv_tapn.hip
+bool conv_tapn_gather_supported(const GatherConv& g, const float* in, const float* mask_y);
+int conv_tapn_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s);
 // conv_direct.hip
 bool conv_direct_gather_supported(const GatherConv& g, const Epi& ep);
 int conv_direct_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
@@ -95,6 +98,10 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
     set_error("%s: MFMA kernel does not cover this shape", who);
     return SRK_ERR_UNSUPPORTED;
   }
+  // few-output-channel 3x3 convs (the 64 -> 3 reconstruction layers): taps-as-N bf16x6 kernel for every bf16 class
+  if ((algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3 || algo == SRK_ALGO_MFMA_BF16X6) &&
+      conv_tapn_gather_supported(g, in, mask_y))
+    return conv_tapn_gather(g, in, wp, out, ep, s);
   // the bfd / bfr kernels are compiled without the scalar store fallback
   const bool bfd_ok = conv_bfd_gather_supported(g, ep) && conv_epi_all_vector(g.OC, ep, out);
   if (algo == SRK_ALGO_MFMA_BF16X6) {  // fp32-faithful class: bf16x6 where it applies, else the exact fp32 kernels

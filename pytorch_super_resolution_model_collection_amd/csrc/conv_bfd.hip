@@ -26,12 +26,10 @@
 #include "srk_common.h"
 #include "conv_problem.h"
 #include "conv_tile.h"
+#include "bf16_frag.h"
 #include <stdlib.h>
 
 namespace srk {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct BfdParams {
   MfmaConvParams P;
@@ -44,28 +42,6 @@ struct BfdParams {
   int dbg;
   int allc;          // small problems: every channel chunk of the halo staged up front (one load latency, one barrier)
 };
-
-template <int NP>
-__device__ __forceinline__ void split8n(const float (&f)[8], uint4 (&pl)[NP]) {
-  bf16x8 h, m, l;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const __bf16 hh = (__bf16)f[e];
-    const float r1 = f[e] - (float)hh;
-    const __bf16 mm = (__bf16)r1;
-    h[e] = hh;
-    m[e] = mm;
-    if (NP == 3) l[e] = (__bf16)(r1 - (float)mm);
-  }
-  pl[0] = __builtin_bit_cast(uint4, h);
-  pl[1] = __builtin_bit_cast(uint4, m);
-  if (NP == 3) pl[NP - 1] = __builtin_bit_cast(uint4, l);
-}
-
-__device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
-                                                 0);
-}
 
 // halo chunk: channels [cb, cb+32) of every halo pixel -> NP planes.  thread -> (8-channel group
 // g = tid&3, pixel slot tid>>2); all global loads of a batch are issued before the first conversion.
@@ -274,6 +250,7 @@ __global__ __launch_bounds__(64 * NPW * NOW, 2) void k_conv_bfd(
   // filter fragments of the head position -> registers (past the end the walk re-reads the last chunk: valid
   // memory, never used)
   auto load_b = [&](const Walk& h, uint4 (&dst)[NP][NTW]) {
+    if (B.dbg & 8) return;
     const int hc = h.cc < B.ICc ? h.cc : B.ICc - 1;
     const size_t slot = (size_t)(h.wt * B.ICc + hc) * B.OCb + ocbi;
     const uint4* w = B.wq + slot * (size_t)(8 * NB) + wlane;
@@ -322,18 +299,37 @@ __global__ __launch_bounds__(64 * NPW * NOW, 2) void k_conv_bfd(
       walk_next(head);
     }
     const int cstride = NP * 4 * B.NPIXp;  // uint4 per staged chunk
-    for (int cc = 0; cc < B.ICc; ++cc) {
+    // Segments of taps between barriers: one chunk each, or (allc) a single segment over every chunk so that
+    // the rotation below runs across chunk boundaries.
+    const int nseg = B.allc ? 1 : B.ICc;
+    const int seg_len = B.allc ? B.ICc * T : T;
+    const int cadv = B.allc ? cstride : 0;
+    int ct = 0, ctv = 0, coff = 0, cbase = 0;  // compute walk: halo offset of the current tap
+    auto cwalk_next = [&]() {
+      ++coff;
+      if (++ctv == P.KWv) {
+        ctv = 0;
+        coff += P.HW - P.KWv;
+      }
+      if (++ct == T) {
+        ct = 0;
+        ctv = 0;
+        cbase += cadv;
+        coff = cbase;
+      }
+    };
+    for (int seg = 0; seg < nseg; ++seg) {
       if (!B.allc) {
-        if (cc) __syncthreads();  // previous chunk's halo fully consumed
+        if (seg) __syncthreads();  // previous chunk's halo fully consumed
         if (!(B.dbg & 1)) {
           if (P.mask_y)
-            bfd_stage_halo_t<true, NTHR, NP>(B, hal, n, r0, c0, cc * 32);
+            bfd_stage_halo_t<true, NTHR, NP>(B, hal, n, r0, c0, seg * 32);
           else
-            bfd_stage_halo_t<false, NTHR, NP>(B, hal, n, r0, c0, cc * 32);
+            bfd_stage_halo_t<false, NTHR, NP>(B, hal, n, r0, c0, seg * 32);
         }
         __syncthreads();
-      } else if (cc == 0) {
-        for (int c2 = 0; c2 < B.ICc; ++c2) {
+      } else {
+        for (int c2 = 0; c2 < B.ICc && !(B.dbg & 1); ++c2) {
           if (P.mask_y)
             bfd_stage_halo_t<true, NTHR, NP>(B, hal + c2 * cstride, n, r0, c0, c2 * 32);
           else
@@ -341,34 +337,25 @@ __global__ __launch_bounds__(64 * NPW * NOW, 2) void k_conv_bfd(
         }
         __syncthreads();
       }
-      const uint4* halc = B.allc ? hal + cc * cstride : hal;
-      int toff = 0, tv = 0;
-      auto toff_next = [&]() {
-        ++toff;
-        if (++tv == P.KWv) {
-          tv = 0;
-          toff += P.HW - P.KWv;
-        }
-      };
-      int t = 0;
+      int it = 0;
       if (NTW * NP <= 6) {
         // rotate through the PF+1 register sets instead of shifting them: after PF+1 taps the roles are back
         // where they started (wider tiles spill when unrolled like this and take the shifting loop below)
-        for (; t + PF + 1 <= T; t += PF + 1) {
+        for (; it + PF + 1 <= seg_len; it += PF + 1) {
 #pragma unroll
           for (int k = 0; k <= PF; ++k) {
             load_b(head, bq[(k + PF) % (PF + 1)]);
             walk_next(head);
-            tap_mfma(halc, toff, bq[k]);
-            toff_next();
+            tap_mfma(hal, coff, bq[k]);
+            cwalk_next();
           }
         }
       }
-      for (; t < T; ++t) {
+      for (; it < seg_len; ++it) {
         load_b(head, bq[PF]);
         walk_next(head);
-        tap_mfma(halc, toff, bq[0]);
-        toff_next();
+        tap_mfma(hal, coff, bq[0]);
+        cwalk_next();
 #pragma unroll
         for (int d = 0; d < PF; ++d)
 #pragma unroll
@@ -706,7 +693,12 @@ static int bfd_launch_phase(MfmaConvParams P, const uint4* wq, const uint4* wq3,
       case 1: return bfd_launch<1, 1, 1, NP, 2>(B, SMALL, s);
       case 2: return bfd_launch<1, 1, 2, NP, 2>(B, SMALL, s);
       case 3: return bfd_launch<1, 1, 3, NP, 2>(B, SMALL, s);
-      default: return bfd_launch<1, 1, 4, NP, 2>(B, SMALL, s);
+      default: {
+        static const int pf = getenv("SRK_BFD_PF") ? atoi(getenv("SRK_BFD_PF")) : 2;
+        if (pf == 5) return bfd_launch<1, 1, 4, NP, 5>(B, SMALL, s);
+        if (pf == 8) return bfd_launch<1, 1, 4, NP, 8>(B, SMALL, s);
+        return bfd_launch<1, 1, 4, NP, 2>(B, SMALL, s);
+      }
     }
   }
   switch (NT) {

@@ -69,12 +69,12 @@ class Conv2d(torch.nn.Conv2d):
         self._k, self._s, self._p = _single(self.kernel_size), _single(self.stride), _single(self.padding)
         self._cache = _PackCache()
 
-    def run(self, x, act=ACT_NONE, slope=0.0, prelu_w=None, residual=None, ps_r=0):
+    def run(self, x, act=ACT_NONE, slope=0.0, prelu_w=None, residual=None, ps_r=0, res_box=None, add_box=None):
         """conv (+ fused epilogue).  In grad mode only none/relu/lrelu are fused (see ops.conv2d);
-        the caller applies other activations unfused."""
+        the caller applies other activations unfused.  res_box / add_box: ops.GradBox of a residual block."""
         cfg = ops.ConvCfg(self._s, self._p, False, 0, act, slope, ps_r)
         if grad_mode(x, self.weight, self.bias, residual, prelu_w):
-            return ops.conv2d(x, self.weight, self.bias, residual, cfg, _plan_views(self, ps_r))
+            return ops.conv2d(x, self.weight, self.bias, residual, cfg, _plan_views(self, ps_r), res_box, add_box)
         packed = self._cache.get(self.weight, self.bias, False, ps_r)
         return ops.conv2d_infer(x, self.weight, self.bias, residual, cfg, prelu_w, packed)
 

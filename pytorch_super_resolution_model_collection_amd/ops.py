@@ -233,11 +233,27 @@ def join_side_streams():
             ent[1] = []
 
 
+FUSE_SKIP_GRAD = os.environ.get("SRK_FUSE_SKIP_GRAD", "1") != "0"  # 0: residual blocks sum their gradient fan-in with srk_axpby
+
+
+class GradBox(object):
+    """Gradient fan-in of a residual block without a separate add pass.  The block output gradient reaches the
+    backward of the block's LAST conv as the gradient of its fused residual input; that backward parks it here
+    (`res_box`) instead of returning it to autograd, and the backward of the block's FIRST conv -- which autograd
+    runs later, and whose input is the same tensor as the skip -- hands it to srk_conv2d_backward_data as `add_to`
+    (`add_box`), so dx = conv1^T(...) + dy_block comes out of the data-gradient kernel's epilogue."""
+    __slots__ = ("g",)
+
+    def __init__(self):
+        self.g = None
+
+
 class _Conv2d(torch.autograd.Function):
     """y = PS_r(act(conv(x, w) + b)) + residual, training-capable for act in {none, relu, lrelu}."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, cfg, packed):
+    def forward(ctx, x, weight, bias, residual, cfg, packed, res_box=None, add_box=None):
+        ctx.res_box, ctx.add_box = res_box, add_box
         require_cuda(x, weight, bias, residual)
         x = to_nhwc(x)
         if residual is not None:
@@ -268,6 +284,8 @@ class _Conv2d(torch.autograd.Function):
         dy = to_nhwc(dy if (_is_nchw_dense(dy) or _is_nhwc_dense(dy)) else dy.contiguous())
         d = _make_desc(x.shape, weight, cfg, "bwd")
         dres = dy if ctx.has_res else None
+        if ctx.has_res and ctx.res_box is not None:
+            ctx.res_box.g, dres = dy, None  # consumed by the first conv of the block (GradBox)
         dyc = dy
         if cfg.ps_r > 1:
             r = cfg.ps_r
@@ -318,7 +336,13 @@ class _Conv2d(torch.autograd.Function):
             plan_wpb = ctx.wpb if cfg.ps_r <= 1 else ctx_wpb
             wpb = plan_wpb if plan_wpb is not None else pack_weight_bwd(weight, cfg.transposed, d.dy_ps_r)
             dx = _empty_cl(d.N, d.Cin, d.H, d.W, dy)
-            check(lib.srk_conv2d_backward_data(ctypes.byref(d), ptr(dyc), ptr(wpb), ptr(dx), mref, None,
+            add_to = None
+            if ctx.add_box is not None and ctx.add_box.g is not None:
+                add_to, ctx.add_box.g = ctx.add_box.g, None
+                if tuple(add_to.shape) != tuple(dx.shape):
+                    raise RuntimeError("conv backward: skip gradient %s does not match dx %s"
+                                       % (tuple(add_to.shape), tuple(dx.shape)))
+            check(lib.srk_conv2d_backward_data(ctypes.byref(d), ptr(dyc), ptr(wpb), ptr(dx), mref, ptr(add_to),
                                                stream_ptr()), "srk_conv2d_backward_data")
         if need_w and not flat_mode:
             ws_bytes = lib.srk_conv2d_backward_weight_workspace_bytes(ctypes.byref(d))
@@ -328,17 +352,18 @@ class _Conv2d(torch.autograd.Function):
             check(lib.srk_conv2d_backward_weight(ctypes.byref(d), ptr(x), ptr(dyc), mref, ptr(dw), ptr(db), 0.0,
                                                  ptr(ws), ws.numel(), stream_ptr()),
                   "srk_conv2d_backward_weight")
-        return dx, dw, db, dres, None, None
+        return dx, dw, db, dres, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, residual=None, cfg=None, packed=None):
-    """Fused conv for training (act limited to none/relu/lrelu; no act together with residual/ps)."""
+def conv2d(x, weight, bias=None, residual=None, cfg=None, packed=None, res_box=None, add_box=None):
+    """Fused conv for training (act limited to none/relu/lrelu; no act together with residual/ps).
+    res_box / add_box: see GradBox (both convs of a residual block share one box)."""
     cfg = cfg or ConvCfg()
     if cfg.act not in (ACT_NONE, ACT_RELU, ACT_LRELU):
         raise RuntimeError("conv2d (autograd path) fuses only none/relu/lrelu; use conv2d_infer or an unfused act")
     if cfg.act != ACT_NONE and (residual is not None or cfg.ps_r > 1):
         raise RuntimeError("conv2d (autograd path): activation cannot be fused together with residual/pixel-shuffle")
-    return _Conv2d.apply(x, weight, bias, residual, cfg, packed)
+    return _Conv2d.apply(x, weight, bias, residual, cfg, packed, res_box, add_box)
 
 
 def conv2d_infer(x, weight, bias=None, residual=None, cfg=None, prelu_w=None, packed=None):

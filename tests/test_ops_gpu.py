@@ -72,6 +72,33 @@ def test_conv_infer_fused_epilogue(gpu, idx):
     assert rel_err(y, ref) < 1e-4
 
 
+@pytest.mark.parametrize("cin,cout,k,p,H,W,N", [
+    (64, 3, 3, 1, 37, 29, 2),    # several ragged 16x16 tiles per image (EDSR / VDSR reconstruction conv)
+    (64, 3, 3, 0, 20, 45, 1),    # no padding, wide
+    (32, 2, 3, 1, 17, 17, 3),    # one 32-channel step, two output channels
+    (64, 1, 3, 1, 16, 16, 1),    # single output channel: one 16-column fragment
+    (64, 3, 1, 0, 19, 23, 2),    # 1x1
+    (32, 3, 2, 1, 9, 12, 1),     # even kernel
+])
+@pytest.mark.parametrize("algo", ["auto", "bf16x6"])
+def test_conv_few_output_channels(gpu, cin, cout, k, p, H, W, N, algo):
+    """The taps-as-N kernel (KH*KW*Cout <= 32 columns, conv_tapn.hip) against torch fp64 on CPU, held to the
+    exact-fp32 tolerance in every precision class (it always runs the exact 3-way split); bias + LeakyReLU +
+    residual go through its scalar epilogue."""
+    pkg = _pkg()
+    ops = pkg.ops
+    x = fill.randn((N, cin, H, W), 71)
+    w = fill.randn((cout, cin, k, k), 72, (2.0 / (cin * k * k)) ** 0.5)
+    b = fill.randn((cout,), 73, 0.1)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 1, p)
+    res = fill.randn(tuple(ref.shape), 74)
+    ref = torch.nn.functional.leaky_relu(ref, 0.2) + res.double()
+    cfg = ops.ConvCfg(1, p, False, 0, ACTS["lrelu"], 0.2, 0, ALGOS[algo])
+    with torch.no_grad():
+        y = ops.conv2d_infer(x.to(gpu), w.to(gpu), b.to(gpu), res.to(gpu), cfg)
+    assert rel_err(y, ref.float()) < TOL_TIGHT
+
+
 @pytest.mark.parametrize("r,C", [(2, 64), (4, 3), (3, 2)])
 def test_conv_fused_pixel_shuffle(gpu, r, C):
     """conv + PixelShuffle store (PSBlock, base_networks.py:179-181), forward and backward."""
