@@ -20,6 +20,12 @@ void set_error(const char* fmt, ...) {
 // conv_tapn.hip
 bool conv_tapn_gather_supported(const GatherConv& g, const float* in, const float* mask_y);
 int conv_tapn_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s);
+bool conv_tapk_gather_supported(const GatherConv& g, const Epi& ep, const float* out, const float* mask_y);
+int conv_tapk_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s);
+bool conv_wgrad_tapn_supported(const srk_conv_desc& d, const float* x, const srk_bwd_mask* mask);
+size_t conv_wgrad_tapn_ws(const srk_conv_desc& d);
+int conv_wgrad_tapn(const srk_conv_desc& d, const float* x, const float* dy, float* dw, float* db, float beta, void* ws,
+                    size_t ws_bytes, hipStream_t s);
 // conv_direct.hip
 bool conv_direct_gather_supported(const GatherConv& g, const Epi& ep);
 int conv_direct_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
@@ -102,6 +108,9 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
   if ((algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3 || algo == SRK_ALGO_MFMA_BF16X6) &&
       conv_tapn_gather_supported(g, in, mask_y))
     return conv_tapn_gather(g, in, wp, out, ep, s);
+  // ... and their data gradients (<= 3 input channels, TRANS gather): taps-in-K bf16x3 kernel
+  if ((algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3) && conv_tapk_gather_supported(g, ep, out, mask_y))
+    return conv_tapk_gather(g, in, wp, out, ep, s);
   // the bfd / bfr kernels are compiled without the scalar store fallback
   const bool bfd_ok = conv_bfd_gather_supported(g, ep) && conv_epi_all_vector(g.OC, ep, out);
   if (algo == SRK_ALGO_MFMA_BF16X6) {  // fp32-faithful class: bf16x6 where it applies, else the exact fp32 kernels
@@ -212,7 +221,9 @@ extern "C" size_t srk_conv2d_backward_weight_workspace_bytes(const srk_conv_desc
   size_t b = conv_wgrad_mfma_supported(*d) ? conv_wgrad_mfma_ws(*d) : 0;
   size_t c = conv_wgrad_bf_supported(*d) ? conv_wgrad_bf_ws(*d) : 0;
   if (b > a) a = b;
-  return a > c ? a : c;
+  if (c > a) a = c;
+  const size_t t = conv_wgrad_tapn_supported(*d, nullptr, nullptr) ? conv_wgrad_tapn_ws(*d) : 0;
+  return a > t ? a : t;
 }
 
 extern "C" int srk_conv2d_backward_weight(const srk_conv_desc* d, const float* x, const float* dy,
@@ -225,7 +236,10 @@ extern "C" int srk_conv2d_backward_weight(const srk_conv_desc* d, const float* x
   // AUTO / BF16X3: bf16x3 MFMA kernel where it applies (stride-1 convs up to 3x3); MFMA / BF16X6 / DIRECT: the
   // exact fp32 MFMA kernel; GENERIC: the plain kernel
   const int algo = forced_algo(d->algo);
-  const char* wb = getenv("SRK_WGRAD_BF16");  // 0 disables the bf16x3 weight-gradient kernel
+  const char* wb = getenv("SRK_WGRAD_BF16");  // 0 disables the bf16x3 weight-gradient kernels
+  if ((algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3) && !(wb && atoi(wb) == 0) &&
+      conv_wgrad_tapn_supported(*d, x, mask))  // few-output-channel reconstruction convs
+    return conv_wgrad_tapn(*d, x, dy, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);
   if ((algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3) && !(wb && atoi(wb) == 0) && conv_wgrad_bf_supported(*d))
     return conv_wgrad_bf(*d, x, dy, mask, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);
   if (d->dy_ps_r > 1) {

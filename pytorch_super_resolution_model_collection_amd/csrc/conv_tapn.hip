@@ -200,4 +200,320 @@ int conv_tapn_gather(const GatherConv& g, const float* in, const float* wp, floa
   });
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of the same layers (Cout <= 3, KH*KW*Cout <= 32, stride 1, 2*pad <= K-1):
+//
+//   dW[t][ci][oc] = sum over input pixels p of  x[p][ci] * dyc[p][t*OC + oc],   dyc[p][(t, oc)] = dy[p + pad - t][oc]
+//
+// one GEMM with M = ci (<= 64), N = t*OC + oc (<= 32), K = pixels.  A K step is 32 consecutive pixels of one image
+// row.  The MFMA wants 8 consecutive K values of one M row per lane; with lane (j, kq) loading the float4
+// x[pixel kq*8 + e][channels 4j .. 4j+3] for e < 8 (fully coalesced 256-byte pixel rows) the lane ends up holding
+// exactly that for FOUR rows -- channel 4j + i is row j of M tile i -- so the big operand needs no transposition
+// through LDS at all (M rows are merely labelled in a permuted order).  The small operand dyc is gathered from dy
+// (12 bytes per pixel, L1-resident).  Waves walk the K steps of the whole batch with a grid stride, keep the full
+// 64 x 32 accumulator in registers (8 tiles), and every block writes ONE partial slab at the end (4 waves summed
+// through LDS); the deterministic slab reduction and bias finish are the shared k_wgrad_reduce.  The bias gradient
+// partials come for free: the centre tap's dyc column IS dy.
+// bf16x3 arithmetic (as the other weight-gradient kernels of the bf16 class).
+// ---------------------------------------------------------------------------------------------
+int conv_wgrad_reduce_launch(const float* ws, float* dw, int G, int Cout, int Cin, int KH, int KW, int transposed,
+                             float beta, const float* bias_partial, float* db, int bias_cout, int out_ps_r,
+                             hipStream_t s);  // conv_wgrad_mfma.hip
+
+struct WgTapnParams {
+  const float* x;
+  const float* dy;
+  float* ws;            // [G][T][Cin][Cout]
+  float* bias_partial;  // [G][Cout] or NULL
+  int N, H, W, Cin, OH, OW, pad, KH, KW;
+  int S;      // 32-pixel K steps per image row
+  int units;  // N * H * S
+};
+
+constexpr int WGT_RS = 33;  // LDS row stride of the per-wave partial [64][32]
+
+template <int OCT>
+__global__ __launch_bounds__(256, 3) void k_wgrad_tapn(WgTapnParams P) {
+  __shared__ float red[4][64 * WGT_RS];
+  __shared__ float bred[4][2][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int T = P.KH * P.KW, NN = T * OCT;
+  // this lane's two dyc columns
+  bool on[2], centre[2];
+  int tu[2], tv[2], toc[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int nn = nt * 16 + j;
+    on[nt] = nn < NN;
+    const int t = on[nt] ? nn / OCT : 0;
+    toc[nt] = nn - t * OCT;
+    tu[nt] = t / P.KW;
+    tv[nt] = t - tu[nt] * P.KW;
+    centre[nt] = on[nt] && tu[nt] == P.pad && tv[nt] == P.pad;
+  }
+  const bool two = NN > 16;
+  const bool ch_on = 4 * j < P.Cin;
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[i][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
+  const int nw = gridDim.x * 4;
+  for (int unit = blockIdx.x * 4 + wave; unit < P.units; unit += nw) {
+    const int rr = unit / P.S, sg = unit - rr * P.S;
+    const int n = rr / P.H, r = rr - n * P.H;
+    const int cb = sg * 32 + kq * 8;  // first pixel column of this lane's 8
+    // dyc fragments (gather; zero outside dy)
+    float braw[2][8];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int qy = r + P.pad - tu[nt];
+      const bool oky = on[nt] && (unsigned)qy < (unsigned)P.OH && (nt == 0 || two);
+      const float* __restrict__ src = P.dy + ((size_t)(n * P.OH + qy) * P.OW) * OCT + toc[nt];
+      const int qx0 = cb + P.pad - tv[nt];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int qx = qx0 + e;
+        braw[nt][e] = (oky && (unsigned)qx < (unsigned)P.OW) ? src[(size_t)qx * OCT] : 0.f;
+      }
+    }
+    // x fragments: float4 = channels 4j..4j+3 of pixel cb + e
+    f32x4 araw[8];
+    const float* __restrict__ xs = P.x + ((size_t)(n * P.H + r) * P.W) * P.Cin + 4 * j;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      araw[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (ch_on && cb + e < P.W) araw[e] = *reinterpret_cast<const f32x4*>(xs + (size_t)(cb + e) * P.Cin);
+    }
+    uint4 bfr[2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      if (centre[nt]) {
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t += braw[nt][e];
+        bsum[nt] += t;
+      }
+      split8n<2>(braw[nt], bfr[nt]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = araw[e][i];
+      uint4 a[2];
+      split8n<2>(f, a);
+      acc[i][0] = mfma16(a[1], bfr[0][0], acc[i][0]);
+      acc[i][0] = mfma16(a[0], bfr[0][1], acc[i][0]);
+      acc[i][0] = mfma16(a[0], bfr[0][0], acc[i][0]);
+      if (two) {
+        acc[i][1] = mfma16(a[1], bfr[1][0], acc[i][1]);
+        acc[i][1] = mfma16(a[0], bfr[1][1], acc[i][1]);
+        acc[i][1] = mfma16(a[0], bfr[1][0], acc[i][1]);
+      }
+    }
+  }
+  // block partial: C/D layout col = lane & 15 (nn), row = (lane >> 4) * 4 + reg; row m of tile i is channel 4m + i
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave][(4 * (kq * 4 + e) + i) * WGT_RS + nt * 16 + j] = acc[i][nt][e];
+  bred[wave][0][lane] = bsum[0];
+  bred[wave][1][lane] = bsum[1];
+  __syncthreads();
+  float* slab = P.ws + (size_t)blockIdx.x * T * P.Cin * OCT;
+  for (int idx = tid; idx < 64 * 32; idx += 256) {
+    const int ci = idx >> 5, nn = idx & 31;
+    if (ci < P.Cin && nn < NN) {
+      const float v = (red[0][ci * WGT_RS + nn] + red[1][ci * WGT_RS + nn]) + (red[2][ci * WGT_RS + nn] + red[3][ci * WGT_RS + nn]);
+      const int t = nn / OCT, oc = nn - t * OCT;
+      slab[((size_t)t * P.Cin + ci) * OCT + oc] = v;
+    }
+  }
+  if (P.bias_partial && tid < OCT) {
+    const int nn = (P.pad * P.KW + P.pad) * OCT + tid;  // centre tap column of channel tid
+    const int nt = nn >> 4, jj = nn & 15;
+    float t = 0.f;
+    for (int w = 0; w < 4; ++w)
+      for (int q = 0; q < 4; ++q) t += bred[w][nt][jj + 16 * q];
+    P.bias_partial[(size_t)blockIdx.x * OCT + tid] = t;
+  }
+}
+
+static int wgrad_tapn_blocks(const srk_conv_desc& d) {
+  const long units = (long)d.N * d.H * ((d.W + 31) / 32);
+  long g = (units + 15) / 16;  // >= 4 K steps per wave (measured: 2..4 equal, 8 slower on the 16-image shard)
+  if (g > 4 * kNumCU) g = 4 * kNumCU;  // 4 blocks per CU resident (36 KB LDS, 123 VGPRs)
+  return g < 1 ? 1 : (int)g;
+}
+
+bool conv_wgrad_tapn_supported(const srk_conv_desc& d, const float* x, const srk_bwd_mask* mask) {
+  static const int off = getenv("SRK_TAPN") ? !atoi(getenv("SRK_TAPN")) : 0;
+  if (off) return false;
+  if (d.transposed || d.stride != 1 || d.dy_ps_r > 1 || (mask && mask->y)) return false;
+  if (d.Cout < 1 || d.Cout > 3 || d.KH * d.KW * d.Cout > 32) return false;
+  if (d.Cin < 8 || d.Cin > 64 || d.Cin % 4 != 0) return false;
+  if (2 * d.pad > d.KH - 1 || 2 * d.pad > d.KW - 1) return false;
+  if ((long)d.N * d.H * ((d.W + 31) / 32) >= (1L << 30)) return false;
+  if (x && (uintptr_t)x % 16 != 0) return false;
+  return true;
+}
+
+size_t conv_wgrad_tapn_ws(const srk_conv_desc& d) {
+  return (size_t)wgrad_tapn_blocks(d) * ((size_t)d.KH * d.KW * d.Cin * d.Cout + d.Cout) * sizeof(float);
+}
+
+int conv_wgrad_tapn(const srk_conv_desc& d, const float* x, const float* dy, float* dw, float* db, float beta, void* ws,
+                    size_t ws_bytes, hipStream_t s) {
+  const int G = wgrad_tapn_blocks(d);
+  const size_t need = conv_wgrad_tapn_ws(d);
+  if (!ws || ws_bytes < need) {
+    set_error("conv_wgrad_tapn: workspace %zu < %zu", ws_bytes, need);
+    return SRK_ERR_WORKSPACE;
+  }
+  WgTapnParams P{};
+  P.x = x; P.dy = dy; P.ws = (float*)ws;
+  const size_t slab_floats = (size_t)G * d.KH * d.KW * d.Cin * d.Cout;
+  P.bias_partial = db ? P.ws + slab_floats : nullptr;
+  P.N = d.N; P.H = d.H; P.W = d.W; P.Cin = d.Cin; P.OH = d.OH; P.OW = d.OW; P.pad = d.pad; P.KH = d.KH; P.KW = d.KW;
+  P.S = (d.W + 31) / 32;
+  P.units = d.N * d.H * P.S;
+  switch (d.Cout) {
+    case 1: hipLaunchKernelGGL(k_wgrad_tapn<1>, dim3(G), dim3(256), 0, s, P); break;
+    case 2: hipLaunchKernelGGL(k_wgrad_tapn<2>, dim3(G), dim3(256), 0, s, P); break;
+    default: hipLaunchKernelGGL(k_wgrad_tapn<3>, dim3(G), dim3(256), 0, s, P); break;
+  }
+  int rc = check_launch("conv_wgrad_tapn");
+  if (rc) return rc;
+  return conv_wgrad_reduce_launch(P.ws, dw, G, d.Cout, d.Cin, d.KH, d.KW, 0, beta, P.bias_partial, db, d.Cout, 0, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The mirror case: gathers with <= 3 INPUT channels and KH*KW*IC <= 32 (the data gradient of the reconstruction
+// convs: dx[64] from dy[3]), written for the TRANS gathers that the row-packed bf16x3 first-layer kernel
+// (k_conv_bf3_rows) does not take.  Here the taps join the contraction index:
+//
+//   out[p][oc] = sum over k = (t, c) of  inc[p][k] * w[k][oc],   inc[p][(t, c)] = in[p + offset(t)][c]    (K <= 32)
+//
+// computed transposed (M = oc in 16-channel tiles, N = 16 consecutive pixels of a row, ONE K step): the filter
+// (A operand) stays in registers as bf16 planes, the B operand is 8 gathered floats per lane and 16 pixels, and the
+// C/D layout (lane = pixel, 4 registers = 4 consecutive channels) stores float4s straight to global memory --
+// no LDS, no barriers; waves walk the 16-pixel groups of the batch with a grid stride.  bf16x3 arithmetic.
+// The kernel is bound by its output write (e.g. 537 MB for 128 x 64 x 128 x 128).
+// ---------------------------------------------------------------------------------------------
+template <int MTN>  // 16-channel output tiles (OC = 16 * MTN)
+__global__ __launch_bounds__(256) void k_conv_tapk(MfmaConvParams P, int groups_per_row, int units) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int T = P.KHv * P.KWv, KK = T * P.IC;
+  // filter fragments: row m = j of tile i is output channel 16 i + j; k = kq*8 + e = t*IC + c
+  uint4 af[MTN][2];
+  int koff[8];       // gather offset of contraction slot e relative to the pixel's base address (elements)
+  int kuv[8];        // (u << 16) | v of slot e, -1 = padding slot
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = kq * 8 + e;
+    const bool on = k < KK;
+    const int t = on ? k / P.IC : 0, c = k - t * P.IC;
+    const int u = t / P.KWv, v = t - u * P.KWv;
+    koff[e] = (u * P.IW + v) * P.IC + c;
+    kuv[e] = on ? ((u << 16) | v) : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < MTN; ++i) {
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      f[e] = 0.f;
+      if (kuv[e] >= 0) {
+        const int k = kq * 8 + e;
+        const int t = k / P.IC, c = k - t * P.IC;
+        const int u = t / P.KWv, v = t - u * P.KWv;
+        const int tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
+        f[e] = P.wp[((size_t)tapw * P.IC + c) * P.OC + 16 * i + j];
+      }
+    }
+    split8n<2>(f, af[i]);
+  }
+  // two pixel groups per iteration: 16 independent gathers in flight before the first conversion
+  constexpr int U = 2;
+  const int nw = gridDim.x * 4;
+  const float* __restrict__ res = P.ep.residual;
+  for (int unit0 = (blockIdx.x * 4 + wave) * U; unit0 < units; unit0 += nw * U) {
+    float f[U][8];
+    size_t ooff[U];
+    bool px_on[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int unit = unit0 + q < units ? unit0 + q : units - 1;
+      const int rr = unit / groups_per_row, gx = unit - rr * groups_per_row;
+      const int n = rr / P.PH, pr = rr - n * P.PH;
+      const int pc = gx * 16 + j;  // this lane's pixel (phase coordinates)
+      px_on[q] = pc < P.PW && unit0 + q < units;
+      const int iyb = pr * P.is + P.iy0, ixb = pc * P.is + P.ix0;
+      const float* __restrict__ src = P.in + (((size_t)n * P.IH + iyb) * P.IW + ixb) * P.IC;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int u = kuv[e] >> 16, v = kuv[e] & 0xffff;
+        const bool ok = px_on[q] && kuv[e] >= 0 && (unsigned)(iyb + u) < (unsigned)P.IH && (unsigned)(ixb + v) < (unsigned)P.IW;
+        f[q][e] = ok ? src[koff[e]] : 0.f;
+      }
+      const int oy = P.oy0 + pr * P.os, ox = P.ox0 + pc * P.os;
+      ooff[q] = (((size_t)n * P.OH + oy) * P.OW + ox) * P.OC + kq * 4;
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      uint4 bf[2];
+      split8n<2>(f[q], bf);
+#pragma unroll
+      for (int i = 0; i < MTN; ++i) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc = mfma16(af[i][1], bf[0], acc);
+        acc = mfma16(af[i][0], bf[1], acc);
+        acc = mfma16(af[i][0], bf[0], acc);
+        // C/D layout: col = lane & 15 = pixel j, rows kq*4 + reg = channels 16 i + kq*4 .. +3
+        if (px_on[q]) {
+          if (res) acc += *reinterpret_cast<const f32x4*>(res + ooff[q] + 16 * i);
+          *reinterpret_cast<f32x4*>(P.out + ooff[q] + 16 * i) = acc;
+        }
+      }
+    }
+  }
+}
+
+// (epilogue: optional "+ residual" only -- what a data gradient needs)
+bool conv_tapk_gather_supported(const GatherConv& g, const Epi& ep, const float* out, const float* mask_y) {
+  if (ep.bias || ep.act != SRK_ACT_NONE || ep.ps_r > 1 || (uintptr_t)out % 16 != 0 || (uintptr_t)ep.residual % 16 != 0)
+    return false;
+  static const int off = getenv("SRK_TAPN") ? !atoi(getenv("SRK_TAPN")) : 0;
+  if (off) return false;
+  if (!g.trans || g.stride != 1) return false;  // CONV gathers with IC <= 4 have the row-packed kernel
+  if (g.IC < 1 || g.IC > 3 || g.KH * g.KW * g.IC > 32) return false;
+  if (g.OC % 16 != 0 || g.OC > 64) return false;
+  if (mask_y || g.in_nchw || g.in_ps_r > 1) return false;
+  if ((long)g.IH * g.IW * g.IC >= (1L << 30) || (long)g.N * g.OH * ((g.OW + 15) / 16) >= (1L << 30)) return false;
+  return true;
+}
+
+int conv_tapk_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s) {
+  return for_each_phase(g, in, wp, out, ep, nullptr, 0.f, [&](const MfmaConvParams& P) {
+    const int gpr = (P.PW + 15) / 16;
+    const int units = P.N * P.PH * gpr;
+    long nb = (units + 15) / 16;  // >= 4 pixel groups per wave
+    if (nb > 8 * kNumCU) nb = 8 * kNumCU;
+    if (nb < 1) nb = 1;
+    switch (P.OC / 16) {
+      case 1: hipLaunchKernelGGL(k_conv_tapk<1>, dim3((unsigned)nb), dim3(256), 0, s, P, gpr, units); break;
+      case 2: hipLaunchKernelGGL(k_conv_tapk<2>, dim3((unsigned)nb), dim3(256), 0, s, P, gpr, units); break;
+      case 3: hipLaunchKernelGGL(k_conv_tapk<3>, dim3((unsigned)nb), dim3(256), 0, s, P, gpr, units); break;
+      default: hipLaunchKernelGGL(k_conv_tapk<4>, dim3((unsigned)nb), dim3(256), 0, s, P, gpr, units); break;
+    }
+    return check_launch("conv_tapk");
+  });
+}
+
 }  // namespace srk

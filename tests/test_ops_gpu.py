@@ -99,6 +99,34 @@ def test_conv_few_output_channels(gpu, cin, cout, k, p, H, W, N, algo):
     assert rel_err(y, ref.float()) < TOL_TIGHT
 
 
+@pytest.mark.parametrize("cin,cout,k,p,H,W,N", [
+    (64, 3, 3, 1, 41, 41, 3),    # VDSR patch: the second 32-pixel K step of every row is ragged
+    (64, 3, 3, 0, 20, 70, 2),    # no padding: dy smaller than x
+    (32, 2, 3, 1, 17, 33, 2),    # half of the channel lanes idle
+    (48, 1, 3, 1, 16, 16, 1),    # one 16-column fragment, Cin not a multiple of 32 (forward runs k_conv_direct)
+    (64, 3, 1, 0, 19, 23, 2),    # 1x1
+])
+def test_conv_few_output_channels_backward(gpu, cin, cout, k, p, H, W, N):
+    """Training step pieces of the reconstruction convs: forward (taps-as-N kernel, bf16x6), data gradient, and the
+    transposition-free weight-gradient kernel with its fused bias-gradient partials (conv_tapn.hip), vs torch fp64."""
+    pkg = _pkg()
+    ops = pkg.ops
+    x = fill.randn((N, cin, H, W), 81)
+    w = fill.randn((cout, cin, k, k), 82, (2.0 / (cin * k * k)) ** 0.5)
+    b = fill.randn((cout,), 83, 0.1)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    ref = torch.nn.functional.conv2d(xr, wr, br, 1, p)
+    g = fill.randn(tuple(ref.shape), 84)
+    ref.backward(g.double())
+    xg, wg, bg = (t.to(gpu).requires_grad_(True) for t in (x, w, b))
+    y = ops.conv2d(xg, wg, bg, None, ops.ConvCfg(1, p, False, 0, 0, 0.0, 0, ALGOS["auto"]))
+    y.backward(g.to(gpu))
+    assert rel_err(y, ref.detach().float()) < TOL_TIGHT
+    assert rel_err(xg.grad, xr.grad.float()) < 1e-4
+    assert rel_err(wg.grad, wr.grad.float()) < 1e-4
+    assert rel_err(bg.grad, br.grad.float()) < 1e-4
+
+
 @pytest.mark.parametrize("r,C", [(2, 64), (4, 3), (3, 2)])
 def test_conv_fused_pixel_shuffle(gpu, r, C):
     """conv + PixelShuffle store (PSBlock, base_networks.py:179-181), forward and backward."""

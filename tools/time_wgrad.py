@@ -6,7 +6,8 @@ sys.path.insert(0, ROOT)
 import pytorch_super_resolution_model_collection_amd as pkg
 from pytorch_super_resolution_model_collection_amd._lib import ConvDesc, check, load, ptr, stream_ptr
 lib = load()
-SHAPES = {"edsr128": (128, 64, 32, 32, 64, 3, 1), "vdsr": (256, 64, 41, 41, 64, 3, 1), "edsr16": (16, 64, 32, 32, 64, 3, 1)}
+SHAPES = {"edsr128": (128, 64, 32, 32, 64, 3, 1), "vdsr": (256, 64, 41, 41, 64, 3, 1), "edsr16": (16, 64, 32, 32, 64, 3, 1),
+          "edsrtail128": (128, 64, 128, 128, 3, 3, 1), "edsrtail16": (16, 64, 128, 128, 3, 3, 1), "vdsrtail": (256, 64, 41, 41, 3, 3, 1)}
 dev = torch.device("cuda:0")
 for name in (sys.argv[1:] or list(SHAPES)):
     N, cin, H, W, cout, k, pad = SHAPES[name]
