@@ -20,6 +20,9 @@ void set_error(const char* fmt, ...) {
 // conv_tapn.hip
 bool conv_tapn_gather_supported(const GatherConv& g, const float* in, const float* mask_y);
 int conv_tapn_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s);
+// conv_bfw.hip
+bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, const float* out, const float* mask_y);
+int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s);
 bool conv_tapk_gather_supported(const GatherConv& g, const Epi& ep, const float* out, const float* mask_y);
 int conv_tapk_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s);
 bool conv_wgrad_tapn_supported(const srk_conv_desc& d, const float* x, const srk_bwd_mask* mask);
@@ -130,6 +133,10 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
     const int direct_w = e ? (atoi(e) ? 1 : 0) : 2;
     if (bfd_ok && (direct_w == 1 || (direct_w == 2 && conv_bfd_small_problem(g))))
       return conv_bfd_gather(g, in, wp, out, ep, mask_y, mask_slope, 2, s);
+    if (conv_bfw_applicable(g, ep, in, out, mask_y)) {  // wave-specialised persistent kernel (ESPCN-size layers)
+      const int rc = conv_bfw_gather(g, in, wp, out, ep, s);
+      if (rc >= 0) return rc;
+    }
     if (bfd_ok && conv_bfr_applicable(g, mask_y)) {  // filter resident in LDS, persistent blocks (ESPCN-size layers)
       const int rc = conv_bfr_gather(g, in, wp, out, ep, s);
       if (rc >= 0) return rc;

@@ -1,0 +1,430 @@
+// Wave-specialised persistent bf16x3 convolution for layers whose whole prepared filter fits in LDS next to TWO
+// halo-chunk buffers (the ESPCN 64->32 and 32->48 3x3 layers: the c2 benchmark).
+//
+// Why: on those layers every phase of the per-tile kernels is short and the phases do not overlap -- measured on
+// the 64->32 layer (SRK_DBG ablations): halo staging 0.19 ms (= the activation read at HBM speed), MFMAs 0.17 ms,
+// epilogue 0.08 ms, per-tap filter copies 0.07 ms, loop/barrier skeleton 0.11 ms, total 0.57 ms; co-resident blocks
+// run the same phases in lockstep.  Here the phases run CONCURRENTLY on different waves of one block:
+//
+//   * one block per CU, 8 waves: waves 0-3 are CONSUMERS (one per SIMD, 64 pixels x all 16*NTW output channels
+//     each), waves 4-7 are PRODUCERS;
+//   * the filter is copied to LDS once per block (as in k_conv_bfr); the block then walks (tile, 32-channel chunk)
+//     stages; stage s computes from halo buffer s&1 while the producers fill buffer (s+1)&1 -- one barrier per stage;
+//   * producers: global fp32 loads of stage s+2 are issued right after the LDS commit of stage s+1 (a full stage
+//     of latency cover), commit = bf16 split + ds_write_b128: their VALU work interleaves with the consumers'
+//     MFMAs on the same SIMD;
+//   * consumers: fragment reads + MFMAs only (software-pipelined tap loop, no global-memory waits), then -- after
+//     the last chunk of a tile -- the epilogue straight from the accumulators, while the producers already stage the
+//     next tile.  The MFMA runs transposed (D[channel][pixel]: A = filter, B = pixels): lane (pixel j, group kq)
+//     holds 4 consecutive output channels per 16-channel tile, so its stores are 16-byte vectors and the 4 kq lanes
+//     of a pixel write 64 contiguous bytes per instruction -- no LDS transpose (there is no LDS left for one:
+//     filter 72 KB + 2 x 42 KB halo buffers).
+//
+// Arithmetic identical to k_conv_bf3 / k_conv_bfr (x = h + m, products m*h + h*m + h*h, fp32 accumulate; the
+// accumulation order over (chunk, tap) is the same).
+#include "srk_common.h"
+#include "conv_problem.h"
+#include "conv_tile.h"
+#include "bf16_frag.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace srk {
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, I1)
+template <int I0, int I1, typename F>
+__device__ __forceinline__ void srk_static_for(F&& f) {
+  if constexpr (I0 < I1) {
+    f(std::integral_constant<int, I0>{});
+    srk_static_for<I0 + 1, I1>(f);
+  }
+}
+
+constexpr int BFW_MAXTAPS = 32;
+constexpr int BFW_IT = 6;  // producer register batches: halos of <= 64 * 6 = 384 pixels
+
+struct BfwParams {
+  MfmaConvParams P;
+  const uint4* wq;  // prepared filter planes (h, m)
+  int ICc, NB, NPIXp, ntiles;
+  int dbg;  // ablation (SRK_DBG): 1 no global loads, 2 no epilogue, 4 no MFMA loop, 16 no LDS commit, 1024 no deferred stores
+};
+
+template <int NTW, int TT>
+__global__ __launch_bounds__(512, 2) void k_conv_bfw(BfwParams B) {
+  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+  const MfmaConvParams& P = B.P;
+  const int NB = B.NB;
+  const int wslot = 8 * NB;  // uint4 per (tap, chunk): [plane 2][group 4][NB]
+  const int T = P.KHv * P.KWv;
+  const int hbuf = 8 * B.NPIXp;  // uint4 per halo buffer: [plane 2][group 4][NPIXp]
+  uint4* wl = smem4;
+  uint4* hal0 = smem4 + (size_t)T * B.ICc * wslot;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave >= 4;
+  const int j = lane & 15, kq = lane >> 4;
+  const int npx = P.TH * P.TW, npix = P.HH * P.HW;
+
+  for (int e = tid; e < T * B.ICc * wslot; e += 512) {
+    const int slot = e / wslot, w = e - slot * wslot;
+    const int t = slot / B.ICc, cc = slot - t * B.ICc;
+    const int u = t / P.KWv, v = t - u * P.KWv;
+    const int tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
+    wl[e] = B.wq[(size_t)(tapw * B.ICc + cc) * (size_t)wslot + w];
+  }
+  // tiles of this block: XCD-aware order (consecutive block ids go round-robin over the 8 XCDs / L2s; give each XCD
+  // a contiguous range of tiles so neighbouring tiles share halo rows in one L2)
+  const int nblk = gridDim.x;
+  int first, count;
+  {
+    const int per_x = B.ntiles >> 3, rem_x = B.ntiles & 7;  // tiles per XCD
+    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;   // block index inside the XCD
+    const int nb_x = (nblk + 7 - xcd) >> 3;                 // blocks on this XCD
+    const int tiles_x = per_x + (xcd < rem_x ? 1 : 0);
+    const int start_x = xcd * per_x + (xcd < rem_x ? xcd : rem_x);
+    first = start_x + bi;  // block bi takes tiles start_x + bi, + nb_x, ...
+    count = bi < tiles_x ? (tiles_x - bi + nb_x - 1) / nb_x : 0;
+    (void)nb_x;
+  }
+  const int tstride = (nblk + 7 - (blockIdx.x & 7)) >> 3;
+  const int S = count * B.ICc;  // stages of this block
+
+  auto decode = [&](int s, int& n, int& r0, int& c0, int& cc) {
+    const int ti = s / B.ICc;
+    cc = s - ti * B.ICc;
+    const int tile = first + ti * tstride;
+    const int txi = tile % P.tiles_x;
+    const int q = tile / P.tiles_x;
+    const int tyi = q % P.tiles_y;
+    n = q / P.tiles_y;
+    r0 = tyi * P.TH;
+    c0 = txi * P.TW;
+  };
+
+  if (producer) {
+    // ------------------------------------------------------------------ producers
+    const int ptid = tid - 256;
+    const int g = ptid & 3, hp0 = ptid >> 2;
+    const int hy0 = hp0 / P.HW, hx0 = hp0 - hy0 * P.HW;
+    const int dyp = 64 / P.HW, dxp = 64 - dyp * P.HW;
+    f32x4 pv0[BFW_IT], pv1[BFW_IT];
+    auto issue = [&](int s) {
+      if (B.dbg & 1) return;
+      int n, r0, c0, cc;
+      decode(s, n, r0, c0, cc);
+      const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
+      const int ch = cc * 32 + g * 8;
+      const bool ch_on = ch + 7 < P.IC;
+      const float* __restrict__ inb = P.in + (size_t)n * P.IH * P.IW * P.IC + ch;
+      int hy = hy0, hx = hx0;
+#pragma unroll
+      for (int k = 0; k < BFW_IT; ++k) {
+        pv0[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        pv1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int iy = iyb + hy, ix = ixb + hx;
+        if (hp0 + 64 * k < npix && ch_on && (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW) {
+          const float* src = inb + ((size_t)iy * P.IW + ix) * P.IC;
+          pv0[k] = *reinterpret_cast<const f32x4*>(src);
+          pv1[k] = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+        hy += dyp;
+        hx += dxp;
+        if (hx >= P.HW) {
+          hx -= P.HW;
+          ++hy;
+        }
+      }
+    };
+    auto commit = [&](uint4* hal) {
+      if (B.dbg & 16) return;
+#pragma unroll
+      for (int k = 0; k < BFW_IT; ++k) {
+        const int hq = hp0 + 64 * k;
+        if (hq < npix) {
+          float f[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            f[e] = pv0[k][e];
+            f[4 + e] = pv1[k][e];
+          }
+          uint4 pl[2];
+          split8n<2>(f, pl);
+          hal[(0 * 4 + g) * B.NPIXp + hq] = pl[0];
+          hal[(1 * 4 + g) * B.NPIXp + hq] = pl[1];
+        }
+      }
+    };
+    if (S > 0 && T > 0) {
+      issue(0);
+      commit(hal0);
+      if (S > 1) issue(1);
+    }
+    __syncthreads();  // filter, tap table and stage 0 visible
+    for (int s = 0; s < S; ++s) {
+      if (T > 0) {
+        if (s + 1 < S) commit(hal0 + (size_t)((s + 1) & 1) * hbuf);
+        if (s + 2 < S) issue(s + 2);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumers
+  const int pw = wave;
+  int hp[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    int m = pw * 64 + mt * 16 + j;
+    if (m >= npx) m = 0;
+    const int r = m / P.TW, c = m - r * P.TW;
+    hp[mt] = (r * P.is) * P.HW + c * P.is + kq * B.NPIXp;
+  }
+  const bool wave_live = pw * 64 < npx;
+  const int plane = 4 * B.NPIXp;
+  // transposed MFMA (A = filter, B = pixels): C/D col = lane & 15 = pixel, rows kq*4 + reg of M tile nt = the 4
+  // consecutive output channels nt*16 + kq*4 + reg -> one 16-byte store per (pixel, tile); the 4 kq lanes of a pixel
+  // cover 64 contiguous bytes per store instruction
+  int wrow[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) wrow[nt] = kq * NB + nt * 16 + j;
+  // Epilogue data that does not depend on the tile: bias of the lane's 4 channels per M tile, and the element
+  // offset of (pixel mt, channel group nt) relative to the tile origin (epi_tile_setup / epi_col_setup arithmetic:
+  // plain NHWC or the fused pixel shuffle).  Only none / ReLU / leaky / scalar-PReLU activations reach this kernel
+  // (conv_bfw_applicable), which makes the activation one branch-free select: v > 0 ? v : slope * v.
+  f32x4 bias4[NTW];
+  int coff[NTW], poff[4];  // element offset of slot (mt, nt) from the tile origin = coff[nt] + poff[mt]
+  int pix_ok[4];  // (r << 16) | c of the lane's pixel in tile coordinates, -1 = beyond the tile
+  {
+    const EpiTile e0 = epi_tile_setup(P, 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = pw * 64 + mt * 16 + j;
+      const int r = m / P.TW, c = m - r * P.TW;
+      pix_ok[mt] = m < npx ? ((r << 16) | c) : -1;
+      poff[mt] = r * e0.RS + c * e0.CS;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const EpiCol cl = epi_col_setup(P.ep, P.OW, P.OC, nt * 16 + kq * 4);
+      coff[nt] = (int)cl.off_oc;
+      bias4[nt] = cl.bias;
+    }
+  }
+  const float act_slope = P.ep.act == SRK_ACT_NONE ? 1.f
+                          : P.ep.act == SRK_ACT_RELU ? 0.f
+                          : P.ep.act == SRK_ACT_PRELU ? P.ep.prelu_w[0] : P.ep.slope;
+  f32x4 acc[NTW][4];
+  // Deferred epilogue: the finished tile's values wait in `pend` and are stored one or two at a time between the taps
+  // of the NEXT stage.  (A burst of 4*NTW KB per wave right after the last tap stalls the wave on the CU's write path
+  // for ~2000 cycles per tile -- measured 0.06-0.09 ms per layer; spread out, the stores ride under the MFMAs.)
+  // Needs the tap loop unrolled at compile time (TT = taps per chunk; TT = 0: dynamic loop, immediate epilogue).
+  f32x4 pend[NTW][4];
+  float* pend_base = P.out;  // wave-uniform: P.out + tile origin
+  int pend_mask = 0;
+  bool pend_live = false;
+  constexpr int NST = NTW * 4;               // stores per tile and lane, slot q = mt * NTW + nt
+  constexpr int PER_TAP = NTW >= 3 ? 2 : 1;  // slots slipped in after each tap
+  static_assert(TT == 0 || NST <= TT * PER_TAP, "every pending store must find a tap");
+  auto store_slot = [&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int mt = q / NTW, nt = q - mt * NTW;
+    if ((pend_mask >> mt) & 1) *reinterpret_cast<f32x4*>(pend_base + (coff[nt] + poff[mt])) = pend[nt][mt];
+  };
+  auto flush_from = [&](auto q0c) {  // slots q0 .. NST-1
+    constexpr int q0 = decltype(q0c)::value;
+    srk_static_for<q0, NST>([&](auto qc) { store_slot(qc); });
+  };
+  __syncthreads();  // filter and stage 0 visible
+  for (int s = 0; s < S; ++s) {
+    int n, r0, c0, cc;
+    decode(s, n, r0, c0, cc);
+    if (cc == 0) {
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (wave_live && T > 0 && !(B.dbg & 4)) {
+      const uint4* hal = hal0 + (size_t)(s & 1) * hbuf;
+      const uint4* wb = wl + (size_t)cc * wslot;
+      const size_t wstep = (size_t)B.ICc * wslot;
+      uint4 fa[2][2][NTW], fb[2][2][4];  // [buffer][plane][tile]
+      // tap walk in scalar registers (no LDS table: a table lookup would put a dependent LDS round trip and an
+      // lgkmcnt(0) in front of every tap's fragment reads): halo offset u*HW + v, filter slot t
+      int wt_toff = 0, wt_tv = 0, wt_t = 0;
+      auto load_frags = [&](uint4 (&a)[2][NTW], uint4 (&b)[2][4]) {
+        const uint4* hb = hal + wt_toff;
+        const uint4* wt = wb + (size_t)wt_t * wstep;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          b[0][mt] = hb[hp[mt]];
+          b[1][mt] = hb[hp[mt] + plane];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          a[0][nt] = wt[wrow[nt]];
+          a[1][nt] = wt[4 * NB + wrow[nt]];
+        }
+        ++wt_t;
+        ++wt_toff;
+        if (++wt_tv == P.KWv) {
+          wt_tv = 0;
+          wt_toff += P.HW - P.KWv;
+        }
+      };
+      auto mfmas = [&](const uint4 (&a)[2][NTW], const uint4 (&b)[2][4]) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mfma16(a[0][nt], b[1][mt], acc[nt][mt]);  // w_h * x_m
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mfma16(a[1][nt], b[0][mt], acc[nt][mt]);  // w_m * x_h
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mfma16(a[0][nt], b[0][mt], acc[nt][mt]);  // w_h * x_h
+      };
+      // (sched_barrier: keep the next tap's ds_read_b128s IN FRONT of the current tap's MFMAs -- the machine
+      //  scheduler otherwise sinks them behind ~16 MFMAs)
+      load_frags(fa[0], fb[0]);
+      if (TT > 0) {
+        srk_static_for<0, (TT > 0 ? TT : 1)>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          if (t + 1 < TT) load_frags(fa[(t + 1) & 1], fb[(t + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          mfmas(fa[t & 1], fb[t & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (pend_live) {
+            srk_static_for<t * PER_TAP, ((t + 1) * PER_TAP < NST ? (t + 1) * PER_TAP : NST)>([&](auto qc) { store_slot(qc); });
+          }
+        });
+        pend_live = false;
+      } else {
+        int t = 0;
+        for (; t + 2 <= T; t += 2) {
+          load_frags(fa[1], fb[1]);
+          __builtin_amdgcn_sched_barrier(0);
+          mfmas(fa[0], fb[0]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (t + 2 < T) load_frags(fa[0], fb[0]);
+          __builtin_amdgcn_sched_barrier(0);
+          mfmas(fa[1], fb[1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (t < T) mfmas(fa[0], fb[0]);
+      }
+    }
+    if (cc == B.ICc - 1 && wave_live && !(B.dbg & 2)) {
+      // tile finished (C/D col = lane & 15 = pixel, rows kq*4 + reg = 4 consecutive channels per M tile): park it
+      if (pend_live) flush_from(std::integral_constant<int, 0>{});  // (cannot happen with TT > 0)
+      pend_base = P.out + epi_tile_setup(P, n, r0, c0).off0;
+      pend_mask = 0;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int r = pix_ok[mt] >> 16, c = pix_ok[mt] & 0xffff;
+        if (pix_ok[mt] >= 0 && r0 + r < P.PH && c0 + c < P.PW) pend_mask |= 1 << mt;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          f32x4 v = acc[nt][mt] + bias4[nt];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : act_slope * v[e];
+          pend[nt][mt] = v;
+        }
+      }
+      pend_live = true;
+      if (TT == 0 || s == S - 1 || (B.dbg & 1024)) {  // no unrolled tap loop to ride under / last tile of this block
+        flush_from(std::integral_constant<int, 0>{});
+        pend_live = false;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Applicability: stride-1 CONV gathers, IC a multiple of 8 (16-byte channel groups), OC = 16 * {1..4}, filter planes
+// + two halo buffers within the LDS, every output group on the 16-byte store path, and a problem large enough to
+// keep one persistent block per CU busy for many tiles.  SRK_BFW: 0 never, 1 whenever applicable, unset = large only.
+bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, const float* out, const float* mask_y) {
+  const char* e = getenv("SRK_BFW");
+  const int mode = e ? atoi(e) : 2;
+  if (mode == 0 || mask_y || g.trans || g.stride != 1 || g.in_nchw || g.in_ps_r > 1) return false;
+  if (g.IC < 8 || g.IC % 8 != 0 || (uintptr_t)in % 16 != 0) return false;
+  if (g.OC % 16 != 0 || g.OC < 16 || g.OC > 64) return false;
+  const int T = g.KH * g.KW;
+  if (T > BFW_MAXTAPS - 1 || (T != 9 && g.OC > 48)) return false;  // (the 64-channel dynamic-tap variant spills)
+  if (!conv_epi_all_vector(g.OC, ep, out)) return false;
+  if (ep.residual || (ep.act == SRK_ACT_PRELU && ep.prelu_n > 1)) return false;
+  if (ep.act != SRK_ACT_NONE && ep.act != SRK_ACT_RELU && ep.act != SRK_ACT_LRELU && ep.act != SRK_ACT_PRELU) return false;
+  if ((long)g.N * g.OH * g.OW * g.OC >= (1L << 31)) return false;  // 32-bit in-tile output offsets
+  const size_t wbytes = (size_t)T * ((g.IC + 31) / 32) * 8 * g.OC * 16;
+  if (wbytes > 100 * 1024) return false;
+  if ((long)g.N * g.OH * g.OW >= (1L << 30) || (long)g.IH * g.IW * g.IC >= (1L << 30)) return false;
+  if (mode == 1) return true;
+  return (long)g.N * g.OH * g.OW >= 256L * 8 * kNumCU;
+}
+
+template <int NTW, int TT>
+static int bfw_launch_t(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
+  static int cur = 0;
+  const void* fn = reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT>);
+  if ((int)lds > cur) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    cur = (int)lds;
+  }
+  hipLaunchKernelGGL((k_conv_bfw<NTW, TT>), dim3(grid), dim3(512), lds, s, B);
+  return check_launch("conv_bfw");
+}
+template <int NTW>
+static int bfw_launch(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
+  // 3x3 with <= 32 output channels: unrolled taps + deferred stores (0.507 -> 0.492 ms on the c2 64->32 layer).  With
+  // 48 / 64 channels the unrolled variant needs > 256 VGPRs (spills; 0.42 -> 0.45 ms on the c2 32->48 layer).
+  if (NTW <= 2 && B.P.KHv * B.P.KWv == 9) return bfw_launch_t<NTW, 9>(B, lds, grid, s);
+  return bfw_launch_t<NTW, 0>(B, lds, grid, s);
+}
+
+// returns -1 when no tile fits (the caller falls back to the other kernels)
+int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s) {
+  const size_t elems = (size_t)g.KH * g.KW * g.IC * g.OC;
+  const uint4* wq = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wp) + bf3_prepared_offset(elems));
+  static int dbg = -1;
+  if (dbg < 0) dbg = getenv("SRK_DBG") ? atoi(getenv("SRK_DBG")) : 0;
+  return for_each_phase(g, in, wp, out, ep, nullptr, 0.f, [&](const MfmaConvParams& P0) {
+    BfwParams B{};
+    B.P = P0;
+    MfmaConvParams& P = B.P;
+    B.wq = wq;
+    B.NB = P.OC;
+    B.ICc = (P.IC + 31) / 32;
+    B.dbg = dbg;
+    const int T = P.KHv * P.KWv;
+    const size_t wbytes = (size_t)T * B.ICc * 8 * B.NB * 16;
+    const long lds_cap = 160L * 1024 - 512;
+    long px_cap = (lds_cap - (long)wbytes) / (2 * 128);  // halo pixels per buffer (128 bytes each)
+    px_cap &= ~15L;
+    if (px_cap > 64 * BFW_IT) px_cap = 64 * BFW_IT;
+    TilePick best{};
+    if (px_cap < 64 || !pick_tile(256, P.PH, P.PW, P.is, P.KHv, P.KWv, 32, (int)px_cap * 32, best)) return -1;
+    P.TH = best.TH; P.TW = best.TW; P.tiles_y = best.tiles_y; P.tiles_x = best.tiles_x; P.HH = best.HH; P.HW = best.HW;
+    B.NPIXp = (best.HH * best.HW + 15) & ~15;
+    const size_t lds = wbytes + (size_t)2 * 8 * B.NPIXp * 16;
+    const long ntiles = (long)P.tiles_x * P.tiles_y * P.N;
+    if (ntiles >= (1L << 30)) return -1;
+    B.ntiles = (int)ntiles;
+    int grid = kNumCU;
+    if (grid > ntiles) grid = (int)ntiles;
+    if (dbg & 32)
+      fprintf(stderr, "[srk] k_conv_bfw<%d>: lds %zu B (filter %zu), grid %d of %ld tiles, tile %dx%d halo %dx%d\n", P.OC / 16,
+              lds, wbytes, grid, ntiles, P.TH, P.TW, P.HH, P.HW);
+    switch (P.OC / 16) {
+      case 1: return bfw_launch<1>(B, lds, grid, s);
+      case 2: return bfw_launch<2>(B, lds, grid, s);
+      case 3: return bfw_launch<3>(B, lds, grid, s);
+      default: return bfw_launch<4>(B, lds, grid, s);
+    }
+  });
+}
+
+}  // namespace srk

@@ -21,7 +21,8 @@ ALGOS = {"auto": 0, "generic": 1, "mfma_fp32": 2, "bf16x6": 5}
 VARIANTS = {"auto": ("auto", {}), "generic": ("generic", {}), "mfma_fp32": ("mfma_fp32", {}),
             "auto_lds_weights": ("auto", {"SRK_BFD_SMALL": "0"}),
             "auto_global_weights_big": ("auto", {"SRK_BF3_DIRECT": "1", "SRK_BFD_SMALL": "0"}),
-            "auto_resident_filter": ("auto", {"SRK_BFR": "1", "SRK_BFD_SMALL": "0"}),
+            "auto_resident_filter": ("auto", {"SRK_BFR": "1", "SRK_BFD_SMALL": "0", "SRK_BFW": "0"}),
+            "auto_wave_specialized": ("auto", {"SRK_BFW": "1"}),
             "bf16x6": ("bf16x6", {}), "bf16x6_big": ("bf16x6", {"SRK_BFD_SMALL": "0"})}
 TOL_ALGO = {"auto": 1e-4, "generic": TOL_TIGHT, "mfma_fp32": TOL_TIGHT, "bf16x6": TOL_TIGHT}
 ACTS = {None: 0, "relu": 1, "lrelu": 3}
