@@ -325,8 +325,8 @@ def main():
         flop_l2 = 2.0 * args.batch * (H - 6) ** 2 * 32 * 64 * 9
         dom = max(range(3), key=lambda i: layer_ms[i])
         bf3 = pkg.ops.get_precision() != "fp32"
-        names = ["k_conv_bf3_rows<4> conv5x5 3->64 + ReLU", "k_conv_bf3<2> conv3x3 64->32 + ReLU",
-                 "k_conv_bfr<1,3> conv3x3 32->48 + pixel-shuffle store"] if bf3 else [
+        names = ["k_conv_bf3_rows<4> conv5x5 3->64 + ReLU", "k_conv_bfw<2> conv3x3 64->32 + ReLU",
+                 "k_conv_bfw<3> conv3x3 32->48 + pixel-shuffle store"] if bf3 else [
                  "k_conv_mfma_tg<4> conv5x5 3->64 + ReLU", "k_conv_mfma<2> conv3x3 64->32 + ReLU",
                  "k_conv_mfma<3> conv3x3 32->48 + pixel-shuffle store"]
         peak = BF16X3_PEAK_TFLOPS if bf3 else FP32_MFMA_PEAK_TFLOPS
