@@ -6,8 +6,8 @@
 // epilogue 0.08 ms, per-tap filter copies 0.07 ms, loop/barrier skeleton 0.11 ms, total 0.57 ms; co-resident blocks
 // run the same phases in lockstep.  Here the phases run CONCURRENTLY on different waves of one block:
 //
-//   * one block per CU, 8 waves: waves 0-3 are CONSUMERS (one per SIMD, 64 pixels x all 16*NTW output channels
-//     each), waves 4-7 are PRODUCERS;
+//   * one block per CU: 8 (or 4) CONSUMER waves of 32 (64) pixels x all 16*NTW output channels each, plus 4 PRODUCER
+//     waves;
 //   * the filter is copied to LDS once per block (as in k_conv_bfr); the block then walks (tile, 32-channel chunk)
 //     stages; stage s computes from halo buffer s&1 while the producers fill buffer (s+1)&1 -- one barrier per stage;
 //   * producers: global fp32 loads of stage s+2 are issued right after the LDS commit of stage s+1 (a full stage
@@ -50,8 +50,10 @@ struct BfwParams {
   int dbg;  // ablation (SRK_DBG): 1 no global loads, 2 no epilogue, 4 no MFMA loop, 16 no LDS commit, 1024 no deferred stores
 };
 
-template <int NTW, int TT>
-__global__ __launch_bounds__(512, 2) void k_conv_bfw(BfwParams B) {
+template <int NTW, int TT, int MTW>
+__global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_conv_bfw(BfwParams B) {
+  constexpr int NCW = 16 / MTW;          // consumer waves: MTW 16-pixel groups each, 256 pixels per block
+  constexpr int NTHR = 64 * (NCW + 4);   // + 4 producer waves
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   const MfmaConvParams& P = B.P;
   const int NB = B.NB;
@@ -61,11 +63,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfw(BfwParams B) {
   uint4* wl = smem4;
   uint4* hal0 = smem4 + (size_t)T * B.ICc * wslot;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool producer = wave >= 4;
+  const bool producer = wave >= NCW;
   const int j = lane & 15, kq = lane >> 4;
   const int npx = P.TH * P.TW, npix = P.HH * P.HW;
 
-  for (int e = tid; e < T * B.ICc * wslot; e += 512) {
+  for (int e = tid; e < T * B.ICc * wslot; e += NTHR) {
     const int slot = e / wslot, w = e - slot * wslot;
     const int t = slot / B.ICc, cc = slot - t * B.ICc;
     const int u = t / P.KWv, v = t - u * P.KWv;
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfw(BfwParams B) {
 
   if (producer) {
     // ------------------------------------------------------------------ producers
-    const int ptid = tid - 256;
+    const int ptid = tid - 64 * NCW;
     const int g = ptid & 3, hp0 = ptid >> 2;
     const int hy0 = hp0 / P.HW, hx0 = hp0 - hy0 * P.HW;
     const int dyp = 64 / P.HW, dxp = 64 - dyp * P.HW;
@@ -172,15 +174,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfw(BfwParams B) {
 
   // -------------------------------------------------------------------- consumers
   const int pw = wave;
-  int hp[4];
+  int hp[MTW];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    int m = pw * 64 + mt * 16 + j;
+  for (int mt = 0; mt < MTW; ++mt) {
+    int m = pw * (16 * MTW) + mt * 16 + j;
     if (m >= npx) m = 0;
     const int r = m / P.TW, c = m - r * P.TW;
     hp[mt] = (r * P.is) * P.HW + c * P.is + kq * B.NPIXp;
   }
-  const bool wave_live = pw * 64 < npx;
+  const bool wave_live = pw * (16 * MTW) < npx;
   const int plane = 4 * B.NPIXp;
   // transposed MFMA (A = filter, B = pixels): C/D col = lane & 15 = pixel, rows kq*4 + reg of M tile nt = the 4
   // consecutive output channels nt*16 + kq*4 + reg -> one 16-byte store per (pixel, tile); the 4 kq lanes of a pixel
@@ -193,13 +195,13 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfw(BfwParams B) {
   // plain NHWC or the fused pixel shuffle).  Only none / ReLU / leaky / scalar-PReLU activations reach this kernel
   // (conv_bfw_applicable), which makes the activation one branch-free select: v > 0 ? v : slope * v.
   f32x4 bias4[NTW];
-  int coff[NTW], poff[4];  // element offset of slot (mt, nt) from the tile origin = coff[nt] + poff[mt]
-  int pix_ok[4];  // (r << 16) | c of the lane's pixel in tile coordinates, -1 = beyond the tile
+  int coff[NTW], poff[MTW];  // element offset of slot (mt, nt) from the tile origin = coff[nt] + poff[mt]
+  int pix_ok[MTW];  // (r << 16) | c of the lane's pixel in tile coordinates, -1 = beyond the tile
   {
     const EpiTile e0 = epi_tile_setup(P, 0, 0, 0);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int m = pw * 64 + mt * 16 + j;
+    for (int mt = 0; mt < MTW; ++mt) {
+      const int m = pw * (16 * MTW) + mt * 16 + j;
       const int r = m / P.TW, c = m - r * P.TW;
       pix_ok[mt] = m < npx ? ((r << 16) | c) : -1;
       poff[mt] = r * e0.RS + c * e0.CS;
@@ -214,17 +216,17 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfw(BfwParams B) {
   const float act_slope = P.ep.act == SRK_ACT_NONE ? 1.f
                           : P.ep.act == SRK_ACT_RELU ? 0.f
                           : P.ep.act == SRK_ACT_PRELU ? P.ep.prelu_w[0] : P.ep.slope;
-  f32x4 acc[NTW][4];
+  f32x4 acc[NTW][MTW];
   // Deferred epilogue: the finished tile's values wait in `pend` and are stored one or two at a time between the taps
   // of the NEXT stage.  (A burst of 4*NTW KB per wave right after the last tap stalls the wave on the CU's write path
   // for ~2000 cycles per tile -- measured 0.06-0.09 ms per layer; spread out, the stores ride under the MFMAs.)
   // Needs the tap loop unrolled at compile time (TT = taps per chunk; TT = 0: dynamic loop, immediate epilogue).
-  f32x4 pend[NTW][4];
+  f32x4 pend[NTW][MTW];
   float* pend_base = P.out;  // wave-uniform: P.out + tile origin
   int pend_mask = 0;
   bool pend_live = false;
-  constexpr int NST = NTW * 4;               // stores per tile and lane, slot q = mt * NTW + nt
-  constexpr int PER_TAP = NTW >= 3 ? 2 : 1;  // slots slipped in after each tap
+  constexpr int NST = NTW * MTW;             // stores per tile and lane, slot q = mt * NTW + nt
+  constexpr int PER_TAP = NST > 9 ? 2 : 1;   // slots slipped in after each tap
   static_assert(TT == 0 || NST <= TT * PER_TAP, "every pending store must find a tap");
   auto store_slot = [&](auto qc) {
     constexpr int q = decltype(qc)::value;
@@ -243,21 +245,21 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfw(BfwParams B) {
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     if (wave_live && T > 0 && !(B.dbg & 4)) {
       const uint4* hal = hal0 + (size_t)(s & 1) * hbuf;
       const uint4* wb = wl + (size_t)cc * wslot;
       const size_t wstep = (size_t)B.ICc * wslot;
-      uint4 fa[2][2][NTW], fb[2][2][4];  // [buffer][plane][tile]
+      uint4 fa[2][2][NTW], fb[2][2][MTW];  // [buffer][plane][tile]
       // tap walk in scalar registers (no LDS table: a table lookup would put a dependent LDS round trip and an
       // lgkmcnt(0) in front of every tap's fragment reads): halo offset u*HW + v, filter slot t
       int wt_toff = 0, wt_tv = 0, wt_t = 0;
-      auto load_frags = [&](uint4 (&a)[2][NTW], uint4 (&b)[2][4]) {
+      auto load_frags = [&](uint4 (&a)[2][NTW], uint4 (&b)[2][MTW]) {
         const uint4* hb = hal + wt_toff;
         const uint4* wt = wb + (size_t)wt_t * wstep;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MTW; ++mt) {
           b[0][mt] = hb[hp[mt]];
           b[1][mt] = hb[hp[mt] + plane];
         }
@@ -273,19 +275,19 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfw(BfwParams B) {
           wt_toff += P.HW - P.KWv;
         }
       };
-      auto mfmas = [&](const uint4 (&a)[2][NTW], const uint4 (&b)[2][4]) {
+      auto mfmas = [&](const uint4 (&a)[2][NTW], const uint4 (&b)[2][MTW]) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mfma16(a[0][nt], b[1][mt], acc[nt][mt]);  // w_h * x_m
+          for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = mfma16(a[0][nt], b[1][mt], acc[nt][mt]);  // w_h * x_m
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mfma16(a[1][nt], b[0][mt], acc[nt][mt]);  // w_m * x_h
+          for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = mfma16(a[1][nt], b[0][mt], acc[nt][mt]);  // w_m * x_h
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mfma16(a[0][nt], b[0][mt], acc[nt][mt]);  // w_h * x_h
+          for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = mfma16(a[0][nt], b[0][mt], acc[nt][mt]);  // w_h * x_h
       };
       // (sched_barrier: keep the next tap's ds_read_b128s IN FRONT of the current tap's MFMAs -- the machine
       //  scheduler otherwise sinks them behind ~16 MFMAs)
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfw(BfwParams B) {
       pend_base = P.out + epi_tile_setup(P, n, r0, c0).off0;
       pend_mask = 0;
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
+      for (int mt = 0; mt < MTW; ++mt) {
         const int r = pix_ok[mt] >> 16, c = pix_ok[mt] & 0xffff;
         if (pix_ok[mt] >= 0 && r0 + r < P.PH && c0 + c < P.PW) pend_mask |= 1 << mt;
 #pragma unroll
@@ -366,23 +368,32 @@ bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, co
   return (long)g.N * g.OH * g.OW >= 256L * 8 * kNumCU;
 }
 
-template <int NTW, int TT>
+template <int NTW, int TT, int MTW>
 static int bfw_launch_t(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
   static int cur = 0;
-  const void* fn = reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT>);
+  const void* fn = reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, MTW>);
   if ((int)lds > cur) {
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     cur = (int)lds;
   }
-  hipLaunchKernelGGL((k_conv_bfw<NTW, TT>), dim3(grid), dim3(512), lds, s, B);
+  hipLaunchKernelGGL((k_conv_bfw<NTW, TT, MTW>), dim3(grid), dim3(64 * (16 / MTW + 4)), lds, s, B);
   return check_launch("conv_bfw");
 }
 template <int NTW>
 static int bfw_launch(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
-  // 3x3 with <= 32 output channels: unrolled taps + deferred stores (0.507 -> 0.492 ms on the c2 64->32 layer).  With
-  // 48 / 64 channels the unrolled variant needs > 256 VGPRs (spills; 0.42 -> 0.45 ms on the c2 32->48 layer).
-  if (NTW <= 2 && B.P.KHv * B.P.KWv == 9) return bfw_launch_t<NTW, 9>(B, lds, grid, s);
-  return bfw_launch_t<NTW, 0>(B, lds, grid, s);
+  // Consumer waves: 8 x 32 pixels (two per SIMD: LDS latency of one hides under the MFMAs of the other; measured
+  // -1 % / -3.5 % on the c2 64->32 / 32->48 layers vs 4 x 64 pixels) while the kernel fits 168 VGPRs (<= 48 output
+  // channels); 64 channels: 4 x 64 pixels.  3x3 kernels get the unrolled tap loop with deferred stores; with 64-pixel
+  // consumer waves and > 32 channels that variant spills (256 VGPRs) and the dynamic loop is used.
+  static const int mtw_env = getenv("SRK_BFW_MTW") ? atoi(getenv("SRK_BFW_MTW")) : 0;  // experiment: 2 or 4
+  const bool t9 = B.P.KHv * B.P.KWv == 9;
+  const int mtw = mtw_env ? mtw_env : (NTW <= 3 ? 2 : 4);
+  if (mtw == 2 && NTW <= 3) {
+    if (t9) return bfw_launch_t<NTW, 9, 2>(B, lds, grid, s);
+    return bfw_launch_t<NTW, 0, 2>(B, lds, grid, s);
+  }
+  if (NTW <= 2 && t9) return bfw_launch_t<NTW, 9, 4>(B, lds, grid, s);
+  return bfw_launch_t<NTW, 0, 4>(B, lds, grid, s);
 }
 
 // returns -1 when no tile fits (the caller falls back to the other kernels)
