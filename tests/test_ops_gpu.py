@@ -128,6 +128,43 @@ def test_conv_few_output_channels_backward(gpu, cin, cout, k, p, H, W, N):
     assert rel_err(bg.grad, br.grad.float()) < 1e-4
 
 
+@pytest.mark.parametrize("cin,cout,k,p,H,W,N,act,ps", [
+    (64, 32, 3, 0, 30, 41, 2, "relu", 0),     # c2 layer 2 shape class: two chunks, unrolled taps + deferred stores
+    (32, 48, 3, 0, 21, 37, 2, None, 4),       # c2 layer 3: one chunk, fused pixel-shuffle store
+    (96, 16, 3, 1, 19, 19, 1, "lrelu", 0),    # three chunks, one 16-channel tile, padding
+    (40, 64, 3, 1, 17, 23, 2, "prelu", 0),    # Cin not a multiple of 32 (last chunk partly empty), 64 channels
+    (16, 32, 5, 2, 20, 20, 1, "relu", 0),     # 5x5: dynamic tap loop, immediate epilogue
+    (32, 48, 1, 0, 33, 9, 3, None, 0),        # 1x1
+    (64, 48, 3, 1, 40, 40, 1, "relu", 2),     # pixel shuffle r = 2 with 12-channel runs
+])
+def test_conv_wave_specialized(gpu, monkeypatch, cin, cout, k, p, H, W, N, act, ps):
+    """k_conv_bfw (producer / consumer waves, filter resident in LDS) forced onto small problems: every template
+    variant (1-4 channel tiles, unrolled / dynamic taps, 32- / 64-pixel consumer waves), ragged tiles on both image
+    edges, partial channel chunks, all activations it accepts, the fused pixel-shuffle store; vs torch fp64."""
+    monkeypatch.setenv("SRK_BFW", "1")
+    pkg = _pkg()
+    ops = pkg.ops
+    x = fill.randn((N, cin, H, W), 91)
+    w = fill.randn((cout, cin, k, k), 92, (2.0 / (cin * k * k)) ** 0.5)
+    b = fill.randn((cout,), 93, 0.1)
+    slope = torch.tensor([0.3])
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 1, p)
+    if act == "relu":
+        ref = torch.relu(ref)
+    elif act == "lrelu":
+        ref = torch.nn.functional.leaky_relu(ref, 0.2)
+    elif act == "prelu":
+        ref = torch.nn.functional.prelu(ref, slope.double())
+    if ps:
+        ref = torch.nn.functional.pixel_shuffle(ref, ps)
+    code = {None: 0, "relu": 1, "lrelu": 3, "prelu": pkg._lib.ACT_PRELU}[act]
+    cfg = ops.ConvCfg(1, p, False, 0, code, 0.2 if act == "lrelu" else 0.0, ps, ALGOS["auto"])
+    with torch.no_grad():
+        y = ops.conv2d_infer(x.to(gpu), w.to(gpu), b.to(gpu), None, cfg, slope.to(gpu) if act == "prelu" else None)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert rel_err(y, ref.float()) < 1e-4
+
+
 @pytest.mark.parametrize("r,C", [(2, 64), (4, 3), (3, 2)])
 def test_conv_fused_pixel_shuffle(gpu, r, C):
     """conv + PixelShuffle store (PSBlock, base_networks.py:179-181), forward and backward."""
