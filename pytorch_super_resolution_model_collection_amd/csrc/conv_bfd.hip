@@ -138,7 +138,7 @@ constexpr int BFD_EPI_STRIDE = 68;  // floats per staged output row (64 + 4: con
 // stores by all NOW waves of the group.  C/D layout: col = lane&15 (channel), row = (lane>>4)*4+reg.
 template <int NTW, int NPW, int NOW>
 __device__ __forceinline__ void bfd_epilogue(const MfmaConvParams& P, float* smem_f, const f32x4 (&acc)[4][NTW], int n,
-                                             int r0, int c0, int ocb, int pw, int ow, int lane) {
+                                             int r0, int c0, int ocb, int pw, int ow, int lane, bool active = true) {
   const int j = lane & 15, kq = lane >> 4;
   const int npx = P.TH * P.TW;
   __syncthreads();
@@ -148,20 +148,22 @@ __device__ __forceinline__ void bfd_epilogue(const MfmaConvParams& P, float* sme
   const int gi = ow * 64 + lane;
   const int row0 = gi / Q4, q4 = gi - row0 * Q4;
   const int oc4 = ocb + q4 * 4;
-  const bool lane_on = row0 < RPI && oc4 < P.OC;
+  const bool lane_on = active && row0 < RPI && oc4 < P.OC;  // (inactive waves -- K-split partners -- only keep the barriers)
   const int tw_magic = div_small_magic(P.TW);
   EpiCol col{};
   if (lane_on) col = epi_col_setup(P.ep, P.OW, P.OC, oc4);
   const EpiTile et = epi_tile_setup(P, n, r0, c0);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
+    if (active) {
 #pragma unroll
-    for (int mh = 0; mh < 2; ++mh)
+      for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt)
+        for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-          st[(mh * 16 + kq * 4 + reg) * BFD_EPI_STRIDE + (ow * NTW + nt) * 16 + j] = acc[2 * h + mh][nt][reg];
+          for (int reg = 0; reg < 4; ++reg)
+            st[(mh * 16 + kq * 4 + reg) * BFD_EPI_STRIDE + (ow * NTW + nt) * 16 + j] = acc[2 * h + mh][nt][reg];
+    }
     __syncthreads();
     if (lane_on) {
 #pragma unroll 2
@@ -183,14 +185,18 @@ __device__ __forceinline__ void bfd_epilogue(const MfmaConvParams& P, float* sme
   }
 }
 
-template <int NTW, int NPW, int NOW, int NP, int PF>
-__global__ __launch_bounds__(64 * NPW * NOW, 2) void k_conv_bfd(
+// KS = 2 (small problems with every chunk staged up front): a second set of NPW*NOW waves takes the odd channel
+// chunks -- two waves per SIMD on a block that is pure latency otherwise -- and the partial accumulators meet in LDS
+// before the epilogue.
+template <int NTW, int NPW, int NOW, int NP, int PF, int KS>
+__global__ __launch_bounds__(64 * NPW * NOW * KS, 2) void k_conv_bfd(
     BfdParams B) {
-  constexpr int NTHR = 64 * NPW * NOW;
+  constexpr int NTHR = 64 * NPW * NOW * KS;
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   const MfmaConvParams& P = B.P;
   uint4* hal = smem4;  // [NP][4][NPIXp]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave0 = tid >> 6;
+  const int kgrp = wave0 / (NPW * NOW), wave = wave0 - kgrp * (NPW * NOW);  // K-split group, wave inside it
   const int pw = wave % NPW, ow = wave / NPW;
   const int j = lane & 15, kq = lane >> 4;
   int b = blockIdx.x;
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(64 * NPW * NOW, 2) void k_conv_bfd(
       h.t = 0;
       h.tv = 0;
       h.wt = wtap0;
-      ++h.cc;
+      h.cc += KS;
     }
   };
   // filter fragments of the head position -> registers (past the end the walk re-reads the last chunk: valid
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(64 * NPW * NOW, 2) void k_conv_bfd(
 
   if (T > 0) {
     uint4 bq[PF + 1][NP][NTW];  // bq[0] = current tap, bq[1..PF] = the following taps
-    Walk head{0, 0, 0, wtap0};
+    Walk head{kgrp, 0, 0, wtap0};
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
       load_b(head, bq[d]);
@@ -302,9 +308,10 @@ __global__ __launch_bounds__(64 * NPW * NOW, 2) void k_conv_bfd(
     // Segments of taps between barriers: one chunk each, or (allc) a single segment over every chunk so that
     // the rotation below runs across chunk boundaries.
     const int nseg = B.allc ? 1 : B.ICc;
-    const int seg_len = B.allc ? B.ICc * T : T;
-    const int cadv = B.allc ? cstride : 0;
-    int ct = 0, ctv = 0, coff = 0, cbase = 0;  // compute walk: halo offset of the current tap
+    // (KS = 2 runs only with allc: group kgrp walks chunks kgrp, kgrp + 2, ...)
+    const int seg_len = B.allc ? ((B.ICc - kgrp + KS - 1) / KS) * T : T;
+    const int cadv = B.allc ? KS * cstride : 0;
+    int ct = 0, ctv = 0, cbase = kgrp * cstride, coff = cbase;  // compute walk: halo offset of the current tap
     auto cwalk_next = [&]() {
       ++coff;
       if (++ctv == P.KWv) {
@@ -369,7 +376,25 @@ __global__ __launch_bounds__(64 * NPW * NOW, 2) void k_conv_bfd(
     if (acc[0][0][0] == 123.456f) P.out[0] = 1.f;  // keep the accumulators live
     return;
   }
-  bfd_epilogue<NTW, NPW, NOW>(P, reinterpret_cast<float*>(smem4), acc, n, r0, c0, ocb, pw, ow, lane);
+  if (KS > 1) {
+    // partial sums of the odd-chunk group -> LDS (the halo is dead) -> added by the even-chunk group, in a fixed order
+    f32x4* red = reinterpret_cast<f32x4*>(smem4) + (size_t)wave * (4 * NTW * 64) + lane;
+    __syncthreads();
+    if (kgrp == 1) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) red[(mt * NTW + nt) * 64] = acc[mt][nt];
+    }
+    __syncthreads();
+    if (kgrp == 0) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] += red[(mt * NTW + nt) * 64];
+    }
+  }
+  bfd_epilogue<NTW, NPW, NOW>(P, reinterpret_cast<float*>(smem4), acc, n, r0, c0, ocb, pw, ow, lane, kgrp == 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -631,20 +656,41 @@ static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
   }
   const size_t epi_bytes = (size_t)NPW * 32 * BFD_EPI_STRIDE * sizeof(float);
   if (lds < epi_bytes) lds = epi_bytes;
+  dim3 grid((unsigned)((size_t)P.tiles_x * P.tiles_y * P.N), B.OCb);
+  if constexpr (NPW == 1) {
+    // small-problem blocks with >= 2 staged chunks: split the chunks over two wave groups (SRK_BFD_KSPLIT=0: off)
+    static const int ksplit = getenv("SRK_BFD_KSPLIT") ? atoi(getenv("SRK_BFD_KSPLIT")) : 1;
+    const size_t red_bytes = (size_t)NOW * 4 * NTW * 64 * 16;
+    // only while the grid leaves the CUs with one block each: with two resident blocks the other block already hides the
+    // latency and the split just adds the reduction (B = 32 EDSR shard: 3.28 -> 3.55 ms with it, B = 16: 2.63 -> 2.37 ms)
+    if (ksplit && B.allc && B.ICc >= 2 && ((long)grid.x * grid.y <= kNumCU + kNumCU / 4 || ksplit > 1)) {
+      if (lds < red_bytes) lds = red_bytes;
+      static int cur2 = 0;
+      const void* fn2 = reinterpret_cast<const void*>(&k_conv_bfd<NTW, NPW, NOW, NP, PF, 2>);
+      if ((int)lds > cur2) {
+        (void)hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        cur2 = (int)lds;
+      }
+      if (B.dbg & 32)
+        fprintf(stderr, "[srk] k_conv_bfd<%d,%d,%d,%d,%d> K-split 2: lds %zu B, grid %u x %u, tile %dx%d halo %dx%d\n", NTW, NPW,
+                NOW, NP, PF, lds, grid.x, grid.y, P.TH, P.TW, P.HH, P.HW);
+      hipLaunchKernelGGL((k_conv_bfd<NTW, NPW, NOW, NP, PF, 2>), grid, dim3(64 * NPW * NOW * 2), lds, s, B);
+      return check_launch("conv_bfd");
+    }
+  }
   static int cur = 0;
-  const void* fn = reinterpret_cast<const void*>(&k_conv_bfd<NTW, NPW, NOW, NP, PF>);
+  const void* fn = reinterpret_cast<const void*>(&k_conv_bfd<NTW, NPW, NOW, NP, PF, 1>);
   if ((int)lds > cur) {
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     cur = (int)lds;
   }
-  dim3 grid((unsigned)((size_t)P.tiles_x * P.tiles_y * P.N), B.OCb);
   if (B.dbg & 32) {
     int nb = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * NPW * NOW, lds);
     fprintf(stderr, "[srk] k_conv_bfd<%d,%d,%d,%d,%d>: lds %zu B, grid %u x %u, occupancy %d blocks/CU, tile %dx%d halo %dx%d\n",
             NTW, NPW, NOW, NP, PF, lds, grid.x, grid.y, nb, P.TH, P.TW, P.HH, P.HW);
   }
-  hipLaunchKernelGGL((k_conv_bfd<NTW, NPW, NOW, NP, PF>), grid, dim3(64 * NPW * NOW), lds, s, B);
+  hipLaunchKernelGGL((k_conv_bfd<NTW, NPW, NOW, NP, PF, 1>), grid, dim3(64 * NPW * NOW), lds, s, B);
   return check_launch("conv_bfd");
 }
 
@@ -693,12 +739,7 @@ static int bfd_launch_phase(MfmaConvParams P, const uint4* wq, const uint4* wq3,
       case 1: return bfd_launch<1, 1, 1, NP, 2>(B, SMALL, s);
       case 2: return bfd_launch<1, 1, 2, NP, 2>(B, SMALL, s);
       case 3: return bfd_launch<1, 1, 3, NP, 2>(B, SMALL, s);
-      default: {
-        static const int pf = getenv("SRK_BFD_PF") ? atoi(getenv("SRK_BFD_PF")) : 2;
-        if (pf == 5) return bfd_launch<1, 1, 4, NP, 5>(B, SMALL, s);
-        if (pf == 8) return bfd_launch<1, 1, 4, NP, 8>(B, SMALL, s);
-        return bfd_launch<1, 1, 4, NP, 2>(B, SMALL, s);
-      }
+      default: return bfd_launch<1, 1, 4, NP, 2>(B, SMALL, s);  // (filter prefetch depth 5 / 8 measured: no gain)
     }
   }
   switch (NT) {
