@@ -35,6 +35,7 @@ int conv_wgrad_reduce_launch(const float* ws, float* dw, int G, int Cout, int Ci
                              hipStream_t s);
 
 constexpr int WB_MAXOCT = 64;  // octets per tile (<= 512 pixels)
+constexpr int WB_IT = 1;       // pixel pairs per thread loaded together while staging (4 measured: no gain plain, spills in the specialised variant)
 
 struct WgBfParams {
   const float* x;
@@ -110,23 +111,31 @@ __device__ __forceinline__ f32x4 wb_load4(const float* __restrict__ src, const f
 
 // CIT: 16-channel input tiles per block (one per wave row), COW: output-channel wave columns,
 // NTW: 16-channel output tiles per wave.  CIT * COW = 4 waves.
-template <int CIT, int COW, int NTW>
-__global__ __launch_bounds__(256, 2) void k_wgrad_bf(WgBfParams P) {
+// SPEC (wave-specialised, 768 threads, one block per CU): waves 4-11 stage tile t+1 into the second LDS buffer set
+// (global loads, masking, bf16 split, transposed stores) WHILE waves 0-3 run the K loop of tile t; one barrier per tile.
+// The per-tile kernel's two phases are about equally long and co-resident blocks run them in lockstep; here they
+// overlap by construction, and one block per CU halves the number of partial slabs.
+template <int CIT, int COW, int NTW, bool SPEC>
+__global__ __launch_bounds__(SPEC ? 768 : 256, SPEC ? 3 : 2) void k_wgrad_bf(WgBfParams P) {
   constexpr int CIB = CIT * 16, COB = COW * NTW * 16;
+  constexpr int NTHR = SPEC ? 768 : 256;
+  constexpr int NST = SPEC ? 512 : 256;  // staging threads (SPEC: 8 stager waves keep the staging rate of two 256-thread blocks)
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
   __shared__ int oct_x[WB_MAXOCT], oct_y[WB_MAXOCT];
-  __shared__ float bred[256][4];
-  unsigned short* xs = smem16;                          // [2][CIB][CS]
-  unsigned short* ys = smem16 + (size_t)2 * CIB * P.CS;  // [2][COB][DS]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float bred[NST][4];
+  const size_t buf_shorts = (size_t)2 * CIB * P.CS + (size_t)2 * COB * P.DS;  // one buffer set: [2][CIB][CS] + [2][COB][DS]
+  const int tid0 = threadIdx.x, lane = tid0 & 63, wave = tid0 >> 6;
+  const bool stager = !SPEC || wave >= 4;    // stages tiles
+  const bool worker = !SPEC || wave < 4;     // runs the K loop, owns accumulators
+  const int tid = SPEC ? (wave >= 4 ? tid0 - 256 : tid0) : tid0;  // index among the staging threads (stagers) / working threads
   const int i = lane & 15, kq = lane >> 4;
-  const int cit = wave % CIT, cow = wave / CIT;
+  const int cit = (wave & 3) % CIT, cow = (wave & 3) / CIT;
   const int cib = blockIdx.y * CIB, cob = blockIdx.z * COB;
   const int noct = P.TH * P.TWo;
   const bool want_bias = P.bias_partial != nullptr && blockIdx.y == 0;
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
-  for (int o = tid; o < P.nks * 4; o += 256) {
+  for (int o = tid0; o < P.nks * 4; o += NTHR) {
     if (o < noct) {
       const int orow = o / P.TWo, oc = o - orow * P.TWo;
       oct_x[o] = orow * P.HWp + oc * 8;
@@ -136,9 +145,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf(WgBfParams P) {
       oct_y[o] = P.TH * P.TW;
     }
   }
-  for (int e = tid; e < 2 * COB * 4; e += 256) {  // zero octets (never overwritten by the staging)
-    const int pc = e >> 2, w = e & 3;
-    reinterpret_cast<unsigned*>(ys + (size_t)pc * P.DS + P.TH * P.TW)[w] = 0u;
+  for (int e = tid0; e < (SPEC ? 2 : 1) * 2 * COB * 4; e += NTHR) {  // zero octets (never overwritten by the staging)
+    const int bsel = e / (2 * COB * 4), e2 = e - bsel * (2 * COB * 4);
+    const int pc = e2 >> 2, w = e2 & 3;
+    unsigned short* ysb = smem16 + bsel * buf_shorts + (size_t)2 * CIB * P.CS;
+    reinterpret_cast<unsigned*>(ysb + (size_t)pc * P.DS + P.TH * P.TW)[w] = 0u;
   }
 
   f32x4 acc[3][3][NTW];
@@ -149,23 +160,21 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf(WgBfParams P) {
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) acc[u][v][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const unsigned short* xa_h = xs + (size_t)(cit * 16 + i) * P.CS;
-  const unsigned short* xa_l = xa_h + (size_t)CIB * P.CS;
-  const unsigned short* yb_h = ys + (size_t)(cow * NTW * 16 + i) * P.DS;
-  const unsigned short* yb_l = yb_h + (size_t)COB * P.DS;
   const int tw2 = P.TW >> 1;
 
-  for (int tile = blockIdx.x; tile < P.ntiles; tile += P.G) {
+  // ---- stage one tile into buffer set `bsel` (256 staging threads)
+  auto stage = [&](int tile, int bsel) {
+    unsigned short* xs = smem16 + bsel * buf_shorts;          // [2][CIB][CS]
+    unsigned short* ys = xs + (size_t)2 * CIB * P.CS;          // [2][COB][DS]
     int b = tile;
     const int txi = b % P.tiles_x;
     b /= P.tiles_x;
     const int tyi = b % P.tiles_y;
     const int n = b / P.tiles_y;
     const int r0 = tyi * P.TH, c0 = txi * P.TW;
-    __syncthreads();  // previous tile fully consumed (tables / zero octets visible on the first pass)
     if (!(P.dbg & 2)) {  // X halo: rows [r0-pad, +HH), cols [c0-pad, +TW+KW-1), channels [cib, cib+CIB) -> planes [ci][hy][hx]
       // A thread's channel group q is fixed (256 % QN == 0): it walks pixel pairs pp, pp + 256/QN, ...
-      constexpr int QN = CIB / 4, PSTEP = 256 / QN;
+      constexpr int QN = CIB / 4, PSTEP = NST / QN;
       // only the TW + KW - 1 columns the fragments can touch are loaded (the plane row stride HWp = TW + 8 is for
       // the 16-byte alignment of the octets)
       const int need2 = (P.TW + P.KW) >> 1;
@@ -176,26 +185,40 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf(WgBfParams P) {
       const int nch = P.Cin - ch;  // channels of this group that exist (<= 0: none)
       const float* __restrict__ xb = P.x + (size_t)n * P.XH * P.XW * P.Cin;  // wave-uniform image base
       unsigned short* xq = xs + (size_t)(q * 4) * P.CS;
-      for (int pp = tid / QN; pp < npairs; pp += PSTEP) {
-        const int hy = wb_div20(pp, need2_magic), hx = (pp - hy * need2) * 2;
-        const int iy = by0 + hy, ix = bx0 + hx;
-        const bool rowok = (unsigned)iy < (unsigned)P.XH && nch > 0;
-        const unsigned off = (unsigned)(iy * P.XW + ix) * (unsigned)P.Cin + (unsigned)ch;
-        const f32x4 p0 = wb_load4(xb, nullptr, 0.f, off, rowok && (unsigned)ix < (unsigned)P.XW, nch, P.vec_x);
-        const f32x4 p1 = wb_load4(xb, nullptr, 0.f, off + (unsigned)P.Cin, rowok && (unsigned)(ix + 1) < (unsigned)P.XW,
-                                  nch, P.vec_x);
-        unsigned hi[4], lo[4];
-        wb_split_pair(p0, p1, hi, lo);
-        unsigned short* dst = xq + hy * P.HWp + hx;
+      // batches of WB_IT pixel pairs per thread: every global load of a batch is issued before the first conversion
+      // (one exposed load latency per batch instead of one per pair)
+      for (int pp0 = tid / QN; pp0 < npairs; pp0 += PSTEP * WB_IT) {
+        f32x4 p0[WB_IT], p1[WB_IT];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          *reinterpret_cast<unsigned*>(dst + (size_t)c * P.CS) = hi[c];
-          *reinterpret_cast<unsigned*>(dst + (size_t)(CIB + c) * P.CS) = lo[c];
+        for (int k = 0; k < WB_IT; ++k) {
+          const int pp = pp0 + k * PSTEP;
+          const int hy = wb_div20(pp, need2_magic), hx = (pp - hy * need2) * 2;
+          const int iy = by0 + hy, ix = bx0 + hx;
+          const bool rowok = pp < npairs && (unsigned)iy < (unsigned)P.XH && nch > 0;
+          const unsigned off = (unsigned)(iy * P.XW + ix) * (unsigned)P.Cin + (unsigned)ch;
+          p0[k] = wb_load4(xb, nullptr, 0.f, off, rowok && (unsigned)ix < (unsigned)P.XW, nch, P.vec_x);
+          p1[k] = wb_load4(xb, nullptr, 0.f, off + (unsigned)P.Cin, rowok && (unsigned)(ix + 1) < (unsigned)P.XW, nch,
+                           P.vec_x);
+        }
+#pragma unroll
+        for (int k = 0; k < WB_IT; ++k) {
+          const int pp = pp0 + k * PSTEP;
+          if (pp < npairs) {
+            const int hy = wb_div20(pp, need2_magic), hx = (pp - hy * need2) * 2;
+            unsigned hi[4], lo[4];
+            wb_split_pair(p0[k], p1[k], hi, lo);
+            unsigned short* dst = xq + hy * P.HWp + hx;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              *reinterpret_cast<unsigned*>(dst + (size_t)c * P.CS) = hi[c];
+              *reinterpret_cast<unsigned*>(dst + (size_t)(CIB + c) * P.CS) = lo[c];
+            }
+          }
         }
       }
     }
     if (!(P.dbg & 2)) {  // dY tile: rows [r0, +TH), cols [c0, +TW), channels [cob, cob+COB) -> planes [co][r][c] (masked)
-      constexpr int QN = COB / 4, PSTEP = 256 / QN;
+      constexpr int QN = COB / 4, PSTEP = NST / QN;
       const unsigned tw2_magic = wb_magic20(tw2);
       const int npairs = P.TH * tw2;
       const int q = tid % QN, ch = cob + q * 4;
@@ -220,25 +243,45 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf(WgBfParams P) {
       const float* __restrict__ yb = P.dy + img;
       const float* __restrict__ mb = P.mask_y ? P.mask_y + img : nullptr;
       unsigned short* yq = ys + (size_t)(q * 4) * P.DS;
-      for (int pp = tid / QN; pp < npairs; pp += PSTEP) {
-        const int r = wb_div20(pp, tw2_magic), c = (pp - r * tw2) * 2;
-        const int iy = r0 + r, ix = c0 + c;
-        const bool rowok = iy < P.YH && nch > 0;
-        const unsigned off = (unsigned)iy * srow + (unsigned)ix * scol + koff;
-        const f32x4 p0 = wb_load4(yb, mb, P.mask_slope, off, rowok && ix < P.YW, nch, P.vec_y);
-        const f32x4 p1 = wb_load4(yb, mb, P.mask_slope, off + scol, rowok && ix + 1 < P.YW, nch, P.vec_y);
-        bsum += p0 + p1;  // this thread's channel group is fixed
-        unsigned hi[4], lo[4];
-        wb_split_pair(p0, p1, hi, lo);
-        unsigned short* dst = yq + r * P.TW + c;
+      for (int pp0 = tid / QN; pp0 < npairs; pp0 += PSTEP * WB_IT) {
+        f32x4 p0[WB_IT], p1[WB_IT];
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          *reinterpret_cast<unsigned*>(dst + (size_t)cc * P.DS) = hi[cc];
-          *reinterpret_cast<unsigned*>(dst + (size_t)(COB + cc) * P.DS) = lo[cc];
+        for (int k = 0; k < WB_IT; ++k) {
+          const int pp = pp0 + k * PSTEP;
+          const int r = wb_div20(pp, tw2_magic), c = (pp - r * tw2) * 2;
+          const int iy = r0 + r, ix = c0 + c;
+          const bool rowok = pp < npairs && iy < P.YH && nch > 0;
+          const unsigned off = (unsigned)iy * srow + (unsigned)ix * scol + koff;
+          p0[k] = wb_load4(yb, mb, P.mask_slope, off, rowok && ix < P.YW, nch, P.vec_y);
+          p1[k] = wb_load4(yb, mb, P.mask_slope, off + scol, rowok && ix + 1 < P.YW, nch, P.vec_y);
+        }
+#pragma unroll
+        for (int k = 0; k < WB_IT; ++k) {
+          const int pp = pp0 + k * PSTEP;
+          if (pp < npairs) {
+            const int r = wb_div20(pp, tw2_magic), c = (pp - r * tw2) * 2;
+            bsum += p0[k] + p1[k];  // this thread's channel group is fixed
+            unsigned hi[4], lo[4];
+            wb_split_pair(p0[k], p1[k], hi, lo);
+            unsigned short* dst = yq + r * P.TW + c;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+              *reinterpret_cast<unsigned*>(dst + (size_t)cc * P.DS) = hi[cc];
+              *reinterpret_cast<unsigned*>(dst + (size_t)(COB + cc) * P.DS) = lo[cc];
+            }
+          }
         }
       }
     }
-    __syncthreads();
+  };
+  // ---- K loop of the tile in buffer set `bsel` (4 working waves)
+  auto kloop = [&](int bsel) {
+    const unsigned short* xs = smem16 + bsel * buf_shorts;
+    const unsigned short* ys = xs + (size_t)2 * CIB * P.CS;
+    const unsigned short* xa_h = xs + (size_t)(cit * 16 + i) * P.CS;
+    const unsigned short* xa_l = xa_h + (size_t)CIB * P.CS;
+    const unsigned short* yb_h = ys + (size_t)(cow * NTW * 16 + i) * P.DS;
+    const unsigned short* yb_l = yb_h + (size_t)COB * P.DS;
     for (int ks = 0; ks < ((P.dbg & 4) ? 0 : P.nks); ++ks) {
       const int ox = oct_x[ks * 4 + kq], oy = oct_y[ks * 4 + kq];
       uint4 bh[NTW], bl[NTW];
@@ -283,21 +326,46 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf(WgBfParams P) {
         }
       }
     }
+  };
+
+  if (!SPEC) {
+    for (int tile = blockIdx.x; tile < P.ntiles; tile += P.G) {
+      __syncthreads();  // previous tile fully consumed (tables / zero octets visible on the first pass)
+      stage(tile, 0);
+      __syncthreads();
+      kloop(0);
+    }
+  } else {
+    const int ntb = ((int)blockIdx.x < P.ntiles) ? (P.ntiles - (int)blockIdx.x + P.G - 1) / P.G : 0;
+    __syncthreads();  // tables / zero octets visible
+    if (stager && ntb > 0) stage(blockIdx.x, 0);
+    __syncthreads();
+    for (int it = 0; it < ntb; ++it) {
+      if (stager) {
+        if (it + 1 < ntb) stage(blockIdx.x + (it + 1) * P.G, (it + 1) & 1);
+      } else {
+        kloop(it & 1);
+      }
+      __syncthreads();
+    }
   }
 
   if (want_bias) {  // column sums of dY: combine the threads that staged the same channel group
     constexpr int QN = COB / 4;
     __syncthreads();
+    if (stager) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bred[tid][e] = bsum[e];
+      for (int e = 0; e < 4; ++e) bred[tid][e] = bsum[e];
+    }
     __syncthreads();
-    if (tid < COB && cob + tid < P.Cout) {
+    if (stager && tid < COB && cob + tid < P.Cout) {
       const int q = tid >> 2, e = tid & 3;
       float s = 0.f;
-      for (int t = q; t < 256; t += QN) s += bred[t][e];
+      for (int t = q; t < NST; t += QN) s += bred[t][e];
       P.bias_partial[(size_t)blockIdx.x * P.Cout + cob + tid] = s;
     }
   }
+  if (!worker) return;
   // partial slab ws[g][t][ci][co]; C/D layout: col = lane&15 (co), row = (lane>>4)*4 + reg (ci)
   float* slab = P.ws + (size_t)blockIdx.x * P.KH * P.KW * P.Cin * P.Cout;
 #pragma unroll
@@ -409,14 +477,24 @@ size_t conv_wgrad_bf_ws(const srk_conv_desc& d) {
 }
 
 template <int CIT, int COW, int NTW>
-static void wb_launch(const WgBfParams& P, dim3 grid, size_t lds, hipStream_t s) {
+static void wb_launch(const WgBfParams& P, dim3 grid, size_t lds, bool spec, hipStream_t s) {
+  if (spec) {
+    static int cur2 = 0;
+    if ((int)(2 * lds) > cur2) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
+      cur2 = (int)(2 * lds);
+    }
+    hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, true>), grid, dim3(768), 2 * lds, s, P);
+    return;
+  }
   static int cur = 0;
   if ((int)lds > cur) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     cur = (int)lds;
   }
-  hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW>), grid, dim3(256), lds, s, P);
+  hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, false>), grid, dim3(256), lds, s, P);
 }
 
 int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const srk_bwd_mask* mask, float* dw,
@@ -447,7 +525,21 @@ int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const
   P.vec_y = (d.Cout % 4 == 0) && ((uintptr_t)dy % 16 == 0) && (!P.mask_y || (uintptr_t)P.mask_y % 16 == 0);
   P.dy_ps_r = d.dy_ps_r > 1 ? d.dy_ps_r : 0;
   P.dy_ps_C = d.dy_ps_r > 1 ? d.Cout / (d.dy_ps_r * d.dy_ps_r) : d.Cout;
-  dim3 grid(pl.G, pl.gy, pl.gz);
+  // wave-specialised variant: one 512-thread block per CU with two LDS buffer sets, when every block has >= 2 tiles
+  // to pipeline (SRK_WGRAD_SPEC=0: never)
+  static const int spec_env = getenv("SRK_WGRAD_SPEC") ? atoi(getenv("SRK_WGRAD_SPEC")) : 1;
+  int G = pl.G;
+  bool spec = false;
+  if (spec_env && 2 * pl.lds + 8 * 1024 <= 160 * 1024) {
+    int g1 = kNumCU / (pl.gy * pl.gz);
+    if (g1 < 1) g1 = 1;
+    if (pl.ntiles >= 2 * g1) {
+      spec = true;
+      G = g1;
+    }
+  }
+  P.G = G;
+  dim3 grid(G, pl.gy, pl.gz);
   {
     static int dbg = -1;
     if (dbg < 0) {
@@ -456,17 +548,17 @@ int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const
     }
     P.dbg = dbg;
     if (dbg & 32)
-      fprintf(stderr, "[srk] k_wgrad_bf cfg %d: tile %d x %d (%d K steps), %d tiles over %d x %d x %d blocks, lds %zu B\n",
-              pl.cfg, pl.TH, pl.TW, pl.nks, pl.ntiles, pl.G, pl.gy, pl.gz, pl.lds);
+      fprintf(stderr, "[srk] k_wgrad_bf cfg %d%s: tile %d x %d (%d K steps), %d tiles over %d x %d x %d blocks, lds %zu B\n",
+              pl.cfg, spec ? " (wave-specialised)" : "", pl.TH, pl.TW, pl.nks, pl.ntiles, G, pl.gy, pl.gz, spec ? 2 * pl.lds : pl.lds);
   }
   switch (pl.cfg) {
-    case 0: wb_launch<2, 2, 2>(P, grid, pl.lds, s); break;
-    case 1: wb_launch<4, 1, 2>(P, grid, pl.lds, s); break;
-    default: wb_launch<4, 1, 1>(P, grid, pl.lds, s); break;
+    case 0: wb_launch<2, 2, 2>(P, grid, pl.lds, spec, s); break;
+    case 1: wb_launch<4, 1, 2>(P, grid, pl.lds, spec, s); break;
+    default: wb_launch<4, 1, 1>(P, grid, pl.lds, spec, s); break;
   }
   int rc = check_launch("conv_wgrad_bf");
   if (rc) return rc;
-  return conv_wgrad_reduce_launch((const float*)ws, dw, pl.G, d.Cout, d.Cin, d.KH, d.KW, 0, beta, db ? bias_ws : nullptr,
+  return conv_wgrad_reduce_launch((const float*)ws, dw, G, d.Cout, d.Cin, d.KH, d.KW, 0, beta, db ? bias_ws : nullptr,
                                   db, d.Cout, d.dy_ps_r > 1 ? d.dy_ps_r : 0, s);
 }
 
