@@ -583,8 +583,7 @@ class _Loss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        dpred = ctx.dpred
-        ctx.dpred = None
+        dpred = ctx.dpred  # (kept on the ctx: a second backward over a retained graph must see it; freed with the graph)
         if dpred is None:
             return None, None, None, None
         lib = _lib.load()

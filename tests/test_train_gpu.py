@@ -240,3 +240,38 @@ def test_wgrad_side_stream_matches_single_stream(gpu):
             pkg.ops.WGRAD_SIDE_STREAM = False
     assert float(grads[0].abs().max()) > 0
     assert torch.equal(grads[0], grads[1])
+
+
+def test_fused_skip_gradient_matches_axpby_fan_in(gpu):
+    """ops.GradBox (the residual blocks' skip gradient added by conv1's data-gradient epilogue) against the unfused
+    fan-in (ops.fork + srk_axpby): same parameter gradients up to summation order, also when backward runs twice over
+    a retained graph (the box is refilled by every backward pass) and when the block input needs no gradient."""
+    pkg = _pkg()
+    x, t = B((4, 3, 12, 12), 81).to(gpu), B((4, 3, 48, 48), 82).to(gpu)
+    grads = []
+    for fused in (False, True):
+        pkg.ops.FUSE_SKIP_GRAD = fused
+        try:
+            net = pkg.EDSRNet(3, 64, 4)
+            fill.fill_module(net, 3, 0.5)
+            net.to(gpu).train()
+            flat = pkg.optim.FlatParams(net)
+            flat.zero_grad()
+            loss = pkg.ops.l1_loss(net(x), t)
+            loss.backward(retain_graph=True)
+            g1 = flat.grad.clone()
+            loss.backward()  # accumulates a second, identical contribution
+            grads.append((g1, flat.grad.clone()))
+        finally:
+            pkg.ops.FUSE_SKIP_GRAD = True
+    (a1, a2), (b1, b2) = grads
+    assert float(a1.abs().max()) > 0
+    assert rel_err(b1, a1) < 1e-5
+    assert rel_err(a2, 2 * a1) < 1e-5 and rel_err(b2, 2 * b1) < 1e-5
+    # a residual block fed by a tensor that needs no gradient: no box, no fan-in, weights still get gradients
+    blk = pkg.base_networks.ResnetBlock(64, norm=None)
+    fill.fill_module(blk, 5, 0.5)
+    blk.to(gpu).train()
+    xin = B((2, 64, 9, 9), 83).to(gpu)
+    blk(xin).sum().backward()
+    assert all(p.grad is not None and float(p.grad.abs().max()) > 0 for p in blk.parameters())
