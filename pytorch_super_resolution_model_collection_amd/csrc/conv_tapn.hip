@@ -1,6 +1,6 @@
 // Output convolutions with a handful of output channels (the 64 -> 3 reconstruction convs that end EDSR, VDSR,
-// SRResNet-style generators; reference base_networks.py ConvBlock with output_size = num_channels), stride 1,
-// KH*KW*OC <= 32.
+// SRResNet-style generators, the 9x9 / 5x5 output convs of SRGAN-G and SRCNN; reference base_networks.py ConvBlock with
+// output_size = num_channels), stride 1.
 //
 // An MFMA tile over (pixels x output channels) would be >= 80 % padding, and the plain-VALU kernel
 // (k_conv_direct) is latency-bound on interleaved LDS / scalar-cache reads (1.2 TB/s at 128 x 64 x 128 x 128).
@@ -8,6 +8,8 @@
 //
 //   z[p][t*OC + oc] = sum_c x[p][c] * w[t][c][oc]          one GEMM [halo pixels x IC] x [IC x (T*OC <= 32)]
 //   y[q][oc]        = sum_t z[q + offset(t)][t*OC + oc]     a 9-term shifted sum per output pixel
+// (kernels with more than 32/OC taps run the GEMM once per group of 32/OC taps -- 9 passes for 9x9 x 3 channels --
+//  over the SAME activation registers, each pass adding its taps into the output pixel's running sums)
 //
 //   * the A operand (16 pixels x 32 channels, lane = (pixel j, group kq)) is read STRAIGHT from global memory
 //     into fragment registers, every input pixel of the tile exactly once, all loads of a wave (<= 6 pixel
@@ -34,8 +36,8 @@ constexpr int TAPN_ZS = 36;    // z row stride in floats: 4*ZS = 16 (mod 64) spr
 constexpr int TAPN_MAXI = 6;   // pixel groups (16 pixels each) per wave: halo <= 4 * 6 * 16 = 384 pixels
 constexpr int TAPN_NP = 3;     // bf16 planes
 
-template <int KS, int OCT>  // KS = IC / 32, OCT = output channels
-__global__ __launch_bounds__(256, 3) void k_conv_tapn(MfmaConvParams P) {
+template <int KS, int OCT, bool MULTI>  // KS = IC / 32, OCT = output channels, MULTI = more than one tap group
+__global__ __launch_bounds__(256, MULTI ? 2 : 3) void k_conv_tapn(MfmaConvParams P) {
   extern __shared__ __attribute__((aligned(16))) float zbuf[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
@@ -53,12 +55,20 @@ __global__ __launch_bounds__(256, 3) void k_conv_tapn(MfmaConvParams P) {
   const int n = b / P.tiles_y;
   const int r0 = tyi * P.TH, c0 = txi * P.TW;
   const int T = P.KHv * P.KWv;
-  const int NN = T * OCT;
+  constexpr int TPG = 32 / OCT;             // taps per group: one pass of the [pixels x IC] x [IC x 32] GEMM
+  const int NG = MULTI ? (T + TPG - 1) / TPG : 1;  // passes (1 for 3x3; 3 for 5x5; 9 for 9x9 with 3 output channels)
   const int npix = P.HH * P.HW;
   const int MT = (npix + 15) >> 4;
+  const bool live = tid < P.TH * P.TW;
+  const int m = live ? tid : 0;
+  const int r = m / P.TW, c = m - r * P.TW;
+  float sum[OCT];
+#pragma unroll
+  for (int o = 0; o < OCT; ++o) sum[o] = 0.f;
 
   if (T > 0) {
-    // activation fragments of this wave's pixel groups: all global loads issued before anything else
+    // activation fragments of this wave's pixel groups: all global loads issued before anything else, kept in
+    // registers across the tap-group passes
     f32x4 raw[TAPN_MAXI][KS * 2];
     const float* __restrict__ inb = P.in + (size_t)n * P.IH * P.IW * P.IC + kq * 4;
     const int iyb = r0 + P.iy0, ixb = c0 + P.ix0;
@@ -75,80 +85,87 @@ __global__ __launch_bounds__(256, 3) void k_conv_tapn(MfmaConvParams P) {
         if (ok) raw[i][q] = *reinterpret_cast<const f32x4*>(src + q * 16);
       }
     }
-    // filter fragments: column nn = t*OC + oc of the [IC x 32] matrix, rows in the permuted channel order above
-    uint4 bf[KS][2][TAPN_NP];
+    for (int tg = 0; tg < NG; ++tg) {
+      const int t0 = tg * TPG;
+      const int tcount = (T - t0) < TPG ? (T - t0) : TPG;
+      const int NN = tcount * OCT;
+      // filter fragments of this tap group: column nn = (t - t0)*OC + oc of the [IC x 32] matrix, rows in the
+      // permuted channel order above
+      uint4 bf[KS][2][TAPN_NP];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int nn = nt * 16 + j;
-      const bool on = nn < NN;
-      const int t = on ? nn / OCT : 0, oc = nn - t * OCT;
-      const int u = t / P.KWv, v = t - u * P.KWv;
-      const int tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
-      const float* __restrict__ w = P.wp + ((size_t)tapw * P.IC + kq * 4) * OCT + oc;
+      for (int nt = 0; nt < 2; ++nt) {
+        const int nn = nt * 16 + j;
+        const bool on = nn < NN;
+        const int t = t0 + (on ? nn / OCT : 0), oc = on ? nn % OCT : 0;
+        const int u = t / P.KWv, v = t - u * P.KWv;
+        const int tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
+        const float* __restrict__ w = P.wp + ((size_t)tapw * P.IC + kq * 4) * OCT + oc;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        float f[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = on ? w[(s * 32 + (e >> 2) * 16 + (e & 3)) * OCT] : 0.f;
-        split8n<TAPN_NP>(f, bf[s][nt]);
-      }
-    }
-    const bool two = NN > 16;
-#pragma unroll
-    for (int i = 0; i < TAPN_MAXI; ++i) {
-      const int mt = wave + 4 * i;
-      if (mt < MT) {  // wave-uniform
-        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-        uint4 a[KS][TAPN_NP];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
+        for (int s2 = 0; s2 < KS; ++s2) {
           float f[8];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            f[e] = raw[i][2 * s][e];
-            f[4 + e] = raw[i][2 * s + 1][e];
-          }
-          split8n<TAPN_NP>(f, a[s]);
+          for (int e = 0; e < 8; ++e) f[e] = on ? w[(s2 * 32 + (e >> 2) * 16 + (e & 3)) * OCT] : 0.f;
+          split8n<TAPN_NP>(f, bf[s2][nt]);
         }
-        // smallest products first (as in k_conv_bfd)
-#define SRK_TAPN_PASS(pa, pb)                                      \
-  _Pragma("unroll") for (int s = 0; s < KS; ++s) {                 \
-    acc[0] = mfma16(a[s][pa], bf[s][0][pb], acc[0]);               \
-    if (two) acc[1] = mfma16(a[s][pa], bf[s][1][pb], acc[1]);      \
-  }
-        SRK_TAPN_PASS(2, 0)
-        SRK_TAPN_PASS(0, 2)
-        SRK_TAPN_PASS(1, 1)
-        SRK_TAPN_PASS(1, 0)
-        SRK_TAPN_PASS(0, 1)
-        SRK_TAPN_PASS(0, 0)
-#undef SRK_TAPN_PASS
-        // C/D layout: col = lane & 15 (nn), row = (lane >> 4) * 4 + reg (pixel of the group)
-        float* zr = zbuf + (size_t)(mt * 16 + kq * 4) * TAPN_ZS + j;
+      }
+      const bool two = NN > 16;
+      if (tg) __syncthreads();  // the previous group's z fully consumed
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          zr[e * TAPN_ZS] = acc[0][e];
-          if (two) zr[e * TAPN_ZS + 16] = acc[1][e];
+      for (int i = 0; i < TAPN_MAXI; ++i) {
+        const int mt = wave + 4 * i;
+        if (mt < MT) {  // wave-uniform
+          f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+          uint4 a[KS][TAPN_NP];
+#pragma unroll
+          for (int s2 = 0; s2 < KS; ++s2) {
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              f[e] = raw[i][2 * s2][e];
+              f[4 + e] = raw[i][2 * s2 + 1][e];
+            }
+            split8n<TAPN_NP>(f, a[s2]);
+          }
+          // smallest products first (as in k_conv_bfd)
+#define SRK_TAPN_PASS(pa, pb)                                        \
+  _Pragma("unroll") for (int s2 = 0; s2 < KS; ++s2) {                \
+    acc[0] = mfma16(a[s2][pa], bf[s2][0][pb], acc[0]);               \
+    if (two) acc[1] = mfma16(a[s2][pa], bf[s2][1][pb], acc[1]);      \
+  }
+          SRK_TAPN_PASS(2, 0)
+          SRK_TAPN_PASS(0, 2)
+          SRK_TAPN_PASS(1, 1)
+          SRK_TAPN_PASS(1, 0)
+          SRK_TAPN_PASS(0, 1)
+          SRK_TAPN_PASS(0, 0)
+#undef SRK_TAPN_PASS
+          // C/D layout: col = lane & 15 (nn), row = (lane >> 4) * 4 + reg (pixel of the group)
+          float* zr = zbuf + (size_t)(mt * 16 + kq * 4) * TAPN_ZS + j;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            zr[e * TAPN_ZS] = acc[0][e];
+            if (two) zr[e * TAPN_ZS + 16] = acc[1][e];
+          }
+        }
+      }
+      __syncthreads();
+      if (live) {  // this thread's output pixel: add the taps of the group
+        int u = t0 / P.KWv, v = t0 - u * P.KWv;
+        for (int q = 0; q < tcount; ++q) {
+          const float* zt = zbuf + (size_t)((r + u) * P.HW + c + v) * TAPN_ZS + q * OCT;
+#pragma unroll
+          for (int o = 0; o < OCT; ++o) sum[o] += zt[o];
+          if (++v == P.KWv) {
+            v = 0;
+            ++u;
+          }
         }
       }
     }
   }
-  __syncthreads();
-  if (tid >= P.TH * P.TW) return;
-  const int r = tid / P.TW, c = tid - r * P.TW;
+  if (!live) return;
   const int pr = r0 + r, pc = c0 + c;
   if (pr >= P.PH || pc >= P.PW) return;
-  float sum[OCT];
-#pragma unroll
-  for (int o = 0; o < OCT; ++o) sum[o] = 0.f;
-  const float* zp = zbuf + (size_t)(r * P.HW + c) * TAPN_ZS;
-  int t = 0;
-  for (int u = 0; u < P.KHv; ++u)
-    for (int v = 0; v < P.KWv; ++v, ++t) {
-      const float* zt = zp + (u * P.HW + v) * TAPN_ZS + t * OCT;
-#pragma unroll
-      for (int o = 0; o < OCT; ++o) sum[o] += zt[o];
-    }
   GatherConv g{};
   g.OH = P.OH; g.OW = P.OW; g.OC = P.OC;
   const int oy = P.oy0 + pr * P.os, ox = P.ox0 + pc * P.os;
@@ -159,7 +176,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_tapn(MfmaConvParams P) {
 bool conv_tapn_gather_supported(const GatherConv& g, const float* in, const float* mask_y) {
   static const int off = getenv("SRK_TAPN") ? !atoi(getenv("SRK_TAPN")) : 0;  // SRK_TAPN=0: use k_conv_direct
   if (off) return false;
-  if (g.OC < 1 || g.OC > 3 || g.KH * g.KW * g.OC > 32) return false;
+  if (g.OC < 1 || g.OC > 3 || g.KH * g.KW > 121) return false;  // larger kernels: several 32-column tap groups
   if (g.IC != 32 && g.IC != 64) return false;
   if (!g.trans && g.stride != 1) return false;
   if (mask_y || g.in_nchw || g.in_ps_r > 1) return false;
@@ -178,7 +195,10 @@ static int tapn_launch(MfmaConvParams P, hipStream_t s) {
   P.TH = best.TH; P.TW = best.TW; P.tiles_y = best.tiles_y; P.tiles_x = best.tiles_x; P.HH = best.HH; P.HW = best.HW;
   const size_t lds = (size_t)(((best.HH * best.HW + 15) & ~15)) * TAPN_ZS * sizeof(float);
   dim3 grid((unsigned)((size_t)P.tiles_x * P.tiles_y * P.N));
-  hipLaunchKernelGGL((k_conv_tapn<KS, OCT>), grid, dim3(256), lds, s, P);
+  if (P.KHv * P.KWv * OCT > 32)
+    hipLaunchKernelGGL((k_conv_tapn<KS, OCT, true>), grid, dim3(256), lds, s, P);
+  else
+    hipLaunchKernelGGL((k_conv_tapn<KS, OCT, false>), grid, dim3(256), lds, s, P);
   return check_launch("conv_tapn");
 }
 

@@ -80,6 +80,9 @@ def test_conv_infer_fused_epilogue(gpu, idx):
     (64, 1, 3, 1, 16, 16, 1),    # single output channel: one 16-column fragment
     (64, 3, 1, 0, 19, 23, 2),    # 1x1
     (32, 3, 2, 1, 9, 12, 1),     # even kernel
+    (64, 3, 9, 4, 30, 26, 2),    # SRGAN-G output conv: 9 tap groups of 27 columns over the same activation registers
+    (32, 3, 5, 0, 20, 24, 2),    # SRCNN output conv: 3 tap groups (10 + 10 + 5 taps)
+    (64, 2, 7, 3, 15, 17, 1),    # 16 taps per group, 49 taps
 ])
 @pytest.mark.parametrize("algo", ["auto", "bf16x6"])
 def test_conv_few_output_channels(gpu, cin, cout, k, p, H, W, N, algo):

@@ -15,7 +15,7 @@ SHAPES = {  # N, Cin, H, W, Cout, k, pad, act, ps
     "edsr128": (128, 64, 32, 32, 64, 3, 1, 1, 0),
     "edsr16": (16, 64, 32, 32, 64, 3, 1, 1, 0),
     "edsrup16": (16, 64, 64, 64, 256, 3, 1, 0, 2),
-    "srgan9": (16, 64, 96, 96, 3, 9, 4, 0, 0),
+    "srgan9": (16, 64, 128, 128, 3, 9, 4, 0, 0),
     "edsrtail128": (128, 64, 128, 128, 3, 3, 1, 0, 0),
     "edsrtail16": (16, 64, 128, 128, 3, 3, 1, 0, 0),
     "vdsrtail": (256, 64, 41, 41, 3, 3, 1, 0, 0),
