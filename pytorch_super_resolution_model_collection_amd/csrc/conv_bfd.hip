@@ -41,6 +41,7 @@ struct BfdParams {
   int NPIXp;         // halo pixels rounded up to 16
   int dbg;
   int allc;          // small problems: every channel chunk of the halo staged up front (one load latency, one barrier)
+  int cpr;           // chunks staged per barrier round: ICc (allc), 2 (K-split without allc) or 1
 };
 
 // halo chunk: channels [cb, cb+32) of every halo pixel -> NP planes.  thread -> (8-channel group
@@ -305,12 +306,12 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, 2) void k_conv_bfd(
       walk_next(head);
     }
     const int cstride = NP * 4 * B.NPIXp;  // uint4 per staged chunk
-    // Segments of taps between barriers: one chunk each, or (allc) a single segment over every chunk so that
-    // the rotation below runs across chunk boundaries.
-    const int nseg = B.allc ? 1 : B.ICc;
-    // (KS = 2 runs only with allc: group kgrp walks chunks kgrp, kgrp + 2, ...)
-    const int seg_len = B.allc ? ((B.ICc - kgrp + KS - 1) / KS) * T : T;
-    const int cadv = B.allc ? KS * cstride : 0;
+    // Rounds of `cpr` chunks between barriers: 1 chunk, 2 chunks (K-split: one per wave group), or all of them (allc,
+    // a single round so that the rotation below runs across chunk boundaries).  Group kgrp computes the chunks
+    // kgrp, kgrp + KS, ... of its round.
+    const int cpr = B.cpr;
+    const int nseg = (B.ICc + cpr - 1) / cpr;
+    const int cadv = KS * cstride;
     int ct = 0, ctv = 0, cbase = kgrp * cstride, coff = cbase;  // compute walk: halo offset of the current tap
     auto cwalk_next = [&]() {
       ++coff;
@@ -326,24 +327,20 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, 2) void k_conv_bfd(
       }
     };
     for (int seg = 0; seg < nseg; ++seg) {
-      if (!B.allc) {
-        if (seg) __syncthreads();  // previous chunk's halo fully consumed
-        if (!(B.dbg & 1)) {
-          if (P.mask_y)
-            bfd_stage_halo_t<true, NTHR, NP>(B, hal, n, r0, c0, seg * 32);
-          else
-            bfd_stage_halo_t<false, NTHR, NP>(B, hal, n, r0, c0, seg * 32);
-        }
-        __syncthreads();
-      } else {
-        for (int c2 = 0; c2 < B.ICc && !(B.dbg & 1); ++c2) {
-          if (P.mask_y)
-            bfd_stage_halo_t<true, NTHR, NP>(B, hal + c2 * cstride, n, r0, c0, c2 * 32);
-          else
-            bfd_stage_halo_t<false, NTHR, NP>(B, hal + c2 * cstride, n, r0, c0, c2 * 32);
-        }
-        __syncthreads();
+      const int cfirst = seg * cpr;
+      const int cend = cfirst + cpr < B.ICc ? cfirst + cpr : B.ICc;
+      if (seg) __syncthreads();  // previous round's halo fully consumed
+      for (int c2 = cfirst; c2 < cend && !(B.dbg & 1); ++c2) {
+        if (P.mask_y)
+          bfd_stage_halo_t<true, NTHR, NP>(B, hal + (c2 - cfirst) * cstride, n, r0, c0, c2 * 32);
+        else
+          bfd_stage_halo_t<false, NTHR, NP>(B, hal + (c2 - cfirst) * cstride, n, r0, c0, c2 * 32);
       }
+      __syncthreads();
+      const int mine = cfirst + kgrp < cend ? (cend - cfirst - kgrp + KS - 1) / KS : 0;  // chunks of this group in the round
+      const int seg_len = mine * T;
+      cbase = kgrp * cstride;
+      coff = cbase;
       int it = 0;
       if (NTW * NP <= 6) {
         // rotate through the PF+1 register sets instead of shifting them: after PF+1 taps the roles are back
@@ -650,8 +647,11 @@ static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
   B.NPIXp = (best.HH * best.HW + 15) & ~15;  // multiple of 16: the kq lane groups of a ds_read_b128 interleave conflict-free
   size_t lds = (size_t)NP * 4 * B.NPIXp * 16;
   B.allc = 0;
+  B.cpr = 1;
+  const size_t lds_chunk = lds;
   if (NPW == 1 && B.ICc > 1 && lds * B.ICc <= 64 * 1024) {  // small-problem blocks: stage all chunks at once
     B.allc = 1;
+    B.cpr = B.ICc;
     lds *= B.ICc;
   }
   const size_t epi_bytes = (size_t)NPW * 32 * BFD_EPI_STRIDE * sizeof(float);
@@ -663,7 +663,12 @@ static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
     const size_t red_bytes = (size_t)NOW * 4 * NTW * 64 * 16;
     // only while the grid leaves the CUs with one block each: with two resident blocks the other block already hides the
     // latency and the split just adds the reduction (B = 32 EDSR shard: 3.28 -> 3.55 ms with it, B = 16: 2.63 -> 2.37 ms)
-    if (ksplit && B.allc && B.ICc >= 2 && ((long)grid.x * grid.y <= kNumCU + kNumCU / 4 || ksplit > 1)) {
+    if (ksplit && B.ICc >= 2 && ((long)grid.x * grid.y <= kNumCU + kNumCU / 4 || ksplit > 1)) {
+      if (!B.allc) {  // many chunks (deep layers of the SRGAN discriminator): two chunks per barrier round, one per group
+        B.cpr = 2;
+        lds = 2 * lds_chunk;
+        if (lds < epi_bytes) lds = epi_bytes;
+      }
       if (lds < red_bytes) lds = red_bytes;
       static int cur2 = 0;
       const void* fn2 = reinterpret_cast<const void*>(&k_conv_bfd<NTW, NPW, NOW, NP, PF, 2>);
