@@ -167,3 +167,32 @@ class GraphedStep(object):
             self._exchange()
             self.graph_b.replay()
         return self.loss
+
+
+class GraphedFn(object):
+    """hipGraph capture of an arbitrary single-GPU step function of tensors (e.g. the two-model, two-optimizer SRGAN
+    step, `srgan_step` without data parallelism): static input buffers, `warmup` eager calls on a side stream, one
+    graph; call with new batches (copied into the static buffers), returns the captured output tensors.  Everything
+    the step does must be stream work (no host reads of device values), which holds for all steps of this package."""
+
+    def __init__(self, fn, example_inputs, warmup=3):
+        self.fn = fn
+        self.static = [torch.empty_like(t).copy_(t) for t in example_inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fn(*self.static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = fn(*self.static)
+
+    def __call__(self, *batch):
+        for s, b in zip(self.static, batch):
+            if b is not s:
+                s.copy_(b, non_blocking=True)
+        self.graph.replay()
+        return self.out
+

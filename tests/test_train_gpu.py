@@ -275,3 +275,42 @@ def test_fused_skip_gradient_matches_axpby_fan_in(gpu):
     xin = B((2, 64, 9, 9), 83).to(gpu)
     blk(xin).sum().backward()
     assert all(p.grad is not None and float(p.grad.abs().max()) > 0 for p in blk.parameters())
+
+
+def test_graphed_srgan_step_equals_eager(gpu):
+    """trainers.GraphedFn around the SRGAN adversarial step (two models, two optimizers, BatchNorm running statistics,
+    weight re-packing after each optimizer step all inside one hipGraph): same loss trajectory as the eager step."""
+    pkg = _pkg()
+    batches = [(B((4, 3, 8, 8), 90 + i).to(gpu), B((4, 3, 32, 32), 95 + i).to(gpu)) for i in range(3)]
+
+    def make():
+        G, D = pkg.SRGANGenerator(3, 16, 2), pkg.SRGANDiscriminator(3, 8, 32)
+        fill.fill_module(G, 5, 0.7)
+        fill.fill_module(D, 6, 1.0)
+        G.to(gpu).train()
+        D.to(gpu).train()
+        g_opt = pkg.optim.make_optimizer("srgan_g", pkg.optim.FlatParams(G), 1e-4)
+        d_opt = pkg.optim.make_optimizer("srgan_d", pkg.optim.FlatParams(D), 1e-2)
+        return G, D, g_opt, d_opt, pkg.trainers.srgan_step(G, D, g_opt, d_opt)
+
+    Ga, Da, ga, da, step_a = make()
+    ref = [[float(v) for v in step_a(*b)] for b in batches]
+    Gb, Db, gb, db, step_b = make()
+    def state(o):
+        return [o.flat.data] + [getattr(o, k) for k in ("buf", "exp_avg", "exp_avg_sq", "step_dev")
+                                if getattr(o, k, None) is not None]
+
+    snap = [[t.clone() for t in state(o)] for o in (gb, db)]
+    bn_state = [(m, m.running_mean.clone(), m.running_var.clone()) for net in (Gb, Db) for m in net.modules()
+                if isinstance(m, torch.nn.BatchNorm2d) and m.running_mean is not None]
+    graphed = pkg.trainers.GraphedFn(step_b, batches[0], warmup=2)
+    # the warm-up / capture calls moved the state: restore it before the measured replays
+    for o, saved in zip((gb, db), snap):
+        for t, t0 in zip(state(o), saved):
+            t.copy_(t0)
+    for m, rm, rv in bn_state:
+        m.running_mean.copy_(rm)
+        m.running_var.copy_(rv)
+    got = [[float(v) for v in graphed(*b)] for b in batches]
+    assert rel_err(np.array(got), np.array(ref)) < 1e-4
+
