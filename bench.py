@@ -170,10 +170,16 @@ def train_extra(pkg, dev, rank, world):
         inp = torch.rand(16, 3, 32, 32, generator=g).to(dev)
         tgt = torch.rand(16, 3, 64, 64, generator=g).to(dev)
 
-        def one():
-            return step(pkg.utils.img_interp(inp, 2), pkg.utils.shave(tgt, 8).contiguous())
+        def one(a, b):
+            return step(pkg.utils.img_interp(a, 2), pkg.utils.shave(b, 8).contiguous())
 
-        sec = time_steps(one, 20, 5, 1, dev)
+        try:  # the whole iteration (bicubic pre-step + crop + train step) as one hipGraph; eager if capture is refused
+            graphed = pkg.trainers.GraphedFn(one, (inp, tgt))
+            out["c1_mode"] = "hipGraph"
+        except Exception:  # noqa: BLE001
+            graphed = one
+            out["c1_mode"] = "eager"
+        sec = time_steps(lambda: graphed(inp, tgt), 20, 5, 1, dev)
         out["c1_srcnn_x2_train_patches_per_s_batch_16"] = round(16 * 20 / sec, 1)
         out["c1_srcnn_ms_per_step"] = round(1e3 * sec / 20, 3)
         # the reference's CPU path for the same step on this box's host cores (oracle = stock torch + Pillow)
