@@ -663,7 +663,8 @@ static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
     const size_t red_bytes = (size_t)NOW * 4 * NTW * 64 * 16;
     // only while the grid leaves the CUs with one block each: with two resident blocks the other block already hides the
     // latency and the split just adds the reduction (B = 32 EDSR shard: 3.28 -> 3.55 ms with it, B = 16: 2.63 -> 2.37 ms)
-    if (ksplit && B.ICc >= 2 && ((long)grid.x * grid.y <= kNumCU + kNumCU / 4 || ksplit > 1)) {
+    if (ksplit && B.ICc >= 2 && (B.allc || 2 * lds_chunk <= (size_t)150 * 1024) &&
+        ((long)grid.x * grid.y <= kNumCU + kNumCU / 4 || ksplit > 1)) {
       if (!B.allc) {  // many chunks (deep layers of the SRGAN discriminator): two chunks per barrier round, one per group
         B.cpr = 2;
         lds = 2 * lds_chunk;

@@ -168,6 +168,32 @@ def test_conv_wave_specialized(gpu, monkeypatch, cin, cout, k, p, H, W, N, act, 
     assert rel_err(y, ref.float()) < 1e-4
 
 
+@pytest.mark.parametrize("cin,cout,k,s,p,op,H,W", [
+    (64, 8, 9, 4, 3, 1, 8, 8),     # data gradient = 9x9 stride-4 gather over 64 channels: halo chunk > half the LDS
+    (56, 32, 8, 4, 2, 0, 6, 9),
+    (64, 64, 5, 2, 2, 1, 12, 7),
+])
+def test_deconv_large_halo_small_problem(gpu, cin, cout, k, s, p, op, H, W):
+    """Small-problem blocks whose halo chunk is large (big strided kernels): the K-split must not ask for two chunk
+    buffers that exceed the LDS (found by tools/fuzz_deconv.py); forward and all gradients vs torch fp64."""
+    pkg = _pkg()
+    ops = pkg.ops
+    x = fill.randn((2, cin, H, W), 31)
+    w = fill.randn((cin, cout, k, k), 32, (2.0 / (cin * k * k)) ** 0.5)
+    b = fill.randn((cout,), 33, 0.1)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    ref = torch.nn.functional.conv_transpose2d(xr, wr, br, s, p, op)
+    g = fill.randn(tuple(ref.shape), 34)
+    ref.backward(g.double())
+    xg, wg, bg = (t.to(gpu).requires_grad_(True) for t in (x, w, b))
+    y = ops.conv2d(xg, wg, bg, None, ops.ConvCfg(s, p, True, op, 0, 0.0, 0, ALGOS["auto"]))
+    y.backward(g.to(gpu))
+    assert rel_err(y, ref.detach().float()) < 1e-4
+    assert rel_err(xg.grad, xr.grad.float()) < 1e-4
+    assert rel_err(wg.grad, wr.grad.float()) < 1e-4
+    assert rel_err(bg.grad, br.grad.float()) < 1e-4
+
+
 @pytest.mark.parametrize("r,C", [(2, 64), (4, 3), (3, 2)])
 def test_conv_fused_pixel_shuffle(gpu, r, C):
     """conv + PixelShuffle store (PSBlock, base_networks.py:179-181), forward and backward."""
