@@ -373,7 +373,8 @@ def conv2d_infer(x, weight, bias=None, residual=None, cfg=None, prelu_w=None, pa
     cout, cin, _, _ = _weight_dims(weight, cfg.transposed)
     # the Cin <= 4 bf16x3 first-layer kernel reads the caller's NCHW tensor in place (no layout copy)
     x_nchw = (x.dim() == 4 and cin <= 4 and cout >= 8 and not cfg.transposed and not _is_nhwc_dense(x)
-              and _is_nchw_dense(x) and _algo_for(cfg, "infer") == ALGO_AUTO)
+              and _is_nchw_dense(x) and _algo_for(cfg, "infer") == ALGO_AUTO
+              and not os.environ.get("SRK_FORCE_ALGO"))  # (the debugging override may pick a kernel without the in-place NCHW read)
     if not x_nchw:
         x = to_nhwc(x)
     if residual is not None:

@@ -8,6 +8,8 @@ sys.path.insert(0, ROOT)
 import pytorch_super_resolution_model_collection_amd as pkg
 from oracle import fill, ref_modules as R
 dev = torch.device("cuda:0")
+if os.environ.get("FUZZ_PRECISION"):
+    pkg.ops.set_precision(os.environ["FUZZ_PRECISION"])  # mixed | bf16x3 | fp32
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad, worst = 0, 0.0
