@@ -18,7 +18,8 @@
 //     the 4 lanes of a pixel read 64 CONTIGUOUS bytes per load instruction;
 //   * the B operand (the whole filter, 64 x 27 values) is built once per wave from the fp32 filter and stays
 //     in registers as bf16 planes;
-//   * always the exact 3-way split (bf16x6: rms error 3.5e-7, below an fp32-accumulating FMA chain) -- the
+//   * the exact 3-way split (bf16x6: rms error 3.5e-7, below an fp32-accumulating FMA chain) in every class for <= 32
+//     columns; kernels with several tap groups run bf16x3 in the bf16x3 class (inference, gradients) -- the
 //     kernel is bound by the activation read, the MFMAs are free;
 //   * z goes through LDS ([pixel][36] floats: conflict-free fragment writes), then one thread per output pixel
 //     sums its taps and runs the scalar epilogue (bias / activation / residual / pixel shuffle).
@@ -34,9 +35,11 @@ namespace srk {
 
 constexpr int TAPN_ZS = 36;    // z row stride in floats: 4*ZS = 16 (mod 64) spreads the 4 row groups of a fragment over the banks
 constexpr int TAPN_MAXI = 6;   // pixel groups (16 pixels each) per wave: halo <= 4 * 6 * 16 = 384 pixels
-constexpr int TAPN_NP = 3;     // bf16 planes
 
-template <int KS, int OCT, bool MULTI>  // KS = IC / 32, OCT = output channels, MULTI = more than one tap group
+// KS = IC / 32, OCT = output channels, MULTI = more than one tap group, NP = bf16 planes (3: bf16x6; 2: bf16x3, only for
+// MULTI kernels in the bf16x3 class -- there the GEMM runs once per tap group over a halo 2-3x the tile and the MFMAs
+// are no longer free)
+template <int KS, int OCT, bool MULTI, int NP>
 __global__ __launch_bounds__(256, MULTI ? 2 : 3) void k_conv_tapn(MfmaConvParams P) {
   extern __shared__ __attribute__((aligned(16))) float zbuf[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void k_conv_tapn(MfmaConvParams
       const int NN = tcount * OCT;
       // filter fragments of this tap group: column nn = (t - t0)*OC + oc of the [IC x 32] matrix, rows in the
       // permuted channel order above
-      uint4 bf[KS][2][TAPN_NP];
+      uint4 bf[KS][2][NP];
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         const int nn = nt * 16 + j;
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void k_conv_tapn(MfmaConvParams
           float f[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) f[e] = on ? w[(s2 * 32 + (e >> 2) * 16 + (e & 3)) * OCT] : 0.f;
-          split8n<TAPN_NP>(f, bf[s2][nt]);
+          split8n<NP>(f, bf[s2][nt]);
         }
       }
       const bool two = NN > 16;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void k_conv_tapn(MfmaConvParams
         const int mt = wave + 4 * i;
         if (mt < MT) {  // wave-uniform
           f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-          uint4 a[KS][TAPN_NP];
+          uint4 a[KS][NP];
 #pragma unroll
           for (int s2 = 0; s2 < KS; ++s2) {
             float f[8];
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void k_conv_tapn(MfmaConvParams
               f[e] = raw[i][2 * s2][e];
               f[4 + e] = raw[i][2 * s2 + 1][e];
             }
-            split8n<TAPN_NP>(f, a[s2]);
+            split8n<NP>(f, a[s2]);
           }
           // smallest products first (as in k_conv_bfd)
 #define SRK_TAPN_PASS(pa, pb)                                        \
@@ -132,9 +135,11 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void k_conv_tapn(MfmaConvParams
     acc[0] = mfma16(a[s2][pa], bf[s2][0][pb], acc[0]);               \
     if (two) acc[1] = mfma16(a[s2][pa], bf[s2][1][pb], acc[1]);      \
   }
-          SRK_TAPN_PASS(2, 0)
-          SRK_TAPN_PASS(0, 2)
-          SRK_TAPN_PASS(1, 1)
+          if (NP == 3) {
+            SRK_TAPN_PASS(NP - 1, 0)
+            SRK_TAPN_PASS(0, NP - 1)
+            SRK_TAPN_PASS(1, 1)
+          }
           SRK_TAPN_PASS(1, 0)
           SRK_TAPN_PASS(0, 1)
           SRK_TAPN_PASS(0, 0)
@@ -185,7 +190,7 @@ bool conv_tapn_gather_supported(const GatherConv& g, const float* in, const floa
 }
 
 template <int KS, int OCT>
-static int tapn_launch(MfmaConvParams P, hipStream_t s) {
+static int tapn_launch(MfmaConvParams P, bool x6, hipStream_t s) {
   TilePick best{};
   const int kh = P.KHv > 0 ? P.KHv : 1, kw = P.KWv > 0 ? P.KWv : 1;
   if (!pick_tile(256, P.PH, P.PW, 1, kh, kw, TAPN_ZS, 4 * TAPN_MAXI * 16 * TAPN_ZS, best)) {
@@ -195,14 +200,19 @@ static int tapn_launch(MfmaConvParams P, hipStream_t s) {
   P.TH = best.TH; P.TW = best.TW; P.tiles_y = best.tiles_y; P.tiles_x = best.tiles_x; P.HH = best.HH; P.HW = best.HW;
   const size_t lds = (size_t)(((best.HH * best.HW + 15) & ~15)) * TAPN_ZS * sizeof(float);
   dim3 grid((unsigned)((size_t)P.tiles_x * P.tiles_y * P.N));
-  if (P.KHv * P.KWv * OCT > 32)
-    hipLaunchKernelGGL((k_conv_tapn<KS, OCT, true>), grid, dim3(256), lds, s, P);
-  else
-    hipLaunchKernelGGL((k_conv_tapn<KS, OCT, false>), grid, dim3(256), lds, s, P);
+  if (P.KHv * P.KWv * OCT > 32) {
+    if (x6)
+      hipLaunchKernelGGL((k_conv_tapn<KS, OCT, true, 3>), grid, dim3(256), lds, s, P);
+    else
+      hipLaunchKernelGGL((k_conv_tapn<KS, OCT, true, 2>), grid, dim3(256), lds, s, P);
+  } else {
+    hipLaunchKernelGGL((k_conv_tapn<KS, OCT, false, 3>), grid, dim3(256), lds, s, P);
+  }
   return check_launch("conv_tapn");
 }
 
-int conv_tapn_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s) {
+int conv_tapn_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, bool x6,
+                     hipStream_t s) {
   return for_each_phase(g, in, wp, out, ep, nullptr, 0.f, [&](const MfmaConvParams& P) {
     if (P.is != 1) {
       set_error("conv_tapn: strided gather");
@@ -210,12 +220,12 @@ int conv_tapn_gather(const GatherConv& g, const float* in, const float* wp, floa
     }
     const int key = (g.IC / 32) * 10 + g.OC;
     switch (key) {
-      case 11: return tapn_launch<1, 1>(P, s);
-      case 12: return tapn_launch<1, 2>(P, s);
-      case 13: return tapn_launch<1, 3>(P, s);
-      case 21: return tapn_launch<2, 1>(P, s);
-      case 22: return tapn_launch<2, 2>(P, s);
-      default: return tapn_launch<2, 3>(P, s);
+      case 11: return tapn_launch<1, 1>(P, x6, s);
+      case 12: return tapn_launch<1, 2>(P, x6, s);
+      case 13: return tapn_launch<1, 3>(P, x6, s);
+      case 21: return tapn_launch<2, 1>(P, x6, s);
+      case 22: return tapn_launch<2, 2>(P, x6, s);
+      default: return tapn_launch<2, 3>(P, x6, s);
     }
   });
 }
