@@ -12,9 +12,13 @@
  *   - every pointer is a DEVICE pointer to fp32 data owned by the caller; the library never
  *     allocates, frees or retains a pointer past the call;
  *   - activations are dense NHWC ("channels_last"): x[n][h][w][c];
- *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); no call
- *     synchronises the device; calls are re-entrant (no global mutable state besides the
- *     thread-local last-error string);
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*) of the CURRENT
+ *     device (hipSetDevice is the caller's job); no call synchronises the device;
+ *   - calls may be made concurrently from several host threads and for several devices of one
+ *     process.  The library's only mutable state is: the thread-local last-error string; one
+ *     atomic "dynamic-LDS limit raised" flag per (kernel, device) — hipFuncSetAttribute is a
+ *     per-device property, set on a kernel's first large-LDS launch on that device; and the
+ *     SRK_* debugging environment switches, each read once (C++11 thread-safe statics);
  *   - return value: SRK_OK (0) or a negative srk_status; no exception crosses the ABI.
  */
 #ifndef SRK_H_
@@ -260,6 +264,26 @@ typedef enum srk_interp { SRK_INTERP_NEAREST = 0, SRK_INTERP_BILINEAR = 2, SRK_I
 size_t srk_img_interp_workspace_bytes(int N, int C, int H, int W, int OH, int OW, int filter);
 int srk_img_interp(const float* x_nchw, float* y_nchw, int N, int C, int H, int W, int OH, int OW, int filter,
                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- steps either side of the nets ------------------------------------------------
+ * utils.PSNR (utils.py:208-216): mse = mean((clamp(pred,0,1) - gt)^2) over all elements, *psnr_out = mse == 0 ? 100 :
+ * 10*log10(1/mse), on the device (the reference copies both images to the host per test image).  pred / gt are
+ * addressed through element strides (n,c,h,w); NULL = NHWC-dense.  mse_out may be NULL. */
+size_t srk_psnr_workspace_bytes(void);
+int srk_psnr(const float* pred, const int64_t* pred_strides, const float* gt, const int64_t* gt_strides, int N, int C,
+             int H, int W, float* psnr_out, float* mse_out, void* workspace, void* stream);
+/* utils.norm / utils.denorm (utils.py:219-239; torchvision Normalize = sub_(mean).div_(std)):
+ * y[e] = (x[e] - sub[c]) / div[c], c = (e / inner) % C (inner = H*W for NCHW storage, 1 for NHWC), optionally clamped
+ * to [0,1] (denorm's non-VGG branch).  sub_host / div_host are HOST arrays of C <= 8 floats. Bit-equal to torch. */
+int srk_channel_affine(const float* x, float* y, size_t n, int C, size_t inner, const float* sub_host,
+                       const float* div_host, int clamp01, void* stream);
+/* torch.nn.Upsample(scale_factor=r, mode='nearest') of Upsample2xBlock('rnc') (base_networks.py:204-210), NHWC:
+ * y[n,oy,ox,c] = x[n,oy/r,ox/r,c]; backward: dx = sum of each r x r block of dy. */
+int srk_upsample_nearest_forward(const float* x, float* y, int N, int H, int W, int C, int r, void* stream);
+int srk_upsample_nearest_backward(const float* dy, float* dx, int N, int H, int W, int C, int r, void* stream);
+/* nn.MaxPool2d(2, 2) of the VGG19 feature extractor (srgan.py:84-90: vgg19.features[:9] holds one), NHWC, floor mode:
+ * y [N, H/2, W/2, C].  Forward only — the reference evaluates the VGG loss on detached tensors (srgan.py:302-305). */
+int srk_maxpool2x2_forward(const float* x, float* y, int N, int H, int W, int C, void* stream);
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,7 @@ LapSRN / SRGAN on the shared base_networks blocks), drop-in for the nn.Module su
 togheppi/pytorch-super-resolution-model-collection.  See DESIGN.md."""
 from . import _lib, ops, layers, base_networks, utils, models, optim, dp, trainers  # noqa: F401
 from .models import (SRCNNNet, ESPCNNet, FSRCNNNet, VDSRNet, EDSRNet, LapSRNNet, SRGANGenerator,  # noqa: F401
-                     SRGANDiscriminator)
+                     SRGANDiscriminator, FeatureExtractor)
 
 __all__ = ["ops", "layers", "base_networks", "utils", "models", "SRCNNNet", "ESPCNNet", "FSRCNNNet", "VDSRNet",
-           "EDSRNet", "LapSRNNet", "SRGANGenerator", "SRGANDiscriminator"]
+           "EDSRNet", "LapSRNNet", "SRGANGenerator", "SRGANDiscriminator", "FeatureExtractor"]

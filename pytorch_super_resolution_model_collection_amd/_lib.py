@@ -90,6 +90,14 @@ _PROTOTYPES = {
     "srk_scale_dev": (c_int, [c_f, c_f, c_f, c_size, c_vp]),
     "srk_linear_forward": (c_int, [c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int, c_float, c_vp]),
     "srk_linear_backward": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_float, c_vp]),
+    "srk_psnr_workspace_bytes": (c_size, []),
+    "srk_psnr": (c_int, [c_f, ctypes.POINTER(ctypes.c_int64), c_f, ctypes.POINTER(ctypes.c_int64), c_int, c_int, c_int,
+                         c_int, c_f, c_f, c_vp, c_vp]),
+    "srk_channel_affine": (c_int, [c_f, c_f, c_size, c_int, c_size, ctypes.POINTER(c_float), ctypes.POINTER(c_float),
+                                   c_int, c_vp]),
+    "srk_upsample_nearest_forward": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "srk_upsample_nearest_backward": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "srk_maxpool2x2_forward": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_vp]),
     "srk_img_interp_workspace_bytes": (ctypes.c_size_t, [c_int] * 7),
     "srk_img_interp": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, ctypes.c_size_t, c_vp]),
 }

@@ -16,7 +16,7 @@ import torch
 
 from . import ops
 from .layers import (ACT_LRELU, ACT_NONE, ACT_PRELU, ACT_RELU, BatchNorm2d, Conv2d, ConvTranspose2d, Linear,
-                     PixelShuffle, grad_mode, make_activation, make_norm2d)
+                     PixelShuffle, grad_mode, make_activation, make_norm1d, make_norm2d)
 
 _FUSABLE_IN_TRAINING = (ACT_NONE, ACT_RELU, ACT_LRELU)
 
@@ -26,9 +26,7 @@ class _Block(torch.nn.Module):
 
     def _setup(self, channels, activation, norm, norm1d=False):
         self.norm = norm
-        if norm1d and norm is not None:
-            raise NotImplementedError("DenseBlock with normalisation is never used by the reference nets")
-        bn = make_norm2d(norm, channels)
+        bn = make_norm1d(norm, channels) if norm1d else make_norm2d(norm, channels)
         if bn is not None:
             self.bn = bn
         self.activation = activation
@@ -73,11 +71,9 @@ class DenseBlock(_Block):
 
     def forward(self, x):
         kind, slope, pw = self._act_args()
-        fuse = kind != ACT_PRELU
+        fuse = kind != ACT_PRELU and self.norm is None   # act(bn(fc(x))): the activation follows the norm
         out = self.fc.run(x, kind if fuse else ACT_NONE, slope)
-        if not fuse:
-            out = self.act(out)
-        return out
+        return self._post(out, fuse)
 
 
 class ConvBlock(_Block):
@@ -133,7 +129,7 @@ class ResnetBlock(_Block):
         kind, slope, pw = self._act_args()
         training = grad_mode(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, pw)
         if self.norm is None:
-            fuse = self._fuse_act(x, self.conv1.weight)
+            fuse = self._fuse_act(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)
             # training: the skip gradient (= the block output gradient) is added by conv1's data-gradient kernel
             # (ops.GradBox); it needs x itself to require grad, else there is no fan-in to sum
             box = ops.GradBox() if (training and x.requires_grad and ops.FUSE_SKIP_GRAD) else None
@@ -176,6 +172,17 @@ class PSBlock(_Block):
         return self._post(out, fuse)
 
 
+class UpsampleNearest(torch.nn.Upsample):
+    """torch.nn.Upsample(scale_factor=r, mode='nearest') surface (base_networks.py:206) on srk_upsample_nearest_*."""
+
+    def __init__(self, scale_factor):
+        super(UpsampleNearest, self).__init__(scale_factor=scale_factor, mode='nearest')
+        self._r = int(scale_factor)
+
+    def forward(self, x):
+        return ops.upsample_nearest(x, self._r)
+
+
 class Upsample2xBlock(torch.nn.Module):
     """base_networks.py:188-214"""
 
@@ -189,8 +196,12 @@ class Upsample2xBlock(torch.nn.Module):
             self.upsample = PSBlock(input_size, output_size, scale_factor=scale_factor, bias=bias,
                                     activation=activation, norm=norm)
         elif upsample == 'rnc':
-            raise NotImplementedError("upsample='rnc' (nearest resize + conv) is unused by every reference net "
-                                      "(only a commented-out line, fsrcnn.py:34-37)")
+            # 3. Resize and Convolution (base_networks.py:204-210): nn.Sequential(Upsample(x2, nearest), ConvBlock 3x3)
+            # — same container and indices, so the state_dict keys are `upsample.1.conv.weight` etc. like the reference
+            self.upsample = torch.nn.Sequential(
+                UpsampleNearest(scale_factor),
+                ConvBlock(input_size, output_size, kernel_size=3, stride=1, padding=1, bias=bias,
+                          activation=activation, norm=norm))
         else:
             raise ValueError("unknown upsample mode %r" % (upsample,))
 

@@ -2,6 +2,7 @@
 // (base_networks.py:7,46,117,161; srgan.py:49-81).  NHWC: a tensor is [rows][C] with
 // rows = N*H*W, so per-channel statistics are column sums with lanes = channels (coalesced rows).
 #include "srk_common.h"
+#include <stdlib.h>
 
 namespace srk {
 
@@ -10,7 +11,7 @@ constexpr int kBnRowSplits = 512;
 // partial[split][2][C] (double): sum(a), sum(a*b') where the second operand depends on MODE:
 //   MODE 0: a = x,  second = x*x                      (forward statistics)
 //   MODE 1: a = dy, second = dy * (x-mean)*rstd       (backward statistics)
-template <int MODE>
+template <int MODE, bool DBL>
 __global__ __launch_bounds__(256) void k_bn_colsum(const float* __restrict__ a, const float* __restrict__ x,
                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                                    double* __restrict__ partial, size_t rows, int C,
@@ -38,14 +39,27 @@ __global__ __launch_bounds__(256) void k_bn_colsum(const float* __restrict__ a, 
         va[u] = r < r1 ? a[r * C + c] : 0.f;
         if (MODE == 1) vx[u] = r < r1 ? x[r * C + c] : mu;
       }
-      float f0 = 0.f, f1 = 0.f;
+      if (MODE == 1 && DBL) {
+        // backward statistics feed a difference that cancels to ~1e-4 of its mass when a BatchNorm follows another
+        // (SRGAN-D at 128x128): products and sums in double, only the inputs are fp32
+        double d0 = 0.0, d1 = 0.0;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        f0 += va[u];
-        f1 += MODE == 0 ? va[u] * va[u] : va[u] * ((vx[u] - mu) * rs);
+        for (int u = 0; u < U; ++u) {
+          d0 += (double)va[u];
+          d1 += (double)va[u] * (((double)vx[u] - (double)mu) * (double)rs);
+        }
+        s0 += d0;
+        s1 += d1;
+      } else {
+        float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          f0 += va[u];
+          f1 += MODE == 0 ? va[u] * va[u] : va[u] * ((vx[u] - mu) * rs);
+        }
+        s0 += f0;
+        s1 += f1;
       }
-      s0 += f0;
-      s1 += f1;
     }
   }
   sm[0][w][lane] = s0;
@@ -120,6 +134,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, f
   }
 }
 
+template <bool DBL>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ gamma,
@@ -128,11 +143,20 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int c = (int)(i % C);
     const float rs = rstd[c];
-    const float xhat = (x[i] - mean[c]) * rs;
-    const float m1 = (float)(dstats[c] / count);
-    const float m2 = (float)(dstats[C + c] / count);
     const float g = gamma ? gamma[c] : 1.f;
-    dx[i] = g * rs * (dy[i] - m1 - xhat * m2);
+    if (DBL) {
+      // dy - mean(dy) - xhat*mean(dy*xhat) cancels heavily when this BN's output feeds another BN: evaluate the
+      // difference in double from the fp32 inputs and the double sums, round once
+      const double xhat = ((double)x[i] - (double)mean[c]) * (double)rs;
+      const double m1 = dstats[c] / count;
+      const double m2 = dstats[C + c] / count;
+      dx[i] = (float)((double)g * (double)rs * ((double)dy[i] - m1 - xhat * m2));
+    } else {
+      const float xhat = (x[i] - mean[c]) * rs;
+      const float m1 = (float)(dstats[c] / count);
+      const float m2 = (float)(dstats[C + c] / count);
+      dx[i] = g * rs * (dy[i] - m1 - xhat * m2);
+    }
   }
 }
 
@@ -144,6 +168,12 @@ __global__ __launch_bounds__(256) void k_bn_param_grads(const double* __restrict
   if (dgamma) dgamma[c] += (float)dstats[C + c];
 }
 
+// SRK_BN_F32=1 (debugging / A-B only): the backward arithmetic of round 1 (fp32 per-element terms)
+static bool bn_fp32_backward() {
+  static const bool v = [] { const char* e = getenv("SRK_BN_F32"); return e && e[0] == '1'; }();
+  return v;
+}
+
 static int bn_colsum(int mode, const float* a, const float* x, const float* mean, const float* rstd, double* out,
                      size_t rows, int C, void* ws, hipStream_t s) {
   int splits = (int)((rows + 127) / 128);
@@ -152,9 +182,11 @@ static int bn_colsum(int mode, const float* a, const float* x, const float* mean
   const size_t rps = (rows + splits - 1) / splits;
   dim3 grid(cdiv(C, 64), splits);
   if (mode == 0)
-    hipLaunchKernelGGL(k_bn_colsum<0>, grid, dim3(256), 0, s, a, x, mean, rstd, (double*)ws, rows, C, rps);
+    hipLaunchKernelGGL((k_bn_colsum<0, false>), grid, dim3(256), 0, s, a, x, mean, rstd, (double*)ws, rows, C, rps);
+  else if (bn_fp32_backward())
+    hipLaunchKernelGGL((k_bn_colsum<1, false>), grid, dim3(256), 0, s, a, x, mean, rstd, (double*)ws, rows, C, rps);
   else
-    hipLaunchKernelGGL(k_bn_colsum<1>, grid, dim3(256), 0, s, a, x, mean, rstd, (double*)ws, rows, C, rps);
+    hipLaunchKernelGGL((k_bn_colsum<1, true>), grid, dim3(256), 0, s, a, x, mean, rstd, (double*)ws, rows, C, rps);
   hipLaunchKernelGGL(k_bn_reduce, dim3(cdiv(2 * C, 64)), dim3(256), 0, s, (const double*)ws, out, splits, 2 * C);
   return check_launch("bn_colsum");
 }
@@ -337,8 +369,12 @@ extern "C" int srk_bn_backward_apply(const float* dy, const float* x, const floa
   const size_t total = rows * (size_t)C;
   size_t nb = (total + 256 * 4 - 1) / (256 * 4);
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma,
-                     dstats, count, dx, total, C);
+  if (bn_fp32_backward())
+    hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd,
+                       gamma, dstats, count, dx, total, C);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd,
+                       gamma, dstats, count, dx, total, C);
   return check_launch("bn_backward_apply");
 }
 

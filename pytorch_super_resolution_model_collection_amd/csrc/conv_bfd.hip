@@ -607,12 +607,9 @@ static int bfr_launch(BfdParams B, hipStream_t s) {
   if (hal_bytes < epi_bytes) hal_bytes = epi_bytes;
   const size_t lds = wbytes + hal_bytes;
   if ((long)lds > lds_cap) return -1;
-  static int cur = 0;
+  static LdsLimit lim;
   const void* fn = reinterpret_cast<const void*>(&k_conv_bfr<NTW, NOW>);
-  if ((int)lds > cur) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    cur = (int)lds;
-  }
+  lim.ensure(fn, lds);
   const long ntiles = (long)P.tiles_x * P.tiles_y * P.N;
   int gx = kNumCU / B.OCb;
   if (gx < 1) gx = 1;
@@ -671,12 +668,8 @@ static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
         if (lds < epi_bytes) lds = epi_bytes;
       }
       if (lds < red_bytes) lds = red_bytes;
-      static int cur2 = 0;
-      const void* fn2 = reinterpret_cast<const void*>(&k_conv_bfd<NTW, NPW, NOW, NP, PF, 2>);
-      if ((int)lds > cur2) {
-        (void)hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        cur2 = (int)lds;
-      }
+      static LdsLimit lim2;
+      lim2.ensure(reinterpret_cast<const void*>(&k_conv_bfd<NTW, NPW, NOW, NP, PF, 2>), lds);
       if (B.dbg & 32)
         fprintf(stderr, "[srk] k_conv_bfd<%d,%d,%d,%d,%d> K-split 2: lds %zu B, grid %u x %u, tile %dx%d halo %dx%d\n", NTW, NPW,
                 NOW, NP, PF, lds, grid.x, grid.y, P.TH, P.TW, P.HH, P.HW);
@@ -684,12 +677,9 @@ static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
       return check_launch("conv_bfd");
     }
   }
-  static int cur = 0;
+  static LdsLimit lim;
   const void* fn = reinterpret_cast<const void*>(&k_conv_bfd<NTW, NPW, NOW, NP, PF, 1>);
-  if ((int)lds > cur) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    cur = (int)lds;
-  }
+  lim.ensure(fn, lds);
   if (B.dbg & 32) {
     int nb = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * NPW * NOW, lds);

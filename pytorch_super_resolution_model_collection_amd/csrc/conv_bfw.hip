@@ -372,12 +372,8 @@ bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, co
 
 template <int NTW, int TT, int MTW>
 static int bfw_launch_t(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
-  static int cur = 0;
-  const void* fn = reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, MTW>);
-  if ((int)lds > cur) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    cur = (int)lds;
-  }
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, MTW>), lds);
   hipLaunchKernelGGL((k_conv_bfw<NTW, TT, MTW>), dim3(grid), dim3(64 * (16 / MTW + 4)), lds, s, B);
   return check_launch("conv_bfw");
 }

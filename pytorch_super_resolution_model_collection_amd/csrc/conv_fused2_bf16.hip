@@ -324,12 +324,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_fused2(Fused2Params F) {
 
 template <int NT>
 static void f2_launch(const Fused2Params& F, dim3 grid, size_t lds, hipStream_t s) {
-  static int cur = 0;
-  if ((int)lds > cur) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fused2<NT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    cur = (int)lds;
-  }
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&k_conv_fused2<NT>), lds);
   hipLaunchKernelGGL(k_conv_fused2<NT>, grid, dim3(256), lds, s, F);
 }
 

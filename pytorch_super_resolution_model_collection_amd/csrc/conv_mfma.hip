@@ -431,17 +431,12 @@ bool conv_mfma_gather_supported(const GatherConv& g, const Epi& ep) {
   return true;
 }
 
-// Raise the dynamic-LDS limit of a kernel once per size (host call, not a stream op).
-static void ensure_lds(const void* fn, int& cur, size_t lds) {
-  if ((int)lds > cur) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    cur = (int)lds;
-  }
-}
+// Raise the dynamic-LDS limit of a kernel once per device (host call, not a stream op): srk_common.h LdsLimit.
+static void ensure_lds(const void* fn, LdsLimit& lim, size_t lds) { lim.ensure(fn, lds); }
 
 template <int NT>
 static void launch_variant(bool tapgroup, const MfmaConvParams& P, dim3 grid, size_t lds, hipStream_t s) {
-  static int cur_tg = 0, cur_main = 0;
+  static LdsLimit cur_tg, cur_main;
   if (tapgroup) {
     ensure_lds(reinterpret_cast<const void*>(&k_conv_mfma_tg<NT>), cur_tg, lds);
     hipLaunchKernelGGL(k_conv_mfma_tg<NT>, grid, dim3(256), lds, s, P);
@@ -457,7 +452,7 @@ static void apply_pick(MfmaConvParams& P, const TilePick& t) {
 
 template <int OCT>
 static void launch_direct(const MfmaConvParams& P, dim3 grid, size_t lds, hipStream_t s) {
-  static int cur = 0;
+  static LdsLimit cur;
   ensure_lds(reinterpret_cast<const void*>(&k_conv_direct<OCT>), cur, lds);
   hipLaunchKernelGGL(k_conv_direct<OCT>, grid, dim3(256), lds, s, P);
 }

@@ -605,12 +605,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3_rows(Bf3Params B) {
 // ---------------------------------------------------------------------------------------------
 template <int NT>
 static void bf3_launch_vec(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s) {
-  static int cur = 0;
-  if ((int)lds > cur) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bf3<NT, 4, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    cur = (int)lds;
-  }
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&k_conv_bf3<NT, 4, true>), lds);
   if (B.dbg & 32) {
     int nb = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_conv_bf3<NT, 4, true>), 256,
@@ -623,12 +619,8 @@ static void bf3_launch_vec(const Bf3Params& B, dim3 grid, size_t lds, hipStream_
 
 template <int NT, int NW>
 static void bf3_launch(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s) {
-  static int cur = 0;
-  if ((int)lds > cur) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bf3<NT, NW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    cur = (int)lds;
-  }
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&k_conv_bf3<NT, NW>), lds);
   if (B.dbg & 32) {
     int nb = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_conv_bf3<NT, NW>), 64 * NW,
@@ -651,12 +643,8 @@ bool conv_bf3_gather_supported(const GatherConv& g, const Epi& ep) {
 
 template <int NT, bool VEC_ONLY>
 static void bf3_launch_rows_v(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s) {
-  static int cur = 0;
-  if ((int)lds > cur) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_bf3_rows<NT, VEC_ONLY>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    cur = (int)lds;
-  }
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&k_conv_bf3_rows<NT, VEC_ONLY>), lds);
   hipLaunchKernelGGL((k_conv_bf3_rows<NT, VEC_ONLY>), grid, dim3(256), lds, s, B);
 }
 template <int NT>

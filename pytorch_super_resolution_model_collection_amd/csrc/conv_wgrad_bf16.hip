@@ -479,21 +479,13 @@ size_t conv_wgrad_bf_ws(const srk_conv_desc& d) {
 template <int CIT, int COW, int NTW>
 static void wb_launch(const WgBfParams& P, dim3 grid, size_t lds, bool spec, hipStream_t s) {
   if (spec) {
-    static int cur2 = 0;
-    if ((int)(2 * lds) > cur2) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
-      cur2 = (int)(2 * lds);
-    }
+    static LdsLimit lim2;
+    lim2.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, true>), 2 * lds);
     hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, true>), grid, dim3(768), 2 * lds, s, P);
     return;
   }
-  static int cur = 0;
-  if ((int)lds > cur) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    cur = (int)lds;
-  }
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, false>), lds);
   hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, false>), grid, dim3(256), lds, s, P);
 }
 

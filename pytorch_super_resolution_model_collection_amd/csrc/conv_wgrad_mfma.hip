@@ -511,23 +511,19 @@ size_t conv_wgrad_mfma_ws(const srk_conv_desc& d) {
 }
 
 template <typename K>
-static void wg_set_lds(K kern, int& cur, size_t lds) {
-  if ((int)lds > cur) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    cur = (int)lds;
-  }
+static void wg_set_lds(K kern, LdsLimit& cur, size_t lds) {
+  cur.ensure(reinterpret_cast<const void*>(kern), lds);
 }
 
 template <int NTC, bool TRANS>
 static void launch_w1(const WgradParams& P, dim3 grid, size_t lds, hipStream_t s) {
-  static int cur = 0;
+  static LdsLimit cur;
   wg_set_lds(&k_wgrad_mfma<NTC, TRANS>, cur, lds);
   hipLaunchKernelGGL((k_wgrad_mfma<NTC, TRANS>), grid, dim3(256), lds, s, P);
 }
 template <int MT>
 static void launch_w2(const WgradParams& P, dim3 grid, size_t lds, hipStream_t s) {
-  static int cur = 0;
+  static LdsLimit cur;
   wg_set_lds(&k_wgrad_mfma_smallcin<MT>, cur, lds);
   hipLaunchKernelGGL((k_wgrad_mfma_smallcin<MT>), grid, dim3(256), lds, s, P);
 }

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include "../../include/srk.h"
 
 namespace srk {
@@ -29,6 +30,32 @@ inline int check_launch(const char* what) {
 
 constexpr int kWave = 64;
 constexpr int kNumCU = 256;
+constexpr int kMaxDynLds = 160 * 1024;  // gfx950: 160 KB of LDS per CU, all of it usable by one workgroup
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel.  Every launcher that needs more than
+// the 64 KB default owns one `static LdsLimit` and calls ensure() before launching: the limit is raised to the hardware
+// maximum once per (kernel, device).  Thread-safe (relaxed atomics; a race only repeats an idempotent host call), so the
+// main and the autograd threads — or several devices driven from one process — can launch concurrently.
+struct LdsLimit {
+  static constexpr int kMaxDevices = 64;
+  std::atomic<unsigned char> done[kMaxDevices];
+  LdsLimit() {
+    for (int i = 0; i < kMaxDevices; ++i) done[i].store(0, std::memory_order_relaxed);
+  }
+  void ensure(const void* fn, size_t lds) {
+    if (lds <= 48 * 1024) return;  // under the default limit: nothing to raise
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < kMaxDevices && done[dev].load(std::memory_order_relaxed)) return;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds) != hipSuccess) {
+      // (a kernel that also has static LDS cannot take the full 160 KB as dynamic: ask for what this launch needs)
+      (void)hipGetLastError();
+      (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      return;
+    }
+    if (dev >= 0 && dev < kMaxDevices) done[dev].store(1, std::memory_order_relaxed);
+  }
+};
 
 inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 

@@ -70,10 +70,11 @@ class DataParallel(object):
         if self.world > 1:
             dist.broadcast(self.flat.data, src=src, group=self.group)
             # the parameters changed behind the optimizer's back: invalidate packed-filter caches / the PackPlan
-            from .layers import bump_weight_epoch
-            bump_weight_epoch()
-            if hasattr(self.flat, "epoch"):
-                self.flat.epoch += 1
+            if hasattr(self.flat, "mark_changed"):
+                self.flat.mark_changed()
+            else:
+                from .layers import bump_weight_epoch
+                bump_weight_epoch()
 
     def buckets(self):
         n = self.flat.grad.numel()

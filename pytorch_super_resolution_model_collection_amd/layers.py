@@ -127,6 +127,36 @@ class BatchNorm2d(torch.nn.BatchNorm2d):
                               self.eps, self.sync_group if training else None)
 
 
+class BatchNorm1d(torch.nn.BatchNorm1d):
+    """torch.nn.BatchNorm1d surface on [B, F] inputs (DenseBlock's default norm, base_networks.py:10-11): the same
+    two-phase statistics kernels as BatchNorm2d with rows = B, channels = F."""
+
+    sync_group = None
+
+    def forward(self, x):
+        if x.dim() != 2:
+            raise NotImplementedError("BatchNorm1d is implemented for [B, F] inputs (DenseBlock); got %s" % (tuple(x.shape),))
+        training = self.training or self.running_mean is None
+        if training and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        momentum = 0.1 if self.momentum is None else self.momentum
+        return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, training, momentum,
+                              self.eps, self.sync_group if training else None)
+
+
+class InstanceNorm2d(torch.nn.InstanceNorm2d):
+    """torch.nn.InstanceNorm2d(C) with its defaults — no affine parameters, no running statistics, so no state_dict
+    entries (base_networks.py:48,83,119,163) — on per-sample statistics kernels."""
+
+    def __init__(self, num_features):
+        super(InstanceNorm2d, self).__init__(num_features)
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != self.num_features:
+            raise RuntimeError("InstanceNorm2d(%d): bad input shape %s" % (self.num_features, tuple(x.shape)))
+        return ops.instance_norm(x, self.eps)
+
+
 class Linear(torch.nn.Linear):
     """torch.nn.Linear surface (base_networks.py:7)."""
 
@@ -193,5 +223,18 @@ def make_norm2d(norm, channels):
     if norm == "batch":
         return BatchNorm2d(channels)
     if norm == "instance":
-        raise NotImplementedError("norm='instance' is never used by the reference nets and is not implemented")
+        return InstanceNorm2d(channels)
+    return None
+
+
+def make_norm1d(norm, features):
+    """DenseBlock's norm (base_networks.py:9-13)."""
+    if norm is None:
+        return None
+    if norm == "batch":
+        return BatchNorm1d(features)
+    if norm == "instance":
+        # nn.InstanceNorm1d on a [B, F] tensor is ill-defined (modern torch reads it as one unbatched (C, L) sample)
+        raise NotImplementedError("DenseBlock(norm='instance'): InstanceNorm1d over a [B, F] activation is ill-defined "
+                                  "and unused by every reference net")
     return None

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import ops, utils
+from ._lib import ACT_RELU
 from .base_networks import ConvBlock, DeconvBlock, DenseBlock, PSBlock, ResnetBlock, Upsample2xBlock
 from .layers import Conv2d, ConvTranspose2d, PReLU, grad_mode
 
@@ -257,3 +258,75 @@ class SRGANDiscriminator(nn.Module):
     def weight_init(self, mean=0.0, std=0.02):
         for m in self.modules():
             utils.weights_init_normal(m, mean=mean, std=std)
+
+
+class _MaxPool2x2(nn.MaxPool2d):
+    """nn.MaxPool2d(kernel_size=2, stride=2) surface (vgg19.features[4]) on srk_maxpool2x2_forward."""
+
+    def __init__(self):
+        super(_MaxPool2x2, self).__init__(kernel_size=2, stride=2)
+
+    def forward(self, x):
+        return ops.max_pool2x2(x)
+
+
+class FeatureExtractor(nn.Module):
+    """srgan.py:84-90 — `nn.Sequential(*list(vgg19.features.children())[:feature_layer + 1])`: for the reference's
+    feature_layer = 8 that is conv3-64, ReLU, conv64-64, ReLU, MaxPool 2x2, conv64-128, ReLU, conv128-128, ReLU, kept
+    under the same indices so a torchvision `vgg19` checkpoint's `features.{0,2,5,7}.{weight,bias}` load directly
+    (`load_vgg19`).  The reference downloads pretrained weights (srgan.py:144); without network access the weights
+    are whatever the caller loads (kaiming-normal until then, like torchvision's own init).  The module is evaluated
+    without gradients only (srgan.py:302-305): conv + ReLU run as one fused kernel each."""
+
+    # torchvision.models.vgg19 `features` layout up to index 36: numbers = conv3x3 output channels, 'M' = MaxPool2d(2,2)
+    VGG19_CFG = (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M')
+
+    def __init__(self, netVGG=None, feature_layer=8):
+        super(FeatureExtractor, self).__init__()
+        from .layers import Conv2d, ReLU
+        mods, cin = [], 3
+        for v in self.VGG19_CFG:
+            if v == 'M':
+                mods.append(_MaxPool2x2())
+            else:
+                mods += [Conv2d(cin, v, 3, 1, 1), ReLU(True)]
+                cin = v
+        self.features = nn.Sequential(*mods[:feature_layer + 1])
+        for m in self.features:
+            if isinstance(m, nn.Conv2d):   # torchvision's VGG initialisation
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+                m.bias.data.zero_()
+        for p in self.parameters():
+            p.requires_grad_(False)
+        if netVGG is not None:
+            self.load_vgg19(netVGG.state_dict() if hasattr(netVGG, "state_dict") else netVGG)
+
+    def load_vgg19(self, state_dict):
+        """Copy `features.N.weight/bias` of a torchvision vgg19 state_dict (or a path to its .pth file) for the
+        layers this extractor keeps; classifier / deeper feature entries are ignored."""
+        if isinstance(state_dict, str):
+            state_dict = torch.load(state_dict, map_location="cpu")
+        own = self.state_dict()
+        picked = {k: v for k, v in state_dict.items() if k in own}
+        missing = [k for k in own if k not in picked]
+        if missing:
+            raise KeyError("vgg19 state_dict lacks %s" % missing)
+        self.load_state_dict(picked)
+        from .layers import bump_weight_epoch
+        bump_weight_epoch()
+        return self
+
+    def forward(self, x):
+        with torch.no_grad():
+            out = x.detach()
+            mods = list(self.features)
+            i = 0
+            while i < len(mods):
+                m = mods[i]
+                if isinstance(m, nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+                    out = m.run(out, ACT_RELU)   # conv + bias + ReLU in one kernel
+                    i += 2
+                else:
+                    out = m(out)
+                    i += 1
+            return out

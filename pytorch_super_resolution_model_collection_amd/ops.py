@@ -622,9 +622,9 @@ class _BatchNorm(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, sync_group):
         lib = _lib.load()
         require_cuda(x, gamma, beta)
-        x = _dense(x)
-        n, c, h, w = x.shape
-        rows = n * h * w
+        x = _dense(x)   # [N,C,H,W] stored NHWC, or [B,F] (BatchNorm1d of DenseBlock, base_networks.py:13): rows x C
+        c = x.shape[1]
+        rows = x.numel() // c
         mean = torch.empty(c, dtype=torch.float32, device=x.device)
         rstd = torch.empty(c, dtype=torch.float32, device=x.device)
         count = float(rows)
@@ -654,8 +654,8 @@ class _BatchNorm(torch.autograd.Function):
         lib = _lib.load()
         x, gamma, mean, rstd = ctx.saved_tensors
         dy = _dense(dy)
-        n, c, h, w = x.shape
-        rows = n * h * w
+        c = x.shape[1]
+        rows = x.numel() // c
         dstats = torch.empty(2 * c, dtype=torch.float64, device=x.device)
         ws = torch.empty(int(lib.srk_bn_workspace_bytes(c)), dtype=torch.uint8, device=x.device)
         check(lib.srk_bn_backward_stats(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(dstats), rows, c, ptr(ws),
@@ -682,9 +682,166 @@ class _BatchNorm(torch.autograd.Function):
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, sync_group=None):
-    """nn.BatchNorm2d (base_networks.py:46,117,161)."""
+    """nn.BatchNorm2d (base_networks.py:46,117,161) on [N,C,H,W]; nn.BatchNorm1d (base_networks.py:13) on [B,F]."""
     return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, bool(training), float(momentum), float(eps),
                             sync_group)
+
+
+class _InstanceNorm(torch.autograd.Function):
+    """nn.InstanceNorm2d defaults (affine=False, no running statistics; base_networks.py:48,83,119,163): every
+    (sample, channel) plane is normalised with its own biased statistics.  A sample of an NHWC tensor is a dense
+    [H*W, C] matrix, so this is the BatchNorm kernels applied per sample (unused by every reference net: N small
+    launches rather than a dedicated kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        lib = _lib.load()
+        require_cuda(x)
+        x = _dense(x)
+        n, c, h, w = x.shape
+        rows = h * w
+        mean = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        stats = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+        ws = torch.empty(int(lib.srk_bn_workspace_bytes(c)), dtype=torch.uint8, device=x.device)
+        y = torch.empty_like(x)
+        xs, ys = x.permute(0, 2, 3, 1), y.permute(0, 2, 3, 1)   # [n][h][w][c] views of the NHWC storage
+        for i in range(n):
+            check(lib.srk_bn_stats(ptr(xs[i]), ptr(stats), rows, c, ptr(ws), stream_ptr()), "srk_bn_stats")
+            check(lib.srk_bn_finalize(ptr(stats), float(rows), ptr(mean[i]), ptr(rstd[i]), None, None, 0.0, eps, c,
+                                      stream_ptr()), "srk_bn_finalize")
+            check(lib.srk_bn_apply(ptr(xs[i]), ptr(ys[i]), ptr(mean[i]), ptr(rstd[i]), None, None, rows, c, ACT_NONE, 0.0,
+                                   stream_ptr()), "srk_bn_apply")
+        ctx.save_for_backward(x, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, mean, rstd = ctx.saved_tensors
+        dy = _dense(dy)
+        n, c, h, w = x.shape
+        rows = h * w
+        dstats = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+        ws = torch.empty(int(lib.srk_bn_workspace_bytes(c)), dtype=torch.uint8, device=x.device)
+        dx = torch.empty_like(dy)
+        xs, dys, dxs = x.permute(0, 2, 3, 1), dy.permute(0, 2, 3, 1), dx.permute(0, 2, 3, 1)
+        for i in range(n):
+            check(lib.srk_bn_backward_stats(ptr(dys[i]), ptr(xs[i]), ptr(mean[i]), ptr(rstd[i]), ptr(dstats), rows, c,
+                                            ptr(ws), stream_ptr()), "srk_bn_backward_stats")
+            check(lib.srk_bn_backward_apply(ptr(dys[i]), ptr(xs[i]), ptr(mean[i]), ptr(rstd[i]), None, ptr(dstats),
+                                            float(rows), ptr(dxs[i]), rows, c, stream_ptr()), "srk_bn_backward_apply")
+        return dx, None
+
+
+def instance_norm(x, eps=1e-5):
+    """nn.InstanceNorm2d(C) with its defaults (base_networks.py:48)."""
+    return _InstanceNorm.apply(x, float(eps))
+
+
+class _UpsampleNearest(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, r):
+        lib = _lib.load()
+        require_cuda(x)
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        y = _empty_cl(n, c, h * r, w * r, x)
+        check(lib.srk_upsample_nearest_forward(ptr(x), ptr(y), n, h, w, c, r, stream_ptr()), "srk_upsample_nearest_forward")
+        ctx.r = r
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        r = ctx.r
+        dy = _dense(dy)
+        n, c, hr, wr = dy.shape
+        dx = _empty_cl(n, c, hr // r, wr // r, dy)
+        check(lib.srk_upsample_nearest_backward(ptr(dy), ptr(dx), n, hr // r, wr // r, c, r, stream_ptr()),
+              "srk_upsample_nearest_backward")
+        return dx, None
+
+
+def upsample_nearest(x, r):
+    """torch.nn.Upsample(scale_factor=r, mode='nearest') (base_networks.py:206)."""
+    return _UpsampleNearest.apply(x, int(r))
+
+
+def max_pool2x2(x):
+    """nn.MaxPool2d(2, 2) of vgg19.features[4] (srgan.py:84-90).  No-grad only: the reference feeds the VGG loss
+    detached tensors (srgan.py:302-305)."""
+    if grad_enabled_for(x):
+        raise RuntimeError("max_pool2x2 has no backward (the reference's VGG loss carries no gradient, srgan.py:302-305); "
+                           "call it under torch.no_grad() or on detached tensors")
+    lib = _lib.load()
+    require_cuda(x)
+    x = to_nhwc(x)
+    n, c, h, w = x.shape
+    if h < 2 or w < 2:
+        raise RuntimeError("max_pool2x2: input %s too small" % (tuple(x.shape),))
+    y = _empty_cl(n, c, h // 2, w // 2, x)
+    check(lib.srk_maxpool2x2_forward(ptr(x), ptr(y), n, h, w, c, stream_ptr()), "srk_maxpool2x2_forward")
+    return y
+
+
+def grad_enabled_for(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _strides4(t):
+    """Element strides (n, c, h, w) of a [N,C,H,W] tensor in any dense-or-view layout, as a ctypes array."""
+    return (ctypes.c_int64 * 4)(*[int(v) for v in t.stride()])
+
+
+def psnr(pred, gt):
+    """utils.PSNR (utils.py:208-216) on the device: returns (psnr, mse) as 0-dim device tensors, no host sync.
+    pred / gt: [N,C,H,W] or [C,H,W] CUDA tensors of any strides (channels_last net outputs, NCHW targets, crops)."""
+    lib = _lib.load()
+    require_cuda(pred, gt)
+    if pred.shape != gt.shape:
+        raise RuntimeError("psnr: pred %s vs gt %s" % (tuple(pred.shape), tuple(gt.shape)))
+    p = pred.detach()
+    g = gt.detach()
+    if p.dim() == 3:
+        p, g = p.unsqueeze(0), g.unsqueeze(0)
+    if p.dim() != 4:
+        raise RuntimeError("psnr expects [N,C,H,W] or [C,H,W] tensors, got shape %s" % (tuple(pred.shape),))
+    n, c, h, w = p.shape
+    out = torch.empty(2, dtype=torch.float32, device=p.device)
+    ws = torch.empty(int(lib.srk_psnr_workspace_bytes()), dtype=torch.uint8, device=p.device)
+    check(lib.srk_psnr(ptr(p), _strides4(p), ptr(g), _strides4(g), n, c, h, w, ptr(out[0:1]), ptr(out[1:2]), ptr(ws),
+                       stream_ptr()), "srk_psnr")
+    return out[0], out[1]
+
+
+def channel_affine(x, sub, div, clamp01=False):
+    """y = (x - sub[c]) / div[c] per channel (utils.norm / utils.denorm, utils.py:219-239), same storage layout as x
+    ([C,H,W] / [B,C,H,W] NCHW-contiguous or channels_last); bit-equal to torchvision's Normalize."""
+    lib = _lib.load()
+    require_cuda(x)
+    if x.dim() not in (3, 4):
+        raise RuntimeError("channel_affine expects [C,H,W] or [B,C,H,W], got shape %s" % (tuple(x.shape),))
+    c = x.shape[-3]
+    if len(sub) < c or len(div) < c:
+        raise RuntimeError("channel_affine: %d channels but only %d constants" % (c, min(len(sub), len(div))))
+    x4 = x if x.dim() == 4 else x.unsqueeze(0)
+    if _is_nchw_dense(x4):
+        xs = x4 if x4.is_contiguous() else x4.contiguous()
+        inner = x.shape[-1] * x.shape[-2]
+    elif _is_nhwc_dense(x4):
+        xs, inner = x4, 1
+    else:
+        xs = x4.contiguous()
+        inner = x.shape[-1] * x.shape[-2]
+    y = torch.empty_like(xs)
+    if y.stride() != xs.stride():
+        raise RuntimeError("channel_affine: internal layout mismatch")
+    fa = (ctypes.c_float * c)(*[float(v) for v in sub[:c]])
+    fb = (ctypes.c_float * c)(*[float(v) for v in div[:c]])
+    check(lib.srk_channel_affine(ptr(xs), ptr(y), xs.numel(), c, inner, fa, fb, int(bool(clamp01)), stream_ptr()),
+          "srk_channel_affine")
+    return y if x.dim() == 4 else y[0]
 
 
 class _Linear(torch.autograd.Function):

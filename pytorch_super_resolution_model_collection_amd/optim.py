@@ -63,6 +63,12 @@ class FlatParams(object):
         ops.join_side_streams()  # no weight gradient of the previous step may still be accumulating
         self.grad.zero_()  # one memset node
 
+    def mark_changed(self):
+        """Call after the flat parameters changed by anything other than optimizer.step() — a hipGraph replay of a
+        captured step, a direct write to `.data`, a broadcast: invalidates the PackPlan and every cached packed filter."""
+        bump_weight_epoch()
+        self.epoch += 1
+
     def named_grads(self):
         return {n: p._srk_grad for n, p in zip(self.names, self.params)}
 
@@ -205,8 +211,7 @@ class SGD(_FlatOptimizer):
         check(lib.srk_sgd_step(ptr(f.data), ptr(f.grad), ptr(self.buf), f.numel, 0.0, self.momentum,
                                self.weight_decay, int(self.nesterov), 0, ptr(self.lr_dev), ptr(self.scale_dev),
                                stream_ptr()), "srk_sgd_step")
-        bump_weight_epoch()
-        f.epoch += 1
+        f.mark_changed()
 
 
 class Adam(_FlatOptimizer):
@@ -227,8 +232,7 @@ class Adam(_FlatOptimizer):
         check(lib.srk_adam_step(ptr(f.data), ptr(f.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), f.numel, 0.0,
                                 self.betas[0], self.betas[1], self.eps, self.weight_decay, ptr(self.step_dev),
                                 ptr(self.lr_dev), ptr(self.scale_dev), stream_ptr()), "srk_adam_step")
-        bump_weight_epoch()
-        f.epoch += 1
+        f.mark_changed()
 
 
 def make_optimizer(kind, flat, lr):

@@ -36,6 +36,24 @@ def synthetic_loader(kind, args, steps, device, seed=1234):
             yield torch.rand(b, c, lr, lr, generator=g).to(device), torch.rand(b, c, hr, hr, generator=g).to(device)
 
 
+# Epoch-wise learning-rate decay of each reference trainer: kind -> (every N epochs, divide by).  Applied at the top of
+# epoch e when (e + 1) % N == 0, to every param group of every optimizer of the trainer.
+#   vdsr.py:127-129  /10 every 20     edsr.py:131-133  /2 every 40     lapsrn.py:173-175  /10 every 100
+#   srgan.py:239-244 /10 every 20 (G and D)            srcnn.py / espcn.py / fsrcnn.py: no decay
+LR_DECAY = {"vdsr": (20, 10.0), "edsr": (40, 2.0), "lapsrn": (100, 10.0), "srgan": (20, 10.0)}
+
+
+def apply_lr_decay(kind, epoch, *optimizers):
+    """The reference's `if (epoch+1) % N == 0: param_group['lr'] /= F` (see LR_DECAY).  Returns True if it decayed."""
+    rule = LR_DECAY.get(kind)
+    if rule is None or (epoch + 1) % rule[0] != 0:
+        return False
+    for opt in optimizers:
+        for g in opt.param_groups:
+            g['lr'] = g['lr'] / rule[1]
+    return True
+
+
 class _Trainer(object):
     kind = None
 
@@ -59,7 +77,7 @@ class _Trainer(object):
         raise NotImplementedError
 
     def lr_decay(self, epoch, opt):
-        pass
+        apply_lr_decay(self.kind, epoch, opt)
 
     def prepare(self, inp, target):
         """(input, target) of the data loader -> the tensors the train step consumes, on the device:
@@ -127,8 +145,8 @@ class _Trainer(object):
             if self.kind == "srcnn":     # srcnn.py:193-199: border pixels excluded
                 tgt = utils.shave(tgt, 8)
             if out.shape == tgt.shape:
-                psnrs.append(utils.PSNR(out, tgt))
-        return psnrs
+                psnrs.append(utils.PSNR(out, tgt))   # 0-dim device tensors: nothing syncs inside the loop
+        return [float(v) for v in torch.stack(psnrs).cpu()] if psnrs else []
 
     def test_single(self, img):
         """Super-resolve one [C,H,W] (or [1,C,H,W]) tensor (the reference reads an image file with PIL)."""
@@ -192,10 +210,6 @@ class VDSR(_Trainer):
     def build_model(self):
         return models.VDSRNet(self.num_channels, 64, 18)   # vdsr.py:80
 
-    def lr_decay(self, epoch, opt):   # vdsr.py:127-129: /10 every 20 epochs
-        if (epoch + 1) % 20 == 0:
-            for g in opt.param_groups:
-                g['lr'] = g['lr'] / 10.0
 
 
 class EDSR(_Trainer):
@@ -204,10 +218,6 @@ class EDSR(_Trainer):
     def build_model(self):
         return models.EDSRNet(self.num_channels, 64, 16)   # edsr.py:87
 
-    def lr_decay(self, epoch, opt):   # edsr.py:131-133: /2 every 40 epochs
-        if (epoch + 1) % 40 == 0:
-            for g in opt.param_groups:
-                g['lr'] = g['lr'] / 2.0
 
 
 class LapSRN(_Trainer):
@@ -216,10 +226,6 @@ class LapSRN(_Trainer):
     def build_model(self):
         return models.LapSRNNet(self.num_channels, 64, 10)   # lapsrn.py:129
 
-    def lr_decay(self, epoch, opt):   # lapsrn.py:173-175: /2 every 50 epochs
-        if (epoch + 1) % 50 == 0:
-            for g in opt.param_groups:
-                g['lr'] = g['lr'] / 2.0
 
 
 class SRGAN(_Trainer):
@@ -246,26 +252,30 @@ class SRGAN(_Trainer):
             g_dp.broadcast_params()
             d_dp.broadcast_params()
         norm = lambda t: utils.norm(t, vgg=True)   # srgan.py:193-194,257-258
-        # generator pre-training (srgan.py:179-219; 50 epochs in the reference)
-        pre = 1 if pretrain_epochs is None else pretrain_epochs
-        pre_step = trainers.mse_step(self.G, g_opt, g_dp)
-        for epoch in range(pre):
-            for lr_img, hr_img in (loader or synthetic_loader("srgan", self.args, self.steps_per_epoch, self.device,
-                                                              77 + epoch)):
-                pre_step(norm(lr_img.to(self.device)), norm(hr_img.to(self.device)))
-        if self.rank == 0:
-            self.save_model(is_pretrain=True)
+
+        def batches(seed):   # loaders yield (lr, hr) or the reference's (lr, hr, bicubic) tuples (dataset.py:101)
+            for batch in (loader or synthetic_loader("srgan", self.args, self.steps_per_epoch, self.device, seed)):
+                lr_img, hr_img = batch[:2]
+                yield norm(lr_img.to(self.device, non_blocking=True)), norm(hr_img.to(self.device, non_blocking=True))
+
+        # generator pre-training (srgan.py:179-219): 50 epochs of MSE unless a pre-trained generator checkpoint loads
+        self.epoch_pretrain = int(getattr(self.args, "epoch_pretrain", 50)) if pretrain_epochs is None else pretrain_epochs
+        if self.load_model(is_pretrain=True):
+            g_flat.mark_changed()      # parameters changed behind the optimizer's back: re-pack filters
+        else:
+            pre_step = trainers.mse_step(self.G, g_opt, g_dp)
+            for epoch in range(self.epoch_pretrain):
+                for y_, x_ in batches(77 + epoch):
+                    pre_step(y_, x_)
+            if self.rank == 0:
+                self.save_model(is_pretrain=True)
         step = trainers.srgan_step(self.G, self.D, g_opt, d_opt, g_dp, d_dp)
         hist = []
         for epoch in range(self.num_epochs):
-            if (epoch + 1) % 20 == 0:   # srgan.py:239-244: both learning rates /2 every 20 epochs
-                for o in (g_opt, d_opt):
-                    for g in o.param_groups:
-                        g['lr'] = g['lr'] / 2.0
+            apply_lr_decay("srgan", epoch, g_opt, d_opt)   # srgan.py:239-244: both learning rates /10 every 20 epochs
             d_tot, g_tot, n = torch.zeros((), device=self.device), torch.zeros((), device=self.device), 0
-            for lr_img, hr_img in (loader or synthetic_loader("srgan", self.args, self.steps_per_epoch, self.device,
-                                                              1234 + epoch)):
-                d_loss, g_loss = step(norm(lr_img.to(self.device)), norm(hr_img.to(self.device)))
+            for y_, x_ in batches(1234 + epoch):
+                d_loss, g_loss = step(y_, x_)
                 d_tot += d_loss.detach()
                 g_tot += g_loss.detach()
                 n += 1

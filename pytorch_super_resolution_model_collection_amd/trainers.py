@@ -10,6 +10,7 @@ two graph launches (+ the all-reduce) instead of ~200 kernel launches from Pytho
 import torch
 
 from . import ops
+from .layers import bump_weight_epoch
 from .optim import FlatParams, make_optimizer
 
 
@@ -65,11 +66,15 @@ def lapsrn_step(model, opt, dp=None):
     return step
 
 
-def srgan_step(G, D, g_opt, d_opt, g_dp=None, d_dp=None):
-    """srgan.py:249-310 with [B,1] labels; the VGG term is omitted (it has zero gradient in the
-    reference).  As in the reference the D step back-propagates through G
+def srgan_step(G, D, g_opt, d_opt, g_dp=None, d_dp=None, feature_extractor=None):
+    """srgan.py:249-310 with [B,1] labels.  As in the reference the D step back-propagates through G
     (G is not detached, srgan.py:279) and the G step accumulates into D's gradients, which the
-    next D step's zero_grad discards."""
+    next D step's zero_grad discards.
+    `feature_extractor` (models.FeatureExtractor): adds the reference's VGG content term 6e-3 * MSE(vgg(norm(recon.data)),
+    vgg(norm(hr)).detach()) to the reported G loss (srgan.py:301-308).  Both operands are detached in the reference,
+    so the term changes the logged scalar only — never a gradient; without an extractor the step
+    returns mse + 1e-3 * GAN, which has the same gradients."""
+    from . import utils
     def step(lr_img, hr_img):
         b = lr_img.shape[0]
         real = torch.ones(b, 1, device=lr_img.device)
@@ -84,6 +89,12 @@ def srgan_step(G, D, g_opt, d_opt, g_dp=None, d_dp=None):
         recon = G(lr_img)
         gan_loss = ops.bce_loss(D(recon), real)
         g_loss = ops.mse_loss(recon, hr_img) + 1e-3 * gan_loss
+        if feature_extractor is not None:
+            with torch.no_grad():   # srgan.py:301-305 (the inputs are already normalised once, as in the reference)
+                real_feature = feature_extractor(utils.norm(hr_img, vgg=True))
+                fake_feature = feature_extractor(utils.norm(recon.detach(), vgg=True))
+                vgg_loss = ops.mse_loss(fake_feature, real_feature)
+            g_loss = g_loss + 6e-3 * vgg_loss
         _backward(g_loss, g_dp)
         if g_dp is not None:
             g_dp.allreduce_grads()
@@ -166,6 +177,9 @@ class GraphedStep(object):
         if self.graph_b is not None:
             self._exchange()
             self.graph_b.replay()
+        # the replayed optimizer kernel changed the weights without running optim.step()'s host bookkeeping: packed
+        # filters cached by no-grad forwards (layers._PackCache) and the PackPlan must not be reused
+        self.opt.flat.mark_changed()
         return self.loss
 
 
@@ -175,8 +189,9 @@ class GraphedFn(object):
     graph; call with new batches (copied into the static buffers), returns the captured output tensors.  Everything
     the step does must be stream work (no host reads of device values), which holds for all steps of this package."""
 
-    def __init__(self, fn, example_inputs, warmup=3):
+    def __init__(self, fn, example_inputs, warmup=3, flats=()):
         self.fn = fn
+        self.flats = list(flats)   # FlatParams the step updates (their PackPlans are invalidated after every replay)
         self.static = [torch.empty_like(t).copy_(t) for t in example_inputs]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -194,5 +209,9 @@ class GraphedFn(object):
             if b is not s:
                 s.copy_(b, non_blocking=True)
         self.graph.replay()
+        # weights changed inside the graph: invalidate the packed-filter caches of no-grad forwards (see GraphedStep)
+        bump_weight_epoch()
+        for f in self.flats:
+            f.mark_changed()
         return self.out
 

@@ -2,8 +2,6 @@
 initialisers (utils.py:76-113), border crop (`shave`, :197-205), PSNR (:208-216) and the
 mean/std normalisation constants (:219-239).  Plotting / GIF / PNG helpers are out of scope
 (SURVEY.md §2 rows 11-12)."""
-import math
-
 import torch
 
 
@@ -13,7 +11,9 @@ def _init_by_classname(m, conv_linear_init, norm_init):
         conv_linear_init(m.weight)
         if getattr(m, "bias", None) is not None:
             m.bias.data.zero_()
-    elif name.find("Norm") != -1:
+    elif name.find("Norm") != -1 and getattr(m, "weight", None) is not None:
+        # (parameter-free norms — InstanceNorm2d's default — have nothing to initialise; the reference's
+        #  `m.weight.data.normal_` would raise on them, utils.py:89)
         norm_init(m.weight)
         if m.bias is not None:
             m.bias.data.zero_()
@@ -38,36 +38,38 @@ def shave(imgs, border_size=0):
 
 
 def PSNR(pred, gt):
-    """utils.py:208-216 (prediction clamped to [0,1], peak 1.0)."""
-    pred = pred.detach().float().cpu().clamp(0, 1)
-    mse = torch.mean((pred - gt.detach().float().cpu()) ** 2).item()
-    if mse == 0:
-        return 100
-    return 10 * math.log10(1.0 / mse)
+    """utils.py:208-216 (prediction clamped to [0,1], peak 1.0; 100 for identical images).  GPU tensors: computed on
+    the device by srk_psnr and returned as a 0-dim DEVICE tensor — no host copy and no sync per image (float() it, or
+    torch.stack a list of them, when the numbers are needed).  CPU tensors (what the reference passes) are moved to the
+    current device first; there is no host arithmetic."""
+    from . import ops
+    if not pred.is_cuda:
+        pred = pred.to("cuda")
+    return ops.psnr(pred.float(), gt.to(pred.device).float())[0]
 
 
 VGG_MEAN = (0.485, 0.456, 0.406)
 VGG_STD = (0.229, 0.224, 0.225)
+VGG_DENORM_MEAN = (-2.118, -2.036, -1.804)
+VGG_DENORM_STD = (4.367, 4.464, 4.444)
 
 
 def norm(img, vgg=False):
-    """utils.py:219-229 applied per channel on a [C,H,W] or [B,C,H,W] tensor (the reference's 4-D use
-    is broken on its own stack; this is the intended arithmetic)."""
+    """utils.py:219-229 applied per channel on a [C,H,W] or [B,C,H,W] tensor (the reference's 4-D use is broken on
+    its own stack; this is the intended arithmetic).  One kernel (srk_channel_affine), bit-equal
+    to torchvision's Normalize (sub_(mean).div_(std))."""
+    from . import ops
     mean, std = (VGG_MEAN, VGG_STD) if vgg else ((0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
-    c = img.shape[-3]
-    m = torch.tensor(mean[:c], dtype=img.dtype, device=img.device).view(-1, 1, 1)
-    s = torch.tensor(std[:c], dtype=img.dtype, device=img.device).view(-1, 1, 1)
-    return (img - m) / s
+    return ops.channel_affine(img, mean, std)
 
 
 def denorm(img, vgg=False):
-    """utils.py:232-239"""
+    """utils.py:232-239: vgg -> Normalize(mean=[-2.118,-2.036,-1.804], std=[4.367,4.464,4.444]); else
+    ((img + 1) / 2).clamp(0, 1) — written as (img - (-1)) / 2, the same two IEEE operations."""
+    from . import ops
     if vgg:
-        c = img.shape[-3]
-        m = torch.tensor((-2.118, -2.036, -1.804)[:c], dtype=img.dtype, device=img.device).view(-1, 1, 1)
-        s = torch.tensor((4.367, 4.464, 4.444)[:c], dtype=img.dtype, device=img.device).view(-1, 1, 1)
-        return (img - m) / s
-    return ((img + 1) / 2).clamp(0, 1)
+        return ops.channel_affine(img, VGG_DENORM_MEAN, VGG_DENORM_STD)
+    return ops.channel_affine(img, (-1.0,) * 8, (2.0,) * 8, clamp01=True)
 
 
 def img_interp(imgs, scale_factor, interpolation='bicubic'):

@@ -38,6 +38,11 @@ def train_golden():
     return _load("train_traj.npz")
 
 
+@pytest.fixture(scope="session")
+def blocks_r2():
+    return _load("blocks_r2.npz")
+
+
 def rel_err(a, b):
     """max |a-b| / max(|b|, tiny) on numpy arrays / tensors."""
     import torch
@@ -50,6 +55,28 @@ def rel_err(a, b):
     assert a.shape == b.shape, (a.shape, b.shape)
     denom = max(float(np.abs(b).max()), 1e-30)
     return float(np.abs(a - b).max()) / denom
+
+
+def assert_close_elementwise(a, b, rtol, atol=None, what=""):
+    """Element-wise |a-b| <= atol + rtol*|b| (numpy.allclose form) -- stricter than the max-norm `rel_err`: small
+    elements must be right too.  `atol` defaults to rtol * rms(b): elements far below the tensor's typical magnitude
+    are held to an absolute bar at that scale (they are sums of products whose rounding error scales with the rms of
+    the terms, not with the cancelled result)."""
+    import torch
+    if isinstance(a, torch.Tensor):
+        a = a.detach().float().cpu().numpy()
+    if isinstance(b, torch.Tensor):
+        b = b.detach().float().cpu().numpy()
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if atol is None:
+        atol = rtol * float(np.sqrt(np.mean(b * b))) if b.size else 0.0
+    bad = np.abs(a - b) > atol + rtol * np.abs(b)
+    if bad.any():
+        i = np.unravel_index(np.argmax(np.abs(a - b) - (atol + rtol * np.abs(b))), a.shape)
+        raise AssertionError("%s: %d of %d elements outside atol=%.3g rtol=%.3g; worst at %s: got %.9g want %.9g"
+                             % (what, int(bad.sum()), a.size, atol, rtol, i, a[i], b[i]))
 
 
 @pytest.fixture(scope="session")

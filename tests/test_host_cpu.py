@@ -80,6 +80,121 @@ def test_block_constructor_signatures_match_reference(pkg):
             assert pa[k].default == pb[k].default, (cls, k)
 
 
+def test_block_variants_construct_like_the_reference(pkg):
+    """Every (upsample, norm) variant the reference's blocks can be built with constructs here too, with the same
+    state_dict keys and shapes: 'rnc' upsampler, instance norm, DenseBlock's BatchNorm1d."""
+    B = pkg.base_networks
+    cases = [(B.Upsample2xBlock, R.Upsample2xBlock, (8, 12), dict(upsample='rnc', activation='relu', norm=None)),
+             (B.Upsample2xBlock, R.Upsample2xBlock, (8, 12), dict(upsample='rnc', activation='prelu', norm='batch')),
+             (B.ConvBlock, R.ConvBlock, (8, 16, 3, 1, 1), dict(norm='instance')),
+             (B.DeconvBlock, R.DeconvBlock, (8, 16), dict(norm='instance')),
+             (B.ResnetBlock, R.ResnetBlock, (16,), dict(norm='instance')),
+             (B.PSBlock, R.PSBlock, (8, 8, 2), dict(norm='instance')),
+             (B.DenseBlock, R.DenseBlock, (24, 10), dict()),                       # default norm='batch' -> BatchNorm1d
+             (B.DenseBlock, R.DenseBlock, (24, 10), dict(activation='prelu', norm='batch'))]
+    for ours, theirs, args, kw in cases:
+        a, b = ours(*args, **kw), theirs(*args, **kw)
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys()), (ours.__name__, kw)
+        for k in sa:
+            assert tuple(sa[k].shape) == tuple(sb[k].shape), k
+        b.load_state_dict(sa)
+        a.load_state_dict(sb)
+        for m in a.modules():          # the reference's initialiser walks every module by class name
+            pkg.utils.weights_init_normal(m)
+    with pytest.raises(NotImplementedError):
+        B.DenseBlock(24, 10, norm='instance')   # InstanceNorm1d on [B, F] is ill-defined (see layers.make_norm1d)
+    with pytest.raises(ValueError):
+        B.Upsample2xBlock(8, 8, upsample='bogus')
+
+
+def test_vgg_feature_extractor_layout(pkg):
+    """srgan.py:84-90: vgg19.features[:9] — same Sequential indices, so a torchvision vgg19 state_dict loads directly."""
+    fe = pkg.FeatureExtractor()
+    assert list(fe.state_dict().keys()) == ["features.%d.%s" % (i, k) for i in (0, 2, 5, 7) for k in ("weight", "bias")]
+    assert [tuple(fe.state_dict()["features.%d.weight" % i].shape) for i in (0, 2, 5, 7)] == \
+        [(64, 3, 3, 3), (64, 64, 3, 3), (128, 64, 3, 3), (128, 128, 3, 3)]
+    assert len(fe.features) == 9 and isinstance(fe.features[4], torch.nn.MaxPool2d)
+    assert not any(p.requires_grad for p in fe.parameters())
+    full = {k: torch.zeros_like(v) for k, v in fe.state_dict().items()}
+    full["features.10.weight"] = torch.zeros(256, 128, 3, 3)     # deeper vgg19 entries are ignored
+    full["classifier.0.weight"] = torch.zeros(8, 8)
+    fe.load_vgg19(full)
+    assert float(fe.features[0].weight.abs().max()) == 0.0
+    with pytest.raises(KeyError):
+        fe.load_vgg19({"features.0.weight": torch.zeros(64, 3, 3, 3)})
+    assert len(pkg.FeatureExtractor(feature_layer=36).features) == 37   # the whole vgg19.features stack
+
+
+def test_lr_decay_rules_match_reference(pkg):
+    """vdsr.py:127-129 (/10 every 20), edsr.py:131-133 (/2 every 40), lapsrn.py:173-175 (/10 every 100),
+    srgan.py:239-244 (/10 every 20, G and D); srcnn / espcn / fsrcnn never decay."""
+    from pytorch_super_resolution_model_collection_amd import sr_trainers as T
+
+    class Opt(object):
+        def __init__(self, lr):
+            self.param_groups = [{"lr": lr}, {"lr": lr * 2}]
+
+    def run(kind, epochs, n_opts=1):
+        opts = [Opt(1.0) for _ in range(n_opts)]
+        for e in range(epochs):
+            T.apply_lr_decay(kind, e, *opts)
+        return [o.param_groups[0]["lr"] for o in opts], opts[0].param_groups[1]["lr"]
+
+    def ref(every, factor, epochs):
+        lr = 1.0
+        for e in range(epochs):
+            if (e + 1) % every == 0:
+                lr /= factor
+        return lr
+
+    assert run("vdsr", 45)[0] == [ref(20, 10.0, 45)]
+    assert run("edsr", 100)[0] == [ref(40, 2.0, 100)]
+    assert run("lapsrn", 250)[0] == [ref(100, 10.0, 250)]
+    assert run("lapsrn", 99)[0] == [1.0]
+    assert run("srgan", 60, 2)[0] == [ref(20, 10.0, 60)] * 2
+    assert run("srgan", 60, 2)[1] == 2 * ref(20, 10.0, 60)       # every param group
+    for kind in ("srcnn", "espcn", "fsrcnn"):
+        assert run(kind, 300)[0] == [1.0]
+    assert T.LR_DECAY == {"vdsr": (20, 10.0), "edsr": (40, 2.0), "lapsrn": (100, 10.0), "srgan": (20, 10.0)}
+
+
+def test_integration_md_stubs_match_header(pkg):
+    """INTEGRATION.md's ctypes stub is what a maintainer pastes: its Structure `_fields_` must match include/srk.h
+    (names, order, count) and the package's own binding."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    header = open(os.path.join(root, "include", "srk.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+
+    def header_fields(struct):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), header, flags=re.S).group(1)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            decl = re.sub(r"^(const\s+)?(float|int32_t|int64_t|double|int)\s*\*?", "", decl).strip()
+            names += [n.strip().lstrip("*") for n in decl.split(",")]
+        return names
+
+    def md_fields(cls):
+        m = re.search(r"class %s\(ctypes\.Structure\):.*?_fields_\s*=\s*\[(.*?)\]\n" % cls, text, flags=re.S)
+        assert m, "INTEGRATION.md has no ctypes stub for %s" % cls
+        return re.findall(r'\(\s*"(\w+)"', m.group(1))
+
+    for struct, cls, ours in (("srk_conv_desc", "ConvDesc", pkg._lib.ConvDesc), ("srk_epilogue", "Epilogue", pkg._lib.Epilogue),
+                              ("srk_bwd_mask", "BwdMask", pkg._lib.BwdMask)):
+        want = header_fields(struct)
+        assert md_fields(cls) == want, (cls, md_fields(cls), want)
+        assert [f[0] for f in ours._fields_] == want, cls
+    n_units = len([f for f in os.listdir(os.path.join(root, "pytorch_super_resolution_model_collection_amd", "csrc"))
+                   if f.endswith(".hip")])
+    m = re.search(r"(\d+) translation units", text)
+    assert m and int(m.group(1)) == n_units == len(pkg._build.SOURCES), (m and m.group(1), n_units)
+
+
 def test_weight_init_distributions(pkg):
     torch.manual_seed(0)
     net = pkg.EDSRNet(3, 64, 16)

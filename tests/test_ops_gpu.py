@@ -381,3 +381,56 @@ def test_conv_fused2(gpu, k1, p1, k2, p2, c1, c2, act, nchw, hw):
         y = pkg.ops.conv2d_fused2_infer(xg, conv1, a[0], a[1], conv2, a[0], a[1])
     assert y is not None, "fused kernel declined a shape inside its envelope"
     assert rel_err(y, ref.detach()) < 1e-4
+
+
+class _OneParam(torch.nn.Module):
+    def __init__(self, p0):
+        super(_OneParam, self).__init__()
+        self.p = torch.nn.Parameter(p0.clone())
+
+
+@pytest.mark.parametrize("kind", ["srcnn", "fsrcnn", "vdsr", "edsr", "srgan_d"])
+def test_optimizers_kat(gpu, ops_kat, kind):
+    """srk_sgd_step / srk_adam_step against the reference's optimizer choices (srcnn.py:79 plain SGD; fsrcnn.py:105
+    momentum; vdsr.py:86-90 momentum + weight decay; edsr.py:93 Adam with the device step counter / bias correction;
+    srgan.py:149 Nesterov at lr/100): 3 steps on a flat 1000-vector with the committed gradients."""
+    pkg = _pkg()
+    mod = _OneParam(torch.from_numpy(ops_kat["opt.p0"])).to(gpu)
+    flat = pkg.optim.FlatParams(mod)
+    opt = pkg.optim.make_optimizer(kind, flat, 1e-2)
+    for g in ops_kat["opt.grads"]:
+        opt.zero_grad()
+        flat.grad[:1000].copy_(torch.from_numpy(g).to(gpu))
+        opt.step()
+    want = ops_kat["opt.%s.final" % kind]
+    got = mod.p.detach().cpu().numpy()
+    assert float(np.abs(got - ops_kat["opt.p0"]).max()) > 1e-4          # the parameters did move
+    assert float(np.abs(got - want).max()) <= 1e-6 * max(1.0, float(np.abs(want).max())), kind
+    if kind == "edsr":
+        assert int(opt.step_dev.item()) == 3
+
+
+def test_grad_norm_clip_kat(gpu, ops_kat):
+    """srk_grad_norm_clip = torch.nn.utils.clip_grad_norm (vdsr.py:149): the norm, and the scale the next optimizer
+    step applies (the flat gradient itself stays unscaled)."""
+    pkg = _pkg()
+    mod = _OneParam(torch.from_numpy(ops_kat["opt.p0"])).to(gpu)
+    flat = pkg.optim.FlatParams(mod)
+    opt = pkg.optim.SGD(flat, 1.0)
+    g = torch.from_numpy(ops_kat["opt.grads"][0]).to(gpu) * 3
+    opt.zero_grad()
+    flat.grad[:1000].copy_(g)
+    norm = opt.clip_grad_norm(0.4)
+    assert abs(float(norm) - float(ops_kat["opt.clip.norm"])) <= 1e-6 * float(ops_kat["opt.clip.norm"])
+    clipped = (flat.grad[:1000] * opt.scale_dev).cpu().numpy()
+    assert float(np.abs(clipped - ops_kat["opt.clip.grad"]).max()) <= 1e-6 * float(np.abs(ops_kat["opt.clip.grad"]).max())
+    # the SGD step (lr 1) applies exactly that scaled gradient
+    p_before = mod.p.detach().clone()
+    opt.step()
+    step = (p_before - mod.p.detach()).cpu().numpy()
+    assert float(np.abs(step - ops_kat["opt.clip.grad"]).max()) <= 2e-6 * float(np.abs(ops_kat["opt.clip.grad"]).max()) + 1e-7
+    # a gradient already inside the ball is left alone (scale 1)
+    opt.zero_grad()
+    flat.grad[:1000].copy_(g * 1e-3)
+    opt.clip_grad_norm(0.4)
+    assert float(opt.scale_dev) == 1.0

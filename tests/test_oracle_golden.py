@@ -75,3 +75,28 @@ def test_reference_quirks_are_preserved():
     assert len(lap.state_dict()) == 2 * (2 + 1) + 5  # aliased keys are listed twice
     fs = R.FSRCNN(3, 4, 56, 12, 4)
     assert tuple(fs(torch.zeros(1, 3, 12, 12)).shape) == (1, 3, 4 * (12 - 5) + 4, 4 * (12 - 5) + 4)
+
+
+R2_BLOCKS = {
+    "rnc": (lambda: R.Upsample2xBlock(8, 12, upsample='rnc', activation='relu', norm=None), ("rand", (2, 8, 5, 6), 601), 602, 1.0),
+    "rnc_prelu": (lambda: R.Upsample2xBlock(16, 16, upsample='rnc', activation='prelu', norm=None), ("rand", (1, 16, 7, 4), 603), 604, 1.0),
+    "inst": (lambda: R.ConvBlock(8, 16, 3, 1, 1, activation='lrelu', norm='instance'), ("randn", (3, 8, 9, 7), 611), 612, 1.0),
+    "resinst": (lambda: R.ResnetBlock(16, activation='relu', norm='instance'), ("randn", (2, 16, 6, 8), 613), 614, 0.7),
+    "dense_bn": (lambda: R.DenseBlock(24, 10, activation='lrelu', norm='batch'), ("randn", (6, 24), 621), 622, 1.0),
+}
+
+
+@pytest.mark.parametrize("tag", list(R2_BLOCKS))
+def test_oracle_block_variants_match_reference_vectors(blocks_r2, tag):
+    """Block variants no reference net instantiates ('rnc' upsampler, instance norm, DenseBlock + BatchNorm1d) against
+    tests/golden/blocks_r2.npz (reference classes, make_golden_r2.py)."""
+    make, (kind, shape, xs), gs, gain = R2_BLOCKS[tag]
+    mod = fill.fill_module(make(), 4242, gain)
+    mod.train()
+    x = getattr(fill, kind)(shape, xs).requires_grad_(True)
+    y = mod(x)
+    (y * fill.randn(tuple(y.shape), gs)).sum().backward()
+    assert rel_err(y, blocks_r2[tag + ".y"]) < TOL
+    assert rel_err(x.grad, blocks_r2[tag + ".dx"]) < 10 * TOL
+    for n, p in mod.named_parameters():
+        assert rel_err(p.grad, blocks_r2["%s.grad.%s" % (tag, n)]) < 10 * TOL, n

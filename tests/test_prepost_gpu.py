@@ -1,0 +1,226 @@
+"""GPU parity of the steps either side of the nets: device PSNR, norm / denorm,
+the 'rnc' upsampler, instance norm, DenseBlock + BatchNorm1d, the VGG19 feature extractor and the VGG content term
+of the SRGAN step — against tests/golden/blocks_r2.npz (reference classes) and the oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import rel_err
+from oracle import fill, ref_modules as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _pkg():
+    import pytorch_super_resolution_model_collection_amd as pkg
+    return pkg
+
+
+def test_psnr_on_device(gpu, blocks_r2):
+    """utils.PSNR (utils.py:208-216) without leaving the device: reference values, any strides, identical -> 100."""
+    pkg = _pkg()
+    pred = fill.rand((2, 3, 9, 11), 631, -0.2, 1.2)
+    gt = fill.rand((2, 3, 9, 11), 632)
+    want = float(blocks_r2["psnr.value"])
+    for p, g in ((pred.to(gpu), gt.to(gpu)),                                                   # NCHW / NCHW
+                 (pred.to(gpu).contiguous(memory_format=torch.channels_last), gt.to(gpu)),     # net output layout
+                 (pred.to(gpu), gt.to(gpu).contiguous(memory_format=torch.channels_last))):
+        v = pkg.utils.PSNR(p, g)
+        assert isinstance(v, torch.Tensor) and v.is_cuda and v.dim() == 0      # stays on the device
+        assert abs(float(v) - want) <= 1e-5 * abs(want)
+    assert abs(float(pkg.utils.PSNR(pred[0].to(gpu), gt[0].to(gpu))) - float(blocks_r2["psnr.single"])) <= 1e-5 * want
+    assert float(pkg.utils.PSNR(gt.to(gpu), gt.to(gpu))) == float(blocks_r2["psnr.identical"]) == 100.0
+    # a shaved (strided view) target, as srcnn.py:193-199 builds it
+    bp, bg = fill.rand((1, 3, 64, 48), 633), fill.rand((1, 3, 64, 48), 634)
+    mix = bp * 0.05 + bg * 0.95
+    assert abs(float(pkg.utils.PSNR(mix.to(gpu), bg.to(gpu))) - float(blocks_r2["psnr.big"])) <= 1e-5 * float(blocks_r2["psnr.big"])
+    a, b = pkg.utils.shave(mix.to(gpu), 8), pkg.utils.shave(bg.to(gpu), 8)
+    d = (mix[..., 8:-8, 8:-8].clamp(0, 1) - bg[..., 8:-8, 8:-8]).double()
+    ref = 10 * math.log10(1.0 / float((d * d).mean()))
+    assert abs(float(pkg.utils.PSNR(a, b)) - ref) <= 1e-5 * ref
+    psnr, mse = pkg.ops.psnr(mix.to(gpu), bg.to(gpu))
+    assert abs(float(mse) - float(((mix.clamp(0, 1) - bg).double() ** 2).mean())) <= 1e-6 * float(mse)
+
+
+@pytest.mark.parametrize("layout", ["nchw", "channels_last", "chw"])
+def test_norm_denorm_constants(gpu, layout):
+    """utils.norm / utils.denorm (utils.py:219-239): torchvision's Normalize is sub_(mean).div_(std) per channel —
+    bit-equal results for the [-1,1] and the VGG constants, both denorm branches, NCHW / channels_last / [C,H,W]."""
+    pkg = _pkg()
+    x = fill.rand((2, 3, 7, 5), 641, -0.5, 1.5)
+    if layout == "chw":
+        x = x[0]
+    xg = x.to(gpu)
+    if layout == "channels_last":
+        xg = xg.contiguous(memory_format=torch.channels_last)
+
+    def normalize(t, mean, std):       # torchvision.transforms.functional.normalize arithmetic
+        m = torch.tensor(mean, dtype=torch.float32).view(-1, 1, 1)
+        s = torch.tensor(std, dtype=torch.float32).view(-1, 1, 1)
+        return t.clone().sub_(m).div_(s)
+
+    assert torch.equal(pkg.utils.norm(xg).cpu(), normalize(x, [0.5, 0.5, 0.5], [0.5, 0.5, 0.5]))
+    assert torch.equal(pkg.utils.norm(xg, vgg=True).cpu(), normalize(x, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]))
+    assert torch.equal(pkg.utils.denorm(xg, vgg=True).cpu(),
+                       normalize(x, [-2.118, -2.036, -1.804], [4.367, 4.464, 4.444]))
+    assert torch.equal(pkg.utils.denorm(xg).cpu(), ((x + 1) / 2).clamp(0, 1))
+    # round trip of the [-1,1] pair on in-range data
+    y = fill.rand(tuple(x.shape), 642).to(gpu)
+    assert rel_err(pkg.utils.denorm(pkg.utils.norm(y)), y) < 1e-6
+    # single-channel images (num_channels == 1 path of srgan.py:188-190)
+    g1 = fill.rand((2, 1, 6, 6), 643)
+    assert torch.equal(pkg.utils.norm(g1.to(gpu), vgg=True).cpu(), normalize(g1, [0.485], [0.229]))
+
+
+def _run_block(pkg, gpu, blocks_r2, tag, make_ours, make_ora, kind, shape, xs, gs, gain, tol_f, tol_g):
+    ora = fill.fill_module(make_ora(), 4242, gain)
+    net = make_ours()
+    net.load_state_dict(ora.state_dict())
+    net.to(gpu).train()
+    x = getattr(fill, kind)(shape, xs).to(gpu).requires_grad_(True)
+    y = net(x)
+    (y * fill.randn(tuple(y.shape), gs).to(gpu)).sum().backward()
+    assert rel_err(y, blocks_r2[tag + ".y"]) < tol_f, tag
+    assert rel_err(x.grad, blocks_r2[tag + ".dx"]) < tol_g, tag
+    for n, p in net.named_parameters():
+        assert rel_err(p.grad, blocks_r2["%s.grad.%s" % (tag, n)]) < tol_g, (tag, n)
+    return net, ora
+
+
+@pytest.mark.parametrize("tag", ["rnc", "rnc_prelu"])
+def test_upsample2x_rnc(gpu, blocks_r2, tag):
+    """Upsample2xBlock(upsample='rnc') (base_networks.py:204-210): nearest x2 + ConvBlock 3x3, training forward,
+    input gradient and parameter gradients against the reference vectors; no-grad path equals the autograd path."""
+    pkg = _pkg()
+    B = pkg.base_networks
+    if tag == "rnc":
+        args = (lambda: B.Upsample2xBlock(8, 12, upsample='rnc', activation='relu', norm=None),
+                lambda: R.Upsample2xBlock(8, 12, upsample='rnc', activation='relu', norm=None), "rand", (2, 8, 5, 6), 601, 602)
+    else:
+        args = (lambda: B.Upsample2xBlock(16, 16, upsample='rnc', activation='prelu', norm=None),
+                lambda: R.Upsample2xBlock(16, 16, upsample='rnc', activation='prelu', norm=None), "rand", (1, 16, 7, 4), 603, 604)
+    net, ora = _run_block(pkg, gpu, blocks_r2, tag, *args, 1.0, 1e-4, 5e-4)
+    net.eval()
+    with torch.no_grad():
+        assert rel_err(net(fill.rand(args[3], args[4]).to(gpu)), blocks_r2[tag + ".y"]) < 1e-4
+    # the nearest kernel alone is a permutation: bit-exact forward, exact block sums backward
+    x = fill.randn((2, 6, 3, 5), 650).to(gpu).requires_grad_(True)
+    y = pkg.ops.upsample_nearest(x, 2)
+    assert torch.equal(y.detach().cpu(), nn.Upsample(scale_factor=2, mode='nearest')(x.detach().cpu()))
+    g = fill.randn(tuple(y.shape), 651)
+    y.backward(g.to(gpu))
+    xc = x.detach().cpu().requires_grad_(True)
+    nn.Upsample(scale_factor=2, mode='nearest')(xc).backward(g)
+    assert rel_err(x.grad, xc.grad) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["inst", "resinst"])
+def test_instance_norm_blocks(gpu, blocks_r2, tag):
+    """norm='instance' (base_networks.py:48,119): ConvBlock and ResnetBlock (shared norm called twice)."""
+    pkg = _pkg()
+    B = pkg.base_networks
+    if tag == "inst":
+        args = (lambda: B.ConvBlock(8, 16, 3, 1, 1, activation='lrelu', norm='instance'),
+                lambda: R.ConvBlock(8, 16, 3, 1, 1, activation='lrelu', norm='instance'), "randn", (3, 8, 9, 7), 611, 612, 1.0)
+    else:
+        args = (lambda: B.ResnetBlock(16, activation='relu', norm='instance'),
+                lambda: R.ResnetBlock(16, activation='relu', norm='instance'), "randn", (2, 16, 6, 8), 613, 614, 0.7)
+    _run_block(pkg, gpu, blocks_r2, tag, *args, 1e-4, 5e-4)
+
+
+def test_dense_block_batchnorm1d(gpu, blocks_r2):
+    """DenseBlock's default norm='batch' -> BatchNorm1d (base_networks.py:10-11): two train calls (running
+    statistics) and the eval-mode output."""
+    pkg = _pkg()
+    net, ora = _run_block(pkg, gpu, blocks_r2, "dense_bn",
+                          lambda: pkg.base_networks.DenseBlock(24, 10, activation='lrelu', norm='batch'),
+                          lambda: R.DenseBlock(24, 10, activation='lrelu', norm='batch'), "randn", (6, 24), 621, 622, 1.0,
+                          2e-5, 2e-4)
+    y2 = net(fill.randn((6, 24), 623).to(gpu))
+    assert rel_err(y2, blocks_r2["dense_bn.y2"]) < 2e-5
+    sd = net.state_dict()
+    for k in ("bn.running_mean", "bn.running_var"):
+        assert rel_err(sd[k], blocks_r2["dense_bn." + k]) < 1e-5, k
+    assert int(sd["bn.num_batches_tracked"]) == 2
+    net.eval()
+    with torch.no_grad():
+        assert rel_err(net(fill.randn((6, 24), 621).to(gpu)), blocks_r2["dense_bn.eval_y"]) < 2e-5
+
+
+def _torch_vgg_head():
+    """vgg19.features[:9] built from stock torch.nn layers (what torchvision constructs)."""
+    return nn.Sequential(nn.Conv2d(3, 64, 3, padding=1), nn.ReLU(True), nn.Conv2d(64, 64, 3, padding=1), nn.ReLU(True),
+                         nn.MaxPool2d(2, 2), nn.Conv2d(64, 128, 3, padding=1), nn.ReLU(True),
+                         nn.Conv2d(128, 128, 3, padding=1), nn.ReLU(True))
+
+
+def test_maxpool_and_vgg_feature_extractor(gpu):
+    """srgan.py:84-90: the VGG19 feature head (4 conv+ReLU, one 2x2 max-pool) against stock torch layers holding the
+    same weights; the pool kernel alone is bit-exact (odd sizes: floor mode)."""
+    pkg = _pkg()
+    for shape in ((2, 8, 6, 10), (1, 5, 7, 9), (1, 64, 2, 2)):
+        x = fill.randn(shape, 660)
+        with torch.no_grad():
+            y = pkg.ops.max_pool2x2(x.to(gpu))
+        assert torch.equal(y.cpu(), nn.functional.max_pool2d(x, 2, 2))
+    with pytest.raises(RuntimeError):
+        pkg.ops.max_pool2x2(x.to(gpu).requires_grad_(True))
+    head = _torch_vgg_head()
+    sd = {"features." + k: v for k, v in fill.fill_module(head, 77).state_dict().items()}
+    fe = pkg.FeatureExtractor().load_vgg19(sd).to(gpu)
+    x = fill.rand((2, 3, 32, 24), 661)
+    with torch.no_grad():
+        want = head(x)
+    got = fe(x.to(gpu))
+    assert not got.requires_grad and tuple(got.shape) == (2, 128, 16, 12)
+    assert rel_err(got, want) < 1e-4
+
+
+def test_srgan_step_with_vgg_content_term(gpu):
+    """srgan.py:296-310: G_loss = mse + 6e-3 * vgg + 1e-3 * GAN with the VGG term built from detached tensors — the
+    reported loss includes it, the parameter update does not depend on it."""
+    pkg = _pkg()
+    head = fill.fill_module(_torch_vgg_head(), 78)
+    sd = {"features." + k: v for k, v in head.state_dict().items()}
+    lr_img, hr_img = fill.rand((2, 3, 8, 8), 670), fill.rand((2, 3, 32, 32), 671)
+
+    def run(with_vgg):
+        G, D = pkg.SRGANGenerator(3, 16, 2), pkg.SRGANDiscriminator(3, 8, 32)
+        fill.fill_module(G, 5, 0.7)
+        fill.fill_module(D, 6, 1.0)
+        G.to(gpu).train()
+        D.to(gpu).train()
+        g_opt = pkg.optim.make_optimizer("srgan_g", pkg.optim.FlatParams(G), 1e-3)
+        d_opt = pkg.optim.make_optimizer("srgan_d", pkg.optim.FlatParams(D), 1e-2)
+        fe = pkg.FeatureExtractor().load_vgg19(sd).to(gpu) if with_vgg else None
+        step = pkg.trainers.srgan_step(G, D, g_opt, d_opt, feature_extractor=fe)
+        d_loss, g_loss = step(lr_img.to(gpu), hr_img.to(gpu))
+        return float(d_loss), float(g_loss), g_opt.flat.data.clone(), G
+
+    d0, g0, p0, _ = run(False)
+    d1, g1, p1, G1 = run(True)
+    assert d0 == d1 and torch.equal(p0, p1)          # no gradient through the VGG term
+    assert g1 > g0
+    # the term itself, from the oracle generator + stock torch VGG head on the same weights
+    oG2 = fill.fill_module(R.Generator(3, 16, 2), 5, 0.7).train()
+    oD2 = fill.fill_module(R.Discriminator(3, 8, 32), 6, 1.0).train()
+    od_opt = R.make_optimizer("srgan_d", oD2.parameters(), 1e-2)
+    # D step only (srgan.py:264-287), then the generator forward the G step sees
+    od_opt.zero_grad()
+    bce = nn.BCELoss()
+    real, fake = torch.ones(2, 1), torch.zeros(2, 1)
+    (bce(oD2(hr_img), real) + bce(oD2(oG2(lr_img)), fake)).backward()
+    od_opt.step()
+    recon = oG2(lr_img).detach()
+
+    def vnorm(t):
+        m = torch.tensor([0.485, 0.456, 0.406]).view(-1, 1, 1)
+        s = torch.tensor([0.229, 0.224, 0.225]).view(-1, 1, 1)
+        return (t - m) / s
+
+    with torch.no_grad():
+        vgg = nn.functional.mse_loss(head(vnorm(recon)), head(vnorm(hr_img)))
+    assert abs((g1 - g0) - 6e-3 * float(vgg)) <= 2e-3 * 6e-3 * float(vgg) + 1e-7

@@ -203,7 +203,7 @@ def test_trainer_objects_and_cli(gpu, tmp_path):
     from oracle import ref_modules as R
     from pytorch_super_resolution_model_collection_amd.sr_trainers import TRAINERS
     for name, extra in (("EDSR", ["--crop_size", "32"]), ("VDSR", ["--crop_size", "17"]),
-                        ("ESPCN", ["--crop_size", "48"]), ("SRGAN", ["--crop_size", "32", "--batch_size", "2"])):
+                        ("ESPCN", ["--crop_size", "48"]), ("SRGAN", ["--crop_size", "32", "--batch_size", "2", "--epoch_pretrain", "1"])):
         args = cli.parse_args(["--model_name", name, "--num_epochs", "2", "--save_epochs", "1", "--batch_size", "2",
                                "--steps_per_epoch", "2", "--lr", "1e-4", "--save_dir", str(tmp_path)] + extra)
         t = TRAINERS[name](args)
@@ -314,3 +314,53 @@ def test_graphed_srgan_step_equals_eager(gpu):
     got = [[float(v) for v in graphed(*b)] for b in batches]
     assert rel_err(np.array(got), np.array(ref)) < 1e-4
 
+
+
+def test_graphed_steps_interleaved_with_eval_forwards(gpu):
+    """A hipGraph replay runs the optimizer kernel without optim.step()'s host bookkeeping; no-grad forwards cache
+    their packed filters (layers._PackCache).  train(graph) -> eval -> train(graph) -> eval must see the NEW weights in
+    the second eval: compare each eval output with a fresh model that loads the current state_dict."""
+    pkg = _pkg()
+    x, t = B((4, 3, 12, 12), 31).to(gpu), B((4, 3, 48, 48), 32).to(gpu)
+    probe = B((2, 3, 10, 10), 33).to(gpu)
+    net = pkg.EDSRNet(3, 64, 2)
+    fill.fill_module(net, 3, 0.5)
+    net.to(gpu).train()
+    flat, opt, dp, step = pkg.trainers.build("edsr", net, 1e-2)
+    graphed = pkg.trainers.GraphedStep(net, opt, pkg.ops.l1_loss, (x, t), warmup=1)
+    outs = []
+    for _ in range(3):
+        graphed(x, t)
+        net.eval()
+        with torch.no_grad():
+            y = net(probe).clone()
+        net.train()
+        fresh = pkg.EDSRNet(3, 64, 2)
+        fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in net.state_dict().items()})
+        fresh.to(gpu).eval()
+        with torch.no_grad():
+            want = fresh(probe)
+        assert torch.equal(y, want), "eval forward after a graph replay used stale packed filters"
+        outs.append(y)
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])  # lr 1e-2: the weights do move
+
+    # GraphedFn: same property through the generic wrapper
+    net2 = pkg.EDSRNet(3, 64, 2)
+    fill.fill_module(net2, 3, 0.5)
+    net2.to(gpu).train()
+    flat2, opt2, _, step2 = pkg.trainers.build("edsr", net2, 1e-2)
+    gfn = pkg.trainers.GraphedFn(step2, (x, t), warmup=1, flats=[flat2])
+    prev = None
+    for _ in range(2):
+        gfn(x, t)
+        net2.eval()
+        with torch.no_grad():
+            y = net2(probe).clone()
+        net2.train()
+        fresh = pkg.EDSRNet(3, 64, 2)
+        fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in net2.state_dict().items()})
+        fresh.to(gpu).eval()
+        with torch.no_grad():
+            assert torch.equal(y, fresh(probe))
+        assert prev is None or not torch.equal(prev, y)
+        prev = y
