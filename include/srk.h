@@ -177,6 +177,18 @@ int srk_conv2d_backward_weight(const srk_conv_desc* d, const float* x, const flo
                                float* dw, float* db, float beta, void* workspace, size_t workspace_bytes,
                                void* stream);
 
+/* The weight gradients of n convolutions that share ONE geometry `d` — the 32 + 1 body convs of EDSR (edsr.py:37-45),
+ * the 18 of VDSR (vdsr.py:17-24), the 32 of SRResNet — in one launch plus one reduce launch.  x / dy / dw / db are HOST
+ * arrays of n device pointers (db may be NULL, or hold n non-NULL pointers: bias and bias-free layers cannot share a
+ * group), masks a host array of n srk_bwd_mask (NULL = none; an entry's y may be NULL).  No two layers may share a dw
+ * (LapSRN's aliased branches go into separate calls).  Same results as n srk_conv2d_backward_weight calls; geometries
+ * without a grouped kernel run exactly those.  Nothing but the pointer VALUES is read from the host arrays, at call
+ * time (the call is hipGraph-capturable). */
+size_t srk_conv2d_backward_weight_grouped_workspace_bytes(const srk_conv_desc* d, int n);
+int srk_conv2d_backward_weight_grouped(const srk_conv_desc* d, int n, const float* const* x, const float* const* dy,
+                                       const srk_bwd_mask* masks, float* const* dw, float* const* db, float beta,
+                                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- pixel shuffle (torch.nn.PixelShuffle: base_networks.py:157,179-181) ----------------- */
 /* x [N,H,W,C*r*r] -> y [N,H*r,W*r,C];  channel c*r*r + i*r + j -> (c, h*r+i, w*r+j). */
 int srk_pixel_shuffle_forward(const float* x, float* y, int N, int H, int W, int C, int r, void* stream);

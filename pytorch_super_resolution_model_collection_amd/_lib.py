@@ -66,6 +66,10 @@ _PROTOTYPES = {
     "srk_conv2d_backward_weight_workspace_bytes": (c_size, [ctypes.POINTER(ConvDesc)]),
     "srk_conv2d_backward_weight": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, ctypes.POINTER(BwdMask), c_f, c_f,
                                            c_float, c_vp, c_size, c_vp]),
+    "srk_conv2d_backward_weight_grouped_workspace_bytes": (c_size, [ctypes.POINTER(ConvDesc), c_int]),
+    "srk_conv2d_backward_weight_grouped": (c_int, [ctypes.POINTER(ConvDesc), c_int, ctypes.POINTER(c_vp),
+                                                   ctypes.POINTER(c_vp), ctypes.POINTER(BwdMask), ctypes.POINTER(c_vp),
+                                                   ctypes.POINTER(c_vp), c_float, c_vp, c_size, c_vp]),
     "srk_pixel_shuffle_forward": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "srk_pixel_shuffle_backward": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "srk_act_forward": (c_int, [c_f, c_f, c_size, c_int, c_int, c_float, c_f, c_int, c_vp]),

@@ -50,6 +50,12 @@ size_t conv_wgrad_bf_ws(const srk_conv_desc& d);
 int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const srk_bwd_mask* mask, float* dw,
                   float* db, float beta, void* ws, size_t ws_bytes, hipStream_t s);
 
+size_t conv_wgrad_bf_grouped_ws(const srk_conv_desc& d, int n);
+int conv_wgrad_bf_grouped(const srk_conv_desc& d, int n, const float* const* xs, const float* const* dys,
+                          const srk_bwd_mask* masks, float* const* dws, float* const* dbs, float beta, void* ws,
+                          size_t ws_bytes, hipStream_t s);
+constexpr int kMaxWgradGroup = 40;  // = WB_MAXGROUP of conv_wgrad_bf16.hip
+
 // conv_fused2_bf16.hip
 int conv_fused2_forward(const srk_conv_desc& d1, const srk_conv_desc& d2, const float* x, int x_nchw,
                         const float* wp1, const float* wp2, float* y, const Epi& ep1, const Epi& ep2, hipStream_t s);
@@ -258,6 +264,56 @@ extern "C" int srk_conv2d_backward_weight(const srk_conv_desc* d, const float* x
   if (algo != SRK_ALGO_GENERIC && conv_wgrad_mfma_supported(*d))
     return conv_wgrad_mfma(*d, x, dy, mask, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);
   return conv_generic_wgrad(*d, x, dy, mask, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+static bool wgrad_group_uses_bf(const srk_conv_desc& d) {
+  const int algo = forced_algo(d.algo);
+  const char* wb = getenv("SRK_WGRAD_BF16");
+  const char* gg = getenv("SRK_WGRAD_GROUPED");  // 0: grouped calls run layer by layer (A/B against the per-layer kernels)
+  return (algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3) && !(wb && atoi(wb) == 0) && !(gg && atoi(gg) == 0) &&
+         d.dy_ps_r == 0 && !conv_wgrad_tapn_supported(d, nullptr, nullptr) && conv_wgrad_bf_supported(d);
+}
+
+extern "C" size_t srk_conv2d_backward_weight_grouped_workspace_bytes(const srk_conv_desc* d, int n) {
+  if (!d || n < 1) return 0;
+  size_t a = srk_conv2d_backward_weight_workspace_bytes(d);
+  if (wgrad_group_uses_bf(*d)) {
+    const int chunk = n < kMaxWgradGroup ? n : kMaxWgradGroup;
+    const size_t b = conv_wgrad_bf_grouped_ws(*d, chunk);
+    if (b > a) a = b;
+  }
+  return a;
+}
+
+extern "C" int srk_conv2d_backward_weight_grouped(const srk_conv_desc* d, int n, const float* const* x,
+                                                  const float* const* dy, const srk_bwd_mask* masks, float* const* dw,
+                                                  float* const* db, float beta, void* workspace, size_t workspace_bytes,
+                                                  void* stream) {
+  int rc = validate_desc(d, "conv2d_backward_weight_grouped");
+  if (rc) return rc;
+  SRK_REQUIRE(n >= 1 && x && dy && dw, "conv2d_backward_weight_grouped: empty group or null pointer array");
+  SRK_REQUIRE(beta == 0.f || beta == 1.f, "conv2d_backward_weight_grouped: beta must be 0 or 1");
+  for (int l = 0; l < n; ++l) {
+    SRK_REQUIRE(x[l] && dy[l] && dw[l], "conv2d_backward_weight_grouped: null tensor pointer in layer %d", l);
+    for (int k = 0; k < l; ++k)
+      SRK_REQUIRE(dw[k] != dw[l], "conv2d_backward_weight_grouped: layers %d and %d write the same dw (shared weights must "
+                  "go into separate calls)", k, l);
+  }
+  if (n >= 2 && wgrad_group_uses_bf(*d)) {
+    for (int l0 = 0; l0 < n; l0 += kMaxWgradGroup) {
+      const int m = n - l0 < kMaxWgradGroup ? n - l0 : kMaxWgradGroup;
+      rc = conv_wgrad_bf_grouped(*d, m, x + l0, dy + l0, masks ? masks + l0 : nullptr, dw + l0, db ? db + l0 : nullptr, beta,
+                                 workspace, workspace_bytes, (hipStream_t)stream);
+      if (rc) return rc;
+    }
+    return SRK_OK;
+  }
+  for (int l = 0; l < n; ++l) {  // geometry without a grouped kernel (or a single layer): the per-layer path, same results
+    rc = srk_conv2d_backward_weight(d, x[l], dy[l], (masks && masks[l].y) ? &masks[l] : nullptr, dw[l], db ? db[l] : nullptr,
+                                    beta, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+  }
+  return SRK_OK;
 }
 
 extern "C" int srk_conv2d_fused2_forward(const srk_conv_desc* d1, const srk_conv_desc* d2, const float* x,

@@ -55,6 +55,40 @@ struct WgBfParams {
   int dy_ps_r, dy_ps_C;  // dY handed over pixel-shuffled [N, YH*r, YW*r, Cout/r^2]: un-shuffled while staging
 };
 
+// Grouped launch: the weight gradients of up to WB_MAXGROUP convolutions that share ONE geometry (the 33 body convs
+// of EDSR, edsr.py:37-45; the 18 of VDSR, vdsr.py:17-24) in one launch.  Only the tensors differ per layer; their
+// pointers travel by value in the kernel arguments (no device-side table, so the call is hipGraph-capturable as is).
+// Block x = layer * G + g: layer `layer` has G split-K partial slabs, slab / bias-partial index = blockIdx.x.
+constexpr int WB_MAXGROUP = 40;
+struct WgLayer {
+  const float* x;
+  const float* dy;
+  const float* mask_y;
+  float mask_slope;
+  int pad_;
+};
+struct WgGroup {
+  WgLayer L[WB_MAXGROUP];
+};
+struct WgNoGroup {
+  int unused;
+};
+template <bool GRP>
+struct WgGroupArg {
+  typedef WgNoGroup type;
+};
+template <>
+struct WgGroupArg<true> {
+  typedef WgGroup type;
+};
+struct WgOut {
+  float* dw;
+  float* db;
+};
+struct WgGroupOut {
+  WgOut L[WB_MAXGROUP];
+};
+
 __device__ __forceinline__ f32x4 wb_mfma(const uint4& a, const uint4& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
                                                  0);
@@ -115,8 +149,9 @@ __device__ __forceinline__ f32x4 wb_load4(const float* __restrict__ src, const f
 // (global loads, masking, bf16 split, transposed stores) WHILE waves 0-3 run the K loop of tile t; one barrier per tile.
 // The per-tile kernel's two phases are about equally long and co-resident blocks run them in lockstep; here they
 // overlap by construction, and one block per CU halves the number of partial slabs.
-template <int CIT, int COW, int NTW, bool SPEC>
-__global__ __launch_bounds__(SPEC ? 768 : 256, SPEC ? 3 : 2) void k_wgrad_bf(WgBfParams P) {
+template <int CIT, int COW, int NTW, bool SPEC, bool GRP>
+__global__ __launch_bounds__(SPEC ? 768 : 256, SPEC ? 3 : 2) void k_wgrad_bf(WgBfParams P,
+                                                                             typename WgGroupArg<GRP>::type GR) {
   constexpr int CIB = CIT * 16, COB = COW * NTW * 16;
   constexpr int NTHR = SPEC ? 768 : 256;
   constexpr int NST = SPEC ? 512 : 256;  // staging threads (SPEC: 8 stager waves keep the staging rate of two 256-thread blocks)
@@ -134,6 +169,20 @@ __global__ __launch_bounds__(SPEC ? 768 : 256, SPEC ? 3 : 2) void k_wgrad_bf(WgB
   const int noct = P.TH * P.TWo;
   const bool want_bias = P.bias_partial != nullptr && blockIdx.y == 0;
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  // this block's layer (grouped launch) and its split-K index inside the layer; tensors of that layer
+  int bx = blockIdx.x;
+  const float* __restrict__ Lx = P.x;
+  const float* __restrict__ Ldy = P.dy;
+  const float* __restrict__ Lmask = P.mask_y;
+  float Lslope = P.mask_slope;
+  if constexpr (GRP) {
+    const int layer = (int)blockIdx.x / P.G;
+    bx = (int)blockIdx.x - layer * P.G;
+    Lx = GR.L[layer].x;
+    Ldy = GR.L[layer].dy;
+    Lmask = GR.L[layer].mask_y;
+    Lslope = GR.L[layer].mask_slope;
+  }
 
   for (int o = tid0; o < P.nks * 4; o += NTHR) {
     if (o < noct) {
@@ -183,7 +232,7 @@ __global__ __launch_bounds__(SPEC ? 768 : 256, SPEC ? 3 : 2) void k_wgrad_bf(WgB
       const int by0 = r0 - P.pad, bx0 = c0 - P.pad;
       const int q = tid % QN, ch = cib + q * 4;
       const int nch = P.Cin - ch;  // channels of this group that exist (<= 0: none)
-      const float* __restrict__ xb = P.x + (size_t)n * P.XH * P.XW * P.Cin;  // wave-uniform image base
+      const float* __restrict__ xb = Lx + (size_t)n * P.XH * P.XW * P.Cin;  // wave-uniform image base
       unsigned short* xq = xs + (size_t)(q * 4) * P.CS;
       // batches of WB_IT pixel pairs per thread: every global load of a batch is issued before the first conversion
       // (one exposed load latency per batch instead of one per pair)
@@ -240,8 +289,8 @@ __global__ __launch_bounds__(SPEC ? 768 : 256, SPEC ? 3 : 2) void k_wgrad_bf(WgB
         koff = (unsigned)ch;
       }
       const size_t img = (size_t)n * P.YH * srow;
-      const float* __restrict__ yb = P.dy + img;
-      const float* __restrict__ mb = P.mask_y ? P.mask_y + img : nullptr;
+      const float* __restrict__ yb = Ldy + img;
+      const float* __restrict__ mb = Lmask ? Lmask + img : nullptr;
       unsigned short* yq = ys + (size_t)(q * 4) * P.DS;
       for (int pp0 = tid / QN; pp0 < npairs; pp0 += PSTEP * WB_IT) {
         f32x4 p0[WB_IT], p1[WB_IT];
@@ -252,8 +301,8 @@ __global__ __launch_bounds__(SPEC ? 768 : 256, SPEC ? 3 : 2) void k_wgrad_bf(WgB
           const int iy = r0 + r, ix = c0 + c;
           const bool rowok = pp < npairs && iy < P.YH && nch > 0;
           const unsigned off = (unsigned)iy * srow + (unsigned)ix * scol + koff;
-          p0[k] = wb_load4(yb, mb, P.mask_slope, off, rowok && ix < P.YW, nch, P.vec_y);
-          p1[k] = wb_load4(yb, mb, P.mask_slope, off + scol, rowok && ix + 1 < P.YW, nch, P.vec_y);
+          p0[k] = wb_load4(yb, mb, Lslope, off, rowok && ix < P.YW, nch, P.vec_y);
+          p1[k] = wb_load4(yb, mb, Lslope, off + scol, rowok && ix + 1 < P.YW, nch, P.vec_y);
         }
 #pragma unroll
         for (int k = 0; k < WB_IT; ++k) {
@@ -329,20 +378,20 @@ __global__ __launch_bounds__(SPEC ? 768 : 256, SPEC ? 3 : 2) void k_wgrad_bf(WgB
   };
 
   if (!SPEC) {
-    for (int tile = blockIdx.x; tile < P.ntiles; tile += P.G) {
+    for (int tile = bx; tile < P.ntiles; tile += P.G) {
       __syncthreads();  // previous tile fully consumed (tables / zero octets visible on the first pass)
       stage(tile, 0);
       __syncthreads();
       kloop(0);
     }
   } else {
-    const int ntb = ((int)blockIdx.x < P.ntiles) ? (P.ntiles - (int)blockIdx.x + P.G - 1) / P.G : 0;
+    const int ntb = (bx < P.ntiles) ? (P.ntiles - bx + P.G - 1) / P.G : 0;
     __syncthreads();  // tables / zero octets visible
-    if (stager && ntb > 0) stage(blockIdx.x, 0);
+    if (stager && ntb > 0) stage(bx, 0);
     __syncthreads();
     for (int it = 0; it < ntb; ++it) {
       if (stager) {
-        if (it + 1 < ntb) stage(blockIdx.x + (it + 1) * P.G, (it + 1) & 1);
+        if (it + 1 < ntb) stage(bx + (it + 1) * P.G, (it + 1) & 1);
       } else {
         kloop(it & 1);
       }
@@ -480,13 +529,82 @@ template <int CIT, int COW, int NTW>
 static void wb_launch(const WgBfParams& P, dim3 grid, size_t lds, bool spec, hipStream_t s) {
   if (spec) {
     static LdsLimit lim2;
-    lim2.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, true>), 2 * lds);
-    hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, true>), grid, dim3(768), 2 * lds, s, P);
+    lim2.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, true, false>), 2 * lds);
+    hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, true, false>), grid, dim3(768), 2 * lds, s, P, WgNoGroup{0});
     return;
   }
   static LdsLimit lim;
-  lim.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, false>), lds);
-  hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, false>), grid, dim3(256), lds, s, P);
+  lim.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, false, false>), lds);
+  hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, false, false>), grid, dim3(256), lds, s, P, WgNoGroup{0});
+}
+
+template <int CIT, int COW, int NTW>
+static void wb_launch_grouped(const WgBfParams& P, const WgGroup& GR, dim3 grid, size_t lds, bool spec, hipStream_t s) {
+  if (spec) {
+    static LdsLimit lim2;
+    lim2.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, true, true>), 2 * lds);
+    hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, true, true>), grid, dim3(768), 2 * lds, s, P, GR);
+    return;
+  }
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, false, true>), lds);
+  hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, false, true>), grid, dim3(256), lds, s, P, GR);
+}
+
+// dw_l (torch layout [co][ci][kh][kw]) = beta*dw_l + sum_g ws[l][g][t][ci][co] and db_l likewise, for every layer of
+// a grouped launch (blockIdx.y = layer): the single-layer k_wgrad_reduce of conv_wgrad_mfma.hip with a layer axis.
+__global__ __launch_bounds__(256) void k_wgrad_reduce_grouped(const float* __restrict__ ws, WgGroupOut O, int G, int Cout,
+                                                              int Cin, int KH, int KW, float beta,
+                                                              const float* __restrict__ bias_partial) {
+  __shared__ float sm[4][64];
+  const int elems = KH * KW * Cin * Cout;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nwb = (elems + 63) / 64;
+  const int layer = blockIdx.y;
+  float* __restrict__ dw = O.L[layer].dw;
+  float* __restrict__ db = O.L[layer].db;
+  if ((int)blockIdx.x >= nwb) {
+    if (!db || !bias_partial) return;
+    const float* bp = bias_partial + (size_t)layer * G * Cout;
+    const int co = ((int)blockIdx.x - nwb) * 64 + lane;
+    float t0 = 0.f, t1 = 0.f;
+    if (co < Cout) {
+      int g = w;
+      for (; g + 4 < G; g += 8) {
+        t0 += bp[(size_t)g * Cout + co];
+        t1 += bp[(size_t)(g + 4) * Cout + co];
+      }
+      for (; g < G; g += 4) t0 += bp[(size_t)g * Cout + co];
+    }
+    sm[w][lane] = t0 + t1;
+    __syncthreads();
+    if (w == 0 && co < Cout) {
+      const float t = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+      db[co] = beta != 0.f ? beta * db[co] + t : t;
+    }
+    return;
+  }
+  const float* wl = ws + (size_t)layer * G * elems;
+  const int e = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
+  if (e < elems) {
+    int g = w;
+    for (; g + 4 < G; g += 8) {
+      s0 += wl[(size_t)g * elems + e];
+      s1 += wl[(size_t)(g + 4) * elems + e];
+    }
+    for (; g < G; g += 4) s0 += wl[(size_t)g * elems + e];
+  }
+  sm[w][lane] = s0 + s1;
+  __syncthreads();
+  if (w != 0 || e >= elems) return;
+  const float v = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+  const int co = e % Cout;
+  const int ci = (e / Cout) % Cin;
+  const int tap = e / (Cout * Cin);
+  const int kh = tap / KW, kw = tap - kh * KW;
+  const size_t o = (((size_t)co * Cin + ci) * KH + kh) * KW + kw;
+  dw[o] = beta != 0.f ? beta * dw[o] + v : v;
 }
 
 int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const srk_bwd_mask* mask, float* dw,
@@ -552,6 +670,114 @@ int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const
   if (rc) return rc;
   return conv_wgrad_reduce_launch((const float*)ws, dw, G, d.Cout, d.Cin, d.KH, d.KW, 0, beta, db ? bias_ws : nullptr,
                                   db, d.Cout, d.dy_ps_r > 1 ? d.dy_ps_r : 0, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grouped weight gradient: n layers of one geometry in ONE launch (+ one reduce launch).
+// Why: a strong-scaled data-parallel shard (EDSR x4, 16 patches per GPU) gives each layer's weight gradient only
+// 128 pixel tiles — one tile per block, a 73 KB partial slab written for 64 KB read, 26 us per layer for 3 us of matrix
+// work.  With the layer axis in the grid every block walks ~30-40 tiles of ONE layer (double-buffered by the
+// wave-specialised variant), writes one slab, and 33 layers cost two launches instead of 66.
+// ---------------------------------------------------------------------------------------------
+static int wb_group_G(const WbPlan& pl, int n, bool& spec) {
+  static const int spec_env = getenv("SRK_WGRAD_SPEC") ? atoi(getenv("SRK_WGRAD_SPEC")) : 1;
+  static const int g_env = getenv("SRK_WG_GROUP_G") ? atoi(getenv("SRK_WG_GROUP_G")) : 0;  // experiment: slabs per layer
+  const int per = n * pl.gy * pl.gz;  // (layer, channel-chunk) pairs
+  // one block per CU (wave-specialised, two LDS buffer sets) when every block gets >= 2 tiles; else two per CU
+  int g1 = kNumCU / per;
+  if (g1 < 1) g1 = 1;
+  spec = spec_env && 2 * pl.lds + 8 * 1024 <= 160 * 1024 && pl.ntiles >= 2 * g1;
+  int G = spec ? g1 : (2 * kNumCU) / per;
+  if (G < 1) G = 1;
+  if (g_env > 0) G = g_env;
+  if (G > pl.ntiles) G = pl.ntiles;
+  if (spec && pl.ntiles < 2 * G) spec = false;
+  return G;
+}
+
+size_t conv_wgrad_bf_grouped_ws(const srk_conv_desc& d, int n) {
+  WbPlan pl = wb_plan(d);
+  if (!pl.ok || n < 1) return 0;
+  bool spec;
+  // workspace for the largest G either variant may pick (2 blocks per CU)
+  int G = (2 * kNumCU) / (n * pl.gy * pl.gz);
+  const int G2 = wb_group_G(pl, n, spec);
+  if (G2 > G) G = G2;
+  if (G < 1) G = 1;
+  if (G > pl.ntiles) G = pl.ntiles;
+  return (size_t)n * G * ((size_t)d.KH * d.KW * d.Cin * d.Cout + d.Cout) * sizeof(float);
+}
+
+int conv_wgrad_bf_grouped(const srk_conv_desc& d, int n, const float* const* xs, const float* const* dys,
+                          const srk_bwd_mask* masks, float* const* dws, float* const* dbs, float beta, void* ws,
+                          size_t ws_bytes, hipStream_t s) {
+  WbPlan pl = wb_plan(d);
+  if (!pl.ok || n < 1 || n > WB_MAXGROUP || d.dy_ps_r > 1) {
+    set_error("conv_wgrad_bf_grouped: shape / group size not covered");
+    return SRK_ERR_UNSUPPORTED;
+  }
+  bool spec = false;
+  const int G = wb_group_G(pl, n, spec);
+  const size_t elems = (size_t)d.KH * d.KW * d.Cin * d.Cout;
+  const size_t slab_bytes = (size_t)n * G * elems * sizeof(float);
+  const size_t need = slab_bytes + (size_t)n * G * d.Cout * sizeof(float);
+  if (!ws || ws_bytes < need) {
+    set_error("conv_wgrad_bf_grouped: workspace %zu < %zu", ws_bytes, need);
+    return SRK_ERR_WORKSPACE;
+  }
+  const bool has_bias = dbs && dbs[0];
+  WgGroup GR{};
+  WgGroupOut GO{};
+  bool vec_x = d.Cin % 4 == 0, vec_y = d.Cout % 4 == 0;
+  for (int l = 0; l < n; ++l) {
+    if (!xs[l] || !dys[l] || !dws[l] || (has_bias != (dbs && dbs[l] != nullptr))) {
+      set_error("conv_wgrad_bf_grouped: null tensor or mixed bias / bias-free layers in one group (layer %d)", l);
+      return SRK_ERR_BAD_ARG;
+    }
+    GR.L[l].x = xs[l];
+    GR.L[l].dy = dys[l];
+    GR.L[l].mask_y = masks ? masks[l].y : nullptr;
+    GR.L[l].mask_slope = masks ? masks[l].slope : 0.f;
+    GO.L[l].dw = dws[l];
+    GO.L[l].db = has_bias ? dbs[l] : nullptr;
+    vec_x = vec_x && ((uintptr_t)xs[l] % 16 == 0);
+    vec_y = vec_y && ((uintptr_t)dys[l] % 16 == 0) && (!GR.L[l].mask_y || (uintptr_t)GR.L[l].mask_y % 16 == 0);
+  }
+  WgBfParams P{};
+  P.ws = (float*)ws;
+  float* bias_ws = reinterpret_cast<float*>(static_cast<char*>(ws) + slab_bytes);
+  P.bias_partial = has_bias ? bias_ws : nullptr;
+  P.N = d.N; P.Cin = d.Cin; P.Cout = d.Cout;
+  P.XH = d.H; P.XW = d.W; P.YH = d.OH; P.YW = d.OW;
+  P.KH = d.KH; P.KW = d.KW; P.pad = d.pad;
+  P.TH = pl.TH; P.TW = pl.TW; P.TWo = pl.TWo; P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x;
+  P.HH = pl.HH; P.HWp = pl.HWp; P.CS = pl.CS; P.DS = pl.DS;
+  P.ntiles = pl.ntiles; P.G = G; P.nks = pl.nks;
+  P.vec_x = vec_x; P.vec_y = vec_y;
+  P.dy_ps_r = 0; P.dy_ps_C = d.Cout;
+  {
+    static int dbg = -1;
+    if (dbg < 0) {
+      const char* e = getenv("SRK_DBG");
+      dbg = e ? atoi(e) : 0;
+    }
+    P.dbg = dbg;
+    if (dbg & 32)
+      fprintf(stderr, "[srk] k_wgrad_bf grouped cfg %d%s: %d layers x %d slabs, tile %d x %d, %d tiles per layer, grid %d x %d x %d\n",
+              pl.cfg, spec ? " (wave-specialised)" : "", n, G, pl.TH, pl.TW, pl.ntiles, n * G, pl.gy, pl.gz);
+  }
+  dim3 grid(n * G, pl.gy, pl.gz);
+  switch (pl.cfg) {
+    case 0: wb_launch_grouped<2, 2, 2>(P, GR, grid, pl.lds, spec, s); break;
+    case 1: wb_launch_grouped<4, 1, 2>(P, GR, grid, pl.lds, spec, s); break;
+    default: wb_launch_grouped<4, 1, 1>(P, GR, grid, pl.lds, spec, s); break;
+  }
+  int rc = check_launch("conv_wgrad_bf_grouped");
+  if (rc) return rc;
+  const int nwb = cdiv(elems, 64), bias_blocks = has_bias ? cdiv(d.Cout, 64) : 0;
+  hipLaunchKernelGGL(k_wgrad_reduce_grouped, dim3(nwb + bias_blocks, n), dim3(256), 0, s, (const float*)ws, GO, G, d.Cout,
+                     d.Cin, d.KH, d.KW, beta, has_bias ? (const float*)bias_ws : nullptr);
+  return check_launch("conv_wgrad_reduce_grouped");
 }
 
 }  // namespace srk

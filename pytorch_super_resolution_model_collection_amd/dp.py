@@ -56,9 +56,11 @@ def shard(tensor, rank, world):
 class DataParallel(object):
     """Gradient exchange for a FlatParams-like object (anything with flat `.data` and `.grad`)."""
 
-    def __init__(self, flat, group=None, bucket_bytes=32 << 20):
+    def __init__(self, flat, group=None, bucket_bytes=32 << 20, min_bucket_bytes=256 << 10, trunk_chunk_layers=11):
         self.flat = flat
         self.group = group
+        self.min_bucket_elems = max(1, int(min_bucket_bytes) // 4)   # smaller final runs wait for a neighbour
+        self.trunk_chunk_layers = int(trunk_chunk_layers)             # layers per grouped weight-gradient launch under DP
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.bucket_elems = max(1, int(bucket_bytes) // 4)
@@ -80,18 +82,94 @@ class DataParallel(object):
         n = self.flat.grad.numel()
         return [(lo, min(lo + self.bucket_elems, n)) for lo in range(0, n, self.bucket_elems)]
 
-    def allreduce_grads(self):
-        """SUM all-reduce of the flat gradient buffer, in a few multi-MB buckets issued
-        back-to-back (async) so RCCL pipelines them over the xGMI links."""
-        from . import ops
-        ops.join_side_streams()  # weight gradients forked onto the side stream must have landed
-        if self.world == 1:
-            return
+    # -- overlapped exchange ------------------------------------------------------------------------------------
+    # After loss.backward() the data-gradient chain is done and the conv weight gradients are still pending
+    # (ops.DEFER_WGRAD) as a short list of grouped launches in backward order: reconstruction conv, upsamplers, the
+    # residual trunk in chunks, input conv.  exchange() launches them one group at a time and, right after each
+    # group, hands the part of the flat gradient buffer that just became final to RCCL (async: ProcessGroupNCCL runs
+    # it on its own stream behind an event), so a bucket travels over xGMI while the next group computes.  xGMI is
+    # point-to-point, so a few multi-hundred-KB..MB messages (<= 8 per EDSR step) beat one message per tensor; the
+    # trunk is cut into `trunk_chunks` pieces so that only the last ~2 MB bucket is exposed.
+    def plan(self, groups, min_elems=None):
+        """For launch groups (ops.pending_wgrad_groups order) -> per group the list of [lo, hi) ranges of the flat
+        gradient buffer to send after it.  A parameter is final after the last group that writes it (parameters no
+        pending record writes are final already); ranges are maximal runs of final, unsent parameters, held back while
+        shorter than `min_elems` unless nothing will follow."""
+        flat = self.flat
+        if min_elems is None:
+            min_elems = self.min_bucket_elems
+        base, total = flat.grad.data_ptr(), flat.grad.numel()
+        spans = []   # (lo, hi, ready_after_group) per parameter, in buffer order
+        ready = {}
+        for k, recs in enumerate(groups):
+            for r in recs:
+                for t in (r[6], r[7]):
+                    if t is None:
+                        continue
+                    off = (t.data_ptr() - base) // 4
+                    if 0 <= off < total and t.device == flat.grad.device:
+                        ready[off] = k
+        offs = list(flat.offsets) + [total]
+        for i in range(len(flat.offsets)):
+            spans.append((offs[i], offs[i + 1], ready.get(offs[i], -1)))
+        sent = [False] * len(spans)
+        out = []
+        for k in range(len(groups)):
+            last = k == len(groups) - 1
+            ranges, i = [], 0
+            while i < len(spans):
+                if sent[i] or spans[i][2] > k:
+                    i += 1
+                    continue
+                j = i
+                while j < len(spans) and not sent[j] and spans[j][2] <= k:
+                    j += 1
+                lo, hi = spans[i][0], spans[j - 1][1]
+                if last or hi - lo >= min_elems:
+                    ranges.append((lo, hi))
+                    for q in range(i, j):
+                        sent[q] = True
+                i = j
+            out.append(ranges)
+        if not groups:
+            out.append([(0, total)])
+        return out
+
+    def send(self, ranges, works):
         g = self.flat.grad
-        works = [dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                 for lo, hi in self.buckets()]
+        for lo, hi in ranges:
+            for b0 in range(lo, hi, self.bucket_elems):
+                works.append(dist.all_reduce(g[b0:min(b0 + self.bucket_elems, hi)], op=dist.ReduceOp.SUM, group=self.group,
+                                             async_op=True))
+
+    def exchange(self):
+        """Launch the pending weight gradients group by group and all-reduce (SUM; the 1/world seed of the backward
+        makes it the mean) every part of the flat gradient buffer as soon as it is final.  Returns when the current
+        stream is ordered after the last bucket."""
+        from . import ops
+        if self.world == 1:
+            ops.join_side_streams()
+            return
+        groups = ops.pending_wgrad_groups(self.trunk_chunk_layers)
+        if not groups:      # nothing deferred (side-stream mode, or a model without conv layers)
+            ops.join_side_streams()
+            works = []
+            self.send([(0, self.flat.grad.numel())], works)
+            for w in works:
+                w.wait()
+            return
+        sends = self.plan(groups)
+        works = []
+        ops.drop_pending_wgrads()
+        for recs, ranges in zip(groups, sends):
+            ops.launch_wgrad_group(recs)
+            self.send(ranges, works)
         for w in works:
             w.wait()
+
+    def allreduce_grads(self):
+        """SUM all-reduce of the flat gradient buffer (see exchange: overlapped with the pending weight gradients)."""
+        self.exchange()
 
     def allreduce_scalar(self, t):
         """Mean of a logging scalar (the loss) over ranks — off the critical path."""

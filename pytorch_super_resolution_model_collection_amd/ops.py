@@ -225,12 +225,106 @@ def _side(device):
 
 
 def join_side_streams():
-    """Make the current stream wait for every weight gradient forked onto the side stream.  Runs automatically at
-    the end of every backward pass that forked (autograd engine callback), so `loss.backward(); p.grad...` is safe."""
+    """Every weight gradient of the backward passes so far is enqueued on / ordered before the current stream: launches
+    the deferred grouped weight gradients that are still pending (flush_wgrads) and makes the current stream wait for
+    any forked onto the side stream.  Runs automatically at the end of every backward pass (autograd engine callback),
+    so `loss.backward(); p.grad...` is safe; optimizers, zero_grad, clipping and the gradient exchange call it too."""
+    if _PENDING:
+        flush_wgrads()
     for idx, ent in _SIDE.items():
         if ent[1]:
             torch.cuda.current_stream(idx).wait_stream(ent[0])
             ent[1] = []
+
+
+# ------------------------------------------------------------------------------------------------
+# Deferred, grouped weight gradients
+# ------------------------------------------------------------------------------------------------
+# The data-gradient chain (layer L's dx feeds layer L-1) is the critical path of a backward pass; a layer's WEIGHT
+# gradient feeds nothing until the optimizer / the gradient exchange.  In flat-buffer mode (optim.FlatParams: kernels
+# accumulate straight into the flat gradient buffer, autograd never sees dw) the conv backward therefore only RECORDS
+# (x, dy, mask) and the weight gradients of a whole backward pass are launched afterwards, grouped by geometry:
+# srk_conv2d_backward_weight_grouped runs e.g. the 33 body convs of EDSR as ONE launch + one reduce launch in which every
+# block walks ~40 tiles of one layer, instead of 66 launches of one-tile blocks that each write a 73 KB partial slab
+# (strong-scaled shard of 16 patches: 0.89 ms -> 0.1x of the step).  The flush happens at the end of the backward pass
+# (autograd engine callback) — `loss.backward(); p.grad` keeps working — or, under data parallelism, group by group
+# from dp.DataParallel.exchange(), which sends each group's bucket off while the next group computes.
+DEFER_WGRAD = os.environ.get("SRK_DEFER_WGRAD", "1") != "0"
+WGRAD_GROUP_MAX = int(os.environ.get("SRK_WGRAD_GROUP_MAX", "0"))   # > 0: split geometry groups into chunks of this many layers
+_PENDING = []                      # [(key, desc, x, dy, y_mask, slope, wacc, bacc)] in backward order
+_DEFER = {"queued": False, "manual": 0}
+
+
+class manual_wgrad_flush(object):
+    """Context: the end-of-backward callback leaves the recorded weight gradients pending; the caller flushes them
+    (flush_wgrads) — used by the trainers to interleave the grouped launches with the gradient exchange."""
+
+    def __enter__(self):
+        _DEFER["manual"] += 1
+
+    def __exit__(self, *a):
+        _DEFER["manual"] -= 1
+
+
+def _auto_flush():
+    _DEFER["queued"] = False
+    if not _DEFER["manual"]:
+        flush_wgrads()
+
+
+def pending_wgrad_groups(max_layers=None):
+    """The recorded weight gradients as launch groups [[record, ...], ...]: same geometry (and bias / no bias), backward
+    order, no two records of a group writing the same dw (shared weights), at most `max_layers` layers per group."""
+    cap = max_layers or WGRAD_GROUP_MAX or 0
+    groups, open_by_key = [], {}
+    for rec in _PENDING:
+        key, wptr = rec[0], rec[6].data_ptr()
+        g = open_by_key.get(key)
+        if g is None or wptr in g[1] or (cap and len(g[0]) >= cap):
+            g = ([], set())
+            groups.append(g)
+            open_by_key[key] = g
+        g[0].append(rec)
+        g[1].add(wptr)
+    return [g[0] for g in groups]
+
+
+def launch_wgrad_group(recs):
+    """One srk_conv2d_backward_weight_grouped call for records of one geometry (beta = 1: accumulate into the flat
+    gradient views)."""
+    lib = _lib.load()
+    n = len(recs)
+    d = recs[0][1]
+    vp = ctypes.c_void_p
+    xs = (vp * n)(*[r[2].data_ptr() for r in recs])
+    dys = (vp * n)(*[r[3].data_ptr() for r in recs])
+    masks = (BwdMask * n)(*[BwdMask(None if r[4] is None else r[4].data_ptr(), r[5]) for r in recs])
+    dws = (vp * n)(*[r[6].data_ptr() for r in recs])
+    has_bias = recs[0][7] is not None
+    dbs = (vp * n)(*[r[7].data_ptr() for r in recs]) if has_bias else None
+    dev = recs[0][3].device
+    ws_bytes = int(lib.srk_conv2d_backward_weight_grouped_workspace_bytes(ctypes.byref(d), n))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    check(lib.srk_conv2d_backward_weight_grouped(ctypes.byref(d), n, xs, dys, masks, dws, dbs, 1.0, ptr(ws), ws.numel(),
+                                                 stream_ptr()), "srk_conv2d_backward_weight_grouped")
+
+
+def flush_wgrads(on_group=None, max_layers=None):
+    """Launch every recorded weight gradient (grouped by geometry).  `on_group(records)` runs after each group's
+    launches — dp.DataParallel uses it to start that group's gradient bucket on its way."""
+    if not _PENDING:
+        return 0
+    groups = pending_wgrad_groups(max_layers)
+    del _PENDING[:]
+    for recs in groups:
+        launch_wgrad_group(recs)
+        if on_group is not None:
+            on_group(recs)
+    return len(groups)
+
+
+def drop_pending_wgrads():
+    del _PENDING[:]
 
 
 FUSE_SKIP_GRAD = os.environ.get("SRK_FUSE_SKIP_GRAD", "1") != "0"  # 0: residual blocks sum their gradient fan-in with srk_axpby
@@ -315,8 +409,17 @@ class _Conv2d(torch.autograd.Function):
         if need_w and flat_mode:
             # flat-buffer mode: accumulate straight into the (pre-zeroed) gradient views — on the side stream, forked
             # here (after dy / x are ready, before the data gradient is launched) so the two kernels overlap
-            ws_bytes = lib.srk_conv2d_backward_weight_workspace_bytes(ctypes.byref(d))
-            if WGRAD_SIDE_STREAM:
+            ws_bytes = 0 if (DEFER_WGRAD and not WGRAD_SIDE_STREAM) else \
+                lib.srk_conv2d_backward_weight_workspace_bytes(ctypes.byref(d))
+            if DEFER_WGRAD and not WGRAD_SIDE_STREAM:
+                key = (d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout, d.KH, d.KW, d.stride, d.pad, d.transposed, d.out_pad,
+                       d.algo, d.dy_ps_r, bacc is not None, str(dy.device))
+                _PENDING.append((key, d, x, dyc, y if mask is not None else None,
+                                 cfg.slope if cfg.act == ACT_LRELU else 0.0, wacc, bacc))
+                if not _DEFER["queued"]:   # first record of this backward pass: flush when the engine finishes it
+                    _DEFER["queued"] = True
+                    torch.autograd.Variable._execution_engine.queue_callback(_auto_flush)
+            elif WGRAD_SIDE_STREAM:
                 side, keep = _side(dy.device)
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):

@@ -15,11 +15,15 @@ from .optim import FlatParams, make_optimizer
 
 
 def _backward(loss, dp):
+    """loss.backward() of the reference (edsr.py:154 ...).  Single GPU: the deferred weight gradients are launched
+    (grouped) when the autograd engine finishes the pass.  Data parallel: they stay pending so that dp.exchange() can
+    interleave the grouped launches with the gradient buckets; the backward is seeded with 1/world."""
     if dp is not None and dp.world > 1:
-        loss.backward(dp.loss_seed)
+        with ops.manual_wgrad_flush():
+            loss.backward(dp.loss_seed)
     else:
         loss.backward()
-    ops.join_side_streams()  # weight gradients run on a second stream (ops.WGRAD_SIDE_STREAM)
+        ops.join_side_streams()  # (also flushes weight gradients recorded outside an engine callback)
 
 
 def mse_step(model, opt, dp=None, clip=None):
@@ -58,7 +62,11 @@ def lapsrn_step(model, opt, dp=None):
         l1 = ops.charbonnier_loss(hr2, target2x)
         l2 = ops.charbonnier_loss(hr4, target4x)
         seed = dp.loss_seed if (dp is not None and dp.world > 1) else None
-        torch.autograd.backward([l1, l2], [seed, seed] if seed is not None else None)
+        if seed is not None:
+            with ops.manual_wgrad_flush():
+                torch.autograd.backward([l1, l2], [seed, seed])
+        else:
+            torch.autograd.backward([l1, l2])
         if dp is not None:
             dp.allreduce_grads()
         opt.step()
@@ -103,6 +111,105 @@ def srgan_step(G, D, g_opt, d_opt, g_dp=None, d_dp=None, feature_extractor=None)
     return step
 
 
+def srgan_segments(G, D, g_opt, d_opt, g_dp=None, d_dp=None):
+    """The adversarial step of `srgan_step` cut at its two gradient exchanges, for GraphedSegments:
+    [(D forward/backward, d_dp), (D update + G forward/backward, g_dp), (G update, None)]."""
+    out = {}
+
+    def seg_d(lr_img, hr_img):
+        b = lr_img.shape[0]
+        real = torch.ones(b, 1, device=lr_img.device)
+        fake = torch.zeros(b, 1, device=lr_img.device)
+        d_opt.zero_grad()
+        out["d"] = ops.bce_loss(D(hr_img), real) + ops.bce_loss(D(G(lr_img)), fake)
+        _backward(out["d"], d_dp)
+        return out["d"]
+
+    def seg_g(lr_img, hr_img):
+        real = torch.ones(lr_img.shape[0], 1, device=lr_img.device)
+        d_opt.step()
+        g_opt.zero_grad()
+        recon = G(lr_img)
+        out["g"] = ops.mse_loss(recon, hr_img) + 1e-3 * ops.bce_loss(D(recon), real)
+        _backward(out["g"], g_dp)
+        return out["g"]
+
+    def seg_u(lr_img, hr_img):
+        g_opt.step()
+        return out["d"], out["g"]
+
+    return [(seg_d, d_dp), (seg_g, g_dp), (seg_u, None)]
+
+
+class GraphedSegments(object):
+    """A data-parallel train step as hipGraphs split at the gradient exchanges.
+
+    `segments` = [(fn(*inputs), dp or None), ...]: every fn is captured as one graph; a segment with a DataParallel
+    ends in a backward pass whose weight gradients were left pending (ops.manual_wgrad_flush): each pending launch
+    group becomes a small graph of its own, and at replay the groups run one after the other with the RCCL all-reduce
+    of the bucket each one completes issued (eagerly, async) right behind it — the bucket travels while the next
+    group computes.  Call with new batches (copied into the static buffers); returns what the last fn returned."""
+
+    def __init__(self, segments, example_inputs, warmup=2, eager_step=None):
+        self.static = [torch.empty_like(t).copy_(t) for t in example_inputs]
+        self.segments = segments
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.plan, pool = [], None
+        for fn, dp in segments:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                self.out = fn(*self.static)
+            pool = g.pool()
+            wgraphs, sends, keep = [], [], None
+            if dp is not None and dp.world > 1:
+                keep = ops.pending_wgrad_groups(dp.trunk_chunk_layers)   # holds x / dy / mask tensors of graph `g` alive
+                sends = dp.plan(keep)
+                ops.drop_pending_wgrads()
+                for recs in keep:
+                    wg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(wg, pool=pool):
+                        ops.launch_wgrad_group(recs)
+                    wgraphs.append(wg)
+            else:
+                ops.join_side_streams()
+            self.plan.append((g, dp, wgraphs, sends, keep))
+
+    def _eager(self):
+        out = None
+        for fn, dp in self.segments:
+            out = fn(*self.static)
+            if dp is not None:
+                dp.exchange()
+        return out
+
+    def __call__(self, *batch):
+        for s, b in zip(self.static, batch):
+            if b is not s:
+                s.copy_(b, non_blocking=True)
+        for g, dp, wgraphs, sends, _ in self.plan:
+            g.replay()
+            if dp is not None and dp.world > 1:
+                works = []
+                if not wgraphs:
+                    dp.send(sends[0] if sends else [(0, dp.flat.grad.numel())], works)
+                for wg, ranges in zip(wgraphs, sends):
+                    wg.replay()
+                    dp.send(ranges, works)
+                for w in works:
+                    w.wait()
+        bump_weight_epoch()
+        for _, dp, _, _, _ in self.plan:
+            if dp is not None and hasattr(dp.flat, "mark_changed"):
+                dp.flat.mark_changed()
+        return self.out
+
+
 def build(kind, model, lr, dp_group=None, use_dp=False):
     """(flat, optimizer, dp, step) for one of 'srcnn' | 'fsrcnn' | 'vdsr' | 'edsr' | 'lapsrn' | 'espcn'."""
     from .dp import DataParallel
@@ -125,34 +232,42 @@ def build(kind, model, lr, dp_group=None, use_dp=False):
 class GraphedStep(object):
     """hipGraph capture of a train step with static input buffers.
 
-    The step is split at the gradient all-reduce: graph A = zero_grad + forward + loss + backward,
-    then the (eager) RCCL all-reduce, then graph B = [clip] + optimizer.  Without data parallelism
-    everything is one graph.  Call with new batches; they are copied into the static buffers.
+    Single GPU: one graph = zero_grad + filter packing + forward + loss + backward (data-gradient chain, then the
+    grouped weight gradients) + [clip] + optimizer.  Data parallel: GraphedSegments — graph A (through the data-gradient
+    chain), one small graph per weight-gradient group with its gradient bucket's RCCL all-reduce issued behind it, then
+    graph B = [clip] + optimizer.  Call with new batches; they are copied into the static buffers.
     """
 
     def __init__(self, model, opt, loss_fn, example_inputs, dp=None, clip=None, warmup=3):
         self.model, self.opt, self.dp, self.clip = model, opt, dp, clip
-        self.static = [torch.empty_like(t).copy_(t) for t in example_inputs]
         self.loss_fn = loss_fn
+        self.seg = None
+        if dp is not None and dp.world > 1:
+            self.seg = GraphedSegments([(self._fwd_bwd_args, dp), (self._update_args, None)], example_inputs, warmup=warmup)
+            self.static = self.seg.static
+            return
+        self.static = [torch.empty_like(t).copy_(t) for t in example_inputs]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self._fwd_bwd()
-                self._exchange()
                 self._update()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a):
             self.loss = self._fwd_bwd()
-            if dp is None or dp.world == 1:
-                self._update()
-        self.graph_b = None
-        if dp is not None and dp.world > 1:
-            self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b):
-                self._update()
+            self._update()
+
+    def _fwd_bwd_args(self, *static):
+        self.static = list(static)
+        self.loss = self._fwd_bwd()
+        return self.loss
+
+    def _update_args(self, *static):
+        self._update()
+        return self.loss
 
     def _fwd_bwd(self):
         self.opt.zero_grad()
@@ -160,23 +275,18 @@ class GraphedStep(object):
         _backward(loss, self.dp)
         return loss
 
-    def _exchange(self):
-        if self.dp is not None:
-            self.dp.allreduce_grads()
-
     def _update(self):
         if self.clip is not None:
             self.opt.clip_grad_norm(self.clip)
         self.opt.step()
 
     def __call__(self, *batch):
+        if self.seg is not None:
+            return self.seg(*batch)
         for s, b in zip(self.static, batch):
             if b is not s:
                 s.copy_(b, non_blocking=True)
         self.graph_a.replay()
-        if self.graph_b is not None:
-            self._exchange()
-            self.graph_b.replay()
         # the replayed optimizer kernel changed the weights without running optim.step()'s host bookkeeping: packed
         # filters cached by no-grad forwards (layers._PackCache) and the PackPlan must not be reused
         self.opt.flat.mark_changed()

@@ -14,9 +14,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), SRK_DIST_BACKEND="gloo", SRK_SINGLE_GPU="1")
+                      LOCAL_RANK=str(rank), SRK_DIST_BACKEND=backend)
+    if backend == "gloo":
+        os.environ["SRK_SINGLE_GPU"] = "1"   # both ranks share device 0
     sys.path.insert(0, ROOT)
     import pytorch_super_resolution_model_collection_amd as pkg
     from oracle import fill
@@ -41,6 +43,17 @@ def _worker(rank, world, port, out):
     lo, hi = pkg.dp.shard_range(gb, r, w)
     loss = step(x[lo:hi].to(dev), t[lo:hi].to(dev))
     g_dp, p_dp = flat.grad.clone().cpu(), flat.data.clone().cpu()
+    # the same shard gradient exchanged as ONE all-reduce after all weight gradients (no overlap, no buckets): the
+    # overlapped, bucketed exchange must give bit-identical sums
+    net_s, flat_s, opt_s = make()
+    opt_s.zero_grad()
+    with pkg.ops.manual_wgrad_flush():
+        pkg.ops.l1_loss(net_s(x[lo:hi].to(dev)), t[lo:hi].to(dev)).backward(dp.loss_seed)
+    n_groups = len(pkg.ops.pending_wgrad_groups(dp.trunk_chunk_layers))
+    sends = dp.__class__(flat_s, trunk_chunk_layers=dp.trunk_chunk_layers).plan(pkg.ops.pending_wgrad_groups(dp.trunk_chunk_layers))
+    pkg.ops.flush_wgrads()
+    torch.distributed.all_reduce(flat_s.grad)
+    g_single = flat_s.grad.clone().cpu()
     # graph-captured DP step from the same start (second model)
     net2, flat2, opt2 = make()
     dp2 = pkg.dp.DataParallel(flat2)
@@ -51,7 +64,44 @@ def _worker(rank, world, port, out):
     opt2.exp_avg.zero_(); opt2.exp_avg_sq.zero_(); opt2.step_dev.zero_()
     gstep(x[lo:hi].to(dev), t[lo:hi].to(dev))
     p_graph = flat2.data.clone().cpu()
-    res = {"g": g_dp, "p": p_dp, "p_graph": p_graph, "loss": float(dp.allreduce_scalar(loss.detach().clone()))}
+    # SRGAN: eager DP step vs the step as graphs split at the two exchanges (trainers.GraphedSegments)
+    def make_gan():
+        G, D = pkg.SRGANGenerator(3, 16, 2), pkg.SRGANDiscriminator(3, 8, 32)
+        fill.fill_module(G, 5, 0.7)
+        fill.fill_module(D, 6, 1.0)
+        G.to(dev).train()
+        D.to(dev).train()
+        gf, df = pkg.optim.FlatParams(G), pkg.optim.FlatParams(D)
+        return G, D, pkg.optim.make_optimizer("srgan_g", gf, 1e-3), pkg.optim.make_optimizer("srgan_d", df, 1e-2), \
+            pkg.dp.DataParallel(gf), pkg.dp.DataParallel(df)
+
+    lr_img, hr_img = fill.rand((4, 3, 8, 8), 31)[2 * r:2 * r + 2].to(dev), fill.rand((4, 3, 32, 32), 32)[2 * r:2 * r + 2].to(dev)
+    G, D, g_opt, d_opt, g_dp, d_dp = make_gan()
+    sstep = pkg.trainers.srgan_step(G, D, g_opt, d_opt, g_dp, d_dp)
+    gan_losses = [[float(v) for v in sstep(lr_img, hr_img)] for _ in range(2)]
+    gan_p = torch.cat([g_opt.flat.data, d_opt.flat.data]).cpu()
+
+    def state(o):
+        return [o.flat.data] + [getattr(o, k) for k in ("buf", "exp_avg", "exp_avg_sq", "step_dev") if getattr(o, k, None) is not None]
+
+    G2, D2, g_opt2, d_opt2, g_dp2, d_dp2 = make_gan()
+    snap = [[t_.clone() for t_ in state(o)] for o in (g_opt2, d_opt2)]
+    bn = [(m, m.running_mean.clone(), m.running_var.clone()) for net_ in (G2, D2) for m in net_.modules()
+          if isinstance(m, torch.nn.BatchNorm2d)]
+    seg = pkg.trainers.GraphedSegments(pkg.trainers.srgan_segments(G2, D2, g_opt2, d_opt2, g_dp2, d_dp2), (lr_img, hr_img),
+                                       warmup=1)
+    for o, saved in zip((g_opt2, d_opt2), snap):
+        for t_, t0 in zip(state(o), saved):
+            t_.copy_(t0)
+    for m, rm, rv in bn:
+        m.running_mean.copy_(rm)
+        m.running_var.copy_(rv)
+    gan_losses_graph = [[float(v) for v in seg(lr_img, hr_img)] for _ in range(2)]
+    gan_p_graph = torch.cat([g_opt2.flat.data, d_opt2.flat.data]).cpu()
+    res = {"g": g_dp, "p": p_dp, "p_graph": p_graph, "loss": float(dp.allreduce_scalar(loss.detach().clone())),
+           "g_single": g_single, "n_groups": n_groups, "n_sends": sum(len(r_) for r_ in sends),
+           "covered": sorted(rg for r_ in sends for rg in r_), "numel": flat_s.grad.numel(),
+           "gan_losses": gan_losses, "gan_losses_graph": gan_losses_graph, "gan_p": gan_p, "gan_p_graph": gan_p_graph}
     if r == 0:  # single-process reference on the full batch
         net1, flat1, opt1 = make()
         step1 = pkg.trainers.l1_step(net1, opt1, None)
@@ -61,14 +111,40 @@ def _worker(rank, world, port, out):
     torch.distributed.destroy_process_group()
 
 
-def test_dp_two_ranks_match_single_process(gpu, tmp_path):
-    world, port = 2, 29700 + os.getpid() % 200
-    out = str(tmp_path / "dp%d.pt")
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
-    r0, r1 = torch.load(out % 0), torch.load(out % 1)
+def _check(r0, r1):
     assert torch.equal(r0["g"], r1["g"]) and torch.equal(r0["p"], r1["p"])          # replicas stay identical
     scale = r0["g1"].abs().max()
     assert (r0["g"] - r0["g1"]).abs().max() <= 2e-5 * scale                          # mean of shard grads == full-batch grad
     assert (r0["p"] - r0["p1"]).abs().max() <= 1e-5 * r0["p1"].abs().max() + 2e-6   # same Adam step
     assert abs(r0["loss"] - r0["loss1"]) <= 1e-6 * abs(r0["loss1"]) + 1e-7
     assert (r0["p_graph"] - r0["p"]).abs().max() <= 1e-6 * r0["p"].abs().max() + 2e-6  # hipGraph DP step == eager DP step
+    # overlapped + bucketed exchange == one all-reduce after everything, bit for bit; the buckets tile the buffer
+    assert torch.equal(r0["g"], r0["g_single"]) and torch.equal(r1["g"], r1["g_single"])
+    assert r0["n_groups"] >= 4 and r0["n_sends"] >= 2
+    pos = 0
+    for lo, hi in r0["covered"]:
+        assert lo == pos and hi > lo
+        pos = hi
+    assert pos == r0["numel"]
+    # SRGAN under DP: graphs split at the exchanges == eager, replicas identical
+    assert torch.equal(r0["gan_p"], r1["gan_p"]) and torch.equal(r0["gan_p_graph"], r1["gan_p_graph"])
+    for a, b in zip(sum(r0["gan_losses"], []), sum(r0["gan_losses_graph"], [])):
+        assert abs(a - b) <= 1e-4 * abs(a) + 1e-7
+    assert (r0["gan_p_graph"] - r0["gan_p"]).abs().max() <= 1e-4 * r0["gan_p"].abs().max()
+
+
+def test_dp_two_ranks_match_single_process(gpu, tmp_path):
+    world, port = 2, 29700 + os.getpid() % 200
+    out = str(tmp_path / "dp%d.pt")
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    _check(torch.load(out % 0), torch.load(out % 1))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (>= 2 visible devices)")
+def test_dp_two_ranks_rccl(gpu, tmp_path):
+    """The same equivalences over RCCL (backend "nccl", one process per GPU, device_id binding, async bucket
+    all-reduces behind the grouped weight-gradient launches, graphs split at the exchange)."""
+    world, port = 2, 29900 + os.getpid() % 90
+    out = str(tmp_path / "rccl%d.pt")
+    mp.spawn(_worker, args=(world, port, out, "nccl"), nprocs=world, join=True)
+    _check(torch.load(out % 0), torch.load(out % 1))

@@ -119,6 +119,33 @@ def test_c4_edsr_full_size_step_and_shard_algebra(gpu):
     assert rel_err(acc, full) < 2e-4
 
 
+def test_c4_shard_grouped_weight_gradients(gpu):
+    """The strong-scaled shard of c4 (16 patches per GPU): one EDSR step with the deferred, grouped weight gradients
+    (33 body layers in one launch) against the oracle at the contract tolerance, and against the same step with one
+    weight-gradient launch per layer (ops.DEFER_WGRAD = False) to summation-order accuracy."""
+    pkg = _pkg()
+    x, t = fill.rand((16, 3, 32, 32), 211), fill.rand((16, 3, 128, 128), 212)
+    ora = fill.fill_module(R.EDSR(3, 64, 16), 9, 0.5)
+    grads = []
+    for defer in (True, False):
+        pkg.ops.DEFER_WGRAD = defer
+        try:
+            net = pkg.EDSRNet(3, 64, 16)
+            fill.fill_module(net, 9, 0.5)
+            if defer:
+                _, flat, opt = _one_step_case(pkg, gpu, "edsr", net, ora, x, t, "l1", None, 1e-4, 1e-3)
+            else:
+                net.to(gpu).train()
+                flat = pkg.optim.FlatParams(net)
+                flat.zero_grad()
+                flat.plan.pack()
+                pkg.ops.l1_loss(net(x.to(gpu)), t.to(gpu)).backward()
+            grads.append(flat.grad.clone())
+        finally:
+            pkg.ops.DEFER_WGRAD = True
+    assert rel_err(grads[0], grads[1]) < 2e-5
+
+
 def test_c4_shard_step_uses_small_problem_kernels_and_matches(gpu):
     """The per-GPU shard of c4 (16 patches) selects the channel-split 64-pixel blocks (small-problem
     configuration); its forward must equal the same images inside the full batch (large-problem kernels)."""
@@ -156,22 +183,37 @@ def test_c5_srgan_full_size_adversarial_step(gpu):
     assert abs(float(d_loss) - od_loss) <= 1e-4 * abs(od_loss)
     assert abs(float(g_loss) - og_loss) <= 1e-4 * abs(og_loss)
     # Gradients left in the buffers by the step (G: the G step's; D: D step + the G step's accumulation, a reference
-    # quirk both sides share), per tensor in the L2 norm.  At this size the problem is ill-conditioned in fp32: the
-    # backward sums of a BatchNorm that feeds another BatchNorm cancel to ~1e-4 of their mass, and stock torch fp32
-    # itself deviates from an fp64 run of the same oracle by ~2e-3 (tools/srgan_iso_err.py).  The yardstick is
-    # therefore the fp64 oracle, and the bar is a small multiple of the fp32 oracle's own deviation from it.
+    # quirk both sides share), per tensor in the L2 norm, against an fp64 run of the oracle.  At this size the problem
+    # is ill-conditioned in fp32: the backward sums of a BatchNorm that feeds another BatchNorm cancel to ~1e-4 of their
+    # mass, so the ~3e-7 rounding of a conv output comes back as ~3e-3 in a gradient (tools/srgan_bisect.py: with the
+    # convs alone evaluated in fp64 the same step is within 1e-4, with only the BatchNorm in fp64 nothing changes).
+    # The reference's own CPU path is not reproducible below that either: stock torch fp32 deviates from its fp64 run by
+    # 2.0e-3 with oneDNN convolutions and by 5.5e-3 with ATen's native ones (tools/c5_oracle_spread.py) — two equally
+    # valid evaluation orders of the same torch.nn modules.  The bar is therefore the contract 1e-3 or 1.5x the larger
+    # of those two deviations, both measured here on the same inputs.
     import copy
     oG64 = fill.fill_module(R.Generator(3, 64, 16), 5, 0.7).double()
     oD64 = fill.fill_module(R.Discriminator(3, 64, 128), 6, 1.0).double()
     R.step_srgan(oG64, oD64, R.make_optimizer("srgan_g", oG64.parameters(), 1e-4),
                  R.make_optimizer("srgan_d", oD64.parameters(), 1e-2), lr_img.double(), hr_img.double())
-    for net, ora, ora64 in ((G, oG, oG64), (D, oD, oD64)):
+    # second fp32 evaluation of the oracle: ATen's native convolutions instead of oneDNN's
+    oG_n = fill.fill_module(R.Generator(3, 64, 16), 5, 0.7)
+    oD_n = fill.fill_module(R.Discriminator(3, 64, 128), 6, 1.0)
+    prev = torch.backends.mkldnn.enabled
+    torch.backends.mkldnn.enabled = False
+    try:
+        R.step_srgan(oG_n, oD_n, R.make_optimizer("srgan_g", oG_n.parameters(), 1e-4),
+                     R.make_optimizer("srgan_d", oD_n.parameters(), 1e-2), lr_img, hr_img)
+    finally:
+        torch.backends.mkldnn.enabled = prev
+    for net, ora, ora_n, ora64 in ((G, oG, oG_n, oG64), (D, oD, oD_n, oD64)):
         g32 = dict((n, p.grad.double()) for n, p in ora.named_parameters())
+        g32n = dict((n, p.grad.double()) for n, p in ora_n.named_parameters())
         g64 = dict((n, p.grad) for n, p in ora64.named_parameters())
         gmax = max(float(g.abs().max()) for g in g64.values())
         worst_p, worst_o = 0.0, 0.0
         for n, p in net.named_parameters():
             den = max(float(g64[n].norm()), 1e-3 * gmax * g64[n].numel() ** 0.5)
             worst_p = max(worst_p, float((p.grad.detach().cpu().double() - g64[n]).norm()) / den)
-            worst_o = max(worst_o, float((g32[n] - g64[n]).norm()) / den)
-        assert worst_p < max(1e-3, 4.0 * worst_o), (worst_p, worst_o)
+            worst_o = max(worst_o, float((g32[n] - g64[n]).norm()) / den, float((g32n[n] - g64[n]).norm()) / den)
+        assert worst_p <= max(1e-3, 1.5 * worst_o), (worst_p, worst_o)

@@ -247,6 +247,38 @@ def test_shard_range_covers_batch_exactly(pkg):
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_dp_bucket_plan(pkg):
+    """dp.DataParallel.plan: which ranges of the flat gradient buffer leave after which weight-gradient group —
+    every element exactly once, never before the group that finalises it, small runs held back for a neighbour."""
+    class FakeFlat(object):
+        pass
+    sizes = [12, 400, 400, 400, 400, 4, 200, 8]      # input conv, 4 trunk layers, a PReLU slope, upsampler, output conv
+    flat = FakeFlat()
+    flat.offsets, total = [], 0
+    for n in sizes:
+        flat.offsets.append(total)
+        total += n
+    flat.grad = torch.zeros(total)
+    flat.data = torch.zeros(total)
+    views = [flat.grad[o:o + n] for o, n in zip(flat.offsets, sizes)]
+    dp = pkg.dp.DataParallel(flat, min_bucket_bytes=4 * 100)
+
+    def rec(i):   # (key, desc, x, dy, mask, slope, wacc, bacc)
+        return ("k%d" % i, None, None, None, None, 0.0, views[i], None)
+    # backward order: output conv, upsampler, trunk in two chunks (layers 4,3 then 2,1), input conv; index 5 never deferred
+    groups = [[rec(7)], [rec(6)], [rec(4), rec(3)], [rec(2), rec(1)], [rec(0)]]
+    sends = dp.plan(groups)
+    assert len(sends) == len(groups)
+    assert sends[0] == []                                   # 8 floats: held back
+    assert sends[1] == [(flat.offsets[5], total)]           # slope (final all along) + upsampler + output conv
+    assert sends[2] == [(flat.offsets[3], flat.offsets[5])]
+    assert sends[3] == [(flat.offsets[1], flat.offsets[3])]
+    assert sends[4] == [(0, flat.offsets[1])]               # last group: whatever is left, however small
+    covered = sorted(r for s_ in sends for r in s_)
+    assert covered[0][0] == 0 and covered[-1][1] == total and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    assert dp.plan([]) == [[(0, total)]]
+
+
 class _Flat(object):
     def __init__(self, n, seed):
         self.data = fill.randn((n,), seed)

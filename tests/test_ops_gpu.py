@@ -434,3 +434,68 @@ def test_grad_norm_clip_kat(gpu, ops_kat):
     flat.grad[:1000].copy_(g * 1e-3)
     opt.clip_grad_norm(0.4)
     assert float(opt.scale_dev) == 1.0
+
+
+@pytest.mark.parametrize("n,N,cin,cout,k,p,H,W,act,bias", [
+    (5, 2, 64, 64, 3, 1, 12, 12, "relu", True),     # EDSR / SRResNet body class: two input-channel chunks per layer
+    (7, 1, 64, 64, 3, 1, 33, 21, None, False),      # VDSR class (bias-free), ragged tiles
+    (3, 2, 32, 48, 3, 0, 17, 19, "lrelu", True),    # one chunk, 48 output channels, no padding
+    (4, 1, 24, 16, 1, 0, 9, 40, None, True),        # 1x1, 16 output channels (one-tile waves)
+    (2, 1, 16, 32, 5, 2, 14, 14, "relu", True),     # 5x5: no grouped kernel -> the per-layer path behind the same call
+    (45, 1, 64, 64, 3, 1, 8, 8, "relu", True),      # more layers than one launch holds (chunks of 40)
+])
+def test_wgrad_grouped(gpu, n, N, cin, cout, k, p, H, W, act, bias):
+    """srk_conv2d_backward_weight_grouped: the weight (+ bias) gradients of n same-geometry convs in one call against
+    n per-layer srk_conv2d_backward_weight calls (same kernels, other split-K counts) and torch fp64; beta = 1
+    accumulates; layers with and without an activation mask mix freely."""
+    pkg = _pkg()
+    lib, L = pkg._lib.load(), pkg._lib
+    OH = lib.srk_conv_out_dim(H, k, 1, p, 0, 0)
+    OW = lib.srk_conv_out_dim(W, k, 1, p, 0, 0)
+    d = L.ConvDesc(N, H, W, cin, OH, OW, cout, k, k, 1, p, 0, 0, 0, 0, 0)
+    st = L.stream_ptr()
+    slope = 0.2 if act == "lrelu" else 0.0
+    xs, dys, ys, dws, dbs, refs = [], [], [], [], [], []
+    for l in range(n):
+        x = fill.randn((N, cin, H, W), 900 + l)
+        dy = fill.randn((N, cout, OH, OW), 950 + l)
+        y = fill.randn((N, cout, OH, OW), 990 + l) if (act and l % 3 != 2) else None   # every third layer unmasked
+        dym = dy.double()
+        if y is not None:
+            dym = torch.where(y > 0, dym, dym * slope)
+        xr = x.double().requires_grad_(True)
+        wr = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+        br = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+        torch.nn.functional.conv2d(xr, wr, br, 1, p).backward(dym)
+        refs.append((wr.grad, br.grad))
+        cl = lambda t: t.to(gpu).contiguous(memory_format=torch.channels_last)
+        xs.append(cl(x)); dys.append(cl(dy)); ys.append(None if y is None else cl(y))
+        dws.append(torch.full((cout, cin, k, k), 0.5, device=gpu)); dbs.append(torch.full((cout,), -0.25, device=gpu) if bias else None)
+    vp = ctypes.c_void_p
+    arr = lambda ts: (vp * n)(*[None if t is None else t.data_ptr() for t in ts])
+    masks = (L.BwdMask * n)(*[L.BwdMask(None if y is None else y.data_ptr(), slope) for y in ys])
+    nbytes = int(lib.srk_conv2d_backward_weight_grouped_workspace_bytes(ctypes.byref(d), n))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=gpu)
+    L.check(lib.srk_conv2d_backward_weight_grouped(ctypes.byref(d), n, arr(xs), arr(dys), masks, arr(dws),
+                                                   arr(dbs) if bias else None, 1.0, L.ptr(ws), ws.numel(), st), "grouped")
+    # per-layer reference through the single-layer entry point
+    nb1 = int(lib.srk_conv2d_backward_weight_workspace_bytes(ctypes.byref(d)))
+    ws1 = torch.empty(max(nb1, 16), dtype=torch.uint8, device=gpu)
+    for l in range(n):
+        dw1 = torch.full((cout, cin, k, k), 0.5, device=gpu)
+        db1 = torch.full((cout,), -0.25, device=gpu) if bias else None
+        m = L.BwdMask(None if ys[l] is None else ys[l].data_ptr(), slope)
+        L.check(lib.srk_conv2d_backward_weight(ctypes.byref(d), L.ptr(xs[l]), L.ptr(dys[l]),
+                                               ctypes.byref(m) if ys[l] is not None else None, L.ptr(dw1), L.ptr(db1), 1.0,
+                                               L.ptr(ws1), ws1.numel(), st), "single")
+        assert rel_err(dws[l], dw1) < 2e-5, l
+        assert rel_err(dws[l] - 0.5, refs[l][0].float()) < 1e-4, l          # beta = 1: accumulated onto the 0.5 fill
+        if bias:
+            assert rel_err(dbs[l], db1) < 2e-5, l
+            assert rel_err(dbs[l] + 0.25, refs[l][1].float()) < 1e-4, l
+    # shared weights in one call are refused (LapSRN's aliased branches go into separate calls)
+    if n >= 2:
+        dup = (vp * 2)(dws[0].data_ptr(), dws[0].data_ptr())
+        rc = lib.srk_conv2d_backward_weight_grouped(ctypes.byref(d), 2, arr(xs[:2] + [None] * (n - 2)), arr(dys[:2] + [None] * (n - 2)),
+                                                    masks, dup, None, 1.0, L.ptr(ws), ws.numel(), st)
+        assert rc == -1 and b"same dw" in lib.srk_last_error_string()

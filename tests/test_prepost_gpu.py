@@ -85,8 +85,13 @@ def _run_block(pkg, gpu, blocks_r2, tag, make_ours, make_ora, kind, shape, xs, g
     (y * fill.randn(tuple(y.shape), gs).to(gpu)).sum().backward()
     assert rel_err(y, blocks_r2[tag + ".y"]) < tol_f, tag
     assert rel_err(x.grad, blocks_r2[tag + ".dx"]) < tol_g, tag
+    # a conv bias in front of a norm has an exactly-zero gradient: both sides hold rounding noise there, so errors are
+    # measured against the largest parameter gradient of the block when a tensor's own scale is below 1e-3 of it
+    gmax = max(float(np.abs(blocks_r2["%s.grad.%s" % (tag, n)]).max()) for n, _ in net.named_parameters())
     for n, p in net.named_parameters():
-        assert rel_err(p.grad, blocks_r2["%s.grad.%s" % (tag, n)]) < tol_g, (tag, n)
+        want = blocks_r2["%s.grad.%s" % (tag, n)]
+        err = float(np.abs(p.grad.detach().cpu().numpy().astype(np.float64) - want).max())
+        assert err <= tol_g * max(float(np.abs(want).max()), 1e-3 * gmax), (tag, n, err)
     return net, ora
 
 
