@@ -251,8 +251,14 @@ def join_side_streams():
 # from dp.DataParallel.exchange(), which sends each group's bucket off while the next group computes.
 DEFER_WGRAD = os.environ.get("SRK_DEFER_WGRAD", "1") != "0"
 WGRAD_GROUP_MAX = int(os.environ.get("SRK_WGRAD_GROUP_MAX", "0"))   # > 0: split geometry groups into chunks of this many layers
+# Deferral trades launches and partial-slab traffic for cache locality: a weight gradient launched right behind its
+# layer's data gradient finds dy (and x) in the 256 MB Infinity Cache, one launched at the end of the pass reads them
+# from HBM.  Records are therefore flushed (grouped) as soon as their x + dy bytes exceed DEFER_MAX_BYTES: a 16-patch
+# EDSR shard (8 MB per layer) defers ~19 layers at a time, a 128-patch batch (67 MB per layer) falls back to
+# one-or-two-layer groups, i.e. the per-layer behaviour.
+DEFER_MAX_BYTES = int(float(os.environ.get("SRK_DEFER_MAX_MB", "160")) * (1 << 20))
 _PENDING = []                      # [(key, desc, x, dy, y_mask, slope, wacc, bacc)] in backward order
-_DEFER = {"queued": False, "manual": 0}
+_DEFER = {"queued": False, "manual": 0, "bytes": 0}
 
 
 class manual_wgrad_flush(object):
@@ -316,6 +322,7 @@ def flush_wgrads(on_group=None, max_layers=None):
         return 0
     groups = pending_wgrad_groups(max_layers)
     del _PENDING[:]
+    _DEFER["bytes"] = 0
     for recs in groups:
         launch_wgrad_group(recs)
         if on_group is not None:
@@ -325,6 +332,7 @@ def flush_wgrads(on_group=None, max_layers=None):
 
 def drop_pending_wgrads():
     del _PENDING[:]
+    _DEFER["bytes"] = 0
 
 
 FUSE_SKIP_GRAD = os.environ.get("SRK_FUSE_SKIP_GRAD", "1") != "0"  # 0: residual blocks sum their gradient fan-in with srk_axpby
@@ -416,7 +424,10 @@ class _Conv2d(torch.autograd.Function):
                        d.algo, d.dy_ps_r, bacc is not None, str(dy.device))
                 _PENDING.append((key, d, x, dyc, y if mask is not None else None,
                                  cfg.slope if cfg.act == ACT_LRELU else 0.0, wacc, bacc))
-                if not _DEFER["queued"]:   # first record of this backward pass: flush when the engine finishes it
+                _DEFER["bytes"] += 4 * (x.numel() + dyc.numel())
+                if _DEFER["bytes"] > DEFER_MAX_BYTES:
+                    flush_wgrads()   # (also under manual_wgrad_flush: these gradients are simply final before the exchange)
+                elif not _DEFER["queued"]:   # first record of this backward pass: flush when the engine finishes it
                     _DEFER["queued"] = True
                     torch.autograd.Variable._execution_engine.queue_callback(_auto_flush)
             elif WGRAD_SIDE_STREAM:

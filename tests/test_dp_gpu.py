@@ -107,8 +107,15 @@ def _worker(rank, world, port, out, backend="gloo"):
         step1 = pkg.trainers.l1_step(net1, opt1, None)
         l1 = step1(x.to(dev), t.to(dev))
         res.update(g1=flat1.grad.clone().cpu(), p1=flat1.data.clone().cpu(), loss1=float(l1))
-    torch.save(res, out % r)
+    # (plain numpy payloads: the result file must not depend on how torch.save de-duplicates storages)
+    torch.save({k: (v.detach().cpu().numpy().copy() if isinstance(v, torch.Tensor) else v) for k, v in res.items()}, out % r)
     torch.distributed.destroy_process_group()
+
+
+def _load(path):
+    import numpy as np
+    d = torch.load(path, weights_only=False)
+    return {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()}
 
 
 def _check(r0, r1):
@@ -137,7 +144,7 @@ def test_dp_two_ranks_match_single_process(gpu, tmp_path):
     world, port = 2, 29700 + os.getpid() % 200
     out = str(tmp_path / "dp%d.pt")
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
-    _check(torch.load(out % 0), torch.load(out % 1))
+    _check(_load(out % 0), _load(out % 1))
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (>= 2 visible devices)")
@@ -147,4 +154,4 @@ def test_dp_two_ranks_rccl(gpu, tmp_path):
     world, port = 2, 29900 + os.getpid() % 90
     out = str(tmp_path / "rccl%d.pt")
     mp.spawn(_worker, args=(world, port, out, "nccl"), nprocs=world, join=True)
-    _check(torch.load(out % 0), torch.load(out % 1))
+    _check(_load(out % 0), _load(out % 1))
