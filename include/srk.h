@@ -116,6 +116,9 @@ typedef struct srk_bwd_mask {
 int srk_version(void);
 const char* srk_status_string(int status);
 const char* srk_last_error_string(void); /* thread-local, valid until the next failing call */
+/* Name (with template arguments) of the kernel the calling thread's last srk_conv2d_forward / _backward_data call
+ * dispatched to, e.g. "k_conv_bfw<2,9,2>" — what a measurement should quote (thread-local, never NULL). */
+const char* srk_last_kernel_name(void);
 /* Output spatial size of a conv / transposed conv along one axis (torch semantics). */
 int srk_conv_out_dim(int in, int k, int stride, int pad, int transposed, int out_pad);
 
@@ -276,6 +279,21 @@ typedef enum srk_interp { SRK_INTERP_NEAREST = 0, SRK_INTERP_BILINEAR = 2, SRK_I
 size_t srk_img_interp_workspace_bytes(int N, int C, int H, int W, int OH, int OW, int filter);
 int srk_img_interp(const float* x_nchw, float* y_nchw, int N, int C, int H, int W, int OH, int OW, int filter,
                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- training-set pipeline on 8-bit images (dataset.py:51-99; torchvision's Scale / RandomCrop / flips around Pillow) ----
+ * Image.resize((OW, OH), BICUBIC | BILINEAR) on 8-bit planes, bit-exact with Pillow (same two-pass resampler as
+ * srk_img_interp; a pass is skipped when that axis keeps its size, as Pillow does).  x is addressed through element
+ * strides (plane, row, pixel): an interleaved HWC decode buffer is read in place with (1, W*C, C).  y: planar
+ * [planes][OH][OW], uint8 (out_float = 0) or float = value / 255 (out_float = 1: ToTensor). */
+size_t srk_img_resize_u8_workspace_bytes(int planes, int H, int W, int OH, int OW, int filter);
+int srk_img_resize_u8(const uint8_t* x, int64_t plane_stride, int64_t row_stride, int64_t px_stride, void* y,
+                      int out_float, int planes, int H, int W, int OH, int OW, int filter, void* workspace,
+                      size_t workspace_bytes, void* stream);
+/* RandomCrop -> Image.rotate(90*rot_k, expand=True) (counter-clockwise quarter turns) -> horizontal flip -> vertical
+ * flip (dataset.py:65-84) as one gather: y planar [C][crop_h or crop_w][...] uint8. */
+int srk_patch_augment_u8(const uint8_t* x, int64_t plane_stride, int64_t row_stride, int64_t px_stride, uint8_t* y, int C,
+                         int H, int W, int crop_x, int crop_y, int crop_w, int crop_h, int rot_k, int fliplr, int fliptb,
+                         void* stream);
 
 /* ---- steps either side of the nets ------------------------------------------------
  * utils.PSNR (utils.py:208-216): mse = mean((clamp(pred,0,1) - gt)^2) over all elements, *psnr_out = mse == 0 ? 100 :

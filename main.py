@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Entry point with the reference's command line (main.py:13-36: the same 15 flags and defaults)
-dispatching to the MI355X trainers.  Extra flags: --steps_per_epoch (synthetic patches per epoch,
-the dataset pipeline being out of scope) and --precision {mixed,bf16x3,fp32}.
+dispatching to the MI355X trainers.  Extra flags: --steps_per_epoch (synthetic patches per epoch when
+the image folders under --data_dir do not exist), --epoch_pretrain and --precision {mixed,bf16x3,fp32}.
 Multi-GPU: python -m torch.distributed.run --nproc-per-node N main.py ..."""
 import argparse
 import os

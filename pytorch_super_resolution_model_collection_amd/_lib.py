@@ -50,6 +50,7 @@ _PROTOTYPES = {
     "srk_version": (c_int, []),
     "srk_status_string": (ctypes.c_char_p, [c_int]),
     "srk_last_error_string": (ctypes.c_char_p, []),
+    "srk_last_kernel_name": (ctypes.c_char_p, []),
     "srk_conv_out_dim": (c_int, [c_int] * 6),
     "srk_nchw_to_nhwc": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_vp]),
     "srk_nhwc_to_nchw": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_vp]),
@@ -94,6 +95,11 @@ _PROTOTYPES = {
     "srk_scale_dev": (c_int, [c_f, c_f, c_f, c_size, c_vp]),
     "srk_linear_forward": (c_int, [c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_int, c_float, c_vp]),
     "srk_linear_backward": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_float, c_vp]),
+    "srk_img_resize_u8_workspace_bytes": (c_size, [c_int] * 6),
+    "srk_img_resize_u8": (c_int, [c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, c_int, c_int, c_int, c_int,
+                                  c_int, c_int, c_int, c_vp, c_size, c_vp]),
+    "srk_patch_augment_u8": (c_int, [c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, c_int, c_int, c_int,
+                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "srk_psnr_workspace_bytes": (c_size, []),
     "srk_psnr": (c_int, [c_f, ctypes.POINTER(ctypes.c_int64), c_f, ctypes.POINTER(ctypes.c_int64), c_int, c_int, c_int,
                          c_int, c_f, c_f, c_vp, c_vp]),

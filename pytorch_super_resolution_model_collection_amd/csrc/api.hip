@@ -17,6 +17,15 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static thread_local char g_kernel[128] = "";
+
+void note_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+  va_end(ap);
+}
+
 // conv_tapn.hip
 bool conv_tapn_gather_supported(const GatherConv& g, const float* in, const float* mask_y);
 int conv_tapn_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, bool x6,
@@ -173,6 +182,8 @@ extern "C" const char* srk_status_string(int status) {
 }
 
 extern "C" const char* srk_last_error_string(void) { return g_err; }
+
+extern "C" const char* srk_last_kernel_name(void) { return g_kernel; }
 
 extern "C" int srk_conv_out_dim(int in, int k, int stride, int pad, int transposed, int out_pad) {
   if (in <= 0 || k <= 0 || stride <= 0 || pad < 0) return -1;

@@ -617,6 +617,7 @@ static int bfr_launch(BfdParams B, hipStream_t s) {
   if (B.dbg & 32)
     fprintf(stderr, "[srk] k_conv_bfr<%d,%d>: lds %zu B (filter %zu), grid %d x %d of %ld tiles, tile %dx%d halo %dx%d\n", NTW,
             NOW, lds, wbytes, gx, B.OCb, ntiles, P.TH, P.TW, P.HH, P.HW);
+  note_kernel("k_conv_bfr<%d,%d>", NTW, NOW);
   hipLaunchKernelGGL((k_conv_bfr<NTW, NOW>), dim3(gx, B.OCb), dim3(256 * NOW), lds, s, B, (int)ntiles);
   return check_launch("conv_bfr");
 }
@@ -673,6 +674,7 @@ static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
       if (B.dbg & 32)
         fprintf(stderr, "[srk] k_conv_bfd<%d,%d,%d,%d,%d> K-split 2: lds %zu B, grid %u x %u, tile %dx%d halo %dx%d\n", NTW, NPW,
                 NOW, NP, PF, lds, grid.x, grid.y, P.TH, P.TW, P.HH, P.HW);
+      note_kernel("k_conv_bfd<%d,%d,%d,%d,%d,2>", NTW, NPW, NOW, NP, PF);
       hipLaunchKernelGGL((k_conv_bfd<NTW, NPW, NOW, NP, PF, 2>), grid, dim3(64 * NPW * NOW * 2), lds, s, B);
       return check_launch("conv_bfd");
     }
@@ -686,6 +688,7 @@ static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
     fprintf(stderr, "[srk] k_conv_bfd<%d,%d,%d,%d,%d>: lds %zu B, grid %u x %u, occupancy %d blocks/CU, tile %dx%d halo %dx%d\n",
             NTW, NPW, NOW, NP, PF, lds, grid.x, grid.y, nb, P.TH, P.TW, P.HH, P.HW);
   }
+  note_kernel("k_conv_bfd<%d,%d,%d,%d,%d,1>", NTW, NPW, NOW, NP, PF);
   hipLaunchKernelGGL((k_conv_bfd<NTW, NPW, NOW, NP, PF, 1>), grid, dim3(64 * NPW * NOW), lds, s, B);
   return check_launch("conv_bfd");
 }

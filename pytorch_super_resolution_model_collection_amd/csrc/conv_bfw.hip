@@ -374,6 +374,7 @@ template <int NTW, int TT, int MTW>
 static int bfw_launch_t(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
   static LdsLimit lim;
   lim.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, MTW>), lds);
+  note_kernel("k_conv_bfw<%d,%d,%d>", NTW, TT, MTW);
   hipLaunchKernelGGL((k_conv_bfw<NTW, TT, MTW>), dim3(grid), dim3(64 * (16 / MTW + 4)), lds, s, B);
   return check_launch("conv_bfw");
 }

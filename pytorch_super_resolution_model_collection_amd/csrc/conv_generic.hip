@@ -72,6 +72,7 @@ int conv_generic_gather(const GatherConv& g, const float* in, const float* wp, f
   const size_t total = (size_t)g.N * g.OH * g.OW * g.OC;
   size_t nb = (total + 255) / 256;
   if (nb > 256 * 32) nb = 256 * 32;
+  note_kernel("k_gather_conv");
   hipLaunchKernelGGL(k_gather_conv, dim3((unsigned)nb), dim3(256), 0, s, g, in, wp, out, ep, mask_y, mask_slope);
   return check_launch("conv_generic_gather");
 }

@@ -439,9 +439,11 @@ static void launch_variant(bool tapgroup, const MfmaConvParams& P, dim3 grid, si
   static LdsLimit cur_tg, cur_main;
   if (tapgroup) {
     ensure_lds(reinterpret_cast<const void*>(&k_conv_mfma_tg<NT>), cur_tg, lds);
+    note_kernel("k_conv_mfma_tg<%d>", NT);
     hipLaunchKernelGGL(k_conv_mfma_tg<NT>, grid, dim3(256), lds, s, P);
   } else {
     ensure_lds(reinterpret_cast<const void*>(&k_conv_mfma<NT>), cur_main, lds);
+    note_kernel("k_conv_mfma<%d>", NT);
     hipLaunchKernelGGL(k_conv_mfma<NT>, grid, dim3(256), lds, s, P);
   }
 }
@@ -454,6 +456,7 @@ template <int OCT>
 static void launch_direct(const MfmaConvParams& P, dim3 grid, size_t lds, hipStream_t s) {
   static LdsLimit cur;
   ensure_lds(reinterpret_cast<const void*>(&k_conv_direct<OCT>), cur, lds);
+  note_kernel("k_conv_direct<%d>", OCT);
   hipLaunchKernelGGL(k_conv_direct<OCT>, grid, dim3(256), lds, s, P);
 }
 

@@ -614,6 +614,7 @@ static void bf3_launch_vec(const Bf3Params& B, dim3 grid, size_t lds, hipStream_
     fprintf(stderr, "[srk] k_conv_bf3<%d,4,vec>: lds %zu B, grid %u x %u, occupancy %d blocks/CU, tile %dx%d halo %dx%d\n", NT,
             lds, grid.x, grid.y, nb, B.P.TH, B.P.TW, B.P.HH, B.P.HW);
   }
+  note_kernel("k_conv_bf3<%d,4,vec>", NT);
   hipLaunchKernelGGL((k_conv_bf3<NT, 4, true>), grid, dim3(256), lds, s, B);
 }
 
@@ -628,6 +629,7 @@ static void bf3_launch(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s)
     fprintf(stderr, "[srk] k_conv_bf3<%d,%d>: lds %zu B, grid %u x %u, occupancy %d blocks/CU, tile %dx%d halo %dx%d\n", NT,
             NW, lds, grid.x, grid.y, nb, B.P.TH, B.P.TW, B.P.HH, B.P.HW);
   }
+  note_kernel("k_conv_bf3<%d,%d>", NT, NW);
   hipLaunchKernelGGL((k_conv_bf3<NT, NW>), grid, dim3(64 * NW), lds, s, B);
 }
 
@@ -645,6 +647,7 @@ template <int NT, bool VEC_ONLY>
 static void bf3_launch_rows_v(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s) {
   static LdsLimit lim;
   lim.ensure(reinterpret_cast<const void*>(&k_conv_bf3_rows<NT, VEC_ONLY>), lds);
+  note_kernel("k_conv_bf3_rows<%d>", NT);
   hipLaunchKernelGGL((k_conv_bf3_rows<NT, VEC_ONLY>), grid, dim3(256), lds, s, B);
 }
 template <int NT>

@@ -206,6 +206,7 @@ static int tapn_launch(MfmaConvParams P, bool x6, hipStream_t s) {
     else
       hipLaunchKernelGGL((k_conv_tapn<KS, OCT, true, 2>), grid, dim3(256), lds, s, P);
   } else {
+    note_kernel("k_conv_tapn<%d,%d>", KS, OCT);
     hipLaunchKernelGGL((k_conv_tapn<KS, OCT, false, 3>), grid, dim3(256), lds, s, P);
   }
   return check_launch("conv_tapn");

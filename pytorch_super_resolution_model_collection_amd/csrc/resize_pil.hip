@@ -94,6 +94,88 @@ __global__ __launch_bounds__(256) void k_resize_h(const float* __restrict__ x, u
   }
 }
 
+// horizontal pass on 8-bit pixels addressed through element strides (plane, row, pixel): a decoded interleaved HWC
+// image is read in place (plane stride 1, pixel stride 3), planar images with (H*W, W, 1)
+__global__ __launch_bounds__(256) void k_resize_h_u8(const unsigned char* __restrict__ x, long long sp, long long sr,
+                                                     long long sx, unsigned char* __restrict__ tmp, int planes, int H,
+                                                     int OW, int ksize, const int* __restrict__ kk,
+                                                     const int* __restrict__ bounds) {
+  const size_t total = (size_t)planes * H * OW;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int ox = (int)(e % OW);
+    const size_t r = e / OW;
+    const int row = (int)(r % H);
+    const int pl = (int)(r / H);
+    const int xmin = bounds[2 * ox], xmax = bounds[2 * ox + 1];
+    const int* k = kk + (size_t)ox * ksize;
+    const unsigned char* src = x + pl * sp + row * sr + xmin * sx;
+    int ss = 1 << (kPrecisionBits - 1);
+    for (int t = 0; t < xmax; ++t) ss += (int)src[t * sx] * k[t];
+    tmp[e] = clip8(ss);
+  }
+}
+
+// vertical pass with an 8-bit result (the image stays a PIL-style uint8 image for the next transform)
+__global__ __launch_bounds__(256) void k_resize_v_u8(const unsigned char* __restrict__ tmp, unsigned char* __restrict__ y,
+                                                     size_t planes, int H, int OH, int OW, int ksize,
+                                                     const int* __restrict__ kk, const int* __restrict__ bounds) {
+  const size_t total = planes * (size_t)OH * OW;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int ox = (int)(e % OW);
+    const size_t r = e / OW;
+    const int oy = (int)(r % OH);
+    const size_t pl = r / OH;
+    const int ymin = bounds[2 * oy], ymax = bounds[2 * oy + 1];
+    const int* k = kk + (size_t)oy * ksize;
+    const unsigned char* src = tmp + (pl * H + ymin) * (size_t)OW + ox;
+    int ss = 1 << (kPrecisionBits - 1);
+    for (int t = 0; t < ymax; ++t) ss += (int)src[(size_t)t * OW] * k[t];
+    y[e] = clip8(ss);
+  }
+}
+
+// gather copy of 8-bit planes through element strides (a pass Pillow skips because the size does not change)
+__global__ __launch_bounds__(256) void k_copy_u8_strided(const unsigned char* __restrict__ x, long long sp, long long sr,
+                                                         long long sx, unsigned char* __restrict__ y, int planes, int H,
+                                                         int W) {
+  const size_t total = (size_t)planes * H * W;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int xx = (int)(e % W);
+    const size_t r = e / W;
+    y[e] = x[(long long)(r / H) * sp + (long long)(r % H) * sr + xx * sx];
+  }
+}
+
+// planar uint8 -> float / 255 (ToTensor)
+__global__ __launch_bounds__(256) void k_u8_to_float(const unsigned char* __restrict__ x, float* __restrict__ y, size_t n) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) y[e] = (float)x[e] / 255.f;
+}
+
+// crop -> rotate by k x 90 degrees counter-clockwise (PIL Image.rotate(90*k, expand=True) = transpose(ROTATE_*)) ->
+// horizontal flip -> vertical flip (dataset.py:65-84), composed into one gather: out [C][OH][OW] planar.
+__global__ __launch_bounds__(256) void k_patch_augment(const unsigned char* __restrict__ x, long long sp, long long sr,
+                                                       long long sx, unsigned char* __restrict__ y, int C, int cx0, int cy0,
+                                                       int cw, int ch, int rot, int fliplr, int fliptb) {
+  const int OW = (rot & 1) ? ch : cw, OH = (rot & 1) ? cw : ch;
+  const size_t total = (size_t)C * OH * OW;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    int ox = (int)(e % OW);
+    const size_t r = e / OW;
+    int oy = (int)(r % OH);
+    const int c = (int)(r / OH);
+    if (fliptb) oy = OH - 1 - oy;   // undo the flips (the last transform applied comes off first)
+    if (fliplr) ox = OW - 1 - ox;
+    int iy, ix;                     // position in the cropped image A [ch][cw]: R = rot90^k(A)
+    switch (rot & 3) {
+      case 1: iy = ox; ix = cw - 1 - oy; break;            // R[i][j] = A[j][cw-1-i]
+      case 2: iy = ch - 1 - oy; ix = cw - 1 - ox; break;
+      case 3: iy = ch - 1 - ox; ix = oy; break;            // R[i][j] = A[ch-1-j][i]
+      default: iy = oy; ix = ox;
+    }
+    y[e] = x[c * sp + (long long)(cy0 + iy) * sr + (long long)(cx0 + ix) * sx];
+  }
+}
+
 // vertical pass: uint8 [planes][H][OW] -> float [planes][OH][OW] (ToTensor: /255)
 __global__ __launch_bounds__(256) void k_resize_v(const unsigned char* __restrict__ tmp, float* __restrict__ y,
                                                   size_t planes, int H, int OH, int OW, int ksize,
@@ -209,4 +291,81 @@ extern "C" int srk_img_interp(const float* x_nchw, float* y_nchw, int N, int C, 
   if (nb > 65535) nb = 65535;
   hipLaunchKernelGGL(k_resize_v, dim3((unsigned)nb), dim3(256), 0, s, tmp, y_nchw, planes, H, OH, OW, kv, kkv, bv);
   return check_launch("img_interp");
+}
+
+// ---- 8-bit image transforms of the training-set pipeline (dataset.py:51-99) ------------------------------------------
+extern "C" size_t srk_img_resize_u8_workspace_bytes(int planes, int H, int W, int OH, int OW, int filter) {
+  if (planes <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return 0;
+  const size_t kh = (size_t)resize_ksize(W, OW, filter), kv = (size_t)resize_ksize(H, OH, filter);
+  return align256((size_t)planes * H * OW) + align256((size_t)planes * OH * OW) + align256((size_t)OW * kh * 4) +
+         align256((size_t)OW * 8) + align256((size_t)OH * kv * 4) + align256((size_t)OH * 8);
+}
+
+extern "C" int srk_img_resize_u8(const uint8_t* x, int64_t plane_stride, int64_t row_stride, int64_t px_stride, void* y,
+                                 int out_float, int planes, int H, int W, int OH, int OW, int filter, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  SRK_REQUIRE(x && y, "img_resize_u8: null pointer");
+  SRK_REQUIRE(planes > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "img_resize_u8: non-positive dims");
+  SRK_REQUIRE(filter == SRK_INTERP_BILINEAR || filter == SRK_INTERP_BICUBIC, "img_resize_u8: filter must be bilinear or bicubic");
+  const size_t need = srk_img_resize_u8_workspace_bytes(planes, H, W, OH, OW, filter);
+  SRK_REQUIRE(workspace && workspace_bytes >= need, "img_resize_u8: workspace %zu < %zu", workspace_bytes, need);
+  hipStream_t s = (hipStream_t)stream;
+  const int kh = resize_ksize(W, OW, filter), kv = resize_ksize(H, OH, filter);
+  char* p = static_cast<char*>(workspace);
+  unsigned char* tmp = reinterpret_cast<unsigned char*>(p);
+  p += align256((size_t)planes * H * OW);
+  unsigned char* out8 = reinterpret_cast<unsigned char*>(p);
+  p += align256((size_t)planes * OH * OW);
+  int* kkh = reinterpret_cast<int*>(p);
+  p += align256((size_t)OW * kh * 4);
+  int* bh = reinterpret_cast<int*>(p);
+  p += align256((size_t)OW * 8);
+  int* kkv = reinterpret_cast<int*>(p);
+  p += align256((size_t)OH * kv * 4);
+  int* bv = reinterpret_cast<int*>(p);
+  auto grid = [](size_t n) {
+    size_t nb = (n + 255) / 256;
+    return dim3((unsigned)(nb > 65535 ? 65535 : (nb < 1 ? 1 : nb)));
+  };
+  // Pillow (ImagingResample) runs a pass only when that axis changes size
+  const bool need_h = OW != W, need_v = OH != H;
+  if (need_h) {
+    hipLaunchKernelGGL(k_resize_tables, dim3(cdiv(OW, 128)), dim3(128), 0, s, W, OW, filter, kh, kkh, bh);
+    hipLaunchKernelGGL(k_resize_h_u8, grid((size_t)planes * H * OW), dim3(256), 0, s, x, (long long)plane_stride,
+                       (long long)row_stride, (long long)px_stride, tmp, planes, H, OW, kh, kkh, bh);
+  } else {
+    hipLaunchKernelGGL(k_copy_u8_strided, grid((size_t)planes * H * W), dim3(256), 0, s, x, (long long)plane_stride,
+                       (long long)row_stride, (long long)px_stride, tmp, planes, H, W);
+  }
+  unsigned char* v_out = out_float ? out8 : static_cast<unsigned char*>(y);
+  const unsigned char* last = tmp;
+  if (need_v) {
+    hipLaunchKernelGGL(k_resize_tables, dim3(cdiv(OH, 128)), dim3(128), 0, s, H, OH, filter, kv, kkv, bv);
+    hipLaunchKernelGGL(k_resize_v_u8, grid((size_t)planes * OH * OW), dim3(256), 0, s, (const unsigned char*)tmp, v_out,
+                       (size_t)planes, H, OH, OW, kv, kkv, bv);
+    last = v_out;
+  }
+  const size_t n = (size_t)planes * OH * OW;
+  if (out_float)
+    hipLaunchKernelGGL(k_u8_to_float, grid(n), dim3(256), 0, s, last, static_cast<float*>(y), n);
+  else if (last != v_out)
+    hipLaunchKernelGGL(k_copy_u8_strided, grid(n), dim3(256), 0, s, last, (long long)OH * OW, (long long)OW, 1LL, v_out,
+                       planes, OH, OW);
+  return check_launch("img_resize_u8");
+}
+
+extern "C" int srk_patch_augment_u8(const uint8_t* x, int64_t plane_stride, int64_t row_stride, int64_t px_stride,
+                                    uint8_t* y, int C, int H, int W, int crop_x, int crop_y, int crop_w, int crop_h,
+                                    int rot_k, int fliplr, int fliptb, void* stream) {
+  SRK_REQUIRE(x && y, "patch_augment_u8: null pointer");
+  SRK_REQUIRE(C > 0 && H > 0 && W > 0 && crop_w > 0 && crop_h > 0, "patch_augment_u8: non-positive dims");
+  SRK_REQUIRE(crop_x >= 0 && crop_y >= 0 && crop_x + crop_w <= W && crop_y + crop_h <= H,
+              "patch_augment_u8: crop [%d,%d)+(%d,%d) outside the %dx%d image", crop_x, crop_y, crop_w, crop_h, W, H);
+  SRK_REQUIRE(rot_k >= 0 && rot_k <= 3, "patch_augment_u8: rot_k must be 0..3 (quarter turns, counter-clockwise)");
+  size_t nb = ((size_t)C * crop_w * crop_h + 255) / 256;
+  if (nb > 65535) nb = 65535;
+  hipLaunchKernelGGL(k_patch_augment, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, (long long)plane_stride,
+                     (long long)row_stride, (long long)px_stride, y, C, crop_x, crop_y, crop_w, crop_h, rot_k, fliplr ? 1 : 0,
+                     fliptb ? 1 : 0);
+  return check_launch("patch_augment_u8");
 }

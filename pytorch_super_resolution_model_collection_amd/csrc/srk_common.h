@@ -10,6 +10,9 @@
 namespace srk {
 
 void set_error(const char* fmt, ...);
+// Records the kernel a conv entry point just launched (thread-local; read back through srk_last_kernel_name()) so that
+// measurements can name the kernel that actually ran instead of guessing it from the shape.
+void note_kernel(const char* fmt, ...);
 
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();

@@ -6,10 +6,11 @@ lapsrn.py:88-349, srgan.py:93-528), on the MI355X hot path.
 Kept from the reference: per-model hyper-parameters hard-coded in train() (e.g. EDSR base_filter 64 /
 16 residuals, edsr.py:87; VDSR momentum 0.9 / wd 1e-4 / clip 0.4, vdsr.py:86-90,149), the epoch-wise
 LR decay rules, the checkpoint file names and that checkpoints are weights-only state_dict pickles.
-Not kept (out of scope): the PIL/torchvision dataset pipeline, TF1 logging, PNG/plot
-side effects and the per-iteration host sync (`loss.data[0]`).  Training data comes from a
-`loader` argument (any iterable of tensor tuples in the reference's (lr, hr, bicubic) order) or, by
-default, from seeded synthetic patches of the configured crop size.
+Not kept (out of scope): TF1 logging, PNG/plot side effects and the per-iteration host
+sync (`loss.data[0]`).  Training data comes from a `loader` argument (any iterable of tensor tuples in
+the reference's (lr, hr, bicubic) order), else from the reference's image folders under `data_dir`
+(data.PatchLoader: decode on host threads, transforms on the GPU) when they exist, else from seeded
+synthetic patches of the configured crop size.
 """
 import os
 
@@ -93,6 +94,33 @@ class _Trainer(object):
             return inp, utils.img_interp(target, 1 / self.scale_factor * 2), target
         return inp, target
 
+    def load_dataset(self, dataset, is_train=True):
+        """edsr.py:67-84 / srgan.py:110-129: the image-folder loaders of data.py behind the reference's directory layout
+        (data_dir/<dataset>/..., DIV2K_train_LR_bicubic/X4 for DIV2K), as data.PatchLoader (decode on host threads,
+        uint8 over PCIe through pinned memory, every transform on the GPU).  None when a folder is missing — the
+        trainer then runs on seeded synthetic patches."""
+        from . import data
+        is_gray = self.num_channels == 1
+        try:
+            if is_train:
+                ds = data.get_training_set(self.data_dir, dataset, self.crop_size, self.scale_factor, is_gray=is_gray,
+                                           device=self.device)
+                bs, shuffle = self.batch_size, True
+            else:
+                ds = data.get_test_set(self.data_dir, dataset, self.scale_factor, is_gray=is_gray, device=self.device)
+                bs, shuffle = self.test_batch_size or 1, False
+        except (OSError, TypeError):
+            return None
+        if len(ds) == 0:
+            return None
+        return data.PatchLoader(ds, bs, shuffle=shuffle, num_threads=self.num_threads or 4)
+
+    def _channels(self, *tensors):
+        """num_channels == 1: only the Y channel is super-resolved (edsr.py:139-142: hr[:, 0].unsqueeze(1))."""
+        if self.num_channels == 1:
+            return tuple(t[:, :1].contiguous() if t.shape[1] != 1 else t for t in tensors)
+        return tensors
+
     # -- reference surface ------------------------------------------------------------------------
     def train(self, loader=None, log_every=0):
         self.model = self.build_model()
@@ -102,13 +130,17 @@ class _Trainer(object):
         self.flat, self.optimizer, self.dp, step = trainers.build(self.kind, self.model, self.lr,
                                                                   use_dp=self.world > 1)
         avg_loss = []
+        self.data_source = "loader"
+        if loader is None:
+            loader = self.load_dataset(self.train_dataset, is_train=True)
+            self.data_source = "folder" if loader is not None else "synthetic"
         for epoch in range(self.num_epochs):
             self.lr_decay(epoch, self.optimizer)
             batches = loader if loader is not None else synthetic_loader(self.kind, self.args, self.steps_per_epoch,
                                                                          self.device, 1234 + epoch * self.world + self.rank)
             total, n = torch.zeros((), device=self.device), 0
             for batch in batches:
-                inp, target = [t.to(self.device, non_blocking=True) for t in batch][:2]
+                inp, target = self._channels(*[t.to(self.device, non_blocking=True) for t in batch][:2])
                 out = step(*self.prepare(inp, target))
                 loss = sum(out) if isinstance(out, tuple) else out
                 total += loss.detach()   # device-side accumulation: no host sync inside the loop
@@ -253,9 +285,14 @@ class SRGAN(_Trainer):
             d_dp.broadcast_params()
         norm = lambda t: utils.norm(t, vgg=True)   # srgan.py:193-194,257-258
 
+        self.data_source = "loader"
+        if loader is None:
+            loader = self.load_dataset(self.train_dataset, is_train=True)
+            self.data_source = "folder" if loader is not None else "synthetic"
+
         def batches(seed):   # loaders yield (lr, hr) or the reference's (lr, hr, bicubic) tuples (dataset.py:101)
             for batch in (loader or synthetic_loader("srgan", self.args, self.steps_per_epoch, self.device, seed)):
-                lr_img, hr_img = batch[:2]
+                lr_img, hr_img = self._channels(*batch[:2])
                 yield norm(lr_img.to(self.device, non_blocking=True)), norm(hr_img.to(self.device, non_blocking=True))
 
         # generator pre-training (srgan.py:179-219): 50 epochs of MSE unless a pre-trained generator checkpoint loads
