@@ -76,8 +76,8 @@ def _worker(rank, world, port, out, backend="gloo"):
             pkg.dp.DataParallel(gf), pkg.dp.DataParallel(df)
 
     lr_img, hr_img = fill.rand((4, 3, 8, 8), 31)[2 * r:2 * r + 2].to(dev), fill.rand((4, 3, 32, 32), 32)[2 * r:2 * r + 2].to(dev)
-    G, D, g_opt, d_opt, g_dp, d_dp = make_gan()
-    sstep = pkg.trainers.srgan_step(G, D, g_opt, d_opt, g_dp, d_dp)
+    G, D, g_opt, d_opt, gan_gdp, gan_ddp = make_gan()
+    sstep = pkg.trainers.srgan_step(G, D, g_opt, d_opt, gan_gdp, gan_ddp)
     gan_losses = [[float(v) for v in sstep(lr_img, hr_img)] for _ in range(2)]
     gan_p = torch.cat([g_opt.flat.data, d_opt.flat.data]).cpu()
 
@@ -108,13 +108,17 @@ def _worker(rank, world, port, out, backend="gloo"):
         l1 = step1(x.to(dev), t.to(dev))
         res.update(g1=flat1.grad.clone().cpu(), p1=flat1.data.clone().cpu(), loss1=float(l1))
     # (plain numpy payloads: the result file must not depend on how torch.save de-duplicates storages)
-    torch.save({k: (v.detach().cpu().numpy().copy() if isinstance(v, torch.Tensor) else v) for k, v in res.items()}, out % r)
+    import pickle
+    with open(out % r, "wb") as fh:
+        pickle.dump({k: (v.detach().cpu().numpy().copy() if isinstance(v, torch.Tensor) else v) for k, v in res.items()}, fh)
     torch.distributed.destroy_process_group()
 
 
 def _load(path):
+    import pickle
     import numpy as np
-    d = torch.load(path, weights_only=False)
+    with open(path, "rb") as fh:
+        d = pickle.load(fh)
     return {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()}
 
 
