@@ -44,7 +44,8 @@ def parse():
     ap.add_argument("--lr-size", type=int, default=256)
     ap.add_argument("--no-extra", action="store_true", help="skip the c3/c4 training side metrics")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="mixed", choices=["mixed", "bf16x3", "fp32"],
+    ap.add_argument("--extra-steps", type=int, default=20, help="timed steps of every side metric (after 5 warm-ups)")
+    ap.add_argument("--precision", default="mixed", choices=["mixed", "bf16x3", "bf16x6", "fp32"],
                     help="conv arithmetic (ops.set_precision); inference uses bf16x3 unless 'fp32'")
     return ap.parse_args()
 
@@ -79,8 +80,9 @@ def espcn_layer_events(net, x, steps):
     """HIP events on the launch stream around each of the three fused kernels (conv5+ReLU,
     conv3+ReLU, conv3+pixel-shuffle store). Returns average ms per layer."""
     import pytorch_super_resolution_model_collection_amd as pkg
-    xs = pkg.ops.to_nhwc(x)
-    evs = []
+    lib = pkg._lib.load()
+    xs = x   # the first layer reads the NCHW batch in place, exactly as net(x) does
+    evs, names = [], ["", "", ""]
     with torch.no_grad():
         for _ in range(steps):
             e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -88,10 +90,11 @@ def espcn_layer_events(net, x, steps):
             e[0].record()
             for i, layer in enumerate(net.layers):
                 h = layer(h)
+                names[i] = lib.srk_last_kernel_name().decode()   # the kernel the dispatcher actually launched
                 e[i + 1].record()
             evs.append(e)
     torch.cuda.synchronize()
-    return [sum(e[i].elapsed_time(e[i + 1]) for e in evs) / len(evs) for i in range(3)]
+    return [sum(e[i].elapsed_time(e[i + 1]) for e in evs) / len(evs) for i in range(3)], names
 
 
 def pmc_traffic(kernel_label, batch, lr_size):
@@ -106,11 +109,11 @@ def pmc_traffic(kernel_label, batch, lr_size):
         return None
     with open(files[-1]) as fh:
         kernels = json.load(fh).get("kernels", {})
-    short = kernel_label.split(" ")[0].rstrip(">")      # "k_conv_bf3<2" matches "srk::k_conv_bf3<2, 4>(...)"
+    want = kernel_label.split(" ")[0].replace(" ", "")      # "k_conv_bfw<2,9,2>" == "srk::k_conv_bfw<2, 9, 2>(...)"
     for name, rec in kernels.items():
         name = name.replace(" ", "")
-        i = name.find("::" + short)
-        if i >= 0 and name[i + 2 + len(short)] in ">," and rec.get("hbm_bytes"):
+        i = name.find("::" + want)
+        if i >= 0 and rec.get("hbm_bytes"):
             return int(rec["hbm_bytes"])
     return None
 
@@ -140,14 +143,28 @@ def cpu_baseline(batch_cap=8, lr_size=256):
                       "%s threads" % (batch_cap, lr_size, lr_size, sorted({ncpu, ncpu // 2, ncpu // 4, 32, 16, 8}))}
 
 
-def train_extra(pkg, dev, rank, world):
-    """Side metrics: c3 VDSR x4 training (41x41, batch 256, one GPU's worth per rank is NOT sharded —
-    reported from rank 0 only at N=1) and c4 EDSR x4 training with global batch 128 sharded over the ranks."""
-    from oracle import fill
+# Per-sample algorithmic conv FLOPs of the training configs and the bf16 MFMA work the default
+# "mixed" precision issues for them: forward = 6 bf16 MFMAs per product (bf16x6), data + weight gradient = 3 each (bf16x3).
+# Upper estimates: the few Cin<=4 / 9x9 / 64->3 layers run on other kernels (fp32 MFMA, taps-as-N).
+C3_FWD, C4_FWD = 2.2425e9, 4.0615e9
+C5_G_FWD, C5_D_FWD = 4.543e9, 3.1437e9
+
+
+def bf16_pipe_frac(fwd_flop, bwd_flop, seconds_per_sample):
+    """(MFMAs issued x 16384 FLOP) / time / 2.5 PF for a training sample: fwd_flop of forward convs, bwd_flop of
+    backward convs (data + weight gradient together)."""
+    return (6.0 * fwd_flop + 3.0 * bwd_flop) / seconds_per_sample / (BF16_MFMA_PEAK_TFLOPS * 1e12)
+
+
+def train_extra(pkg, dev, rank, world, nsteps=20):
+    """Side metrics: c1 (SRCNN step incl. the bicubic pre-step) and c3 (VDSR x4, 41x41, batch 256) on one GPU; c4 EDSR x4
+    training with global batch 128 sharded over the ranks (strong scaling; grouped weight gradients + overlapped bucketed
+    RCCL exchange) and with 128 per GPU (weak); the 16-patch shard step that bounds 8-GPU strong scaling; c5 SRGAN."""
     out = {}
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    WARM = 5
 
-    def run(kind, net, inp, tgt, loss_fn, clip, use_dp, steps=6, warmup=3):
+    def run(kind, net, inp, tgt, loss_fn, clip, use_dp, steps=nsteps, warmup=WARM):
         net.to(dev).train()
         flat = pkg.optim.FlatParams(net)
         opt = pkg.optim.make_optimizer(kind, flat, 1e-5)
@@ -156,7 +173,13 @@ def train_extra(pkg, dev, rank, world):
             dp = pkg.dp.DataParallel(flat)
             dp.broadcast_params()
         step = pkg.trainers.GraphedStep(net, opt, loss_fn, (inp, tgt), dp=dp, clip=clip, warmup=2)
-        return time_steps(lambda: step(inp, tgt), steps, warmup, world if use_dp else 1, dev), steps
+        sec = time_steps(lambda: step(inp, tgt), steps, warmup, world if use_dp else 1, dev)
+        sec_nocomm = None
+        if dp is not None:   # the same step with the all-reduces skipped: the difference is the exposed communication
+            dp.comm_enabled = False
+            sec_nocomm = time_steps(lambda: step(inp, tgt), steps, 2, world, dev)
+            dp.comm_enabled = True
+        return sec, steps, sec_nocomm
 
     def c1():
         # BASELINE c1: SRCNN x2, 16 LR patches 32x32 -> bicubic x2 (utils.img_interp, bit-exact PIL) -> 3x64x64 ->
@@ -174,14 +197,14 @@ def train_extra(pkg, dev, rank, world):
             return step(pkg.utils.img_interp(a, 2), pkg.utils.shave(b, 8).contiguous())
 
         try:  # the whole iteration (bicubic pre-step + crop + train step) as one hipGraph; eager if capture is refused
-            graphed = pkg.trainers.GraphedFn(one, (inp, tgt))
+            graphed = pkg.trainers.GraphedFn(one, (inp, tgt), flats=[flat])
             out["c1_mode"] = "hipGraph"
         except Exception:  # noqa: BLE001
             graphed = one
             out["c1_mode"] = "eager"
-        sec = time_steps(lambda: graphed(inp, tgt), 20, 5, 1, dev)
-        out["c1_srcnn_x2_train_patches_per_s_batch_16"] = round(16 * 20 / sec, 1)
-        out["c1_srcnn_ms_per_step"] = round(1e3 * sec / 20, 3)
+        sec = time_steps(lambda: graphed(inp, tgt), 50, 10, 1, dev)
+        out["c1_srcnn_x2_train_patches_per_s_batch_16"] = round(16 * 50 / sec, 1)
+        out["c1_srcnn_ms_per_step"] = round(1e3 * sec / 50, 3)
         # the reference's CPU path for the same step on this box's host cores (oracle = stock torch + Pillow)
         from oracle import ref_modules as R, img_interp as OI
         onet = R.SRCNN(3, 64)
@@ -204,40 +227,56 @@ def train_extra(pkg, dev, rank, world):
         net.weight_init()
         x = torch.rand(256, 3, 41, 41, generator=g).to(dev)
         t = torch.rand(256, 3, 41, 41, generator=g).to(dev)
-        sec, k = run("vdsr", net, x, t, pkg.ops.mse_loss, 0.4, False)
+        sec, k, _ = run("vdsr", net, x, t, pkg.ops.mse_loss, 0.4, False)
         out["c3_vdsr_x4_train_patches_per_s"] = round(256 * k / sec, 1)
         out["c3_vdsr_ms_per_step"] = round(1e3 * sec / k, 3)
-        out["c3_vdsr_frac_fp32_mfma_peak"] = round(256 * k / sec * 6.72e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
+        out["c3_vdsr_bf16_pipe_frac"] = round(bf16_pipe_frac(C3_FWD, 2 * C3_FWD, sec / k / 256), 4)
 
     gb = 128
 
-    def c4_strong():
-        lo, hi = pkg.dp.shard_range(gb, rank, world)
+    def edsr():
         net = pkg.EDSRNet(3, 64, 16)
         torch.manual_seed(1234)
         net.weight_init()
+        return net
+
+    def c4_strong():
+        lo, hi = pkg.dp.shard_range(gb, rank, world)
         x = torch.rand(gb, 3, 32, 32, generator=torch.Generator().manual_seed(99))[lo:hi].to(dev)
         t = torch.rand(gb, 3, 128, 128, generator=torch.Generator().manual_seed(98))[lo:hi].to(dev)
-        sec, k = run("edsr", net, x, t, pkg.ops.l1_loss, None, True)
+        sec, k, nocomm = run("edsr", edsr(), x, t, pkg.ops.l1_loss, None, True)
         out["c4_edsr_x4_train_patches_per_s_global_batch_128"] = round(gb * k / sec, 1)
         out["c4_edsr_ms_per_step"] = round(1e3 * sec / k, 3)
-        out["c4_scaling"] = "strong (global batch 128 sharded over %d rank(s), RCCL all-reduce of 6.07 MB grads)" % world
+        out["c4_edsr_bf16_pipe_frac"] = round(bf16_pipe_frac(C4_FWD, 2 * C4_FWD, sec / k / gb) / world, 4)
+        out["c4_scaling"] = ("strong (global batch 128 sharded over %d rank(s); 6.07 MB of gradients per step as bucketed RCCL "
+                             "all-reduces issued behind the grouped weight-gradient launches)" % world)
+        if nocomm is not None:
+            out["c4_exposed_comm_ms"] = round(1e3 * (sec - nocomm) / k, 3)
+
+    def c4_shard16():
+        # what ONE of 8 ranks computes per step under strong scaling (16 of the 128 patches), timed on this GPU alone:
+        # full-batch step / shard step is the ceiling of the 8-GPU speed-up before any communication
+        x = torch.rand(16, 3, 32, 32, generator=g).to(dev)
+        t = torch.rand(16, 3, 128, 128, generator=g).to(dev)
+        sec, k, _ = run("edsr", edsr(), x, t, pkg.ops.l1_loss, None, False)
+        out["c4_shard16_ms_per_step"] = round(1e3 * sec / k, 3)
+        if "c4_edsr_ms_per_step" in out and world == 1:
+            out["c4_strong_scaling_ceiling_at_8_gpus"] = round(out["c4_edsr_ms_per_step"] / out["c4_shard16_ms_per_step"], 2)
 
     def c4_weak():
         # the same step with the per-GPU batch held at 128 (weak scaling: global batch 128 * world)
-        net = pkg.EDSRNet(3, 64, 16)
-        torch.manual_seed(1234)
-        net.weight_init()
         x = torch.rand(gb, 3, 32, 32, generator=g).to(dev)
         t = torch.rand(gb, 3, 128, 128, generator=g).to(dev)
-        sec, k = run("edsr", net, x, t, pkg.ops.l1_loss, None, True)
+        sec, k, nocomm = run("edsr", edsr(), x, t, pkg.ops.l1_loss, None, True)
         out["c4_weak_edsr_x4_train_patches_per_s_batch_128_per_gpu"] = round(world * gb * k / sec, 1)
         out["c4_weak_ms_per_step"] = round(1e3 * sec / k, 3)
+        if nocomm is not None:
+            out["c4_weak_exposed_comm_ms"] = round(1e3 * (sec - nocomm) / k, 3)
 
     def c5():
         # SRGAN x4 generator + discriminator adversarial step (srgan.py:249-310), reference default batch 16 per GPU,
-        # 32x32 LR -> 128x128 HR crops; two models, two optimizers; hipGraph-captured on one GPU, eager with both
-        # gradients all-reduced under DP
+        # 32x32 LR -> 128x128 HR crops; two models, two optimizers.  One GPU: the whole step as one hipGraph.  DP: graphs
+        # split at the two gradient exchanges (trainers.GraphedSegments), D's 153 MB of gradients in 32 MB buckets.
         G, D = pkg.SRGANGenerator(3, 64, 16), pkg.SRGANDiscriminator(3, 64, 128)
         torch.manual_seed(1234)
         G.weight_init()
@@ -247,23 +286,25 @@ def train_extra(pkg, dev, rank, world):
         gflat, dflat = pkg.optim.FlatParams(G), pkg.optim.FlatParams(D)
         g_opt = pkg.optim.make_optimizer("srgan_g", gflat, 1e-4)
         d_opt = pkg.optim.make_optimizer("srgan_d", dflat, 1e-4)
-        g_dp = d_dp = None
+        lr_img = torch.rand(16, 3, 32, 32, generator=g).to(dev)
+        hr_img = torch.rand(16, 3, 128, 128, generator=g).to(dev)
         if world > 1:
             g_dp, d_dp = pkg.dp.DataParallel(gflat), pkg.dp.DataParallel(dflat)
             g_dp.broadcast_params()
             d_dp.broadcast_params()
-        sstep = pkg.trainers.srgan_step(G, D, g_opt, d_opt, g_dp, d_dp)
-        lr_img = torch.rand(16, 3, 32, 32, generator=g).to(dev)
-        hr_img = torch.rand(16, 3, 128, 128, generator=g).to(dev)
-        if world == 1:  # single GPU: the whole two-model step as one hipGraph (~3 400 launches per step otherwise)
-            sstep = pkg.trainers.GraphedFn(sstep, (lr_img, hr_img))
-        sec = time_steps(lambda: sstep(lr_img, hr_img), 6, 3, world, dev)
-        out["c5_srgan_x4_adv_step_patches_per_s_batch_16_per_gpu"] = round(world * 16 * 6 / sec, 1)
-        out["c5_srgan_ms_per_step"] = round(1e3 * sec / 6, 3)
+            sstep = pkg.trainers.GraphedSegments(pkg.trainers.srgan_segments(G, D, g_opt, d_opt, g_dp, d_dp), (lr_img, hr_img))
+        else:
+            sstep = pkg.trainers.GraphedFn(pkg.trainers.srgan_step(G, D, g_opt, d_opt), (lr_img, hr_img), flats=[gflat, dflat])
+        k = max(6, nsteps // 2)
+        sec = time_steps(lambda: sstep(lr_img, hr_img), k, 3, world, dev)
+        out["c5_srgan_x4_adv_step_patches_per_s_batch_16_per_gpu"] = round(world * 16 * k / sec, 1)
+        out["c5_srgan_ms_per_step"] = round(1e3 * sec / k, 3)
+        fwd = 2 * C5_G_FWD + 3 * C5_D_FWD      # as executed by the reference: G fwd x2, D fwd x3, ...
+        out["c5_srgan_bf16_pipe_frac"] = round(bf16_pipe_frac(fwd, 2 * fwd, sec / k / 16), 4)
 
     # every side metric is isolated: a failure is reported in the JSON instead of losing the headline line
     sections = ([("c1", c1), ("c3", c3)] if world == 1 else []) + [("c4_strong", c4_strong)] + \
-               ([("c4_weak", c4_weak)] if world > 1 else []) + [("c5", c5)]
+               ([("c4_shard16", c4_shard16)] if world == 1 else [("c4_weak", c4_weak)]) + [("c5", c5)]
     for name, fn in sections:
         try:
             fn()
@@ -271,6 +312,23 @@ def train_extra(pkg, dev, rank, world):
             out[name + "_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
         torch.cuda.empty_cache()
     return out
+
+
+def c2_other_precisions(pkg, net, x, steps, warmup, dev):
+    """The same c2 forward in the fp32-faithful modes: bf16x6 (exact 3-way split, 6 bf16 MFMAs per product) and exact
+    fp32 MFMA — what the headline's bf16x3 products (~5e-6 rel) buy."""
+    res = {}
+    prev = pkg.ops.get_precision()
+    for mode in ("bf16x6", "fp32"):
+        try:
+            pkg.ops.set_precision(mode)
+            with torch.no_grad():
+                sec = time_steps(lambda: net(x), steps, warmup, 1, dev)
+            res["c2_%s_images_per_s" % mode] = round(x.shape[0] * steps / sec, 1)
+        except Exception as e:  # noqa: BLE001
+            res["c2_%s_error" % mode] = "%s: %s" % (type(e).__name__, str(e)[:200])
+    pkg.ops.set_precision(prev)
+    return res
 
 
 def main():
@@ -307,7 +365,7 @@ def main():
     assert tuple(y.shape) == (args.batch, 3, 4 * (args.lr_size - 8), 4 * (args.lr_size - 8))
     sec = time_steps(step, args.steps, args.warmup, world, dev)
     imgs_per_s = world * args.batch * args.steps / sec
-    layer_ms = espcn_layer_events(net, x, max(3, min(args.steps, 10)))
+    layer_ms, layer_kernels = espcn_layer_events(net, x, max(3, min(args.steps, 10)))
 
     # measured device-to-device copy bandwidth on this box (read + write bytes / time), beside the vendor peak
     copy_gbps = None
@@ -334,10 +392,8 @@ def main():
         flop_l2 = 2.0 * args.batch * (H - 6) ** 2 * 32 * 64 * 9
         dom = max(range(3), key=lambda i: layer_ms[i])
         bf3 = pkg.ops.get_precision() != "fp32"
-        names = ["k_conv_bf3_rows<4> conv5x5 3->64 + ReLU", "k_conv_bfw<2> conv3x3 64->32 + ReLU",
-                 "k_conv_bfw<3> conv3x3 32->48 + pixel-shuffle store"] if bf3 else [
-                 "k_conv_mfma_tg<4> conv5x5 3->64 + ReLU", "k_conv_mfma<2> conv3x3 64->32 + ReLU",
-                 "k_conv_mfma<3> conv3x3 32->48 + pixel-shuffle store"]
+        what = ["conv5x5 3->64 + ReLU", "conv3x3 64->32 + ReLU", "conv3x3 32->48 + pixel-shuffle store"]
+        names = ["%s %s" % (k, w) for k, w in zip(layer_kernels, what)]   # kernel ids come from the dispatcher
         peak = BF16X3_PEAK_TFLOPS if bf3 else FP32_MFMA_PEAK_TFLOPS
         flops = [2.0 * args.batch * (H - 4) ** 2 * 64 * 3 * 25, flop_l2, 2.0 * args.batch * (H - 8) ** 2 * 48 * 32 * 9]
         achieved = flops[dom] / (layer_ms[dom] * 1e-3) / 1e12
@@ -360,7 +416,7 @@ def main():
                                  "MFMA peak / 3 (three bf16 MFMAs per fp32-equivalent product)" if bf3 else
                                  "achieved = algorithmic conv FLOPs / live HIP-event kernel time; peak = fp32 MFMA",
                          "kernel_ms": round(layer_ms[dom], 4),
-                         "layer_ms": [round(m, 4) for m in layer_ms],
+                         "layer_ms": [round(m, 4) for m in layer_ms], "layer_kernels": names,
                          "whole_net_hbm": {
                              "achieved_GBps": round(ESPCN_BYTES_PER_IMG * scale * imgs_per_s / world / 1e9, 1),
                              "peak_GBps": HBM_PEAK_GBS, "measured_copy_GBps": copy_gbps,
@@ -371,7 +427,9 @@ def main():
         }
     extra = {}
     if not args.no_extra:
-        extra = train_extra(pkg, dev, rank, world)
+        if world == 1 and pkg.ops.get_precision() == "mixed":
+            extra.update(c2_other_precisions(pkg, net, x, max(5, args.steps // 2), 2, dev))
+        extra.update(train_extra(pkg, dev, rank, world, args.extra_steps))
     if rank == 0:
         if extra:
             result["extra"] = extra

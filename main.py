@@ -27,7 +27,7 @@ def parse_args(argv=None):
     p.add_argument('--gpu_mode', type=bool, default=True)
     p.add_argument('--steps_per_epoch', type=int, default=8)
     p.add_argument('--epoch_pretrain', type=int, default=50, help='SRGAN generator pre-training epochs (srgan.py:179)')
-    p.add_argument('--precision', type=str, default='mixed', choices=['mixed', 'bf16x3', 'fp32'])
+    p.add_argument('--precision', type=str, default='mixed', choices=['mixed', 'bf16x3', 'bf16x6', 'fp32'])
     return check_args(p.parse_args(argv))
 
 

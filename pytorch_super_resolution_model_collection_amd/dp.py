@@ -59,6 +59,7 @@ class DataParallel(object):
     def __init__(self, flat, group=None, bucket_bytes=32 << 20, min_bucket_bytes=256 << 10, trunk_chunk_layers=11):
         self.flat = flat
         self.group = group
+        self.comm_enabled = True
         self.min_bucket_elems = max(1, int(min_bucket_bytes) // 4)   # smaller final runs wait for a neighbour
         self.trunk_chunk_layers = int(trunk_chunk_layers)             # layers per grouped weight-gradient launch under DP
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -136,6 +137,8 @@ class DataParallel(object):
         return out
 
     def send(self, ranges, works):
+        if not self.comm_enabled:   # measurement only (bench.py: step time without the exchange = exposed communication)
+            return
         g = self.flat.grad
         for lo, hi in ranges:
             for b0 in range(lo, hi, self.bucket_elems):

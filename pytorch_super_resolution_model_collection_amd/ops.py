@@ -39,13 +39,16 @@ FUSE_ESPCN_HEAD = False
 #            the mask-flip sensitivity above).
 #   "fp32"   everything exact fp32 (summation-order-level agreement with ATen/oneDNN).
 _MODES = {"mixed": {"infer": ALGO_AUTO, "train_fwd": _lib.ALGO_MFMA_BF16X6, "bwd": ALGO_AUTO},
+          # fp32-faithful products everywhere they exist (inference included): what "mixed" costs when bf16x3's ~5e-6 is
+          # not acceptable for the forward either
+          "bf16x6": {"infer": _lib.ALGO_MFMA_BF16X6, "train_fwd": _lib.ALGO_MFMA_BF16X6, "bwd": ALGO_AUTO},
           "bf16x3": {"infer": ALGO_AUTO, "train_fwd": ALGO_AUTO, "bwd": ALGO_AUTO},
           "fp32": {"infer": _lib.ALGO_MFMA, "train_fwd": _lib.ALGO_MFMA, "bwd": _lib.ALGO_MFMA}}
 _PRECISION = {"mode": "mixed"}
 
 
 def set_precision(mode):
-    """Select the convolution arithmetic: 'mixed' (default), 'bf16x3' or 'fp32' (see above)."""
+    """Select the convolution arithmetic: 'mixed' (default), 'bf16x3', 'bf16x6' or 'fp32' (see above)."""
     if mode not in _MODES:
         raise ValueError("precision must be one of %s" % sorted(_MODES))
     _PRECISION["mode"] = mode

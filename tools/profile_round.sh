@@ -5,7 +5,7 @@
 #   3. the same for one EDSR x4 training step (c4) so the train-path kernels are on record as well
 # Output: gpurun_out/prof_<tag>/...; tools/summarize_prof.py turns it into profiles/<tag>_*.{csv,json}.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -19,6 +19,11 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/c2_write -o c2 -- $C2 > $
 # matrix-core and LDS activity of the same command (SQ counters share a pass: 8 SQ slots)
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/c2_sq -o c2 -- $C2 > $OUT/c2_sq.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_kt -o c4 -- $C4 > $OUT/c4_kt.log 2>&1
+# the other training configs: c3 (VDSR, batch 256), c5 (SRGAN adversarial step), and the 16-patch EDSR shard that bounds
+# 8-GPU strong scaling (kernel traces only)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3_kt -o c3 -- python $ROOT/tools/vdsr_step.py 256 > $OUT/c3_kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_kt -o c5 -- python $ROOT/tools/srgan_step.py 16 > $OUT/c5_kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4s16_kt -o c4s16 -- python $ROOT/tools/edsr_b16.py 16 > $OUT/c4s16_kt.log 2>&1
 cd $ROOT
 python tools/summarize_prof.py $TAG > $OUT/summary.log 2>&1
 cat $OUT/summary.log | tail -30

@@ -9,7 +9,7 @@ bench.py reads <tag>_c2_pmc_traffic.json for `roofline.traffic` (the counters ca
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 
@@ -19,7 +19,7 @@ def find(sub, suffix):
     return hits[0] if hits else None
 
 
-for wl in ("c2", "c4"):
+for wl in ("c2", "c4", "c3", "c5", "c4s16"):
     f = find(wl + "_kt", "kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, wl)))
