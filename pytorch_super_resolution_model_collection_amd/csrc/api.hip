@@ -65,9 +65,9 @@ int conv_wgrad_bf_grouped(const srk_conv_desc& d, int n, const float* const* xs,
                           size_t ws_bytes, hipStream_t s);
 constexpr int kMaxWgradGroup = 40;  // = WB_MAXGROUP of conv_wgrad_bf16.hip
 
-// conv_fused2_bf16.hip
-int conv_fused2_forward(const srk_conv_desc& d1, const srk_conv_desc& d2, const float* x, int x_nchw,
-                        const float* wp1, const float* wp2, float* y, const Epi& ep1, const Epi& ep2, hipStream_t s);
+// conv_bfw.hip (fused first layer)
+int conv_bfw_fused_forward(const srk_conv_desc& d1, const srk_conv_desc& d2, const float* x, int x_nchw,
+                           const float* wp1, const float* wp2, float* y, const Epi& ep1, const Epi& ep2, hipStream_t s);
 
 // conv_mfma_bf16.hip
 int pack_weights_batched(const float* params, void* packed, const long long* table, int n_layers, int blocks,
@@ -337,8 +337,8 @@ extern "C" int srk_conv2d_fused2_forward(const srk_conv_desc* d1, const srk_conv
   SRK_REQUIRE(x && w1_packed_fwd && w2_packed_fwd && y, "conv2d_fused2_forward: null tensor pointer");
   const Epi e1 = make_epi(ep1), e2 = make_epi(ep2);
   SRK_REQUIRE(e2.act != SRK_ACT_PRELU || (e2.prelu_w && e2.prelu_n >= 1), "conv2d_fused2_forward: PReLU needs its weight");
-  return conv_fused2_forward(*d1, *d2, x, x_is_nchw ? 1 : 0, w1_packed_fwd, w2_packed_fwd, y, e1, e2,
-                             (hipStream_t)stream);
+  return conv_bfw_fused_forward(*d1, *d2, x, x_is_nchw ? 1 : 0, w1_packed_fwd, w2_packed_fwd, y, e1, e2,
+                                (hipStream_t)stream);
 }
 
 extern "C" int srk_pack_weights_batched(const float* params_base, void* packed_base, const int64_t* table, int n_layers,

@@ -16,11 +16,11 @@ from ._lib import (ACT_BY_NAME, ACT_LRELU, ACT_NONE, ACT_PRELU, ACT_RELU, ALGO_A
 
 CL = torch.channels_last
 
-# ESPCNNet inference through the LDS-fused conv5+conv3 kernel (srk_conv2d_fused2_forward).  Correct and
-# tested, but measured SLOWER than the two separate kernels on MI355X (1.44 ms vs 1.01 ms for the c2
-# batch): at the current ~30 % MFMA-phase efficiency the extra halo recompute + 47 %-dense conv1 K
-# costs more than the 2 GB of HBM traffic it removes.  Off by default.
-FUSE_ESPCN_HEAD = False
+# ESPCNNet inference through the fused conv5+ReLU -> conv3+ReLU kernel (srk_conv2d_fused2_forward): the producer waves
+# of the wave-specialised conv3 kernel compute conv5 on the matrix cores straight into the LDS halo planes, so the
+# 64-channel intermediate (2.1 of the 3.9 GB the net moves per 64-image batch) never touches HBM.  SRK_FUSE_HEAD=0
+# runs the layers one by one.
+FUSE_ESPCN_HEAD = os.environ.get("SRK_FUSE_HEAD", "1") != "0"
 
 # Convolution arithmetic used when a ConvCfg leaves algo = AUTO, per role:
 #   infer     forward under torch.no_grad()
@@ -511,8 +511,8 @@ def conv2d_fused2_infer(x, conv1, act1, slope1, conv2, act2, slope2, prelu2=None
     envelope or the precision mode forbids bf16x3, so the caller can run the layers one by one."""
     if _PRECISION["mode"] == "fp32" or x.dim() != 4:
         return None
-    if (conv1.in_channels > 4 or conv1.out_channels % 64 or conv1._s != 1 or conv2._s != 1
-            or conv2.in_channels != conv1.out_channels or conv2.out_channels < 8 or act1 == ACT_PRELU):
+    if (conv1.in_channels > 4 or conv1.out_channels % 32 or conv1.out_channels < 64 or conv1._s != 1 or conv2._s != 1
+            or conv2.in_channels != conv1.out_channels or conv2.out_channels not in (16, 32, 48) or act1 == ACT_PRELU):
         return None
     lib = _lib.load()
     require_cuda(x, conv1.weight, conv2.weight)

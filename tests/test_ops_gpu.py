@@ -354,9 +354,11 @@ def test_errors_are_loud(gpu):
 @pytest.mark.parametrize("k1,p1,k2,p2,c1,c2,act,nchw,hw", [
     (5, 0, 3, 0, 64, 32, "relu", True, (40, 37)),     # ESPCN head (espcn.py:18-19), NCHW input, ragged size
     (5, 0, 3, 0, 64, 32, "relu", False, (23, 50)),
-    (3, 1, 3, 1, 64, 64, "lrelu", True, (19, 21)),    # padded convs: zero padding of the fused intermediate
-    (9, 4, 1, 0, 64, 48, None, False, (17, 16)),
-    (5, 2, 5, 2, 128, 80, "relu", True, (13, 30)),    # C1 = 128 (4 chunks), C2 > 64 (two output blocks)
+    (5, 0, 3, 0, 64, 32, "relu", True, (150, 170)),   # every block walks several tiles: window / halo double buffering
+    (3, 1, 3, 1, 64, 48, "lrelu", True, (19, 21)),    # padded convs: zero padding of the fused intermediate
+    (9, 4, 1, 0, 64, 48, None, False, (17, 16)),      # 9-wide first kernel: two K steps per kernel row; 1x1 second conv
+    (5, 2, 5, 2, 128, 16, "relu", True, (13, 30)),    # C1 = 128 (4 chunks per tile), 5x5 second conv (dynamic tap loop)
+    (3, 0, 3, 0, 96, 32, "relu", True, (64, 64)),     # 3 chunks per tile
 ])
 def test_conv_fused2(gpu, k1, p1, k2, p2, c1, c2, act, nchw, hw):
     """conv -> act -> conv -> act fused through LDS (srk_conv2d_fused2_forward) vs torch CPU."""
@@ -380,7 +382,12 @@ def test_conv_fused2(gpu, k1, p1, k2, p2, c1, c2, act, nchw, hw):
     with torch.no_grad():
         y = pkg.ops.conv2d_fused2_infer(xg, conv1, a[0], a[1], conv2, a[0], a[1])
     assert y is not None, "fused kernel declined a shape inside its envelope"
+    assert _pkg()._lib.load().srk_last_kernel_name().decode().endswith("fused>")
     assert rel_err(y, ref.detach()) < 1e-4
+    # outside the envelope the call declines (None) and the caller runs the layers one by one
+    wide = L.Conv2d(c1, 64, 3, 1, 1).to(gpu)
+    with torch.no_grad():
+        assert pkg.ops.conv2d_fused2_infer(xg, conv1, a[0], a[1], wide, 0, 0.0) is None
 
 
 class _OneParam(torch.nn.Module):
