@@ -64,7 +64,11 @@ struct BfwParams {
 constexpr int BFW_MT1 = 6;  // conv1 M-tiles (16 halo pixels) per producer wave: halos of <= 4 * 6 * 16 = 384 pixels
 constexpr int BFW_IT0 = 2;  // input-window pixels per producer thread: windows of <= 512 pixels
 
-template <int NTW, int TT, int MTW, bool FUSE>
+// Q1C (fused only): conv1 K steps when its filter is REGISTER-RESIDENT (two 32-channel chunks, kernel width <= 8, e.g.
+// 5 for ESPCN's 5x5): producer wave w keeps the fragments of ONE 16-channel tile (w & 1) of BOTH chunks — 4 * Q1C
+// uint4 — for the whole kernel and computes that channel tile for every other pixel tile (parity w >> 1).  Q1C = 0:
+// any conv1 geometry, fragments re-read from L1 / L2 every stage (5 exposed load latencies per stage: 3x slower).
+template <int NTW, int TT, int MTW, bool FUSE, int Q1C = 0>
 __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_conv_bfw(BfwParams B) {
   constexpr int NCW = 16 / MTW;          // consumer waves: MTW 16-pixel groups each, 256 pixels per block
   constexpr int NTHR = 64 * (NCW + 4);   // + 4 producer waves
@@ -181,6 +185,91 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
         }
       };
       // conv1 M-tiles of this wave: halo pixels (pw4 + 4 i) * 16 + j
+      // ---- register-resident filter (Q1C > 0) -------------------------------------------------------------------
+      constexpr int QR = Q1C > 0 ? Q1C : 1;
+      uint4 fw0[QR][2], fw1[QR][2];  // [K step][plane] of channel tile (pw4 & 1), chunk 0 / chunk 1
+      if constexpr (Q1C > 0) {
+#pragma unroll
+        for (int q = 0; q < Q1C; ++q) {
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            const int co0 = (pw4 & 1) * 16 + j, co1 = 32 + co0;
+            fw0[q][pl] = B.wq1[((size_t)q * B.OCb1 + (co0 >> 6)) * 512 + (pl * 4 + kq) * 64 + (co0 & 63)];
+            fw1[q][pl] = B.wq1[((size_t)q * B.OCb1 + (co1 >> 6)) * 512 + (pl * 4 + kq) * 64 + (co1 & 63)];
+          }
+        }
+      }
+      auto conv1r = [&](int s) {
+        const int ti = s >> 1, cc = s & 1;
+        int n, r0, c0;
+        tile_of(ti, n, r0, c0);
+        const int h2y = r0 + P.iy0, h2x = c0 + P.ix0;
+        const uint2* lw = l0 + (size_t)(ti & 1) * l0buf;
+        uint2* hal2 = reinterpret_cast<uint2*>(hal0 + (size_t)(s & 1) * hbuf);
+        const int nt = pw4 & 1;
+        const int col = nt * 16 + kq * 4, co = cc * 32 + col;  // this lane's 4 channels
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (B.bias1) b4 = *reinterpret_cast<const f32x4*>(B.bias1 + co);
+        const int g = col >> 3, half = (col >> 2) & 1;
+        auto pass = [&](const uint4 (&fw)[QR][2], int mt0) {  // pixel tiles mt0, mt0 + 2, mt0 + 4
+          f32x4 a[3];
+          int off[3], pix[3];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            a[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int p = (mt0 + 2 * t) * 16 + j;
+            pix[t] = p;
+            const int pp = p < npix ? p : 0;
+            const int r = pp / P.HW, c = pp - r * P.HW;
+            off[t] = r * B.HW0 + c + 2 * kq;
+          }
+          if (!(B.dbg & 4)) {
+#pragma unroll
+            for (int q = 0; q < QR; ++q) {
+#pragma unroll
+              for (int t = 0; t < 3; ++t) {
+                if (mt0 + 2 * t < mt1_count) {  // wave-uniform
+                  const uint2* pp = lw + off[t] + q * B.HW0;   // (KS1 == 1: K step q = kernel row q)
+                  const uint2 h0 = pp[0], h1 = pp[1];
+                  const uint2 q0 = pp[B.NPIX0p], q1 = pp[B.NPIX0p + 1];
+                  const uint4 ah = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                  const uint4 al = make_uint4(q0.x, q0.y, q1.x, q1.y);
+                  a[t] = mfma16(fw[q][0], al, a[t]);
+                  a[t] = mfma16(fw[q][1], ah, a[t]);
+                  a[t] = mfma16(fw[q][0], ah, a[t]);
+                }
+              }
+            }
+          }
+          if (B.dbg & 16) return;
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            if (mt0 + 2 * t < mt1_count && pix[t] < npix) {
+              const int r1 = pix[t] / P.HW, c1 = pix[t] - r1 * P.HW;
+              const bool inside = (unsigned)(h2y + r1) < (unsigned)B.H1 && (unsigned)(h2x + c1) < (unsigned)B.W1;
+              typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+              bf16x4 h, l;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float v = 0.f;
+                if (inside) v = act_apply(a[t][e] + b4[e], B.act1, B.slope1);
+                const __bf16 hh = (__bf16)v;
+                h[e] = hh;
+                l[e] = (__bf16)(v - (float)hh);
+              }
+              hal2[((0 * 4 + g) * B.NPIXp + pix[t]) * 2 + half] = __builtin_bit_cast(uint2, h);
+              hal2[((1 * 4 + g) * B.NPIXp + pix[t]) * 2 + half] = __builtin_bit_cast(uint2, l);
+            }
+          }
+        };
+        for (int mt0 = pw4 >> 1; mt0 < mt1_count; mt0 += 6) {
+          if (cc == 0)
+            pass(fw0, mt0);
+          else
+            pass(fw1, mt0);
+        }
+      };
+      // ---- any conv1 geometry: fragments from global memory every stage -----------------------------------------
       int off1[BFW_MT1];
 #pragma unroll
       for (int i = 0; i < BFW_MT1; ++i) {
@@ -298,14 +387,18 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
         win_commit(0);
       }
       __syncthreads();  // window of tile 0 (and the filter) visible to all producer waves
-      if (S > 0 && T > 0) conv1(0);
+      if (S > 0 && T > 0) {
+        if constexpr (Q1C > 0) conv1r(0); else conv1(0);
+      }
       // (ICc >= 2 here.)  Window of tile 1: first needed by conv1(ICc) during stage ICc - 1, committed at the end of
       // stage ICc - 2, loaded now
       if (count > 1) win_issue(1);
       __syncthreads();  // stage 0 visible
       for (int s = 0; s < S; ++s) {
         if (T > 0) {
-          if (s + 1 < S) conv1(s + 1);
+          if (s + 1 < S) {
+            if constexpr (Q1C > 0) conv1r(s + 1); else conv1(s + 1);
+          }
           if ((s + 2) % B.ICc == 0) {  // commit the window whose first conv1 runs during stage s + 1
             const int tc = (s + 2) / B.ICc;
             if (tc < count) win_commit(tc);
@@ -596,13 +689,23 @@ static int bfw_launch_t(const BfwParams& B, size_t lds, int grid, hipStream_t s)
   hipLaunchKernelGGL((k_conv_bfw<NTW, TT, MTW, false>), dim3(grid), dim3(64 * (16 / MTW + 4)), lds, s, B);
   return check_launch("conv_bfw");
 }
+template <int NTW, int TT, int Q1C>
+static int bfw_launch_fused_q(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, 2, true, Q1C>), lds);
+  note_kernel("k_conv_bfw<%d,%d,2,fused>", NTW, TT);
+  hipLaunchKernelGGL((k_conv_bfw<NTW, TT, 2, true, Q1C>), dim3(grid), dim3(64 * 12), lds, s, B);
+  return check_launch("conv_bfw_fused");
+}
 template <int NTW, int TT>
 static int bfw_launch_fused(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
-  static LdsLimit lim;
-  lim.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, 2, true>), lds);
-  note_kernel("k_conv_bfw<%d,%d,2,fused>", NTW, TT);
-  hipLaunchKernelGGL((k_conv_bfw<NTW, TT, 2, true>), dim3(grid), dim3(64 * 12), lds, s, B);
-  return check_launch("conv_bfw_fused");
+  // register-resident first-layer filter: two 32-channel chunks, one K step per kernel row, 3 or 5 rows
+  static const int regw_env = getenv("SRK_BFW_REGW") ? atoi(getenv("SRK_BFW_REGW")) : 1;
+  if (regw_env && B.ICc == 2 && B.KS1 == 1 && TT == 9) {
+    if (B.KH1 == 5) return bfw_launch_fused_q<NTW, TT, 5>(B, lds, grid, s);
+    if (B.KH1 == 3) return bfw_launch_fused_q<NTW, TT, 3>(B, lds, grid, s);
+  }
+  return bfw_launch_fused_q<NTW, TT, 0>(B, lds, grid, s);
 }
 template <int NTW>
 static int bfw_launch(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
