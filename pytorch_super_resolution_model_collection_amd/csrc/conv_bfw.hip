@@ -211,41 +211,60 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
         f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
         if (B.bias1) b4 = *reinterpret_cast<const f32x4*>(B.bias1 + co);
         const int g = col >> 3, half = (col >> 2) & 1;
-        auto pass = [&](const uint4 (&fw)[QR][2], int mt0) {  // pixel tiles mt0, mt0 + 2, mt0 + 4
-          f32x4 a[3];
-          int off[3], pix[3];
+        // One pass = NTP pixel tiles (mt0, mt0 + 2, ...) through all QR kernel rows.  The producer is a latency chain
+        // unless its LDS fragment reads run ahead of the MFMAs: the fragments of kernel row q + 1 (all NTP tiles) are in
+        // flight while the MFMAs of row q issue, tile-interleaved so that consecutive MFMAs never share an accumulator.
+        constexpr int NTP = 2;
+        auto pass = [&](const uint4 (&fw)[QR][2], int mt0) {
+          f32x4 a[NTP];
+          int off[NTP], rc[NTP];
+          bool live[NTP];
 #pragma unroll
-          for (int t = 0; t < 3; ++t) {
+          for (int t = 0; t < NTP; ++t) {
             a[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int p = (mt0 + 2 * t) * 16 + j;
-            pix[t] = p;
+            live[t] = mt0 + 2 * t < mt1_count;  // wave-uniform
             const int pp = p < npix ? p : 0;
             const int r = pp / P.HW, c = pp - r * P.HW;
             off[t] = r * B.HW0 + c + 2 * kq;
+            rc[t] = p < npix ? ((r << 16) | c) : -1;
           }
-          if (!(B.dbg & 4)) {
+          uint4 fh[2][NTP], fl[2][NTP];
+          auto afrag = [&](int q, uint4 (&ah)[NTP], uint4 (&al)[NTP]) {
 #pragma unroll
-            for (int q = 0; q < QR; ++q) {
-#pragma unroll
-              for (int t = 0; t < 3; ++t) {
-                if (mt0 + 2 * t < mt1_count) {  // wave-uniform
-                  const uint2* pp = lw + off[t] + q * B.HW0;   // (KS1 == 1: K step q = kernel row q)
-                  const uint2 h0 = pp[0], h1 = pp[1];
-                  const uint2 q0 = pp[B.NPIX0p], q1 = pp[B.NPIX0p + 1];
-                  const uint4 ah = make_uint4(h0.x, h0.y, h1.x, h1.y);
-                  const uint4 al = make_uint4(q0.x, q0.y, q1.x, q1.y);
-                  a[t] = mfma16(fw[q][0], al, a[t]);
-                  a[t] = mfma16(fw[q][1], ah, a[t]);
-                  a[t] = mfma16(fw[q][0], ah, a[t]);
-                }
+            for (int t = 0; t < NTP; ++t) {
+              if (live[t]) {
+                const uint2* pp = lw + off[t] + q * B.HW0;   // (KS1 == 1: K step q = kernel row q)
+                const uint2 h0 = pp[0], h1 = pp[1];
+                const uint2 q0 = pp[B.NPIX0p], q1 = pp[B.NPIX0p + 1];
+                ah[t] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                al[t] = make_uint4(q0.x, q0.y, q1.x, q1.y);
               }
             }
+          };
+          if (!(B.dbg & (4 | 64))) {
+            afrag(0, fh[0], fl[0]);
+            srk_static_for<0, QR>([&](auto qc) {
+              constexpr int q = decltype(qc)::value;
+              if (q + 1 < QR) afrag(q + 1, fh[(q + 1) & 1], fl[(q + 1) & 1]);
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int t = 0; t < NTP; ++t)
+                if (live[t]) a[t] = mfma16(fw[q][0], fl[q & 1][t], a[t]);
+#pragma unroll
+              for (int t = 0; t < NTP; ++t)
+                if (live[t]) a[t] = mfma16(fw[q][1], fh[q & 1][t], a[t]);
+#pragma unroll
+              for (int t = 0; t < NTP; ++t)
+                if (live[t]) a[t] = mfma16(fw[q][0], fh[q & 1][t], a[t]);
+              __builtin_amdgcn_sched_barrier(0);
+            });
           }
           if (B.dbg & 16) return;
 #pragma unroll
-          for (int t = 0; t < 3; ++t) {
-            if (mt0 + 2 * t < mt1_count && pix[t] < npix) {
-              const int r1 = pix[t] / P.HW, c1 = pix[t] - r1 * P.HW;
+          for (int t = 0; t < NTP; ++t) {
+            if (live[t] && rc[t] >= 0) {
+              const int r1 = rc[t] >> 16, c1 = rc[t] & 0xffff;
               const bool inside = (unsigned)(h2y + r1) < (unsigned)B.H1 && (unsigned)(h2x + c1) < (unsigned)B.W1;
               typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
               bf16x4 h, l;
@@ -257,12 +276,13 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
                 h[e] = hh;
                 l[e] = (__bf16)(v - (float)hh);
               }
-              hal2[((0 * 4 + g) * B.NPIXp + pix[t]) * 2 + half] = __builtin_bit_cast(uint2, h);
-              hal2[((1 * 4 + g) * B.NPIXp + pix[t]) * 2 + half] = __builtin_bit_cast(uint2, l);
+              const int px = (mt0 + 2 * t) * 16 + j;
+              hal2[((0 * 4 + g) * B.NPIXp + px) * 2 + half] = __builtin_bit_cast(uint2, h);
+              hal2[((1 * 4 + g) * B.NPIXp + px) * 2 + half] = __builtin_bit_cast(uint2, l);
             }
           }
         };
-        for (int mt0 = pw4 >> 1; mt0 < mt1_count; mt0 += 6) {
+        for (int mt0 = pw4 >> 1; mt0 < mt1_count; mt0 += 2 * NTP) {
           if (cc == 0)
             pass(fw0, mt0);
           else
@@ -558,7 +578,7 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    if (wave_live && T > 0 && !(B.dbg & 4)) {
+    if (wave_live && T > 0 && !(B.dbg & (4 | 128))) {
       const uint4* hal = hal0 + (size_t)(s & 1) * hbuf;
       const uint4* wb = wl + (size_t)cc * wslot;
       const size_t wstep = (size_t)B.ICc * wslot;
