@@ -158,15 +158,6 @@ int srk_pack_weights_batched(const float* params_base, void* packed_base, const 
 /* ---- convolution (Conv2d / ConvTranspose2d: base_networks.py:42,77,112-113,156; fsrcnn.py:33) */
 int srk_conv2d_forward(const srk_conv_desc* d, const float* x, const float* w_packed_fwd, float* y,
                        const srk_epilogue* ep, void* stream);
-/* Two stride-1 Conv2d layers fused through LDS (inference): y = ep2(conv2(ep1(conv1(x)))) with
- * conv1: Cin <= 4 -> C1 (multiple of 64) and conv2: C1 -> C2 — e.g. ESPCN's conv5(3->64)+ReLU ->
- * conv3(64->32)+ReLU (espcn.py:18-19).  The C1-channel intermediate never touches HBM.  `x` may be
- * NHWC (x_is_nchw = 0) or the caller's original NCHW tensor (x_is_nchw = 1, saves the layout copy).
- * ep1 supports bias + none/relu/lrelu/tanh/sigmoid; ep2 is a full srk_epilogue.  bf16x3 arithmetic.
- * Returns SRK_ERR_UNSUPPORTED outside that envelope (run the two layers separately then). */
-int srk_conv2d_fused2_forward(const srk_conv_desc* d1, const srk_conv_desc* d2, const float* x, int x_is_nchw,
-                              const float* w1_packed_fwd, const float* w2_packed_fwd, float* y,
-                              const srk_epilogue* ep1, const srk_epilogue* ep2, void* stream);
 /* dx = d(loss)/dx given dy; optional act-grad prologue on dy; optional fused "+ add_to"
  * (gradient fan-in of a residual connection).  Replaces aten::convolution_backward (input
  * gradient) as dispatched from loss.backward() — edsr.py:154, vdsr.py:146, srgan.py:286,309. */

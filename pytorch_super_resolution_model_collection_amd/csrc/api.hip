@@ -65,10 +65,6 @@ int conv_wgrad_bf_grouped(const srk_conv_desc& d, int n, const float* const* xs,
                           size_t ws_bytes, hipStream_t s);
 constexpr int kMaxWgradGroup = 40;  // = WB_MAXGROUP of conv_wgrad_bf16.hip
 
-// conv_bfw.hip (fused first layer)
-int conv_bfw_fused_forward(const srk_conv_desc& d1, const srk_conv_desc& d2, const float* x, int x_nchw,
-                           const float* wp1, const float* wp2, float* y, const Epi& ep1, const Epi& ep2, hipStream_t s);
-
 // conv_mfma_bf16.hip
 int pack_weights_batched(const float* params, void* packed, const long long* table, int n_layers, int blocks,
                          hipStream_t s);
@@ -130,7 +126,7 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
   // ... and their data gradients (<= 3 input channels, TRANS gather): taps-in-K bf16x3 kernel
   if ((algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3) && conv_tapk_gather_supported(g, ep, out, mask_y))
     return conv_tapk_gather(g, in, wp, out, ep, s);
-  // the bfd / bfr kernels are compiled without the scalar store fallback
+  // the bfd kernels are compiled without the scalar store fallback
   const bool bfd_ok = conv_bfd_gather_supported(g, ep) && conv_epi_all_vector(g.OC, ep, out);
   if (algo == SRK_ALGO_MFMA_BF16X6) {  // fp32-faithful class: bf16x6 where it applies, else the exact fp32 kernels
     if (bfd_ok && !direct_ok) return conv_bfd_gather(g, in, wp, out, ep, mask_y, mask_slope, 3, s);
@@ -151,10 +147,6 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
       return conv_bfd_gather(g, in, wp, out, ep, mask_y, mask_slope, 2, s);
     if (conv_bfw_applicable(g, ep, in, out, mask_y)) {  // wave-specialised persistent kernel (ESPCN-size layers)
       const int rc = conv_bfw_gather(g, in, wp, out, ep, s);
-      if (rc >= 0) return rc;
-    }
-    if (bfd_ok && conv_bfr_applicable(g, mask_y)) {  // filter resident in LDS, persistent blocks (ESPCN-size layers)
-      const int rc = conv_bfr_gather(g, in, wp, out, ep, s);
       if (rc >= 0) return rc;
     }
     return conv_bf3_gather(g, in, wp, out, ep, mask_y, mask_slope, s);
@@ -325,20 +317,6 @@ extern "C" int srk_conv2d_backward_weight_grouped(const srk_conv_desc* d, int n,
     if (rc) return rc;
   }
   return SRK_OK;
-}
-
-extern "C" int srk_conv2d_fused2_forward(const srk_conv_desc* d1, const srk_conv_desc* d2, const float* x,
-                                         int x_is_nchw, const float* w1_packed_fwd, const float* w2_packed_fwd,
-                                         float* y, const srk_epilogue* ep1, const srk_epilogue* ep2, void* stream) {
-  int rc = validate_desc(d1, "conv2d_fused2_forward(conv1)");
-  if (rc) return rc;
-  rc = validate_desc(d2, "conv2d_fused2_forward(conv2)");
-  if (rc) return rc;
-  SRK_REQUIRE(x && w1_packed_fwd && w2_packed_fwd && y, "conv2d_fused2_forward: null tensor pointer");
-  const Epi e1 = make_epi(ep1), e2 = make_epi(ep2);
-  SRK_REQUIRE(e2.act != SRK_ACT_PRELU || (e2.prelu_w && e2.prelu_n >= 1), "conv2d_fused2_forward: PReLU needs its weight");
-  return conv_bfw_fused_forward(*d1, *d2, x, x_is_nchw ? 1 : 0, w1_packed_fwd, w2_packed_fwd, y, e1, e2,
-                                (hipStream_t)stream);
 }
 
 extern "C" int srk_pack_weights_batched(const float* params_base, void* packed_base, const int64_t* table, int n_layers,

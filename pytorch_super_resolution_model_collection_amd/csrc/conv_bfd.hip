@@ -395,233 +395,8 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, 2) void k_conv_bfd(
 }
 
 // ---------------------------------------------------------------------------------------------
-// "Resident" persistent kernel for layers whose whole prepared filter (<= ~75 KB) fits in LDS next
-// to one halo chunk (the ESPCN 64->32 and 32->48 layers: the c2 benchmark).
-//
-// One block per CU (4 pixel-waves x NOW channel-waves) copies the filter into LDS ONCE and then
-// walks pixel tiles blockIdx.x, +gridDim.x, ...  The tap loop reads A and B fragments from LDS and
-// contains NO barrier and NO global-memory wait, so the global loads of the NEXT (tile, chunk) halo
-// — issued into registers right before the tap loop — stay in flight during all T taps of MFMAs
-// (with per-tap filter loads in the loop, the in-order vmcnt counter would force them to land
-// within the first tap).  The epilogue's stores are fire-and-forget and drain under the next tile.
-// ---------------------------------------------------------------------------------------------
-template <int NTW, int NOW>
-__global__ __launch_bounds__(256 * NOW, NOW) void k_conv_bfr(BfdParams B, int ntiles) {
-  constexpr int NTHR = 256 * NOW;
-  constexpr int PPP = NTHR / 4;              // halo pixels per staging pass
-  constexpr int IT = 384 / PPP;              // register batches: halos of <= 384 pixels
-  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
-  __shared__ int tap_toff[BFD_MAXTAPS];
-  const MfmaConvParams& P = B.P;
-  const int NB = B.NB;
-  const int wslot = 8 * NB;
-  const int T = P.KHv * P.KWv;
-  uint4* wl = smem4;                                  // [T][ICc][2][4][NB]
-  uint4* hal = smem4 + (size_t)T * B.ICc * wslot;     // [2][4][NPIXp]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int pw = wave & 3, ow = wave >> 2;
-  const int j = lane & 15, kq = lane >> 4;
-  const int ocbi = blockIdx.y;
-  const int ocb = ocbi * 64;
-  const int npx = P.TH * P.TW;
-  const int npix = P.HH * P.HW;
-
-  for (int t = tid; t < T; t += NTHR) {
-    const int u = t / P.KWv, v = t - u * P.KWv;
-    tap_toff[t] = u * P.HW + v;
-  }
-  // whole filter of this 64-channel output block -> LDS, slot (t, cc) at (t*ICc + cc)*wslot
-  for (int e = tid; e < T * B.ICc * wslot; e += NTHR) {
-    const int slot = e / wslot, w = e - slot * wslot;
-    const int t = slot / B.ICc, cc = slot - t * B.ICc;
-    const int u = t / P.KWv, v = t - u * P.KWv;
-    const int tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
-    wl[e] = B.wq[((size_t)(tapw * B.ICc + cc) * B.OCb + ocbi) * (size_t)wslot + w];
-  }
-  int hp[4];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    int m = pw * 64 + mt * 16 + j;
-    if (m >= npx) m = 0;
-    const int r = m / P.TW, c = m - r * P.TW;
-    hp[mt] = (r * P.is) * P.HW + c * P.is + kq * B.NPIXp;
-  }
-  const bool wave_live = pw * 64 < npx;
-  const int plane = 4 * B.NPIXp;
-  const int wlane = kq * NB + j + ow * NTW * 16;
-
-  // halo prefetch: thread -> (8-channel group g, halo pixels hp0 + PPP k)
-  const int g = tid & 3, hp0 = tid >> 2;
-  const int hy0 = hp0 / P.HW, hx0 = hp0 - hy0 * P.HW;
-  const int dyp = PPP / P.HW, dxp = PPP - dyp * P.HW;
-  f32x4 pv0[IT], pv1[IT];
-
-  auto decode = [&](int tile, int& n, int& r0, int& c0) {
-    const int txi = tile % P.tiles_x;
-    const int q = tile / P.tiles_x;
-    const int tyi = q % P.tiles_y;
-    n = q / P.tiles_y;
-    r0 = tyi * P.TH;
-    c0 = txi * P.TW;
-  };
-  auto issue = [&](int tile, int cc) {
-    int n, r0, c0;
-    decode(tile, n, r0, c0);
-    const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
-    const int ch = cc * 32 + g * 8;
-    const bool ch_any = ch < P.IC, ch_vec = P.vec_in && ch + 7 < P.IC;
-    const size_t img = (size_t)n * P.IH;
-    int hy = hy0, hx = hx0;
-#pragma unroll
-    for (int k = 0; k < IT; ++k) {
-      pv0[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      pv1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int iy = iyb + hy, ix = ixb + hx;
-      if (hp0 + PPP * k < npix && ch_any && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) {
-        const size_t off = ((img + iy) * P.IW + ix) * P.IC + ch;
-        if (ch_vec) {
-          pv0[k] = *reinterpret_cast<const f32x4*>(P.in + off);
-          pv1[k] = *reinterpret_cast<const f32x4*>(P.in + off + 4);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (ch + e < P.IC) pv0[k][e] = P.in[off + e];
-            if (ch + 4 + e < P.IC) pv1[k][e] = P.in[off + 4 + e];
-          }
-        }
-      }
-      hy += dyp;
-      hx += dxp;
-      if (hx >= P.HW) {
-        hx -= P.HW;
-        ++hy;
-      }
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int k = 0; k < IT; ++k) {
-      const int hq = hp0 + PPP * k;
-      if (hq < npix) {
-        float f[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          f[e] = pv0[k][e];
-          f[4 + e] = pv1[k][e];
-        }
-        uint4 pl[2];
-        split8n<2>(f, pl);
-        hal[(0 * 4 + g) * B.NPIXp + hq] = pl[0];
-        hal[(1 * 4 + g) * B.NPIXp + hq] = pl[1];
-      }
-    }
-  };
-
-  int tile = blockIdx.x;
-  if (T > 0 && tile < ntiles) issue(tile, 0);
-  for (; tile < ntiles; tile += gridDim.x) {
-    int n, r0, c0;
-    decode(tile, n, r0, c0);
-    f32x4 acc[4][NTW];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (T > 0) {
-      for (int cc = 0; cc < B.ICc; ++cc) {
-        __syncthreads();  // halo region free (previous taps / epilogue done); first pass: filter + tables visible
-        commit();
-        __syncthreads();
-        if (cc + 1 < B.ICc)
-          issue(tile, cc + 1);
-        else if (tile + (int)gridDim.x < ntiles)
-          issue(tile + (int)gridDim.x, 0);
-        if (wave_live) {
-          // software-pipelined tap loop: the LDS fragment reads of tap t+1 are issued before the MFMAs of tap t
-          const uint4* wb = wl + (size_t)cc * wslot + wlane;
-          const size_t wstep = (size_t)B.ICc * wslot;
-          uint4 a0[2][4], b0[2][NTW], a1[2][4], b1[2][NTW];
-          auto load_frags = [&](int t, uint4 (&a)[2][4], uint4 (&b)[2][NTW]) {
-            const uint4* hb = hal + tap_toff[t];
-            const uint4* wt = wb + (size_t)t * wstep;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-              a[0][mt] = hb[hp[mt]];
-              a[1][mt] = hb[hp[mt] + plane];
-            }
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-              b[0][nt] = wt[nt * 16];
-              b[1][nt] = wt[4 * NB + nt * 16];
-            }
-          };
-          auto mfmas = [&](const uint4 (&a)[2][4], const uint4 (&b)[2][NTW]) {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = mfma16(a[1][mt], b[0][nt], acc[mt][nt]);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = mfma16(a[0][mt], b[1][nt], acc[mt][nt]);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = mfma16(a[0][mt], b[0][nt], acc[mt][nt]);
-          };
-          load_frags(0, a0, b0);
-          int t = 0;
-          for (; t + 2 <= T; t += 2) {
-            load_frags(t + 1, a1, b1);
-            mfmas(a0, b0);
-            if (t + 2 < T) load_frags(t + 2, a0, b0);
-            mfmas(a1, b1);
-          }
-          if (t < T) mfmas(a0, b0);
-        }
-      }
-    }
-    bfd_epilogue<NTW, 4, NOW>(P, reinterpret_cast<float*>(hal), acc, n, r0, c0, ocb, pw, ow, lane);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Host
 // ---------------------------------------------------------------------------------------------
-template <int NTW, int NOW>
-static int bfr_launch(BfdParams B, hipStream_t s) {
-  MfmaConvParams& P = B.P;
-  const int T = P.KHv * P.KWv;
-  const size_t wbytes = (size_t)T * B.ICc * 8 * B.NB * 16;
-  const long lds_cap = 156L * 1024;
-  TilePick best{};
-  const int kh = P.KHv > 0 ? P.KHv : 1, kw = P.KWv > 0 ? P.KWv : 1;
-  // halo: <= 384 pixels (one register batch per thread) and (with the filter) inside the LDS
-  long halo_floats = (lds_cap - (long)wbytes) / 4 - 16 * 32;
-  if (halo_floats > 384L * 32) halo_floats = 384L * 32;
-  if (halo_floats <= 0 || !pick_tile(256, P.PH, P.PW, P.is, kh, kw, 32, (int)halo_floats, best)) return -1;
-  P.TH = best.TH; P.TW = best.TW; P.tiles_y = best.tiles_y; P.tiles_x = best.tiles_x; P.HH = best.HH; P.HW = best.HW;
-  B.NPIXp = (best.HH * best.HW + 15) & ~15;  // multiple of 16: the kq lane groups of a ds_read_b128 interleave conflict-free
-  size_t hal_bytes = (size_t)8 * B.NPIXp * 16;
-  const size_t epi_bytes = (size_t)4 * 32 * BFD_EPI_STRIDE * sizeof(float);
-  if (hal_bytes < epi_bytes) hal_bytes = epi_bytes;
-  const size_t lds = wbytes + hal_bytes;
-  if ((long)lds > lds_cap) return -1;
-  static LdsLimit lim;
-  const void* fn = reinterpret_cast<const void*>(&k_conv_bfr<NTW, NOW>);
-  lim.ensure(fn, lds);
-  const long ntiles = (long)P.tiles_x * P.tiles_y * P.N;
-  int gx = kNumCU / B.OCb;
-  if (gx < 1) gx = 1;
-  if (gx > ntiles) gx = (int)ntiles;
-  if (B.dbg & 32)
-    fprintf(stderr, "[srk] k_conv_bfr<%d,%d>: lds %zu B (filter %zu), grid %d x %d of %ld tiles, tile %dx%d halo %dx%d\n", NTW,
-            NOW, lds, wbytes, gx, B.OCb, ntiles, P.TH, P.TW, P.HH, P.HW);
-  note_kernel("k_conv_bfr<%d,%d>", NTW, NOW);
-  hipLaunchKernelGGL((k_conv_bfr<NTW, NOW>), dim3(gx, B.OCb), dim3(256 * NOW), lds, s, B, (int)ntiles);
-  return check_launch("conv_bfr");
-}
-
 template <int NTW, int NPW, int NOW, int NP, int PF>
 static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
   MfmaConvParams& P = B.P;
@@ -761,55 +536,6 @@ int conv_bfd_gather(const GatherConv& g, const float* in, const float* wp, float
   const bool small = conv_bfd_small_problem(g);
   return for_each_phase(g, in, wp, out, ep, mask_y, mask_slope, [&](const MfmaConvParams& P) {
     return planes == 3 ? bfd_launch_phase<3>(P, wq, wq3, small, s) : bfd_launch_phase<2>(P, wq, wq3, small, s);
-  });
-}
-
-}  // namespace srk
-
-namespace srk {
-
-// Resident-filter persistent kernel (k_conv_bfr): bf16x3 forward-type gathers without gradient mask whose
-// per-output-block filter fits LDS, on problems large enough that every CU walks many tiles.
-// Measured on the c2 layers (MI355X, ms): 32->48 + pixel shuffle (NT = 3): 0.521 with 12 waves (1 x 3 channel
-// waves) vs 0.569 for the per-tile kernel at 2 blocks/CU -> used automatically; 64->32 (NT = 2): 0.77 (8 waves)
-// / 0.96 (4 waves) vs 0.64 for the per-tile kernel at 3 blocks/CU -> NOT used (a single persistent block keeps
-// only one halo chunk of loads in flight; three independent blocks keep more bytes in flight).  SRK_BFR=1
-// forces the kernel wherever it is legal (tests), SRK_BFR=0 disables it.
-bool conv_bfr_applicable(const GatherConv& g, const float* mask_y) {
-  const char* e = getenv("SRK_BFR");
-  const int mode = e ? atoi(e) : 2;
-  if (mode == 0 || mask_y || g.trans || g.IC < 8 || g.OC < 8) return false;
-  const int T = g.KH * g.KW;
-  if (T > BFD_MAXTAPS) return false;
-  const int NT = g.OC >= 64 ? 4 : (g.OC + 15) / 16;
-  const size_t wbytes = (size_t)T * ((g.IC + 31) / 32) * 8 * NT * 16 * 16;
-  if (wbytes > 100 * 1024) return false;
-  if (mode == 1) return true;
-  return NT == 3 && (long)g.N * g.OH * g.OW * ((g.OC + 63) / 64) >= 256L * 8 * kNumCU;
-}
-
-// returns -1 when the tile does not fit (caller falls back to the per-tile kernels)
-int conv_bfr_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s) {
-  const size_t elems = (size_t)g.KH * g.KW * g.IC * g.OC;
-  const uint4* wq = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wp) + bf3_prepared_offset(elems));
-  const char* e = getenv("SRK_BFR_NOW");  // experiment: channel-waves per block (1 = 4-wave blocks)
-  const int now_req = e ? atoi(e) : 0;
-  return for_each_phase(g, in, wp, out, ep, nullptr, 0.f, [&](const MfmaConvParams& P) {
-    BfdParams B{};
-    const int NT = P.OC >= 64 ? 4 : (P.OC + 15) / 16;
-    B.NB = NT * 16;
-    B.ICc = (P.IC + 31) / 32;
-    B.OCb = (P.OC + 63) / 64;
-    B.wq = wq;
-    B.wq3 = nullptr;
-    B.dbg = bfd_dbg();
-    B.P = P;
-    switch (NT) {
-      case 1: return bfr_launch<1, 1>(B, s);
-      case 2: return now_req == 1 ? bfr_launch<2, 1>(B, s) : bfr_launch<1, 2>(B, s);
-      case 3: return now_req == 1 ? bfr_launch<3, 1>(B, s) : bfr_launch<1, 3>(B, s);
-      default: return now_req == 1 ? bfr_launch<4, 1>(B, s) : bfr_launch<2, 2>(B, s);
-    }
   });
 }
 

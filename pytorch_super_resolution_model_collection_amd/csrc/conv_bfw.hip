@@ -8,7 +8,7 @@
 //
 //   * one block per CU: 8 (or 4) CONSUMER waves of 32 (64) pixels x all 16*NTW output channels each, plus 4 PRODUCER
 //     waves;
-//   * the filter is copied to LDS once per block (as in k_conv_bfr); the block then walks (tile, 32-channel chunk)
+//   * the filter is copied to LDS once per block (once, not per tap); the block then walks (tile, 32-channel chunk)
 //     stages; stage s computes from halo buffer s&1 while the producers fill buffer (s+1)&1 -- one barrier per stage;
 //   * producers: global fp32 loads of stage s+2 are issued right after the LDS commit of stage s+1 (a full stage
 //     of latency cover), commit = bf16 split + ds_write_b128: their VALU work interleaves with the consumers'
@@ -20,7 +20,7 @@
 //     of a pixel write 64 contiguous bytes per instruction -- no LDS transpose (there is no LDS left for one:
 //     filter 72 KB + 2 x 42 KB halo buffers).
 //
-// Arithmetic identical to k_conv_bf3 / k_conv_bfr (x = h + m, products m*h + h*m + h*h, fp32 accumulate; the
+// Arithmetic identical to k_conv_bf3 (x = h + m, products m*h + h*m + h*h, fp32 accumulate; the
 // accumulation order over (chunk, tap) is the same).
 #include "srk_common.h"
 #include "conv_problem.h"
@@ -48,27 +48,9 @@ struct BfwParams {
   const uint4* wq;  // prepared filter planes (h, m)
   int ICc, NB, NPIXp, ntiles;
   int dbg;  // ablation (SRK_DBG): 1 no global loads, 2 no epilogue, 4 no MFMA loop, 16 no LDS commit, 1024 no deferred stores
-  // FUSE: the layer's input is itself a convolution of a <= 4-channel image (ESPCN: conv5 3->64 + ReLU in front of
-  // conv3 64->32, espcn.py:18-19); the PRODUCER waves compute it on the matrix cores straight into the halo buffers,
-  // so that intermediate — the largest tensor of the network, 53 % of its compulsory HBM traffic — never exists
-  const float* x1;    // network input [N, IC1, IH0, IW0] (x1_nchw) or [N, IH0, IW0, IC1]
-  const uint4* wq1;   // conv1 filters, row-packed prepared layout [KH1][KS1][ocb][plane][g][64][8]
-  const float* bias1;
-  float slope1;
-  int act1, x1_nchw;
-  int IH0, IW0, IC1, KH1, KS1, OCb1, pad1;
-  int H1, W1;         // conv1 output size = this layer's input size
-  int HH0, HW0, NPIX0p;  // input window of a tile: (HH + KH1 - 1) x (HW + KW1 - 1) pixels, padded
 };
 
-constexpr int BFW_MT1 = 6;  // conv1 M-tiles (16 halo pixels) per producer wave: halos of <= 4 * 6 * 16 = 384 pixels
-constexpr int BFW_IT0 = 2;  // input-window pixels per producer thread: windows of <= 512 pixels
-
-// Q1C (fused only): conv1 K steps when its filter is REGISTER-RESIDENT (two 32-channel chunks, kernel width <= 8, e.g.
-// 5 for ESPCN's 5x5): producer wave w keeps the fragments of ONE 16-channel tile (w & 1) of BOTH chunks — 4 * Q1C
-// uint4 — for the whole kernel and computes that channel tile for every other pixel tile (parity w >> 1).  Q1C = 0:
-// any conv1 geometry, fragments re-read from L1 / L2 every stage (5 exposed load latencies per stage: 3x slower).
-template <int NTW, int TT, int MTW, bool FUSE, int Q1C = 0>
+template <int NTW, int TT, int MTW>
 __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_conv_bfw(BfwParams B) {
   constexpr int NCW = 16 / MTW;          // consumer waves: MTW 16-pixel groups each, 256 pixels per block
   constexpr int NTHR = 64 * (NCW + 4);   // + 4 producer waves
@@ -121,319 +103,7 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
     c0 = txi * P.TW;
   };
 
-  if constexpr (FUSE) {
-    if (producer) {
-      // ---------------------------------------------------------- producers, fused first layer
-      // Stage s = (tile ti, 32-channel chunk cc).  During stage s the producers run conv1 for stage s+1 — bias,
-      // activation and the bf16 split included — from the tile's input window l0[ti & 1] (hi / lo planes of the <= 4
-      // input channels) into halo buffer (s+1) & 1; the window of the next tile is loaded a stage before it is
-      // committed and committed two stages before its first use, so the one barrier per stage orders everything.
-      const int ptid = tid - 64 * NCW, pw4 = ptid >> 6;
-      uint2* l0 = reinterpret_cast<uint2*>(hal0 + 2 * (size_t)hbuf);  // [tile parity][plane][NPIX0p] x (4 bf16)
-      const int l0buf = 2 * B.NPIX0p;
-      const int npix0 = B.HH0 * B.HW0;
-      const int Q1 = B.KH1 * B.KS1;
-      const int mt1_count = (npix + 15) >> 4;
-      auto tile_of = [&](int ti, int& n, int& r0, int& c0) {
-        const int tile = first + ti * tstride;
-        const int txi = tile % P.tiles_x;
-        const int q = tile / P.tiles_x;
-        n = q / P.tiles_y;
-        r0 = (q % P.tiles_y) * P.TH;
-        c0 = txi * P.TW;
-      };
-      float win[BFW_IT0][4];
-      auto win_issue = [&](int ti) {
-        int n, r0, c0;
-        tile_of(ti, n, r0, c0);
-        const int h0y = r0 + P.iy0 - B.pad1, h0x = c0 + P.ix0 - B.pad1;  // (P.is == 1)
-#pragma unroll
-        for (int k = 0; k < BFW_IT0; ++k) {
-          const int hp = ptid + 256 * k;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) win[k][e] = 0.f;
-          if (hp < npix0 && !(B.dbg & 1)) {
-            const int hy = hp / B.HW0, hx = hp - hy * B.HW0;
-            const int iy = h0y + hy, ix = h0x + hx;
-            if ((unsigned)iy < (unsigned)B.IH0 && (unsigned)ix < (unsigned)B.IW0) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (e < B.IC1)
-                  win[k][e] = B.x1_nchw ? B.x1[(((size_t)n * B.IC1 + e) * B.IH0 + iy) * B.IW0 + ix]
-                                        : B.x1[(((size_t)n * B.IH0 + iy) * B.IW0 + ix) * B.IC1 + e];
-            }
-          }
-        }
-      };
-      auto win_commit = [&](int ti) {
-        uint2* dst = l0 + (size_t)(ti & 1) * l0buf;
-#pragma unroll
-        for (int k = 0; k < BFW_IT0; ++k) {
-          const int hp = ptid + 256 * k;
-          if (hp < B.NPIX0p) {  // (the pad pixels past the window are zero: K padding of the last kernel-row step)
-            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-            bf16x4 h, l;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const __bf16 hh = (__bf16)win[k][e];
-              h[e] = hh;
-              l[e] = (__bf16)(win[k][e] - (float)hh);
-            }
-            dst[hp] = __builtin_bit_cast(uint2, h);
-            dst[B.NPIX0p + hp] = __builtin_bit_cast(uint2, l);
-          }
-        }
-      };
-      // conv1 M-tiles of this wave: halo pixels (pw4 + 4 i) * 16 + j
-      // ---- register-resident filter (Q1C > 0) -------------------------------------------------------------------
-      constexpr int QR = Q1C > 0 ? Q1C : 1;
-      uint4 fw0[QR][2], fw1[QR][2];  // [K step][plane] of channel tile (pw4 & 1), chunk 0 / chunk 1
-      if constexpr (Q1C > 0) {
-#pragma unroll
-        for (int q = 0; q < Q1C; ++q) {
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl) {
-            const int co0 = (pw4 & 1) * 16 + j, co1 = 32 + co0;
-            fw0[q][pl] = B.wq1[((size_t)q * B.OCb1 + (co0 >> 6)) * 512 + (pl * 4 + kq) * 64 + (co0 & 63)];
-            fw1[q][pl] = B.wq1[((size_t)q * B.OCb1 + (co1 >> 6)) * 512 + (pl * 4 + kq) * 64 + (co1 & 63)];
-          }
-        }
-      }
-      auto conv1r = [&](int s) {
-        const int ti = s >> 1, cc = s & 1;
-        int n, r0, c0;
-        tile_of(ti, n, r0, c0);
-        const int h2y = r0 + P.iy0, h2x = c0 + P.ix0;
-        const uint2* lw = l0 + (size_t)(ti & 1) * l0buf;
-        uint2* hal2 = reinterpret_cast<uint2*>(hal0 + (size_t)(s & 1) * hbuf);
-        const int nt = pw4 & 1;
-        const int col = nt * 16 + kq * 4, co = cc * 32 + col;  // this lane's 4 channels
-        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-        if (B.bias1) b4 = *reinterpret_cast<const f32x4*>(B.bias1 + co);
-        const int g = col >> 3, half = (col >> 2) & 1;
-        // One pass = NTP pixel tiles (mt0, mt0 + 2, ...) through all QR kernel rows.  The producer is a latency chain
-        // unless its LDS fragment reads run ahead of the MFMAs: the fragments of kernel row q + 1 (all NTP tiles) are in
-        // flight while the MFMAs of row q issue, tile-interleaved so that consecutive MFMAs never share an accumulator.
-        constexpr int NTP = 2;
-        auto pass = [&](const uint4 (&fw)[QR][2], int mt0) {
-          f32x4 a[NTP];
-          int off[NTP], rc[NTP];
-          bool live[NTP];
-#pragma unroll
-          for (int t = 0; t < NTP; ++t) {
-            a[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int p = (mt0 + 2 * t) * 16 + j;
-            live[t] = mt0 + 2 * t < mt1_count;  // wave-uniform
-            const int pp = p < npix ? p : 0;
-            const int r = pp / P.HW, c = pp - r * P.HW;
-            off[t] = r * B.HW0 + c + 2 * kq;
-            rc[t] = p < npix ? ((r << 16) | c) : -1;
-          }
-          uint4 fh[2][NTP], fl[2][NTP];
-          auto afrag = [&](int q, uint4 (&ah)[NTP], uint4 (&al)[NTP]) {
-#pragma unroll
-            for (int t = 0; t < NTP; ++t) {
-              if (live[t]) {
-                const uint2* pp = lw + off[t] + q * B.HW0;   // (KS1 == 1: K step q = kernel row q)
-                const uint2 h0 = pp[0], h1 = pp[1];
-                const uint2 q0 = pp[B.NPIX0p], q1 = pp[B.NPIX0p + 1];
-                ah[t] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-                al[t] = make_uint4(q0.x, q0.y, q1.x, q1.y);
-              }
-            }
-          };
-          if (!(B.dbg & (4 | 64))) {
-            afrag(0, fh[0], fl[0]);
-            srk_static_for<0, QR>([&](auto qc) {
-              constexpr int q = decltype(qc)::value;
-              if (q + 1 < QR) afrag(q + 1, fh[(q + 1) & 1], fl[(q + 1) & 1]);
-              __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-              for (int t = 0; t < NTP; ++t)
-                if (live[t]) a[t] = mfma16(fw[q][0], fl[q & 1][t], a[t]);
-#pragma unroll
-              for (int t = 0; t < NTP; ++t)
-                if (live[t]) a[t] = mfma16(fw[q][1], fh[q & 1][t], a[t]);
-#pragma unroll
-              for (int t = 0; t < NTP; ++t)
-                if (live[t]) a[t] = mfma16(fw[q][0], fh[q & 1][t], a[t]);
-              __builtin_amdgcn_sched_barrier(0);
-            });
-          }
-          if (B.dbg & 16) return;
-#pragma unroll
-          for (int t = 0; t < NTP; ++t) {
-            if (live[t] && rc[t] >= 0) {
-              const int r1 = rc[t] >> 16, c1 = rc[t] & 0xffff;
-              const bool inside = (unsigned)(h2y + r1) < (unsigned)B.H1 && (unsigned)(h2x + c1) < (unsigned)B.W1;
-              typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-              bf16x4 h, l;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                float v = 0.f;
-                if (inside) v = act_apply(a[t][e] + b4[e], B.act1, B.slope1);
-                const __bf16 hh = (__bf16)v;
-                h[e] = hh;
-                l[e] = (__bf16)(v - (float)hh);
-              }
-              const int px = (mt0 + 2 * t) * 16 + j;
-              hal2[((0 * 4 + g) * B.NPIXp + px) * 2 + half] = __builtin_bit_cast(uint2, h);
-              hal2[((1 * 4 + g) * B.NPIXp + px) * 2 + half] = __builtin_bit_cast(uint2, l);
-            }
-          }
-        };
-        for (int mt0 = pw4 >> 1; mt0 < mt1_count; mt0 += 2 * NTP) {
-          if (cc == 0)
-            pass(fw0, mt0);
-          else
-            pass(fw1, mt0);
-        }
-      };
-      // ---- any conv1 geometry: fragments from global memory every stage -----------------------------------------
-      int off1[BFW_MT1];
-#pragma unroll
-      for (int i = 0; i < BFW_MT1; ++i) {
-        const int p = (pw4 + 4 * i) * 16 + j;
-        const int pp = p < npix ? p : 0;
-        const int r = pp / P.HW, c = pp - r * P.HW;
-        off1[i] = r * B.HW0 + c + 2 * kq;
-      }
-      auto conv1 = [&](int s) {
-        const int ti = s / B.ICc, cc = s - ti * B.ICc;
-        int n, r0, c0;
-        tile_of(ti, n, r0, c0);
-        const int h2y = r0 + P.iy0, h2x = c0 + P.ix0;  // halo origin in conv1-output coordinates
-        const uint2* lw = l0 + (size_t)(ti & 1) * l0buf;
-        uint2* hal2 = reinterpret_cast<uint2*>(hal0 + (size_t)(s & 1) * hbuf);
-        f32x4 a1[BFW_MT1][2];
-#pragma unroll
-        for (int i = 0; i < BFW_MT1; ++i) {
-          a1[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          a1[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        // filter fragments of K step q (row operand: lane (j = channel in tile, kq = kw pair)), straight from global
-        // memory (40 KB for 5x5x3 -> 64, shared by every CU: L1 / L2 hits), one step ahead of its MFMAs
-        auto w1frag = [&](int q, uint4 (&bh)[2], uint4 (&bl)[2]) {
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            const int co = cc * 32 + nt * 16 + j;
-            const uint4* blk = B.wq1 + ((size_t)q * B.OCb1 + (co >> 6)) * (size_t)512;
-            bh[nt] = blk[(0 * 4 + kq) * 64 + (co & 63)];
-            bl[nt] = blk[(1 * 4 + kq) * 64 + (co & 63)];
-          }
-        };
-        // one K step (kernel row u, 8-wide column block ks) with the filter fragments (fh, fm)
-        int u = 0, ks = 0;
-        auto kstep = [&](const uint4 (&fh)[2], const uint4 (&fm)[2]) {
-          const int toff = u * B.HW0 + ks * 8;
-          if (!(B.dbg & 4)) {
-            // activation fragments one M-tile ahead of their MFMAs, two register sets (the scheduler would otherwise
-            // hoist all six tiles' LDS reads in front of the first MFMA and spill)
-            uint4 fah[2], fal[2];
-            auto afrag = [&](int i, uint4& ah, uint4& al) {
-              const uint2* pp = lw + off1[i] + toff;
-              const uint2 h0 = pp[0], h1 = pp[1];
-              const uint2 q0 = pp[B.NPIX0p], q1 = pp[B.NPIX0p + 1];
-              ah = make_uint4(h0.x, h0.y, h1.x, h1.y);
-              al = make_uint4(q0.x, q0.y, q1.x, q1.y);
-            };
-            afrag(0, fah[0], fal[0]);
-            srk_static_for<0, BFW_MT1>([&](auto ic) {
-              constexpr int i = decltype(ic)::value;
-              if (pw4 + 4 * i < mt1_count) {  // wave-uniform
-                if (i + 1 < BFW_MT1 && pw4 + 4 * (i + 1) < mt1_count) afrag(i + 1 < BFW_MT1 ? i + 1 : i, fah[(i + 1) & 1], fal[(i + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {  // transposed product: rows = output channels, cols = pixels
-                  a1[i][nt] = mfma16(fh[nt], fal[i & 1], a1[i][nt]);
-                  a1[i][nt] = mfma16(fm[nt], fah[i & 1], a1[i][nt]);
-                  a1[i][nt] = mfma16(fh[nt], fah[i & 1], a1[i][nt]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-              }
-            });
-          }
-          if (++ks == B.KS1) {
-            ks = 0;
-            ++u;
-          }
-        };
-        // two register sets ping-pong (compile-time names: a runtime-indexed fragment array would live in scratch)
-        uint4 wAh[2], wAm[2], wBh[2], wBm[2];
-        w1frag(0, wAh, wAm);
-        for (int q = 0; q < Q1; q += 2) {
-          if (q + 1 < Q1) w1frag(q + 1, wBh, wBm);
-          kstep(wAh, wAm);
-          if (q + 1 < Q1) {
-            if (q + 2 < Q1) w1frag(q + 2, wAh, wAm);
-            kstep(wBh, wBm);
-          }
-        }
-        // conv1 epilogue: bias + activation, bf16 split, 8-byte stores into the halo planes this layer's MFMA loop
-        // reads ([plane][8-channel group][pixel][8 bf16]); C/D: col = lane & 15 = pixel, rows kq*4 + reg = channel
-        if (B.dbg & 16) return;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const int col = nt * 16 + kq * 4;  // channel within the 32-channel chunk
-          const int co = cc * 32 + col;
-          f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-          if (B.bias1) b4 = *reinterpret_cast<const f32x4*>(B.bias1 + co);
-          const int g = col >> 3, half = (col >> 2) & 1;
-#pragma unroll
-          for (int i = 0; i < BFW_MT1; ++i) {
-            const int p1i = (pw4 + 4 * i) * 16 + j;
-            if (pw4 + 4 * i < mt1_count && p1i < npix) {
-              const int r1 = p1i / P.HW, c1 = p1i - r1 * P.HW;
-              const int y1 = h2y + r1, x1 = h2x + c1;
-              const bool inside = (unsigned)y1 < (unsigned)B.H1 && (unsigned)x1 < (unsigned)B.W1;
-              typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-              bf16x4 h, l;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                float v = 0.f;  // outside the conv1 output image this layer's input is zero padding
-                if (inside) v = act_apply(a1[i][nt][e] + b4[e], B.act1, B.slope1);
-                const __bf16 hh = (__bf16)v;
-                h[e] = hh;
-                l[e] = (__bf16)(v - (float)hh);
-              }
-              hal2[((0 * 4 + g) * B.NPIXp + p1i) * 2 + half] = __builtin_bit_cast(uint2, h);
-              hal2[((1 * 4 + g) * B.NPIXp + p1i) * 2 + half] = __builtin_bit_cast(uint2, l);
-            }
-          }
-        }
-      };
-      if (S > 0) {
-        win_issue(0);
-        win_commit(0);
-      }
-      __syncthreads();  // window of tile 0 (and the filter) visible to all producer waves
-      if (S > 0 && T > 0) {
-        if constexpr (Q1C > 0) conv1r(0); else conv1(0);
-      }
-      // (ICc >= 2 here.)  Window of tile 1: first needed by conv1(ICc) during stage ICc - 1, committed at the end of
-      // stage ICc - 2, loaded now
-      if (count > 1) win_issue(1);
-      __syncthreads();  // stage 0 visible
-      for (int s = 0; s < S; ++s) {
-        if (T > 0) {
-          if (s + 1 < S) {
-            if constexpr (Q1C > 0) conv1r(s + 1); else conv1(s + 1);
-          }
-          if ((s + 2) % B.ICc == 0) {  // commit the window whose first conv1 runs during stage s + 1
-            const int tc = (s + 2) / B.ICc;
-            if (tc < count) win_commit(tc);
-          }
-          if ((s + 3) % B.ICc == 0) {  // and load the one after it
-            const int tn = (s + 3) / B.ICc;
-            if (tn < count && tn >= 2) win_issue(tn);
-          }
-        }
-        __syncthreads();
-      }
-      return;
-    }
-  }
-  if (!FUSE && producer) {
+  if (producer) {
     // ------------------------------------------------------------------ producers
     const int ptid = tid - 64 * NCW;
     const int g = ptid & 3, hp0 = ptid >> 2;
@@ -567,7 +237,6 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
     constexpr int q0 = decltype(q0c)::value;
     srk_static_for<q0, NST>([&](auto qc) { store_slot(qc); });
   };
-  if constexpr (FUSE) __syncthreads();  // (the producers' barrier between the first input window and its conv1)
   __syncthreads();  // filter and stage 0 visible
   for (int s = 0; s < S; ++s) {
     int n, r0, c0, cc;
@@ -578,7 +247,7 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    if (wave_live && T > 0 && !(B.dbg & (4 | 128))) {
+    if (wave_live && T > 0 && !(B.dbg & 4)) {
       const uint4* hal = hal0 + (size_t)(s & 1) * hbuf;
       const uint4* wb = wl + (size_t)cc * wslot;
       const size_t wstep = (size_t)B.ICc * wslot;
@@ -704,28 +373,10 @@ bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, co
 template <int NTW, int TT, int MTW>
 static int bfw_launch_t(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
   static LdsLimit lim;
-  lim.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, MTW, false>), lds);
+  lim.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, MTW>), lds);
   note_kernel("k_conv_bfw<%d,%d,%d>", NTW, TT, MTW);
-  hipLaunchKernelGGL((k_conv_bfw<NTW, TT, MTW, false>), dim3(grid), dim3(64 * (16 / MTW + 4)), lds, s, B);
+  hipLaunchKernelGGL((k_conv_bfw<NTW, TT, MTW>), dim3(grid), dim3(64 * (16 / MTW + 4)), lds, s, B);
   return check_launch("conv_bfw");
-}
-template <int NTW, int TT, int Q1C>
-static int bfw_launch_fused_q(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
-  static LdsLimit lim;
-  lim.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, 2, true, Q1C>), lds);
-  note_kernel("k_conv_bfw<%d,%d,2,fused>", NTW, TT);
-  hipLaunchKernelGGL((k_conv_bfw<NTW, TT, 2, true, Q1C>), dim3(grid), dim3(64 * 12), lds, s, B);
-  return check_launch("conv_bfw_fused");
-}
-template <int NTW, int TT>
-static int bfw_launch_fused(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
-  // register-resident first-layer filter: two 32-channel chunks, one K step per kernel row, 3 or 5 rows
-  static const int regw_env = getenv("SRK_BFW_REGW") ? atoi(getenv("SRK_BFW_REGW")) : 1;
-  if (regw_env && B.ICc == 2 && B.KS1 == 1 && TT == 9) {
-    if (B.KH1 == 5) return bfw_launch_fused_q<NTW, TT, 5>(B, lds, grid, s);
-    if (B.KH1 == 3) return bfw_launch_fused_q<NTW, TT, 3>(B, lds, grid, s);
-  }
-  return bfw_launch_fused_q<NTW, TT, 0>(B, lds, grid, s);
 }
 template <int NTW>
 static int bfw_launch(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
@@ -784,81 +435,6 @@ int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float
       default: return bfw_launch<4>(B, lds, grid, s);
     }
   });
-}
-
-// Two layers in one launch:  y = ep2( conv2( act1( conv1(x) + b1 ) ) )  with conv1: Cin <= 4 -> C1 (a multiple of 32, >= 64),
-// stride 1, kernel width <= 8, and conv2 a layer k_conv_bfw covers with 8 consumer waves (OC = 16 / 32 / 48) — ESPCN's
-// conv5 3->64 + ReLU -> conv3 64->32 + ReLU (espcn.py:18-19).  SRK_ERR_UNSUPPORTED outside that envelope.
-int conv_bfw_fused_forward(const srk_conv_desc& d1, const srk_conv_desc& d2, const float* x, int x_nchw, const float* wp1,
-                           const float* wp2, float* y, const Epi& ep1, const Epi& ep2, hipStream_t s) {
-  auto no = [](const char* why) {
-    set_error("conv2d_fused2_forward: %s", why);
-    return (int)SRK_ERR_UNSUPPORTED;
-  };
-  if (d1.transposed || d2.transposed || d1.stride != 1 || d2.stride != 1) return no("only stride-1 Conv2d layers are fused");
-  if (d1.Cin > 4 || d1.Cout % 32 != 0 || d1.Cout < 64 || d1.KW > 16 || d1.KH > 16) return no("conv1 must be Cin <= 4 -> 32k >= 64 channels, kernel <= 16x16");
-  if (d1.Cout != d2.Cin || d1.OH != d2.H || d1.OW != d2.W || d1.N != d2.N) return no("conv1 output does not feed conv2");
-  if (ep1.residual || ep1.ps_r > 1 || (ep1.act != SRK_ACT_NONE && ep1.act != SRK_ACT_RELU && ep1.act != SRK_ACT_LRELU))
-    return no("conv1 epilogue must be bias + none / ReLU / LeakyReLU");
-  if (ep1.bias && (uintptr_t)ep1.bias % 16 != 0) return no("conv1 bias must be 16-byte aligned");
-  GatherConv g{d2.N, d2.H, d2.W, d2.Cin, d2.OH, d2.OW, d2.Cout, d2.KH, d2.KW, 1, d2.pad, 0, 0, 0};
-  if (d2.Cout % 16 != 0 || d2.Cout < 16 || d2.Cout > 48) return no("conv2 must have 16 / 32 / 48 output channels");
-  if (d2.KH * d2.KW > BFW_MAXTAPS - 1 || !conv_epi_all_vector(g.OC, ep2, y)) return no("conv2 kernel / epilogue not covered");
-  if (ep2.residual || (ep2.act == SRK_ACT_PRELU && ep2.prelu_n > 1)) return no("conv2 epilogue not covered");
-  if (ep2.act != SRK_ACT_NONE && ep2.act != SRK_ACT_RELU && ep2.act != SRK_ACT_LRELU && ep2.act != SRK_ACT_PRELU)
-    return no("conv2 activation not covered");
-  if ((long)g.N * g.OH * g.OW * g.OC >= (1L << 31) || (long)g.N * g.OH * g.OW >= (1L << 30)) return no("tensor too large");
-  static int dbg = -1;
-  if (dbg < 0) dbg = getenv("SRK_DBG") ? atoi(getenv("SRK_DBG")) : 0;
-  BfwParams B{};
-  MfmaConvParams& P = B.P;
-  P.in = nullptr; P.out = y; P.ep = ep2;
-  P.N = d2.N; P.IH = d2.H; P.IW = d2.W; P.IC = d2.Cin; P.OH = d2.OH; P.OW = d2.OW; P.OC = d2.Cout;
-  P.PH = d2.OH; P.PW = d2.OW; P.oy0 = 0; P.ox0 = 0; P.os = 1; P.iy0 = -d2.pad; P.ix0 = -d2.pad; P.is = 1;
-  P.KHv = d2.KH; P.KWv = d2.KW; P.wh0 = 0; P.wdh = 1; P.ww0 = 0; P.wdw = 1; P.KW_full = d2.KW;
-  const size_t e1 = (size_t)d1.KH * d1.KW * d1.Cin * d1.Cout, e2 = (size_t)d2.KH * d2.KW * d2.Cin * d2.Cout;
-  B.wq = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wp2) + bf3_prepared_offset(e2));
-  B.wq1 = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wp1) + bf3_prepared_offset(e1));
-  B.NB = P.OC; B.ICc = d2.Cin / 32; B.dbg = dbg;
-  B.x1 = x; B.x1_nchw = x_nchw; B.bias1 = ep1.bias; B.act1 = ep1.act; B.slope1 = ep1.slope;
-  B.IH0 = d1.H; B.IW0 = d1.W; B.IC1 = d1.Cin; B.KH1 = d1.KH; B.KS1 = (d1.KW + 7) / 8; B.OCb1 = (d1.Cout + 63) / 64;
-  B.pad1 = d1.pad; B.H1 = d1.OH; B.W1 = d1.OW;
-  const int T = P.KHv * P.KWv;
-  const size_t wbytes = (size_t)T * B.ICc * 8 * B.NB * 16;
-  const long lds_cap = 160L * 1024 - 512;
-  // LDS = conv2 filter + two halo buffers (128 B per pixel) + two input windows (16 B per pixel): largest tile that fits
-  TilePick best{};
-  bool found = false;
-  size_t lds = 0;
-  for (int cap = 64 * BFW_MT1; cap >= 64 && !found; cap -= 16) {
-    TilePick tp{};
-    if (!pick_tile(256, P.PH, P.PW, 1, P.KHv, P.KWv, 32, cap * 32, tp)) continue;
-    const int hh0 = tp.HH + d1.KH - 1, hw0 = tp.HW + d1.KW - 1;
-    const long npix0p = ((long)hh0 * hw0 + 16 + 15) & ~15L;
-    const long npixp = ((long)tp.HH * tp.HW + 15) & ~15L;
-    const long need = (long)wbytes + 2 * 8 * npixp * 16 + 2 * 2 * npix0p * 8;
-    if (need > lds_cap || npix0p > 256 * BFW_IT0 || npixp > 64 * BFW_MT1) continue;
-    best = tp;
-    found = true;
-    lds = (size_t)need;
-    B.HH0 = hh0; B.HW0 = hw0; B.NPIX0p = (int)npix0p; B.NPIXp = (int)npixp;
-  }
-  if (!found) return no("no tile fits LDS");
-  P.TH = best.TH; P.TW = best.TW; P.tiles_y = best.tiles_y; P.tiles_x = best.tiles_x; P.HH = best.HH; P.HW = best.HW;
-  const long ntiles = (long)P.tiles_x * P.tiles_y * P.N;
-  if (ntiles >= (1L << 30)) return no("too many tiles");
-  B.ntiles = (int)ntiles;
-  int grid = kNumCU;
-  if (grid > ntiles) grid = (int)ntiles;
-  if (dbg & 32)
-    fprintf(stderr, "[srk] k_conv_bfw fused: lds %zu B (filter %zu), grid %d of %ld tiles, tile %dx%d halo %dx%d window %dx%d\n",
-            lds, wbytes, grid, ntiles, P.TH, P.TW, P.HH, P.HW, B.HH0, B.HW0);
-  const bool t9 = T == 9;
-  switch (P.OC / 16) {
-    case 1: return t9 ? bfw_launch_fused<1, 9>(B, lds, grid, s) : bfw_launch_fused<1, 0>(B, lds, grid, s);
-    case 2: return t9 ? bfw_launch_fused<2, 9>(B, lds, grid, s) : bfw_launch_fused<2, 0>(B, lds, grid, s);
-    default: return t9 ? bfw_launch_fused<3, 9>(B, lds, grid, s) : bfw_launch_fused<3, 0>(B, lds, grid, s);
-  }
 }
 
 }  // namespace srk

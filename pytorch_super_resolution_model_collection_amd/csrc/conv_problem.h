@@ -110,8 +110,6 @@ static inline bool conv_epi_all_vector(int OC, const Epi& ep, const float* out) 
 // conv_bfd.hip: filters straight from global memory; planes 2 = bf16x3, 3 = bf16x6 (fp32-faithful)
 bool conv_bfd_gather_supported(const GatherConv& g, const Epi& ep);
 bool conv_bfd_small_problem(const GatherConv& g);
-bool conv_bfr_applicable(const GatherConv& g, const float* mask_y);
-int conv_bfr_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s);
 int conv_bfd_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
                     const float* mask_y, float mask_slope, int planes, hipStream_t s);
 int bf3_pack_prepared(const float* w, void* packed_base, int Cout, int Cin, int KH, int KW, int transposed, int ps_r,

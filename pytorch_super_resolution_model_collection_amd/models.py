@@ -51,15 +51,6 @@ class ESPCNNet(nn.Module):
             PSBlock(base_filter // 2, num_channels, scale_factor, 3, 1, 0, activation=None, norm=None))
 
     def forward(self, x):
-        if ops.FUSE_ESPCN_HEAD and not _training_graph(self, x):
-            # opt-in: conv5+ReLU and conv3+ReLU fused through LDS (the 64-channel intermediate —
-            # half of the net's HBM traffic — never leaves the CU), reading the NCHW input directly
-            l1, l2 = self.layers[0], self.layers[1]
-            k1, s1, _ = l1._act_args()
-            k2, s2, p2 = l2._act_args()
-            y = ops.conv2d_fused2_infer(x, l1.conv, k1, s1, l2.conv, k2, s2, p2)
-            if y is not None:
-                return self.layers[2](y)
         return self.layers(x)
 
     def weight_init(self):

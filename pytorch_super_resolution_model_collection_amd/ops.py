@@ -16,12 +16,6 @@ from ._lib import (ACT_BY_NAME, ACT_LRELU, ACT_NONE, ACT_PRELU, ACT_RELU, ALGO_A
 
 CL = torch.channels_last
 
-# ESPCNNet inference through the fused conv5+ReLU -> conv3+ReLU kernel (srk_conv2d_fused2_forward): the producer waves
-# of the wave-specialised conv3 kernel compute conv5 on the matrix cores straight into the LDS halo planes, so the
-# 64-channel intermediate (2.1 of the 3.9 GB the net moves per 64-image batch) never touches HBM.  SRK_FUSE_HEAD=0
-# runs the layers one by one.
-FUSE_ESPCN_HEAD = os.environ.get("SRK_FUSE_HEAD", "1") != "0"
-
 # Convolution arithmetic used when a ConvCfg leaves algo = AUTO, per role:
 #   infer     forward under torch.no_grad()
 #   train_fwd forward that will be differentiated
@@ -502,40 +496,6 @@ def conv2d_infer(x, weight, bias=None, residual=None, cfg=None, prelu_w=None, pa
         wp = pack_weight_fwd(weight, cfg.transposed, cfg.ps_r)
         bp = pack_bias_ps(bias, cfg.ps_r)
     return conv_forward_raw(x, wp, bp, weight, cfg, prelu_w, residual, "infer", x_nchw)
-
-
-def conv2d_fused2_infer(x, conv1, act1, slope1, conv2, act2, slope2, prelu2=None):
-    """No-grad fused pair of stride-1 convs (srk_conv2d_fused2_forward): `conv1`/`conv2` are
-    layers.Conv2d modules, conv1 with <= 4 input channels.  `x` may be NCHW (as the reference feeds
-    it) or channels_last.  Returns None when the configuration is outside the fused kernel's
-    envelope or the precision mode forbids bf16x3, so the caller can run the layers one by one."""
-    if _PRECISION["mode"] == "fp32" or x.dim() != 4:
-        return None
-    if (conv1.in_channels > 4 or conv1.out_channels % 32 or conv1.out_channels < 64 or conv1._s != 1 or conv2._s != 1
-            or conv2.in_channels != conv1.out_channels or conv2.out_channels not in (16, 32, 48) or act1 == ACT_PRELU):
-        return None
-    lib = _lib.load()
-    require_cuda(x, conv1.weight, conv2.weight)
-    x_nchw = 0
-    if not _is_nhwc_dense(x):
-        if not _is_nchw_dense(x):
-            return None
-        x_nchw = 1
-    cfg1 = ConvCfg(1, conv1._p, False, 0, act1, slope1, 0)
-    cfg2 = ConvCfg(1, conv2._p, False, 0, act2, slope2, 0)
-    d1 = _make_desc(x.shape, conv1.weight, cfg1)
-    d2 = _make_desc((d1.N, d1.Cout, d1.OH, d1.OW), conv2.weight, cfg2)
-    wp1, bp1 = conv1._cache.get(conv1.weight, conv1.bias, False, 0)
-    wp2, bp2 = conv2._cache.get(conv2.weight, conv2.bias, False, 0)
-    y = _empty_cl(d2.N, d2.Cout, d2.OH, d2.OW, x)
-    ep1 = Epilogue(ptr(bp1), None, None, slope1, act1, 0, 0)
-    ep2 = Epilogue(ptr(bp2), ptr(prelu2), None, slope2, act2, 0 if prelu2 is None else prelu2.numel(), 0)
-    rc = lib.srk_conv2d_fused2_forward(ctypes.byref(d1), ctypes.byref(d2), ptr(x), x_nchw, ptr(wp1), ptr(wp2), ptr(y),
-                                       ctypes.byref(ep1), ctypes.byref(ep2), stream_ptr())
-    if rc == -2:  # SRK_ERR_UNSUPPORTED: legal request the fused kernel does not cover
-        return None
-    check(rc, "srk_conv2d_fused2_forward")
-    return y
 
 
 # ------------------------------------------------------------------------------------------------

@@ -21,7 +21,6 @@ ALGOS = {"auto": 0, "generic": 1, "mfma_fp32": 2, "bf16x6": 5}
 VARIANTS = {"auto": ("auto", {}), "generic": ("generic", {}), "mfma_fp32": ("mfma_fp32", {}),
             "auto_lds_weights": ("auto", {"SRK_BFD_SMALL": "0"}),
             "auto_global_weights_big": ("auto", {"SRK_BF3_DIRECT": "1", "SRK_BFD_SMALL": "0"}),
-            "auto_resident_filter": ("auto", {"SRK_BFR": "1", "SRK_BFD_SMALL": "0", "SRK_BFW": "0"}),
             "auto_wave_specialized": ("auto", {"SRK_BFW": "1"}),
             "bf16x6": ("bf16x6", {}), "bf16x6_big": ("bf16x6", {"SRK_BFD_SMALL": "0"})}
 TOL_ALGO = {"auto": 1e-4, "generic": TOL_TIGHT, "mfma_fp32": TOL_TIGHT, "bf16x6": TOL_TIGHT}
@@ -349,45 +348,6 @@ def test_errors_are_loud(gpu):
     lib = pkg._lib.load()
     assert lib.srk_axpby(None, None, None, 0, 1.0, 1.0, None) == -1
     assert b"null" in lib.srk_last_error_string()
-
-
-@pytest.mark.parametrize("k1,p1,k2,p2,c1,c2,act,nchw,hw", [
-    (5, 0, 3, 0, 64, 32, "relu", True, (40, 37)),     # ESPCN head (espcn.py:18-19), NCHW input, ragged size
-    (5, 0, 3, 0, 64, 32, "relu", False, (23, 50)),
-    (5, 0, 3, 0, 64, 32, "relu", True, (150, 170)),   # every block walks several tiles: window / halo double buffering
-    (3, 1, 3, 1, 64, 48, "lrelu", True, (19, 21)),    # padded convs: zero padding of the fused intermediate
-    (9, 4, 1, 0, 64, 48, None, False, (17, 16)),      # 9-wide first kernel: two K steps per kernel row; 1x1 second conv
-    (5, 2, 5, 2, 128, 16, "relu", True, (13, 30)),    # C1 = 128 (4 chunks per tile), 5x5 second conv (dynamic tap loop)
-    (3, 0, 3, 0, 96, 32, "relu", True, (64, 64)),     # 3 chunks per tile
-])
-def test_conv_fused2(gpu, k1, p1, k2, p2, c1, c2, act, nchw, hw):
-    """conv -> act -> conv -> act fused through LDS (srk_conv2d_fused2_forward) vs torch CPU."""
-    pkg = _pkg()
-    L = pkg.layers
-    H, W = hw
-    a = {None: (0, 0.0, None), "relu": (1, 0.0, torch.nn.ReLU()), "lrelu": (3, 0.2, torch.nn.LeakyReLU(0.2))}[act]
-    conv1, conv2 = L.Conv2d(3, c1, k1, 1, p1), L.Conv2d(c1, c2, k2, 1, p2)
-    for i, m in enumerate((conv1, conv2)):
-        m.weight.data.copy_(fill.randn(tuple(m.weight.shape), 40 + i, (2.0 / (m.in_channels * m._k ** 2)) ** 0.5))
-        m.bias.data.copy_(fill.randn((m.out_channels,), 50 + i, 0.1))
-    x = fill.randn((2, 3, H, W), 60)
-    f = torch.nn.functional
-    ref = f.conv2d(x, conv1.weight, conv1.bias, 1, p1)
-    ref = a[2](ref) if a[2] else ref
-    ref = f.conv2d(ref, conv2.weight, conv2.bias, 1, p2)
-    ref = a[2](ref) if a[2] else ref
-    conv1.to(gpu)
-    conv2.to(gpu)
-    xg = x.to(gpu) if nchw else pkg.ops.to_nhwc(x.to(gpu))
-    with torch.no_grad():
-        y = pkg.ops.conv2d_fused2_infer(xg, conv1, a[0], a[1], conv2, a[0], a[1])
-    assert y is not None, "fused kernel declined a shape inside its envelope"
-    assert _pkg()._lib.load().srk_last_kernel_name().decode().endswith("fused>")
-    assert rel_err(y, ref.detach()) < 1e-4
-    # outside the envelope the call declines (None) and the caller runs the layers one by one
-    wide = L.Conv2d(c1, 64, 3, 1, 1).to(gpu)
-    with torch.no_grad():
-        assert pkg.ops.conv2d_fused2_infer(xg, conv1, a[0], a[1], wide, 0, 0.0) is None
 
 
 class _OneParam(torch.nn.Module):
