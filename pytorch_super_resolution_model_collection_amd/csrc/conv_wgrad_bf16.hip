@@ -35,6 +35,7 @@ int conv_wgrad_reduce_launch(const float* ws, float* dw, int G, int Cout, int Ci
                              hipStream_t s);
 
 constexpr int WB_MAXOCT = 64;  // octets per tile (<= 512 pixels)
+constexpr int WB_PIT = 2;      // SPEC stagers: register batches per tensor and tile when prefetching one tile ahead
 constexpr int WB_IT = 1;       // pixel pairs per thread loaded together while staging (4 measured: no gain plain, spills in the specialised variant)
 
 struct WgBfParams {
@@ -53,6 +54,7 @@ struct WgBfParams {
   int vec_x, vec_y;
   int dbg;  // ablation (SRK_DBG): 2 skip the staging, 4 skip the K loop
   int dy_ps_r, dy_ps_C;  // dY handed over pixel-shuffled [N, YH*r, YW*r, Cout/r^2]: un-shuffled while staging
+  int prefetch;          // SPEC: a tile's loads fit the stagers' register batch (WB_PIT x 512 items): load one tile ahead
 };
 
 // Grouped launch: the weight gradients of up to WB_MAXGROUP convolutions that share ONE geometry (the 33 body convs
@@ -165,19 +167,29 @@ __global__ __launch_bounds__(SPEC ? 768 : 256, SPEC ? 3 : 2) void k_wgrad_bf(WgB
   const int tid = SPEC ? (wave >= 4 ? tid0 - 256 : tid0) : tid0;  // index among the staging threads (stagers) / working threads
   const int i = lane & 15, kq = lane >> 4;
   const int cit = (wave & 3) % CIT, cow = (wave & 3) / CIT;
-  const int cib = blockIdx.y * CIB, cob = blockIdx.z * COB;
+  // (slab index, input-channel chunk) of this block.  The gy = 2 blocks that share a slab index read the SAME dY / mask
+  // tiles in the same order: place them on one XCD (workgroups are dealt round-robin over the 8 XCDs in dispatch order)
+  // so that the second reader hits that XCD's L2 instead of HBM — the weight gradient moves ~3.5 TB/s, it is bound by
+  // bytes, and dY + mask are two thirds of them.
+  int bxl = blockIdx.x, byl = blockIdx.y;
+  if (gridDim.y == 2 && (gridDim.x & 7) == 0) {
+    const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    bxl = (lin >> 4) * 8 + (lin & 7);
+    byl = (lin >> 3) & 1;
+  }
+  const int cib = byl * CIB, cob = blockIdx.z * COB;
   const int noct = P.TH * P.TWo;
-  const bool want_bias = P.bias_partial != nullptr && blockIdx.y == 0;
+  const bool want_bias = P.bias_partial != nullptr && byl == 0;
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   // this block's layer (grouped launch) and its split-K index inside the layer; tensors of that layer
-  int bx = blockIdx.x;
+  int bx = bxl;
   const float* __restrict__ Lx = P.x;
   const float* __restrict__ Ldy = P.dy;
   const float* __restrict__ Lmask = P.mask_y;
   float Lslope = P.mask_slope;
   if constexpr (GRP) {
-    const int layer = (int)blockIdx.x / P.G;
-    bx = (int)blockIdx.x - layer * P.G;
+    const int layer = bxl / P.G;
+    bx = bxl - layer * P.G;
     Lx = GR.L[layer].x;
     Ldy = GR.L[layer].dy;
     Lmask = GR.L[layer].mask_y;
@@ -323,6 +335,146 @@ __global__ __launch_bounds__(SPEC ? 768 : 256, SPEC ? 3 : 2) void k_wgrad_bf(WgB
       }
     }
   };
+  // ---- SPEC stagers, one tile ahead.  The staging above is four dependent load rounds per tile (X and dY, two batches
+  // each): ~1.5 us of exposed latency per round against 1.1 us of matrix work per tile.  Here every load of tile t+2
+  // is issued (into registers, nothing depends on it yet) right after tile t+1 has been committed to LDS, and lands
+  // while the workers run the K loop of tile t+1: the stagers never wait for memory.
+  f32x4 pxa[SPEC ? WB_PIT : 1], pxb[SPEC ? WB_PIT : 1], pya[SPEC ? WB_PIT : 1], pyb[SPEC ? WB_PIT : 1];
+  f32x4 pma[SPEC ? WB_PIT : 1], pmb[SPEC ? WB_PIT : 1];
+  auto tile_origin = [&](int tile, int& n, int& r0, int& c0) {
+    int b = tile;
+    const int txi = b % P.tiles_x;
+    b /= P.tiles_x;
+    const int tyi = b % P.tiles_y;
+    n = b / P.tiles_y;
+    r0 = tyi * P.TH;
+    c0 = txi * P.TW;
+  };
+  auto dy_strides = [&](int ch, unsigned& srow, unsigned& scol, unsigned& koff) {
+    if (P.dy_ps_r > 1) {
+      const int r = P.dy_ps_r, C = P.dy_ps_C;
+      const int chc = ch < P.Cout ? ch : 0;
+      const int qq = chc / C, c = chc - qq * C;
+      const int i = qq / r, j = qq - i * r;
+      scol = (unsigned)(r * C);
+      srow = (unsigned)(r * P.YW) * scol;
+      koff = (unsigned)(i * P.YW) * scol + (unsigned)(j * C + c);
+    } else {
+      scol = (unsigned)P.Cout;
+      srow = (unsigned)P.YW * scol;
+      koff = (unsigned)ch;
+    }
+  };
+  auto issue = [&](int tile) {
+    if constexpr (SPEC) {
+      int n, r0, c0;
+      tile_origin(tile, n, r0, c0);
+      {
+        constexpr int QN = CIB / 4, PSTEP = NST / QN;
+        const int need2 = (P.TW + P.KW) >> 1;
+        const unsigned need2_magic = wb_magic20(need2);
+        const int npairs = P.HH * need2;
+        const int by0 = r0 - P.pad, bx0 = c0 - P.pad;
+        const int q = tid % QN, ch = cib + q * 4;
+        const int nch = P.Cin - ch;
+        const float* __restrict__ xb = Lx + (size_t)n * P.XH * P.XW * P.Cin;
+#pragma unroll
+        for (int k = 0; k < WB_PIT; ++k) {
+          const int pp = tid / QN + k * PSTEP;
+          const int hy = wb_div20(pp, need2_magic), hx = (pp - hy * need2) * 2;
+          const int iy = by0 + hy, ix = bx0 + hx;
+          const bool rowok = pp < npairs && (unsigned)iy < (unsigned)P.XH && nch > 0;
+          const unsigned off = (unsigned)(iy * P.XW + ix) * (unsigned)P.Cin + (unsigned)ch;
+          pxa[k] = wb_load4(xb, nullptr, 0.f, off, rowok && (unsigned)ix < (unsigned)P.XW, nch, P.vec_x);
+          pxb[k] = wb_load4(xb, nullptr, 0.f, off + (unsigned)P.Cin, rowok && (unsigned)(ix + 1) < (unsigned)P.XW, nch, P.vec_x);
+        }
+      }
+      {
+        constexpr int QN = COB / 4, PSTEP = NST / QN;
+        const unsigned tw2_magic = wb_magic20(tw2);
+        const int npairs = P.TH * tw2;
+        const int q = tid % QN, ch = cob + q * 4;
+        const int nch = P.Cout - ch;
+        unsigned srow, scol, koff;
+        dy_strides(ch, srow, scol, koff);
+        const size_t img = (size_t)n * P.YH * srow;
+        const float* __restrict__ yb = Ldy + img;
+        const float* __restrict__ mb = Lmask ? Lmask + img : nullptr;
+#pragma unroll
+        for (int k = 0; k < WB_PIT; ++k) {
+          const int pp = tid / QN + k * PSTEP;
+          const int r = wb_div20(pp, tw2_magic), c = (pp - r * tw2) * 2;
+          const int iy = r0 + r, ix = c0 + c;
+          const bool rowok = pp < npairs && iy < P.YH && nch > 0;
+          const unsigned off = (unsigned)iy * srow + (unsigned)ix * scol + koff;
+          pya[k] = wb_load4(yb, nullptr, 0.f, off, rowok && ix < P.YW, nch, P.vec_y);
+          pyb[k] = wb_load4(yb, nullptr, 0.f, off + scol, rowok && ix + 1 < P.YW, nch, P.vec_y);
+          if (mb) {  // raw mask values: applied at commit time, so that nothing here waits for a load
+            pma[k] = wb_load4(mb, nullptr, 0.f, off, rowok && ix < P.YW, nch, P.vec_y);
+            pmb[k] = wb_load4(mb, nullptr, 0.f, off + scol, rowok && ix + 1 < P.YW, nch, P.vec_y);
+          }
+        }
+      }
+    }
+  };
+  auto commit = [&](int bsel) {
+    if constexpr (SPEC) {
+      unsigned short* xs = smem16 + bsel * buf_shorts;
+      unsigned short* ys = xs + (size_t)2 * CIB * P.CS;
+      {
+        constexpr int QN = CIB / 4, PSTEP = NST / QN;
+        const int need2 = (P.TW + P.KW) >> 1;
+        const unsigned need2_magic = wb_magic20(need2);
+        const int npairs = P.HH * need2;
+        unsigned short* xq = xs + (size_t)((tid % QN) * 4) * P.CS;
+#pragma unroll
+        for (int k = 0; k < WB_PIT; ++k) {
+          const int pp = tid / QN + k * PSTEP;
+          if (pp < npairs) {
+            const int hy = wb_div20(pp, need2_magic), hx = (pp - hy * need2) * 2;
+            unsigned hi[4], lo[4];
+            wb_split_pair(pxa[k], pxb[k], hi, lo);
+            unsigned short* dst = xq + hy * P.HWp + hx;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              *reinterpret_cast<unsigned*>(dst + (size_t)c * P.CS) = hi[c];
+              *reinterpret_cast<unsigned*>(dst + (size_t)(CIB + c) * P.CS) = lo[c];
+            }
+          }
+        }
+      }
+      {
+        constexpr int QN = COB / 4, PSTEP = NST / QN;
+        const unsigned tw2_magic = wb_magic20(tw2);
+        const int npairs = P.TH * tw2;
+        unsigned short* yq = ys + (size_t)((tid % QN) * 4) * P.DS;
+#pragma unroll
+        for (int k = 0; k < WB_PIT; ++k) {
+          const int pp = tid / QN + k * PSTEP;
+          if (pp < npairs) {
+            const int r = wb_div20(pp, tw2_magic), c = (pp - r * tw2) * 2;
+            f32x4 v0 = pya[k], v1 = pyb[k];
+            if (Lmask) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v0[e] = pma[k][e] > 0.f ? v0[e] : v0[e] * Lslope;
+                v1[e] = pmb[k][e] > 0.f ? v1[e] : v1[e] * Lslope;
+              }
+            }
+            bsum += v0 + v1;
+            unsigned hi[4], lo[4];
+            wb_split_pair(v0, v1, hi, lo);
+            unsigned short* dst = yq + r * P.TW + c;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+              *reinterpret_cast<unsigned*>(dst + (size_t)cc * P.DS) = hi[cc];
+              *reinterpret_cast<unsigned*>(dst + (size_t)(COB + cc) * P.DS) = lo[cc];
+            }
+          }
+        }
+      }
+    }
+  };
   // ---- K loop of the tile in buffer set `bsel` (4 working waves)
   auto kloop = [&](int bsel) {
     const unsigned short* xs = smem16 + bsel * buf_shorts;
@@ -387,15 +539,35 @@ __global__ __launch_bounds__(SPEC ? 768 : 256, SPEC ? 3 : 2) void k_wgrad_bf(WgB
   } else {
     const int ntb = (bx < P.ntiles) ? (P.ntiles - bx + P.G - 1) / P.G : 0;
     __syncthreads();  // tables / zero octets visible
-    if (stager && ntb > 0) stage(bx, 0);
-    __syncthreads();
-    for (int it = 0; it < ntb; ++it) {
-      if (stager) {
-        if (it + 1 < ntb) stage(bx + (it + 1) * P.G, (it + 1) & 1);
+    // Two loops, one per role, with the same barriers (1 + ntb): the stagers' prefetch registers and the workers'
+    // accumulators are never live in the same wave.
+    if (stager) {
+      if (P.prefetch && !(P.dbg & 2)) {
+        if (ntb > 0) {
+          issue(bx);
+          commit(0);
+          if (ntb > 1) issue(bx + P.G);
+        }
+        __syncthreads();
+        for (int it = 0; it < ntb; ++it) {
+          if (it + 1 < ntb) commit((it + 1) & 1);        // tile it+1: its loads were issued an iteration ago
+          if (it + 2 < ntb) issue(bx + (it + 2) * P.G);  // tile it+2: lands under the K loop of tile it+1
+          __syncthreads();
+        }
       } else {
-        kloop(it & 1);
+        if (ntb > 0) stage(bx, 0);
+        __syncthreads();
+        for (int it = 0; it < ntb; ++it) {
+          if (it + 1 < ntb) stage(bx + (it + 1) * P.G, (it + 1) & 1);
+          __syncthreads();
+        }
       }
+    } else {
       __syncthreads();
+      for (int it = 0; it < ntb; ++it) {
+        kloop(it & 1);
+        __syncthreads();
+      }
     }
   }
 
@@ -411,12 +583,12 @@ __global__ __launch_bounds__(SPEC ? 768 : 256, SPEC ? 3 : 2) void k_wgrad_bf(WgB
       const int q = tid >> 2, e = tid & 3;
       float s = 0.f;
       for (int t = q; t < NST; t += QN) s += bred[t][e];
-      P.bias_partial[(size_t)blockIdx.x * P.Cout + cob + tid] = s;
+      P.bias_partial[(size_t)bxl * P.Cout + cob + tid] = s;
     }
   }
   if (!worker) return;
   // partial slab ws[g][t][ci][co]; C/D layout: col = lane&15 (co), row = (lane>>4)*4 + reg (ci)
-  float* slab = P.ws + (size_t)blockIdx.x * P.KH * P.KW * P.Cin * P.Cout;
+  float* slab = P.ws + (size_t)bxl * P.KH * P.KW * P.Cin * P.Cout;
 #pragma unroll
   for (int u = 0; u < 3; ++u)
 #pragma unroll
@@ -473,10 +645,17 @@ static WbPlan wb_plan(const srk_conv_desc& d) {
   // pixels per padded K step (e.g. 41-wide VDSR patches: 2 x 48 -> 83 % instead of 4 x 32 -> 60 %); ties -> taller
   // tiles (less halo per pixel).
   double best_eff = -1.0;
+  static const char* tile_env = getenv("SRK_WG_TILE");  // experiment: "TH,TWo" forces the tile shape
+  int force_th = 0, force_two = 0;
+  if (tile_env) sscanf(tile_env, "%d,%d", &force_th, &force_two);
   for (int TWo = 1; TWo <= 6 && (TWo - 1) * 8 < d.OW; ++TWo) {
     const int TW = TWo * 8;
     int TH = 16 / TWo;  // <= 128 pixels per tile
     if (TH > d.OH) TH = d.OH;
+    if (force_two) {
+      if (TWo != force_two) continue;
+      TH = force_th < d.OH ? force_th : d.OH;
+    }
     for (; TH >= 1; --TH) {
       const int HH = TH + d.KH - 1, HWp = TW + 8;
       const int CS = round_8odd(HH * HWp), DS = round_8odd(TH * TW + 8);
@@ -515,6 +694,15 @@ static WbPlan wb_plan(const srk_conv_desc& d) {
   pl.G = pl.ntiles < g ? pl.ntiles : g;
   pl.ok = true;
   return pl;
+}
+
+// SPEC stagers prefetch one tile ahead when a tile's pixel pairs fit their register batches (WB_PIT x 512 items per tensor)
+static int wb_prefetch_ok(const WbPlan& pl, const srk_conv_desc& d) {
+  static const int env = getenv("SRK_WGRAD_PREFETCH") ? atoi(getenv("SRK_WGRAD_PREFETCH")) : 1;
+  if (!env) return 0;
+  const long x_items = (long)pl.HH * ((pl.TW + d.KW) >> 1) * (pl.CIB / 4);
+  const long y_items = (long)pl.TH * (pl.TW >> 1) * (pl.COB / 4);
+  return x_items <= (long)WB_PIT * 512 && y_items <= (long)WB_PIT * 512;
 }
 
 bool conv_wgrad_bf_supported(const srk_conv_desc& d) { return wb_plan(d).ok; }
@@ -635,6 +823,7 @@ int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const
   P.vec_y = (d.Cout % 4 == 0) && ((uintptr_t)dy % 16 == 0) && (!P.mask_y || (uintptr_t)P.mask_y % 16 == 0);
   P.dy_ps_r = d.dy_ps_r > 1 ? d.dy_ps_r : 0;
   P.dy_ps_C = d.dy_ps_r > 1 ? d.Cout / (d.dy_ps_r * d.dy_ps_r) : d.Cout;
+  P.prefetch = wb_prefetch_ok(pl, d);
   // wave-specialised variant: one 512-thread block per CU with two LDS buffer sets, when every block has >= 2 tiles
   // to pipeline (SRK_WGRAD_SPEC=0: never)
   static const int spec_env = getenv("SRK_WGRAD_SPEC") ? atoi(getenv("SRK_WGRAD_SPEC")) : 1;
@@ -755,6 +944,7 @@ int conv_wgrad_bf_grouped(const srk_conv_desc& d, int n, const float* const* xs,
   P.ntiles = pl.ntiles; P.G = G; P.nks = pl.nks;
   P.vec_x = vec_x; P.vec_y = vec_y;
   P.dy_ps_r = 0; P.dy_ps_C = d.Cout;
+  P.prefetch = wb_prefetch_ok(pl, d);
   {
     static int dbg = -1;
     if (dbg < 0) {
