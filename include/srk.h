@@ -239,8 +239,9 @@ int srk_grad_norm_clip(const float* g, size_t n, float max_norm, float* norm_out
  * data-parallel caller can all-reduce them (SyncBN) between the two phases. */
 int srk_bn_stats(const float* x, double* stats, size_t rows, int C, void* workspace, void* stream);
 size_t srk_bn_workspace_bytes(int C);
+/* num_batches_tracked: the module's int64 counter buffer (device), incremented by one; may be NULL */
 int srk_bn_finalize(const double* stats, double count, float* save_mean, float* save_rstd, float* running_mean,
-                    float* running_var, float momentum, float eps, int C, void* stream);
+                    float* running_var, float momentum, float eps, int C, int64_t* num_batches_tracked, void* stream);
 int srk_bn_apply(const float* x, float* y, const float* mean, const float* rstd, const float* gamma,
                  const float* beta, size_t rows, int C, int act, float slope, void* stream);
 int srk_bn_eval_params(const float* running_mean, const float* running_var, float eps, float* mean, float* rstd,

@@ -98,8 +98,9 @@ __global__ __launch_bounds__(256) void k_bn_reduce(const double* __restrict__ pa
 __global__ __launch_bounds__(256) void k_bn_finalize(const double* __restrict__ stats, double count,
                                                      float* __restrict__ save_mean, float* __restrict__ save_rstd,
                                                      float* __restrict__ rm, float* __restrict__ rv, float momentum,
-                                                     float eps, int C) {
+                                                     float eps, int C, long long* __restrict__ nbt) {
   const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;  // nn.BatchNorm's num_batches_tracked bookkeeping, without a launch of its own
   if (c >= C) return;
   const double mean = stats[c] / count;
   double var = stats[C + c] / count - mean * mean;
@@ -329,10 +330,10 @@ extern "C" int srk_bn_stats(const float* x, double* stats, size_t rows, int C, v
 
 extern "C" int srk_bn_finalize(const double* stats, double count, float* save_mean, float* save_rstd,
                                float* running_mean, float* running_var, float momentum, float eps, int C,
-                               void* stream) {
+                               int64_t* num_batches_tracked, void* stream) {
   SRK_REQUIRE(stats && save_mean && save_rstd && C > 0 && count > 0, "bn_finalize: bad args");
   hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, count, save_mean,
-                     save_rstd, running_mean, running_var, momentum, eps, C);
+                     save_rstd, running_mean, running_var, momentum, eps, C, (long long*)num_batches_tracked);
   return check_launch("bn_finalize");
 }
 

@@ -54,8 +54,14 @@ def _plan_views(m, ps_r):
     if plan is None:
         return None
     owner, plan_ps, wpf, bp, wpb, wver, bver = plan
-    if not owner.current() or (plan_ps if plan_ps > 1 else 0) != (ps_r if ps_r > 1 else 0):
+    if (plan_ps if plan_ps > 1 else 0) != (ps_r if ps_r > 1 else 0):
         return None
+    if not owner.current():
+        # the parameters changed since the plan was packed (an optimizer step of THIS model in the middle of a train
+        # step: SRGAN runs D again after d_opt.step(), and G's forward of the D step follows g_opt.step()): re-pack the
+        # whole model with one launch instead of two small pack launches per layer and direction
+        owner.pack()
+        owner, plan_ps, wpf, bp, wpb, wver, bver = m._plan
     if m.weight._version != wver or (m.bias is not None and m.bias._version != bver):
         return None
     return (wpf, bp if (ps_r > 1 and m.bias is not None) else m.bias, wpb)
@@ -120,11 +126,11 @@ class BatchNorm2d(torch.nn.BatchNorm2d):
 
     def forward(self, x):
         training = self.training or self.running_mean is None
-        if training and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)  # bookkeeping counter, not arithmetic on the path
         momentum = 0.1 if self.momentum is None else self.momentum
+        # (num_batches_tracked is bumped by the finalize kernel: no launch of its own)
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, training, momentum,
-                              self.eps, self.sync_group if training else None)
+                              self.eps, self.sync_group if training else None,
+                              self.num_batches_tracked if training else None)
 
 
 class BatchNorm1d(torch.nn.BatchNorm1d):
@@ -137,11 +143,11 @@ class BatchNorm1d(torch.nn.BatchNorm1d):
         if x.dim() != 2:
             raise NotImplementedError("BatchNorm1d is implemented for [B, F] inputs (DenseBlock); got %s" % (tuple(x.shape),))
         training = self.training or self.running_mean is None
-        if training and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
         momentum = 0.1 if self.momentum is None else self.momentum
+        # (num_batches_tracked is bumped by the finalize kernel: no launch of its own)
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, training, momentum,
-                              self.eps, self.sync_group if training else None)
+                              self.eps, self.sync_group if training else None,
+                              self.num_batches_tracked if training else None)
 
 
 class InstanceNorm2d(torch.nn.InstanceNorm2d):

@@ -696,7 +696,7 @@ def bce_loss(pred, target):
 # ------------------------------------------------------------------------------------------------
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, sync_group):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, sync_group, nbt=None):
         lib = _lib.load()
         require_cuda(x, gamma, beta)
         x = _dense(x)   # [N,C,H,W] stored NHWC, or [B,F] (BatchNorm1d of DenseBlock, base_networks.py:13): rows x C
@@ -713,8 +713,11 @@ class _BatchNorm(torch.autograd.Function):
                 import torch.distributed as dist
                 dist.all_reduce(stats, group=sync_group)
                 count *= dist.get_world_size(sync_group)
+            if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
+                raise RuntimeError("batch_norm: num_batches_tracked must be a CUDA int64 tensor")
             check(lib.srk_bn_finalize(ptr(stats), count, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
-                                      momentum, eps, c, stream_ptr()), "srk_bn_finalize")
+                                      momentum, eps, c, None if nbt is None else ctypes.c_void_p(nbt.data_ptr()),
+                                      stream_ptr()), "srk_bn_finalize")
         else:
             check(lib.srk_bn_eval_params(ptr(running_mean), ptr(running_var), eps, ptr(mean), ptr(rstd), c,
                                          stream_ptr()), "srk_bn_eval_params")
@@ -755,13 +758,14 @@ class _BatchNorm(torch.autograd.Function):
                                         ptr(dx), rows, c, stream_ptr()), "srk_bn_backward_apply")
         # parameter gradients use the LOCAL sums (the DP gradient all-reduce happens later)
         check(lib.srk_bn_param_grads(ptr(local), ptr(dgamma), ptr(dbeta), c, stream_ptr()), "srk_bn_param_grads")
-        return dx, ret_g, ret_b, None, None, None, None, None, None
+        return dx, ret_g, ret_b, None, None, None, None, None, None, None
 
 
-def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, sync_group=None):
+def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, sync_group=None,
+               num_batches_tracked=None):
     """nn.BatchNorm2d (base_networks.py:46,117,161) on [N,C,H,W]; nn.BatchNorm1d (base_networks.py:13) on [B,F]."""
     return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, bool(training), float(momentum), float(eps),
-                            sync_group)
+                            sync_group, num_batches_tracked)
 
 
 class _InstanceNorm(torch.autograd.Function):
@@ -785,7 +789,7 @@ class _InstanceNorm(torch.autograd.Function):
         xs, ys = x.permute(0, 2, 3, 1), y.permute(0, 2, 3, 1)   # [n][h][w][c] views of the NHWC storage
         for i in range(n):
             check(lib.srk_bn_stats(ptr(xs[i]), ptr(stats), rows, c, ptr(ws), stream_ptr()), "srk_bn_stats")
-            check(lib.srk_bn_finalize(ptr(stats), float(rows), ptr(mean[i]), ptr(rstd[i]), None, None, 0.0, eps, c,
+            check(lib.srk_bn_finalize(ptr(stats), float(rows), ptr(mean[i]), ptr(rstd[i]), None, None, 0.0, eps, c, None,
                                       stream_ptr()), "srk_bn_finalize")
             check(lib.srk_bn_apply(ptr(xs[i]), ptr(ys[i]), ptr(mean[i]), ptr(rstd[i]), None, None, rows, c, ACT_NONE, 0.0,
                                    stream_ptr()), "srk_bn_apply")

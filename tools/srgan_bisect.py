@@ -30,7 +30,7 @@ def conv2d_ref(x, weight, bias=None, residual=None, cfg=None, packed=None, res_b
     return y.float().contiguous(memory_format=torch.channels_last)
 
 
-def bn_ref(x, gamma, beta, rm, rv, training, momentum=0.1, eps=1e-5, sync_group=None):
+def bn_ref(x, gamma, beta, rm, rv, training, momentum=0.1, eps=1e-5, sync_group=None, num_batches_tracked=None):
     xd = x.double()
     dims = [0, 2, 3] if x.dim() == 4 else [0]
     shape = [1, -1, 1, 1] if x.dim() == 4 else [1, -1]
