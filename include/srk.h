@@ -242,6 +242,11 @@ size_t srk_bn_workspace_bytes(int C);
 /* num_batches_tracked: the module's int64 counter buffer (device), incremented by one; may be NULL */
 int srk_bn_finalize(const double* stats, double count, float* save_mean, float* save_rstd, float* running_mean,
                     float* running_var, float momentum, float eps, int C, int64_t* num_batches_tracked, void* stream);
+/* srk_bn_stats + srk_bn_finalize in two launches instead of three (single-GPU / per-shard statistics: no all-reduce
+ * between the phases); `stats` still receives the [2*C] sums. */
+int srk_bn_stats_finalize(const float* x, double* stats, size_t rows, int C, float* save_mean, float* save_rstd,
+                          float* running_mean, float* running_var, float momentum, float eps,
+                          int64_t* num_batches_tracked, void* workspace, void* stream);
 int srk_bn_apply(const float* x, float* y, const float* mean, const float* rstd, const float* gamma,
                  const float* beta, size_t rows, int C, int act, float slope, void* stream);
 int srk_bn_eval_params(const float* running_mean, const float* running_var, float eps, float* mean, float* rstd,
@@ -252,6 +257,10 @@ int srk_bn_eval_params(const float* running_mean, const float* running_var, floa
  * dgamma += dstats[C+c]. */
 int srk_bn_backward_stats(const float* dy, const float* x, const float* mean, const float* rstd, double* dstats,
                           size_t rows, int C, void* workspace, void* stream);
+/* srk_bn_backward_stats + srk_bn_param_grads (from the LOCAL sums, as the data-parallel gradient exchange expects) in
+ * two launches instead of three; dgamma / dbeta may be NULL. */
+int srk_bn_backward_stats_grads(const float* dy, const float* x, const float* mean, const float* rstd, double* dstats,
+                                size_t rows, int C, float* dgamma, float* dbeta, void* workspace, void* stream);
 int srk_bn_backward_apply(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                           const double* dstats, double count, float* dx, size_t rows, int C, void* stream);
 int srk_bn_param_grads(const double* dstats, float* dgamma, float* dbeta, int C, void* stream);

@@ -85,6 +85,8 @@ _PROTOTYPES = {
     "srk_bn_stats": (c_int, [c_f, c_vp, c_size, c_int, c_vp, c_vp]),
     "srk_bn_workspace_bytes": (c_size, [c_int]),
     "srk_bn_finalize": (c_int, [c_vp, ctypes.c_double, c_f, c_f, c_f, c_f, c_float, c_float, c_int, c_vp, c_vp]),
+    "srk_bn_stats_finalize": (c_int, [c_f, c_vp, c_size, c_int, c_f, c_f, c_f, c_f, c_float, c_float, c_vp, c_vp, c_vp]),
+    "srk_bn_backward_stats_grads": (c_int, [c_f, c_f, c_f, c_f, c_vp, c_size, c_int, c_f, c_f, c_vp, c_vp]),
     "srk_bn_apply": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_size, c_int, c_int, c_float, c_vp]),
     "srk_bn_eval_params": (c_int, [c_f, c_f, c_float, c_f, c_f, c_int, c_vp]),
     "srk_bn_backward_stats": (c_int, [c_f, c_f, c_f, c_f, c_vp, c_size, c_int, c_vp, c_vp]),

@@ -95,6 +95,59 @@ __global__ __launch_bounds__(256) void k_bn_reduce(const double* __restrict__ pa
   if (w == 0 && i < C2) stats[i] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
 }
 
+// k_bn_reduce fused with what consumes the reduced sums (one launch less per BatchNorm call and direction):
+//   MODE 0 (forward):  + k_bn_finalize  (mean / rstd / running statistics / num_batches_tracked)
+//   MODE 1 (backward): + k_bn_param_grads (dbeta += sum dy, dgamma += sum dy * xhat)
+// 64 channels per block, lane = channel; the 4 waves take every 4th split, combined through LDS in a fixed order.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bn_reduce_fused(const double* __restrict__ partial, double* __restrict__ stats,
+                                                         int nsplit, int C, double count, float* __restrict__ o0,
+                                                         float* __restrict__ o1, float* __restrict__ rm,
+                                                         float* __restrict__ rv, float momentum, float eps,
+                                                         long long* __restrict__ nbt) {
+  __shared__ double sm[2][4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+  if (c < C) {
+    int k = w;
+    for (; k + 4 < nsplit; k += 8) {
+      a0 += partial[(size_t)k * 2 * C + c];
+      b0 += partial[(size_t)k * 2 * C + C + c];
+      a1 += partial[(size_t)(k + 4) * 2 * C + c];
+      b1 += partial[(size_t)(k + 4) * 2 * C + C + c];
+    }
+    for (; k < nsplit; k += 4) {
+      a0 += partial[(size_t)k * 2 * C + c];
+      b0 += partial[(size_t)k * 2 * C + C + c];
+    }
+  }
+  sm[0][w][lane] = a0 + a1;
+  sm[1][w][lane] = b0 + b1;
+  __syncthreads();
+  if (w != 0 || c >= C) return;
+  const double s0 = (sm[0][0][lane] + sm[0][1][lane]) + (sm[0][2][lane] + sm[0][3][lane]);
+  const double s1 = (sm[1][0][lane] + sm[1][1][lane]) + (sm[1][2][lane] + sm[1][3][lane]);
+  stats[c] = s0;
+  stats[C + c] = s1;
+  if (MODE == 0) {
+    if (c == 0 && nbt) *nbt += 1;
+    const double mean = s0 / count;
+    double var = s1 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    o0[c] = (float)mean;
+    o1[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rm) rm[c] = (1.f - momentum) * rm[c] + momentum * (float)mean;
+    if (rv) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unbiased;
+    }
+  } else {
+    if (o1) o1[c] += (float)s0;  // dbeta
+    if (o0) o0[c] += (float)s1;  // dgamma
+  }
+}
+
 __global__ __launch_bounds__(256) void k_bn_finalize(const double* __restrict__ stats, double count,
                                                      float* __restrict__ save_mean, float* __restrict__ save_rstd,
                                                      float* __restrict__ rm, float* __restrict__ rv, float momentum,
@@ -175,8 +228,16 @@ static bool bn_fp32_backward() {
   return v;
 }
 
+struct BnFused {   // fused tail of bn_colsum: what the reduce kernel also computes
+  int mode = -1;   // -1: plain reduce
+  double count = 0.0;
+  float *o0 = nullptr, *o1 = nullptr, *rm = nullptr, *rv = nullptr;
+  float momentum = 0.f, eps = 0.f;
+  long long* nbt = nullptr;
+};
+
 static int bn_colsum(int mode, const float* a, const float* x, const float* mean, const float* rstd, double* out,
-                     size_t rows, int C, void* ws, hipStream_t s) {
+                     size_t rows, int C, void* ws, hipStream_t s, const BnFused& fu = BnFused()) {
   int splits = (int)((rows + 127) / 128);
   if (splits > kBnRowSplits) splits = kBnRowSplits;
   if (splits < 1) splits = 1;
@@ -188,7 +249,14 @@ static int bn_colsum(int mode, const float* a, const float* x, const float* mean
     hipLaunchKernelGGL((k_bn_colsum<1, false>), grid, dim3(256), 0, s, a, x, mean, rstd, (double*)ws, rows, C, rps);
   else
     hipLaunchKernelGGL((k_bn_colsum<1, true>), grid, dim3(256), 0, s, a, x, mean, rstd, (double*)ws, rows, C, rps);
-  hipLaunchKernelGGL(k_bn_reduce, dim3(cdiv(2 * C, 64)), dim3(256), 0, s, (const double*)ws, out, splits, 2 * C);
+  if (fu.mode == 0)
+    hipLaunchKernelGGL(k_bn_reduce_fused<0>, dim3(cdiv(C, 64)), dim3(256), 0, s, (const double*)ws, out, splits, C, fu.count,
+                       fu.o0, fu.o1, fu.rm, fu.rv, fu.momentum, fu.eps, fu.nbt);
+  else if (fu.mode == 1)
+    hipLaunchKernelGGL(k_bn_reduce_fused<1>, dim3(cdiv(C, 64)), dim3(256), 0, s, (const double*)ws, out, splits, C, 0.0, fu.o0,
+                       fu.o1, nullptr, nullptr, 0.f, 0.f, nullptr);
+  else
+    hipLaunchKernelGGL(k_bn_reduce, dim3(cdiv(2 * C, 64)), dim3(256), 0, s, (const double*)ws, out, splits, 2 * C);
   return check_launch("bn_colsum");
 }
 
@@ -326,6 +394,25 @@ extern "C" size_t srk_bn_workspace_bytes(int C) { return (size_t)kBnRowSplits * 
 extern "C" int srk_bn_stats(const float* x, double* stats, size_t rows, int C, void* workspace, void* stream) {
   SRK_REQUIRE(x && stats && workspace && rows > 0 && C > 0, "bn_stats: bad args");
   return bn_colsum(0, x, nullptr, nullptr, nullptr, stats, rows, C, workspace, (hipStream_t)stream);
+}
+
+extern "C" int srk_bn_stats_finalize(const float* x, double* stats, size_t rows, int C, float* save_mean, float* save_rstd,
+                                     float* running_mean, float* running_var, float momentum, float eps,
+                                     int64_t* num_batches_tracked, void* workspace, void* stream) {
+  SRK_REQUIRE(x && stats && workspace && save_mean && save_rstd && rows > 0 && C > 0, "bn_stats_finalize: bad args");
+  BnFused fu;
+  fu.mode = 0; fu.count = (double)rows; fu.o0 = save_mean; fu.o1 = save_rstd; fu.rm = running_mean; fu.rv = running_var;
+  fu.momentum = momentum; fu.eps = eps; fu.nbt = (long long*)num_batches_tracked;
+  return bn_colsum(0, x, nullptr, nullptr, nullptr, stats, rows, C, workspace, (hipStream_t)stream, fu);
+}
+
+extern "C" int srk_bn_backward_stats_grads(const float* dy, const float* x, const float* mean, const float* rstd,
+                                           double* dstats, size_t rows, int C, float* dgamma, float* dbeta, void* workspace,
+                                           void* stream) {
+  SRK_REQUIRE(dy && x && mean && rstd && dstats && workspace && rows > 0 && C > 0, "bn_backward_stats_grads: bad args");
+  BnFused fu;
+  fu.mode = 1; fu.o0 = dgamma; fu.o1 = dbeta;
+  return bn_colsum(1, dy, x, mean, rstd, dstats, rows, C, workspace, (hipStream_t)stream, fu);
 }
 
 extern "C" int srk_bn_finalize(const double* stats, double count, float* save_mean, float* save_rstd,

@@ -708,16 +708,20 @@ class _BatchNorm(torch.autograd.Function):
         if training:
             stats = torch.empty(2 * c, dtype=torch.float64, device=x.device)
             ws = torch.empty(int(lib.srk_bn_workspace_bytes(c)), dtype=torch.uint8, device=x.device)
-            check(lib.srk_bn_stats(ptr(x), ptr(stats), rows, c, ptr(ws), stream_ptr()), "srk_bn_stats")
-            if sync_group is not None:
-                import torch.distributed as dist
-                dist.all_reduce(stats, group=sync_group)
-                count *= dist.get_world_size(sync_group)
             if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
                 raise RuntimeError("batch_norm: num_batches_tracked must be a CUDA int64 tensor")
-            check(lib.srk_bn_finalize(ptr(stats), count, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
-                                      momentum, eps, c, None if nbt is None else ctypes.c_void_p(nbt.data_ptr()),
-                                      stream_ptr()), "srk_bn_finalize")
+            nbt_p = None if nbt is None else ctypes.c_void_p(nbt.data_ptr())
+            if sync_group is None:   # statistics + finalize: column sums, then reduce + mean / rstd / running stats
+                check(lib.srk_bn_stats_finalize(ptr(x), ptr(stats), rows, c, ptr(mean), ptr(rstd), ptr(running_mean),
+                                                ptr(running_var), momentum, eps, nbt_p, ptr(ws), stream_ptr()),
+                      "srk_bn_stats_finalize")
+            else:                    # SyncBN: the [2C] sums are all-reduced between the two phases
+                import torch.distributed as dist
+                check(lib.srk_bn_stats(ptr(x), ptr(stats), rows, c, ptr(ws), stream_ptr()), "srk_bn_stats")
+                dist.all_reduce(stats, group=sync_group)
+                count *= dist.get_world_size(sync_group)
+                check(lib.srk_bn_finalize(ptr(stats), count, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
+                                          momentum, eps, c, nbt_p, stream_ptr()), "srk_bn_finalize")
         else:
             check(lib.srk_bn_eval_params(ptr(running_mean), ptr(running_var), eps, ptr(mean), ptr(rstd), c,
                                          stream_ptr()), "srk_bn_eval_params")
@@ -738,26 +742,24 @@ class _BatchNorm(torch.autograd.Function):
         rows = x.numel() // c
         dstats = torch.empty(2 * c, dtype=torch.float64, device=x.device)
         ws = torch.empty(int(lib.srk_bn_workspace_bytes(c)), dtype=torch.uint8, device=x.device)
-        check(lib.srk_bn_backward_stats(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(dstats), rows, c, ptr(ws),
-                                        stream_ptr()), "srk_bn_backward_stats")
-        local = dstats
-        if ctx.training and ctx.sync_group is not None:
-            import torch.distributed as dist
-            local = dstats.clone()
-            dist.all_reduce(dstats, group=ctx.sync_group)
-        dx = torch.empty_like(dy)
         dgamma = getattr(ctx.gamma_ref, "_srk_grad", None)
         dbeta = getattr(ctx.beta_ref, "_srk_grad", None)
         ret_g = ret_b = None
         if dgamma is None or dbeta is None:
             dgamma = ret_g = torch.zeros(c, dtype=torch.float32, device=x.device)
             dbeta = ret_b = torch.zeros(c, dtype=torch.float32, device=x.device)
+        # statistics of the backward + the parameter gradients (from the LOCAL sums: the DP gradient all-reduce happens
+        # later) in two launches
+        check(lib.srk_bn_backward_stats_grads(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(dstats), rows, c, ptr(dgamma),
+                                              ptr(dbeta), ptr(ws), stream_ptr()), "srk_bn_backward_stats_grads")
+        if ctx.training and ctx.sync_group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(dstats, group=ctx.sync_group)
+        dx = torch.empty_like(dy)
         # eval-mode BN: statistics are constants -> no mean/projection terms in dx
         use = dstats if ctx.training else torch.zeros_like(dstats)
         check(lib.srk_bn_backward_apply(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(use), ctx.count,
                                         ptr(dx), rows, c, stream_ptr()), "srk_bn_backward_apply")
-        # parameter gradients use the LOCAL sums (the DP gradient all-reduce happens later)
-        check(lib.srk_bn_param_grads(ptr(local), ptr(dgamma), ptr(dbeta), c, stream_ptr()), "srk_bn_param_grads")
         return dx, ret_g, ret_b, None, None, None, None, None, None, None
 
 
