@@ -179,6 +179,8 @@ def train_extra(pkg, dev, rank, world, nsteps=20):
             dp.comm_enabled = False
             sec_nocomm = time_steps(lambda: step(inp, tgt), steps, 2, world, dev)
             dp.comm_enabled = True
+        torch.cuda.synchronize()
+        step.close()          # graphs are destroyed here, never by the garbage collector in the middle of a later capture
         return sec, steps, sec_nocomm
 
     def c1():
@@ -310,6 +312,8 @@ def train_extra(pkg, dev, rank, world, nsteps=20):
             fn()
         except Exception as e:  # noqa: BLE001 - reported, not swallowed
             out[name + "_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+        import gc
+        gc.collect()
         torch.cuda.empty_cache()
     return out
 

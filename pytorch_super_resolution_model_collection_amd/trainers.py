@@ -7,11 +7,30 @@ synchronisation (the reference syncs every iteration through loss.data[0], edsr.
 `GraphedStep` captures the forward+backward and the optimizer parts into hipGraphs so a step is
 two graph launches (+ the all-reduce) instead of ~200 kernel launches from Python.
 """
+import contextlib
+import gc
+
 import torch
 
 from . import ops
 from .layers import bump_weight_epoch
 from .optim import FlatParams, make_optimizer
+
+
+@contextlib.contextmanager
+def _no_gc_during_capture():
+    """hipGraph objects must not be destroyed while a stream is capturing (`hipErrorStreamCaptureUnsupported`, raised
+    from a destructor = process abort).  An earlier GraphedStep / GraphedSegments that is only reachable through a
+    reference cycle (bound methods in its segment list) is freed by the cyclic garbage collector at an arbitrary
+    allocation — e.g. in the middle of the next capture.  Collect first, keep the collector off while capturing."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def _backward(loss, dp):
@@ -161,24 +180,25 @@ class GraphedSegments(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.plan, pool = [], None
-        for fn, dp in segments:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
-                self.out = fn(*self.static)
-            pool = g.pool()
-            wgraphs, sends, keep = [], [], None
-            if dp is not None and dp.world > 1:
-                keep = ops.pending_wgrad_groups(dp.trunk_chunk_layers)   # holds x / dy / mask tensors of graph `g` alive
-                sends = dp.plan(keep)
-                ops.drop_pending_wgrads()
-                for recs in keep:
-                    wg = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(wg, pool=pool):
-                        ops.launch_wgrad_group(recs)
-                    wgraphs.append(wg)
-            else:
-                ops.join_side_streams()
-            self.plan.append((g, dp, wgraphs, sends, keep))
+        with _no_gc_during_capture():
+            for fn, dp in segments:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    self.out = fn(*self.static)
+                pool = g.pool()
+                wgraphs, sends, keep = [], [], None
+                if dp is not None and dp.world > 1:
+                    keep = ops.pending_wgrad_groups(dp.trunk_chunk_layers)   # holds x / dy / mask tensors of graph `g` alive
+                    sends = dp.plan(keep)
+                    ops.drop_pending_wgrads()
+                    for recs in keep:
+                        wg = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(wg, pool=pool):
+                            ops.launch_wgrad_group(recs)
+                        wgraphs.append(wg)
+                else:
+                    ops.join_side_streams()
+                self.plan.append((g, dp, wgraphs, sends, keep))
 
     def _eager(self):
         out = None
@@ -256,9 +276,15 @@ class GraphedStep(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_a):
-            self.loss = self._fwd_bwd()
-            self._update()
+        with _no_gc_during_capture():
+            with torch.cuda.graph(self.graph_a):
+                self.loss = self._fwd_bwd()
+                self._update()
+
+    def close(self):
+        """Drop the captured graphs now (outside any capture) instead of whenever the garbage collector finds them."""
+        self.seg = None
+        self.graph_a = None
 
     def _fwd_bwd_args(self, *static):
         self.static = list(static)
@@ -311,8 +337,9 @@ class GraphedFn(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = fn(*self.static)
+        with _no_gc_during_capture():
+            with torch.cuda.graph(self.graph):
+                self.out = fn(*self.static)
 
     def __call__(self, *batch):
         for s, b in zip(self.static, batch):
