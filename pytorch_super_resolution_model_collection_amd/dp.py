@@ -14,8 +14,12 @@ whole model one message (EDSR 6.07 MB, VDSR 2.67 MB) or a handful of multi-MB bu
 """
 import os
 
-import torch
-import torch.distributed as dist
+# the host driver of these boxes only supports dmabuf IPC: without this RCCL / cross-process GPU memory sharing fails with
+# `hipIpcGetMemHandle: invalid argument` (must be in the environment before the HIP runtime initialises)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 def init_from_env(backend=None):

@@ -26,8 +26,13 @@ try:
     dp = pkg.dp.DataParallel(flat); dp.broadcast_params()
     x = torch.rand(B, 3, 32, 32, device=dev); t = torch.rand(B, 3, 128, 128, device=dev)
     step = pkg.trainers.GraphedStep(net, opt, pkg.ops.l1_loss, (x, t), dp=dp, warmup=2)
+    import time
     for _ in range(3): step(x, t)
     torch.cuda.synchronize()
+    for i in range(4):
+        torch.distributed.barrier(); t0 = time.perf_counter(); step(x, t); torch.cuda.synchronize()
+        print("rank", rank, "step %d: %.2f ms" % (i, (time.perf_counter() - t0) * 1e3), flush=True)
+    print("rank", rank, "sends per group:", [[(lo, hi - lo) for lo, hi in r] for _, _, _, r_all, _ in step.seg.plan for r in (r_all or [])], flush=True)
     print("rank", rank, "edsr graph-split DP step ok, loss", float(step.loss), flush=True)
 except Exception:
     traceback.print_exc(); sys.stdout.flush(); sys.stderr.flush(); os._exit(1)
