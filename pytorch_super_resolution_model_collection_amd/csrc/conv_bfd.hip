@@ -186,6 +186,35 @@ __device__ __forceinline__ void bfd_epilogue(const MfmaConvParams& P, float* sme
   }
 }
 
+// Direct epilogue of the transposed product (C/D: col = lane & 15 = pixel of the M tile, rows kq*4 + reg = 4
+// consecutive output channels of the N tile): one 16-byte store per (pixel tile, channel tile) and lane, the 4 kq
+// lanes of a pixel cover 64 contiguous bytes — no LDS slab, no barrier.  On a small problem (one tile per CU, the
+// kernel a latency chain) the LDS-staged epilogue was 2.2 of the 12.4 us; its better store coalescing only pays
+// when the epilogue is bandwidth-bound (large problems keep it).
+template <int NTW>
+__device__ __forceinline__ void bfd_epilogue_direct(const MfmaConvParams& P, const f32x4 (&acc)[4][NTW], int n, int r0,
+                                                    int c0, int ocb, int pw, int ow, int lane, bool active) {
+  if (!active) return;
+  const int j = lane & 15, kq = lane >> 4;
+  const int npx = P.TH * P.TW;
+  const int tw_magic = div_small_magic(P.TW);
+  const EpiTile et = epi_tile_setup(P, n, r0, c0);
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const int oc4 = ocb + (ow * NTW + nt) * 16 + kq * 4;
+    if (oc4 >= P.OC) continue;
+    const EpiCol col = epi_col_setup(P.ep, P.OW, P.OC, oc4);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = pw * 64 + mt * 16 + j;
+      if (m < npx) {
+        const int r = div_small(m, tw_magic), c = m - r * P.TW;
+        if (r0 + r < P.PH && c0 + c < P.PW) epi_store4_tile(P.ep, col, et, r, c, acc[mt][nt], P.out);
+      }
+    }
+  }
+}
+
 // KS = 2 (small problems with every chunk staged up front): a second set of NPW*NOW waves takes the odd channel
 // chunks -- two waves per SIMD on a block that is pure latency otherwise -- and the partial accumulators meet in LDS
 // before the epilogue.
@@ -193,6 +222,7 @@ template <int NTW, int NPW, int NOW, int NP, int PF, int KS>
 __global__ __launch_bounds__(64 * NPW * NOW * KS, 2) void k_conv_bfd(
     BfdParams B) {
   constexpr int NTHR = 64 * NPW * NOW * KS;
+  constexpr bool TEPI = NPW == 1;
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   const MfmaConvParams& P = B.P;
   uint4* hal = smem4;  // [NP][4][NPIXp]
@@ -282,9 +312,12 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, 2) void k_conv_bfd(
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) a[p][mt] = hb[hp[mt] + p * plane];
       // smallest products first; every pass runs over 4*NTW independent accumulators
+      // TEPI (single pixel-wave blocks = the small-problem configuration): the product runs transposed (A = filter,
+      // B = pixels; the fragment layouts of the two operands are the same), so that a lane ends up with 4 consecutive
+      // output channels of one pixel and stores them directly (bfd_epilogue_direct)
 #define SRK_BFD_PASS(pa, pb)                                                              \
   _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = \
-      mfma16(a[pa][mt], bf[pb][nt], acc[mt][nt]);
+      TEPI ? mfma16(bf[pb][nt], a[pa][mt], acc[mt][nt]) : mfma16(a[pa][mt], bf[pb][nt], acc[mt][nt]);
       if (NP == 3) {
         SRK_BFD_PASS(NP - 1, 0)
         SRK_BFD_PASS(0, NP - 1)
@@ -391,7 +424,10 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, 2) void k_conv_bfd(
         for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] += red[(mt * NTW + nt) * 64];
     }
   }
-  bfd_epilogue<NTW, NPW, NOW>(P, reinterpret_cast<float*>(smem4), acc, n, r0, c0, ocb, pw, ow, lane, kgrp == 0);
+  if constexpr (TEPI)
+    bfd_epilogue_direct<NTW>(P, acc, n, r0, c0, ocb, pw, ow, lane, kgrp == 0);
+  else
+    bfd_epilogue<NTW, NPW, NOW>(P, reinterpret_cast<float*>(smem4), acc, n, r0, c0, ocb, pw, ow, lane, kgrp == 0);
 }
 
 // ---------------------------------------------------------------------------------------------
