@@ -165,5 +165,11 @@ def require_cuda(*tensors):
             raise RuntimeError(
                 "the MI355X hot path only runs on GPU tensors (got a %s tensor); there is no CPU fallback — "
                 "use oracle/ for a CPU reference" % t.device)
+        if t is not None and t.device.index is not None and t.device.index != torch.cuda.current_device():
+            # kernels are enqueued on the CURRENT device's stream (one process per GPU): a tensor of another device
+            # would be dereferenced by the wrong GPU
+            raise RuntimeError("tensor on %s but the current device is cuda:%d — call torch.cuda.set_device(%d) (one "
+                               "process per GPU) or wrap the call in torch.cuda.device(...)"
+                               % (t.device, torch.cuda.current_device(), t.device.index))
         if t is not None and t.dtype != torch.float32:
             raise RuntimeError("the hot path is fp32 (got %s)" % t.dtype)
