@@ -164,21 +164,41 @@ class _Trainer(object):
             return self.model(x.to(self.device))
 
     def test(self, loader=None):
-        """Evaluation loop (espcn.py:173-215): forward + PSNR per image; returns the list of PSNRs."""
+        """Evaluation loop (espcn.py:173-215, edsr.py:196-250): forward + PSNR per image (computed on the device), over
+        `loader`, else over every folder of `test_dataset` that exists under `data_dir` (data.get_test_set), else over
+        seeded synthetic pairs.  Returns the list of PSNRs; `self.test_psnr` holds the per-dataset averages."""
         if self.model is None:
             self.model = self.build_model().to(self.device)
             self.load_model()
-        psnrs = []
-        batches = loader if loader is not None else synthetic_loader(self.kind, self.args, 2, self.device, 4321)
-        for batch in batches:
-            out = self._infer(self._net_input(batch[0].to(self.device)))
-            out = out[-1] if isinstance(out, tuple) else out
-            tgt = batch[-1].to(self.device)
-            if self.kind == "srcnn":     # srcnn.py:193-199: border pixels excluded
-                tgt = utils.shave(tgt, 8)
-            if out.shape == tgt.shape:
-                psnrs.append(utils.PSNR(out, tgt))   # 0-dim device tensors: nothing syncs inside the loop
-        return [float(v) for v in torch.stack(psnrs).cpu()] if psnrs else []
+        sources = []
+        if loader is not None:
+            sources.append(("loader", loader))
+        else:
+            for name in (self.test_dataset or []):
+                ld = self.load_dataset(name, is_train=False) if isinstance(name, str) and len(name) > 1 else None
+                if ld is not None:
+                    sources.append((name, ld))
+            if not sources:
+                sources.append(("synthetic", synthetic_loader(self.kind, self.args, 2, self.device, 4321)))
+        psnrs, self.test_psnr = [], {}
+        for name, batches in sources:
+            mine = []
+            for batch in batches:
+                items = [batch] if torch.is_tensor(batch[0]) else list(zip(*batch))   # ragged test images come as lists
+                for item in items:
+                    lr_img, hr_img = self._channels(*[t if t.dim() == 4 else t.unsqueeze(0) for t in item[:2]])
+                    out = self._infer(self._net_input(lr_img.to(self.device)))
+                    out = out[-1] if isinstance(out, tuple) else out
+                    tgt = hr_img.to(self.device)
+                    if self.kind == "srcnn":     # srcnn.py:193-199: border pixels excluded
+                        tgt = utils.shave(tgt, 8)
+                    if out.shape == tgt.shape:
+                        mine.append(utils.PSNR(out, tgt))   # 0-dim device tensors: nothing syncs inside the loop
+            vals = [float(v) for v in torch.stack(mine).cpu()] if mine else []
+            if vals:
+                self.test_psnr[name] = sum(vals) / len(vals)
+            psnrs += vals
+        return psnrs
 
     def test_single(self, img):
         """Super-resolve one [C,H,W] (or [1,C,H,W]) tensor (the reference reads an image file with PIL)."""

@@ -155,3 +155,7 @@ def test_patch_loader_batches_and_trains(gpu, tmp_path):
     hist = t.train()
     assert len(hist) == 2 and all(np.isfinite(hist))
     assert t.data_source == "folder"
+    # test(): the reference's test folders (data.py:54-65) when they exist — per-image device PSNR, HR target = item[1]
+    make_images(os.path.join(root, "Set5"), [(64, 48), (40, 40)])
+    psnr = t.test()
+    assert len(psnr) == 2 and all(np.isfinite(psnr)) and list(t.test_psnr) == ["Set5"]
