@@ -35,7 +35,8 @@ int conv_wgrad_reduce_launch(const float* ws, float* dw, int G, int Cout, int Ci
                              hipStream_t s);
 
 constexpr int WB_MAXOCT = 64;  // octets per tile (<= 512 pixels)
-constexpr int WB_PIT = 2;      // SPEC stagers: register batches per tensor and tile when prefetching one tile ahead
+constexpr int WB_SST = 512;    // SPEC: staging threads (8 waves next to the 4 working waves; 4 stager waves: 0.157 -> 0.20 ms on the VDSR layer)
+constexpr int WB_PIT = 1024 / WB_SST;  // SPEC stagers: register batches per tensor and tile when prefetching one tile ahead
 constexpr int WB_IT = 1;       // pixel pairs per thread loaded together while staging (4 measured: no gain plain, spills in the specialised variant)
 
 struct WgBfParams {
@@ -115,6 +116,20 @@ __device__ __forceinline__ void wb_split_pair(const f32x4& p0, const f32x4& p1, 
   }
 }
 
+// Buffer descriptor over [base, base + bytes) built from wave-uniform values (the readfirstlane makes the uniformity
+// provable: no waterfall loop around the loads), and a 16-byte load through it: an offset outside the range reads zero.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wb_rsrc(const float* base, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  void* p = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(p, (short)0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ f32x4 wb_bload(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  typedef unsigned wb_u32x4 __attribute__((ext_vector_type(4)));
+  const wb_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+  return __builtin_bit_cast(f32x4, v);
+}
+
 // Exact floor(m / d) for 0 <= m < 2^20 / d with one multiply (magic = ceil(2^20 / d)): pixel-pair counters of a tile
 __host__ __device__ __forceinline__ unsigned wb_magic20(int d) { return (unsigned)(((1u << 20) + d - 1) / d); }
 __device__ __forceinline__ int wb_div20(int m, unsigned magic) { return (int)(((unsigned)m * magic) >> 20); }
@@ -152,11 +167,11 @@ __device__ __forceinline__ f32x4 wb_load4(const float* __restrict__ src, const f
 // The per-tile kernel's two phases are about equally long and co-resident blocks run them in lockstep; here they
 // overlap by construction, and one block per CU halves the number of partial slabs.
 template <int CIT, int COW, int NTW, bool SPEC, bool GRP>
-__global__ __launch_bounds__(SPEC ? 768 : 256, SPEC ? 3 : 2) void k_wgrad_bf(WgBfParams P,
+__global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 256 : 2) void k_wgrad_bf(WgBfParams P,
                                                                              typename WgGroupArg<GRP>::type GR) {
   constexpr int CIB = CIT * 16, COB = COW * NTW * 16;
-  constexpr int NTHR = SPEC ? 768 : 256;
-  constexpr int NST = SPEC ? 512 : 256;  // staging threads (SPEC: 8 stager waves keep the staging rate of two 256-thread blocks)
+  constexpr int NTHR = SPEC ? 256 + WB_SST : 256;
+  constexpr int NST = SPEC ? WB_SST : 256;  // staging threads (SPEC: 8 stager waves keep the staging rate of two 256-thread blocks)
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
   __shared__ int oct_x[WB_MAXOCT], oct_y[WB_MAXOCT];
   __shared__ float bred[NST][4];
@@ -365,53 +380,87 @@ __global__ __launch_bounds__(SPEC ? 768 : 256, SPEC ? 3 : 2) void k_wgrad_bf(WgB
       koff = (unsigned)ch;
     }
   };
-  auto issue = [&](int tile) {
-    if constexpr (SPEC) {
-      int n, r0, c0;
-      tile_origin(tile, n, r0, c0);
+  // Everything about a stager's items that does not depend on the tile is computed once: byte offset of the item
+  // relative to the tile origin, its LDS destination (-1: no item), its column inside the tile.  Per tile and item
+  // what is left is one add, two column compares and two selects: loads go through a buffer descriptor of the image
+  // (rows above / below the image fall outside it and read as zero, columns left / right get an out-of-range offset),
+  // so there is no per-load branch either.  The staging waves are bound by their VALU issue slots (2.1 us per tile
+  // with the offsets recomputed per tile: magic divisions, 32-bit multiplies and exec-mask branches around each load).
+  int x_rel[SPEC ? WB_PIT : 1], x_dst[SPEC ? WB_PIT : 1], x_hx[SPEC ? WB_PIT : 1];
+  int y_rel[SPEC ? WB_PIT : 1], y_dst[SPEC ? WB_PIT : 1], y_c[SPEC ? WB_PIT : 1];
+  unsigned y_srow = 0, y_scol = 0;
+  if constexpr (SPEC) {
+    if (stager && P.prefetch) {
       {
         constexpr int QN = CIB / 4, PSTEP = NST / QN;
         const int need2 = (P.TW + P.KW) >> 1;
-        const unsigned need2_magic = wb_magic20(need2);
         const int npairs = P.HH * need2;
-        const int by0 = r0 - P.pad, bx0 = c0 - P.pad;
         const int q = tid % QN, ch = cib + q * 4;
-        const int nch = P.Cin - ch;
-        const float* __restrict__ xb = Lx + (size_t)n * P.XH * P.XW * P.Cin;
 #pragma unroll
         for (int k = 0; k < WB_PIT; ++k) {
           const int pp = tid / QN + k * PSTEP;
-          const int hy = wb_div20(pp, need2_magic), hx = (pp - hy * need2) * 2;
-          const int iy = by0 + hy, ix = bx0 + hx;
-          const bool rowok = pp < npairs && (unsigned)iy < (unsigned)P.XH && nch > 0;
-          const unsigned off = (unsigned)(iy * P.XW + ix) * (unsigned)P.Cin + (unsigned)ch;
-          pxa[k] = wb_load4(xb, nullptr, 0.f, off, rowok && (unsigned)ix < (unsigned)P.XW, nch, P.vec_x);
-          pxb[k] = wb_load4(xb, nullptr, 0.f, off + (unsigned)P.Cin, rowok && (unsigned)(ix + 1) < (unsigned)P.XW, nch, P.vec_x);
+          const int hy = pp / need2, hx = (pp - hy * need2) * 2;
+          const bool act = pp < npairs && ch < P.Cin;
+          x_rel[k] = ((hy * P.XW + hx) * P.Cin + ch) * 4;
+          x_dst[k] = act ? (q * 4) * P.CS + hy * P.HWp + hx : -1;
+          x_hx[k] = hx;
         }
       }
       {
         constexpr int QN = COB / 4, PSTEP = NST / QN;
-        const unsigned tw2_magic = wb_magic20(tw2);
         const int npairs = P.TH * tw2;
         const int q = tid % QN, ch = cob + q * 4;
-        const int nch = P.Cout - ch;
-        unsigned srow, scol, koff;
-        dy_strides(ch, srow, scol, koff);
-        const size_t img = (size_t)n * P.YH * srow;
-        const float* __restrict__ yb = Ldy + img;
-        const float* __restrict__ mb = Lmask ? Lmask + img : nullptr;
+        unsigned koff;
+        dy_strides(ch, y_srow, y_scol, koff);
 #pragma unroll
         for (int k = 0; k < WB_PIT; ++k) {
           const int pp = tid / QN + k * PSTEP;
-          const int r = wb_div20(pp, tw2_magic), c = (pp - r * tw2) * 2;
-          const int iy = r0 + r, ix = c0 + c;
-          const bool rowok = pp < npairs && iy < P.YH && nch > 0;
-          const unsigned off = (unsigned)iy * srow + (unsigned)ix * scol + koff;
-          pya[k] = wb_load4(yb, nullptr, 0.f, off, rowok && ix < P.YW, nch, P.vec_y);
-          pyb[k] = wb_load4(yb, nullptr, 0.f, off + scol, rowok && ix + 1 < P.YW, nch, P.vec_y);
-          if (mb) {  // raw mask values: applied at commit time, so that nothing here waits for a load
-            pma[k] = wb_load4(mb, nullptr, 0.f, off, rowok && ix < P.YW, nch, P.vec_y);
-            pmb[k] = wb_load4(mb, nullptr, 0.f, off + scol, rowok && ix + 1 < P.YW, nch, P.vec_y);
+          const int r = pp / tw2, c = (pp - r * tw2) * 2;
+          const bool act = pp < npairs && ch < P.Cout;
+          y_rel[k] = (int)(((unsigned)r * y_srow + (unsigned)c * y_scol + koff) * 4u);
+          y_dst[k] = act ? (q * 4) * P.DS + r * P.TW + c : -1;
+          y_c[k] = c;
+        }
+      }
+    }
+  }
+  auto issue = [&](int tile) {
+    if constexpr (SPEC) {
+      int n, r0, c0;
+      tile_origin(tile, n, r0, c0);
+      constexpr unsigned OOB = 0x80000000u;
+      {
+        const size_t img = (size_t)P.XH * P.XW * P.Cin;
+        const __amdgpu_buffer_rsrc_t rx = wb_rsrc(Lx + (size_t)n * img, (unsigned)(img * 4));
+        const int by0 = r0 - P.pad, bx0 = c0 - P.pad;
+        const int obase = (by0 * P.XW + bx0) * P.Cin * 4;  // may be negative: rows above the image wrap out of range
+        const unsigned pstride = (unsigned)P.Cin * 4u;
+#pragma unroll
+        for (int k = 0; k < WB_PIT; ++k) {
+          const unsigned o = (unsigned)(obase + x_rel[k]);
+          const int ix = bx0 + x_hx[k];
+          const bool act = x_dst[k] >= 0;
+          pxa[k] = wb_bload(rx, act && (unsigned)ix < (unsigned)P.XW ? o : OOB);
+          pxb[k] = wb_bload(rx, act && (unsigned)(ix + 1) < (unsigned)P.XW ? o + pstride : OOB);
+        }
+      }
+      {
+        const size_t img = (size_t)P.YH * y_srow;
+        const __amdgpu_buffer_rsrc_t ry = wb_rsrc(Ldy + (size_t)n * img, (unsigned)(img * 4));
+        const __amdgpu_buffer_rsrc_t rm = wb_rsrc(Lmask ? Lmask + (size_t)n * img : Ldy, Lmask ? (unsigned)(img * 4) : 0u);
+        const unsigned obase = ((unsigned)r0 * y_srow + (unsigned)c0 * y_scol) * 4u;
+        const unsigned pstride = y_scol * 4u;
+#pragma unroll
+        for (int k = 0; k < WB_PIT; ++k) {
+          const unsigned o = obase + (unsigned)y_rel[k];
+          const int ix = c0 + y_c[k];
+          const bool act = y_dst[k] >= 0;
+          const unsigned o0 = act && ix < P.YW ? o : OOB, o1 = act && ix + 1 < P.YW ? o + pstride : OOB;
+          pya[k] = wb_bload(ry, o0);
+          pyb[k] = wb_bload(ry, o1);
+          if (Lmask) {  // raw mask values: applied at commit time, so that nothing here waits for a load
+            pma[k] = wb_bload(rm, o0);
+            pmb[k] = wb_bload(rm, o1);
           }
         }
       }
@@ -421,55 +470,38 @@ __global__ __launch_bounds__(SPEC ? 768 : 256, SPEC ? 3 : 2) void k_wgrad_bf(WgB
     if constexpr (SPEC) {
       unsigned short* xs = smem16 + bsel * buf_shorts;
       unsigned short* ys = xs + (size_t)2 * CIB * P.CS;
-      {
-        constexpr int QN = CIB / 4, PSTEP = NST / QN;
-        const int need2 = (P.TW + P.KW) >> 1;
-        const unsigned need2_magic = wb_magic20(need2);
-        const int npairs = P.HH * need2;
-        unsigned short* xq = xs + (size_t)((tid % QN) * 4) * P.CS;
 #pragma unroll
-        for (int k = 0; k < WB_PIT; ++k) {
-          const int pp = tid / QN + k * PSTEP;
-          if (pp < npairs) {
-            const int hy = wb_div20(pp, need2_magic), hx = (pp - hy * need2) * 2;
-            unsigned hi[4], lo[4];
-            wb_split_pair(pxa[k], pxb[k], hi, lo);
-            unsigned short* dst = xq + hy * P.HWp + hx;
+      for (int k = 0; k < WB_PIT; ++k) {
+        if (x_dst[k] >= 0) {
+          unsigned hi[4], lo[4];
+          wb_split_pair(pxa[k], pxb[k], hi, lo);
+          unsigned short* dst = xs + x_dst[k];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              *reinterpret_cast<unsigned*>(dst + (size_t)c * P.CS) = hi[c];
-              *reinterpret_cast<unsigned*>(dst + (size_t)(CIB + c) * P.CS) = lo[c];
-            }
+          for (int c = 0; c < 4; ++c) {
+            *reinterpret_cast<unsigned*>(dst + (size_t)c * P.CS) = hi[c];
+            *reinterpret_cast<unsigned*>(dst + (size_t)(CIB + c) * P.CS) = lo[c];
           }
         }
       }
-      {
-        constexpr int QN = COB / 4, PSTEP = NST / QN;
-        const unsigned tw2_magic = wb_magic20(tw2);
-        const int npairs = P.TH * tw2;
-        unsigned short* yq = ys + (size_t)((tid % QN) * 4) * P.DS;
 #pragma unroll
-        for (int k = 0; k < WB_PIT; ++k) {
-          const int pp = tid / QN + k * PSTEP;
-          if (pp < npairs) {
-            const int r = wb_div20(pp, tw2_magic), c = (pp - r * tw2) * 2;
-            f32x4 v0 = pya[k], v1 = pyb[k];
-            if (Lmask) {
+      for (int k = 0; k < WB_PIT; ++k) {
+        if (y_dst[k] >= 0) {
+          f32x4 v0 = pya[k], v1 = pyb[k];
+          if (Lmask) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                v0[e] = pma[k][e] > 0.f ? v0[e] : v0[e] * Lslope;
-                v1[e] = pmb[k][e] > 0.f ? v1[e] : v1[e] * Lslope;
-              }
+            for (int e = 0; e < 4; ++e) {
+              v0[e] = pma[k][e] > 0.f ? v0[e] : v0[e] * Lslope;
+              v1[e] = pmb[k][e] > 0.f ? v1[e] : v1[e] * Lslope;
             }
-            bsum += v0 + v1;
-            unsigned hi[4], lo[4];
-            wb_split_pair(v0, v1, hi, lo);
-            unsigned short* dst = yq + r * P.TW + c;
+          }
+          bsum += v0 + v1;
+          unsigned hi[4], lo[4];
+          wb_split_pair(v0, v1, hi, lo);
+          unsigned short* dst = ys + y_dst[k];
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-              *reinterpret_cast<unsigned*>(dst + (size_t)cc * P.DS) = hi[cc];
-              *reinterpret_cast<unsigned*>(dst + (size_t)(COB + cc) * P.DS) = lo[cc];
-            }
+          for (int cc = 0; cc < 4; ++cc) {
+            *reinterpret_cast<unsigned*>(dst + (size_t)cc * P.DS) = hi[cc];
+            *reinterpret_cast<unsigned*>(dst + (size_t)(COB + cc) * P.DS) = lo[cc];
           }
         }
       }
@@ -702,7 +734,9 @@ static int wb_prefetch_ok(const WbPlan& pl, const srk_conv_desc& d) {
   if (!env) return 0;
   const long x_items = (long)pl.HH * ((pl.TW + d.KW) >> 1) * (pl.CIB / 4);
   const long y_items = (long)pl.TH * (pl.TW >> 1) * (pl.COB / 4);
-  return x_items <= (long)WB_PIT * 512 && y_items <= (long)WB_PIT * 512;
+  // the prefetching stagers load through per-image buffer descriptors with 32-bit byte offsets
+  const long ximg = (long)d.H * d.W * d.Cin * 4, yimg = (long)d.OH * d.OW * d.Cout * 4;
+  return x_items <= (long)WB_PIT * WB_SST && y_items <= (long)WB_PIT * WB_SST && ximg < (1L << 31) && yimg < (1L << 31);
 }
 
 bool conv_wgrad_bf_supported(const srk_conv_desc& d) { return wb_plan(d).ok; }
@@ -718,7 +752,7 @@ static void wb_launch(const WgBfParams& P, dim3 grid, size_t lds, bool spec, hip
   if (spec) {
     static LdsLimit lim2;
     lim2.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, true, false>), 2 * lds);
-    hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, true, false>), grid, dim3(768), 2 * lds, s, P, WgNoGroup{0});
+    hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, true, false>), grid, dim3(256 + WB_SST), 2 * lds, s, P, WgNoGroup{0});
     return;
   }
   static LdsLimit lim;
@@ -731,7 +765,7 @@ static void wb_launch_grouped(const WgBfParams& P, const WgGroup& GR, dim3 grid,
   if (spec) {
     static LdsLimit lim2;
     lim2.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, true, true>), 2 * lds);
-    hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, true, true>), grid, dim3(768), 2 * lds, s, P, GR);
+    hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, true, true>), grid, dim3(256 + WB_SST), 2 * lds, s, P, GR);
     return;
   }
   static LdsLimit lim;
@@ -823,7 +857,7 @@ int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const
   P.vec_y = (d.Cout % 4 == 0) && ((uintptr_t)dy % 16 == 0) && (!P.mask_y || (uintptr_t)P.mask_y % 16 == 0);
   P.dy_ps_r = d.dy_ps_r > 1 ? d.dy_ps_r : 0;
   P.dy_ps_C = d.dy_ps_r > 1 ? d.Cout / (d.dy_ps_r * d.dy_ps_r) : d.Cout;
-  P.prefetch = wb_prefetch_ok(pl, d);
+  P.prefetch = wb_prefetch_ok(pl, d) && P.vec_x && P.vec_y;  // 16-byte channel groups only
   // wave-specialised variant: one 512-thread block per CU with two LDS buffer sets, when every block has >= 2 tiles
   // to pipeline (SRK_WGRAD_SPEC=0: never)
   static const int spec_env = getenv("SRK_WGRAD_SPEC") ? atoi(getenv("SRK_WGRAD_SPEC")) : 1;
@@ -944,7 +978,7 @@ int conv_wgrad_bf_grouped(const srk_conv_desc& d, int n, const float* const* xs,
   P.ntiles = pl.ntiles; P.G = G; P.nks = pl.nks;
   P.vec_x = vec_x; P.vec_y = vec_y;
   P.dy_ps_r = 0; P.dy_ps_C = d.Cout;
-  P.prefetch = wb_prefetch_ok(pl, d);
+  P.prefetch = wb_prefetch_ok(pl, d) && P.vec_x && P.vec_y;  // 16-byte channel groups only
   {
     static int dbg = -1;
     if (dbg < 0) {
