@@ -183,6 +183,24 @@ int srk_conv2d_backward_weight_grouped(const srk_conv_desc* d, int n, const floa
                                        const srk_bwd_mask* masks, float* const* dw, float* const* db, float beta,
                                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- residual block, both convolutions in one launch (base_networks.py:109-150 with norm=None, activation='relu':
+ * edsr.py:37-45 builds its body from it) ------------------------------------------------------------------------------
+ * Forward:   y_mid = relu(conv1(x) + b1),  y = conv2(y_mid) + b2 + x      (3x3, stride 1, pad 1, C -> C -> C)
+ * Backward:  d_mid = conv2^T(dy) * (y_mid > 0),  dx = conv1^T(d_mid) + dy
+ * Same numbers as the two srk_conv2d_forward / srk_conv2d_backward_data calls they replace (same operand splits,
+ * same products; the K-split partial sums meet in a different order).  Only for small problems (strong-scaled shards:
+ * srk_resblock2_supported says when): one 8x8 tile per workgroup, the intermediate stays in LDS, and nothing waits for
+ * the store -> load round trip between the two convs.  y_mid / d_mid are still written: the weight gradients
+ * (srk_conv2d_backward_weight with x = y_mid, dy = dy for conv2 and x = x, dy = d_mid, NO mask, for conv1) need them.
+ * algo: SRK_ALGO_MFMA_BF16X6 (fp32-faithful) or SRK_ALGO_AUTO / SRK_ALGO_MFMA_BF16X3.  b1 / b2 may be NULL.
+ * Filters: the packed buffers of srk_pack_weight_fwd / srk_pack_weight_bwd (ps_r = 0). */
+int srk_resblock2_supported(int N, int H, int W, int C);
+int srk_resblock2_forward(int N, int H, int W, int C, const float* x, const float* w1_packed_fwd, const float* b1,
+                          const float* w2_packed_fwd, const float* b2, float* y_mid, float* y, int algo, void* stream);
+int srk_resblock2_backward_data(int N, int H, int W, int C, const float* dy, const float* w2_packed_bwd,
+                                const float* w1_packed_bwd, const float* y_mid, float* d_mid, float* dx, int algo,
+                                void* stream);
+
 /* ---- pixel shuffle (torch.nn.PixelShuffle: base_networks.py:157,179-181) ----------------- */
 /* x [N,H,W,C*r*r] -> y [N,H*r,W*r,C];  channel c*r*r + i*r + j -> (c, h*r+i, w*r+j). */
 int srk_pixel_shuffle_forward(const float* x, float* y, int N, int H, int W, int C, int r, void* stream);

@@ -69,6 +69,9 @@ _PROTOTYPES = {
     "srk_conv2d_backward_weight_grouped": (c_int, [ctypes.POINTER(ConvDesc), c_int, ctypes.POINTER(c_vp),
                                                    ctypes.POINTER(c_vp), ctypes.POINTER(BwdMask), ctypes.POINTER(c_vp),
                                                    ctypes.POINTER(c_vp), c_float, c_vp, c_size, c_vp]),
+    "srk_resblock2_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "srk_resblock2_forward": (c_int, [c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_vp]),
+    "srk_resblock2_backward_data": (c_int, [c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_vp]),
     "srk_pixel_shuffle_forward": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "srk_pixel_shuffle_backward": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "srk_act_forward": (c_int, [c_f, c_f, c_size, c_int, c_int, c_float, c_f, c_int, c_vp]),

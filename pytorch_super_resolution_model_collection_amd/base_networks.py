@@ -16,7 +16,7 @@ import torch
 
 from . import ops
 from .layers import (ACT_LRELU, ACT_NONE, ACT_PRELU, ACT_RELU, BatchNorm2d, Conv2d, ConvTranspose2d, Linear,
-                     PixelShuffle, grad_mode, make_activation, make_norm1d, make_norm2d)
+                     PixelShuffle, _plan_views, grad_mode, make_activation, make_norm1d, make_norm2d)
 
 _FUSABLE_IN_TRAINING = (ACT_NONE, ACT_RELU, ACT_LRELU)
 
@@ -130,6 +130,12 @@ class ResnetBlock(_Block):
         training = grad_mode(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, pw)
         if self.norm is None:
             fuse = self._fuse_act(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)
+            if (training and fuse and kind == ACT_RELU and self.conv1._s == 1 and self.conv1._p == 1
+                    and self.conv2._s == 1 and self.conv2._p == 1
+                    and ops.resblock2_applicable(x, self.conv1.weight, self.conv2.weight)):
+                # small problems (a strong-scaled shard): both convs, the ReLU and the skip in one launch per direction
+                return ops.resblock2(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                                     _plan_views(self.conv1, 0), _plan_views(self.conv2, 0))
             # training: the skip gradient (= the block output gradient) is added by conv1's data-gradient kernel
             # (ops.GradBox); it needs x itself to require grad, else there is no fan-in to sum
             box = ops.GradBox() if (training and x.requires_grad and ops.FUSE_SKIP_GRAD) else None

@@ -232,6 +232,43 @@ extern "C" int srk_conv2d_backward_data(const srk_conv_desc* d, const float* dy,
                     (hipStream_t)stream, "conv2d_backward_data");
 }
 
+extern "C" int srk_resblock2_supported(int N, int H, int W, int C) { return conv_res2_supported(N, H, W, C) ? 1 : 0; }
+
+static int resblock2_planes(int algo, const char* who) {
+  algo = forced_algo(algo);
+  if (algo == SRK_ALGO_MFMA_BF16X6) return 3;
+  if (algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3) return 2;
+  set_error("%s: only the bf16x3 (SRK_ALGO_AUTO) and bf16x6 arithmetic exist for the fused block", who);
+  return 0;
+}
+
+extern "C" int srk_resblock2_forward(int N, int H, int W, int C, const float* x, const float* w1_packed_fwd,
+                                     const float* b1, const float* w2_packed_fwd, const float* b2, float* y_mid, float* y,
+                                     int algo, void* stream) {
+  SRK_REQUIRE(x && w1_packed_fwd && w2_packed_fwd && y_mid && y, "resblock2_forward: null tensor pointer");
+  SRK_REQUIRE(conv_res2_supported(N, H, W, C), "resblock2_forward: unsupported problem (see srk_resblock2_supported)");
+  SRK_REQUIRE(((uintptr_t)x | (uintptr_t)y_mid | (uintptr_t)y | (uintptr_t)b1 | (uintptr_t)b2) % 16 == 0,
+              "resblock2_forward: tensors must be 16-byte aligned");
+  const int planes = resblock2_planes(algo, "resblock2_forward");
+  if (!planes) return SRK_ERR_UNSUPPORTED;
+  return conv_res2(x, w1_packed_fwd, w2_packed_fwd, b1, b2, nullptr, y_mid, y, N, H, W, planes, false,
+                   (hipStream_t)stream);
+}
+
+extern "C" int srk_resblock2_backward_data(int N, int H, int W, int C, const float* dy, const float* w2_packed_bwd,
+                                           const float* w1_packed_bwd, const float* y_mid, float* d_mid, float* dx,
+                                           int algo, void* stream) {
+  SRK_REQUIRE(dy && w2_packed_bwd && w1_packed_bwd && y_mid && d_mid && dx, "resblock2_backward_data: null tensor pointer");
+  SRK_REQUIRE(conv_res2_supported(N, H, W, C), "resblock2_backward_data: unsupported problem (see srk_resblock2_supported)");
+  SRK_REQUIRE(((uintptr_t)dy | (uintptr_t)y_mid | (uintptr_t)d_mid | (uintptr_t)dx) % 16 == 0,
+              "resblock2_backward_data: tensors must be 16-byte aligned");
+  const int planes = resblock2_planes(algo, "resblock2_backward_data");
+  if (!planes) return SRK_ERR_UNSUPPORTED;
+  // in this direction conv2's transposed filter runs first, conv1's second
+  return conv_res2(dy, w2_packed_bwd, w1_packed_bwd, nullptr, nullptr, y_mid, d_mid, dx, N, H, W, planes, true,
+                   (hipStream_t)stream);
+}
+
 extern "C" size_t srk_conv2d_backward_weight_workspace_bytes(const srk_conv_desc* d) {
   if (!d) return 0;
   size_t a = conv_generic_wgrad_ws(*d);

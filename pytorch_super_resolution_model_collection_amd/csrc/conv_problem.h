@@ -110,6 +110,10 @@ static inline bool conv_epi_all_vector(int OC, const Epi& ep, const float* out) 
 // conv_bfd.hip: filters straight from global memory; planes 2 = bf16x3, 3 = bf16x6 (fp32-faithful)
 bool conv_bfd_gather_supported(const GatherConv& g, const Epi& ep);
 bool conv_bfd_small_problem(const GatherConv& g);
+// conv_res2.hip: both 3x3 64 -> 64 convs of a residual block in one launch per 8x8 tile (small problems)
+bool conv_res2_supported(int N, int H, int W, int C);
+int conv_res2(const float* in, const float* wp1, const float* wp2, const float* bias1, const float* bias2,
+              const float* gate, float* mid, float* out, int N, int H, int W, int planes, bool bwd, hipStream_t s);
 int conv_bfd_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
                     const float* mask_y, float mask_slope, int planes, hipStream_t s);
 int bf3_pack_prepared(const float* w, void* packed_base, int Cout, int Cin, int KH, int KW, int transposed, int ps_r,

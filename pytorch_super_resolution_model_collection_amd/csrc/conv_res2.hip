@@ -1,0 +1,357 @@
+// Both 3x3 convolutions of a residual block in ONE launch per 8x8 output tile ("res2").
+//
+//   forward  (base_networks.py:128-150, norm=None):  mid = relu(conv1(x) + b1)        out = conv2(mid) + b2 + x
+//   backward (data gradient of the same block):      dmid = conv2^T(dy) * (mid > 0)   dx  = conv1^T(dmid) + dy
+//
+// Why: on a strong-scaled shard (EDSR x4, 16 patches per GPU: one 64-pixel tile per CU) a body convolution is a
+// latency chain -- launch, halo load, 9 taps behind global filter fragments, K-split reduce, store -- of ~11-14 us of
+// which the matrix work is 1.4 us, and a block's second conv cannot start before the first one's stores have landed
+// and been re-read.  Here the block's tile keeps the intermediate in LDS: the first conv is evaluated on the 10x10
+// region the second one needs (1.56x its matrix work, which the tile has time for), split into bf16 planes straight
+// from the accumulators, and consumed by the second conv after one barrier.  One launch, one global halo load and one
+// dependent store -> load round trip less per block; the intermediate's centre 8x8 is still written out (the weight
+// gradients and the backward mask need it), but nothing waits for that store.
+//
+// Same arithmetic as conv_bfd.hip (fp32 operands split into bf16 planes, v_mfma_f32_16x16x32_bf16, fp32
+// accumulation; NP = 3: bf16x6 fp32-faithful forward, NP = 2: bf16x3 data gradient), same prepared filter layout
+// [tap][chunk][plane][group][co][8 x bf16] read as MFMA operands straight from global memory, same transposed product
+// (a lane ends up with 4 consecutive channels of one pixel).  Block = 8 waves: wave (ow, kgrp) owns output channels
+// [16 ow, 16 ow + 16) and the 32-channel input chunk kgrp; the two chunk groups swap half of their partial
+// accumulators through LDS and each finishes half of the pixels.
+#include "srk_common.h"
+#include "conv_problem.h"
+#include "bf16_frag.h"
+#include <stdlib.h>
+
+namespace srk {
+
+constexpr int R2_C = 64;       // channels in = mid = out
+constexpr int R2_TS = 8;       // output tile side
+constexpr int R2_H1 = 12;      // input halo side (tile + 2 + 2)
+constexpr int R2_NPIX1 = 144;  // input halo pixels (multiple of 16)
+constexpr int R2_MW = 10;      // mid region side (tile + 1 + 1)
+constexpr int R2_NMID = 100;
+constexpr int R2_NPIX2 = 112;  // mid pixels rounded up to 16
+constexpr int R2_MT1 = 7;      // 16-pixel tiles of the mid region
+
+struct Res2Params {
+  const float* in;    // [N, H, W, 64]: x (forward) / dy (backward); also the residual added to `out`
+  const uint4* wq1;   // first conv: prepared filter planes h, m
+  const uint4* wq1l;  //             third plane (NP = 3)
+  const uint4* wq2;   // second conv
+  const uint4* wq2l;
+  const float* bias1;  // forward only (may be NULL)
+  const float* bias2;
+  const float* gate;   // backward: saved forward `mid`; dmid is zeroed where it is <= 0
+  float* mid;          // [N, H, W, 64] centre store of the intermediate
+  float* out;
+  int N, H, W, tiles_y, tiles_x;
+  int dbg;
+};
+
+template <int NP>
+__device__ __forceinline__ void r2_split4(const f32x4& v, uint2 (&pl)[NP]) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  bf16x4 h, m, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 hh = (__bf16)v[e];
+    const float r1 = v[e] - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    h[e] = hh;
+    m[e] = mm;
+    if (NP == 3) l[e] = (__bf16)(r1 - (float)mm);
+  }
+  pl[0] = __builtin_bit_cast(uint2, h);
+  pl[1] = __builtin_bit_cast(uint2, m);
+  if (NP == 3) pl[NP - 1] = __builtin_bit_cast(uint2, l);
+}
+
+#define SRK_R2_PASSES(ACC, A, BF, MT)                                                                   \
+  {                                                                                                     \
+    if (NP == 3) {                                                                                      \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) ACC[mt] = mfma16(BF[0], A[NP - 1][mt], ACC[mt]); \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) ACC[mt] = mfma16(BF[NP - 1], A[0][mt], ACC[mt]); \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) ACC[mt] = mfma16(BF[1], A[1][mt], ACC[mt]);      \
+    }                                                                                                   \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) ACC[mt] = mfma16(BF[0], A[1][mt], ACC[mt]);        \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) ACC[mt] = mfma16(BF[1], A[0][mt], ACC[mt]);        \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) ACC[mt] = mfma16(BF[0], A[0][mt], ACC[mt]);        \
+  }
+
+template <int NP, bool BWD>
+__global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
+  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+  uint4* hal1 = smem4;                          // [2 chunks][NP][4 groups][144 pixels]
+  uint4* hal2 = smem4 + 2 * NP * 4 * R2_NPIX1;  // [2][NP][4][112]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ow = wave & 3, kgrp = wave >> 2;
+  const int j = lane & 15, kq = lane >> 4;
+  int b = blockIdx.x;
+  const int txi = b % R.tiles_x;
+  b /= R.tiles_x;
+  const int tyi = b % R.tiles_y;
+  const int n = b / R.tiles_y;
+  const int r0 = tyi * R2_TS, c0 = txi * R2_TS;
+  const size_t img = (size_t)n * R.H * R.W * R2_C;
+  const float* __restrict__ inb = R.in + img;
+
+  // ---- filter fragments: position seq = conv * 9 + tap of the 18-tap sequence (the prefetch runs across the two convs)
+  const int wlane = kq * 64 + j + ow * 16;
+  auto load_b = [&](int seq, uint4(&dst)[NP]) {
+    const int cv = seq >= 9 ? 1 : 0, t = seq - 9 * cv;
+    const int wt = BWD ? 8 - t : t;  // data gradient: the taps run flipped (conv_tile.h, TRANS gather with stride 1)
+    const size_t slot = (size_t)(wt * 2 + kgrp);
+    const uint4* w = (cv ? R.wq2 : R.wq1) + slot * 512 + wlane;
+    dst[0] = w[0];
+    dst[1] = w[256];
+    if (NP == 3) dst[NP - 1] = ((cv ? R.wq2l : R.wq1l) + slot * 256)[wlane];
+  };
+  uint4 bq[3][NP];
+  load_b(0, bq[0]);
+  load_b(1, bq[1]);
+
+  // ---- input halo -> planes in LDS.  item = (pixel, 8-channel group of the 64): 8 adjacent lanes read one pixel's
+  // 256 bytes; every global load is issued before the first conversion
+  if (!(R.dbg & 1)) {
+    constexpr int NIT = (R2_NPIX1 * 8 + 511) / 512;
+    f32x4 v0[NIT], v1[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int item = tid + k * 512;
+      const int g8 = item & 7, hp = item >> 3;
+      const int hy = hp / R2_H1, hx = hp - hy * R2_H1;
+      const int iy = r0 - 2 + hy, ix = c0 - 2 + hx;
+      v0[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      v1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (hp < R2_NPIX1 && (unsigned)iy < (unsigned)R.H && (unsigned)ix < (unsigned)R.W) {
+        const float* p = inb + ((size_t)iy * R.W + ix) * R2_C + g8 * 8;
+        v0[k] = *reinterpret_cast<const f32x4*>(p);
+        v1[k] = *reinterpret_cast<const f32x4*>(p + 4);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int item = tid + k * 512;
+      const int g8 = item & 7, hp = item >> 3;
+      if (hp < R2_NPIX1) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f[e] = v0[k][e];
+          f[4 + e] = v1[k][e];
+        }
+        uint4 pl[NP];
+        split8n<NP>(f, pl);
+        const int chunk = g8 >> 2, g = g8 & 3;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) hal1[((chunk * NP + p) * 4 + g) * R2_NPIX1 + hp] = pl[p];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- first conv on the 10x10 mid region: 7 pixel tiles x this wave's 16 channels x chunk kgrp
+  f32x4 acc1[R2_MT1];
+#pragma unroll
+  for (int mt = 0; mt < R2_MT1; ++mt) acc1[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    int hpA[R2_MT1];
+#pragma unroll
+    for (int mt = 0; mt < R2_MT1; ++mt) {
+      int m = mt * 16 + j;
+      if (m >= R2_NMID) m = 0;
+      const int r = m / R2_MW, c = m - r * R2_MW;
+      hpA[mt] = r * R2_H1 + c + kq * R2_NPIX1;
+    }
+    constexpr int plane1 = 4 * R2_NPIX1;
+    const uint4* h1c = hal1 + kgrp * NP * plane1;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      load_b(t + 2, bq[(t + 2) % 3]);
+      if (!(R.dbg & 4)) {
+        const int toff = (t / 3) * R2_H1 + (t % 3);
+        uint4 a[NP][R2_MT1];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int mt = 0; mt < R2_MT1; ++mt) a[p][mt] = h1c[p * plane1 + hpA[mt] + toff];
+        SRK_R2_PASSES(acc1, a, bq[t % 3], R2_MT1)
+      }
+    }
+  }
+
+  // ---- the chunk groups swap halves: group 0 finishes mid tiles 0-3, group 1 tiles 4-6
+  const int ch4 = ow * 16 + kq * 4;
+  f32x4 gt[4];  // backward: forward mid values of this wave's tiles (issued before the barriers)
+  int moff[4];  // element offset of the tile's pixel in the image (-1: outside the image or the region)
+  bool mcen[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int mt = kgrp ? 4 + q : q;
+    const int m = mt * 16 + j;
+    const int r = m / R2_MW, c = m - r * R2_MW;
+    const int iy = r0 - 1 + r, ix = c0 - 1 + c;
+    const bool inimg = mt < R2_MT1 && m < R2_NMID && (unsigned)iy < (unsigned)R.H && (unsigned)ix < (unsigned)R.W;
+    moff[q] = inimg ? (int)(((size_t)iy * R.W + ix) * R2_C) + ch4 : -1;
+    mcen[q] = inimg && r >= 1 && r <= R2_TS && c >= 1 && c <= R2_TS;
+    gt[q] = (f32x4){1.f, 1.f, 1.f, 1.f};
+    if (BWD && inimg) gt[q] = *reinterpret_cast<const f32x4*>(R.gate + img + moff[q]);
+  }
+  __syncthreads();  // every wave is done with the input halo
+  f32x4* red = reinterpret_cast<f32x4*>(smem4) + (size_t)(ow * R2_MT1) * 64 + lane;  // [4 ow][7 tiles][64 lanes]
+  if (kgrp == 0) {
+#pragma unroll
+    for (int mt = 4; mt < R2_MT1; ++mt) red[mt * 64] = acc1[mt];
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) red[mt * 64] = acc1[mt];
+  }
+  __syncthreads();
+  {
+    f32x4 b1 = {0.f, 0.f, 0.f, 0.f};
+    if (!BWD && R.bias1) b1 = *reinterpret_cast<const f32x4*>(R.bias1 + ch4);
+    const int ch2 = ow >> 1, g2 = (ow & 1) * 2 + (kq >> 1);
+#pragma unroll
+    for (int mt = 0; mt < R2_MT1; ++mt) {
+      if ((mt < 4) != (kgrp == 0)) continue;
+      const int q = mt & 3;
+      const int m = mt * 16 + j;
+      f32x4 v = acc1[mt] + red[mt * 64];
+      if (!BWD) {
+        v += b1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gt[q][e] > 0.f ? v[e] : 0.f;
+      }
+      if (moff[q] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};  // outside the image: the second conv's zero padding
+      if (mcen[q]) *reinterpret_cast<f32x4*>(R.mid + img + moff[q]) = v;
+      if (m < R2_NMID) {
+        uint2 pl[NP];
+        r2_split4<NP>(v, pl);
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          reinterpret_cast<uint2*>(hal2 + ((ch2 * NP + p) * 4 + g2) * R2_NPIX2 + m)[kq & 1] = pl[p];
+      }
+    }
+  }
+  // residual (= the centre of the input) for the tiles this wave finishes: group 0 tiles 0, 1; group 1 tiles 2, 3
+  f32x4 res[2];
+  int ooff[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int m = (kgrp * 2 + q) * 16 + j;
+    const int iy = r0 + (m >> 3), ix = c0 + (m & 7);
+    const bool ok = iy < R.H && ix < R.W;
+    ooff[q] = ok ? (int)(((size_t)iy * R.W + ix) * R2_C) + ch4 : -1;
+    res[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (ok) res[q] = *reinterpret_cast<const f32x4*>(inb + ooff[q]);
+  }
+  __syncthreads();  // mid planes complete
+
+  // ---- second conv on the 8x8 centre: 4 pixel tiles
+  f32x4 acc2[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) acc2[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    int hpB[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = mt * 16 + j;
+      hpB[mt] = (m >> 3) * R2_MW + (m & 7) + kq * R2_NPIX2;
+    }
+    constexpr int plane2 = 4 * R2_NPIX2;
+    const uint4* h2c = hal2 + kgrp * NP * plane2;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (t + 2 < 9) load_b(9 + t + 2, bq[(t + 2) % 3]);
+      if (!(R.dbg & 4)) {
+        const int toff = (t / 3) * R2_MW + (t % 3);
+        uint4 a[NP][4];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) a[p][mt] = h2c[p * plane2 + hpB[mt] + toff];
+        SRK_R2_PASSES(acc2, a, bq[t % 3], 4)
+      }
+    }
+  }
+  // swap halves again (the region of the input halo is free: nothing reads it after the barrier above)
+  f32x4* red2 = reinterpret_cast<f32x4*>(smem4) + (size_t)(ow * 4) * 64 + lane;  // [4 ow][4 tiles][64 lanes]
+  if (kgrp == 0) {
+    red2[2 * 64] = acc2[2];
+    red2[3 * 64] = acc2[3];
+  } else {
+    red2[0 * 64] = acc2[0];
+    red2[1 * 64] = acc2[1];
+  }
+  __syncthreads();
+  f32x4 b2 = {0.f, 0.f, 0.f, 0.f};
+  if (!BWD && R.bias2) b2 = *reinterpret_cast<const f32x4*>(R.bias2 + ch4);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int mt = kgrp * 2 + q;
+    if (ooff[q] >= 0) {
+      const f32x4 own = kgrp ? (q ? acc2[3] : acc2[2]) : (q ? acc2[1] : acc2[0]);
+      const f32x4 v = own + red2[mt * 64] + b2 + res[q];
+      *reinterpret_cast<f32x4*>(R.out + img + ooff[q]) = v;
+    }
+  }
+}
+#undef SRK_R2_PASSES
+
+static int r2_dbg() {
+  static const int dbg = getenv("SRK_DBG") ? atoi(getenv("SRK_DBG")) : 0;
+  return dbg;
+}
+
+// Small problems only: the tile does 1.56x the first conv's matrix work, which is free while a CU has one or two
+// tiles and nothing else to do, and a loss once the separate kernels run several tiles per CU at their matrix rate.
+bool conv_res2_supported(int N, int H, int W, int C) {
+  static const int max_tiles = getenv("SRK_RES2_MAX_TILES") ? atoi(getenv("SRK_RES2_MAX_TILES")) : kNumCU + kNumCU / 4;
+  if (C != R2_C || N < 1 || H < 1 || W < 1) return false;
+  if ((long)H * W * R2_C >= (1L << 29)) return false;  // 32-bit element offsets inside an image
+  const long tiles = (long)N * ((H + R2_TS - 1) / R2_TS) * ((W + R2_TS - 1) / R2_TS);
+  return tiles <= max_tiles;
+}
+
+template <int NP, bool BWD>
+static int r2_launch(const Res2Params& R, hipStream_t s) {
+  const size_t lds = (size_t)2 * NP * 4 * (R2_NPIX1 + R2_NPIX2) * 16;
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&k_res2<NP, BWD>), lds);
+  note_kernel("k_res2<%d,%d>", NP, (int)BWD);
+  hipLaunchKernelGGL((k_res2<NP, BWD>), dim3((unsigned)((size_t)R.N * R.tiles_y * R.tiles_x)), dim3(512), lds, s, R);
+  return check_launch("conv_res2");
+}
+
+// `wp1` / `wp2`: packed filter buffers of srk_pack_weight_fwd (forward) / srk_pack_weight_bwd (backward) of the conv
+// that runs first / second in this direction.  planes = 3: bf16x6, 2: bf16x3.
+int conv_res2(const float* in, const float* wp1, const float* wp2, const float* bias1, const float* bias2,
+              const float* gate, float* mid, float* out, int N, int H, int W, int planes, bool bwd, hipStream_t s) {
+  const size_t elems = (size_t)9 * R2_C * R2_C;
+  const char* b1 = reinterpret_cast<const char*>(wp1) + bf3_prepared_offset(elems);
+  const char* b2 = reinterpret_cast<const char*>(wp2) + bf3_prepared_offset(elems);
+  const size_t main_bytes = bf3_main_bytes(R2_C, R2_C, 9);
+  Res2Params R{};
+  R.in = in;
+  R.wq1 = reinterpret_cast<const uint4*>(b1);
+  R.wq1l = reinterpret_cast<const uint4*>(b1 + main_bytes);
+  R.wq2 = reinterpret_cast<const uint4*>(b2);
+  R.wq2l = reinterpret_cast<const uint4*>(b2 + main_bytes);
+  R.bias1 = bias1;
+  R.bias2 = bias2;
+  R.gate = gate;
+  R.mid = mid;
+  R.out = out;
+  R.N = N; R.H = H; R.W = W;
+  R.tiles_y = (H + R2_TS - 1) / R2_TS;
+  R.tiles_x = (W + R2_TS - 1) / R2_TS;
+  R.dbg = r2_dbg();
+  if (bwd) return planes == 3 ? r2_launch<3, true>(R, s) : r2_launch<2, true>(R, s);
+  return planes == 3 ? r2_launch<3, false>(R, s) : r2_launch<2, false>(R, s);
+}
+
+}  // namespace srk

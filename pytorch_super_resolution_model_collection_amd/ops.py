@@ -477,6 +477,108 @@ def conv2d(x, weight, bias=None, residual=None, cfg=None, packed=None, res_box=N
     return _Conv2d.apply(x, weight, bias, residual, cfg, packed, res_box, add_box)
 
 
+# ---- residual block with both convolutions in one launch (srk_resblock2_*) ----------------------------------------
+RES2 = os.environ.get("SRK_RES2", "1") != "0"   # 0: residual blocks always run their two convs as separate launches
+
+
+def _weight_grad(d, x, dyc, weight, bias, need_w):
+    """Weight / bias gradient of one conv without an activation mask: recorded for the grouped deferred launch (flat
+    gradient buffers) or computed now.  Returns (dw, db) for autograd (None, None when accumulated in place)."""
+    if not need_w:
+        return None, None
+    lib = _lib.load()
+    wacc = getattr(weight, "_srk_grad", None)
+    bacc = getattr(bias, "_srk_grad", None) if bias is not None else None
+    flat_mode = wacc is not None and (bias is None or bacc is not None)
+    if flat_mode and DEFER_WGRAD and not WGRAD_SIDE_STREAM:
+        key = (d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout, d.KH, d.KW, d.stride, d.pad, d.transposed, d.out_pad,
+               d.algo, d.dy_ps_r, bacc is not None, str(dyc.device))
+        _PENDING.append((key, d, x, dyc, None, 0.0, wacc, bacc))
+        _DEFER["bytes"] += 4 * (x.numel() + dyc.numel())
+        if _DEFER["bytes"] > DEFER_MAX_BYTES:
+            flush_wgrads()
+        elif not _DEFER["queued"]:
+            _DEFER["queued"] = True
+            torch.autograd.Variable._execution_engine.queue_callback(_auto_flush)
+        return None, None
+    ws = torch.empty(max(int(lib.srk_conv2d_backward_weight_workspace_bytes(ctypes.byref(d))), 16), dtype=torch.uint8,
+                     device=dyc.device)
+    if flat_mode:
+        check(lib.srk_conv2d_backward_weight(ctypes.byref(d), ptr(x), ptr(dyc), None, ptr(wacc), ptr(bacc), 1.0,
+                                             ptr(ws), ws.numel(), stream_ptr()), "srk_conv2d_backward_weight")
+        return None, None
+    dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+    db = torch.empty(d.Cout, dtype=torch.float32, device=dyc.device) if bias is not None else None
+    check(lib.srk_conv2d_backward_weight(ctypes.byref(d), ptr(x), ptr(dyc), None, ptr(dw), ptr(db), 0.0, ptr(ws),
+                                         ws.numel(), stream_ptr()), "srk_conv2d_backward_weight")
+    return dw, db
+
+
+def resblock2_applicable(x, w1, w2):
+    """True when srk_resblock2_* can run this block: 3x3 C -> C -> C filters, a problem small enough that the fused
+    tile pays (srk_resblock2_supported), and a precision mode whose kernels exist fused (not 'fp32')."""
+    if not RES2 or x.dim() != 4 or os.environ.get("SRK_FORCE_ALGO"):
+        return False
+    n, c, h, w = x.shape
+    if tuple(w1.shape) != (c, c, 3, 3) or tuple(w2.shape) != (c, c, 3, 3):
+        return False
+    mode = _MODES[_PRECISION["mode"]]
+    if mode["train_fwd"] not in (ALGO_AUTO, _lib.ALGO_MFMA_BF16X3, _lib.ALGO_MFMA_BF16X6) or \
+            mode["bwd"] not in (ALGO_AUTO, _lib.ALGO_MFMA_BF16X3):
+        return False
+    return bool(_lib.load().srk_resblock2_supported(n, h, w, c))
+
+
+class _ResBlock2(torch.autograd.Function):
+    """out = x + conv2(relu(conv1(x))) (base_networks.py:128-150, norm=None, activation='relu') as ONE forward and ONE
+    data-gradient launch; the two weight gradients take the usual (grouped, deferred) path, without masks: the
+    backward kernel hands out the already masked intermediate gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, packed1, packed2):
+        lib = _lib.load()
+        require_cuda(x, w1, b1, w2, b2)
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        wp1 = packed1[0] if packed1 is not None else pack_weight_fwd(w1, False, 0)
+        wp2 = packed2[0] if packed2 is not None else pack_weight_fwd(w2, False, 0)
+        ctx.wpb1 = packed1[2] if packed1 is not None and len(packed1) > 2 else None
+        ctx.wpb2 = packed2[2] if packed2 is not None and len(packed2) > 2 else None
+        mid = _empty_cl(n, c, h, w, x)
+        out = _empty_cl(n, c, h, w, x)
+        check(lib.srk_resblock2_forward(n, h, w, c, ptr(x), ptr(wp1), ptr(b1), ptr(wp2), ptr(b2), ptr(mid), ptr(out),
+                                        _MODES[_PRECISION["mode"]]["train_fwd"], stream_ptr()), "srk_resblock2_forward")
+        ctx.refs = (w1, b1, w2, b2)
+        ctx.save_for_backward(x, mid)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, mid = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.refs
+        n, c, h, w = x.shape
+        dy = to_nhwc(dy if (_is_nchw_dense(dy) or _is_nhwc_dense(dy)) else dy.contiguous())
+        wpb1 = ctx.wpb1 if ctx.wpb1 is not None else pack_weight_bwd(w1, False, 0)
+        wpb2 = ctx.wpb2 if ctx.wpb2 is not None else pack_weight_bwd(w2, False, 0)
+        dmid = _empty_cl(n, c, h, w, dy)
+        dx = _empty_cl(n, c, h, w, dy)
+        check(lib.srk_resblock2_backward_data(n, h, w, c, ptr(dy), ptr(wpb2), ptr(wpb1), ptr(mid), ptr(dmid), ptr(dx),
+                                              _MODES[_PRECISION["mode"]]["bwd"], stream_ptr()),
+              "srk_resblock2_backward_data")
+        cfg = ConvCfg(1, 1, False, 0, ACT_NONE, 0.0, 0)
+        d = _make_desc(x.shape, w1, cfg, "bwd")
+        need = ctx.needs_input_grad
+        # backward order of the separate convs: conv2 first (x = mid, dy = dy), then conv1 (x = x, dy = dmid)
+        dw2, db2 = _weight_grad(_make_desc(x.shape, w2, cfg, "bwd"), mid, dy, w2, b2, need[3] or (b2 is not None and need[4]))
+        dw1, db1 = _weight_grad(d, x, dmid, w1, b1, need[1] or (b1 is not None and need[2]))
+        return (dx if need[0] else None), dw1, db1, dw2, db2, None, None
+
+
+def resblock2(x, w1, b1, w2, b2, packed1=None, packed2=None):
+    return _ResBlock2.apply(x, w1, b1, w2, b2, packed1, packed2)
+
+
 def conv2d_infer(x, weight, bias=None, residual=None, cfg=None, prelu_w=None, packed=None):
     """No-grad fully fused conv: any activation + residual + pixel shuffle in one kernel."""
     cfg = cfg or ConvCfg()
