@@ -376,6 +376,153 @@ __global__ __launch_bounds__(256) void k_linear_dw(const float* __restrict__ dy,
   }
 }
 
+// ---- wide layers (the SRGAN discriminator's 18432 -> 1024, srgan.py:66-70; 3 forward + 3 backward passes per
+// adversarial step).  A pass is bound by the 75 MB of weights: the kernels above re-read them once per 8 batch rows and
+// re-read x (or dy) from L2 once per weight element (forward 110 us, dx 183 us, dw 142 us at batch 16).  These stream
+// every weight ONCE with 16-byte loads and keep the batch side in registers / LDS.
+typedef float lf4 __attribute__((ext_vector_type(4)));
+constexpr int LW_BT = 16;  // batch rows per pass
+
+// forward: block = 4 output rows x 16 batch rows, its 8 waves split the In axis; wave sums, then 8 partials per value
+__global__ __launch_bounds__(512) void k_linear_fwd_wide(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* __restrict__ y, int B,
+                                                         int In, int Out, int act, float slope) {
+  __shared__ float part[8][4 * LW_BT];
+  const int o0 = blockIdx.x * 4, b0 = blockIdx.y * LW_BT;
+  const int tid = threadIdx.x;
+  float acc[4][LW_BT];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int r = 0; r < LW_BT; ++r) acc[k][r] = 0.f;
+  const float* wr[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) wr[k] = w + (size_t)(o0 + k < Out ? o0 + k : Out - 1) * In;
+  for (int i = tid * 4; i < In; i += 512 * 4) {
+    lf4 wv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wv[k] = *reinterpret_cast<const lf4*>(wr[k] + i);
+#pragma unroll
+    for (int r = 0; r < LW_BT; ++r) {
+      const int br = b0 + r < B ? b0 + r : B - 1;
+      const lf4 xv = *reinterpret_cast<const lf4*>(x + (size_t)br * In + i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        acc[k][r] = fmaf(wv[k][0], xv[0], fmaf(wv[k][1], xv[1], fmaf(wv[k][2], xv[2], fmaf(wv[k][3], xv[3], acc[k][r]))));
+    }
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int r = 0; r < LW_BT; ++r) {
+      const float t = wave_sum(acc[k][r]);
+      if (lane == 0) part[wave][k * LW_BT + r] = t;
+    }
+  __syncthreads();
+  if (tid < 4 * LW_BT) {
+    const int k = tid / LW_BT, r = tid - k * LW_BT;
+    if (o0 + k < Out && b0 + r < B) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v += part[q][tid];
+      v += b ? b[o0 + k] : 0.f;
+      y[(size_t)(b0 + r) * Out + o0 + k] = act_apply(v, act, slope);
+    }
+  }
+}
+
+// dx: block = 64 inputs i x 16 batch rows; its 16 waves split the Out axis (64 rows each per 1024-row pass); dy of the
+// pass sits transposed in LDS ([o][16 b]: four broadcast 16-byte reads per weight), the partials meet in LDS
+__global__ __launch_bounds__(1024) void k_linear_dx_wide(const float* __restrict__ dy, const float* __restrict__ w,
+                                                         float* __restrict__ dx, int B, int In, int Out) {
+  __shared__ __attribute__((aligned(16))) float sm[1024 * LW_BT];  // 64 KB: dyT of a pass, then the partials
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = blockIdx.x * 64 + lane, b0 = blockIdx.y * LW_BT;
+  const bool iok = i < In;
+  float acc[LW_BT];
+#pragma unroll
+  for (int r = 0; r < LW_BT; ++r) acc[r] = 0.f;
+  for (int ob = 0; ob < Out; ob += 1024) {
+    if (ob) __syncthreads();
+    {
+      const int o = ob + tid;
+#pragma unroll
+      for (int r = 0; r < LW_BT; ++r)
+        sm[tid * LW_BT + r] = (o < Out && b0 + r < B) ? dy[(size_t)(b0 + r) * Out + o] : 0.f;
+    }
+    __syncthreads();
+    const int oend = Out - ob < 1024 ? Out - ob : 1024;
+    constexpr int U = 8;
+    for (int ol = wave * 64; ol < wave * 64 + 64 && ol < oend; ol += U) {
+      float wv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) wv[u] = (iok && ol + u < oend) ? w[(size_t)(ob + ol + u) * In + i] : 0.f;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const lf4* g = reinterpret_cast<const lf4*>(sm + (size_t)(ol + u < 1024 ? ol + u : 1023) * LW_BT);
+#pragma unroll
+        for (int q = 0; q < LW_BT / 4; ++q) {
+          const lf4 gv = g[q];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[q * 4 + e] = fmaf(gv[e], wv[u], acc[q * 4 + e]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < LW_BT; ++r) sm[(wave * LW_BT + r) * 64 + lane] = acc[r];  // [16 waves][16 b][64 i]
+  __syncthreads();
+  {
+    const int r = wave;  // 16 waves = 16 batch rows
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += sm[(q * LW_BT + r) * 64 + lane];
+    if (iok && b0 + r < B) dx[(size_t)(b0 + r) * In + i] = v;
+  }
+}
+
+// dw: thread = 4 consecutive i x 16 output rows: x of the batch stays in registers, dy comes through scalar loads
+// (its address is uniform in the block), every dw element is read (beta) and written once
+__global__ __launch_bounds__(256) void k_linear_dw_wide(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        float* __restrict__ dw, int B, int In, int Out, float beta) {
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int o0 = blockIdx.y * 16;
+  if (i >= In) return;
+  lf4 acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = (lf4){0.f, 0.f, 0.f, 0.f};
+  for (int b0 = 0; b0 < B; b0 += LW_BT) {
+    lf4 xv[LW_BT];
+#pragma unroll
+    for (int r = 0; r < LW_BT; ++r)
+      xv[r] = b0 + r < B ? *reinterpret_cast<const lf4*>(x + (size_t)(b0 + r) * In + i) : (lf4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int o = o0 + k < Out ? o0 + k : Out - 1;
+#pragma unroll
+      for (int r = 0; r < LW_BT; ++r) {
+        const float g = b0 + r < B ? dy[(size_t)(b0 + r) * Out + o] : 0.f;
+        acc[k] += g * xv[r];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (o0 + k < Out) {
+      lf4* dst = reinterpret_cast<lf4*>(dw + (size_t)(o0 + k) * In + i);
+      *dst = beta != 0.f ? beta * *dst + acc[k] : acc[k];
+    }
+  }
+}
+
+static bool linear_wide(const void* a, const void* b, const void* c, int In, int Out) {
+  static const int off = getenv("SRK_LINEAR_WIDE") ? atoi(getenv("SRK_LINEAR_WIDE")) == 0 : 0;
+  if (off || (In & 3) || In < 2048 || Out < 64) return false;
+  return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0;
+}
+
 __global__ __launch_bounds__(256) void k_linear_db(const float* __restrict__ dy, float* __restrict__ db, int B,
                                                    int Out, float beta) {
   const int o = blockIdx.x * 256 + threadIdx.x;
@@ -476,6 +623,11 @@ extern "C" int srk_linear_forward(const float* x, const float* w, const float* b
                                   int act, float slope, void* stream) {
   SRK_REQUIRE(x && w && y && B > 0 && In > 0 && Out > 0, "linear_forward: bad args");
   SRK_REQUIRE(act != SRK_ACT_PRELU, "linear_forward: PReLU is not fused here");
+  if (linear_wide(x, w, nullptr, In, Out)) {
+    hipLaunchKernelGGL(k_linear_fwd_wide, dim3(cdiv(Out, 4), cdiv(B, LW_BT)), dim3(512), 0, (hipStream_t)stream, x, w, b, y,
+                       B, In, Out, act, slope);
+    return check_launch("linear_forward");
+  }
   dim3 grid(cdiv(Out, 4), cdiv(B, LIN_BT));
   hipLaunchKernelGGL(k_linear_fwd, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, y, B, In, Out, act, slope);
   return check_launch("linear_forward");
@@ -485,8 +637,15 @@ extern "C" int srk_linear_backward(const float* x, const float* w, const float* 
                                    int B, int In, int Out, float beta, void* stream) {
   SRK_REQUIRE(x && w && dy && B > 0 && In > 0 && Out > 0, "linear_backward: bad args");
   hipStream_t s = (hipStream_t)stream;
-  if (dx) hipLaunchKernelGGL(k_linear_dx, dim3(cdiv(In, 256), cdiv(B, LIN_BT)), dim3(256), 0, s, dy, w, dx, B, In, Out);
-  if (dw) {
+  const bool wide = linear_wide(x, w, dw ? (const void*)dw : (const void*)dx, In, Out) && ((uintptr_t)dx & 15) == 0;
+  if (dx && wide)
+    hipLaunchKernelGGL(k_linear_dx_wide, dim3(cdiv(In, 64), cdiv(B, LW_BT)), dim3(1024), 0, s, dy, w, dx, B, In, Out);
+  else if (dx)
+    hipLaunchKernelGGL(k_linear_dx, dim3(cdiv(In, 256), cdiv(B, LIN_BT)), dim3(256), 0, s, dy, w, dx, B, In, Out);
+  if (dw && wide) {
+    hipLaunchKernelGGL(k_linear_dw_wide, dim3(cdiv(In / 4, 256), cdiv(Out, 16)), dim3(256), 0, s, dy, x, dw, B, In, Out,
+                       beta);
+  } else if (dw) {
     size_t nb = ((size_t)Out * ((In + 3) / 4) + 255) / 256;
     if (nb > 16384) nb = 16384;
     hipLaunchKernelGGL(k_linear_dw, dim3((unsigned)nb), dim3(256), 0, s, dy, x, dw, B, In, Out, beta);

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import TOL_TIGHT, rel_err
+from conftest import TOL_TIGHT, assert_close_elementwise, rel_err
 from oracle import fill
 from oracle.kat_table import CONV_KATS, conv_case_inputs
 
@@ -323,6 +323,32 @@ def test_linear(gpu, ops_kat):
     assert rel_err(x.grad, ops_kat["fc.dx"]) < TOL_TIGHT
     assert rel_err(w.grad, ops_kat["fc.dw"]) < TOL_TIGHT
     assert rel_err(b.grad, ops_kat["fc.db"]) < TOL_TIGHT
+
+
+@pytest.mark.parametrize("shape", [(16, 18432, 1024), (5, 2048, 70), (20, 4096, 65), (1, 2052, 64)])
+def test_linear_wide_layers(gpu, shape):
+    """The weight-streaming kernels of wide dense layers (SRGAN discriminator 512*6*6 -> 1024, srgan.py:66-70; taken
+    for In >= 2048, Out >= 64) against float64 matmuls: forward with fused LeakyReLU, dx, dw (beta = 0 and accumulate),
+    db; batch above / below the 16-row pass, Out not a multiple of the 4- / 16-row blocks, In not a multiple of 64."""
+    pkg = _pkg()
+    B, In, Out = shape
+    x = fill.randn((B, In), 71).to(gpu).requires_grad_(True)
+    w = (fill.randn((Out, In), 72) * 0.02).to(gpu).requires_grad_(True)
+    b = fill.randn((Out,), 73).to(gpu).requires_grad_(True)
+    g = fill.randn((B, Out), 74).to(gpu)
+    y = pkg.ops.linear(x, w, b, 3, 0.2)   # 3 = LeakyReLU
+    z = x.detach().double().cpu() @ w.detach().double().cpu().t() + b.detach().double().cpu()
+    yr = torch.where(z > 0, z, 0.2 * z)
+    assert_close_elementwise(y, yr, 2e-6, what="wide linear forward")
+    y.backward(g)
+    gz = g.double().cpu() * torch.where(z > 0, 1.0, 0.2)
+    assert_close_elementwise(x.grad, gz @ w.detach().double().cpu(), 2e-6, what="wide linear dx")
+    assert_close_elementwise(w.grad, gz.t() @ x.detach().double().cpu(), 2e-6, what="wide linear dw")
+    assert_close_elementwise(b.grad, gz.sum(0), 2e-6, what="wide linear db")
+    first = w.grad.clone()
+    y2 = pkg.ops.linear(x, w, b, 3, 0.2)
+    y2.backward(g)                           # autograd accumulates: 2x
+    assert_close_elementwise(w.grad, 2 * first, 1e-6, what="wide linear dw accumulated")
 
 
 def test_layout_roundtrip_and_ragged(gpu):
