@@ -30,7 +30,9 @@ __global__ __launch_bounds__(256) void k_bn_colsum(const float* __restrict__ a, 
       mu = mean[c];
       rs = rstd[c];
     }
-    constexpr int U = 8;
+    // 16 rows per wave are loaded before the first add: with 64 rows per block (bn_colsum) a block is ONE load round
+    // (these kernels are 5-8 us latency chains on the SRGAN tensors, not bandwidth problems)
+    constexpr int U = 16;
     for (size_t rb = r0 + w; rb < r1; rb += 4 * U) {
       float va[U], vx[U];
 #pragma unroll
@@ -39,14 +41,15 @@ __global__ __launch_bounds__(256) void k_bn_colsum(const float* __restrict__ a, 
         va[u] = r < r1 ? a[r * C + c] : 0.f;
         if (MODE == 1) vx[u] = r < r1 ? x[r * C + c] : mu;
       }
-      if (MODE == 1 && DBL) {
+      if (DBL || MODE == 0) {
         // backward statistics feed a difference that cancels to ~1e-4 of its mass when a BatchNorm follows another
-        // (SRGAN-D at 128x128): products and sums in double, only the inputs are fp32
+        // (SRGAN-D at 128x128): products and sums in double, only the inputs are fp32.  Forward: x*x is exact in
+        // double, so mean / var carry no rounding but that of the inputs.
         double d0 = 0.0, d1 = 0.0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           d0 += (double)va[u];
-          d1 += (double)va[u] * (((double)vx[u] - (double)mu) * (double)rs);
+          d1 += MODE == 0 ? (double)va[u] * (double)va[u] : (double)va[u] * (((double)vx[u] - (double)mu) * (double)rs);
         }
         s0 += d0;
         s1 += d1;
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256) void k_bn_colsum(const float* __restrict__ a, 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           f0 += va[u];
-          f1 += MODE == 0 ? va[u] * va[u] : va[u] * ((vx[u] - mu) * rs);
+          f1 += va[u] * ((vx[u] - mu) * rs);
         }
         s0 += f0;
         s1 += f1;
@@ -110,16 +113,23 @@ __global__ __launch_bounds__(256) void k_bn_reduce_fused(const double* __restric
   const int c = blockIdx.x * 64 + lane;
   double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
   if (c < C) {
-    int k = w;
-    for (; k + 4 < nsplit; k += 8) {
-      a0 += partial[(size_t)k * 2 * C + c];
-      b0 += partial[(size_t)k * 2 * C + C + c];
-      a1 += partial[(size_t)(k + 4) * 2 * C + c];
-      b1 += partial[(size_t)(k + 4) * 2 * C + C + c];
-    }
-    for (; k < nsplit; k += 4) {
-      a0 += partial[(size_t)k * 2 * C + c];
-      b0 += partial[(size_t)k * 2 * C + C + c];
+    // 16 splits per wave in flight (every load issued before the first add): one L2 round trip per 64 splits
+    constexpr int U = 16;
+    for (int kb = w; kb < nsplit; kb += 4 * U) {
+      double va[U], vb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = kb + 4 * u;
+        va[u] = k < nsplit ? partial[(size_t)k * 2 * C + c] : 0.0;
+        vb[u] = k < nsplit ? partial[(size_t)k * 2 * C + C + c] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u += 2) {
+        a0 += va[u];
+        b0 += vb[u];
+        a1 += va[u + 1];
+        b1 += vb[u + 1];
+      }
     }
   }
   sm[0][w][lane] = a0 + a1;
@@ -214,6 +224,61 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
   }
 }
 
+// 16-byte versions (C % 4 == 0, aligned tensors): one float4 per thread and pass, no per-element modulo
+typedef float bn_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_bn_apply4(const float* __restrict__ x, float* __restrict__ y,
+                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   size_t total4, int C, int act, float slope) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+    const int c = (int)((i * 4) % (size_t)C);
+    const bn_f4 xv = *reinterpret_cast<const bn_f4*>(x + i * 4);
+    const bn_f4 mu = *reinterpret_cast<const bn_f4*>(mean + c), rs = *reinterpret_cast<const bn_f4*>(rstd + c);
+    bn_f4 v = (xv - mu) * rs;
+    if (gamma) v *= *reinterpret_cast<const bn_f4*>(gamma + c);
+    if (beta) v += *reinterpret_cast<const bn_f4*>(beta + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act, slope);
+    *reinterpret_cast<bn_f4*>(y + i * 4) = v;
+  }
+}
+
+template <bool DBL>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply4(const float* __restrict__ dy, const float* __restrict__ x,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma,
+                                                       const double* __restrict__ dstats, double count,
+                                                       float* __restrict__ dx, size_t total4, int C) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+    const int c = (int)((i * 4) % (size_t)C);
+    const bn_f4 dv = *reinterpret_cast<const bn_f4*>(dy + i * 4), xv = *reinterpret_cast<const bn_f4*>(x + i * 4);
+    const bn_f4 mu = *reinterpret_cast<const bn_f4*>(mean + c), rs = *reinterpret_cast<const bn_f4*>(rstd + c);
+    bn_f4 g = {1.f, 1.f, 1.f, 1.f};
+    if (gamma) g = *reinterpret_cast<const bn_f4*>(gamma + c);
+    bn_f4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (DBL) {  // (same evaluation as k_bn_bwd_apply<true>)
+        const double xhat = ((double)xv[e] - (double)mu[e]) * (double)rs[e];
+        const double m1 = dstats[c + e] / count;
+        const double m2 = dstats[C + c + e] / count;
+        o[e] = (float)((double)g[e] * (double)rs[e] * ((double)dv[e] - m1 - xhat * m2));
+      } else {
+        const float xhat = (xv[e] - mu[e]) * rs[e];
+        const float m1 = (float)(dstats[c + e] / count);
+        const float m2 = (float)(dstats[C + c + e] / count);
+        o[e] = g[e] * rs[e] * (dv[e] - m1 - xhat * m2);
+      }
+    }
+    *reinterpret_cast<bn_f4*>(dx + i * 4) = o;
+  }
+}
+
+static bool bn_vec4(int C, const void* a, const void* b, const void* c, const void* d, const void* e, const void* f) {
+  if (C & 3) return false;
+  return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e | (uintptr_t)f) & 15) == 0;
+}
+
 __global__ __launch_bounds__(256) void k_bn_param_grads(const double* __restrict__ dstats, float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta, int C) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -238,7 +303,7 @@ struct BnFused {   // fused tail of bn_colsum: what the reduce kernel also compu
 
 static int bn_colsum(int mode, const float* a, const float* x, const float* mean, const float* rstd, double* out,
                      size_t rows, int C, void* ws, hipStream_t s, const BnFused& fu = BnFused()) {
-  int splits = (int)((rows + 127) / 128);
+  int splits = (int)((rows + 63) / 64);
   if (splits > kBnRowSplits) splits = kBnRowSplits;
   if (splits < 1) splits = 1;
   const size_t rps = (rows + splits - 1) / splits;
@@ -586,8 +651,12 @@ extern "C" int srk_bn_apply(const float* x, float* y, const float* mean, const f
   const size_t total = rows * (size_t)C;
   size_t nb = (total + 256 * 4 - 1) / (256 * 4);
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, y, mean, rstd, gamma, beta,
-                     total, C, act, slope);
+  if (bn_vec4(C, x, y, mean, rstd, gamma, beta))
+    hipLaunchKernelGGL(k_bn_apply4, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, y, mean, rstd, gamma, beta,
+                       total / 4, C, act, slope);
+  else
+    hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, y, mean, rstd, gamma, beta,
+                       total, C, act, slope);
   return check_launch("bn_apply");
 }
 
@@ -604,12 +673,21 @@ extern "C" int srk_bn_backward_apply(const float* dy, const float* x, const floa
   const size_t total = rows * (size_t)C;
   size_t nb = (total + 256 * 4 - 1) / (256 * 4);
   if (nb > 4096) nb = 4096;
-  if (bn_fp32_backward())
-    hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd,
-                       gamma, dstats, count, dx, total, C);
-  else
+  const bool v4 = bn_vec4(C, dy, x, mean, rstd, gamma, dx);
+  if (bn_fp32_backward()) {
+    if (v4)
+      hipLaunchKernelGGL(k_bn_bwd_apply4<false>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd,
+                         gamma, dstats, count, dx, total / 4, C);
+    else
+      hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd,
+                         gamma, dstats, count, dx, total, C);
+  } else if (v4) {
+    hipLaunchKernelGGL(k_bn_bwd_apply4<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd,
+                       gamma, dstats, count, dx, total / 4, C);
+  } else {
     hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd,
                        gamma, dstats, count, dx, total, C);
+  }
   return check_launch("bn_backward_apply");
 }
 
