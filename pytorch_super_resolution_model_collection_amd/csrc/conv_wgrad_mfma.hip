@@ -473,6 +473,19 @@ static WgPlan plan(const srk_conv_desc& d) {
   if (nt > (1L << 30)) return pl;
   pl.ntiles = (int)nt;
   pl.G = pl.ntiles < WG_MAXBLOCKS ? pl.ntiles : WG_MAXBLOCKS;
+  {
+    // deep, small layers (SRGAN discriminator: 512 -> 512 at 6x6): every split-K slab is a full filter (9.4 MB), and
+    // one slab per tile makes the slabs -- written here, read back by the reduce -- the dominant traffic.  Cap the
+    // slab count at what fills the GPU (2 blocks per CU) together with the channel blocks of the grid: SRGAN adversarial
+    // step 16.49 -> 15.78 ms (0 = one slab per tile: 16.49, 1: 16.12, 4: 15.99).
+    static const int per_cu = getenv("SRK_WG_MFMA_BLOCKS") ? atoi(getenv("SRK_WG_MFMA_BLOCKS")) : 2;
+    if (per_cu > 0 && !pl.smallcin) {
+      const int chan_blocks = cdiv(d.Cin, 64) * cdiv(d.Cout, pl.NTC * 16);
+      int g = (per_cu * kNumCU + chan_blocks - 1) / chan_blocks;
+      if (g < 1) g = 1;
+      if (pl.G > g) pl.G = g;
+    }
+  }
   pl.ok = true;
   return pl;
 }
