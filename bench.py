@@ -256,6 +256,15 @@ def train_extra(pkg, dev, rank, world, nsteps=20):
                              "all-reduces issued behind the grouped weight-gradient launches)" % world)
         if nocomm is not None:
             out["c4_exposed_comm_ms"] = round(1e3 * (sec - nocomm) / k, 3)
+        if world == 1:
+            # the same step with fp32-faithful (bf16x6) products in EVERY forward conv: by default the activation-free
+            # tail of the net (body-end, upsampler and reconstruction convs) runs its training forward on bf16x3
+            pkg.ops.LINEAR_TAIL_X3 = False
+            try:
+                sec6, k6, _ = run("edsr", edsr(), x, t, pkg.ops.l1_loss, None, False)
+            finally:
+                pkg.ops.LINEAR_TAIL_X3 = True
+            out["c4_edsr_ms_per_step_bf16x6_forward_everywhere"] = round(1e3 * sec6 / k6, 3)
 
     def c4_shard16():
         # what ONE of 8 ranks computes per step under strong scaling (16 of the 128 patches), timed on this GPU alone:

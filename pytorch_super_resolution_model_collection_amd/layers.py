@@ -79,6 +79,7 @@ class Conv2d(torch.nn.Conv2d):
         """conv (+ fused epilogue).  In grad mode only none/relu/lrelu are fused (see ops.conv2d);
         the caller applies other activations unfused.  res_box / add_box: ops.GradBox of a residual block."""
         cfg = ops.ConvCfg(self._s, self._p, False, 0, act, slope, ps_r)
+        cfg.tail = act == ACT_NONE and getattr(self, "_linear_tail", False)
         if grad_mode(x, self.weight, self.bias, residual, prelu_w):
             return ops.conv2d(x, self.weight, self.bias, residual, cfg, _plan_views(self, ps_r), res_box, add_box)
         packed = self._cache.get(self.weight, self.bias, False, ps_r)

@@ -97,6 +97,7 @@ class VDSRNet(nn.Module):
         self.residual_layers = nn.Sequential(*[ConvBlock(base_filter, base_filter, 3, 1, 1, norm=None, bias=False)
                                                for _ in range(num_residuals)])
         self.output_conv = ConvBlock(base_filter, num_channels, 3, 1, 1, activation=None, norm=None, bias=False)
+        self.output_conv.conv._linear_tail = True   # only the global residual add lies between it and the loss (ops.py)
 
     def forward(self, x):
         out = self.residual_layers(self.input_conv(x))
@@ -128,6 +129,13 @@ class EDSRNet(nn.Module):
             Upsample2xBlock(base_filter, base_filter, upsample='ps', activation=None, norm=None),
             Upsample2xBlock(base_filter, base_filter, upsample='ps', activation=None, norm=None))
         self.output_conv = ConvBlock(base_filter, num_channels, 3, 1, 1, activation=None, norm=None)
+        # nothing but additions, pixel shuffles and convolutions lies between these layers' outputs and the loss: no
+        # activation mask depends on their rounding, so their training forward takes the bf16x3 products of the
+        # backward pass (the ReLU-carrying body keeps the fp32-faithful bf16x6; ops.set_precision("bf16x6") keeps it
+        # everywhere)
+        for m in (self.mid_conv.conv, self.upscale4x[0].upsample.conv, self.upscale4x[1].upsample.conv,
+                  self.output_conv.conv):
+            m._linear_tail = True
 
     def weight_init(self, mean=0.0, std=0.02):
         for m in self.modules():

@@ -29,15 +29,23 @@ CL = torch.channels_last
 #            a bias-free ReLU net, and one flipped unit moves that layer's gradient by
 #            ~1/sqrt(units) ~ 1e-2); gradients then only carry the ~5e-6 arithmetic error of the
 #            bf16x3 data-gradient kernels.
+#            train_fwd_tail = bf16x3: the training forward of the layers a model marks `_linear_tail` -- nothing
+#            but convolutions, additions and pixel shuffles between their output and the loss (EDSR: body-end conv,
+#            the two upsampler convs, the reconstruction conv; VDSR: the reconstruction conv), so no mask depends on
+#            their rounding and the ~5e-6 of the backward kernels is what their forward may carry as well (EDSR step
+#            7.11 -> 6.67 ms).  "bf16x6" keeps the fp32-faithful products there too; SRK_LINEAR_TAIL_X3=0 likewise.
 #   "bf16x3" everything on the 3-term bf16 split (fastest; forward error ~1e-5, gradients subject to
 #            the mask-flip sensitivity above).
 #   "fp32"   everything exact fp32 (summation-order-level agreement with ATen/oneDNN).
-_MODES = {"mixed": {"infer": ALGO_AUTO, "train_fwd": _lib.ALGO_MFMA_BF16X6, "bwd": ALGO_AUTO},
+_MODES = {"mixed": {"infer": ALGO_AUTO, "train_fwd": _lib.ALGO_MFMA_BF16X6, "bwd": ALGO_AUTO,
+                    "train_fwd_tail": ALGO_AUTO},
           # fp32-faithful products everywhere they exist (inference included): what "mixed" costs when bf16x3's ~5e-6 is
           # not acceptable for the forward either
-          "bf16x6": {"infer": _lib.ALGO_MFMA_BF16X6, "train_fwd": _lib.ALGO_MFMA_BF16X6, "bwd": ALGO_AUTO},
-          "bf16x3": {"infer": ALGO_AUTO, "train_fwd": ALGO_AUTO, "bwd": ALGO_AUTO},
-          "fp32": {"infer": _lib.ALGO_MFMA, "train_fwd": _lib.ALGO_MFMA, "bwd": _lib.ALGO_MFMA}}
+          "bf16x6": {"infer": _lib.ALGO_MFMA_BF16X6, "train_fwd": _lib.ALGO_MFMA_BF16X6, "bwd": ALGO_AUTO,
+                     "train_fwd_tail": _lib.ALGO_MFMA_BF16X6},
+          "bf16x3": {"infer": ALGO_AUTO, "train_fwd": ALGO_AUTO, "bwd": ALGO_AUTO, "train_fwd_tail": ALGO_AUTO},
+          "fp32": {"infer": _lib.ALGO_MFMA, "train_fwd": _lib.ALGO_MFMA, "bwd": _lib.ALGO_MFMA,
+                   "train_fwd_tail": _lib.ALGO_MFMA}}
 _PRECISION = {"mode": "mixed"}
 
 
@@ -123,12 +131,13 @@ def flatten_nchw(x):
 # ------------------------------------------------------------------------------------------------
 class ConvCfg(object):
     """Static configuration of one Conv2d / ConvTranspose2d call."""
-    __slots__ = ("stride", "pad", "transposed", "out_pad", "act", "slope", "ps_r", "algo")
+    __slots__ = ("stride", "pad", "transposed", "out_pad", "act", "slope", "ps_r", "algo", "tail")
 
     def __init__(self, stride=1, pad=0, transposed=False, out_pad=0, act=ACT_NONE, slope=0.0, ps_r=0,
                  algo=ALGO_AUTO):
         self.stride, self.pad, self.transposed, self.out_pad = int(stride), int(pad), bool(transposed), int(out_pad)
         self.act, self.slope, self.ps_r, self.algo = int(act), float(slope), int(ps_r), int(algo)
+        self.tail = False   # training forward of a layer with no nonlinearity between its output and the loss
 
 
 def _weight_dims(weight, transposed):
@@ -365,7 +374,8 @@ class _Conv2d(torch.autograd.Function):
         else:
             wp = pack_weight_fwd(weight, cfg.transposed, cfg.ps_r)
             bp = pack_bias_ps(bias, cfg.ps_r)
-        y = conv_forward_raw(x, wp, bp, weight, cfg, None, residual, "train_fwd")
+        y = conv_forward_raw(x, wp, bp, weight, cfg, None, residual,
+                             "train_fwd_tail" if (cfg.tail and LINEAR_TAIL_X3) else "train_fwd")
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
@@ -475,6 +485,9 @@ def conv2d(x, weight, bias=None, residual=None, cfg=None, packed=None, res_box=N
     if cfg.act != ACT_NONE and (residual is not None or cfg.ps_r > 1):
         raise RuntimeError("conv2d (autograd path): activation cannot be fused together with residual/pixel-shuffle")
     return _Conv2d.apply(x, weight, bias, residual, cfg, packed, res_box, add_box)
+
+
+LINEAR_TAIL_X3 = os.environ.get("SRK_LINEAR_TAIL_X3", "1") != "0"
 
 
 # ---- residual block with both convolutions in one launch (srk_resblock2_*) ----------------------------------------

@@ -160,3 +160,42 @@ def test_net_elementwise_outputs_and_body_gradients(gpu, name):
         assert_close_elementwise(p.grad, og[pname].grad, 1e-3, what="%s grad %s" % (name, pname))
         n_checked += 1
     assert n_checked == len(og)
+
+
+def test_linear_tail_forward_precision_policy(gpu):
+    """'mixed' precision: layers with no nonlinearity between their output and the loss (EDSR body-end / upsampler /
+    reconstruction convs, VDSR reconstruction conv) run their TRAINING forward on bf16x3, everything that feeds an
+    activation on the fp32-faithful bf16x6; 'bf16x6' mode and ops.LINEAR_TAIL_X3 = False keep bf16x6 everywhere.  The
+    two policies agree to the bf16x3 error (~5e-6 per product) on outputs and gradients."""
+    import pytorch_super_resolution_model_collection_amd as pkg
+    net = pkg.EDSRNet(3, 64, 2)
+    fill.fill_module(net, 5, 0.5)
+    net.to(gpu).train()
+    tails = [net.mid_conv.conv, net.upscale4x[0].upsample.conv, net.upscale4x[1].upsample.conv, net.output_conv.conv]
+    assert all(getattr(m, "_linear_tail", False) for m in tails)
+    assert not getattr(net.input_conv.conv, "_linear_tail", False)
+    assert not any(getattr(m, "_linear_tail", False) for b in net.residual_layers for m in (b.conv1, b.conv2))
+    assert pkg.VDSRNet(3, 64, 2).output_conv.conv._linear_tail
+    lib = pkg._lib.load()
+    x = fill.rand((2, 3, 12, 12), 61).to(gpu)
+
+    def run(flag):
+        old = pkg.ops.LINEAR_TAIL_X3
+        pkg.ops.LINEAR_TAIL_X3 = flag
+        try:
+            for p in net.parameters():
+                p.grad = None
+            y = net(x)
+            name = lib.srk_last_kernel_name().decode()      # the reconstruction conv's forward kernel
+            y.abs().sum().backward()
+            return y.detach(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}, name
+        finally:
+            pkg.ops.LINEAR_TAIL_X3 = old
+
+    y3, g3, k3 = run(True)
+    y6, g6, k6 = run(False)
+    assert k3 != k6 or "tapn" in k3, (k3, k6)      # a different (bf16x3 vs bf16x6) kernel / variant was dispatched
+    assert not torch.equal(y3, y6)
+    assert rel_err(y3, y6) < 5e-5
+    for k in g6:
+        assert rel_err(g3[k], g6[k]) < 2e-4, k
