@@ -149,13 +149,17 @@ def cpu_baseline(batch_cap=8, lr_size=256):
 # "mixed" precision issues for them: forward = 6 bf16 MFMAs per product (bf16x6), data + weight gradient = 3 each (bf16x3).
 # Upper estimates: the few Cin<=4 / 9x9 / 64->3 layers run on other kernels (fp32 MFMA, taps-as-N).
 C3_FWD, C4_FWD = 2.2425e9, 4.0615e9
+# of which: layers whose training forward runs bf16x3 in "mixed" (no activation between them and the loss, ops.py):
+# VDSR's reconstruction conv; EDSR's body-end, 2 upsampler and reconstruction convs (75.5 + 302 + 1208 + 56.6 MFLOP)
+C3_TAIL_FWD, C4_TAIL_FWD = 5.81e6, 1.6421e9
 C5_G_FWD, C5_D_FWD = 4.543e9, 3.1437e9
 
 
-def bf16_pipe_frac(fwd_flop, bwd_flop, seconds_per_sample):
-    """(MFMAs issued x 16384 FLOP) / time / 2.5 PF for a training sample: fwd_flop of forward convs, bwd_flop of
-    backward convs (data + weight gradient together)."""
-    return (6.0 * fwd_flop + 3.0 * bwd_flop) / seconds_per_sample / (BF16_MFMA_PEAK_TFLOPS * 1e12)
+def bf16_pipe_frac(fwd_flop, bwd_flop, seconds_per_sample, fwd_x3_flop=0.0):
+    """(MFMAs issued x 16384 FLOP) / time / 2.5 PF for a training sample: fwd_flop of forward convs (fwd_x3_flop of them
+    on bf16x3, the rest on bf16x6), bwd_flop of backward convs (data + weight gradient together, bf16x3)."""
+    return (6.0 * (fwd_flop - fwd_x3_flop) + 3.0 * fwd_x3_flop + 3.0 * bwd_flop) / seconds_per_sample / \
+        (BF16_MFMA_PEAK_TFLOPS * 1e12)
 
 
 def train_extra(pkg, dev, rank, world, nsteps=20):
@@ -234,7 +238,7 @@ def train_extra(pkg, dev, rank, world, nsteps=20):
         sec, k, _ = run("vdsr", net, x, t, pkg.ops.mse_loss, 0.4, False)
         out["c3_vdsr_x4_train_patches_per_s"] = round(256 * k / sec, 1)
         out["c3_vdsr_ms_per_step"] = round(1e3 * sec / k, 3)
-        out["c3_vdsr_bf16_pipe_frac"] = round(bf16_pipe_frac(C3_FWD, 2 * C3_FWD, sec / k / 256), 4)
+        out["c3_vdsr_bf16_pipe_frac"] = round(bf16_pipe_frac(C3_FWD, 2 * C3_FWD, sec / k / 256, C3_TAIL_FWD), 4)
 
     gb = 128
 
@@ -251,7 +255,7 @@ def train_extra(pkg, dev, rank, world, nsteps=20):
         sec, k, nocomm = run("edsr", edsr(), x, t, pkg.ops.l1_loss, None, True)
         out["c4_edsr_x4_train_patches_per_s_global_batch_128"] = round(gb * k / sec, 1)
         out["c4_edsr_ms_per_step"] = round(1e3 * sec / k, 3)
-        out["c4_edsr_bf16_pipe_frac"] = round(bf16_pipe_frac(C4_FWD, 2 * C4_FWD, sec / k / gb) / world, 4)
+        out["c4_edsr_bf16_pipe_frac"] = round(bf16_pipe_frac(C4_FWD, 2 * C4_FWD, sec / k / gb, C4_TAIL_FWD) / world, 4)
         out["c4_scaling"] = ("strong (global batch 128 sharded over %d rank(s); 6.07 MB of gradients per step as bucketed RCCL "
                              "all-reduces issued behind the grouped weight-gradient launches)" % world)
         if nocomm is not None:
