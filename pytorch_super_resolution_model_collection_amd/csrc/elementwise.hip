@@ -170,6 +170,33 @@ __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ dy, c
   }
 }
 
+// 16-byte version of k_act_bwd for the activations the nets use in training (ReLU / LeakyReLU / single-slope PReLU):
+// one float4 per thread and pass.  The scalar kernel walks 8 elements per thread one dependent 4-byte load pair at a
+// time (13 us for the 1 M-element tensors of the SRGAN generator; 65 calls per adversarial step).
+__global__ __launch_bounds__(256) void k_act_bwd4(const float* __restrict__ dy, const float* __restrict__ saved,
+                                                  float* __restrict__ dx, size_t n4, int act, float slope,
+                                                  const float* __restrict__ pw, float* __restrict__ dpw) {
+  typedef float af4 __attribute__((ext_vector_type(4)));
+  __shared__ float sm[4];
+  float a = act == SRK_ACT_RELU ? 0.f : slope;
+  if (act == SRK_ACT_PRELU) a = pw[0];
+  float dslope = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const af4 g = reinterpret_cast<const af4*>(dy)[i], s = reinterpret_cast<const af4*>(saved)[i];
+    af4 d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      d[e] = s[e] > 0.f ? g[e] : g[e] * a;
+      if (act == SRK_ACT_PRELU) dslope += s[e] > 0.f ? 0.f : g[e] * s[e];
+    }
+    reinterpret_cast<af4*>(dx)[i] = d;
+  }
+  if (act == SRK_ACT_PRELU && dpw) {
+    const float tot = block_sum_256(dslope, sm);
+    if (threadIdx.x == 0 && tot != 0.f) atomicAdd(dpw, tot);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_axpby(const float* __restrict__ a, const float* __restrict__ b,
                                                float* __restrict__ out, size_t n, float alpha, float beta) {
   const size_t n4 = n / 4;
@@ -249,6 +276,12 @@ extern "C" int srk_act_backward(const float* dy, const float* saved, float* dx, 
   if (act == SRK_ACT_PRELU) {
     SRK_REQUIRE(prelu_weight && prelu_n >= 1, "act_backward: PReLU needs its weight");
     SRK_REQUIRE(prelu_n == 1 || prelu_n == channels, "act_backward: prelu_n %d != channels %d", prelu_n, channels);
+  }
+  const bool relu_family = act == SRK_ACT_RELU || act == SRK_ACT_LRELU || (act == SRK_ACT_PRELU && prelu_n == 1);
+  if (relu_family && (n & 3) == 0 && (((uintptr_t)dy | (uintptr_t)saved | (uintptr_t)dx) & 15) == 0) {
+    hipLaunchKernelGGL(k_act_bwd4, dim3(ew_grid(n / 4, 256 * 2)), dim3(256), 0, (hipStream_t)stream, dy, saved, dx, n / 4,
+                       act, slope, prelu_weight, dprelu);
+    return check_launch("act_backward");
   }
   hipLaunchKernelGGL(k_act_bwd, dim3(ew_grid(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, dy, saved, dx, n,
                      channels, act, slope, prelu_weight, prelu_n, dprelu);
