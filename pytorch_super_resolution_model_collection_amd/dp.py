@@ -67,6 +67,10 @@ class DataParallel(object):
         self.min_bucket_elems = max(1, int(min_bucket_bytes) // 4)   # smaller final runs wait for a neighbour
         self.trunk_chunk_layers = int(trunk_chunk_layers)             # layers per grouped weight-gradient launch under DP
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # `active`: the exchange really runs.  SRK_DP_FORCE_COMM=1 (tests) keeps every collective in the path with a
+        # process group of ONE rank -- on a single-GPU box that is the only way to put RCCL itself (communicator init,
+        # async all-reduce kernels between graph replays, stream / event ordering) under the data-parallel step
+        self.active = self.world > 1 or (dist.is_initialized() and bool(os.environ.get("SRK_DP_FORCE_COMM")))
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.bucket_elems = max(1, int(bucket_bytes) // 4)
         # upstream gradient that makes the all-reduced SUM the mean over ranks
@@ -74,7 +78,7 @@ class DataParallel(object):
 
     def broadcast_params(self, src=0):
         """Identical initial replicas: rank `src`'s flat parameter buffer to everyone."""
-        if self.world > 1:
+        if self.active:
             dist.broadcast(self.flat.data, src=src, group=self.group)
             # the parameters changed behind the optimizer's back: invalidate packed-filter caches / the PackPlan
             if hasattr(self.flat, "mark_changed"):
@@ -154,7 +158,7 @@ class DataParallel(object):
         makes it the mean) every part of the flat gradient buffer as soon as it is final.  Returns when the current
         stream is ordered after the last bucket."""
         from . import ops
-        if self.world == 1:
+        if not self.active:
             ops.join_side_streams()
             return
         groups = ops.pending_wgrad_groups(self.trunk_chunk_layers)
@@ -180,7 +184,7 @@ class DataParallel(object):
 
     def allreduce_scalar(self, t):
         """Mean of a logging scalar (the loss) over ranks — off the critical path."""
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             t = t / self.world
         return t

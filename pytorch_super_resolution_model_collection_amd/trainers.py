@@ -37,7 +37,7 @@ def _backward(loss, dp):
     """loss.backward() of the reference (edsr.py:154 ...).  Single GPU: the deferred weight gradients are launched
     (grouped) when the autograd engine finishes the pass.  Data parallel: they stay pending so that dp.exchange() can
     interleave the grouped launches with the gradient buckets; the backward is seeded with 1/world."""
-    if dp is not None and dp.world > 1:
+    if dp is not None and dp.active:
         with ops.manual_wgrad_flush():
             loss.backward(dp.loss_seed)
     else:
@@ -80,7 +80,7 @@ def lapsrn_step(model, opt, dp=None):
         hr2, hr4 = model(inp)
         l1 = ops.charbonnier_loss(hr2, target2x)
         l2 = ops.charbonnier_loss(hr4, target4x)
-        seed = dp.loss_seed if (dp is not None and dp.world > 1) else None
+        seed = dp.loss_seed if (dp is not None and dp.active) else None
         if seed is not None:
             with ops.manual_wgrad_flush():
                 torch.autograd.backward([l1, l2], [seed, seed])
@@ -160,6 +160,15 @@ def srgan_segments(G, D, g_opt, d_opt, g_dp=None, d_dp=None):
     return [(seg_d, d_dp), (seg_g, g_dp), (seg_u, None)]
 
 
+def _capture(graph, pool=None):
+    """torch.cuda.graph with capture_error_mode="thread_local": ProcessGroupNCCL's watchdog thread polls the events of
+    earlier collectives (hipEventQuery) at its own pace, and under the default "global" mode a query that lands while
+    THIS thread is capturing is an illegal call that takes the process down -- seen on MI355X as an intermittent abort
+    of the first capture after a broadcast / all-reduce (tests/test_dp_gpu.py, single-rank RCCL).  Work the autograd
+    thread launches on the capturing stream is captured in either mode."""
+    return torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local")
+
+
 class GraphedSegments(object):
     """A data-parallel train step as hipGraphs split at the gradient exchanges.
 
@@ -183,17 +192,17 @@ class GraphedSegments(object):
         with _no_gc_during_capture():
             for fn, dp in segments:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
+                with _capture(g, pool=pool):
                     self.out = fn(*self.static)
                 pool = g.pool()
                 wgraphs, sends, keep = [], [], None
-                if dp is not None and dp.world > 1:
+                if dp is not None and dp.active:
                     keep = ops.pending_wgrad_groups(dp.trunk_chunk_layers)   # holds x / dy / mask tensors of graph `g` alive
                     sends = dp.plan(keep)
                     ops.drop_pending_wgrads()
                     for recs in keep:
                         wg = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(wg, pool=pool):
+                        with _capture(wg, pool=pool):
                             ops.launch_wgrad_group(recs)
                         wgraphs.append(wg)
                 else:
@@ -214,7 +223,7 @@ class GraphedSegments(object):
                 s.copy_(b, non_blocking=True)
         for g, dp, wgraphs, sends, _ in self.plan:
             g.replay()
-            if dp is not None and dp.world > 1:
+            if dp is not None and dp.active:
                 works = []
                 if not wgraphs:
                     dp.send(sends[0] if sends else [(0, dp.flat.grad.numel())], works)
@@ -262,7 +271,7 @@ class GraphedStep(object):
         self.model, self.opt, self.dp, self.clip = model, opt, dp, clip
         self.loss_fn = loss_fn
         self.seg = None
-        if dp is not None and dp.world > 1:
+        if dp is not None and dp.active:
             self.seg = GraphedSegments([(self._fwd_bwd_args, dp), (self._update_args, None)], example_inputs, warmup=warmup)
             self.static = self.seg.static
             return
@@ -277,7 +286,7 @@ class GraphedStep(object):
         torch.cuda.synchronize()
         self.graph_a = torch.cuda.CUDAGraph()
         with _no_gc_during_capture():
-            with torch.cuda.graph(self.graph_a):
+            with _capture(self.graph_a):
                 self.loss = self._fwd_bwd()
                 self._update()
 
@@ -338,7 +347,7 @@ class GraphedFn(object):
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with _no_gc_during_capture():
-            with torch.cuda.graph(self.graph):
+            with _capture(self.graph):
                 self.out = fn(*self.static)
 
     def __call__(self, *batch):

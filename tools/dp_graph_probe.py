@@ -25,14 +25,23 @@ try:
     flat = pkg.optim.FlatParams(net); opt = pkg.optim.make_optimizer("edsr", flat, 1e-5)
     dp = pkg.dp.DataParallel(flat); dp.broadcast_params()
     x = torch.rand(B, 3, 32, 32, device=dev); t = torch.rand(B, 3, 128, 128, device=dev)
-    step = pkg.trainers.GraphedStep(net, opt, pkg.ops.l1_loss, (x, t), dp=dp, warmup=2)
+    if os.environ.get("EAGER"):   # the same DP step without graphs (overlapped exchange, eager launches)
+        estep = pkg.trainers.l1_step(net, opt, dp)
+        class _S(object):
+            loss = None
+            def __call__(self, a, b):
+                self.loss = estep(a, b)
+                return self.loss
+        step = _S()
+    else:
+        step = pkg.trainers.GraphedStep(net, opt, pkg.ops.l1_loss, (x, t), dp=dp, warmup=2)
     import time
     for _ in range(3): step(x, t)
     torch.cuda.synchronize()
-    for i in range(4):
+    for i in range(int(os.environ.get("NSTEPS", "4"))):
         torch.distributed.barrier(); t0 = time.perf_counter(); step(x, t); torch.cuda.synchronize()
         print("rank", rank, "step %d: %.2f ms" % (i, (time.perf_counter() - t0) * 1e3), flush=True)
-    print("rank", rank, "sends per group:", [[(lo, hi - lo) for lo, hi in r] for _, _, _, r_all, _ in step.seg.plan for r in (r_all or [])], flush=True)
+    if not os.environ.get("EAGER"): print("rank", rank, "sends per group:", [[(lo, hi - lo) for lo, hi in r] for _, _, _, r_all, _ in step.seg.plan for r in (r_all or [])], flush=True)
     print("rank", rank, "edsr graph-split DP step ok, loss", float(step.loss), flush=True)
 except Exception:
     traceback.print_exc(); sys.stdout.flush(); sys.stderr.flush(); os._exit(1)
