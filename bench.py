@@ -54,13 +54,13 @@ def parse():
 
 def barrier_sync(world):
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or torch.distributed.is_initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize()
 
 
 def max_over_ranks(seconds, world, dev):
-    if world == 1:
+    if world == 1 and not torch.distributed.is_initialized():
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=dev)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -169,13 +169,16 @@ def train_extra(pkg, dev, rank, world, nsteps=20):
     out = {}
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     WARM = 5
+    # the N > 1 code path: more than one rank, or a one-rank process group forced by SRK_DP_FORCE_COMM=1 (dry run of the
+    # data-parallel sections with real RCCL collectives on a single GPU; the numbers then mean nothing)
+    multi = world > 1 or torch.distributed.is_initialized()
 
     def run(kind, net, inp, tgt, loss_fn, clip, use_dp, steps=nsteps, warmup=WARM):
         net.to(dev).train()
         flat = pkg.optim.FlatParams(net)
         opt = pkg.optim.make_optimizer(kind, flat, 1e-5)
         dp = None
-        if use_dp and world > 1:
+        if use_dp and multi:
             dp = pkg.dp.DataParallel(flat)
             dp.broadcast_params()
         step = pkg.trainers.GraphedStep(net, opt, loss_fn, (inp, tgt), dp=dp, clip=clip, warmup=2)
@@ -260,7 +263,7 @@ def train_extra(pkg, dev, rank, world, nsteps=20):
                              "all-reduces issued behind the grouped weight-gradient launches)" % world)
         if nocomm is not None:
             out["c4_exposed_comm_ms"] = round(1e3 * (sec - nocomm) / k, 3)
-        if world == 1:
+        if not multi:
             # the same step with fp32-faithful (bf16x6) products in EVERY forward conv: by default the activation-free
             # tail of the net (body-end, upsampler and reconstruction convs) runs its training forward on bf16x3
             pkg.ops.LINEAR_TAIL_X3 = False
@@ -305,7 +308,7 @@ def train_extra(pkg, dev, rank, world, nsteps=20):
         d_opt = pkg.optim.make_optimizer("srgan_d", dflat, 1e-4)
         lr_img = torch.rand(16, 3, 32, 32, generator=g).to(dev)
         hr_img = torch.rand(16, 3, 128, 128, generator=g).to(dev)
-        if world > 1:
+        if multi:
             g_dp, d_dp = pkg.dp.DataParallel(gflat), pkg.dp.DataParallel(dflat)
             g_dp.broadcast_params()
             d_dp.broadcast_params()
@@ -320,8 +323,8 @@ def train_extra(pkg, dev, rank, world, nsteps=20):
         out["c5_srgan_bf16_pipe_frac"] = round(bf16_pipe_frac(fwd, 2 * fwd, sec / k / 16), 4)
 
     # every side metric is isolated: a failure is reported in the JSON instead of losing the headline line
-    sections = ([("c1", c1), ("c3", c3)] if world == 1 else []) + [("c4_strong", c4_strong)] + \
-               ([("c4_shard16", c4_shard16)] if world == 1 else [("c4_weak", c4_weak)]) + [("c5", c5)]
+    sections = ([("c1", c1), ("c3", c3)] if not multi else []) + [("c4_strong", c4_strong)] + \
+               ([("c4_shard16", c4_shard16)] if not multi else [("c4_weak", c4_weak)]) + [("c5", c5)]
     for name, fn in sections:
         try:
             fn()
@@ -363,7 +366,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     pkg._lib.load()
     pkg.ops.set_precision(args.precision)
@@ -455,7 +458,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(lr_size=args.lr_size)
         print(json.dumps(result))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -28,7 +28,10 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    # SRK_DP_FORCE_COMM=1 with ONE rank: a real process group (RCCL on a GPU box) so that every collective of the
+    # data-parallel paths runs on a single-GPU machine (tests, `bench.py` dry runs of the N > 1 code path)
+    forced = world == 1 and bool(os.environ.get("SRK_DP_FORCE_COMM"))
+    if (world > 1 or forced) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
