@@ -48,7 +48,7 @@ struct BfdParams {
 // g = tid&3, pixel slot tid>>2); all global loads of a batch are issued before the first conversion.
 constexpr int BFD_STAGE_IT = 6;
 
-template <bool MASK, int NTHR, int NP>
+template <bool MASK, int NTHR, int NP, int IT>
 __device__ __forceinline__ void bfd_stage_halo_t(const BfdParams& B, uint4* hal, int n, int r0, int c0, int cb) {
   const MfmaConvParams& P = B.P;
   const int npix = P.HH * P.HW;
@@ -67,10 +67,10 @@ __device__ __forceinline__ void bfd_stage_halo_t(const BfdParams& B, uint4* hal,
   const size_t img_off = (size_t)n * P.IH * ia.sA;  // wave-uniform: scalar base pointers
   const float* __restrict__ inb = P.in + img_off;
   const float* __restrict__ mkb = MASK ? P.mask_y + img_off : nullptr;
-  for (int base = hp0; base < npix; base += PPP * BFD_STAGE_IT) {
-    f32x4 v0[BFD_STAGE_IT], v1[BFD_STAGE_IT], m0[BFD_STAGE_IT], m1[BFD_STAGE_IT];
+  for (int base = hp0; base < npix; base += PPP * IT) {
+    f32x4 v0[IT], v1[IT], m0[IT], m1[IT];
 #pragma unroll
-    for (int k = 0; k < BFD_STAGE_IT; ++k) {
+    for (int k = 0; k < IT; ++k) {
       v0[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
       v1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (MASK) {
@@ -110,7 +110,7 @@ __device__ __forceinline__ void bfd_stage_halo_t(const BfdParams& B, uint4* hal,
       }
     }
 #pragma unroll
-    for (int k = 0; k < BFD_STAGE_IT; ++k) {
+    for (int k = 0; k < IT; ++k) {
       const int hp = base + PPP * k;
       if (hp < npix) {
         float f[8];
@@ -133,6 +133,12 @@ __device__ __forceinline__ void bfd_stage_halo_t(const BfdParams& B, uint4* hal,
 }
 
 constexpr int BFD_MAXTAPS = 128;
+#ifndef BFD_OCC3
+#define BFD_OCC3 1
+#endif
+#ifndef BFD_ROT
+#define BFD_ROT 1
+#endif
 constexpr int BFD_EPI_STRIDE = 68;  // floats per staged output row (64 + 4: conflict-free float4 rows)
 
 // accumulators -> LDS slab of the pixel group (32 pixels x block channels, two halves) -> 16-byte
@@ -219,10 +225,16 @@ __device__ __forceinline__ void bfd_epilogue_direct(const MfmaConvParams& P, con
 // chunks -- two waves per SIMD on a block that is pure latency otherwise -- and the partial accumulators meet in LDS
 // before the epilogue.
 template <int NTW, int NPW, int NOW, int NP, int PF, int KS>
-__global__ __launch_bounds__(64 * NPW * NOW * KS, 2) void k_conv_bfd(
+__global__ __launch_bounds__(64 * NPW * NOW * KS, (BFD_OCC3 && NP == 3 && NTW == 2 && NPW * NOW * KS == 4) ? 3 : 2) void k_conv_bfd(
     BfdParams B) {
   constexpr int NTHR = 64 * NPW * NOW * KS;
   constexpr bool TEPI = NPW == 1;
+  // the bf16x6 4-wave block (the training forward of every 64-channel layer at benchmark batch sizes) is compiled for
+  // 3 waves per SIMD (launch bound 168 VGPRs; it took 233 = 2 waves per SIMD): its halo staging keeps 2 pixels per
+  // thread in flight instead of 6, which is what the register budget was spent on.  VDSR step 8.30 -> 7.96 ms, EDSR
+  // 6.66 -> 6.62 ms (BFD_OCC3=0 restores the old build)
+  constexpr bool OCC3 = BFD_OCC3 && NP == 3 && NTW == 2 && NPW * NOW * KS == 4;
+  constexpr int SIT = OCC3 ? 2 : BFD_STAGE_IT;
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   const MfmaConvParams& P = B.P;
   uint4* hal = smem4;  // [NP][4][NPIXp]
@@ -365,9 +377,9 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, 2) void k_conv_bfd(
       if (seg) __syncthreads();  // previous round's halo fully consumed
       for (int c2 = cfirst; c2 < cend && !(B.dbg & 1); ++c2) {
         if (P.mask_y)
-          bfd_stage_halo_t<true, NTHR, NP>(B, hal + (c2 - cfirst) * cstride, n, r0, c0, c2 * 32);
+          bfd_stage_halo_t<true, NTHR, NP, SIT>(B, hal + (c2 - cfirst) * cstride, n, r0, c0, c2 * 32);
         else
-          bfd_stage_halo_t<false, NTHR, NP>(B, hal + (c2 - cfirst) * cstride, n, r0, c0, c2 * 32);
+          bfd_stage_halo_t<false, NTHR, NP, SIT>(B, hal + (c2 - cfirst) * cstride, n, r0, c0, c2 * 32);
       }
       __syncthreads();
       const int mine = cfirst + kgrp < cend ? (cend - cfirst - kgrp + KS - 1) / KS : 0;  // chunks of this group in the round
@@ -375,7 +387,7 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, 2) void k_conv_bfd(
       cbase = kgrp * cstride;
       coff = cbase;
       int it = 0;
-      if (NTW * NP <= 6) {
+      if (BFD_ROT && NTW * NP <= 6) {
         // rotate through the PF+1 register sets instead of shifting them: after PF+1 taps the roles are back
         // where they started (wider tiles spill when unrolled like this and take the shifting loop below)
         for (; it + PF + 1 <= seg_len; it += PF + 1) {
