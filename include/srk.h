@@ -282,6 +282,24 @@ int srk_bn_backward_stats_grads(const float* dy, const float* x, const float* me
 int srk_bn_backward_apply(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                           const double* dstats, double count, float* dx, size_t rows, int C, void* stream);
 int srk_bn_param_grads(const double* dstats, float* dgamma, float* dbeta, int C, void* stream);
+/* BatchNorm with the activation that follows it in the reference's blocks, and the residual add of the BatchNorm
+ * ResnetBlock, folded in: act(bn(.)) of ConvBlock / DeconvBlock / PSBlock / DenseBlock (base_networks.py:58-71) and
+ * bn(conv2(.)) + x (base_networks.py:141-150).
+ *   srk_bn_apply_act:   y = act(gamma * (x - mean) * rstd + beta) [+ residual]   act: NONE / RELU / LRELU / PRELU
+ *   srk_bn_backward_stats_grads_act:  dz = dy * act'(z) with z RECOMPUTED from x (nothing of the activation is saved);
+ *       dstats = (sum dz, sum dz * xhat), dbeta += / dgamma += those, dprelu += sum_{z <= 0} dy * z (PRELU; NULL ok)
+ *   srk_bn_backward_apply_act:        dx = gamma * rstd * (dz - dstats[c]/count - xhat * dstats[C+c]/count)
+ * The gradient of `residual` is dy itself.  C must be a multiple of 4, tensors 16-byte aligned.  prelu_n: 1 or C. */
+int srk_bn_apply_act(const float* x, float* y, const float* mean, const float* rstd, const float* gamma,
+                     const float* beta, size_t rows, int C, int act, float slope, const float* prelu_weight, int prelu_n,
+                     const float* residual, void* stream);
+int srk_bn_backward_stats_grads_act(const float* dy, const float* x, const float* mean, const float* rstd,
+                                    const float* gamma, const float* beta, double* dstats, size_t rows, int C,
+                                    float* dgamma, float* dbeta, int act, float slope, const float* prelu_weight,
+                                    int prelu_n, float* dprelu, void* workspace, void* stream);
+int srk_bn_backward_apply_act(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                              const float* beta, const double* dstats, double count, float* dx, size_t rows, int C,
+                              int act, float slope, const float* prelu_weight, int prelu_n, void* stream);
 
 /* ---- Linear (DenseBlock: base_networks.py:7; srgan.py:66-70) -------------------------------- */
 /* y[B,Out] = act(x[B,In] @ w[Out,In]^T + b) */

@@ -44,6 +44,10 @@ class _Block(torch.nn.Module):
     def _post(self, out, fused_act):
         """norm -> activation after the main op (reference order: act(bn(op(x))))."""
         if self.norm is not None:
+            kind, slope, pw = self._act_args()
+            if (not fused_act and kind != ACT_NONE and isinstance(self.bn, BatchNorm2d)
+                    and ops.bn_fusable(out, kind, pw)):
+                return self.bn.run(out, kind, slope, pw)   # act(bn(x)) in the BatchNorm's launches
             out = self.bn(out)
         if self.activation is not None and not fused_act:
             out = self.act(out)
@@ -150,6 +154,10 @@ class ResnetBlock(_Block):
             x, residual = ops.fork(x)  # gradient fan-in summed by srk_axpby
         else:
             residual = x
+        if isinstance(self.bn, BatchNorm2d) and ops.bn_fusable(x, kind, pw):
+            # act(bn(conv1)) and bn(conv2) + x each in the BatchNorm's own launches (ONE shared bn: base_networks.py:117)
+            out = self.bn.run(self.conv1.run(x), kind, slope, pw)
+            return self.bn.run(self.conv2.run(out), residual=residual)
         out = self.bn(self.conv1.run(x))
         if self.activation is not None:
             out = self.act(out)

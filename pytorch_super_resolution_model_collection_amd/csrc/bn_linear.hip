@@ -274,6 +274,189 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply4(const float* __restrict__
   }
 }
 
+// ---- BatchNorm with the activation that follows it (and a residual add) folded in ------------------------------
+// The reference's blocks run act(bn(conv(x))) (base_networks.py:58-71) and, in the BN ResnetBlock, bn(conv2(.)) + x
+// (base_networks.py:141-150): the activation / add were passes of their own over the tensor (forward + backward, 190
+// launches per SRGAN step).  z = gamma * xhat + beta is recomputed from x in the backward kernels, so no activation
+// input / output is saved at all.
+struct BnAct {
+  const float* gamma;
+  const float* beta;
+  const float* prelu_w;  // SRK_ACT_PRELU: device slope(s)
+  int act;               // SRK_ACT_RELU / LRELU / PRELU (backward: NONE = plain)
+  int prelu_n;           // 1 or C
+  float slope;           // SRK_ACT_LRELU
+};
+
+// z = gamma * xhat + beta, evaluated the SAME way (one subtraction, one product, one fused multiply-add) in the forward
+// and in both backward kernels, so that they agree bit for bit on the sign of every z
+__device__ __forceinline__ float bn_z(float x, float mu, float rs, float g, float b) {
+  return __builtin_fmaf((x - mu) * rs, g, b);
+}
+
+__device__ __forceinline__ float bn_act_slope(const BnAct& A, int c) {
+  if (A.act == SRK_ACT_RELU) return 0.f;
+  if (A.act == SRK_ACT_PRELU) return A.prelu_n > 1 ? A.prelu_w[c] : A.prelu_w[0];
+  return A.slope;
+}
+
+// y = act(gamma * (x - mean) * rstd + beta) [+ residual], one float4 per thread and pass
+__global__ __launch_bounds__(256) void k_bn_apply_act4(const float* __restrict__ x, float* __restrict__ y,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       BnAct A, const float* __restrict__ residual, size_t total4, int C) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+    const int c = (int)((i * 4) % (size_t)C);
+    const bn_f4 xv = *reinterpret_cast<const bn_f4*>(x + i * 4);
+    const bn_f4 mu = *reinterpret_cast<const bn_f4*>(mean + c), rs = *reinterpret_cast<const bn_f4*>(rstd + c);
+    bn_f4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f}, v;
+    if (A.gamma) g = *reinterpret_cast<const bn_f4*>(A.gamma + c);
+    if (A.beta) b = *reinterpret_cast<const bn_f4*>(A.beta + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float z = bn_z(xv[e], mu[e], rs[e], g[e], b[e]);
+      v[e] = (A.act == SRK_ACT_NONE || z > 0.f) ? z : bn_act_slope(A, c + e) * z;
+    }
+    if (residual) v += *reinterpret_cast<const bn_f4*>(residual + i * 4);
+    *reinterpret_cast<bn_f4*>(y + i * 4) = v;
+  }
+}
+
+// backward statistics with dz = dy * act'(z):  partial[split][3][C] = sum dz, sum dz * xhat, sum_{z <= 0} dy * z (PReLU)
+__global__ __launch_bounds__(256) void k_bn_colsum_act(const float* __restrict__ dy, const float* __restrict__ x,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       BnAct A, double* __restrict__ partial, size_t rows, int C,
+                                                       size_t rows_per_split) {
+  __shared__ double sm[3][4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  size_t r0 = (size_t)blockIdx.y * rows_per_split, r1 = r0 + rows_per_split;
+  if (r1 > rows) r1 = rows;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    const float mu = mean[c], rs = rstd[c];
+    const float g = A.gamma ? A.gamma[c] : 1.f, b = A.beta ? A.beta[c] : 0.f;
+    const float a = bn_act_slope(A, c);
+    constexpr int U = 32;
+    for (size_t rb = r0 + w; rb < r1; rb += 4 * U) {
+      float va[U], vx[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t r = rb + 4 * (size_t)u;
+        va[u] = r < r1 ? dy[r * C + c] : 0.f;
+        vx[u] = r < r1 ? x[r * C + c] : mu;
+      }
+      double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        // z in fp32 exactly as the forward kernel evaluated it (same operations, same order): the mask must be the
+        // forward's mask
+        const float z = bn_z(vx[u], mu, rs, g, b);
+        const double xhat = ((double)vx[u] - (double)mu) * (double)rs;
+        const double dz = z > 0.f ? (double)va[u] : (double)va[u] * (double)a;
+        d0 += dz;
+        d1 += dz * xhat;
+        if (A.act == SRK_ACT_PRELU) d2 += z > 0.f ? 0.0 : (double)va[u] * (double)z;
+      }
+      s0 += d0;
+      s1 += d1;
+      s2 += d2;
+    }
+  }
+  sm[0][w][lane] = s0;
+  sm[1][w][lane] = s1;
+  sm[2][w][lane] = s2;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    double* p = partial + (size_t)blockIdx.y * 3 * C;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) p[q * C + c] = sm[q][0][lane] + sm[q][1][lane] + sm[q][2][lane] + sm[q][3][lane];
+  }
+}
+
+// reduce of the above + dbeta += sum dz, dgamma += sum dz * xhat, dprelu += sum_{z<=0} dy * z; stats[2C] as usual
+__global__ __launch_bounds__(256) void k_bn_reduce_act(const double* __restrict__ partial, double* __restrict__ stats,
+                                                       int nsplit, int C, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta, float* __restrict__ dprelu, int prelu_n) {
+  __shared__ double sm[3][4][64];
+  __shared__ float psum[64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  double a[3] = {0.0, 0.0, 0.0};
+  if (c < C) {
+    constexpr int U = 8;
+    for (int kb = w; kb < nsplit; kb += 4 * U) {
+      double v[U][3];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = kb + 4 * u;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v[u][q] = k < nsplit ? partial[(size_t)k * 3 * C + q * C + c] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a[q] += v[u][q];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) sm[q][w][lane] = a[q];
+  __syncthreads();
+  if (w != 0) return;
+  double s[3] = {0.0, 0.0, 0.0};
+  if (c < C) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) s[q] = (sm[q][0][lane] + sm[q][1][lane]) + (sm[q][2][lane] + sm[q][3][lane]);
+    stats[c] = s[0];
+    stats[C + c] = s[1];
+    if (dbeta) dbeta[c] += (float)s[0];
+    if (dgamma) dgamma[c] += (float)s[1];
+    if (dprelu && prelu_n > 1) dprelu[c] += (float)s[2];
+  }
+  if (dprelu && prelu_n == 1) {  // one slope: the block's 64 channels summed in lane order, one atomic per block
+    psum[lane] = c < C ? (float)s[2] : 0.f;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      double t = 0.0;
+      for (int q = 0; q < 64; ++q) t += (double)psum[q];
+      atomicAdd(dprelu, (float)t);
+    }
+  }
+}
+
+template <bool DBL>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_act4(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           BnAct A, const double* __restrict__ dstats, double count,
+                                                           float* __restrict__ dx, size_t total4, int C) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+    const int c = (int)((i * 4) % (size_t)C);
+    const bn_f4 dv = *reinterpret_cast<const bn_f4*>(dy + i * 4), xv = *reinterpret_cast<const bn_f4*>(x + i * 4);
+    const bn_f4 mu = *reinterpret_cast<const bn_f4*>(mean + c), rs = *reinterpret_cast<const bn_f4*>(rstd + c);
+    bn_f4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
+    if (A.gamma) g = *reinterpret_cast<const bn_f4*>(A.gamma + c);
+    if (A.beta) b = *reinterpret_cast<const bn_f4*>(A.beta + c);
+    bn_f4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float z = bn_z(xv[e], mu[e], rs[e], g[e], b[e]);
+      const float dz = (A.act == SRK_ACT_NONE || z > 0.f) ? dv[e] : dv[e] * bn_act_slope(A, c + e);
+      if (DBL) {
+        const double xhat = ((double)xv[e] - (double)mu[e]) * (double)rs[e];
+        const double m1 = dstats[c + e] / count;
+        const double m2 = dstats[C + c + e] / count;
+        o[e] = (float)((double)g[e] * (double)rs[e] * ((double)dz - m1 - xhat * m2));
+      } else {
+        const float xhat = (xv[e] - mu[e]) * rs[e];
+        const float m1 = (float)(dstats[c + e] / count);
+        const float m2 = (float)(dstats[C + c + e] / count);
+        o[e] = g[e] * rs[e] * (dz - m1 - xhat * m2);
+      }
+    }
+    *reinterpret_cast<bn_f4*>(dx + i * 4) = o;
+  }
+}
+
 static bool bn_vec4(int C, const void* a, const void* b, const void* c, const void* d, const void* e, const void* f) {
   if (C & 3) return false;
   return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e | (uintptr_t)f) & 15) == 0;
@@ -689,6 +872,73 @@ extern "C" int srk_bn_backward_apply(const float* dy, const float* x, const floa
                        gamma, dstats, count, dx, total, C);
   }
   return check_launch("bn_backward_apply");
+}
+
+static int bn_act_check(int act, const float* prelu_w, int prelu_n, int C, const char* who) {
+  SRK_REQUIRE(act == SRK_ACT_NONE || act == SRK_ACT_RELU || act == SRK_ACT_LRELU || act == SRK_ACT_PRELU,
+              "%s: only ReLU / LeakyReLU / PReLU fold into BatchNorm", who);
+  if (act == SRK_ACT_PRELU) SRK_REQUIRE(prelu_w && (prelu_n == 1 || prelu_n == C), "%s: PReLU needs 1 or C slopes", who);
+  return SRK_OK;
+}
+
+extern "C" int srk_bn_apply_act(const float* x, float* y, const float* mean, const float* rstd, const float* gamma,
+                                const float* beta, size_t rows, int C, int act, float slope, const float* prelu_weight,
+                                int prelu_n, const float* residual, void* stream) {
+  SRK_REQUIRE(x && y && mean && rstd && rows > 0 && C > 0, "bn_apply_act: bad args");
+  int rc = bn_act_check(act, prelu_weight, prelu_n, C, "bn_apply_act");
+  if (rc) return rc;
+  SRK_REQUIRE(bn_vec4(C, x, y, mean, rstd, gamma, beta) && ((uintptr_t)residual & 15) == 0,
+              "bn_apply_act: C must be a multiple of 4 and the tensors 16-byte aligned");
+  const size_t total = rows * (size_t)C;
+  size_t nb = (total + 256 * 4 - 1) / (256 * 4);
+  if (nb > 4096) nb = 4096;
+  BnAct A{gamma, beta, prelu_weight, act, prelu_n, slope};
+  hipLaunchKernelGGL(k_bn_apply_act4, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, y, mean, rstd, A, residual,
+                     total / 4, C);
+  return check_launch("bn_apply_act");
+}
+
+extern "C" int srk_bn_backward_stats_grads_act(const float* dy, const float* x, const float* mean, const float* rstd,
+                                               const float* gamma, const float* beta, double* dstats, size_t rows, int C,
+                                               float* dgamma, float* dbeta, int act, float slope,
+                                               const float* prelu_weight, int prelu_n, float* dprelu, void* workspace,
+                                               void* stream) {
+  SRK_REQUIRE(dy && x && mean && rstd && dstats && workspace && rows > 0 && C > 0, "bn_backward_stats_grads_act: bad args");
+  int rc = bn_act_check(act, prelu_weight, prelu_n, C, "bn_backward_stats_grads_act");
+  if (rc) return rc;
+  int splits = (int)((rows + 127) / 128);
+  if (splits > kBnRowSplits * 2 / 3) splits = kBnRowSplits * 2 / 3;  // three sums per split in the same workspace
+  if (splits < 1) splits = 1;
+  const size_t rps = (rows + splits - 1) / splits;
+  hipStream_t s = (hipStream_t)stream;
+  BnAct A{gamma, beta, prelu_weight, act, prelu_n, slope};
+  hipLaunchKernelGGL(k_bn_colsum_act, dim3(cdiv(C, 64), splits), dim3(256), 0, s, dy, x, mean, rstd, A, (double*)workspace,
+                     rows, C, rps);
+  hipLaunchKernelGGL(k_bn_reduce_act, dim3(cdiv(C, 64)), dim3(256), 0, s, (const double*)workspace, dstats, splits, C,
+                     dgamma, dbeta, act == SRK_ACT_PRELU ? dprelu : nullptr, prelu_n);
+  return check_launch("bn_backward_stats_grads_act");
+}
+
+extern "C" int srk_bn_backward_apply_act(const float* dy, const float* x, const float* mean, const float* rstd,
+                                         const float* gamma, const float* beta, const double* dstats, double count,
+                                         float* dx, size_t rows, int C, int act, float slope, const float* prelu_weight,
+                                         int prelu_n, void* stream) {
+  SRK_REQUIRE(dy && x && mean && rstd && dstats && dx && rows > 0 && C > 0 && count > 0, "bn_backward_apply_act: bad args");
+  int rc = bn_act_check(act, prelu_weight, prelu_n, C, "bn_backward_apply_act");
+  if (rc) return rc;
+  SRK_REQUIRE(bn_vec4(C, dy, x, mean, rstd, gamma, dx) && ((uintptr_t)beta & 15) == 0,
+              "bn_backward_apply_act: C must be a multiple of 4 and the tensors 16-byte aligned");
+  const size_t total = rows * (size_t)C;
+  size_t nb = (total + 256 * 4 - 1) / (256 * 4);
+  if (nb > 4096) nb = 4096;
+  BnAct A{gamma, beta, prelu_weight, act, prelu_n, slope};
+  if (bn_fp32_backward())
+    hipLaunchKernelGGL(k_bn_bwd_apply_act4<false>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, A,
+                       dstats, count, dx, total / 4, C);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_apply_act4<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, A,
+                       dstats, count, dx, total / 4, C);
+  return check_launch("bn_backward_apply_act");
 }
 
 extern "C" int srk_bn_param_grads(const double* dstats, float* dgamma, float* dbeta, int C, void* stream) {

@@ -809,11 +809,18 @@ def bce_loss(pred, target):
 # ------------------------------------------------------------------------------------------------
 # BatchNorm2d / Linear (SRGAN)
 # ------------------------------------------------------------------------------------------------
+BN_FUSE_ACT = os.environ.get("SRK_BN_FUSE_ACT", "1") != "0"   # 0: activations / residual adds after a BatchNorm stay passes of their own
+
+
 class _BatchNorm(torch.autograd.Function):
+    """y = act(bn(x)) [+ residual].  act in {none, relu, lrelu, prelu} and the residual ride in the BatchNorm kernels
+    (srk_bn_*_act): the backward recomputes z = gamma * xhat + beta from x, so nothing of the activation is saved."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, sync_group, nbt=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, sync_group, nbt=None,
+                act=ACT_NONE, slope=0.0, prelu_w=None, residual=None):
         lib = _lib.load()
-        require_cuda(x, gamma, beta)
+        require_cuda(x, gamma, beta, prelu_w, residual)
         x = _dense(x)   # [N,C,H,W] stored NHWC, or [B,F] (BatchNorm1d of DenseBlock, base_networks.py:13): rows x C
         c = x.shape[1]
         rows = x.numel() // c
@@ -841,17 +848,28 @@ class _BatchNorm(torch.autograd.Function):
             check(lib.srk_bn_eval_params(ptr(running_mean), ptr(running_var), eps, ptr(mean), ptr(rstd), c,
                                          stream_ptr()), "srk_bn_eval_params")
         y = torch.empty_like(x)
-        check(lib.srk_bn_apply(ptr(x), ptr(y), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), rows, c, ACT_NONE, 0.0,
-                               stream_ptr()), "srk_bn_apply")
+        fused = act != ACT_NONE or residual is not None
+        if fused:
+            if residual is not None:
+                residual = _dense(residual)
+                if tuple(residual.shape) != tuple(x.shape) or residual.stride() != x.stride():
+                    raise RuntimeError("batch_norm: residual must have the shape and layout of x")
+            check(lib.srk_bn_apply_act(ptr(x), ptr(y), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), rows, c, act, slope,
+                                       ptr(prelu_w), 0 if prelu_w is None else prelu_w.numel(), ptr(residual),
+                                       stream_ptr()), "srk_bn_apply_act")
+        else:
+            check(lib.srk_bn_apply(ptr(x), ptr(y), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), rows, c, ACT_NONE, 0.0,
+                                   stream_ptr()), "srk_bn_apply")
         ctx.training, ctx.count, ctx.sync_group = training, count, sync_group
-        ctx.gamma_ref, ctx.beta_ref = gamma, beta
-        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.gamma_ref, ctx.beta_ref, ctx.prelu_ref = gamma, beta, prelu_w
+        ctx.act, ctx.slope, ctx.has_res = act, slope, residual is not None
+        ctx.save_for_backward(x, gamma, mean, rstd, beta if act != ACT_NONE else None, prelu_w)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, gamma, mean, rstd = ctx.saved_tensors
+        x, gamma, mean, rstd, beta, prelu_w = ctx.saved_tensors
         dy = _dense(dy)
         c = x.shape[1]
         rows = x.numel() // c
@@ -859,10 +877,31 @@ class _BatchNorm(torch.autograd.Function):
         ws = torch.empty(int(lib.srk_bn_workspace_bytes(c)), dtype=torch.uint8, device=x.device)
         dgamma = getattr(ctx.gamma_ref, "_srk_grad", None)
         dbeta = getattr(ctx.beta_ref, "_srk_grad", None)
-        ret_g = ret_b = None
+        ret_g = ret_b = ret_p = None
         if dgamma is None or dbeta is None:
             dgamma = ret_g = torch.zeros(c, dtype=torch.float32, device=x.device)
             dbeta = ret_b = torch.zeros(c, dtype=torch.float32, device=x.device)
+        dres = dy if ctx.has_res else None   # the residual's gradient is dy itself
+        if ctx.act != ACT_NONE:
+            dprelu = None
+            pn = 0 if prelu_w is None else prelu_w.numel()
+            if ctx.act == ACT_PRELU:
+                dprelu = getattr(ctx.prelu_ref, "_srk_grad", None)
+                if dprelu is None:
+                    dprelu = ret_p = torch.zeros_like(prelu_w)
+            check(lib.srk_bn_backward_stats_grads_act(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+                                                      ptr(dstats), rows, c, ptr(dgamma), ptr(dbeta), ctx.act, ctx.slope,
+                                                      ptr(prelu_w), pn, ptr(dprelu), ptr(ws), stream_ptr()),
+                  "srk_bn_backward_stats_grads_act")
+            if ctx.training and ctx.sync_group is not None:
+                import torch.distributed as dist
+                dist.all_reduce(dstats, group=ctx.sync_group)
+            dx = torch.empty_like(dy)
+            use = dstats if ctx.training else torch.zeros_like(dstats)
+            check(lib.srk_bn_backward_apply_act(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(use),
+                                                ctx.count, ptr(dx), rows, c, ctx.act, ctx.slope, ptr(prelu_w), pn,
+                                                stream_ptr()), "srk_bn_backward_apply_act")
+            return dx, ret_g, ret_b, None, None, None, None, None, None, None, None, None, ret_p, dres
         # statistics of the backward + the parameter gradients (from the LOCAL sums: the DP gradient all-reduce happens
         # later) in two launches
         check(lib.srk_bn_backward_stats_grads(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(dstats), rows, c, ptr(dgamma),
@@ -875,14 +914,23 @@ class _BatchNorm(torch.autograd.Function):
         use = dstats if ctx.training else torch.zeros_like(dstats)
         check(lib.srk_bn_backward_apply(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(use), ctx.count,
                                         ptr(dx), rows, c, stream_ptr()), "srk_bn_backward_apply")
-        return dx, ret_g, ret_b, None, None, None, None, None, None, None
+        return dx, ret_g, ret_b, None, None, None, None, None, None, None, None, None, None, dres
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, sync_group=None,
-               num_batches_tracked=None):
-    """nn.BatchNorm2d (base_networks.py:46,117,161) on [N,C,H,W]; nn.BatchNorm1d (base_networks.py:13) on [B,F]."""
+               num_batches_tracked=None, act=ACT_NONE, slope=0.0, prelu_w=None, residual=None):
+    """nn.BatchNorm2d (base_networks.py:46,117,161) on [N,C,H,W]; nn.BatchNorm1d (base_networks.py:13) on [B,F].
+    act / prelu_w / residual: y = act(bn(x)) [+ residual] in the same launches (see bn_fusable)."""
     return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, bool(training), float(momentum), float(eps),
-                            sync_group, num_batches_tracked)
+                            sync_group, num_batches_tracked, int(act), float(slope), prelu_w, residual)
+
+
+def bn_fusable(x, act, prelu_w=None):
+    """Can `act` (and a residual add) ride in the BatchNorm kernels for this input?  ReLU / LeakyReLU / PReLU with one
+    slope or one per channel, channel count a multiple of 4 (the fused kernels move float4s)."""
+    if not BN_FUSE_ACT or act not in (ACT_NONE, ACT_RELU, ACT_LRELU, ACT_PRELU) or x.dim() < 2 or x.shape[1] % 4:
+        return False
+    return act != ACT_PRELU or (prelu_w is not None and prelu_w.numel() in (1, x.shape[1]))
 
 
 class _InstanceNorm(torch.autograd.Function):

@@ -351,6 +351,73 @@ def test_linear_wide_layers(gpu, shape):
     assert_close_elementwise(w.grad, 2 * first, 1e-6, what="wide linear dw accumulated")
 
 
+@pytest.mark.parametrize("act", ["relu", "lrelu", "prelu1", "preluC", "none+res", "prelu1+res"])
+def test_batchnorm_with_folded_activation_and_residual(gpu, act):
+    """act(bn(x)) [+ residual] in the BatchNorm's own launches (srk_bn_apply_act / _backward_*_act: the backward
+    recomputes z from x) against torch's float64 BatchNorm -> activation -> add on the CPU: output, dx, dgamma, dbeta,
+    dprelu, d(residual); training statistics, running statistics untouched by the fusion."""
+    import torch.nn.functional as F
+    pkg = _pkg()
+    ops = pkg.ops
+    n, c, h, w = 3, 8, 7, 9
+    x = fill.randn((n, c, h, w), 81) * 1.7 + 0.3
+    res = fill.randn((n, c, h, w), 82) if act.endswith("+res") else None
+    dy = fill.randn((n, c, h, w), 83)
+    gamma, beta = fill.rand((c,), 84, 0.5, 1.5), fill.randn((c,), 85) * 0.3
+    kind = act.split("+")[0]
+    pw = None
+    if kind.startswith("prelu"):
+        pw = fill.rand((1 if kind == "prelu1" else c,), 86, 0.1, 0.4)
+    code = {"relu": pkg._lib.ACT_RELU, "lrelu": pkg._lib.ACT_LRELU, "prelu1": pkg._lib.ACT_PRELU,
+            "preluC": pkg._lib.ACT_PRELU, "none": pkg._lib.ACT_NONE}[kind]
+    # float64 reference
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    pr = pw.double().requires_grad_(True) if pw is not None else None
+    rr = res.double().requires_grad_(True) if res is not None else None
+    z = F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    if kind == "relu":
+        yr = F.relu(z)
+    elif kind == "lrelu":
+        yr = F.leaky_relu(z, 0.2)
+    elif pw is not None:
+        yr = F.prelu(z, pr)
+    else:
+        yr = z
+    if rr is not None:
+        yr = yr + rr
+    yr.backward(dy.double())
+    # fused path
+    xg = x.to(gpu).requires_grad_(True)
+    gg, bg = gamma.to(gpu).requires_grad_(True), beta.to(gpu).requires_grad_(True)
+    pg = pw.to(gpu).requires_grad_(True) if pw is not None else None
+    rg = res.to(gpu).requires_grad_(True) if res is not None else None
+    rm, rv = torch.zeros(c, device=gpu), torch.ones(c, device=gpu)
+    assert ops.bn_fusable(xg, code, pg)
+    y = ops.batch_norm(xg, gg, bg, rm, rv, True, 0.1, 1e-5, None, None, code, 0.2, pg, rg)
+    y.backward(dy.to(gpu))
+    assert_close_elementwise(y, yr.detach(), 2e-6, what="fused bn+act forward")
+    assert_close_elementwise(xg.grad, xr.grad, 2e-5, what="dx")
+    assert_close_elementwise(gg.grad, gr.grad, 2e-6, what="dgamma")
+    assert_close_elementwise(bg.grad, br.grad, 2e-6, what="dbeta")
+    if pw is not None:
+        assert_close_elementwise(pg.grad, pr.grad, 2e-6, what="dprelu")
+    if res is not None:
+        assert torch.equal(rg.grad.cpu(), dy)
+    # running statistics as nn.BatchNorm2d updates them (momentum 0.1, unbiased variance)
+    m = x.double().mean((0, 2, 3))
+    v = x.double().var((0, 2, 3), unbiased=True)
+    assert_close_elementwise(rm, 0.1 * m, 2e-6, what="running_mean")
+    assert_close_elementwise(rv, 0.9 + 0.1 * v, 2e-6, what="running_var")
+    # error behaviour: unsupported activations are refused, not mis-computed
+    lib = pkg._lib.load()
+    P = pkg._lib.ptr
+    xs = xg.detach().contiguous(memory_format=torch.channels_last)
+    rc = lib.srk_bn_apply_act(P(xs), P(torch.empty_like(xs)), P(rm), P(rv), None, None, n * h * w, c, pkg._lib.ACT_BY_NAME["tanh"]
+                              if hasattr(pkg._lib, "ACT_BY_NAME") else 4, 0.0, None, 0, None, pkg._lib.stream_ptr())
+    assert rc != 0
+
+
 def test_layout_roundtrip_and_ragged(gpu):
     """NCHW<->NHWC copies at ragged sizes (non multiples of the 32x32 transpose tile)."""
     pkg = _pkg()
