@@ -225,7 +225,7 @@ __device__ __forceinline__ void bfd_epilogue_direct(const MfmaConvParams& P, con
 // chunks -- two waves per SIMD on a block that is pure latency otherwise -- and the partial accumulators meet in LDS
 // before the epilogue.
 template <int NTW, int NPW, int NOW, int NP, int PF, int KS>
-__global__ __launch_bounds__(64 * NPW * NOW * KS, (BFD_OCC3 && NP == 3 && NTW == 2 && NPW * NOW * KS == 4) ? 3 : 2) void k_conv_bfd(
+__global__ __launch_bounds__(64 * NPW * NOW * KS, (BFD_OCC3 && NP == 3 && NTW == 2 && NPW == 2 && NOW == 2 && KS == 1 && PF == 1) ? 3 : 2) void k_conv_bfd(
     BfdParams B) {
   constexpr int NTHR = 64 * NPW * NOW * KS;
   constexpr bool TEPI = NPW == 1;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, (BFD_OCC3 && NP == 3 && NTW ==
   // 3 waves per SIMD (launch bound 168 VGPRs; it took 233 = 2 waves per SIMD): its halo staging keeps 2 pixels per
   // thread in flight instead of 6, which is what the register budget was spent on.  VDSR step 8.30 -> 7.96 ms, EDSR
   // 6.66 -> 6.62 ms (BFD_OCC3=0 restores the old build)
-  constexpr bool OCC3 = BFD_OCC3 && NP == 3 && NTW == 2 && NPW * NOW * KS == 4;
+  constexpr bool OCC3 = BFD_OCC3 && NP == 3 && NTW == 2 && NPW == 2 && NOW == 2 && KS == 1 && PF == 1;  // exactly <2,2,2,3,1,1>
   constexpr int SIT = OCC3 ? 2 : BFD_STAGE_IT;
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   const MfmaConvParams& P = B.P;
