@@ -47,6 +47,17 @@ def calculate_valid_crop_size(crop_size, scale_factor):
     return crop_size - (crop_size % scale_factor)
 
 
+class _Null(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL = _Null()
+
+
 def _stream_ptr(stream):
     return ctypes.c_void_p(stream.cuda_stream)
 
@@ -61,48 +72,106 @@ class _Device(object):
                                % (device,))
         self.lib = _lib.load()
         self.stream = torch.cuda.Stream(device=self.device)
+        self._sp = _stream_ptr(self.stream)
+        self._ws_bytes = {}
+        self._slab_buf, self._slab_off, self._depth = None, 0, 0
+
+    # Every helper below runs on the loader stream.  PatchLoader enters the stream ONCE per batch (`batch()`); a
+    # torch.cuda.stream context per call costs ~10 us of host time, three times per patch.
+    def _on_stream(self):
+        return _NULL if self._depth else torch.cuda.stream(self.stream)
+
+    def batch(self):
+        """Context of one batch: the loader stream is current, workspaces come from the start of the slab again."""
+        dev = self
+
+        class _Ctx(object):
+            def __enter__(self_):
+                self_.cm = torch.cuda.stream(dev.stream)
+                self_.cm.__enter__()
+                dev._depth += 1
+                dev._slab_off = 0
+
+            def __exit__(self_, *a):
+                dev._depth -= 1
+                return self_.cm.__exit__(*a)
+
+        return _Ctx()
+
+    def _slab(self, nbytes):
+        nbytes = (nbytes + 255) & ~255
+        if self._slab_buf is None or self._slab_off + nbytes > self._slab_buf.numel():
+            # (out of room in the middle of a batch: a fresh slab; the old one is released to the loader stream's pool,
+            #  whose reuse is ordered behind the kernels still reading it)
+            self._slab_buf = torch.empty(max(64 << 20, 4 * nbytes), dtype=torch.uint8, device=self.device)
+            self._slab_off = 0
+        v = self._slab_buf[self._slab_off:self._slab_off + nbytes]
+        self._slab_off += nbytes
+        if not self._depth:
+            self._slab_off = 0   # outside a batch context every call may reuse the slab (stream order protects it)
+        return v
+
+    # Pinned staging buffers are a ring allocated once and reused (pinning a fresh buffer per image is a driver call
+    # of several milliseconds that also serialises against the device: 163 patches/s with it, see tools/loader_bench.py)
+    RING = 64
 
     def upload(self, hwc):
         """HWC uint8 numpy -> device uint8 tensor through pinned memory, async on the loader stream."""
-        pinned = torch.from_numpy(np.ascontiguousarray(hwc)).pin_memory()
-        with torch.cuda.stream(self.stream):
-            d = torch.empty(pinned.shape, dtype=torch.uint8, device=self.device)
+        if not hasattr(self, "_ring"):
+            self._ring, self._ring_ev, self._ring_k = [None] * self.RING, [None] * self.RING, 0
+        i = self._ring_k
+        self._ring_k = (i + 1) % self.RING
+        n = int(hwc.size)
+        if self._ring_ev[i] is not None:
+            self._ring_ev[i].synchronize()   # the copy that last used this slot (RING uploads ago) is done
+        if self._ring[i] is None or self._ring[i].numel() < n:
+            self._ring[i] = torch.empty(max(n, 1 << 20), dtype=torch.uint8).pin_memory()
+        pinned = self._ring[i][:n].view(hwc.shape)
+        np.copyto(pinned.numpy(), hwc)
+        with self._on_stream():
+            d = torch.empty(hwc.shape, dtype=torch.uint8, device=self.device)
             d.copy_(pinned, non_blocking=True)
-        d._srk_pinned = pinned   # keep the staging buffer alive until the copy has been consumed
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._ring_ev[i] = ev
         return d
 
     def resize(self, x, strides, planes, h, w, oh, ow, out_float):
         """Image.resize((ow, oh), BICUBIC) of `planes` 8-bit planes addressed by element strides (plane, row, pixel)."""
         lib = self.lib
-        with torch.cuda.stream(self.stream):
+        with self._on_stream():
             y = torch.empty((planes, oh, ow), dtype=torch.float32 if out_float else torch.uint8, device=self.device)
-            nbytes = int(lib.srk_img_resize_u8_workspace_bytes(planes, h, w, oh, ow, BICUBIC))
-            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+            key = (planes, h, w, oh, ow)
+            nbytes = self._ws_bytes.get(key)
+            if nbytes is None:
+                nbytes = self._ws_bytes[key] = max(int(lib.srk_img_resize_u8_workspace_bytes(planes, h, w, oh, ow, BICUBIC)), 256)
+            # one workspace per call (the calls of a batch are in flight together on the loader stream), drawn from a
+            # slab that is re-used batch after batch
+            ws = self._slab(nbytes)
             check(lib.srk_img_resize_u8(ptr(x), strides[0], strides[1], strides[2], ptr(y), int(out_float), planes, h, w,
-                                        oh, ow, BICUBIC, ptr(ws), ws.numel(), _stream_ptr(self.stream)), "srk_img_resize_u8")
+                                        oh, ow, BICUBIC, ptr(ws), nbytes, self._sp), "srk_img_resize_u8")
         return y
 
     def augment(self, x, strides, c, h, w, crop, rot, fliplr, fliptb, out=None):
         """crop (x0, y0, cw, ch) -> rot x 90 deg ccw -> flips; planar uint8 [c, oh, ow]."""
         x0, y0, cw, ch = crop
         oh, ow = (cw, ch) if rot & 1 else (ch, cw)
-        with torch.cuda.stream(self.stream):
+        with self._on_stream():
             y = out if out is not None else torch.empty((c, oh, ow), dtype=torch.uint8, device=self.device)
             check(self.lib.srk_patch_augment_u8(ptr(x), strides[0], strides[1], strides[2], ptr(y), c, h, w, x0, y0, cw, ch,
-                                                rot, int(fliplr), int(fliptb), _stream_ptr(self.stream)),
-                  "srk_patch_augment_u8")
+                                                rot, int(fliplr), int(fliptb), self._sp), "srk_patch_augment_u8")
         return y
 
     def bicubic_of_lr(self, lr, oh, ow):
         """ToPILImage -> Scale -> ToTensor on the float LR batch (dataset.py:98-99) = utils.img_interp's kernel."""
         lib = self.lib
         n, c, h, w = lr.shape
-        with torch.cuda.stream(self.stream):
+        with self._on_stream():
             y = torch.empty((n, c, oh, ow), dtype=torch.float32, device=self.device)
             nbytes = int(lib.srk_img_interp_workspace_bytes(n, c, h, w, oh, ow, BICUBIC))
             ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
             check(lib.srk_img_interp(ptr(lr), ptr(y), n, c, h, w, oh, ow, BICUBIC, ptr(ws), ws.numel(),
-                                     _stream_ptr(self.stream)), "srk_img_interp")
+                                     self._sp), "srk_img_interp")
         return y
 
     def hand_over(self, *tensors):
@@ -298,17 +367,23 @@ class PatchLoader(object):
     def __iter__(self):
         ds = self.ds
         batches = list(self._batches())
-        pending = self._decode(batches[0]) if batches else None
+        # decode ahead: enough batches in flight to keep every decode thread busy while the current batch is uploaded
+        # and transformed (one batch ahead leaves 32 threads half idle at batch 16: 2.6 k -> patches/s decode-bound)
+        depth = max(1, -(-self.pool._max_workers // max(1, self.batch_size))) + 1
+        from collections import deque
+        pending = deque(self._decode(b) for b in batches[:depth])
         for k, idx in enumerate(batches):
-            images = [f.result() for f in pending]
-            pending = self._decode(batches[k + 1]) if k + 1 < len(batches) else None   # overlaps with the work below
+            images = [f.result() for f in pending.popleft()]
+            if k + depth < len(batches):
+                pending.append(self._decode(batches[k + depth]))   # overlaps with the work below
             if isinstance(ds, TrainDatasetFromFolder):
                 crop = calculate_valid_crop_size(ds.crop_size, ds.scale_factor)
-                with torch.cuda.stream(ds.dev.stream):
+                with ds.dev.batch():
                     patches = torch.empty((len(idx), 3, crop, crop), dtype=torch.uint8, device=ds.dev.device)
-                for j, hwc in enumerate(images):
-                    ds.patch_u8(hwc, ds.draw(hwc.shape[1], hwc.shape[0]), out=patches[j])
-                yield ds.dev.hand_over(*ds.finish(patches))
+                    for j, hwc in enumerate(images):
+                        ds.patch_u8(hwc, ds.draw(hwc.shape[1], hwc.shape[0]), out=patches[j])
+                    out = ds.finish(patches)
+                yield ds.dev.hand_over(*out)
             else:   # test images differ in size: one item per batch entry, stacked only when they agree
                 items = [ds[i] for i in idx]
                 yield tuple(torch.stack(t) if len(set(x.shape for x in t)) == 1 else list(t) for t in zip(*items))
