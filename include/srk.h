@@ -331,6 +331,13 @@ int srk_img_resize_u8(const uint8_t* x, int64_t plane_stride, int64_t row_stride
 int srk_patch_augment_u8(const uint8_t* x, int64_t plane_stride, int64_t row_stride, int64_t px_stride, uint8_t* y, int C,
                          int H, int W, int crop_x, int crop_y, int crop_w, int crop_h, int rot_k, int fliplr, int fliptb,
                          void* stream);
+/* The two calls above folded into one per training patch (dataset.py:51-82): img_hwc is the decoded interleaved 8-bit
+ * image [H][W][C]; scale_h / scale_w > 0 rescale the whole image first (Image.resize, BICUBIC), 0 = no rescale; then
+ * crop -> rot_k quarter turns ccw -> flips into the planar patch out_planar [C][oh][ow]. */
+size_t srk_patch_from_image_u8_workspace_bytes(int C, int H, int W, int scale_h, int scale_w);
+int srk_patch_from_image_u8(const uint8_t* img_hwc, int C, int H, int W, int scale_h, int scale_w, int crop_x, int crop_y,
+                            int crop_w, int crop_h, int rot_k, int fliplr, int fliptb, uint8_t* out_planar,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- steps either side of the nets ------------------------------------------------
  * utils.PSNR (utils.py:208-216): mse = mean((clamp(pred,0,1) - gt)^2) over all elements, *psnr_out = mse == 0 ? 100 :

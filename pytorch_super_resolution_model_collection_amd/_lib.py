@@ -108,6 +108,9 @@ _PROTOTYPES = {
                                   c_int, c_int, c_int, c_vp, c_size, c_vp]),
     "srk_patch_augment_u8": (c_int, [c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_vp, c_int, c_int, c_int,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "srk_patch_from_image_u8_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
+    "srk_patch_from_image_u8": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        c_int, c_vp, c_vp, c_size, c_vp]),
     "srk_psnr_workspace_bytes": (c_size, []),
     "srk_psnr": (c_int, [c_f, ctypes.POINTER(ctypes.c_int64), c_f, ctypes.POINTER(ctypes.c_int64), c_int, c_int, c_int,
                          c_int, c_f, c_f, c_vp, c_vp]),

@@ -369,3 +369,30 @@ extern "C" int srk_patch_augment_u8(const uint8_t* x, int64_t plane_stride, int6
                      fliptb ? 1 : 0);
   return check_launch("patch_augment_u8");
 }
+
+// One call per patch for the training loader (dataset.py:51-82): optional whole-image rescale (Image.resize, BICUBIC)
+// and the crop / quarter-turn / flips, from the interleaved 8-bit image straight into the batch's planar 8-bit patch.
+// The host side of the loader is bound by Python calls per patch; this is three of them folded into one.
+extern "C" size_t srk_patch_from_image_u8_workspace_bytes(int C, int H, int W, int scale_h, int scale_w) {
+  if (C <= 0 || H <= 0 || W <= 0 || scale_h <= 0 || scale_w <= 0) return 256;
+  return align256((size_t)C * scale_h * scale_w) + srk_img_resize_u8_workspace_bytes(C, H, W, scale_h, scale_w, SRK_INTERP_BICUBIC);
+}
+
+extern "C" int srk_patch_from_image_u8(const uint8_t* img_hwc, int C, int H, int W, int scale_h, int scale_w, int crop_x,
+                                       int crop_y, int crop_w, int crop_h, int rot_k, int fliplr, int fliptb,
+                                       uint8_t* out_planar, void* workspace, size_t workspace_bytes, void* stream) {
+  SRK_REQUIRE(img_hwc && out_planar, "patch_from_image_u8: null pointer");
+  SRK_REQUIRE(C > 0 && H > 0 && W > 0, "patch_from_image_u8: non-positive dims");
+  if (scale_h <= 0 || scale_w <= 0)   // no rescale: crop straight from the interleaved image
+    return srk_patch_augment_u8(img_hwc, 1, (int64_t)W * C, C, out_planar, C, H, W, crop_x, crop_y, crop_w, crop_h, rot_k,
+                                fliplr, fliptb, stream);
+  const size_t need = srk_patch_from_image_u8_workspace_bytes(C, H, W, scale_h, scale_w);
+  SRK_REQUIRE(workspace && workspace_bytes >= need, "patch_from_image_u8: workspace %zu < %zu", workspace_bytes, need);
+  uint8_t* scaled = static_cast<uint8_t*>(workspace);   // planar [C][scale_h][scale_w]
+  const size_t off = align256((size_t)C * scale_h * scale_w);
+  int rc = srk_img_resize_u8(img_hwc, 1, (int64_t)W * C, C, scaled, 0, C, H, W, scale_h, scale_w, SRK_INTERP_BICUBIC,
+                             static_cast<char*>(workspace) + off, workspace_bytes - off, stream);
+  if (rc) return rc;
+  return srk_patch_augment_u8(scaled, (int64_t)scale_h * scale_w, scale_w, 1, out_planar, C, scale_h, scale_w, crop_x, crop_y,
+                              crop_w, crop_h, rot_k, fliplr, fliptb, stream);
+}

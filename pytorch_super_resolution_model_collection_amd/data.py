@@ -162,6 +162,23 @@ class _Device(object):
                                                 rot, int(fliplr), int(fliptb), self._sp), "srk_patch_augment_u8")
         return y
 
+    def patch(self, img, c, h, w, scale, crop, rot, fliplr, fliptb, out=None):
+        """Decoded interleaved image on the device -> augmented planar 8-bit patch (srk_patch_from_image_u8)."""
+        x0, y0, cw, ch = crop
+        oh, ow = (cw, ch) if rot & 1 else (ch, cw)
+        sh, sw = (scale[1], scale[0]) if scale is not None else (0, 0)
+        lib = self.lib
+        with self._on_stream():
+            y = out if out is not None else torch.empty((c, oh, ow), dtype=torch.uint8, device=self.device)
+            key = ("patch", c, h, w, sh, sw)
+            nbytes = self._ws_bytes.get(key)
+            if nbytes is None:
+                nbytes = self._ws_bytes[key] = int(lib.srk_patch_from_image_u8_workspace_bytes(c, h, w, sh, sw))
+            ws = self._slab(nbytes)
+            check(lib.srk_patch_from_image_u8(ptr(img), c, h, w, sh, sw, x0, y0, cw, ch, rot, int(fliplr), int(fliptb),
+                                              ptr(y), ptr(ws), nbytes, self._sp), "srk_patch_from_image_u8")
+        return y
+
     def bicubic_of_lr(self, lr, oh, ow):
         """ToPILImage -> Scale -> ToTensor on the float LR batch (dataset.py:98-99) = utils.img_interp's kernel."""
         lib = self.lib
@@ -241,6 +258,8 @@ class TrainDatasetFromFolder(object):
         scale, (x0, y0), rot, fl, ft = params
         h, w, c = hwc.shape
         img = dev.upload(hwc)
+        if not self.is_gray:   # rescale + crop / rotation / flips in ONE call, straight into the batch buffer
+            return dev.patch(img, c, h, w, scale, (x0, y0, crop, crop), rot, fl, ft, out)
         strides = _HWC(h, w, c)
         if scale is not None:
             img = dev.resize(img, strides, c, h, w, scale[1], scale[0], out_float=False)
