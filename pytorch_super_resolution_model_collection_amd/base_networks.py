@@ -46,7 +46,7 @@ class _Block(torch.nn.Module):
         if self.norm is not None:
             kind, slope, pw = self._act_args()
             if (not fused_act and kind != ACT_NONE and isinstance(self.bn, BatchNorm2d)
-                    and ops.bn_fusable(out, kind, pw)):
+                    and ops.bn_fusable(out, kind, pw, self.bn)):
                 return self.bn.run(out, kind, slope, pw)   # act(bn(x)) in the BatchNorm's launches
             out = self.bn(out)
         if self.activation is not None and not fused_act:
@@ -154,7 +154,7 @@ class ResnetBlock(_Block):
             x, residual = ops.fork(x)  # gradient fan-in summed by srk_axpby
         else:
             residual = x
-        if isinstance(self.bn, BatchNorm2d) and ops.bn_fusable(x, kind, pw):
+        if isinstance(self.bn, BatchNorm2d) and ops.bn_fusable(x, kind, pw, self.bn):
             # act(bn(conv1)) and bn(conv2) + x each in the BatchNorm's own launches (ONE shared bn: base_networks.py:117)
             out = self.bn.run(self.conv1.run(x), kind, slope, pw)
             return self.bn.run(self.conv2.run(out), residual=residual)

@@ -925,9 +925,12 @@ def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1
                             sync_group, num_batches_tracked, int(act), float(slope), prelu_w, residual)
 
 
-def bn_fusable(x, act, prelu_w=None):
+def bn_fusable(x, act, prelu_w=None, bn=None):
     """Can `act` (and a residual add) ride in the BatchNorm kernels for this input?  ReLU / LeakyReLU / PReLU with one
-    slope or one per channel, channel count a multiple of 4 (the fused kernels move float4s)."""
+    slope or one per channel, channel count a multiple of 4 (the fused kernels move float4s), per-shard statistics
+    (SyncBN keeps the separate passes)."""
+    if bn is not None and getattr(bn, "sync_group", None) is not None:
+        return False
     if not BN_FUSE_ACT or act not in (ACT_NONE, ACT_RELU, ACT_LRELU, ACT_PRELU) or x.dim() < 2 or x.shape[1] % 4:
         return False
     return act != ACT_PRELU or (prelu_w is not None and prelu_w.numel() in (1, x.shape[1]))
