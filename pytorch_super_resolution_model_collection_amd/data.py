@@ -17,6 +17,7 @@ augmented 8-bit patch (one small D2H/H2D per patch, gray mode only): its integer
 Not provided: the BSDS300 HTTP download of data.py:9-30 (no network code in this package).
 """
 import ctypes
+import os
 import random
 from concurrent.futures import ThreadPoolExecutor
 from os import listdir
@@ -215,6 +216,11 @@ class TrainDatasetFromFolder(object):
         self.is_gray, self.random_scale, self.crop_size = is_gray, random_scale, crop_size
         self.rotate, self.fliplr, self.fliptb, self.scale_factor = rotate, fliplr, fliptb, scale_factor
         self._device, self._dev = device, None
+        # Decoded images stay RESIDENT IN HBM as 8-bit tensors once they have been uploaded (DIV2K's 800 LR training images
+        # are ~0.4 GB of 288): from the second epoch on a patch costs no PNG decode, no PCIe copy and one kernel call.  The
+        # transforms still start from the same 8-bit pixels, so nothing changes numerically.  `resident_bytes` bounds it.
+        self.resident_bytes = int(float(os.environ.get("SRK_DATA_RESIDENT_GB", "16")) * (1 << 30))
+        self._resident, self._resident_used = {}, 0
 
     @property
     def dev(self):
@@ -256,8 +262,12 @@ class TrainDatasetFromFolder(object):
         """Decoded image (numpy HWC uint8) + draws -> augmented 8-bit patch [3, crop, crop] on the device."""
         dev, crop = self.dev, self.crop_size
         scale, (x0, y0), rot, fl, ft = params
-        h, w, c = hwc.shape
-        img = dev.upload(hwc)
+        if isinstance(hwc, torch.Tensor):    # resident image (see __init__)
+            img = hwc
+            h, w, c = img.shape
+        else:
+            h, w, c = hwc.shape
+            img = dev.upload(hwc)
         if not self.is_gray:   # rescale + crop / rotation / flips in ONE call, straight into the batch buffer
             return dev.patch(img, c, h, w, scale, (x0, y0, crop, crop), rot, fl, ft, out)
         strides = _HWC(h, w, c)
@@ -275,6 +285,20 @@ class TrainDatasetFromFolder(object):
                 patch.copy_(dev.upload(ycc).permute(2, 0, 1))
         return patch
 
+    def resident(self, index):
+        """The image's 8-bit device tensor if it is resident, else None."""
+        return self._resident.get(index)
+
+    def keep_resident(self, index, hwc):
+        """Upload a decoded image and keep it in HBM (within the byte budget); returns what patch_u8 should consume."""
+        n = int(hwc.size)
+        if self._resident_used + n > self.resident_bytes:
+            return hwc
+        img = self.dev.upload(hwc)
+        self._resident[index] = img
+        self._resident_used += n
+        return img
+
     def finish(self, patches):
         """[B, 3, crop, crop] 8-bit patches -> (lr, hr, bc) float batches: the three resizes of dataset.py:89-99."""
         dev, crop, sf = self.dev, self.crop_size, self.scale_factor
@@ -287,7 +311,9 @@ class TrainDatasetFromFolder(object):
         return lr, hr, bc
 
     def __getitem__(self, index):
-        hwc = load_img(self.image_filenames[index])
+        hwc = self.resident(index)
+        if hwc is None:
+            hwc = self.keep_resident(index, load_img(self.image_filenames[index]))
         params = self.draw(hwc.shape[1], hwc.shape[0])
         patch = self.patch_u8(hwc, params)
         lr, hr, bc = self.finish(patch.unsqueeze(0))
@@ -381,7 +407,9 @@ class PatchLoader(object):
             yield idx
 
     def _decode(self, idx):
-        return [self.pool.submit(load_img, self.ds.image_filenames[i]) for i in idx]
+        res = getattr(self.ds, "resident", None)
+        return [(i, None if (res is not None and res(i) is not None) else self.pool.submit(load_img, self.ds.image_filenames[i]))
+                for i in idx]
 
     def __iter__(self):
         ds = self.ds
@@ -392,7 +420,15 @@ class PatchLoader(object):
         from collections import deque
         pending = deque(self._decode(b) for b in batches[:depth])
         for k, idx in enumerate(batches):
-            images = [f.result() for f in pending.popleft()]
+            images = []
+            for i, f in pending.popleft():
+                if f is None:
+                    images.append(ds.resident(i))
+                elif isinstance(ds, TrainDatasetFromFolder):
+                    with ds.dev.batch():
+                        images.append(ds.keep_resident(i, f.result()))
+                else:
+                    images.append(f.result())
             if k + depth < len(batches):
                 pending.append(self._decode(batches[k + depth]))   # overlaps with the work below
             if isinstance(ds, TrainDatasetFromFolder):

@@ -146,6 +146,22 @@ def test_patch_loader_batches_and_trains(gpu, tmp_path):
             for a, b in zip((lr[j], hr[j], bc[j]), want[k]):
                 assert torch.equal(a.cpu(), b)
             k += 1
+    # second epoch: every image is resident in HBM now (no decode, no PCIe copy) -- same pixels, same draws, same batches
+    assert all(ds.resident(i) is not None for i in range(len(ds))) and ds._resident_used == sum(
+        int(np.prod(ds.resident(i).shape)) for i in range(len(ds)))
+    loader2 = pkg.data.PatchLoader(ds, batch_size=3, shuffle=True, num_threads=2, seed=9)
+    random.seed(21)
+    again = list(loader2)
+    for (a0, a1, a2), (b0, b1, b2) in zip(batches, again):
+        assert torch.equal(a0, b0) and torch.equal(a1, b1) and torch.equal(a2, b2)
+    # a byte budget of zero keeps nothing resident and gives the same batches
+    ds0 = pkg.data.get_training_set(root, ["DIV2K"], 32, 4, device=gpu)
+    ds0.resident_bytes = 0
+    random.seed(21)
+    cold = list(pkg.data.PatchLoader(ds0, batch_size=3, shuffle=True, num_threads=2, seed=9))
+    assert not ds0._resident
+    for (a0, a1, a2), (b0, b1, b2) in zip(batches, cold):
+        assert torch.equal(a0, b0) and torch.equal(a1, b1) and torch.equal(a2, b2)
     # a trainer fed from the folder (2 epochs over 7 images)
     import main as cli
     from pytorch_super_resolution_model_collection_amd.sr_trainers import TRAINERS
