@@ -28,6 +28,7 @@ def parse_args(argv=None):
     p.add_argument('--steps_per_epoch', type=int, default=8)
     p.add_argument('--epoch_pretrain', type=int, default=50, help='SRGAN generator pre-training epochs (srgan.py:179)')
     p.add_argument('--precision', type=str, default='mixed', choices=['mixed', 'bf16x3', 'bf16x6', 'fp32'])
+    p.add_argument('--eager', action='store_true', help='launch every kernel of a train step from Python (default: replay the step as a hipGraph)')
     return check_args(p.parse_args(argv))
 
 

@@ -141,7 +141,7 @@ class _Trainer(object):
             total, n = torch.zeros((), device=self.device), 0
             for batch in batches:
                 inp, target = self._channels(*[t.to(self.device, non_blocking=True) for t in batch][:2])
-                out = step(*self.prepare(inp, target))
+                out = self._step(step, self.prepare(inp, target))
                 loss = sum(out) if isinstance(out, tuple) else out
                 total += loss.detach()   # device-side accumulation: no host sync inside the loop
                 n += 1
@@ -150,9 +150,46 @@ class _Trainer(object):
                 print('Epoch: [%2d] avg loss: %.8f' % (epoch + 1, avg_loss[-1]))
                 if (epoch + 1) % self.save_epochs == 0:
                     self.save_model(epoch + 1)
+        self._close_graph()
         if self.rank == 0:
             self.save_model(epoch=None)
         return avg_loss
+
+    # -- the train step as a hipGraph ------------------------------------------------------------------------------
+    # The reference's loop launches ~110 (EDSR) small kernels per iteration; at its default batch sizes the step is a
+    # few hundred microseconds of GPU work behind 1.5+ ms of host launches.  The FIRST batch of a shape runs eagerly (a
+    # real training step, and every lazy initialisation happens outside a capture), the next one is captured
+    # (trainers.GraphedStep: zero_grad + filter packing + forward + loss + backward + optimizer as one graph, split at
+    # the gradient exchange under data parallelism) and replayed from then on.  A batch of another shape (the ragged
+    # last one) runs eagerly; a learning-rate decay re-captures (the rate is a kernel argument).  --eager turns it off.
+    _GRAPH_LOSS = {"edsr": (ops.l1_loss, None), "vdsr": (ops.mse_loss, 0.4), "srcnn": (ops.mse_loss, None),
+                   "fsrcnn": (ops.mse_loss, None), "espcn": (ops.mse_loss, None)}
+
+    def _step(self, eager_step, tensors):
+        spec = self._GRAPH_LOSS.get(self.kind)
+        if spec is None or getattr(self.args, "eager", False) or not all(t.is_cuda for t in tensors):
+            return eager_step(*tensors)
+        shapes = tuple(tuple(t.shape) for t in tensors)
+        lrs = tuple(g['lr'] for g in self.optimizer.param_groups)
+        g = getattr(self, "_graph", None)
+        if g is not None and g[1] == shapes and g[2] == lrs:
+            return g[0](*tensors)
+        seen = getattr(self, "_graph_seen", None)
+        if seen != shapes:                      # first batch of this shape: eager (and remember the shape)
+            if seen is None or g is None:
+                self._graph_seen = shapes
+            return eager_step(*tensors)
+        self._close_graph()
+        loss_fn, clip = spec
+        gs = trainers.GraphedStep(self.model, self.optimizer, loss_fn, tensors, dp=self.dp, clip=clip, warmup=0)
+        self._graph = (gs, shapes, lrs)
+        return gs(*tensors)
+
+    def _close_graph(self):
+        g = getattr(self, "_graph", None)
+        if g is not None:
+            g[0].close()
+        self._graph = None
 
     def _net_input(self, x):
         """SRCNN / VDSR feed the bicubic-upsampled image to the net (srcnn.py:145, vdsr.py:160)."""

@@ -220,6 +220,36 @@ def test_trainer_objects_and_cli(gpu, tmp_path):
     R.EDSR(3, 64, 16).load_state_dict(torch.load(files[0]))
 
 
+def test_trainer_replays_its_step_as_a_graph(gpu, tmp_path):
+    """MODEL(args).train() captures its step after the first batch of a shape and replays it (sr_trainers._Trainer._step);
+    --eager launches every kernel from Python.  Same data, same seeds: the same loss history and the same checkpoint,
+    across a learning-rate decay (re-capture) and for SGD + clipping (VDSR) as well as Adam (EDSR)."""
+    import main as cli
+    from pytorch_super_resolution_model_collection_amd.sr_trainers import TRAINERS, LR_DECAY
+    pkg = _pkg()
+    for name, extra, epochs in (("EDSR", ["--crop_size", "32"], 3), ("VDSR", ["--crop_size", "17"], 3)):
+        hist, params = {}, {}
+        old = dict(LR_DECAY)
+        LR_DECAY[name.lower()] = (2, 2.0)        # decay after the 2nd epoch: the third runs on a re-captured graph
+        try:
+            for mode in ("graph", "eager"):
+                args = cli.parse_args(["--model_name", name, "--num_epochs", str(epochs), "--save_epochs", "10",
+                                       "--batch_size", "2", "--steps_per_epoch", "4", "--lr", "1e-3",
+                                       "--save_dir", str(tmp_path / mode)] + extra + (["--eager"] if mode == "eager" else []))
+                torch.manual_seed(0)
+                t = TRAINERS[name](args)
+                hist[mode] = t.train()
+                params[mode] = t.flat.data.detach().clone()
+                if mode == "graph":
+                    assert t._graph is None     # closed at the end of train()
+        finally:
+            LR_DECAY.clear()
+            LR_DECAY.update(old)
+        for a, b in zip(hist["graph"], hist["eager"]):
+            assert abs(a - b) <= 2e-5 * abs(b) + 1e-9, (name, hist)
+        assert rel_err(params["graph"], params["eager"]) < (5e-3 if name == "EDSR" else 1e-5), name   # Adam: +-lr sign flips
+
+
 def test_wgrad_side_stream_matches_single_stream(gpu):
     """ops.WGRAD_SIDE_STREAM (weight gradients forked onto a second stream, joined by the autograd-engine callback):
     same gradients as the single-stream path, readable right after loss.backward()."""
