@@ -386,8 +386,11 @@ class PatchLoader(object):
     one trains), pixels cross PCIe as uint8 through pinned memory, all transforms run on the loader's HIP stream, and a
     batch costs 2-3 small launches per patch plus three batched resizes.  Yields (lr, hr, bc) CUDA batches."""
 
-    def __init__(self, dataset, batch_size, shuffle=True, num_threads=4, drop_last=False, seed=None):
+    def __init__(self, dataset, batch_size, shuffle=True, num_threads=4, drop_last=False, seed=None, background=True):
         self.ds, self.batch_size, self.shuffle, self.drop_last = dataset, int(batch_size), shuffle, drop_last
+        # background: batches are produced by a loader thread up to two ahead of the consumer (its host work -- draws,
+        # one call per patch, three batched resizes -- overlaps with the consumer launching / replaying the train step)
+        self.background = bool(background) and os.environ.get("SRK_LOADER_THREAD", "1") != "0"
         self.pool = ThreadPoolExecutor(max_workers=max(1, int(num_threads)))
         self.gen = torch.Generator()
         if seed is not None:
@@ -412,6 +415,54 @@ class PatchLoader(object):
                 for i in idx]
 
     def __iter__(self):
+        ds = self.ds
+        if not (self.background and isinstance(ds, TrainDatasetFromFolder)):
+            for tensors, ev in self._produce():
+                yield ds.dev.hand_over(*tensors) if ev is not None else tensors
+            return
+        import queue
+        import threading
+        q, stop, END = queue.Queue(maxsize=2), threading.Event(), object()
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
+        def work():
+            try:
+                for item in self._produce():
+                    if not put(item):
+                        return
+                put(END)
+            except BaseException as e:   # noqa: BLE001 -- re-raised in the consumer
+                put(e)
+
+        th = threading.Thread(target=work, name="srk-loader", daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is END:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                tensors, ev = item
+                cur = torch.cuda.current_stream(ds.dev.device)
+                cur.wait_event(ev)            # the consumer's stream waits for THIS batch only, not for the loader stream
+                for t in tensors:
+                    t.record_stream(cur)
+                yield tensors
+        finally:
+            stop.set()
+
+    def _produce(self):
+        """Generator of (batch tensors, event recorded on the loader stream behind them); event None = nothing to wait
+        for (test items are handed over one by one)."""
         ds = self.ds
         batches = list(self._batches())
         # decode ahead: enough batches in flight to keep every decode thread busy while the current batch is uploaded
@@ -438,7 +489,9 @@ class PatchLoader(object):
                     for j, hwc in enumerate(images):
                         ds.patch_u8(hwc, ds.draw(hwc.shape[1], hwc.shape[0]), out=patches[j])
                     out = ds.finish(patches)
-                yield ds.dev.hand_over(*out)
+                    ev = torch.cuda.Event()
+                    ev.record(ds.dev.stream)
+                yield out, ev
             else:   # test images differ in size: one item per batch entry, stacked only when they agree
                 items = [ds[i] for i in idx]
-                yield tuple(torch.stack(t) if len(set(x.shape for x in t)) == 1 else list(t) for t in zip(*items))
+                yield tuple(torch.stack(t) if len(set(x.shape for x in t)) == 1 else list(t) for t in zip(*items)), None
