@@ -166,30 +166,26 @@ class _Trainer(object):
                    "fsrcnn": (ops.mse_loss, None), "espcn": (ops.mse_loss, None)}
 
     def _step(self, eager_step, tensors):
-        spec = self._GRAPH_LOSS.get(self.kind)
-        if spec is None or getattr(self.args, "eager", False) or not all(t.is_cuda for t in tensors):
-            return eager_step(*tensors)
-        shapes = tuple(tuple(t.shape) for t in tensors)
-        lrs = tuple(g['lr'] for g in self.optimizer.param_groups)
-        g = getattr(self, "_graph", None)
-        if g is not None and g[1] == shapes and g[2] == lrs:
-            return g[0](*tensors)
-        seen = getattr(self, "_graph_seen", None)
-        if seen != shapes:                      # first batch of this shape: eager (and remember the shape)
-            if seen is None or g is None:
-                self._graph_seen = shapes
-            return eager_step(*tensors)
-        self._close_graph()
-        loss_fn, clip = spec
-        gs = trainers.GraphedStep(self.model, self.optimizer, loss_fn, tensors, dp=self.dp, clip=clip, warmup=0)
-        self._graph = (gs, shapes, lrs)
-        return gs(*tensors)
+        auto = getattr(self, "_auto", None)
+        if auto is None or auto.eager is not eager_step:
+            spec = self._GRAPH_LOSS.get(self.kind)
+
+            def make(ts):
+                return trainers.GraphedStep(self.model, self.optimizer, spec[0], ts, dp=self.dp, clip=spec[1], warmup=0)
+
+            auto = self._auto = trainers.AutoGraph(eager_step, make, lambda: [g['lr'] for g in self.optimizer.param_groups],
+                                                   enabled=spec is not None and not getattr(self.args, "eager", False))
+        return auto(*tensors)
+
+    @property
+    def _graph(self):
+        auto = getattr(self, "_auto", None)
+        return None if auto is None else auto.graph
 
     def _close_graph(self):
-        g = getattr(self, "_graph", None)
-        if g is not None:
-            g[0].close()
-        self._graph = None
+        auto = getattr(self, "_auto", None)
+        if auto is not None:
+            auto.close()
 
     def _net_input(self, x):
         """SRCNN / VDSR feed the bicubic-upsampled image to the net (srcnn.py:145, vdsr.py:160)."""
@@ -357,13 +353,28 @@ class SRGAN(_Trainer):
         if self.load_model(is_pretrain=True):
             g_flat.mark_changed()      # parameters changed behind the optimizer's back: re-pack filters
         else:
-            pre_step = trainers.mse_step(self.G, g_opt, g_dp)
+            eager = bool(getattr(self.args, "eager", False))
+            pre_step = trainers.AutoGraph(
+                trainers.mse_step(self.G, g_opt, g_dp),
+                lambda ts: trainers.GraphedStep(self.G, g_opt, ops.mse_loss, ts, dp=g_dp, warmup=0),
+                lambda: [g['lr'] for g in g_opt.param_groups], enabled=not eager)
             for epoch in range(self.epoch_pretrain):
                 for y_, x_ in batches(77 + epoch):
                     pre_step(y_, x_)
+            pre_step.close()
             if self.rank == 0:
                 self.save_model(is_pretrain=True)
-        step = trainers.srgan_step(self.G, self.D, g_opt, d_opt, g_dp, d_dp)
+        # the adversarial step (two models, two optimizers) as one hipGraph; data parallel: graphs split at the two exchanges
+        eager_step = trainers.srgan_step(self.G, self.D, g_opt, d_opt, g_dp, d_dp)
+
+        def make_graph(ts):
+            if g_dp is not None and g_dp.active:
+                return trainers.GraphedSegments(trainers.srgan_segments(self.G, self.D, g_opt, d_opt, g_dp, d_dp), ts, warmup=0)
+            return trainers.GraphedFn(eager_step, ts, warmup=0, flats=[g_flat, d_flat])
+
+        step = trainers.AutoGraph(eager_step, make_graph,
+                                  lambda: [g['lr'] for o in (g_opt, d_opt) for g in o.param_groups],
+                                  enabled=not bool(getattr(self.args, "eager", False)))
         hist = []
         for epoch in range(self.num_epochs):
             apply_lr_decay("srgan", epoch, g_opt, d_opt)   # srgan.py:239-244: both learning rates /10 every 20 epochs
@@ -378,6 +389,7 @@ class SRGAN(_Trainer):
                 print('Epoch: [%2d] D_loss: %.8f G_loss: %.8f' % ((epoch + 1,) + hist[-1]))
                 if (epoch + 1) % self.save_epochs == 0:
                     self.save_model(epoch + 1)
+        step.close()
         if self.rank == 0:
             self.save_model(epoch=None)
         return hist

@@ -361,3 +361,37 @@ class GraphedFn(object):
             f.mark_changed()
         return self.out
 
+
+class AutoGraph(object):
+    """A train step that turns itself into a hipGraph.  The FIRST batch of a shape runs through `eager` (a real step, and
+    every lazy initialisation happens outside a capture); the next batch of that shape is captured by
+    `make_graph(tensors)` (a GraphedStep / GraphedFn / GraphedSegments built with warmup=0 on that batch) and replayed
+    from then on.  Batches of another shape (the ragged last one of an epoch) run eagerly; a change of `lrs()` (learning
+    rates are kernel arguments) re-captures.  `enabled=False`: always eager."""
+
+    def __init__(self, eager, make_graph, lrs, enabled=True):
+        self.eager, self.make_graph, self.lrs, self.enabled = eager, make_graph, lrs, enabled
+        self.graph, self.seen = None, None
+
+    def __call__(self, *tensors):
+        if not self.enabled or not all(t.is_cuda for t in tensors):
+            return self.eager(*tensors)
+        shapes = tuple(tuple(t.shape) for t in tensors)
+        lrs = tuple(self.lrs())
+        g = self.graph
+        if g is not None and g[1] == shapes and g[2] == lrs:
+            return g[0](*tensors)
+        if self.seen != shapes:                 # first batch of this shape: eager (and remember the shape)
+            if self.seen is None or g is None:
+                self.seen = shapes
+            return self.eager(*tensors)
+        self.close()
+        gs = self.make_graph(tensors)
+        self.graph = (gs, shapes, lrs)
+        return gs(*tensors)
+
+    def close(self):
+        if self.graph is not None and hasattr(self.graph[0], "close"):
+            self.graph[0].close()
+        self.graph = None
+

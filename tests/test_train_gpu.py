@@ -248,6 +248,16 @@ def test_trainer_replays_its_step_as_a_graph(gpu, tmp_path):
         for a, b in zip(hist["graph"], hist["eager"]):
             assert abs(a - b) <= 2e-5 * abs(b) + 1e-9, (name, hist)
         assert rel_err(params["graph"], params["eager"]) < (5e-3 if name == "EDSR" else 1e-5), name   # Adam: +-lr sign flips
+    # SRGAN: generator pre-training (GraphedStep) and the two-model adversarial step (GraphedFn) replayed as graphs
+    hist = {}
+    for mode in ("graph", "eager"):
+        args = cli.parse_args(["--model_name", "SRGAN", "--num_epochs", "2", "--save_epochs", "10", "--batch_size", "2",
+                               "--steps_per_epoch", "4", "--lr", "1e-4", "--crop_size", "32", "--epoch_pretrain", "1",
+                               "--save_dir", str(tmp_path / ("gan_" + mode))] + (["--eager"] if mode == "eager" else []))
+        torch.manual_seed(0)
+        hist[mode] = TRAINERS["SRGAN"](args).train()
+    for (d0, g0), (d1, g1) in zip(hist["graph"], hist["eager"]):
+        assert abs(d0 - d1) <= 1e-3 * abs(d1) + 1e-6 and abs(g0 - g1) <= 1e-3 * abs(g1) + 1e-6, hist
 
 
 def test_wgrad_side_stream_matches_single_stream(gpu):
