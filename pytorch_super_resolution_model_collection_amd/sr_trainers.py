@@ -161,7 +161,7 @@ class _Trainer(object):
     # real training step, and every lazy initialisation happens outside a capture), the next one is captured
     # (trainers.GraphedStep: zero_grad + filter packing + forward + loss + backward + optimizer as one graph, split at
     # the gradient exchange under data parallelism) and replayed from then on.  A batch of another shape (the ragged
-    # last one) runs eagerly; a learning-rate decay re-captures (the rate is a kernel argument).  --eager turns it off.
+    # last one) runs eagerly; a learning-rate decay needs nothing (the rate is a device scalar).  --eager turns it off.
     _GRAPH_LOSS = {"edsr": (ops.l1_loss, None), "vdsr": (ops.mse_loss, 0.4), "srcnn": (ops.mse_loss, None),
                    "fsrcnn": (ops.mse_loss, None), "espcn": (ops.mse_loss, None)}
 
@@ -170,11 +170,15 @@ class _Trainer(object):
         if auto is None or auto.eager is not eager_step:
             spec = self._GRAPH_LOSS.get(self.kind)
 
+            single = self.dp is None or not self.dp.active
+
             def make(ts):
+                if spec is None:    # steps with their own loss structure (LapSRN's two Charbonnier terms): the eager step
+                    return trainers.GraphedFn(eager_step, ts, warmup=0, flats=[self.flat])   # function itself, one GPU
                 return trainers.GraphedStep(self.model, self.optimizer, spec[0], ts, dp=self.dp, clip=spec[1], warmup=0)
 
-            auto = self._auto = trainers.AutoGraph(eager_step, make, lambda: [g['lr'] for g in self.optimizer.param_groups],
-                                                   enabled=spec is not None and not getattr(self.args, "eager", False))
+            auto = self._auto = trainers.AutoGraph(eager_step, make,
+                                                   enabled=(spec is not None or single) and not getattr(self.args, "eager", False))
         return auto(*tensors)
 
     @property
@@ -356,8 +360,7 @@ class SRGAN(_Trainer):
             eager = bool(getattr(self.args, "eager", False))
             pre_step = trainers.AutoGraph(
                 trainers.mse_step(self.G, g_opt, g_dp),
-                lambda ts: trainers.GraphedStep(self.G, g_opt, ops.mse_loss, ts, dp=g_dp, warmup=0),
-                lambda: [g['lr'] for g in g_opt.param_groups], enabled=not eager)
+                lambda ts: trainers.GraphedStep(self.G, g_opt, ops.mse_loss, ts, dp=g_dp, warmup=0), enabled=not eager)
             for epoch in range(self.epoch_pretrain):
                 for y_, x_ in batches(77 + epoch):
                     pre_step(y_, x_)
@@ -372,9 +375,7 @@ class SRGAN(_Trainer):
                 return trainers.GraphedSegments(trainers.srgan_segments(self.G, self.D, g_opt, d_opt, g_dp, d_dp), ts, warmup=0)
             return trainers.GraphedFn(eager_step, ts, warmup=0, flats=[g_flat, d_flat])
 
-        step = trainers.AutoGraph(eager_step, make_graph,
-                                  lambda: [g['lr'] for o in (g_opt, d_opt) for g in o.param_groups],
-                                  enabled=not bool(getattr(self.args, "eager", False)))
+        step = trainers.AutoGraph(eager_step, make_graph, enabled=not bool(getattr(self.args, "eager", False)))
         hist = []
         for epoch in range(self.num_epochs):
             apply_lr_decay("srgan", epoch, g_opt, d_opt)   # srgan.py:239-244: both learning rates /10 every 20 epochs

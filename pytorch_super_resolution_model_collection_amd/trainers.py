@@ -366,20 +366,20 @@ class AutoGraph(object):
     """A train step that turns itself into a hipGraph.  The FIRST batch of a shape runs through `eager` (a real step, and
     every lazy initialisation happens outside a capture); the next batch of that shape is captured by
     `make_graph(tensors)` (a GraphedStep / GraphedFn / GraphedSegments built with warmup=0 on that batch) and replayed
-    from then on.  Batches of another shape (the ragged last one of an epoch) run eagerly; a change of `lrs()` (learning
-    rates are kernel arguments) re-captures.  `enabled=False`: always eager."""
+    from then on.  Batches of another shape (the ragged last one of an epoch) run eagerly.  Learning rates are device
+    scalars the optimizer kernels read (optim._Group: `group['lr'] /= 2` reaches them), so a decay needs no re-capture.
+    `enabled=False`: always eager."""
 
-    def __init__(self, eager, make_graph, lrs, enabled=True):
-        self.eager, self.make_graph, self.lrs, self.enabled = eager, make_graph, lrs, enabled
+    def __init__(self, eager, make_graph, enabled=True):
+        self.eager, self.make_graph, self.enabled = eager, make_graph, enabled
         self.graph, self.seen = None, None
 
     def __call__(self, *tensors):
         if not self.enabled or not all(t.is_cuda for t in tensors):
             return self.eager(*tensors)
         shapes = tuple(tuple(t.shape) for t in tensors)
-        lrs = tuple(self.lrs())
         g = self.graph
-        if g is not None and g[1] == shapes and g[2] == lrs:
+        if g is not None and g[1] == shapes:
             return g[0](*tensors)
         if self.seen != shapes:                 # first batch of this shape: eager (and remember the shape)
             if self.seen is None or g is None:
@@ -387,7 +387,7 @@ class AutoGraph(object):
             return self.eager(*tensors)
         self.close()
         gs = self.make_graph(tensors)
-        self.graph = (gs, shapes, lrs)
+        self.graph = (gs, shapes)
         return gs(*tensors)
 
     def close(self):
