@@ -224,8 +224,19 @@ __device__ __forceinline__ void bfd_epilogue_direct(const MfmaConvParams& P, con
 // KS = 2 (small problems with every chunk staged up front): a second set of NPW*NOW waves takes the odd channel
 // chunks -- two waves per SIMD on a block that is pure latency otherwise -- and the partial accumulators meet in LDS
 // before the epilogue.
+#ifndef BFD_OCC_SMALL
+#define BFD_OCC_SMALL 1
+#endif
+// waves per SIMD the kernel is compiled for (0: the default bound of 2)
 template <int NTW, int NPW, int NOW, int NP, int PF, int KS>
-__global__ __launch_bounds__(64 * NPW * NOW * KS, (BFD_OCC3 && NP == 3 && NTW == 2 && NPW == 2 && NOW == 2 && KS == 1 && PF == 1) ? 3 : 2) void k_conv_bfd(
+constexpr int bfd_occ() {
+  if (BFD_OCC3 && NP == 3 && NTW == 2 && NPW == 2 && NOW == 2 && KS == 1 && PF == 1) return 3;  // exactly <2,2,2,3,1,1>
+  if (BFD_OCC_SMALL && NPW == 1 && NOW == 4 && KS == 1) return NP == 2 ? 4 : 3;               // <1,1,4,NP,*,1>
+  return 0;
+}
+
+template <int NTW, int NPW, int NOW, int NP, int PF, int KS>
+__global__ __launch_bounds__(64 * NPW * NOW * KS, (bfd_occ<NTW, NPW, NOW, NP, PF, KS>() ? bfd_occ<NTW, NPW, NOW, NP, PF, KS>() : 2)) void k_conv_bfd(
     BfdParams B) {
   constexpr int NTHR = 64 * NPW * NOW * KS;
   constexpr bool TEPI = NPW == 1;
@@ -233,7 +244,9 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, (BFD_OCC3 && NP == 3 && NTW ==
   // 3 waves per SIMD (launch bound 168 VGPRs; it took 233 = 2 waves per SIMD): its halo staging keeps 2 pixels per
   // thread in flight instead of 6, which is what the register budget was spent on.  VDSR step 8.30 -> 7.96 ms, EDSR
   // 6.66 -> 6.62 ms (BFD_OCC3=0 restores the old build)
-  constexpr bool OCC3 = BFD_OCC3 && NP == 3 && NTW == 2 && NPW == 2 && NOW == 2 && KS == 1 && PF == 1;  // exactly <2,2,2,3,1,1>
+  // the 4-wave 64-pixel block without the K split (2 .. 8 tiles per CU: the up-sampler and the discriminator's middle
+  // layers at 16 patches) likewise: 187 / 208 -> 116 / 137 VGPRs = 4 / 3 resident blocks per CU instead of 2
+  constexpr bool OCC3 = bfd_occ<NTW, NPW, NOW, NP, PF, KS>() != 0;
   constexpr int SIT = OCC3 ? 2 : BFD_STAGE_IT;
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   const MfmaConvParams& P = B.P;
