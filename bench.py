@@ -162,11 +162,32 @@ def bf16_pipe_frac(fwd_flop, bwd_flop, seconds_per_sample, fwd_x3_flop=0.0):
         (BF16_MFMA_PEAK_TFLOPS * 1e12)
 
 
-def train_extra(pkg, dev, rank, world, nsteps=20):
+def extras_watchdog(result, extra, rank, seconds):
+    """N > 1 only.  A side metric that dies on ONE rank (say a refused graph capture) leaves the others waiting in a
+    collective for ever, and the headline line -- measured before any of them -- would never be printed.  After `seconds`
+    every rank leaves on its own clock (they start it behind the same barrier); rank 0 prints the line first, with what
+    the side metrics had produced so far and the reason."""
+    import threading
+
+    def fire():
+        if rank == 0 and result is not None:
+            extra["extras_error"] = "side metrics did not finish within %d s (SRK_BENCH_EXTRA_TIMEOUT); headline unaffected" % seconds
+            result["extra"] = dict(extra)
+            print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os._exit(0)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
     """Side metrics: c1 (SRCNN step incl. the bicubic pre-step) and c3 (VDSR x4, 41x41, batch 256) on one GPU; c4 EDSR x4
     training with global batch 128 sharded over the ranks (strong scaling; grouped weight gradients + overlapped bucketed
     RCCL exchange) and with 128 per GPU (weak); the 16-patch shard step that bounds 8-GPU strong scaling; c5 SRGAN."""
-    out = {}
+    out = {} if out is None else out
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     WARM = 5
     # the N > 1 code path: more than one rank, or a one-rank process group forced by SRK_DP_FORCE_COMM=1 (dry run of the
@@ -449,9 +470,15 @@ def main():
         }
     extra = {}
     if not args.no_extra:
+        dog = None
+        if torch.distributed.is_initialized():
+            torch.distributed.barrier()
+            dog = extras_watchdog(result, extra, rank, int(os.environ.get("SRK_BENCH_EXTRA_TIMEOUT", "420")))
         if world == 1 and pkg.ops.get_precision() == "mixed":
             extra.update(c2_other_precisions(pkg, net, x, max(5, args.steps // 2), 2, dev))
-        extra.update(train_extra(pkg, dev, rank, world, args.extra_steps))
+        train_extra(pkg, dev, rank, world, args.extra_steps, extra)
+        if dog is not None:
+            dog.cancel()
     if rank == 0:
         if extra:
             result["extra"] = extra

@@ -317,3 +317,22 @@ def test_data_parallel_gloo_world2(tmp_path):
     assert torch.allclose(r0["sum"], r0["local"] + r1["local"]) and torch.equal(r0["sum"], r1["sum"])
     assert torch.allclose(r0["g"], r0["full"], atol=1e-6)
     assert float(r0["loss"]) == 0.5
+
+
+def test_bench_prints_its_line_when_a_side_metric_hangs():
+    """bench.py at N > 1: a side metric that never returns (one rank dropped out of a collective) must not cost the
+    headline line -- the watchdog prints it with what was collected and every rank exits 0."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "res = {'metric': 'm', 'value': 1.0}; extra = {'c4_edsr_ms_per_step': 6.6}\n"
+            "bench.extras_watchdog(res, extra, 0, 1)\n"
+            "time.sleep(30)\n"
+            "print('not reached')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and "not reached" not in r.stdout
+    rec = json.loads(lines[0])
+    assert rec["value"] == 1.0 and rec["extra"]["c4_edsr_ms_per_step"] == 6.6 and "extras_error" in rec["extra"]
