@@ -47,6 +47,7 @@ struct BfwParams {
   MfmaConvParams P;
   const uint4* wq;  // prepared filter planes (h, m)
   int ICc, NB, NPIXp, ntiles;
+  int perm;  // consumer lanes {0-3, 12-15} hold the even pixels of an M tile, {4-11} the odd ones (bfw_group_stride)
   int dbg;  // ablation (SRK_DBG): 1 no global loads, 2 no epilogue, 4 no MFMA loop, 16 no LDS commit, 1024 no deferred stores
 };
 
@@ -174,10 +175,12 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
 
   // -------------------------------------------------------------------- consumers
   const int pw = wave;
+  // pixel of the M tile that this lane's MFMA column holds (see bfw_group_stride)
+  const int pj = !B.perm ? j : (j < 4 ? 2 * j : (j < 12 ? 2 * j - 7 : 2 * j - 16));
   int hp[MTW];
 #pragma unroll
   for (int mt = 0; mt < MTW; ++mt) {
-    int m = pw * (16 * MTW) + mt * 16 + j;
+    int m = pw * (16 * MTW) + mt * 16 + pj;
     if (m >= npx) m = 0;
     const int r = m / P.TW, c = m - r * P.TW;
     hp[mt] = (r * P.is) * P.HW + c * P.is + kq * B.NPIXp;
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
     const EpiTile e0 = epi_tile_setup(P, 0, 0, 0);
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
-      const int m = pw * (16 * MTW) + mt * 16 + j;
+      const int m = pw * (16 * MTW) + mt * 16 + pj;
       const int r = m / P.TW, c = m - r * P.TW;
       pix_ok[mt] = m < npx ? ((r << 16) | c) : -1;
       poff[mt] = r * e0.RS + c * e0.CS;
@@ -346,6 +349,52 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
   }
 }
 
+// LDS stride (in 16-byte slots) between the four 8-channel groups of a halo plane, chosen against the lane groups the LDS
+// serves wide accesses in (MI355X_MICROARCH.md, LDS): ds_read_b128 in {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} / ...
+// with bank = slot mod 16, ds_write_b128 in 8 contiguous lanes with a window of 8 slots.
+//   producers: 8 lanes write (2 pixels) x (4 groups)          -> conflict-free iff stride = 2 or 6 (mod 8)
+//   consumers: a lane group reads 8 columns of k-group kq and the OTHER 8 columns of kq + 1.  With the columns
+//     {0-3, 12-15} on the even pixels of the M tile and {4-11} on the odd ones, a stride of +-2 (mod 16) maps a parity
+//     class onto itself                                         -> conflict-free for M tiles of 16 consecutive slots
+// Measured on the c2 layers (rocprofv3 --pmc SQ_LDS_BANK_CONFLICT, tools/pmc_gpad.sh): 54.1 M -> 21.9 M conflict cycles
+// per launch for 64->32 (0 with 16-wide tiles), 16.2 M -> 0 for 32->48; LDS-busy cycles 139 M -> 107 M.  The layer times
+// do not move (0.472 ms either way): the LDS was not what bounds this kernel.  SRK_BFW_PERM=0 restores the old layout.
+static inline int bfw_group_stride(int npix, bool perm) {
+  if (!perm) return (npix + 15) & ~15;
+  const int a = npix + ((2 - npix) & 15), b = npix + ((14 - npix) & 15);
+  return a < b ? a : b;
+}
+
+// pick_tile (conv_tile.h) with the padded halo size as the fit test; wmult = 16 restricts the tile width to multiples of
+// 16 (SRK_BFW_W16=1: every M tile is 16 consecutive slots)
+static bool bfw_pick_tile(int maxpix, int PH, int PW, int KHv, int KWv, long cap_px, bool perm, int wmult, TilePick& best) {
+  bool found = false;
+  long best_tiles = 0, best_halo = 0;
+  const int maxTW = PW < maxpix ? PW : maxpix;
+  for (int TW = wmult; TW <= (maxTW > wmult ? maxTW : wmult); TW += wmult) {
+    int TH = maxpix / TW;
+    if (TH > PH) TH = PH;
+    for (; TH >= 1; --TH) {
+      const int HH = TH - 1 + KHv, HWd = TW - 1 + KWv;
+      if (bfw_group_stride(HH * HWd, perm) > cap_px) continue;
+      const long tiles = (long)cdiv(PH, TH) * cdiv(PW, TW);
+      const long halo = (long)HH * HWd * tiles;
+      const bool fewer = tiles < best_tiles, same = tiles == best_tiles;
+      const bool wider = same && halo * 100 <= best_halo * 106 && TW > best.TW;
+      const bool smaller = same && halo < best_halo && TW >= best.TW;
+      if (!found || fewer || wider || smaller) {
+        found = true;
+        best_tiles = tiles;
+        best_halo = halo;
+        best = TilePick{TH, TW, (int)cdiv(PH, TH), (int)cdiv(PW, TW), HH, HWd,
+                        (double)PH * PW / ((double)tiles * (double)maxpix)};
+      }
+      break;  // smaller TH only gets worse for this TW
+    }
+  }
+  return found;
+}
+
 // Applicability: stride-1 CONV gathers, IC a multiple of 8 (16-byte channel groups), OC = 16 * {1..4}, filter planes
 // + two halo buffers within the LDS, every output group on the 16-byte store path, and a problem large enough to
 // keep one persistent block per CU busy for several tiles.  SRK_BFW: 0 never, 1 whenever applicable, unset = automatic.
@@ -413,12 +462,15 @@ int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float
     const size_t wbytes = (size_t)T * B.ICc * 8 * B.NB * 16;
     const long lds_cap = 160L * 1024 - 512;
     long px_cap = (lds_cap - (long)wbytes) / (2 * 128);  // halo pixels per buffer (128 bytes each)
-    px_cap &= ~15L;
     if (px_cap > 64 * BFW_IT) px_cap = 64 * BFW_IT;
+    static const int perm = getenv("SRK_BFW_PERM") ? atoi(getenv("SRK_BFW_PERM")) : 1;
+    static const int w16 = getenv("SRK_BFW_W16") ? atoi(getenv("SRK_BFW_W16")) : 0;
+    B.perm = perm;
     TilePick best{};
-    if (px_cap < 64 || !pick_tile(256, P.PH, P.PW, P.is, P.KHv, P.KWv, 32, (int)px_cap * 32, best)) return -1;
+    if (px_cap < 64 || P.is != 1) return -1;
+    if (!bfw_pick_tile(256, P.PH, P.PW, P.KHv, P.KWv, px_cap, perm, w16 ? 16 : 1, best)) return -1;
     P.TH = best.TH; P.TW = best.TW; P.tiles_y = best.tiles_y; P.tiles_x = best.tiles_x; P.HH = best.HH; P.HW = best.HW;
-    B.NPIXp = (best.HH * best.HW + 15) & ~15;
+    B.NPIXp = bfw_group_stride(best.HH * best.HW, perm);
     const size_t lds = wbytes + (size_t)2 * 8 * B.NPIXp * 16;
     const long ntiles = (long)P.tiles_x * P.tiles_y * P.N;
     if (ntiles >= (1L << 30)) return -1;
