@@ -333,9 +333,11 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
             g_dp, d_dp = pkg.dp.DataParallel(gflat), pkg.dp.DataParallel(dflat)
             g_dp.broadcast_params()
             d_dp.broadcast_params()
-            sstep = pkg.trainers.GraphedSegments(pkg.trainers.srgan_segments(G, D, g_opt, d_opt, g_dp, d_dp), (lr_img, hr_img))
+            sstep = pkg.trainers.GraphedSegments(pkg.trainers.srgan_segments(G, D, g_opt, d_opt, g_dp, d_dp, lazy_pack=True),
+                                                 (lr_img, hr_img))
         else:
-            sstep = pkg.trainers.GraphedFn(pkg.trainers.srgan_step(G, D, g_opt, d_opt), (lr_img, hr_img), flats=[gflat, dflat])
+            sstep = pkg.trainers.GraphedFn(pkg.trainers.srgan_step(G, D, g_opt, d_opt, lazy_pack=True), (lr_img, hr_img),
+                                           flats=[gflat, dflat])
         k = max(6, nsteps // 2)
         sec = time_steps(lambda: sstep(lr_img, hr_img), k, 3, world, dev)
         out["c5_srgan_x4_adv_step_patches_per_s_batch_16_per_gpu"] = round(world * 16 * k / sec, 1)

@@ -170,11 +170,16 @@ class _FlatOptimizer(object):
     def _set_lr(self, v):
         self.lr_dev.fill_(float(v))
 
-    def zero_grad(self, set_to_none=False):
+    def zero_grad(self, set_to_none=False, repack="always"):
         """Start of a train step: clear the flat gradient buffer (one memset) and re-pack every conv
-        filter of the model for this step's forward/backward (one launch)."""
+        filter of the model for this step's forward/backward (one launch).
+        repack="stale": skip the pack when the plan is still current -- SRGAN's discriminator at the start of a step was
+        packed for the generator phase of the previous one and has not changed since.  Only for callers that tell their
+        graph which FlatParams it updates (trainers.GraphedFn(flats=...)): inside a replay nobody can see that somebody
+        rewrote the parameters in place, the unconditional pack is what makes that case work by itself."""
         self.flat.zero_grad()
-        self.flat.plan.pack()
+        if repack != "stale" or not self.flat.plan.current():
+            self.flat.plan.pack()
 
     def clip_grad_norm(self, max_norm):
         """torch.nn.utils.clip_grad_norm(params, max_norm) (vdsr.py:149): computes the global L2

@@ -368,11 +368,12 @@ class SRGAN(_Trainer):
             if self.rank == 0:
                 self.save_model(is_pretrain=True)
         # the adversarial step (two models, two optimizers) as one hipGraph; data parallel: graphs split at the two exchanges
-        eager_step = trainers.srgan_step(self.G, self.D, g_opt, d_opt, g_dp, d_dp)
+        eager_step = trainers.srgan_step(self.G, self.D, g_opt, d_opt, g_dp, d_dp, lazy_pack=True)
 
         def make_graph(ts):
             if g_dp is not None and g_dp.active:
-                return trainers.GraphedSegments(trainers.srgan_segments(self.G, self.D, g_opt, d_opt, g_dp, d_dp), ts, warmup=0)
+                return trainers.GraphedSegments(trainers.srgan_segments(self.G, self.D, g_opt, d_opt, g_dp, d_dp, lazy_pack=True), ts,
+                                                warmup=0)
             return trainers.GraphedFn(eager_step, ts, warmup=0, flats=[g_flat, d_flat])
 
         step = trainers.AutoGraph(eager_step, make_graph, enabled=not bool(getattr(self.args, "eager", False)))

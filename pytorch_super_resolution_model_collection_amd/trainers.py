@@ -93,26 +93,30 @@ def lapsrn_step(model, opt, dp=None):
     return step
 
 
-def srgan_step(G, D, g_opt, d_opt, g_dp=None, d_dp=None, feature_extractor=None):
+def srgan_step(G, D, g_opt, d_opt, g_dp=None, d_dp=None, feature_extractor=None, lazy_pack=False):
     """srgan.py:249-310 with [B,1] labels.  As in the reference the D step back-propagates through G
     (G is not detached, srgan.py:279) and the G step accumulates into D's gradients, which the
     next D step's zero_grad discards.
     `feature_extractor` (models.FeatureExtractor): adds the reference's VGG content term 6e-3 * MSE(vgg(norm(recon.data)),
     vgg(norm(hr)).detach()) to the reported G loss (srgan.py:301-308).  Both operands are detached in the reference,
     so the term changes the logged scalar only — never a gradient; without an extractor the step
-    returns mse + 1e-3 * GAN, which has the same gradients."""
+    returns mse + 1e-3 * GAN, which has the same gradients.
+    lazy_pack: the two zero_grad() calls skip the filter pack of a model whose plan is current (optim.zero_grad,
+    repack="stale": 2 instead of 4 whole-model packs per step) -- for steps replayed by a graph that knows both
+    FlatParams (GraphedFn(flats=[...]) / GraphedSegments)."""
     from . import utils
+    repack = "stale" if lazy_pack else "always"
     def step(lr_img, hr_img):
         b = lr_img.shape[0]
         real = torch.ones(b, 1, device=lr_img.device)
         fake = torch.zeros(b, 1, device=lr_img.device)
-        d_opt.zero_grad()
+        d_opt.zero_grad(repack=repack)
         d_loss = ops.bce_loss(D(hr_img), real) + ops.bce_loss(D(G(lr_img)), fake)
         _backward(d_loss, d_dp)
         if d_dp is not None:
             d_dp.allreduce_grads()
         d_opt.step()
-        g_opt.zero_grad()
+        g_opt.zero_grad(repack=repack)
         recon = G(lr_img)
         gan_loss = ops.bce_loss(D(recon), real)
         g_loss = ops.mse_loss(recon, hr_img) + 1e-3 * gan_loss
@@ -130,16 +134,17 @@ def srgan_step(G, D, g_opt, d_opt, g_dp=None, d_dp=None, feature_extractor=None)
     return step
 
 
-def srgan_segments(G, D, g_opt, d_opt, g_dp=None, d_dp=None):
+def srgan_segments(G, D, g_opt, d_opt, g_dp=None, d_dp=None, lazy_pack=False):
     """The adversarial step of `srgan_step` cut at its two gradient exchanges, for GraphedSegments:
-    [(D forward/backward, d_dp), (D update + G forward/backward, g_dp), (G update, None)]."""
+    [(D forward/backward, d_dp), (D update + G forward/backward, g_dp), (G update, None)].  lazy_pack: see srgan_step."""
     out = {}
+    repack = "stale" if lazy_pack else "always"
 
     def seg_d(lr_img, hr_img):
         b = lr_img.shape[0]
         real = torch.ones(b, 1, device=lr_img.device)
         fake = torch.zeros(b, 1, device=lr_img.device)
-        d_opt.zero_grad()
+        d_opt.zero_grad(repack=repack)
         out["d"] = ops.bce_loss(D(hr_img), real) + ops.bce_loss(D(G(lr_img)), fake)
         _backward(out["d"], d_dp)
         return out["d"]
@@ -147,7 +152,7 @@ def srgan_segments(G, D, g_opt, d_opt, g_dp=None, d_dp=None):
     def seg_g(lr_img, hr_img):
         real = torch.ones(lr_img.shape[0], 1, device=lr_img.device)
         d_opt.step()
-        g_opt.zero_grad()
+        g_opt.zero_grad(repack=repack)
         recon = G(lr_img)
         out["g"] = ops.mse_loss(recon, hr_img) + 1e-3 * ops.bce_loss(D(recon), real)
         _backward(out["g"], g_dp)
@@ -208,6 +213,11 @@ class GraphedSegments(object):
                 else:
                     ops.join_side_streams()
                 self.plan.append((g, dp, wgraphs, sends, keep))
+        self._flats = [dp.flat for _, dp in segments if dp is not None and hasattr(dp.flat, "mark_changed")]
+        self._seen = {}
+        for f in self._flats:   # same host bookkeeping as after a replay
+            f.mark_changed()
+        _note_epochs(self._flats, self._seen)
 
     def _eager(self):
         out = None
@@ -221,6 +231,7 @@ class GraphedSegments(object):
         for s, b in zip(self.static, batch):
             if b is not s:
                 s.copy_(b, non_blocking=True)
+        _repack_touched(self._flats, self._seen)
         for g, dp, wgraphs, sends, _ in self.plan:
             g.replay()
             if dp is not None and dp.active:
@@ -233,9 +244,9 @@ class GraphedSegments(object):
                 for w in works:
                     w.wait()
         bump_weight_epoch()
-        for _, dp, _, _, _ in self.plan:
-            if dp is not None and hasattr(dp.flat, "mark_changed"):
-                dp.flat.mark_changed()
+        for f in self._flats:
+            f.mark_changed()
+        _note_epochs(self._flats, self._seen)
         return self.out
 
 
@@ -328,6 +339,20 @@ class GraphedStep(object):
         return self.loss
 
 
+def _repack_touched(flats, seen):
+    """Before a replay: a captured multi-model step packs a model's filters only where ITS OWN updates made them stale
+    (optim.zero_grad skips a current plan), so parameters somebody else changed since the last replay (load_state_dict,
+    a broadcast, an eager step in between) are re-packed here, eagerly, in front of the graph."""
+    for f in flats:
+        if seen.get(id(f)) != f.epoch and not f.plan.current():
+            f.plan.pack()
+
+
+def _note_epochs(flats, seen):
+    for f in flats:
+        seen[id(f)] = f.epoch
+
+
 class GraphedFn(object):
     """hipGraph capture of an arbitrary single-GPU step function of tensors (e.g. the two-model, two-optimizer SRGAN
     step, `srgan_step` without data parallelism): static input buffers, `warmup` eager calls on a side stream, one
@@ -349,16 +374,22 @@ class GraphedFn(object):
         with _no_gc_during_capture():
             with _capture(self.graph):
                 self.out = fn(*self.static)
+        self._seen = {}
+        for f in self.flats:   # same host bookkeeping as after a replay
+            f.mark_changed()
+        _note_epochs(self.flats, self._seen)
 
     def __call__(self, *batch):
         for s, b in zip(self.static, batch):
             if b is not s:
                 s.copy_(b, non_blocking=True)
+        _repack_touched(self.flats, self._seen)
         self.graph.replay()
         # weights changed inside the graph: invalidate the packed-filter caches of no-grad forwards (see GraphedStep)
         bump_weight_epoch()
         for f in self.flats:
             f.mark_changed()
+        _note_epochs(self.flats, self._seen)
         return self.out
 
 

@@ -405,3 +405,37 @@ def test_graphed_steps_interleaved_with_eval_forwards(gpu):
             assert torch.equal(y, fresh(probe))
         assert prev is None or not torch.equal(prev, y)
         prev = y
+
+
+def test_graphed_two_model_step_repacks_what_others_changed(gpu):
+    """The captured SRGAN step packs a model's filters only where its own updates made them stale (the discriminator is
+    NOT re-packed at the start of a step).  Parameters changed from outside between two replays -- here: D scaled in
+    place, as a load_state_dict or a broadcast would -- must still reach the next replay (trainers._repack_touched)."""
+    pkg = _pkg()
+    res = {}
+    for mode in ("graph", "eager"):
+        G, D = pkg.SRGANGenerator(3, 64, 2), pkg.SRGANDiscriminator(3, 64, 32)
+        fill.fill_module(G, 11, 0.5)
+        fill.fill_module(D, 12, 0.5)
+        G.to(gpu).train()
+        D.to(gpu).train()
+        gflat, dflat = pkg.optim.FlatParams(G), pkg.optim.FlatParams(D)
+        g_opt = pkg.optim.make_optimizer("srgan_g", gflat, 1e-4)
+        d_opt = pkg.optim.make_optimizer("srgan_d", dflat, 1e-4)
+        lr, hr = B((4, 3, 8, 8), 81).to(gpu), B((4, 3, 32, 32), 82).to(gpu)
+        step = pkg.trainers.srgan_step(G, D, g_opt, d_opt, lazy_pack=True)
+        if mode == "graph":
+            step = pkg.trainers.GraphedFn(step, (lr, hr), warmup=1, flats=[gflat, dflat])
+        else:
+            step(lr, hr)                      # the graph's warm-up call
+        losses = []
+        for i in range(4):
+            if i == 2:                        # somebody else rewrites D between two steps
+                dflat.data.mul_(0.5)
+                dflat.mark_changed()
+            d, g = step(lr, hr)
+            losses.append((float(d), float(g)))
+        res[mode] = losses
+    for (d0, g0), (d1, g1) in zip(res["graph"], res["eager"]):
+        assert abs(d0 - d1) <= 1e-3 * abs(d1) + 1e-6 and abs(g0 - g1) <= 1e-3 * abs(g1) + 1e-6, res
+    assert abs(res["eager"][2][0] - res["eager"][1][0]) > 1e-3 * abs(res["eager"][1][0])   # the rewrite is visible

@@ -13,7 +13,7 @@ G.weight_init(); D.weight_init(); G.to(dev).train(); D.to(dev).train()
 gflat, dflat = pkg.optim.FlatParams(G), pkg.optim.FlatParams(D)
 g_opt, d_opt = pkg.optim.make_optimizer("srgan_g", gflat, 1e-4), pkg.optim.make_optimizer("srgan_d", dflat, 1e-4)
 x = torch.rand(16, 3, 32, 32, device=dev); t = torch.rand(16, 3, 128, 128, device=dev)
-step = pkg.trainers.GraphedFn(pkg.trainers.srgan_step(G, D, g_opt, d_opt), (x, t), flats=[gflat, dflat])
+step = pkg.trainers.GraphedFn(pkg.trainers.srgan_step(G, D, g_opt, d_opt, lazy_pack=True), (x, t), flats=[gflat, dflat])
 for _ in range(3): step(x, t)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
