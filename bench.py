@@ -344,6 +344,17 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
         out["c5_srgan_ms_per_step"] = round(1e3 * sec / k, 3)
         fwd = 2 * C5_G_FWD + 3 * C5_D_FWD      # as executed by the reference: G fwd x2, D fwd x3, ...
         out["c5_srgan_bf16_pipe_frac"] = round(bf16_pipe_frac(fwd, 2 * fwd, sec / k / 16), 4)
+        if not multi:
+            # NOT the c5 metric: the same iteration without the two gradient computations whose results the reference
+            # discards (G's in the D step, D's parameter gradients in the G step; `main.py --prune_dead_grads`) -- same
+            # parameters after every step, listed beside the faithful number for what the option is worth
+            del sstep          # (the first graph goes before the second one is captured)
+            import gc
+            gc.collect()
+            pstep = pkg.trainers.GraphedFn(pkg.trainers.srgan_step(G, D, g_opt, d_opt, lazy_pack=True, prune_dead_grads=True),
+                                           (lr_img, hr_img), flats=[gflat, dflat])
+            sec_p = time_steps(lambda: pstep(lr_img, hr_img), k, 3, 1, dev)
+            out["c5_srgan_ms_per_step_dead_gradients_pruned_not_the_metric"] = round(1e3 * sec_p / k, 3)
 
     # every side metric is isolated: a failure is reported in the JSON instead of losing the headline line
     sections = ([("c1", c1), ("c3", c3)] if not multi else []) + [("c4_strong", c4_strong)] + \

@@ -1125,6 +1125,12 @@ class _Linear(torch.autograd.Function):
         has_bias = ctx.bias_ref is not None
         wacc = getattr(ctx.weight_ref, "_srk_grad", None)
         bacc = getattr(ctx.bias_ref, "_srk_grad", None) if has_bias else None
+        need_w = ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
+        if not need_w:   # frozen parameters (trainers.srgan_step(prune_dead_grads=True)): data gradient only
+            if dx is not None:
+                check(lib.srk_linear_backward(ptr(x), ptr(weight), ptr(dy), ptr(dx), None, None, b, fin, fout, 0.0,
+                                              stream_ptr()), "srk_linear_backward")
+            return dx, None, None, None, None
         if wacc is not None and (not has_bias or bacc is not None):
             check(lib.srk_linear_backward(ptr(x), ptr(weight), ptr(dy), ptr(dx), ptr(wacc), ptr(bacc), b, fin, fout,
                                           1.0, stream_ptr()), "srk_linear_backward")

@@ -368,7 +368,8 @@ class SRGAN(_Trainer):
             if self.rank == 0:
                 self.save_model(is_pretrain=True)
         # the adversarial step (two models, two optimizers) as one hipGraph; data parallel: graphs split at the two exchanges
-        eager_step = trainers.srgan_step(self.G, self.D, g_opt, d_opt, g_dp, d_dp, lazy_pack=True)
+        eager_step = trainers.srgan_step(self.G, self.D, g_opt, d_opt, g_dp, d_dp, lazy_pack=True,
+                                         prune_dead_grads=bool(getattr(self.args, "prune_dead_grads", False)))
 
         def make_graph(ts):
             if g_dp is not None and g_dp.active:

@@ -93,7 +93,7 @@ def lapsrn_step(model, opt, dp=None):
     return step
 
 
-def srgan_step(G, D, g_opt, d_opt, g_dp=None, d_dp=None, feature_extractor=None, lazy_pack=False):
+def srgan_step(G, D, g_opt, d_opt, g_dp=None, d_dp=None, feature_extractor=None, lazy_pack=False, prune_dead_grads=False):
     """srgan.py:249-310 with [B,1] labels.  As in the reference the D step back-propagates through G
     (G is not detached, srgan.py:279) and the G step accumulates into D's gradients, which the
     next D step's zero_grad discards.
@@ -103,22 +103,45 @@ def srgan_step(G, D, g_opt, d_opt, g_dp=None, d_dp=None, feature_extractor=None,
     returns mse + 1e-3 * GAN, which has the same gradients.
     lazy_pack: the two zero_grad() calls skip the filter pack of a model whose plan is current (optim.zero_grad,
     repack="stale": 2 instead of 4 whole-model packs per step) -- for steps replayed by a graph that knows both
-    FlatParams (GraphedFn(flats=[...]) / GraphedSegments)."""
+    FlatParams (GraphedFn(flats=[...]) / GraphedSegments).
+    prune_dead_grads (NOT the reference's execution, off by default and in bench.py's c5): the reference computes two sets
+    of gradients nobody reads -- G's from D_loss.backward() (G_optimizer.zero_grad() clears them before the G step,
+    srgan.py:287-291) and D's parameter gradients from G_loss.backward() (cleared by the next iteration's
+    D_optimizer.zero_grad(), srgan.py:272).  With the flag the D step sees G's output detached and the G step runs D
+    with its parameters frozen (data gradients only).  Parameters, optimizer states and BatchNorm statistics after the
+    step are the faithful step's (up to the summation order inside the grouped weight-gradient launches, whose split
+    depends on how many layers share a launch); D's `.grad` then holds the D step's gradients only.  Single GPU / eager
+    DP path only (the DP graph segments keep the reference's execution)."""
     from . import utils
     repack = "stale" if lazy_pack else "always"
+    d_params = [p for p in D.parameters()] if prune_dead_grads else []
+
+    def freeze_d(flag):
+        for p in d_params:
+            p.requires_grad_(not flag)
+
     def step(lr_img, hr_img):
         b = lr_img.shape[0]
         real = torch.ones(b, 1, device=lr_img.device)
         fake = torch.zeros(b, 1, device=lr_img.device)
         d_opt.zero_grad(repack=repack)
-        d_loss = ops.bce_loss(D(hr_img), real) + ops.bce_loss(D(G(lr_img)), fake)
+        recon_d = G(lr_img)      # (in grad mode either way: the same kernels and precision class as the reference path)
+        d_loss = ops.bce_loss(D(hr_img), real) + ops.bce_loss(D(recon_d.detach() if prune_dead_grads else recon_d), fake)
+        del recon_d
         _backward(d_loss, d_dp)
         if d_dp is not None:
             d_dp.allreduce_grads()
         d_opt.step()
         g_opt.zero_grad(repack=repack)
         recon = G(lr_img)
-        gan_loss = ops.bce_loss(D(recon), real)
+        if prune_dead_grads:
+            freeze_d(True)
+            try:
+                gan_loss = ops.bce_loss(D(recon), real)
+            finally:
+                freeze_d(False)
+        else:
+            gan_loss = ops.bce_loss(D(recon), real)
         g_loss = ops.mse_loss(recon, hr_img) + 1e-3 * gan_loss
         if feature_extractor is not None:
             with torch.no_grad():   # srgan.py:301-305 (the inputs are already normalised once, as in the reference)

@@ -439,3 +439,40 @@ def test_graphed_two_model_step_repacks_what_others_changed(gpu):
     for (d0, g0), (d1, g1) in zip(res["graph"], res["eager"]):
         assert abs(d0 - d1) <= 1e-3 * abs(d1) + 1e-6 and abs(g0 - g1) <= 1e-3 * abs(g1) + 1e-6, res
     assert abs(res["eager"][2][0] - res["eager"][1][0]) > 1e-3 * abs(res["eager"][1][0])   # the rewrite is visible
+
+
+def test_srgan_step_without_its_dead_gradients(gpu):
+    """srgan_step(prune_dead_grads=True) skips the two gradient computations of the reference's iteration that nothing
+    reads (G's in the D step, D's parameter gradients in the G step): parameters, Adam states and BatchNorm statistics
+    after each step must be the ones of the faithful step (parameters and statistics bit for bit)."""
+    pkg = _pkg()
+    res = {}
+    for prune in (False, True):
+        G, D = pkg.SRGANGenerator(3, 64, 2), pkg.SRGANDiscriminator(3, 64, 32)
+        fill.fill_module(G, 21, 0.5)
+        fill.fill_module(D, 22, 0.5)
+        G.to(gpu).train()
+        D.to(gpu).train()
+        gflat, dflat = pkg.optim.FlatParams(G), pkg.optim.FlatParams(D)
+        g_opt = pkg.optim.make_optimizer("srgan_g", gflat, 1e-4)
+        d_opt = pkg.optim.make_optimizer("srgan_d", dflat, 1e-4)
+        lr, hr = B((4, 3, 8, 8), 83).to(gpu), B((4, 3, 32, 32), 84).to(gpu)
+        step = pkg.trainers.srgan_step(G, D, g_opt, d_opt, prune_dead_grads=prune)
+        losses = [tuple(float(v.detach()) for v in step(lr, hr)) for _ in range(3)]
+        torch.cuda.synchronize()
+        bn = torch.cat([torch.cat([m.running_mean, m.running_var]) for net in (G, D) for m in net.modules()
+                        if isinstance(m, torch.nn.BatchNorm2d)])
+        states = [getattr(o, k).clone() for o in (g_opt, d_opt) for k in ("buf", "exp_avg", "exp_avg_sq")
+                  if getattr(o, k, None) is not None]
+        res[prune] = tuple([[tuple(float(v) for v in l) for l in losses], gflat.data.clone(), dflat.data.clone(), bn,
+                            gflat.grad.clone()] + states)
+        assert all(p.requires_grad for p in D.parameters())
+    assert res[True][0] == res[False][0]
+    names = ["G params", "D params", "BatchNorm running statistics", "G gradients"] + ["optimizer state %d" % i for i in range(8)]
+    for what, a, b in zip(names, res[True][1:], res[False][1:]):
+        if what == "G gradients" or what.startswith("optimizer"):
+            # (the weight gradients of a step are launched grouped by geometry and a group's split-K partition depends on
+            #  how many layers share it: without D's dead records G's groups split differently -- last-bit differences)
+            assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()), what
+        else:
+            assert torch.equal(a, b), (what, float((a - b).abs().max()), float(b.abs().max()))
