@@ -150,11 +150,18 @@ class ResnetBlock(_Block):
             if not fuse:
                 out = self.act(out)
             return self.conv2.run(out, ACT_NONE, 0.0, None, residual, res_box=box)  # conv2 + residual add, one kernel
+        fused_bn = isinstance(self.bn, BatchNorm2d) and ops.bn_fusable(x, kind, pw, self.bn)
+        if fused_bn and training and x.requires_grad and ops.FUSE_SKIP_GRAD:
+            # as in the no-norm block: the skip gradient (= the block output gradient, handed over by the second
+            # BatchNorm's backward) is added by conv1's data-gradient kernel -- no fan-in pass of its own
+            box = ops.GradBox()
+            out = self.bn.run(self.conv1.run(x, add_box=box), kind, slope, pw)
+            return self.bn.run(self.conv2.run(out), residual=x, res_box=box)
         if training:
             x, residual = ops.fork(x)  # gradient fan-in summed by srk_axpby
         else:
             residual = x
-        if isinstance(self.bn, BatchNorm2d) and ops.bn_fusable(x, kind, pw, self.bn):
+        if fused_bn:
             # act(bn(conv1)) and bn(conv2) + x each in the BatchNorm's own launches (ONE shared bn: base_networks.py:117)
             out = self.bn.run(self.conv1.run(x), kind, slope, pw)
             return self.bn.run(self.conv2.run(out), residual=residual)

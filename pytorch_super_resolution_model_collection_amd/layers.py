@@ -125,14 +125,15 @@ class BatchNorm2d(torch.nn.BatchNorm2d):
 
     sync_group = None
 
-    def run(self, x, act=ACT_NONE, slope=0.0, prelu_w=None, residual=None):
-        """act(bn(x)) [+ residual] in the BatchNorm's own launches (callers check ops.bn_fusable first)."""
+    def run(self, x, act=ACT_NONE, slope=0.0, prelu_w=None, residual=None, res_box=None):
+        """act(bn(x)) [+ residual] in the BatchNorm's own launches (callers check ops.bn_fusable first).  res_box: the
+        ops.GradBox that takes the residual's gradient (see ResnetBlock)."""
         training = self.training or self.running_mean is None
         momentum = 0.1 if self.momentum is None else self.momentum
         # (num_batches_tracked is bumped by the finalize kernel: no launch of its own)
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, training, momentum,
                               self.eps, self.sync_group if training else None,
-                              self.num_batches_tracked if training else None, act, slope, prelu_w, residual)
+                              self.num_batches_tracked if training else None, act, slope, prelu_w, residual, res_box)
 
     def forward(self, x):
         return self.run(x)

@@ -818,8 +818,9 @@ class _BatchNorm(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, sync_group, nbt=None,
-                act=ACT_NONE, slope=0.0, prelu_w=None, residual=None):
+                act=ACT_NONE, slope=0.0, prelu_w=None, residual=None, res_box=None):
         lib = _lib.load()
+        ctx.res_box = res_box
         require_cuda(x, gamma, beta, prelu_w, residual)
         x = _dense(x)   # [N,C,H,W] stored NHWC, or [B,F] (BatchNorm1d of DenseBlock, base_networks.py:13): rows x C
         c = x.shape[1]
@@ -882,6 +883,8 @@ class _BatchNorm(torch.autograd.Function):
             dgamma = ret_g = torch.zeros(c, dtype=torch.float32, device=x.device)
             dbeta = ret_b = torch.zeros(c, dtype=torch.float32, device=x.device)
         dres = dy if ctx.has_res else None   # the residual's gradient is dy itself
+        if ctx.has_res and ctx.res_box is not None:
+            ctx.res_box.g, dres = dy, None   # parked for the block's first conv, which adds it in its data-gradient kernel
         if ctx.act != ACT_NONE:
             dprelu = None
             pn = 0 if prelu_w is None else prelu_w.numel()
@@ -901,7 +904,7 @@ class _BatchNorm(torch.autograd.Function):
             check(lib.srk_bn_backward_apply_act(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(use),
                                                 ctx.count, ptr(dx), rows, c, ctx.act, ctx.slope, ptr(prelu_w), pn,
                                                 stream_ptr()), "srk_bn_backward_apply_act")
-            return dx, ret_g, ret_b, None, None, None, None, None, None, None, None, None, ret_p, dres
+            return dx, ret_g, ret_b, None, None, None, None, None, None, None, None, None, ret_p, dres, None
         # statistics of the backward + the parameter gradients (from the LOCAL sums: the DP gradient all-reduce happens
         # later) in two launches
         check(lib.srk_bn_backward_stats_grads(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(dstats), rows, c, ptr(dgamma),
@@ -914,15 +917,16 @@ class _BatchNorm(torch.autograd.Function):
         use = dstats if ctx.training else torch.zeros_like(dstats)
         check(lib.srk_bn_backward_apply(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(use), ctx.count,
                                         ptr(dx), rows, c, stream_ptr()), "srk_bn_backward_apply")
-        return dx, ret_g, ret_b, None, None, None, None, None, None, None, None, None, None, dres
+        return dx, ret_g, ret_b, None, None, None, None, None, None, None, None, None, None, dres, None
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, sync_group=None,
-               num_batches_tracked=None, act=ACT_NONE, slope=0.0, prelu_w=None, residual=None):
+               num_batches_tracked=None, act=ACT_NONE, slope=0.0, prelu_w=None, residual=None, res_box=None):
     """nn.BatchNorm2d (base_networks.py:46,117,161) on [N,C,H,W]; nn.BatchNorm1d (base_networks.py:13) on [B,F].
-    act / prelu_w / residual: y = act(bn(x)) [+ residual] in the same launches (see bn_fusable)."""
+    act / prelu_w / residual: y = act(bn(x)) [+ residual] in the same launches (see bn_fusable).  res_box: GradBox the
+    residual's gradient is parked in instead of being returned to autograd (the block's first conv adds it)."""
     return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, bool(training), float(momentum), float(eps),
-                            sync_group, num_batches_tracked, int(act), float(slope), prelu_w, residual)
+                            sync_group, num_batches_tracked, int(act), float(slope), prelu_w, residual, res_box)
 
 
 def bn_fusable(x, act, prelu_w=None, bn=None):
