@@ -14,6 +14,7 @@ nn.Parameter objects stay in place (their .data / .grad become views), so state_
 reference's checkpoint files keep working.
 """
 import ctypes
+import os
 
 import torch
 
@@ -119,7 +120,7 @@ class PackPlan(object):
         self.table = torch.tensor(rows, dtype=torch.int64, device=dev)
         self.epoch = -1
         biggest = max(r[3] * r[4] * r[5] * r[6] for r in rows)
-        self.blocks = max(1, min(64, (biggest + 255) // 256))
+        self.blocks = max(1, min(int(os.environ.get("SRK_PACK_BLOCKS", "512")), (biggest + 255) // 256))
         for m, fo, nf, bo, nb, bp_off, cout, ps_r in self.layers:
             wpf = self.buf[fo:fo + (nf + 3) // 4 * 4].view(torch.float32)
             wpb = self.buf[bo:bo + (nb + 3) // 4 * 4].view(torch.float32)
