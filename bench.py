@@ -67,6 +67,38 @@ def max_over_ranks(seconds, world, dev):
     return float(t.item())
 
 
+def span_over_ranks(seconds, world, dev):
+    """(min, max) over ranks of a per-rank time -- how far apart the ranks finish the same timed region."""
+    if world == 1 and not torch.distributed.is_initialized():
+        return seconds, seconds
+    t = torch.tensor([seconds, -seconds], dtype=torch.float64, device=dev)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return float(-t[1].item()), float(t[0].item())
+
+
+def rank_local_steps(fn, steps, warmup, dev):
+    """Per-rank time of `steps` calls with NO barrier on either side (device-synchronised only): what this rank's GPU
+    needs on its own, to be compared over ranks."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def rccl_ranks_seen(dev):
+    """SUM all-reduce of a ones tensor: the number of ranks the collective library really connected (WORLD_SIZE is only
+    what the launcher claimed).  None without a process group."""
+    if not torch.distributed.is_initialized():
+        return None
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    torch.distributed.all_reduce(one, op=torch.distributed.ReduceOp.SUM)
+    return int(round(float(one.item())))
+
+
 def time_steps(fn, steps, warmup, world, dev):
     for _ in range(warmup):
         fn()
@@ -139,8 +171,14 @@ def cpu_baseline(batch_cap=8, lr_size=256):
                 dt = time.perf_counter() - t0
                 if i >= 2 and (best is None or dt < best):
                     best, best_threads = dt, nthr
-    return {"value": round(batch_cap / best, 2), "unit": "images/s", "cores": best_threads, "host_threads": ncpu,
-            "kind": "port",
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False)
+    except Exception:  # noqa: BLE001
+        physical = None
+    # "cores" = the torch threads the reported (best) run used, as the bench contract defines it; the box's hardware is beside it
+    return {"value": round(batch_cap / best, 2), "unit": "images/s", "cores": best_threads, "threads": best_threads,
+            "physical_cores": physical, "host_threads": ncpu, "kind": "port",
             "sample": "oracle ESPCN x4 forward (stock torch.nn CPU fp32), batch %d of %dx%d LR, best of 3 at the best of "
                       "%s threads" % (batch_cap, lr_size, lr_size, sorted({ncpu, ncpu // 2, ncpu // 4, 32, 16, 8}))}
 
@@ -162,6 +200,9 @@ def bf16_pipe_frac(fwd_flop, bwd_flop, seconds_per_sample, fwd_x3_flop=0.0):
         (BF16_MFMA_PEAK_TFLOPS * 1e12)
 
 
+PROGRESS = {"section": "start", "since": 0.0}   # which side metric is running (read by the watchdog)
+
+
 def extras_watchdog(result, extra, rank, seconds):
     """N > 1 only.  A side metric that dies on ONE rank (say a refused graph capture) leaves the others waiting in a
     collective for ever, and the headline line -- measured before any of them -- would never be printed.  After `seconds`
@@ -171,7 +212,9 @@ def extras_watchdog(result, extra, rank, seconds):
 
     def fire():
         if rank == 0 and result is not None:
-            extra["extras_error"] = "side metrics did not finish within %d s (SRK_BENCH_EXTRA_TIMEOUT); headline unaffected" % seconds
+            extra["extras_error"] = ("side metrics did not finish within %d s (SRK_BENCH_EXTRA_TIMEOUT); headline unaffected; "
+                                     "section running when the watchdog fired: %s (for %.0f s)"
+                                     % (seconds, PROGRESS["section"], time.perf_counter() - PROGRESS["since"]))
             result["extra"] = dict(extra)
             print(json.dumps(result), flush=True)
         sys.stdout.flush()
@@ -205,9 +248,13 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
         step = pkg.trainers.GraphedStep(net, opt, loss_fn, (inp, tgt), dp=dp, clip=clip, warmup=2)
         sec = time_steps(lambda: step(inp, tgt), steps, warmup, world if use_dp else 1, dev)
         sec_nocomm = None
+        run.rank_span = None
         if dp is not None:   # the same step with the all-reduces skipped: the difference is the exposed communication
             dp.comm_enabled = False
             sec_nocomm = time_steps(lambda: step(inp, tgt), steps, 2, world, dev)
+            # ... and what every rank's GPU needs for its own shard with nobody to wait for (min / max over ranks)
+            local = rank_local_steps(lambda: step(inp, tgt), steps, 2, dev)
+            run.rank_span = span_over_ranks(local / steps, world, dev)
             dp.comm_enabled = True
         torch.cuda.synchronize()
         step.close()          # graphs are destroyed here, never by the garbage collector in the middle of a later capture
@@ -284,6 +331,10 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
                              "all-reduces issued behind the grouped weight-gradient launches)" % world)
         if nocomm is not None:
             out["c4_exposed_comm_ms"] = round(1e3 * (sec - nocomm) / k, 3)
+            out["c4_ms_per_step_without_exchange"] = round(1e3 * nocomm / k, 3)
+        if run.rank_span is not None:
+            out["c4_rank_local_ms_per_step_min_max"] = [round(1e3 * v, 3) for v in run.rank_span]
+            out["c4_gradient_bytes_per_step"] = 4 * sum(p.numel() for p in edsr().parameters())
         if not multi:
             # the same step with fp32-faithful (bf16x6) products in EVERY forward conv: by default the activation-free
             # tail of the net (body-end, upsampler and reconstruction convs) runs its training forward on bf16x3
@@ -313,6 +364,8 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
         out["c4_weak_ms_per_step"] = round(1e3 * sec / k, 3)
         if nocomm is not None:
             out["c4_weak_exposed_comm_ms"] = round(1e3 * (sec - nocomm) / k, 3)
+        if run.rank_span is not None:
+            out["c4_weak_rank_local_ms_per_step_min_max"] = [round(1e3 * v, 3) for v in run.rank_span]
 
     def c5():
         # SRGAN x4 generator + discriminator adversarial step (srgan.py:249-310), reference default batch 16 per GPU,
@@ -338,8 +391,8 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
         else:
             sstep = pkg.trainers.GraphedFn(pkg.trainers.srgan_step(G, D, g_opt, d_opt, lazy_pack=True), (lr_img, hr_img),
                                            flats=[gflat, dflat])
-        k = max(6, nsteps // 2)
-        sec = time_steps(lambda: sstep(lr_img, hr_img), k, 3, world, dev)
+        k = max(20, nsteps)
+        sec = time_steps(lambda: sstep(lr_img, hr_img), k, 5, world, dev)
         out["c5_srgan_x4_adv_step_patches_per_s_batch_16_per_gpu"] = round(world * 16 * k / sec, 1)
         out["c5_srgan_ms_per_step"] = round(1e3 * sec / k, 3)
         fwd = 2 * C5_G_FWD + 3 * C5_D_FWD      # as executed by the reference: G fwd x2, D fwd x3, ...
@@ -353,13 +406,14 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
             gc.collect()
             pstep = pkg.trainers.GraphedFn(pkg.trainers.srgan_step(G, D, g_opt, d_opt, lazy_pack=True, prune_dead_grads=True),
                                            (lr_img, hr_img), flats=[gflat, dflat])
-            sec_p = time_steps(lambda: pstep(lr_img, hr_img), k, 3, 1, dev)
+            sec_p = time_steps(lambda: pstep(lr_img, hr_img), k, 5, 1, dev)
             out["c5_srgan_ms_per_step_dead_gradients_pruned_not_the_metric"] = round(1e3 * sec_p / k, 3)
 
     # every side metric is isolated: a failure is reported in the JSON instead of losing the headline line
     sections = ([("c1", c1), ("c3", c3)] if not multi else []) + [("c4_strong", c4_strong)] + \
                ([("c4_shard16", c4_shard16)] if not multi else [("c4_weak", c4_weak)]) + [("c5", c5)]
     for name, fn in sections:
+        PROGRESS["section"], PROGRESS["since"] = name, time.perf_counter()
         try:
             fn()
         except Exception as e:  # noqa: BLE001 - reported, not swallowed
@@ -367,6 +421,7 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
         import gc
         gc.collect()
         torch.cuda.empty_cache()
+    PROGRESS["section"], PROGRESS["since"] = "done", time.perf_counter()
     return out
 
 
@@ -421,6 +476,8 @@ def main():
     assert tuple(y.shape) == (args.batch, 3, 4 * (args.lr_size - 8), 4 * (args.lr_size - 8))
     sec = time_steps(step, args.steps, args.warmup, world, dev)
     imgs_per_s = world * args.batch * args.steps / sec
+    ranks_seen = rccl_ranks_seen(dev)
+    local_span = span_over_ranks(rank_local_steps(step, args.steps, 1, dev) / args.steps, world, dev)
     layer_ms, layer_kernels = espcn_layer_events(net, x, max(3, min(args.steps, 10)))
 
     # measured device-to-device copy bandwidth on this box (read + write bytes / time), beside the vendor peak
@@ -482,6 +539,14 @@ def main():
                              ESPCN_FLOP_PER_IMG * scale * imgs_per_s / world / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
         }
     extra = {}
+    if torch.distributed.is_initialized():
+        # what the collective library saw, so that an N > 1 record explains itself
+        extra["rccl_ranks_seen"] = ranks_seen
+        extra["dist_backend"] = torch.distributed.get_backend()
+        extra["c2_rank_local_ms_per_step_min_max"] = [round(1e3 * v, 4) for v in local_span]
+        extra["c2_images_per_s_per_gpu"] = round(imgs_per_s / world, 1)   # compare with the N = 1 record's `value`
+        if ranks_seen != world and rank == 0 and result is not None:
+            extra["rccl_error"] = "all-reduce of ones returned %s for WORLD_SIZE %d" % (ranks_seen, world)
     if not args.no_extra:
         dog = None
         if torch.distributed.is_initialized():

@@ -1,10 +1,17 @@
 #!/usr/bin/env python3
 """Entry point with the reference's command line (main.py:13-36: the same 15 flags and defaults)
-dispatching to the MI355X trainers.  Extra flags: --steps_per_epoch (synthetic patches per epoch when
-the image folders under --data_dir do not exist), --epoch_pretrain and --precision {mixed,bf16x3,fp32}.
+dispatching to the MI355X trainers.  Extra flags: --synthetic (seeded random patches instead of the image
+folders under --data_dir; --steps_per_epoch of them per epoch), --epoch_pretrain and --precision {mixed,bf16x3,fp32}.
 Multi-GPU: python -m torch.distributed.run --nproc-per-node N main.py ..."""
 import argparse
 import os
+
+
+def _names(text):
+    """--train_dataset / --test_dataset: the reference declares them `type=list` (main.py:18-19), which turns a value
+    given on the command line into its characters ('DIV2K' -> ['D','I','V','2','K']); here a value is one name or a
+    comma-separated list of names."""
+    return [n for n in (t.strip() for t in str(text).split(',')) if n]
 
 
 def parse_args(argv=None):
@@ -12,8 +19,8 @@ def parse_args(argv=None):
     p.add_argument('--model_name', type=str, default='SRGAN',
                    choices=['SRCNN', 'VDSR', 'ESPCN', 'FSRCNN', 'SRGAN', 'LapSRN', 'EDSR'], help='The type of model')
     p.add_argument('--data_dir', type=str, default='../Data')
-    p.add_argument('--train_dataset', type=list, default=['DIV2K'], help='The name of training dataset')
-    p.add_argument('--test_dataset', type=list, default=['Set5', 'Set14', 'Urban100'], help='The name of test dataset')
+    p.add_argument('--train_dataset', type=_names, default=['DIV2K'], help='The name(s) of the training dataset, comma-separated')
+    p.add_argument('--test_dataset', type=_names, default=['Set5', 'Set14', 'Urban100'], help='The name(s) of the test dataset, comma-separated')
     p.add_argument('--crop_size', type=int, default=128, help='Size of cropped HR image')
     p.add_argument('--num_threads', type=int, default=4, help='number of threads for data loader to use')
     p.add_argument('--num_channels', type=int, default=3, help='The number of channels to super-resolve')
@@ -25,7 +32,10 @@ def parse_args(argv=None):
     p.add_argument('--save_dir', type=str, default='Result_DIV2K', help='Directory name to save the results')
     p.add_argument('--lr', type=float, default=0.00001)
     p.add_argument('--gpu_mode', type=bool, default=True)
-    p.add_argument('--steps_per_epoch', type=int, default=8)
+    p.add_argument('--synthetic', action='store_true',
+                   help='train / test on seeded random patches instead of the image folders under --data_dir '
+                        '(without it a missing folder is an error, as in the reference)')
+    p.add_argument('--steps_per_epoch', type=int, default=8, help='--synthetic: batches per epoch')
     p.add_argument('--epoch_pretrain', type=int, default=50, help='SRGAN generator pre-training epochs (srgan.py:179)')
     p.add_argument('--precision', type=str, default='mixed', choices=['mixed', 'bf16x3', 'bf16x6', 'fp32'])
     p.add_argument('--eager', action='store_true', help='launch every kernel of a train step from Python (default: replay the step as a hipGraph)')

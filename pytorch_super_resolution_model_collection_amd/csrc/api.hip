@@ -318,8 +318,15 @@ extern "C" size_t srk_conv2d_backward_weight_grouped_workspace_bytes(const srk_c
   if (!d || n < 1) return 0;
   size_t a = srk_conv2d_backward_weight_workspace_bytes(d);
   if (wgrad_group_uses_bf(*d)) {
-    const int chunk = n < kMaxWgradGroup ? n : kMaxWgradGroup;
-    const size_t b = conv_wgrad_bf_grouped_ws(*d, chunk);
+    // the call runs chunks of kMaxWgradGroup layers and one of n % kMaxWgradGroup; the slab count of a chunk is not
+    // monotonic in its layer count (G = blocks / layers is rounded), so size for every chunk length the call will use
+    const int full = n < kMaxWgradGroup ? n : kMaxWgradGroup;
+    const int rest = n > kMaxWgradGroup ? n % kMaxWgradGroup : 0;
+    size_t b = conv_wgrad_bf_grouped_ws(*d, full);
+    if (rest) {
+      const size_t c = conv_wgrad_bf_grouped_ws(*d, rest);
+      if (c > b) b = c;
+    }
     if (b > a) a = b;
   }
   return a;

@@ -386,8 +386,14 @@ class PatchLoader(object):
     one trains), pixels cross PCIe as uint8 through pinned memory, all transforms run on the loader's HIP stream, and a
     batch costs 2-3 small launches per patch plus three batched resizes.  Yields (lr, hr, bc) CUDA batches."""
 
-    def __init__(self, dataset, batch_size, shuffle=True, num_threads=4, drop_last=False, seed=None, background=True):
+    def __init__(self, dataset, batch_size, shuffle=True, num_threads=4, drop_last=False, seed=None, background=True,
+                 rank=0, world=1):
         self.ds, self.batch_size, self.shuffle, self.drop_last = dataset, int(batch_size), shuffle, drop_last
+        # data parallel (world > 1): every rank draws the SAME permutation per epoch (so `seed` must be common; default
+        # 0) and takes its own strided 1/world of it, wrapped around so that all ranks see the same number of batches
+        self.rank, self.world = int(rank), max(1, int(world))
+        if self.world > 1 and seed is None:
+            seed = 0
         # background: batches are produced by a loader thread up to two ahead of the consumer (its host work -- draws,
         # one call per patch, three batched resizes -- overlaps with the consumer launching / replaying the train step)
         self.background = bool(background) and os.environ.get("SRK_LOADER_THREAD", "1") != "0"
@@ -396,13 +402,25 @@ class PatchLoader(object):
         if seed is not None:
             self.gen.manual_seed(int(seed))
 
+    def _shard_len(self):
+        return -(-len(self.ds) // self.world)      # ceil: short ranks wrap around (torch's DistributedSampler rule)
+
     def __len__(self):
-        n = len(self.ds)
+        n = self._shard_len()
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
-    def _batches(self):
+    def _order(self):
+        """This rank's image indices of one epoch."""
         n = len(self.ds)
         order = torch.randperm(n, generator=self.gen).tolist() if self.shuffle else list(range(n))
+        if self.world > 1:
+            per = self._shard_len()
+            order = (order + order[:per * self.world - n])[self.rank:per * self.world:self.world]
+        return order
+
+    def _batches(self):
+        order = self._order()
+        n = len(order)
         for i in range(0, n, self.batch_size):
             idx = order[i:i + self.batch_size]
             if len(idx) < self.batch_size and self.drop_last:

@@ -1068,7 +1068,7 @@ def psnr(pred, gt):
     return out[0], out[1]
 
 
-def channel_affine(x, sub, div, clamp01=False):
+def _channel_affine_raw(x, sub, div, clamp01=False):
     """y = (x - sub[c]) / div[c] per channel (utils.norm / utils.denorm, utils.py:219-239), same storage layout as x
     ([C,H,W] / [B,C,H,W] NCHW-contiguous or channels_last); bit-equal to torchvision's Normalize."""
     lib = _lib.load()
@@ -1095,6 +1095,31 @@ def channel_affine(x, sub, div, clamp01=False):
     check(lib.srk_channel_affine(ptr(xs), ptr(y), xs.numel(), c, inner, fa, fb, int(bool(clamp01)), stream_ptr()),
           "srk_channel_affine")
     return y if x.dim() == 4 else y[0]
+
+
+class _ChannelAffine(torch.autograd.Function):
+    """(x - sub[c]) / div[c] with its gradient dy / div[c] (the same kernel with sub = 0)."""
+
+    @staticmethod
+    def forward(ctx, x, sub, div):
+        ctx.div = tuple(float(v) for v in div)
+        return _channel_affine_raw(x, sub, div)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _channel_affine_raw(dy, (0.0,) * len(ctx.div), ctx.div), None, None
+
+
+def channel_affine(x, sub, div, clamp01=False):
+    """utils.norm / utils.denorm (utils.py:219-239).  Differentiable like the reference's tensor arithmetic when x
+    requires grad; the clamped form ((img + 1) / 2).clamp(0, 1) is only available without a graph (the reference uses it
+    on detached images when it saves results) and raises otherwise instead of dropping the gradient silently."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        if clamp01:
+            raise RuntimeError("channel_affine(clamp01=True) has no backward: call it on a detached tensor "
+                               "(utils.denorm of an image that requires grad)")
+        return _ChannelAffine.apply(x, tuple(sub), tuple(div))
+    return _channel_affine_raw(x, sub, div, clamp01)
 
 
 class _Linear(torch.autograd.Function):

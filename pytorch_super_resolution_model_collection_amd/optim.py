@@ -58,6 +58,19 @@ class FlatParams(object):
         bump_weight_epoch()
         self.epoch = 0           # bumped whenever the flat parameters change (optimizer step, load_state_dict)
         self.plan = PackPlan(module, self)
+        # load_state_dict copies into the parameter views in place: the packed filters (PackPlan, no-grad caches) and
+        # the graphs that skip a current plan (trainers._repack_touched compares `epoch`) must see that as a change
+        self._load_hook = None
+        if hasattr(module, "register_load_state_dict_post_hook"):
+            import weakref
+            me = weakref.ref(self)
+
+            def _loaded(mod, incompatible_keys):
+                f = me()
+                if f is not None:
+                    f.mark_changed()
+
+            self._load_hook = module.register_load_state_dict_post_hook(_loaded)
 
     def zero_grad(self):
         from . import ops

@@ -97,10 +97,16 @@ class _Trainer(object):
     def load_dataset(self, dataset, is_train=True):
         """edsr.py:67-84 / srgan.py:110-129: the image-folder loaders of data.py behind the reference's directory layout
         (data_dir/<dataset>/..., DIV2K_train_LR_bicubic/X4 for DIV2K), as data.PatchLoader (decode on host threads,
-        uint8 over PCIe through pinned memory, every transform on the GPU).  None when a folder is missing — the
-        trainer then runs on seeded synthetic patches."""
+        uint8 over PCIe through pinned memory, every transform on the GPU).  Under data parallelism every rank draws the
+        same per-epoch permutation and takes its own 1/world of it (PatchLoader rank / world).
+        A missing or empty TRAINING folder raises, as the reference's DataLoader would -- unless the run asked for
+        seeded synthetic patches (`--synthetic`), in which case None is returned.  Missing TEST folders return None:
+        test() evaluates the test sets that exist (the reference's list names three)."""
         from . import data
         is_gray = self.num_channels == 1
+        synthetic = bool(getattr(self.args, "synthetic", False))
+        if synthetic:
+            return None
         try:
             if is_train:
                 ds = data.get_training_set(self.data_dir, dataset, self.crop_size, self.scale_factor, is_gray=is_gray,
@@ -109,11 +115,25 @@ class _Trainer(object):
             else:
                 ds = data.get_test_set(self.data_dir, dataset, self.scale_factor, is_gray=is_gray, device=self.device)
                 bs, shuffle = self.test_batch_size or 1, False
-        except (OSError, TypeError):
-            return None
+        except (OSError, TypeError) as e:
+            if not is_train:
+                return None
+            raise FileNotFoundError("training set %r not found under --data_dir %r (%s: %s); pass --synthetic to train on "
+                                    "seeded random patches instead" % (dataset, self.data_dir, type(e).__name__, e))
         if len(ds) == 0:
-            return None
+            if not is_train:
+                return None
+            raise FileNotFoundError("training set %r under --data_dir %r holds no images; pass --synthetic to train on "
+                                    "seeded random patches instead" % (dataset, self.data_dir))
+        if is_train:   # DP: disjoint 1/world shards of one common permutation per epoch
+            return data.PatchLoader(ds, bs, shuffle=shuffle, num_threads=self.num_threads or 4, seed=1234,
+                                    rank=self.rank, world=self.world)
         return data.PatchLoader(ds, bs, shuffle=shuffle, num_threads=self.num_threads or 4)
+
+    def _announce_data(self):
+        if self.rank == 0:
+            print("training data: %s%s" % (self.data_source, "" if self.data_source != "folder" else
+                                           " %s under %s" % (self.train_dataset, self.data_dir)))
 
     def _channels(self, *tensors):
         """num_channels == 1: only the Y channel is super-resolved (edsr.py:139-142: hr[:, 0].unsqueeze(1))."""
@@ -134,6 +154,7 @@ class _Trainer(object):
         if loader is None:
             loader = self.load_dataset(self.train_dataset, is_train=True)
             self.data_source = "folder" if loader is not None else "synthetic"
+        self._announce_data()
         for epoch in range(self.num_epochs):
             self.lr_decay(epoch, self.optimizer)
             batches = loader if loader is not None else synthetic_loader(self.kind, self.args, self.steps_per_epoch,
@@ -346,6 +367,7 @@ class SRGAN(_Trainer):
         if loader is None:
             loader = self.load_dataset(self.train_dataset, is_train=True)
             self.data_source = "folder" if loader is not None else "synthetic"
+        self._announce_data()
 
         def batches(seed):   # loaders yield (lr, hr) or the reference's (lr, hr, bicubic) tuples (dataset.py:101)
             for batch in (loader or synthetic_loader("srgan", self.args, self.steps_per_epoch, self.device, seed)):

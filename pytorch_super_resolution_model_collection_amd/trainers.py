@@ -364,8 +364,10 @@ class GraphedStep(object):
 
 def _repack_touched(flats, seen):
     """Before a replay: a captured multi-model step packs a model's filters only where ITS OWN updates made them stale
-    (optim.zero_grad skips a current plan), so parameters somebody else changed since the last replay (load_state_dict,
-    a broadcast, an eager step in between) are re-packed here, eagerly, in front of the graph."""
+    (optim.zero_grad skips a current plan), so parameters somebody else changed since the last replay -- anything that
+    went through FlatParams.mark_changed(): load_state_dict (post-hook registered by FlatParams), DataParallel's
+    broadcast, an eager optimizer step in between; a raw write to `.data` needs an explicit mark_changed() -- are
+    re-packed here, eagerly, in front of the graph."""
     for f in flats:
         if seen.get(id(f)) != f.epoch and not f.plan.current():
             f.plan.pack()

@@ -73,6 +73,18 @@ def test_norm_denorm_constants(gpu, layout):
     # single-channel images (num_channels == 1 path of srgan.py:188-190)
     g1 = fill.rand((2, 1, 6, 6), 643)
     assert torch.equal(pkg.utils.norm(g1.to(gpu), vgg=True).cpu(), normalize(g1, [0.485], [0.229]))
+    # differentiable like the reference's tensor arithmetic (round-2 advisor finding: the gradient used to be dropped)
+    xr = xg.clone().requires_grad_(True)
+    out = pkg.utils.norm(xr, vgg=True)
+    assert out.requires_grad
+    g = fill.rand(tuple(x.shape), 644).to(gpu)
+    if layout == "channels_last":
+        g = g.contiguous(memory_format=torch.channels_last)
+    out.backward(g)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(-1, 1, 1)
+    assert torch.equal(xr.grad.cpu(), (g.cpu() / std))
+    with pytest.raises(RuntimeError, match="no backward"):
+        pkg.utils.denorm(xr)
 
 
 def _run_block(pkg, gpu, blocks_r2, tag, make_ours, make_ora, kind, shape, xs, gs, gain, tol_f, tol_g):

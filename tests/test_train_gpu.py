@@ -205,7 +205,7 @@ def test_trainer_objects_and_cli(gpu, tmp_path):
     for name, extra in (("EDSR", ["--crop_size", "32"]), ("VDSR", ["--crop_size", "17"]),
                         ("ESPCN", ["--crop_size", "48"]), ("SRGAN", ["--crop_size", "32", "--batch_size", "2", "--epoch_pretrain", "1"])):
         args = cli.parse_args(["--model_name", name, "--num_epochs", "2", "--save_epochs", "1", "--batch_size", "2",
-                               "--steps_per_epoch", "2", "--lr", "1e-4", "--save_dir", str(tmp_path)] + extra)
+                               "--synthetic", "--steps_per_epoch", "2", "--lr", "1e-4", "--save_dir", str(tmp_path)] + extra)
         t = TRAINERS[name](args)
         hist = t.train()
         assert len(hist) == 2
@@ -218,6 +218,19 @@ def test_trainer_objects_and_cli(gpu, tmp_path):
     files = glob.glob(str(tmp_path / "EDSR" / "model" / "EDSR_param_ch3_batch2_epoch2_lr0.0001.pkl"))
     assert files, "EDSR checkpoint name does not follow edsr.py:329-335"
     R.EDSR(3, 64, 16).load_state_dict(torch.load(files[0]))
+
+
+def test_trainer_refuses_a_missing_training_folder(gpu, tmp_path):
+    """Without --synthetic a mistyped --data_dir / --train_dataset is an error (the reference crashes in its DataLoader);
+    round-2 advisor finding: the trainer used to fall back to random patches silently."""
+    import main as cli
+    from pytorch_super_resolution_model_collection_amd.sr_trainers import TRAINERS
+    for name in ("EDSR", "SRGAN"):
+        args = cli.parse_args(["--model_name", name, "--num_epochs", "1", "--batch_size", "2", "--crop_size", "32",
+                               "--data_dir", str(tmp_path / "nowhere"), "--train_dataset", "DIV2K",
+                               "--save_dir", str(tmp_path / "out")])
+        with pytest.raises(FileNotFoundError, match="--synthetic"):
+            TRAINERS[name](args).train()
 
 
 def test_trainer_replays_its_step_as_a_graph(gpu, tmp_path):
@@ -235,7 +248,7 @@ def test_trainer_replays_its_step_as_a_graph(gpu, tmp_path):
         try:
             for mode in ("graph", "eager"):
                 args = cli.parse_args(["--model_name", name, "--num_epochs", str(epochs), "--save_epochs", "10",
-                                       "--batch_size", "2", "--steps_per_epoch", "4", "--lr", "1e-3",
+                                       "--batch_size", "2", "--synthetic", "--steps_per_epoch", "4", "--lr", "1e-3",
                                        "--save_dir", str(tmp_path / mode)] + extra + (["--eager"] if mode == "eager" else []))
                 torch.manual_seed(0)
                 t = TRAINERS[name](args)
@@ -253,7 +266,7 @@ def test_trainer_replays_its_step_as_a_graph(gpu, tmp_path):
     hist = {}
     for mode in ("graph", "eager"):
         args = cli.parse_args(["--model_name", "SRGAN", "--num_epochs", "2", "--save_epochs", "10", "--batch_size", "2",
-                               "--steps_per_epoch", "4", "--lr", "1e-4", "--crop_size", "32", "--epoch_pretrain", "1",
+                               "--synthetic", "--steps_per_epoch", "4", "--lr", "1e-4", "--crop_size", "32", "--epoch_pretrain", "1",
                                "--save_dir", str(tmp_path / ("gan_" + mode))] + (["--eager"] if mode == "eager" else []))
         torch.manual_seed(0)
         hist[mode] = TRAINERS["SRGAN"](args).train()

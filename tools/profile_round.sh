@@ -24,6 +24,19 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_kt -o c4 -- $C4 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3_kt -o c3 -- python $ROOT/tools/vdsr_step.py 256 > $OUT/c3_kt.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_kt -o c5 -- python $ROOT/tools/srgan_step.py 16 > $OUT/c5_kt.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4s16_kt -o c4s16 -- python $ROOT/tools/edsr_b16.py 16 > $OUT/c4s16_kt.log 2>&1
+# counter evidence for the training kernels (north star: "rocprof HBM GB/s and MFMA utilisation"): the same three
+# separate passes as c2 for c3, c4 and the 16-patch shard; SQ pass only for c5
+SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
+for WL in c3 c4 c4s16; do
+  case $WL in c3) CMD="python $ROOT/tools/vdsr_step.py 256";; c4) CMD="$C4";; c4s16) CMD="python $ROOT/tools/edsr_b16.py 16";; esac
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${WL}_fetch -o $WL -- $CMD > $OUT/${WL}_fetch.log 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${WL}_write -o $WL -- $CMD > $OUT/${WL}_write.log 2>&1
+  timeout 600 rocprofv3 --pmc $SQ --output-format csv -d $OUT/${WL}_sq -o $WL -- $CMD > $OUT/${WL}_sq.log 2>&1
+done
+timeout 600 rocprofv3 --pmc $SQ --output-format csv -d $OUT/c5_sq -o c5 -- python $ROOT/tools/srgan_step.py 16 > $OUT/c5_sq.log 2>&1
+# raw counter CSVs are large: keep only the reduced files
 cd $ROOT
 python tools/summarize_prof.py $TAG > $OUT/summary.log 2>&1
 cat $OUT/summary.log | tail -30
+find $OUT -name "*counter_collection.csv" -size +8M -delete
+mkdir -p $OUT/reduced && cp $ROOT/profiles/${TAG}_* $OUT/reduced/ 2>/dev/null

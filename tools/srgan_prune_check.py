@@ -9,7 +9,7 @@ hist = {}
 for flag in ([], ["--prune_dead_grads"]):
     d = tempfile.mkdtemp()
     args = cli.parse_args(["--model_name", "SRGAN", "--num_epochs", "2", "--save_epochs", "10", "--batch_size", "2",
-                           "--steps_per_epoch", "4", "--lr", "1e-4", "--crop_size", "32", "--epoch_pretrain", "1",
+                           "--synthetic", "--steps_per_epoch", "4", "--lr", "1e-4", "--crop_size", "32", "--epoch_pretrain", "1",
                            "--save_dir", d] + flag)
     torch.manual_seed(0)
     hist[bool(flag)] = TRAINERS["SRGAN"](args).train()

@@ -41,40 +41,57 @@ def counter_means(sub, counter):
     return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
 
 
-fetch = counter_means("c2_fetch", "FETCH_SIZE")
-write = counter_means("c2_write", "WRITE_SIZE")
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 10 "
-                 "--warmup 3 --no-extra --no-cpu-baseline` (c2: ESPCN x4, 256x256 LR, batch 64)",
-       "corrections": "counters in KiB; FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B); WRITE_SIZE as reported",
-       "kernels": {}}
-for k in sorted(set(fetch) | set(write)):
-    if "srk::" not in k:
-        continue
-    fk, nf = fetch.get(k, (0.0, 0))
-    wk, nw = write.get(k, (0.0, 0))
-    out["kernels"][k] = {"launches": max(nf, nw), "fetch_KiB_raw": round(fk, 1), "write_KiB_raw": round(wk, 1),
-                         "hbm_read_bytes": int(fk * 1024 * 2), "hbm_write_bytes": int(wk * 1024),
-                         "hbm_bytes": int(fk * 1024 * 2 + wk * 1024)}
-# matrix-core / LDS activity (one SQ pass): per-kernel means per launch
-sq_names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_WAVE_CYCLES",
+
+SQ_NAMES = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_WAVE_CYCLES",
             "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS", "GRBM_GUI_ACTIVE"]
-sq = {n: counter_means("c2_sq", n) for n in sq_names}
-sq_out = {"source": "rocprofv3 --pmc " + " ".join(sq_names) + " over the c2 bench command (own pass, no traces)",
-          "note": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 "
-                  "(the counter is summed over the 8 XCDs); SQ_VALU_MFMA_BUSY_CYCLES = 16 cycles per "
-                  "v_mfma_f32_16x16x32_bf16 summed over all SIMDs (checked against the instruction count of the layer)",
-          "kernels": {}}
-for k in sorted(set().union(*[set(v) for v in sq.values()])):
-    if "srk::k_conv" not in k:
-        continue
-    rec = {n: round(sq[n].get(k, (0.0, 0))[0], 1) for n in sq_names}
-    if rec["GRBM_GUI_ACTIVE"] > 0:
-        rec["mfma_util"] = round(rec["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * rec["GRBM_GUI_ACTIVE"] / 8.0), 4)
-    sq_out["kernels"][k] = rec
-if sq_out["kernels"]:
-    with open(os.path.join(dst, "%s_c2_pmc_mfma.json" % tag), "w") as fh:
-        json.dump(sq_out, fh, indent=1)
-    print(json.dumps(sq_out, indent=1))
-with open(os.path.join(dst, "%s_c2_pmc_traffic.json" % tag), "w") as fh:
-    json.dump(out, fh, indent=1)
-print(json.dumps(out, indent=1))
+COMMANDS = {
+    "c2": "python bench.py --steps 10 --warmup 3 --no-extra --no-cpu-baseline (c2: ESPCN x4, 256x256 LR, batch 64)",
+    "c3": "python tools/vdsr_step.py 256 (c3: 5 eager VDSR x4 training steps, 41x41, batch 256)",
+    "c4": "python tools/edsr_b16.py 128 (c4: 5 eager EDSR x4 training steps, 32x32 LR, batch 128)",
+    "c4s16": "python tools/edsr_b16.py 16 (the 16-patch shard of 8-GPU strong scaling)",
+    "c5": "python tools/srgan_step.py 16 (c5: SRGAN adversarial steps, batch 16)",
+}
+
+
+def traffic_and_mfma(wl):
+    """<tag>_<wl>_pmc_traffic.json (FETCH_SIZE x2 / WRITE_SIZE per launch) and <tag>_<wl>_pmc_mfma.json (SQ pass)."""
+    fetch = counter_means(wl + "_fetch", "FETCH_SIZE")
+    write = counter_means(wl + "_write", "WRITE_SIZE")
+    if fetch or write:
+        out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `%s`" % COMMANDS[wl],
+               "corrections": "counters in KiB; FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B); WRITE_SIZE as reported",
+               "kernels": {}}
+        for k in sorted(set(fetch) | set(write)):
+            if "srk::" not in k:
+                continue
+            fk, nf = fetch.get(k, (0.0, 0))
+            wk, nw = write.get(k, (0.0, 0))
+            out["kernels"][k] = {"launches": max(nf, nw), "fetch_KiB_raw": round(fk, 1), "write_KiB_raw": round(wk, 1),
+                                 "hbm_read_bytes": int(fk * 1024 * 2), "hbm_write_bytes": int(wk * 1024),
+                                 "hbm_bytes": int(fk * 1024 * 2 + wk * 1024)}
+        with open(os.path.join(dst, "%s_%s_pmc_traffic.json" % (tag, wl)), "w") as fh:
+            json.dump(out, fh, indent=1)
+        print("wrote %s_%s_pmc_traffic.json (%d kernels)" % (tag, wl, len(out["kernels"])))
+    # matrix-core / LDS activity (one SQ pass): per-kernel means per launch
+    sq = {n: counter_means(wl + "_sq", n) for n in SQ_NAMES}
+    sq_out = {"source": "rocprofv3 --pmc " + " ".join(SQ_NAMES) + " over `%s` (own pass, no traces)" % COMMANDS[wl],
+              "note": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 "
+                      "(the counter is summed over the 8 XCDs); SQ_VALU_MFMA_BUSY_CYCLES = 16 cycles per "
+                      "v_mfma_f32_16x16x32_bf16 summed over all SIMDs (checked against the instruction count of the layer)",
+              "kernels": {}}
+    for k in sorted(set().union(*[set(v) for v in sq.values()])):
+        if "srk::k_conv" not in k and "srk::k_wgrad" not in k and "srk::k_res2" not in k:
+            continue
+        rec = {n: round(sq[n].get(k, (0.0, 0))[0], 1) for n in SQ_NAMES}
+        rec["launches"] = max(sq[n].get(k, (0.0, 0))[1] for n in SQ_NAMES)
+        if rec["GRBM_GUI_ACTIVE"] > 0:
+            rec["mfma_util"] = round(rec["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * rec["GRBM_GUI_ACTIVE"] / 8.0), 4)
+        sq_out["kernels"][k] = rec
+    if sq_out["kernels"]:
+        with open(os.path.join(dst, "%s_%s_pmc_mfma.json" % (tag, wl)), "w") as fh:
+            json.dump(sq_out, fh, indent=1)
+        print("wrote %s_%s_pmc_mfma.json (%d kernels)" % (tag, wl, len(sq_out["kernels"])))
+
+
+for wl in ("c2", "c3", "c4", "c4s16", "c5"):
+    traffic_and_mfma(wl)
