@@ -61,9 +61,21 @@ typedef enum srk_algo {
   SRK_ALGO_MFMA = 2,        /* exact fp32 MFMA (v_mfma_f32_16x16x4_f32)                                    */
   SRK_ALGO_DIRECT = 3,      /* fp32 VALU kernel for Cout <= 4                                              */
   SRK_ALGO_MFMA_BF16X3 = 4, /* 3-term bf16 split on v_mfma_f32_16x16x32_bf16, fp32 accumulate (~1e-5 rel) */
-  SRK_ALGO_MFMA_BF16X6 = 5  /* exact 3-way operand split, 6 bf16 MFMAs per product: fp32-faithful (~1e-7
+  SRK_ALGO_MFMA_BF16X6 = 5, /* exact 3-way operand split, 6 bf16 MFMAs per product: fp32-faithful (~1e-7
                                rel) at 2.7x the fp32-MFMA rate; shapes it does not cover run SRK_ALGO_MFMA */
+  SRK_ALGO_MFMA_F16X3 = 6   /* fp32-faithful with THREE MFMAs per product: both operands scaled by a power of two (exact)
+                               so that their largest magnitude sits at 2^13..2^14, split x = h + m into two fp16 planes
+                               (2 x 11 significant bits), products m*h + h*m + h*h on v_mfma_f32_16x16x32_f16, fp32
+                               accumulate, exact power-of-two descale (~1.2e-7 rms vs 0.8e-7 for plain fp32).  Needs
+                               an upper bound of max|x| on the device (srk_epilogue.x_amax); forward convs the fp16
+                               kernels cover (srk_conv2d_f16x3_supported), SRK_ERR_UNSUPPORTED elsewhere */
 } srk_algo;
+
+/* A device-side running maximum of |values|: SRK_AMAX_FLOATS floats = SRK_AMAX_SLOTS slots, one per 64-byte line (slot
+ * i is float 16 i: atomics on one line serialise in one L2 channel, so the kernels spread theirs over the slots); the
+ * value is the maximum over the slots.  Zero the buffer before the first producer; any upper bound is a valid content. */
+#define SRK_AMAX_SLOTS 16
+#define SRK_AMAX_FLOATS 256
 
 /* Geometry of one torch.nn.Conv2d / ConvTranspose2d call.
  *   conv       (base_networks.py:42,112-113,156): y[n,oy,ox,co] = sum x[n,oy*s-p+kh,ox*s-p+kw,ci] * w
@@ -101,6 +113,10 @@ typedef struct srk_epilogue {
   int32_t act;               /* srk_act */
   int32_t prelu_n;           /* 1 (nn.PReLU() default) or number of output channels */
   int32_t ps_r;
+  const float* x_amax;       /* SRK_ALGO_MFMA_F16X3: SRK_AMAX_FLOATS floats, max over the slots >= max|x| (NULL otherwise) */
+  float* y_amax;             /* optional: SRK_AMAX_FLOATS floats that receive (atomic max) max|y| of this call's output
+                                -- the next layer's x_amax.  Honoured by the kernels listed at srk_conv2d_f16x3_supported;
+                                check srk_conv2d_writes_amax() */
 } srk_epilogue;
 
 /* Activation-gradient prologue of the backward kernels: the incoming gradient dy is
@@ -147,13 +163,29 @@ int srk_pack_weight_fwd(const float* w, float* wp, int Cout, int Cin, int KH, in
 int srk_pack_weight_bwd(const float* w, float* wp, int Cout, int Cin, int KH, int KW, int transposed, int ps_r,
                         void* stream);
 int srk_pack_bias_ps(const float* b, float* bp, int Cout, int ps_r, void* stream);
-/* Whole-model packing in ONE launch (training: the weights change every step).  `params_base` is the
- * flat fp32 parameter buffer, `packed_base` a caller-owned byte buffer, `table` a DEVICE array of
- * n_layers rows x 12 int64: {w_off (floats), fwd_off (bytes, -1 skip), bwd_off (bytes, -1 skip), Cout,
- * Cin, KH, KW, transposed, ps_r, bias_off (floats, -1), bias_ps_off (bytes, -1), 0}.  Every
- * fwd_off / bwd_off region receives exactly what srk_pack_weight_fwd / _bwd would write there. */
+/* Whole-model packing (training: the weights change every step).  `params_base` is the flat fp32 parameter buffer,
+ * `packed_base` a caller-owned byte buffer, `table` a DEVICE array of n_layers rows x 14 int64:
+ *   0 w_off (floats)  1 fwd_off (bytes, -1 skip)  2 bwd_off (bytes, -1 skip)  3 Cout  4 Cin  5 KH  6 KW  7 transposed
+ *   8 ps_r  9 bias_off (floats, -1)  10 bias_ps_off (bytes, -1)
+ *   11 amax_off (bytes into packed_base, -1 none): a 4-byte scratch word per layer, ZEROED BY THE CALLER before the call,
+ *      that lets the layer's max|w| (scale of the fp16 planes of SRK_ALGO_MFMA_F16X3) be taken by parallel slices
+ *      instead of one block per layer; pass -blocks_per_layer when every row has one (skips the single-block pass)
+ *   12 first block of the layer in `fast_blocks` (-1: generic path)  13 reserved (0)
+ * Every fwd_off / bwd_off region receives exactly what srk_pack_weight_fwd / _bwd would write there.
+ * fast_blocks (DEVICE, may be NULL): n_fast_blocks pairs {layer, local block} for the layers with column 12 >= 0 -- plain
+ * Conv2d filters (not transposed, KH*KW <= 25, Cout = 32 or a multiple of 64, Cin = 16 / 32 / 48 or a multiple of 64 --
+ * no channel padding in any prepared layout --, both directions wanted) take
+ * (Cout / 8) * ceil(Cin / 32) blocks each, local block = octet * ceil(Cin / 32) + chunk; a block reads its 8 x 32-channel
+ * filter tile once, coalesced, and writes all layouts from LDS (the generic path gathers every value separately). */
 int srk_pack_weights_batched(const float* params_base, void* packed_base, const int64_t* table, int n_layers,
-                             int blocks_per_layer, void* stream);
+                             int blocks_per_layer, const int32_t* fast_blocks, int n_fast_blocks, void* stream);
+/* max|x| over n floats into an SRK_AMAX_FLOATS buffer (atomic max: zero it first) -- x_amax of a tensor no kernel
+ * of this library produced (the network input). */
+int srk_absmax(const float* x, size_t n, float* amax_slots, void* stream);
+/* 1 when srk_conv2d_forward(d, ..., ep) with d->algo = SRK_ALGO_MFMA_F16X3 has a kernel (stride-1 / strided Conv2d and
+ * ConvTranspose2d with Cin >= 8, Cout >= 8 and every output group on the 16-byte store path), and when that call
+ * fills ep->y_amax. */
+int srk_conv2d_f16x3_supported(const srk_conv_desc* d, const srk_epilogue* ep, const float* y);
 
 /* ---- convolution (Conv2d / ConvTranspose2d: base_networks.py:42,77,112-113,156; fsrcnn.py:33) */
 int srk_conv2d_forward(const srk_conv_desc* d, const float* x, const float* w_packed_fwd, float* y,
@@ -192,11 +224,14 @@ int srk_conv2d_backward_weight_grouped(const srk_conv_desc* d, int n, const floa
  * srk_resblock2_supported says when): one 8x8 tile per workgroup, the intermediate stays in LDS, and nothing waits for
  * the store -> load round trip between the two convs.  y_mid / d_mid are still written: the weight gradients
  * (srk_conv2d_backward_weight with x = y_mid, dy = dy for conv2 and x = x, dy = d_mid, NO mask, for conv1) need them.
- * algo: SRK_ALGO_MFMA_BF16X6 (fp32-faithful) or SRK_ALGO_AUTO / SRK_ALGO_MFMA_BF16X3.  b1 / b2 may be NULL.
+ * algo: SRK_ALGO_MFMA_BF16X6 / SRK_ALGO_MFMA_F16X3 (fp32-faithful; the latter forward only, with x_amax = the
+ * SRK_AMAX_FLOATS running-maximum buffer of |x|) or SRK_ALGO_AUTO / SRK_ALGO_MFMA_BF16X3.  y_amax (optional, any algo) receives
+ * max|y|.  b1 / b2 may be NULL.
  * Filters: the packed buffers of srk_pack_weight_fwd / srk_pack_weight_bwd (ps_r = 0). */
 int srk_resblock2_supported(int N, int H, int W, int C);
 int srk_resblock2_forward(int N, int H, int W, int C, const float* x, const float* w1_packed_fwd, const float* b1,
-                          const float* w2_packed_fwd, const float* b2, float* y_mid, float* y, int algo, void* stream);
+                          const float* w2_packed_fwd, const float* b2, float* y_mid, float* y, int algo,
+                          const float* x_amax, float* y_amax, void* stream);
 int srk_resblock2_backward_data(int N, int H, int W, int C, const float* dy, const float* w2_packed_bwd,
                                 const float* w1_packed_bwd, const float* y_mid, float* d_mid, float* dx, int algo,
                                 void* stream);

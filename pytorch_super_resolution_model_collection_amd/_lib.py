@@ -16,7 +16,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "srk.h")
 
 # enums mirrored from include/srk.h
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = range(6)
-ALGO_AUTO, ALGO_GENERIC, ALGO_MFMA, ALGO_DIRECT, ALGO_MFMA_BF16X3, ALGO_MFMA_BF16X6 = range(6)
+ALGO_AUTO, ALGO_GENERIC, ALGO_MFMA, ALGO_DIRECT, ALGO_MFMA_BF16X3, ALGO_MFMA_BF16X6, ALGO_MFMA_F16X3 = range(7)
+AMAX_FLOATS = 256   # SRK_AMAX_FLOATS: 16 slots, one per 64-byte line
 LOSS_MSE, LOSS_L1, LOSS_CHARBONNIER, LOSS_BCE = range(4)
 ACT_BY_NAME = {None: ACT_NONE, "relu": ACT_RELU, "prelu": ACT_PRELU, "lrelu": ACT_LRELU, "tanh": ACT_TANH,
                "sigmoid": ACT_SIGMOID}
@@ -38,7 +39,8 @@ class ConvDesc(ctypes.Structure):
 class Epilogue(ctypes.Structure):
     """struct srk_epilogue"""
     _fields_ = [("bias", c_vp), ("prelu_weight", c_vp), ("residual", c_vp), ("slope", c_float),
-                ("act", ctypes.c_int32), ("prelu_n", ctypes.c_int32), ("ps_r", ctypes.c_int32)]
+                ("act", ctypes.c_int32), ("prelu_n", ctypes.c_int32), ("ps_r", ctypes.c_int32),
+                ("x_amax", c_vp), ("y_amax", c_vp)]
 
 
 class BwdMask(ctypes.Structure):
@@ -57,7 +59,7 @@ _PROTOTYPES = {
     "srk_pack_weight_fwd": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "srk_pack_weight_bwd": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "srk_pack_bias_ps": (c_int, [c_f, c_f, c_int, c_int, c_vp]),
-    "srk_pack_weights_batched": (c_int, [c_f, c_vp, c_vp, c_int, c_int, c_vp]),
+    "srk_pack_weights_batched": (c_int, [c_f, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     "srk_packed_weight_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
     "srk_conv2d_forward": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, c_f, ctypes.POINTER(Epilogue), c_vp]),
     "srk_conv2d_backward_data": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, c_f, ctypes.POINTER(BwdMask), c_f,
@@ -70,7 +72,10 @@ _PROTOTYPES = {
                                                    ctypes.POINTER(c_vp), ctypes.POINTER(BwdMask), ctypes.POINTER(c_vp),
                                                    ctypes.POINTER(c_vp), c_float, c_vp, c_size, c_vp]),
     "srk_resblock2_supported": (c_int, [c_int, c_int, c_int, c_int]),
-    "srk_resblock2_forward": (c_int, [c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_vp]),
+    "srk_resblock2_forward": (c_int, [c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_f, c_f,
+                                      c_vp]),
+    "srk_absmax": (c_int, [c_f, c_size, c_f, c_vp]),
+    "srk_conv2d_f16x3_supported": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(Epilogue), c_f]),
     "srk_resblock2_backward_data": (c_int, [c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_int, c_vp]),
     "srk_pixel_shuffle_forward": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "srk_pixel_shuffle_backward": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_vp]),

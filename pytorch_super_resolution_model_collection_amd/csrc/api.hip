@@ -67,7 +67,7 @@ constexpr int kMaxWgradGroup = 40;  // = WB_MAXGROUP of conv_wgrad_bf16.hip
 
 // conv_mfma_bf16.hip
 int pack_weights_batched(const float* params, void* packed, const long long* table, int n_layers, int blocks,
-                         hipStream_t s);
+                         hipStream_t s, bool has_unscratched, const int* fast_blocks, int n_fast_blocks);
 
 static int validate_desc(const srk_conv_desc* d, const char* who) {
   SRK_REQUIRE(d, "%s: null descriptor", who);
@@ -80,7 +80,7 @@ static int validate_desc(const srk_conv_desc* d, const char* who) {
   const int ow = srk_conv_out_dim(d->W, d->KW, d->stride, d->pad, d->transposed, d->out_pad);
   SRK_REQUIRE(oh > 0 && ow > 0, "%s: empty output (%d x %d)", who, oh, ow);
   SRK_REQUIRE(d->OH == oh && d->OW == ow, "%s: OH/OW (%d,%d) != expected (%d,%d)", who, d->OH, d->OW, oh, ow);
-  SRK_REQUIRE(d->algo >= SRK_ALGO_AUTO && d->algo <= SRK_ALGO_MFMA_BF16X6, "%s: unknown algo %d", who, d->algo);
+  SRK_REQUIRE(d->algo >= SRK_ALGO_AUTO && d->algo <= SRK_ALGO_MFMA_F16X3, "%s: unknown algo %d", who, d->algo);
   return SRK_OK;
 }
 
@@ -96,6 +96,15 @@ static int forced_algo(int algo) {
   return SRK_ALGO_AUTO;
 }
 
+// SRK_ALGO_MFMA_F16X3 (forward gathers only): what the fp16 kernels cover -- the shapes of conv_bfd.hip, minus the
+// layers the few-output-channel kernels take and inputs in a foreign layout
+static bool f16x3_gather_ok(const GatherConv& g, const Epi& ep, const float* in, const float* out) {
+  if (!ep.x_amax || g.in_nchw || g.in_ps_r > 1) return false;
+  if (!conv_bfd_gather_supported(g, ep) || !conv_epi_all_vector(g.OC, ep, out)) return false;
+  if (conv_direct_gather_supported(g, ep) || conv_tapn_gather_supported(g, in, nullptr)) return false;
+  return true;
+}
+
 static int run_gather(const GatherConv& g, int algo, const float* in, const float* wp, float* out, const Epi& ep,
                       const float* mask_y, float mask_slope, hipStream_t s, const char* who) {
   algo = forced_algo(algo);
@@ -108,6 +117,14 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
     if (conv_bfd_gather_supported(g, ep) && conv_epi_all_vector(g.OC, ep, out) && conv_bfd_small_problem(g))
       return conv_bfd_gather(g, in, wp, out, ep, mask_y, mask_slope, 2, s);
     return conv_bf3_gather(g, in, wp, out, ep, mask_y, mask_slope, s);
+  }
+  if (algo == SRK_ALGO_MFMA_F16X3) {
+    if (mask_y || !f16x3_gather_ok(g, ep, in, out)) {
+      set_error("%s: SRK_ALGO_MFMA_F16X3 covers forward convs with Cin, Cout >= 8 on the 16-byte store path and needs "
+                "srk_epilogue.x_amax (srk_conv2d_f16x3_supported)", who);
+      return SRK_ERR_UNSUPPORTED;
+    }
+    return conv_bfd_gather(g, in, wp, out, ep, nullptr, 0.f, 4, s);
   }
   const bool direct_ok = conv_direct_gather_supported(g, ep);
   const bool mfma_ok = conv_mfma_gather_supported(g, ep);
@@ -214,10 +231,21 @@ extern "C" int srk_conv2d_forward(const srk_conv_desc* d, const float* x, const 
   return run_gather(g, d->algo, x, w_packed_fwd, y, ep, nullptr, 0.f, (hipStream_t)stream, "conv2d_forward");
 }
 
+extern "C" int srk_conv2d_f16x3_supported(const srk_conv_desc* d, const srk_epilogue* ep_in, const float* y) {
+  if (!d || validate_desc(d, "conv2d_f16x3_supported") || d->x_nchw || d->dy_ps_r) return 0;
+  Epi ep = make_epi(ep_in);
+  static const float dummy = 0.f;
+  if (!ep.x_amax) ep.x_amax = &dummy;   // (the question is about the shape; the call itself needs the real slots)
+  GatherConv g{d->N, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->pad, d->transposed, 0};
+  return f16x3_gather_ok(g, ep, reinterpret_cast<const float*>(16), y ? y : reinterpret_cast<const float*>(16)) ? 1 : 0;
+}
+
 extern "C" int srk_conv2d_backward_data(const srk_conv_desc* d, const float* dy, const float* w_packed_bwd, float* dx,
                                         const srk_bwd_mask* mask, const float* add_to, void* stream) {
   int rc = validate_desc(d, "conv2d_backward_data");
   if (rc) return rc;
+  SRK_REQUIRE(d->algo != SRK_ALGO_MFMA_F16X3, "conv2d_backward_data: SRK_ALGO_MFMA_F16X3 is a forward-only arithmetic "
+              "(the backward kernels run bf16x3)");
   SRK_REQUIRE(dy && w_packed_bwd && dx, "conv2d_backward_data: null tensor pointer");
   // dx is a gather over dy with the channel roles swapped and the opposite gather kind.
   GatherConv g{d->N, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad, !d->transposed, 0, 0};
@@ -237,6 +265,7 @@ extern "C" int srk_resblock2_supported(int N, int H, int W, int C) { return conv
 static int resblock2_planes(int algo, const char* who) {
   algo = forced_algo(algo);
   if (algo == SRK_ALGO_MFMA_BF16X6) return 3;
+  if (algo == SRK_ALGO_MFMA_F16X3) return 4;
   if (algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3) return 2;
   set_error("%s: only the bf16x3 (SRK_ALGO_AUTO) and bf16x6 arithmetic exist for the fused block", who);
   return 0;
@@ -244,15 +273,16 @@ static int resblock2_planes(int algo, const char* who) {
 
 extern "C" int srk_resblock2_forward(int N, int H, int W, int C, const float* x, const float* w1_packed_fwd,
                                      const float* b1, const float* w2_packed_fwd, const float* b2, float* y_mid, float* y,
-                                     int algo, void* stream) {
+                                     int algo, const float* x_amax, float* y_amax, void* stream) {
   SRK_REQUIRE(x && w1_packed_fwd && w2_packed_fwd && y_mid && y, "resblock2_forward: null tensor pointer");
   SRK_REQUIRE(conv_res2_supported(N, H, W, C), "resblock2_forward: unsupported problem (see srk_resblock2_supported)");
   SRK_REQUIRE(((uintptr_t)x | (uintptr_t)y_mid | (uintptr_t)y | (uintptr_t)b1 | (uintptr_t)b2) % 16 == 0,
               "resblock2_forward: tensors must be 16-byte aligned");
   const int planes = resblock2_planes(algo, "resblock2_forward");
   if (!planes) return SRK_ERR_UNSUPPORTED;
+  SRK_REQUIRE(planes != 4 || x_amax, "resblock2_forward: SRK_ALGO_MFMA_F16X3 needs x_amax");
   return conv_res2(x, w1_packed_fwd, w2_packed_fwd, b1, b2, nullptr, y_mid, y, N, H, W, planes, false,
-                   (hipStream_t)stream);
+                   (hipStream_t)stream, x_amax, y_amax);
 }
 
 extern "C" int srk_resblock2_backward_data(int N, int H, int W, int C, const float* dy, const float* w2_packed_bwd,
@@ -264,6 +294,7 @@ extern "C" int srk_resblock2_backward_data(int N, int H, int W, int C, const flo
               "resblock2_backward_data: tensors must be 16-byte aligned");
   const int planes = resblock2_planes(algo, "resblock2_backward_data");
   if (!planes) return SRK_ERR_UNSUPPORTED;
+  SRK_REQUIRE(planes != 4, "resblock2_backward_data: SRK_ALGO_MFMA_F16X3 is forward-only");
   // in this direction conv2's transposed filter runs first, conv1's second
   return conv_res2(dy, w2_packed_bwd, w1_packed_bwd, nullptr, nullptr, y_mid, d_mid, dx, N, H, W, planes, true,
                    (hipStream_t)stream);
@@ -364,9 +395,12 @@ extern "C" int srk_conv2d_backward_weight_grouped(const srk_conv_desc* d, int n,
 }
 
 extern "C" int srk_pack_weights_batched(const float* params_base, void* packed_base, const int64_t* table, int n_layers,
-                                        int blocks_per_layer, void* stream) {
+                                        int blocks_per_layer, const int32_t* fast_blocks, int n_fast_blocks, void* stream) {
   SRK_REQUIRE(params_base && packed_base && table, "pack_weights_batched: null pointer");
-  SRK_REQUIRE(n_layers > 0 && n_layers <= 65535 && blocks_per_layer > 0, "pack_weights_batched: bad sizes");
+  SRK_REQUIRE(n_layers > 0 && n_layers <= 65535 && blocks_per_layer != 0, "pack_weights_batched: bad sizes");
+  // blocks_per_layer < 0: EVERY row carries a scratch word (column 11 >= 0), no single-block scan needed
+  const bool all_scratch = blocks_per_layer < 0;
   return pack_weights_batched(params_base, packed_base, reinterpret_cast<const long long*>(table), n_layers,
-                              blocks_per_layer, (hipStream_t)stream);
+                              all_scratch ? -blocks_per_layer : blocks_per_layer, (hipStream_t)stream, !all_scratch,
+                              fast_blocks, n_fast_blocks);
 }

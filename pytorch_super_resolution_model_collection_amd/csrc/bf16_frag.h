@@ -30,4 +30,78 @@ __device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c)
                                                  0);
 }
 
+// ---- f16x3: x * 2^k split into two fp16 planes (h = RN(x s), m = RN(x s - h)); see SRK_ALGO_MFMA_F16X3 -------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8h(const float (&f)[8], float s, uint4 (&pl)[2]) {
+  f16x8 h, m;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = f[e] * s;
+    const _Float16 hh = (_Float16)x;
+    h[e] = hh;
+    m[e] = (_Float16)(x - (float)hh);
+  }
+  pl[0] = __builtin_bit_cast(uint4, h);
+  pl[1] = __builtin_bit_cast(uint4, m);
+}
+
+__device__ __forceinline__ f32x4 mfma16h(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16x(const uint4& a, const uint4& b, f32x4 c) {
+  if constexpr (F16) return mfma16h(a, b, c); else return mfma16(a, b, c);
+}
+
+// Running maximum of |values| (SRK_AMAX_SLOTS = 16 slots, one per 64-byte line; non-negative floats order like their
+// bit patterns).
+// amax_read: wave-uniform maximum over the slots.  amax_scale_exp: k with amax * 2^k in [2^13, 2^14) (0 for amax = 0;
+// inf / nan inputs give k = -114: the products then overflow to inf / nan like the fp32 ones would).
+__device__ __forceinline__ float amax_read(const float* __restrict__ slots) {
+  float a = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a = fmaxf(a, slots[i * 16]);
+  return a;
+}
+__device__ __forceinline__ int amax_scale_exp(float amax) {
+  const int E = (int)((__float_as_uint(amax) >> 23) & 0xff);
+  if (amax == 0.f) return 0;
+  return 140 - E;  // amax in [2^(E-127), 2^(E-126))  ->  amax * 2^(140-E) in [2^13, 2^14)
+}
+__device__ __forceinline__ float exp2i(int k) {  // 2^k for -126 <= k <= 127 (clamped)
+  k = k < -126 ? -126 : (k > 127 ? 127 : k);
+  return __uint_as_float((unsigned)(k + 127) << 23);
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// one atomic per wave, and only while the wave's maximum still raises its slot
+__device__ __forceinline__ void amax_commit(float* __restrict__ slots, float lane_max, int slot_hint) {
+  const float m = wave_max(lane_max);
+  if ((threadIdx.x & 63) == 0) {
+    float* p = slots + (slot_hint & 15) * 16;
+    if (m > __builtin_nontemporal_load(p)) atomicMax(reinterpret_cast<unsigned*>(p), __float_as_uint(m));
+  }
+}
+// one atomic per BLOCK (kernels whose epilogue may use a barrier): `sm` = one float per wave
+__device__ __forceinline__ void amax_commit_block(float* __restrict__ slots, float lane_max, int slot_hint, float* sm,
+                                                  int nwaves) {
+  const float m = wave_max(lane_max);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float b = sm[0];
+    for (int i = 1; i < nwaves; ++i) b = fmaxf(b, sm[i]);
+    float* p = slots + (slot_hint & 15) * 16;
+    if (b > __builtin_nontemporal_load(p)) atomicMax(reinterpret_cast<unsigned*>(p), __float_as_uint(b));
+  }
+}
+__device__ __forceinline__ float abs_max4(float cur, const f32x4& v) {
+  return fmaxf(fmaxf(cur, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+
 }  // namespace srk

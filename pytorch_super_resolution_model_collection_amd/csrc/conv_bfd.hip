@@ -42,14 +42,16 @@ struct BfdParams {
   int dbg;
   int allc;          // small problems: every channel chunk of the halo staged up front (one load latency, one barrier)
   int cpr;           // chunks staged per barrier round: ICc (allc), 2 (K-split without allc) or 1
+  const float* w_descale;  // F16 kernels: trailer of the fp16 filter section {2^-kw, 2^kw}
 };
 
 // halo chunk: channels [cb, cb+32) of every halo pixel -> NP planes.  thread -> (8-channel group
 // g = tid&3, pixel slot tid>>2); all global loads of a batch are issued before the first conversion.
 constexpr int BFD_STAGE_IT = 6;
 
-template <bool MASK, int NTHR, int NP, int IT>
-__device__ __forceinline__ void bfd_stage_halo_t(const BfdParams& B, uint4* hal, int n, int r0, int c0, int cb) {
+template <bool MASK, int NTHR, int NP, int IT, bool F16 = false>
+__device__ __forceinline__ void bfd_stage_halo_t(const BfdParams& B, uint4* hal, int n, int r0, int c0, int cb,
+                                                 float sx = 1.f) {
   const MfmaConvParams& P = B.P;
   const int npix = P.HH * P.HW;
   // (4 adjacent lanes = the 4 channel groups of one pixel: 128 contiguous bytes per pixel for the global loads.
@@ -124,7 +126,7 @@ __device__ __forceinline__ void bfd_stage_halo_t(const BfdParams& B, uint4* hal,
           }
         }
         uint4 pl[NP];
-        split8n<NP>(f, pl);
+        if constexpr (F16) split8h(f, sx, pl); else split8n<NP>(f, pl);
 #pragma unroll
         for (int p = 0; p < NP; ++p) hal[(p * 4 + g) * B.NPIXp + hp] = pl[p];
       }
@@ -146,6 +148,7 @@ constexpr int BFD_EPI_STRIDE = 68;  // floats per staged output row (64 + 4: con
 template <int NTW, int NPW, int NOW>
 __device__ __forceinline__ void bfd_epilogue(const MfmaConvParams& P, float* smem_f, const f32x4 (&acc)[4][NTW], int n,
                                              int r0, int c0, int ocb, int pw, int ow, int lane, bool active = true) {
+  float amax = 0.f;
   const int j = lane & 15, kq = lane >> 4;
   const int npx = P.TH * P.TW;
   __syncthreads();
@@ -183,13 +186,15 @@ __device__ __forceinline__ void bfd_epilogue(const MfmaConvParams& P, float* sme
             const epi_f4 v = *reinterpret_cast<const epi_f4*>(st + row * BFD_EPI_STRIDE + q4 * 4);
             // vector path only: the host routes layers that could need the scalar fallback to other kernels
             // (conv_epi_all_vector), which keeps its hoisted index divisions out of these kernels
-            epi_store4_tile(P.ep, col, et, r, c, v, P.out);
+            const epi_f4 o = epi_store4_tile(P.ep, col, et, r, c, v, P.out);
+            if (P.ep.y_amax) amax = abs_max4(amax, o);
           }
         }
       }
     }
     __syncthreads();
   }
+  if (P.ep.y_amax) amax_commit_block(P.ep.y_amax, amax, blockIdx.x, smem_f, (int)(blockDim.x >> 6));  // (slab is free)
 }
 
 // Direct epilogue of the transposed product (C/D: col = lane & 15 = pixel of the M tile, rows kq*4 + reg = 4
@@ -205,6 +210,7 @@ __device__ __forceinline__ void bfd_epilogue_direct(const MfmaConvParams& P, con
   const int npx = P.TH * P.TW;
   const int tw_magic = div_small_magic(P.TW);
   const EpiTile et = epi_tile_setup(P, n, r0, c0);
+  float amax = 0.f;
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
     const int oc4 = ocb + (ow * NTW + nt) * 16 + kq * 4;
@@ -215,10 +221,14 @@ __device__ __forceinline__ void bfd_epilogue_direct(const MfmaConvParams& P, con
       const int m = pw * 64 + mt * 16 + j;
       if (m < npx) {
         const int r = div_small(m, tw_magic), c = m - r * P.TW;
-        if (r0 + r < P.PH && c0 + c < P.PW) epi_store4_tile(P.ep, col, et, r, c, acc[mt][nt], P.out);
+        if (r0 + r < P.PH && c0 + c < P.PW) {
+          const epi_f4 o = epi_store4_tile(P.ep, col, et, r, c, acc[mt][nt], P.out);
+          if (P.ep.y_amax) amax = abs_max4(amax, o);
+        }
       }
     }
   }
+  if (P.ep.y_amax) amax_commit(P.ep.y_amax, amax, blockIdx.x + (threadIdx.x >> 6));
 }
 
 // KS = 2 (small problems with every chunk staged up front): a second set of NPW*NOW waves takes the odd channel
@@ -235,9 +245,10 @@ constexpr int bfd_occ() {
   return 0;
 }
 
-template <int NTW, int NPW, int NOW, int NP, int PF, int KS>
-__global__ __launch_bounds__(64 * NPW * NOW * KS, (bfd_occ<NTW, NPW, NOW, NP, PF, KS>() ? bfd_occ<NTW, NPW, NOW, NP, PF, KS>() : 2)) void k_conv_bfd(
+template <int NTW, int NPW, int NOW, int NP, int PF, int KS, bool F16 = false, int OCCX = 0>
+__global__ __launch_bounds__(64 * NPW * NOW * KS, OCCX ? OCCX : (bfd_occ<NTW, NPW, NOW, NP, PF, KS>() ? bfd_occ<NTW, NPW, NOW, NP, PF, KS>() : 2)) void k_conv_bfd(
     BfdParams B) {
+  static_assert(!F16 || NP == 2, "f16x3 has two planes");
   constexpr int NTHR = 64 * NPW * NOW * KS;
   constexpr bool TEPI = NPW == 1;
   // the bf16x6 4-wave block (the training forward of every 64-channel layer at benchmark batch sizes) is compiled for
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, (bfd_occ<NTW, NPW, NOW, NP, PF
   // 6.66 -> 6.62 ms (BFD_OCC3=0 restores the old build)
   // the 4-wave 64-pixel block without the K split (2 .. 8 tiles per CU: the up-sampler and the discriminator's middle
   // layers at 16 patches) likewise: 187 / 208 -> 116 / 137 VGPRs = 4 / 3 resident blocks per CU instead of 2
-  constexpr bool OCC3 = bfd_occ<NTW, NPW, NOW, NP, PF, KS>() != 0;
+  constexpr bool OCC3 = bfd_occ<NTW, NPW, NOW, NP, PF, KS>() != 0 || OCCX != 0;
   constexpr int SIT = OCC3 ? 2 : BFD_STAGE_IT;
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   const MfmaConvParams& P = B.P;
@@ -287,6 +298,13 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, (bfd_occ<NTW, NPW, NOW, NP, PF
   const bool wave_live = pw * 64 < npx;
   const int plane = 4 * B.NPIXp;
   const int wlane = kq * NB + j + ow * NTW * 16;
+  // f16x3: activation scale 2^kx from the running maximum of the input tensor, descale 2^-(kx + kw)
+  float sx = 1.f, dsc = 1.f;
+  if constexpr (F16) {
+    const int kx = amax_scale_exp(amax_read(P.ep.x_amax));
+    sx = exp2i(kx);
+    dsc = exp2i(-kx) * B.w_descale[0];
+  }
 
   // Tap walks in scalar registers (no LDS tables, no per-tap division): virtual tap (u, v) reads halo offset
   // u*HW + v and weight tap (wh0 + wdh*u)*KW_full + ww0 + wdw*v.  `Walk` is the prefetch head over the flat
@@ -342,7 +360,7 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, (bfd_occ<NTW, NPW, NOW, NP, PF
       // output channels of one pixel and stores them directly (bfd_epilogue_direct)
 #define SRK_BFD_PASS(pa, pb)                                                              \
   _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = \
-      TEPI ? mfma16(bf[pb][nt], a[pa][mt], acc[mt][nt]) : mfma16(a[pa][mt], bf[pb][nt], acc[mt][nt]);
+      TEPI ? mfma16x<F16>(bf[pb][nt], a[pa][mt], acc[mt][nt]) : mfma16x<F16>(a[pa][mt], bf[pb][nt], acc[mt][nt]);
       if (NP == 3) {
         SRK_BFD_PASS(NP - 1, 0)
         SRK_BFD_PASS(0, NP - 1)
@@ -390,9 +408,9 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, (bfd_occ<NTW, NPW, NOW, NP, PF
       if (seg) __syncthreads();  // previous round's halo fully consumed
       for (int c2 = cfirst; c2 < cend && !(B.dbg & 1); ++c2) {
         if (P.mask_y)
-          bfd_stage_halo_t<true, NTHR, NP, SIT>(B, hal + (c2 - cfirst) * cstride, n, r0, c0, c2 * 32);
+          bfd_stage_halo_t<true, NTHR, NP, SIT, F16>(B, hal + (c2 - cfirst) * cstride, n, r0, c0, c2 * 32, sx);
         else
-          bfd_stage_halo_t<false, NTHR, NP, SIT>(B, hal + (c2 - cfirst) * cstride, n, r0, c0, c2 * 32);
+          bfd_stage_halo_t<false, NTHR, NP, SIT, F16>(B, hal + (c2 - cfirst) * cstride, n, r0, c0, c2 * 32, sx);
       }
       __syncthreads();
       const int mine = cfirst + kgrp < cend ? (cend - cfirst - kgrp + KS - 1) / KS : 0;  // chunks of this group in the round
@@ -449,6 +467,12 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, (bfd_occ<NTW, NPW, NOW, NP, PF
         for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] += red[(mt * NTW + nt) * 64];
     }
   }
+  if constexpr (F16) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] *= dsc;
+  }
   if constexpr (TEPI)
     bfd_epilogue_direct<NTW>(P, acc, n, r0, c0, ocb, pw, ow, lane, kgrp == 0);
   else
@@ -458,7 +482,7 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, (bfd_occ<NTW, NPW, NOW, NP, PF
 // ---------------------------------------------------------------------------------------------
 // Host
 // ---------------------------------------------------------------------------------------------
-template <int NTW, int NPW, int NOW, int NP, int PF>
+template <int NTW, int NPW, int NOW, int NP, int PF, bool F16 = false, int OCCX = 0>
 static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
   MfmaConvParams& P = B.P;
   const int maxpix = 64 * NPW;
@@ -506,17 +530,17 @@ static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
       }
       if (lds < red_bytes) lds = red_bytes;
       static LdsLimit lim2;
-      lim2.ensure(reinterpret_cast<const void*>(&k_conv_bfd<NTW, NPW, NOW, NP, PF, 2>), lds);
+      lim2.ensure(reinterpret_cast<const void*>(&k_conv_bfd<NTW, NPW, NOW, NP, PF, 2, F16, OCCX>), lds);
       if (B.dbg & 32)
         fprintf(stderr, "[srk] k_conv_bfd<%d,%d,%d,%d,%d> K-split 2: lds %zu B, grid %u x %u, tile %dx%d halo %dx%d\n", NTW, NPW,
                 NOW, NP, PF, lds, grid.x, grid.y, P.TH, P.TW, P.HH, P.HW);
-      note_kernel("k_conv_bfd<%d,%d,%d,%d,%d,2>", NTW, NPW, NOW, NP, PF);
-      hipLaunchKernelGGL((k_conv_bfd<NTW, NPW, NOW, NP, PF, 2>), grid, dim3(64 * NPW * NOW * 2), lds, s, B);
+      note_kernel("k_conv_bfd<%d,%d,%d,%d,%d,2%s>", NTW, NPW, NOW, NP, PF, F16 ? ",f16" : "");
+      hipLaunchKernelGGL((k_conv_bfd<NTW, NPW, NOW, NP, PF, 2, F16, OCCX>), grid, dim3(64 * NPW * NOW * 2), lds, s, B);
       return check_launch("conv_bfd");
     }
   }
   static LdsLimit lim;
-  const void* fn = reinterpret_cast<const void*>(&k_conv_bfd<NTW, NPW, NOW, NP, PF, 1>);
+  const void* fn = reinterpret_cast<const void*>(&k_conv_bfd<NTW, NPW, NOW, NP, PF, 1, F16, OCCX>);
   lim.ensure(fn, lds);
   if (B.dbg & 32) {
     int nb = -1;
@@ -524,8 +548,8 @@ static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
     fprintf(stderr, "[srk] k_conv_bfd<%d,%d,%d,%d,%d>: lds %zu B, grid %u x %u, occupancy %d blocks/CU, tile %dx%d halo %dx%d\n",
             NTW, NPW, NOW, NP, PF, lds, grid.x, grid.y, nb, P.TH, P.TW, P.HH, P.HW);
   }
-  note_kernel("k_conv_bfd<%d,%d,%d,%d,%d,1>", NTW, NPW, NOW, NP, PF);
-  hipLaunchKernelGGL((k_conv_bfd<NTW, NPW, NOW, NP, PF, 1>), grid, dim3(64 * NPW * NOW), lds, s, B);
+  note_kernel("k_conv_bfd<%d,%d,%d,%d,%d,1%s%s>", NTW, NPW, NOW, NP, PF, F16 ? ",f16" : "", OCCX == 3 ? ",occ3" : (OCCX == 4 ? ",occ4" : ""));
+  hipLaunchKernelGGL((k_conv_bfd<NTW, NPW, NOW, NP, PF, 1, F16, OCCX>), grid, dim3(64 * NPW * NOW), lds, s, B);
   return check_launch("conv_bfd");
 }
 
@@ -557,9 +581,11 @@ bool conv_bfd_small_problem(const GatherConv& g) {
   return px < 256L * 2 * kNumCU;
 }
 
-template <int NP>
-static int bfd_launch_phase(MfmaConvParams P, const uint4* wq, const uint4* wq3, bool small, hipStream_t s) {
+template <int NP, bool F16 = false>
+static int bfd_launch_phase(MfmaConvParams P, const uint4* wq, const uint4* wq3, bool small, hipStream_t s,
+                            const float* w_descale = nullptr) {
   BfdParams B{};
+  B.w_descale = w_descale;
   const int NT = P.OC >= 64 ? 4 : (P.OC + 15) / 16;
   B.NB = NT * 16;
   B.ICc = (P.IC + 31) / 32;
@@ -571,23 +597,31 @@ static int bfd_launch_phase(MfmaConvParams P, const uint4* wq, const uint4* wq3,
   constexpr int BIG = kLdsBudgetBytes, SMALL = 36 * 1024;
   if (small) {
     switch (NT) {
-      case 1: return bfd_launch<1, 1, 1, NP, 2>(B, SMALL, s);
-      case 2: return bfd_launch<1, 1, 2, NP, 2>(B, SMALL, s);
-      case 3: return bfd_launch<1, 1, 3, NP, 2>(B, SMALL, s);
-      default: return bfd_launch<1, 1, 4, NP, 2>(B, SMALL, s);  // (filter prefetch depth 5 / 8 measured: no gain)
+      case 1: return bfd_launch<1, 1, 1, NP, 2, F16>(B, SMALL, s);
+      case 2: return bfd_launch<1, 1, 2, NP, 2, F16>(B, SMALL, s);
+      case 3: return bfd_launch<1, 1, 3, NP, 2, F16>(B, SMALL, s);
+      default: return bfd_launch<1, 1, 4, NP, 2, F16>(B, SMALL, s);  // (filter prefetch depth 5 / 8 measured: no gain)
     }
   }
   switch (NT) {
-    case 1: return bfd_launch<1, 4, 1, NP, 2>(B, BIG, s);
-    case 2: return bfd_launch<2, 4, 1, NP, 2>(B, BIG, s);
-    case 3: return bfd_launch<3, 4, 1, NP, 1>(B, BIG, s);
+    case 1: return bfd_launch<1, 4, 1, NP, 2, F16>(B, BIG, s);
+    case 2: return bfd_launch<2, 4, 1, NP, 2, F16>(B, BIG, s);
+    case 3: return bfd_launch<3, 4, 1, NP, 1, F16>(B, BIG, s);
     default:
-      if (NP == 3) return bfd_launch<2, 2, 2, NP, 1>(B, BIG, s);
-      return bfd_launch<4, 4, 1, NP, 1>(B, BIG, s);
+      if (NP == 3) return bfd_launch<2, 2, 2, NP, 1, F16>(B, BIG, s);
+      if constexpr (F16) {
+        // experiment switch (SRK_BFD_F16_CFG): 0 = the bf16x3 block (4 pixel-waves x 64 channels, 2 waves per SIMD),
+        // 1 / 2 = the bf16x6 block shape (2 x 2 waves of 64 px x 32 ch) compiled for 3 / 4 waves per SIMD
+        static const int cfg = getenv("SRK_BFD_F16_CFG") ? atoi(getenv("SRK_BFD_F16_CFG")) : 1;
+        if (cfg == 1) return bfd_launch<2, 2, 2, NP, 1, true, 3>(B, BIG, s);
+        if (cfg == 2) return bfd_launch<2, 2, 2, NP, 1, true, 4>(B, BIG, s);
+      }
+      return bfd_launch<4, 4, 1, NP, 1, F16>(B, BIG, s);
   }
 }
 
-// planes = 2: bf16x3, planes = 3: bf16x6.  `wp` is the packed filter buffer of srk_pack_weight_*.
+// planes = 2: bf16x3, planes = 3: bf16x6, planes = 4: f16x3 (forward buffers only; ep.x_amax required).  `wp` is the
+// packed filter buffer of srk_pack_weight_*.
 int conv_bfd_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
                     const float* mask_y, float mask_slope, int planes, hipStream_t s) {
   const size_t elems = (size_t)g.KH * g.KW * g.IC * g.OC;
@@ -595,6 +629,18 @@ int conv_bfd_gather(const GatherConv& g, const float* in, const float* wp, float
   const uint4* wq = reinterpret_cast<const uint4*>(base);
   const uint4* wq3 = reinterpret_cast<const uint4*>(base + bf3_main_bytes(g.IC, g.OC, g.KH * g.KW));
   const bool small = conv_bfd_small_problem(g);
+  if (planes == 4) {
+    if (!ep.x_amax) {
+      set_error("conv_bfd: the f16x3 kernels need srk_epilogue.x_amax");
+      return SRK_ERR_BAD_ARG;
+    }
+    const char* fbase = base + f16_section_offset(g.IC, g.OC, g.KH * g.KW);
+    const uint4* wh = reinterpret_cast<const uint4*>(fbase);
+    const float* trailer = reinterpret_cast<const float*>(fbase + bf3_main_bytes(g.IC, g.OC, g.KH * g.KW));
+    return for_each_phase(g, in, wp, out, ep, mask_y, mask_slope, [&](const MfmaConvParams& P) {
+      return bfd_launch_phase<2, true>(P, wh, nullptr, small, s, trailer);
+    });
+  }
   return for_each_phase(g, in, wp, out, ep, mask_y, mask_slope, [&](const MfmaConvParams& P) {
     return planes == 3 ? bfd_launch_phase<3>(P, wq, wq3, small, s) : bfd_launch_phase<2>(P, wq, wq3, small, s);
   });

@@ -307,7 +307,9 @@ extern "C" int srk_pack_weight_fwd(const float* w, float* wp, int Cout, int Cin,
 extern "C" size_t srk_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int bwd) {
   if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 0;
   const size_t elems = (size_t)KH * KW * Cin * Cout;
-  return bf3_prepared_offset(elems) + bf3_prepared_bytes(bwd ? Cout : Cin, bwd ? Cin : Cout, KH * KW);
+  if (bwd) return bf3_prepared_offset(elems) + bf3_prepared_bytes(Cout, Cin, KH * KW);
+  // forward buffers: + the fp16 planes and trailer of SRK_ALGO_MFMA_F16X3
+  return bf3_prepared_offset(elems) + f16_section_offset(Cin, Cout, KH * KW) + f16_section_bytes(Cin, Cout, KH * KW);
 }
 extern "C" int srk_pack_weight_bwd(const float* w, float* wp, int Cout, int Cin, int KH, int KW, int transposed,
                                    int ps_r, void* stream) {

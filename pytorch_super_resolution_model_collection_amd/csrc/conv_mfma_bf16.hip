@@ -58,27 +58,34 @@ __device__ __forceinline__ void split8(const float (&f)[8], uint4& hi, uint4& lo
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bf3_pack(const float* __restrict__ w, uint4* __restrict__ dst, int Cout,
                                                   int Cin, int KH, int KW, int transposed, int ps_r, int bwd, int IC,
-                                                  int OC, int ICc, int OCb, int NB) {
+                                                  int OC, int ICc, int OCb, int NB, uint4* __restrict__ f16dst,
+                                                  const float* __restrict__ f16trailer) {
   const long items = (long)KH * KW * ICc * OCb * 4 * NB;
   const long it = (long)blockIdx.x * 256 + threadIdx.x;
   if (it >= items) return;
-  pack_bf3_item(it, w, dst, Cout, Cin, KH, KW, transposed, ps_r, bwd, IC, OC, ICc, OCb, NB);
+  pack_bf3_item(it, w, dst, Cout, Cin, KH, KW, transposed, ps_r, bwd, IC, OC, ICc, OCb, NB, f16dst,
+                f16dst ? f16trailer[1] : 1.f);
+}
+
+__global__ __launch_bounds__(256) void k_pack_f16_trailer(const float* __restrict__ w, long elems, float* __restrict__ trailer) {
+  pack_f16_trailer(w, elems, trailer);
 }
 
 __global__ void k_bf3_pack_rows(const float* __restrict__ w, uint4* __restrict__ dst, int Cout, int Cin, int KH, int KW,
                                 int transposed, int ps_r, int bwd, int IC, int OC, int KS, int OCb, int NB);
 
-static inline int bf3_nb(int OC) { return OC >= 64 ? 64 : ((OC + 15) / 16) * 16; }
+static inline int bf3_nb(int OC) { return pk_nb(OC); }
 
-size_t bf3_prepared_offset(size_t elems) { return (elems * sizeof(float) + 255) & ~(size_t)255; }
+size_t bf3_prepared_offset(size_t elems) { return pk_prepared_offset(elems); }
 
 // planes h, m of the main layout; the third plane (bf16x6 kernels, conv_bfd.hip) follows it
-size_t bf3_main_bytes(int IC, int OC, int T) {
-  const int ICc = (IC + 31) / 32, OCb = (OC + 63) / 64, NB = bf3_nb(OC);
-  return (size_t)T * ICc * OCb * 8 * NB * sizeof(uint4);
-}
+size_t bf3_main_bytes(int IC, int OC, int T) { return pk_main_bytes(IC, OC, T); }
 
 size_t bf3_prepared_bytes(int IC, int OC, int T) { return bf3_main_bytes(IC, OC, T) / 2 * 3; }
+
+// forward buffers: fp16 planes (h, m of w * 2^kw) + trailer behind the bf16 planes (pack_items.h)
+size_t f16_section_offset(int IC, int OC, int T) { return pk_f16_offset(IC, OC, T); }
+size_t f16_section_bytes(int IC, int OC, int T) { return pk_f16_bytes(IC, OC, T); }
 
 int bf3_pack_prepared(const float* w, void* packed_base, int Cout, int Cin, int KH, int KW, int transposed, int ps_r,
                       int bwd, hipStream_t s) {
@@ -95,8 +102,16 @@ int bf3_pack_prepared(const float* w, void* packed_base, int Cout, int Cin, int 
     return check_launch("bf3_pack_prepared_rows");
   }
   const long items = (long)KH * KW * ICc * OCb * 4 * NB;
+  uint4* f16dst = nullptr;
+  float* trailer = nullptr;
+  if (!bwd) {  // forward buffers carry the fp16 planes of SRK_ALGO_MFMA_F16X3: layer maximum first, then the planes
+    char* f16base = reinterpret_cast<char*>(dst) + f16_section_offset(IC, OC, KH * KW);
+    f16dst = reinterpret_cast<uint4*>(f16base);
+    trailer = reinterpret_cast<float*>(f16base + bf3_main_bytes(IC, OC, KH * KW));
+    hipLaunchKernelGGL(k_pack_f16_trailer, dim3(1), dim3(256), 0, s, w, (long)elems, trailer);
+  }
   hipLaunchKernelGGL(k_bf3_pack, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, w, dst, Cout, Cin, KH, KW,
-                     transposed, ps_r, bwd, IC, OC, ICc, OCb, NB);
+                     transposed, ps_r, bwd, IC, OC, ICc, OCb, NB, f16dst, (const float*)trailer);
   return check_launch("bf3_pack_prepared");
 }
 
@@ -419,7 +434,8 @@ __global__ __launch_bounds__(256) void k_bf3_pack_rows(const float* __restrict__
 // Each packed buffer has the srk_pack_weight_fwd / _bwd format (fp32 layout + bf16x3 planes).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void pack_one_dir(const float* w, char* dst, int Cout, int Cin, int KH, int KW,
-                                             int transposed, int ps_r, int bwd, long tid0, long stride) {
+                                             int transposed, int ps_r, int bwd, long tid0, long stride,
+                                             const float* wamax = nullptr) {
   const long elems = (long)KH * KW * Cin * Cout;
   float* wp = reinterpret_cast<float*>(dst);
   for (long e = tid0; e < elems; e += stride) pack_f32_item((int)e, w, wp, Cout, Cin, KH, KW, transposed, ps_r, bwd);
@@ -435,20 +451,91 @@ __device__ __forceinline__ void pack_one_dir(const float* w, char* dst, int Cout
   } else {
     const int ICc = (IC + 31) / 32;
     const long items = (long)KH * KW * ICc * OCb * 4 * NB;
+    uint4* f16dst = nullptr;
+    float f16scale = 1.f;
+    if (!bwd) {
+      char* f16base = reinterpret_cast<char*>(q) + pk_f16_offset(IC, OC, KH * KW);
+      f16dst = reinterpret_cast<uint4*>(f16base);
+      float* trailer = reinterpret_cast<float*>(f16base + pk_main_bytes(IC, OC, KH * KW));
+      if (wamax) {  // layer maximum from k_pack_batched_amax: every thread derives the scale, the first one records it
+        const float a = *wamax;
+        int k = 0;
+        if (a != 0.f) k = 140 - (int)((__float_as_uint(a) >> 23) & 0xff);
+        k = k < -126 ? -126 : (k > 126 ? 126 : k);
+        f16scale = __uint_as_float((unsigned)(127 + k) << 23);
+        if (tid0 == 0) {
+          trailer[0] = __uint_as_float((unsigned)(127 - k) << 23);
+          trailer[1] = f16scale;
+        }
+      } else {      // trailer written by k_pack_batched_trailers, launched in front of this kernel
+        f16scale = trailer[1];
+      }
+    }
     for (long it = tid0; it < items; it += stride)
-      pack_bf3_item(it, w, q, Cout, Cin, KH, KW, transposed, ps_r, bwd, IC, OC, ICc, OCb, NB);
+      pack_bf3_item(it, w, q, Cout, Cin, KH, KW, transposed, ps_r, bwd, IC, OC, ICc, OCb, NB, f16dst, f16scale);
   }
+}
+
+// Per-layer weight maxima for the f16 trailers of the forward buffers.  Column 11 of a table row = byte offset (in
+// `packed`) of the layer's 4-byte scratch word, zeroed by the caller before the launch: blocks of 4096 weights take the
+// maximum of their slice and raise the word (one atomic per block); k_pack_batched then derives the scale from it and
+// its first block writes the trailer.  Column 11 < 0: one block scans the whole layer (k_pack_batched_trailers).
+__global__ __launch_bounds__(256) void k_pack_batched_amax(const float* __restrict__ params, char* __restrict__ packed,
+                                                           const long long* __restrict__ table, int slices) {
+  const long long* row = table + (size_t)blockIdx.y * kPackCols;
+  if (row[1] < 0 || row[11] < 0) return;
+  const int Cout = (int)row[3], Cin = (int)row[4], KH = (int)row[5], KW = (int)row[6], transposed = (int)row[7];
+  if (Cin <= 4 && !transposed) return;
+  const long elems = (long)KH * KW * Cin * Cout;
+  const float* w = params + row[0];
+  __shared__ float sm[4];
+  float a = 0.f;
+  if ((long)blockIdx.x * 1024 >= elems) return;   // (whole block: nothing of this layer left for the slice)
+  if ((reinterpret_cast<uintptr_t>(w) & 15) == 0) {   // flat parameter buffers keep every tensor 16-byte aligned
+    typedef float pa_f4 __attribute__((ext_vector_type(4)));
+    const long n4 = elems >> 2;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)slices * 256) {
+      const pa_f4 v = reinterpret_cast<const pa_f4*>(w)[e];
+      a = fmaxf(fmaxf(a, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    if (blockIdx.x == 0)
+      for (long e = (n4 << 2) + threadIdx.x; e < elems; e += 256) a = fmaxf(a, fabsf(w[e]));
+  } else {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < elems; e += (long)slices * 256) a = fmaxf(a, fabsf(w[e]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    atomicMax(reinterpret_cast<unsigned*>(packed + row[11]), __float_as_uint(a));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pack_batched_trailers(const float* __restrict__ params, char* __restrict__ packed,
+                                                               const long long* __restrict__ table) {
+  const long long* row = table + (size_t)blockIdx.x * kPackCols;
+  if (row[1] < 0 || row[11] >= 0) return;
+  const int Cout = (int)row[3], Cin = (int)row[4], KH = (int)row[5], KW = (int)row[6], transposed = (int)row[7];
+  if (Cin <= 4 && !transposed) return;  // row-packed first layers carry no fp16 planes
+  const long elems = (long)KH * KW * Cin * Cout;
+  char* f16base = packed + row[1] + pk_prepared_offset(elems) + pk_f16_offset(Cin, Cout, KH * KW);
+  pack_f16_trailer(params + row[0], elems, reinterpret_cast<float*>(f16base + pk_main_bytes(Cin, Cout, KH * KW)));
 }
 
 __global__ __launch_bounds__(256) void k_pack_batched(const float* __restrict__ params, char* __restrict__ packed,
                                                       const long long* __restrict__ table) {
-  const long long* row = table + (size_t)blockIdx.y * 12;
+  const long long* row = table + (size_t)blockIdx.y * kPackCols;
   const float* w = params + row[0];
   const int Cout = (int)row[3], Cin = (int)row[4], KH = (int)row[5], KW = (int)row[6];
   const int transposed = (int)row[7], ps_r = (int)row[8];
   const long tid0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
-  if (row[1] >= 0) pack_one_dir(w, packed + row[1], Cout, Cin, KH, KW, transposed, ps_r, 0, tid0, stride);
-  if (row[2] >= 0) pack_one_dir(w, packed + row[2], Cout, Cin, KH, KW, transposed, ps_r, 1, tid0, stride);
+  const float* wamax = row[11] >= 0 ? reinterpret_cast<const float*>(packed + row[11]) : nullptr;
+  const bool fast = row[12] >= 0;   // filters packed by k_pack_fast (only the pixel-shuffle bias is left for this kernel)
+  if (fast && !(row[9] >= 0 && row[10] >= 0 && ps_r > 1)) return;
+  if (!fast && row[1] >= 0) pack_one_dir(w, packed + row[1], Cout, Cin, KH, KW, transposed, ps_r, 0, tid0, stride, wamax);
+  if (!fast && row[2] >= 0) pack_one_dir(w, packed + row[2], Cout, Cin, KH, KW, transposed, ps_r, 1, tid0, stride);
   if (row[9] >= 0 && row[10] >= 0 && ps_r > 1) {
     const float* b = params + row[9];
     float* bp = reinterpret_cast<float*>(packed + row[10]);
@@ -460,8 +547,146 @@ __global__ __launch_bounds__(256) void k_pack_batched(const float* __restrict__ 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fast path of the whole-model pack for plain Conv2d filters (not transposed, <= 25 taps, channel counts without padding in
+// the prepared layouts -- Cout = 32 or a multiple of 64, Cin = 16 / 32 / 48 or a multiple of 64 --, both directions wanted): the generic kernel gathers every packed value with its own 4-byte load at a stride of KH*KW or
+// Cin*KH*KW floats -- ~6 M scattered loads per EDSR pack, 38 us.  Here a block reads the filters of 8 packed-consecutive
+// output channels x one 32-channel chunk ONCE, coalesced, into LDS ([8][32][taps], row stride + 1 float against bank
+// conflicts) and writes all six layouts of that tile from there in contiguous runs: fp32 forward / backward, bf16 planes
+// h, m, l of both directions, fp16 planes of the forward buffer.  `fast_blocks`: (layer, local block) per block; local block
+// = octet * ICc + chunk.  Same bytes as pack_one_dir (tests/test_train_gpu.py::test_pack_plan_equals_per_layer_pack).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_fast(const float* __restrict__ params, char* __restrict__ packed,
+                                                   const long long* __restrict__ table, const int* __restrict__ fast_blocks) {
+  extern __shared__ float tile[];
+  const int layer = fast_blocks[2 * blockIdx.x], lb = fast_blocks[2 * blockIdx.x + 1];
+  const long long* row = table + (size_t)layer * kPackCols;
+  const float* __restrict__ w = params + row[0];
+  const int Cout = (int)row[3], Cin = (int)row[4], KH = (int)row[5], KW = (int)row[6], ps_r = (int)row[8];
+  const int T = KH * KW;
+  const int ICc = (Cin + 31) / 32;
+  const int oct = lb / ICc, cc = lb - oct * ICc;
+  const int cop0 = oct * 8;                       // first of 8 packed-consecutive output channels
+  const int CW = Cin - cc * 32 < 32 ? Cin - cc * 32 : 32;
+  const int RS = 32 * T + 1;                      // LDS row stride (floats)
+  const int tid = threadIdx.x;
+  const long elems = (long)T * Cin * Cout;
+  // torch channel of packed channel cop (pixel-shuffle layers: packed order (i, j, c) -> c * r^2 + i * r + j)
+  auto torch_co = [&](int cop) {
+    if (ps_r <= 1) return cop;
+    const int C = Cout / (ps_r * ps_r);
+    const int q = cop / C, c = cop - q * C;
+    return c * ps_r * ps_r + q;
+  };
+#pragma unroll 1
+  for (int k = 0; k < 8; ++k) {
+    const float* src = w + ((size_t)torch_co(cop0 + k) * Cin + cc * 32) * T;
+    for (int r = tid; r < CW * T; r += 256) tile[k * RS + r] = src[r];
+  }
+  __syncthreads();
+  char* dstf = packed + row[1];
+  char* dstb = packed + row[2];
+  // ---- fp32 layouts: forward wp[tap][ci][co'], backward wp[tap][co'][ci]
+  {
+    float* wf = reinterpret_cast<float*>(dstf);
+    float* wb = reinterpret_cast<float*>(dstb);
+    const int n = T * CW * 8;
+    for (int i = tid; i < n; i += 256) {
+      const int k = i & 7, rest = i >> 3;
+      const int tap = rest / CW, c = rest - tap * CW;
+      wf[((size_t)tap * Cin + cc * 32 + c) * Cout + cop0 + k] = tile[k * RS + c * T + tap];
+    }
+    for (int i = tid; i < n; i += 256) {
+      const int c = i % CW, rest = i / CW;
+      const int k = rest & 7, tap = rest >> 3;
+      wb[((size_t)tap * Cout + cop0 + k) * Cin + cc * 32 + c] = tile[k * RS + c * T + tap];
+    }
+  }
+  // ---- forward planes: item (tap, group g, k): 8 input channels g*8 .. g*8+7 of output channel cop0 + k
+  {
+    const int OCb = (Cout + 63) / 64, NB = pk_nb(Cout);
+    uint4* q = reinterpret_cast<uint4*>(dstf + pk_prepared_offset(elems));
+    uint4* third = q + (size_t)T * ICc * OCb * (size_t)(8 * NB);
+    char* f16base = reinterpret_cast<char*>(q) + pk_f16_offset(Cin, Cout, T);
+    uint4* f16dst = reinterpret_cast<uint4*>(f16base);
+    float* trailer = reinterpret_cast<float*>(f16base + pk_main_bytes(Cin, Cout, T));
+    float f16scale;
+    if (row[11] >= 0) {
+      const float a = *reinterpret_cast<const float*>(packed + row[11]);
+      int kx = 0;
+      if (a != 0.f) kx = 140 - (int)((__float_as_uint(a) >> 23) & 0xff);
+      kx = kx < -126 ? -126 : (kx > 126 ? 126 : kx);
+      f16scale = __uint_as_float((unsigned)(127 + kx) << 23);
+      if (lb == 0 && tid == 0) {
+        trailer[0] = __uint_as_float((unsigned)(127 - kx) << 23);
+        trailer[1] = f16scale;
+      }
+    } else {
+      f16scale = trailer[1];
+    }
+    const int n = T * 32;
+    for (int it = tid; it < n; it += 256) {
+      const int k = it & 7, g = (it >> 3) & 3, tap = it >> 5;
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = g * 8 + e < CW ? tile[k * RS + (g * 8 + e) * T + tap] : 0.f;
+      const int cop = cop0 + k;
+      const int ocb = cop >> 6, col = cop - ocb * 64;
+      const size_t slot = (size_t)(tap * ICc + cc) * OCb + ocb;
+      uint4 hi, mid, lo, fh, fm;
+      pk_split8x3(f, hi, mid, lo);
+      pk_split8h(f, f16scale, fh, fm);
+      uint4* blk = q + slot * (size_t)(8 * NB);
+      blk[(0 * 4 + g) * NB + col] = hi;
+      blk[(1 * 4 + g) * NB + col] = mid;
+      third[slot * (size_t)(4 * NB) + g * NB + col] = lo;
+      uint4* fb = f16dst + slot * (size_t)(8 * NB);
+      fb[(0 * 4 + g) * NB + col] = fh;
+      fb[(1 * 4 + g) * NB + col] = fm;
+    }
+  }
+  // ---- backward planes (roles swapped: K runs over the packed output channels): item (tap, c): the 8 channels of this
+  // block are one 8-channel group of the contraction axis
+  {
+    const int ICcb = (Cout + 31) / 32, OCbb = (Cin + 63) / 64, NBb = pk_nb(Cin);
+    uint4* q = reinterpret_cast<uint4*>(dstb + pk_prepared_offset(elems));
+    uint4* third = q + (size_t)T * ICcb * OCbb * (size_t)(8 * NBb);
+    const int ccb = cop0 >> 5, gb = (cop0 & 31) >> 3;
+    const int n = T * CW;
+    for (int it = tid; it < n; it += 256) {
+      const int c = it % CW, tap = it / CW;
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = tile[e * RS + c * T + tap];
+      const int ci = cc * 32 + c;
+      const int ocb = ci >> 6, col = ci - ocb * 64;
+      const size_t slot = (size_t)(tap * ICcb + ccb) * OCbb + ocb;
+      uint4 hi, mid, lo;
+      pk_split8x3(f, hi, mid, lo);
+      uint4* blk = q + slot * (size_t)(8 * NBb);
+      blk[(0 * 4 + gb) * NBb + col] = hi;
+      blk[(1 * 4 + gb) * NBb + col] = mid;
+      third[slot * (size_t)(4 * NBb) + gb * NBb + col] = lo;
+    }
+  }
+}
+
 int pack_weights_batched(const float* params, void* packed, const long long* table, int n_layers, int blocks,
-                         hipStream_t s) {
+                         hipStream_t s, bool has_unscratched, const int* fast_blocks, int n_fast_blocks) {
+  // layer maxima for the fp16 planes: parallel slices into the caller-zeroed scratch words (table column 11 >= 0), or
+  // one block per layer for rows without one
+  const int slices = 16;
+  hipLaunchKernelGGL(k_pack_batched_amax, dim3((unsigned)slices, (unsigned)n_layers), dim3(256), 0, s, params,
+                     static_cast<char*>(packed), table, slices);
+  if (has_unscratched)
+    hipLaunchKernelGGL(k_pack_batched_trailers, dim3((unsigned)n_layers), dim3(256), 0, s, params, static_cast<char*>(packed),
+                       table);
+  if (fast_blocks && n_fast_blocks > 0) {
+    const size_t lds = (size_t)8 * (32 * 25 + 1) * sizeof(float);   // tile of the largest eligible filter (25 taps)
+    hipLaunchKernelGGL(k_pack_fast, dim3((unsigned)n_fast_blocks), dim3(256), lds, s, params, static_cast<char*>(packed),
+                       table, fast_blocks);
+  }
   hipLaunchKernelGGL(k_pack_batched, dim3((unsigned)blocks, (unsigned)n_layers), dim3(256), 0, s, params,
                      static_cast<char*>(packed), table);
   return check_launch("pack_weights_batched");

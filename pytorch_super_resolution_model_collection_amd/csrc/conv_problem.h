@@ -23,6 +23,8 @@ struct Epi {
   int act;
   int prelu_n;
   int ps_r;
+  const float* x_amax;  // SRK_AMAX_SLOTS floats (f16x3 kernels)
+  float* y_amax;        // optional running max of |out| (kernels that support it)
 };
 
 inline Epi make_epi(const srk_epilogue* e) {
@@ -35,6 +37,8 @@ inline Epi make_epi(const srk_epilogue* e) {
     r.act = e->act;
     r.prelu_n = e->prelu_n;
     r.ps_r = e->ps_r > 1 ? e->ps_r : 0;
+    r.x_amax = e->x_amax;
+    r.y_amax = e->y_amax;
   }
   return r;
 }
@@ -107,13 +111,18 @@ static inline bool conv_epi_all_vector(int OC, const Epi& ep, const float* out) 
   return true;
 }
 
-// conv_bfd.hip: filters straight from global memory; planes 2 = bf16x3, 3 = bf16x6 (fp32-faithful)
+// f16x3 section of a forward packed buffer (conv_mfma_bf16.hip): fp16 planes h, m in the bf16 main layout, then a
+// 256-byte trailer {float descale = 2^-kw, float scale = 2^kw}
+size_t f16_section_offset(int IC, int OC, int T);  // from the start of the prepared (bf16) section
+size_t f16_section_bytes(int IC, int OC, int T);
+// conv_bfd.hip: filters straight from global memory; planes 2 = bf16x3, 3 = bf16x6 (fp32-faithful), 4 = f16x3
 bool conv_bfd_gather_supported(const GatherConv& g, const Epi& ep);
 bool conv_bfd_small_problem(const GatherConv& g);
 // conv_res2.hip: both 3x3 64 -> 64 convs of a residual block in one launch per 8x8 tile (small problems)
 bool conv_res2_supported(int N, int H, int W, int C);
 int conv_res2(const float* in, const float* wp1, const float* wp2, const float* bias1, const float* bias2,
-              const float* gate, float* mid, float* out, int N, int H, int W, int planes, bool bwd, hipStream_t s);
+              const float* gate, float* mid, float* out, int N, int H, int W, int planes, bool bwd, hipStream_t s,
+              const float* x_amax = nullptr, float* y_amax = nullptr);
 int conv_bfd_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
                     const float* mask_y, float mask_slope, int planes, hipStream_t s);
 int bf3_pack_prepared(const float* w, void* packed_base, int Cout, int Cin, int KH, int KW, int transposed, int ps_r,

@@ -47,6 +47,11 @@ struct Res2Params {
   float* out;
   int N, H, W, tiles_y, tiles_x;
   int dbg;
+  // f16x3 forward (SRK_ALGO_MFMA_F16X3): wq1 / wq2 point at the fp16 planes, wd1 / wd2 at their trailers {2^-kw, 2^kw}
+  const float* x_amax;
+  float* y_amax;   // optional (any arithmetic): running max of |out|
+  const float* wd1;
+  const float* wd2;
 };
 
 template <int NP>
@@ -67,6 +72,21 @@ __device__ __forceinline__ void r2_split4(const f32x4& v, uint2 (&pl)[NP]) {
   if (NP == 3) pl[NP - 1] = __builtin_bit_cast(uint2, l);
 }
 
+__device__ __forceinline__ void r2_split4h(const f32x4& v, float s, uint2 (&pl)[2]) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  f16x4 h, m;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float x = v[e] * s;
+    const _Float16 hh = (_Float16)x;
+    h[e] = hh;
+    m[e] = (_Float16)(x - (float)hh);
+  }
+  pl[0] = __builtin_bit_cast(uint2, h);
+  pl[1] = __builtin_bit_cast(uint2, m);
+}
+
+#define mfma16 mfma16x<F16>
 #define SRK_R2_PASSES(ACC, A, BF, MT)                                                                   \
   {                                                                                                     \
     if (NP == 3) {                                                                                      \
@@ -79,9 +99,19 @@ __device__ __forceinline__ void r2_split4(const f32x4& v, uint2 (&pl)[NP]) {
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) ACC[mt] = mfma16(BF[0], A[0][mt], ACC[mt]);        \
   }
 
-template <int NP, bool BWD>
+template <int NP, bool BWD, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
+  static_assert(!F16 || (NP == 2 && !BWD), "f16x3 is the two-plane forward arithmetic");
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+  __shared__ float r2_amx[8];
+  // f16x3: input scale 2^kx from the tensor's running maximum; the intermediate gets its own scale from the tile's maximum
+  float sx = 1.f, dsc1 = 1.f;
+  int kx = 0;
+  if constexpr (F16) {
+    kx = amax_scale_exp(amax_read(R.x_amax));
+    sx = exp2i(kx);
+    dsc1 = exp2i(-kx) * R.wd1[0];
+  }
   uint4* hal1 = smem4;                          // [2 chunks][NP][4 groups][144 pixels]
   uint4* hal2 = smem4 + 2 * NP * 4 * R2_NPIX1;  // [2][NP][4][112]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -142,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
           f[4 + e] = v1[k][e];
         }
         uint4 pl[NP];
-        split8n<NP>(f, pl);
+        if constexpr (F16) split8h(f, sx, pl); else split8n<NP>(f, pl);
         const int chunk = g8 >> 2, g = g8 & 3;
 #pragma unroll
         for (int p = 0; p < NP; ++p) hal1[((chunk * NP + p) * 4 + g) * R2_NPIX1 + hp] = pl[p];
@@ -208,17 +238,20 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
     for (int mt = 0; mt < 4; ++mt) red[mt * 64] = acc1[mt];
   }
   __syncthreads();
+  float smid = 1.f, dsc2 = 1.f;
   {
     f32x4 b1 = {0.f, 0.f, 0.f, 0.f};
     if (!BWD && R.bias1) b1 = *reinterpret_cast<const f32x4*>(R.bias1 + ch4);
     const int ch2 = ow >> 1, g2 = (ow & 1) * 2 + (kq >> 1);
+    f32x4 vv[4];
+    float lmax = 0.f;
 #pragma unroll
     for (int mt = 0; mt < R2_MT1; ++mt) {
       if ((mt < 4) != (kgrp == 0)) continue;
       const int q = mt & 3;
-      const int m = mt * 16 + j;
       f32x4 v = acc1[mt] + red[mt * 64];
       if (!BWD) {
+        if constexpr (F16) v *= dsc1;
         v += b1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -228,9 +261,29 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
       }
       if (moff[q] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};  // outside the image: the second conv's zero padding
       if (mcen[q]) *reinterpret_cast<f32x4*>(R.mid + img + moff[q]) = v;
+      vv[q] = v;
+      if constexpr (F16) lmax = abs_max4(lmax, v);
+    }
+    if constexpr (F16) {
+      // the intermediate's scale: maximum over the whole 10 x 10 x 64 tile (the second conv mixes all of it)
+      lmax = wave_max(lmax);
+      if (lane == 0) r2_amx[wave] = lmax;
+      __syncthreads();
+      float m8 = r2_amx[0];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) m8 = fmaxf(m8, r2_amx[i]);
+      const int km = amax_scale_exp(m8);
+      smid = exp2i(km);
+      dsc2 = exp2i(-km) * R.wd2[0];
+    }
+#pragma unroll
+    for (int mt = 0; mt < R2_MT1; ++mt) {
+      if ((mt < 4) != (kgrp == 0)) continue;
+      const int q = mt & 3;
+      const int m = mt * 16 + j;
       if (m < R2_NMID) {
         uint2 pl[NP];
-        r2_split4<NP>(v, pl);
+        if constexpr (F16) r2_split4h(vv[q], smid, pl); else r2_split4<NP>(vv[q], pl);
 #pragma unroll
         for (int p = 0; p < NP; ++p)
           reinterpret_cast<uint2*>(hal2 + ((ch2 * NP + p) * 4 + g2) * R2_NPIX2 + m)[kq & 1] = pl[p];
@@ -290,17 +343,23 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
   __syncthreads();
   f32x4 b2 = {0.f, 0.f, 0.f, 0.f};
   if (!BWD && R.bias2) b2 = *reinterpret_cast<const f32x4*>(R.bias2 + ch4);
+  float oamax = 0.f;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int mt = kgrp * 2 + q;
     if (ooff[q] >= 0) {
       const f32x4 own = kgrp ? (q ? acc2[3] : acc2[2]) : (q ? acc2[1] : acc2[0]);
-      const f32x4 v = own + red2[mt * 64] + b2 + res[q];
+      f32x4 v = own + red2[mt * 64];
+      if constexpr (F16) v *= dsc2;
+      v = v + b2 + res[q];
       *reinterpret_cast<f32x4*>(R.out + img + ooff[q]) = v;
+      if (R.y_amax) oamax = abs_max4(oamax, v);
     }
   }
+  if (R.y_amax) amax_commit_block(R.y_amax, oamax, blockIdx.x, r2_amx, 8);
 }
 #undef SRK_R2_PASSES
+#undef mfma16
 
 static int r2_dbg() {
   static const int dbg = getenv("SRK_DBG") ? atoi(getenv("SRK_DBG")) : 0;
@@ -319,20 +378,21 @@ bool conv_res2_supported(int N, int H, int W, int C) {
   return tiles <= max_tiles;
 }
 
-template <int NP, bool BWD>
+template <int NP, bool BWD, bool F16 = false>
 static int r2_launch(const Res2Params& R, hipStream_t s) {
   const size_t lds = (size_t)2 * NP * 4 * (R2_NPIX1 + R2_NPIX2) * 16;
   static LdsLimit lim;
-  lim.ensure(reinterpret_cast<const void*>(&k_res2<NP, BWD>), lds);
-  note_kernel("k_res2<%d,%d>", NP, (int)BWD);
-  hipLaunchKernelGGL((k_res2<NP, BWD>), dim3((unsigned)((size_t)R.N * R.tiles_y * R.tiles_x)), dim3(512), lds, s, R);
+  lim.ensure(reinterpret_cast<const void*>(&k_res2<NP, BWD, F16>), lds);
+  note_kernel("k_res2<%d,%d%s>", NP, (int)BWD, F16 ? ",f16" : "");
+  hipLaunchKernelGGL((k_res2<NP, BWD, F16>), dim3((unsigned)((size_t)R.N * R.tiles_y * R.tiles_x)), dim3(512), lds, s, R);
   return check_launch("conv_res2");
 }
 
 // `wp1` / `wp2`: packed filter buffers of srk_pack_weight_fwd (forward) / srk_pack_weight_bwd (backward) of the conv
-// that runs first / second in this direction.  planes = 3: bf16x6, 2: bf16x3.
+// that runs first / second in this direction.  planes = 3: bf16x6, 2: bf16x3, 4: f16x3 (forward only, x_amax required).
 int conv_res2(const float* in, const float* wp1, const float* wp2, const float* bias1, const float* bias2,
-              const float* gate, float* mid, float* out, int N, int H, int W, int planes, bool bwd, hipStream_t s) {
+              const float* gate, float* mid, float* out, int N, int H, int W, int planes, bool bwd, hipStream_t s,
+              const float* x_amax, float* y_amax) {
   const size_t elems = (size_t)9 * R2_C * R2_C;
   const char* b1 = reinterpret_cast<const char*>(wp1) + bf3_prepared_offset(elems);
   const char* b2 = reinterpret_cast<const char*>(wp2) + bf3_prepared_offset(elems);
@@ -352,6 +412,20 @@ int conv_res2(const float* in, const float* wp1, const float* wp2, const float* 
   R.tiles_y = (H + R2_TS - 1) / R2_TS;
   R.tiles_x = (W + R2_TS - 1) / R2_TS;
   R.dbg = r2_dbg();
+  R.x_amax = x_amax;
+  R.y_amax = y_amax;
+  if (planes == 4) {
+    if (bwd || !x_amax) {
+      set_error("conv_res2: f16x3 is a forward arithmetic and needs x_amax");
+      return SRK_ERR_BAD_ARG;
+    }
+    const size_t foff = f16_section_offset(R2_C, R2_C, 9);
+    R.wq1 = reinterpret_cast<const uint4*>(b1 + foff);
+    R.wq2 = reinterpret_cast<const uint4*>(b2 + foff);
+    R.wd1 = reinterpret_cast<const float*>(b1 + foff + main_bytes);
+    R.wd2 = reinterpret_cast<const float*>(b2 + foff + main_bytes);
+    return r2_launch<2, false, true>(R, s);
+  }
   if (bwd) return planes == 3 ? r2_launch<3, true>(R, s) : r2_launch<2, true>(R, s);
   return planes == 3 ? r2_launch<3, false>(R, s) : r2_launch<2, false>(R, s);
 }

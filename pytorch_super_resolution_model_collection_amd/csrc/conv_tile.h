@@ -295,9 +295,9 @@ __device__ __forceinline__ EpiTile epi_tile_setup(const MfmaConvParams& P, int n
   return t;
 }
 
-// vector path of epi_store4_col (col.vec must hold) for tile pixel (r, c)
-__device__ __forceinline__ void epi_store4_tile(const Epi& ep, const EpiCol& col, const EpiTile& t, int r, int c,
-                                                epi_f4 v, float* __restrict__ out) {
+// vector path of epi_store4_col (col.vec must hold) for tile pixel (r, c); returns the stored values
+__device__ __forceinline__ epi_f4 epi_store4_tile(const Epi& ep, const EpiCol& col, const EpiTile& t, int r, int c,
+                                                  epi_f4 v, float* __restrict__ out) {
   const size_t off = t.off0 + col.off_oc + (size_t)(unsigned)(r * t.RS + c * t.CS);
   v += col.bias;
   // one (wave-uniform) dispatch per 16-byte store instead of one switch per element
@@ -313,6 +313,7 @@ __device__ __forceinline__ void epi_store4_tile(const Epi& ep, const EpiCol& col
   }
   if (ep.residual) v += *reinterpret_cast<const epi_f4*>(ep.residual + off);
   *reinterpret_cast<epi_f4*>(out + off) = v;
+  return v;
 }
 
 // Exact floor(m / d) for 0 <= m < 256, 1 <= d <= 256 with one multiply (magic = ceil(65536 / d)).

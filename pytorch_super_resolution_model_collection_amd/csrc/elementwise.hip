@@ -222,6 +222,35 @@ __global__ __launch_bounds__(256) void k_scale_dev(const float* __restrict__ x, 
 
 }  // namespace srk
 
+
+namespace srk {
+// max|x| -> the SRK_AMAX_FLOATS buffer (atomic max of non-negative floats as unsigned), one atomic per block
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, size_t n, float* __restrict__ slots) {
+  float a = 0.f;
+  const size_t n4 = n / 4;
+  typedef float am_f4 __attribute__((ext_vector_type(4)));
+  if (((uintptr_t)x & 15) == 0) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+      const am_f4 v = reinterpret_cast<const am_f4*>(x)[i];
+      a = fmaxf(fmaxf(a, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a = fmaxf(a, fabsf(x[i]));
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a = fmaxf(a, fabsf(x[i]));
+  }
+  __shared__ float sm[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    float* p = slots + (blockIdx.x & 15) * 16;   // one slot per 64-byte line (SRK_AMAX_FLOATS)
+    if (a > *p) atomicMax(reinterpret_cast<unsigned*>(p), __float_as_uint(a));
+  }
+}
+}  // namespace srk
+
 using namespace srk;
 
 extern "C" int srk_scale_dev(const float* x, const float* alpha_dev, float* out, size_t n, void* stream) {
@@ -294,4 +323,12 @@ extern "C" int srk_axpby(const float* a, const float* b, float* out, size_t n, f
               "axpby: pointers must be 16-byte aligned");
   hipLaunchKernelGGL(k_axpby, dim3(ew_grid(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, a, b, out, n, alpha, beta);
   return check_launch("axpby");
+}
+
+extern "C" int srk_absmax(const float* x, size_t n, float* amax_slots, void* stream) {
+  SRK_REQUIRE(x && amax_slots && n > 0, "absmax: null pointer or empty");
+  size_t b = (n + 256 * 16 - 1) / (256 * 16);
+  if (b > 1024) b = 1024;
+  hipLaunchKernelGGL(k_absmax, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, x, n, amax_slots);
+  return check_launch("absmax");
 }

@@ -64,6 +64,68 @@ def _algo_for(cfg, role):
     return cfg.algo if cfg.algo != ALGO_AUTO else _MODES[_PRECISION["mode"]][role]
 
 
+# ------------------------------------------------------------------------------------------------
+# fp32-faithful products with three MFMAs: SRK_ALGO_MFMA_F16X3
+# ------------------------------------------------------------------------------------------------
+# Wherever a mode asks for the fp32-faithful class (ALGO_MFMA_BF16X6: six bf16 MFMAs per product) and the fp16 kernels
+# cover the layer, the forward runs f16x3 instead: both operands scaled by a power of two so that their largest magnitude
+# sits at 2^13..2^14, split into two fp16 planes (2 x 11 bits), three MFMAs, exact descale -- 1.2e-7 rms against 0.8e-7
+# for plain fp32 products and 7.6e-8 for bf16x6 (tools/precision_check.py), at the bf16x3 rate.  The scale of the
+# activations needs an upper bound of max|x| ON THE DEVICE: every kernel that can (conv_bfd.hip, conv_res2.hip) leaves
+# the running maximum of what it stored in a 1 KB buffer of 16 slots (`y_amax`), attached to the output tensor as `_srk_amax`;
+# tensors without one (network inputs, outputs of other kernels) get it from one srk_absmax pass.  SRK_F16X3=0: off.
+F16X3 = os.environ.get("SRK_F16X3", "1") != "0"
+F16X3_ALWAYS = os.environ.get("SRK_F16X3", "1") == "2"   # tests: take the srk_absmax pass for every untagged input
+_AMAX_CHUNK_TENSORS = 128
+_AMAX = {}   # device index -> [chunk tensor, slots used]
+_AMAX_EPOCH = [0]
+
+
+def amax_new_step():
+    """Start of a train step (optimizer.zero_grad) or of a graph capture: the next running maximum comes from a fresh
+    zeroed chunk (inside a captured step the zero fill is part of the graph, so every replay starts from zero), and
+    maxima attached to tensors before this point are no longer trusted -- a captured step must recompute the maximum of
+    its static input buffers inside the graph, where every replay sees the batch of that replay."""
+    _AMAX.clear()
+    _AMAX_EPOCH[0] += 1
+
+
+def _amax_alloc(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ent = _AMAX.get(idx)
+    if ent is None or ent[1] >= _AMAX_CHUNK_TENSORS:
+        ent = _AMAX[idx] = [torch.zeros(_AMAX_CHUNK_TENSORS * _lib.AMAX_FLOATS, dtype=torch.float32,
+                                        device=torch.device("cuda", idx)), 0]
+    lo = ent[1] * _lib.AMAX_FLOATS
+    ent[1] += 1
+    return ent[0][lo:lo + _lib.AMAX_FLOATS]
+
+
+def _tag_amax(t, slots):
+    t._srk_amax = (slots, t._version, _AMAX_EPOCH[0])
+
+
+def amax_of(x, compute=True):
+    """The running-maximum buffer of |x| on the device: the producer's, or one srk_absmax pass.  compute=False: only
+    where that pass is known to pay -- x carries the marker a conv kernel without amax support leaves on its output
+    (the first layer of a net: one pass buys f16x3 for the whole trunk behind it); anything else (a BatchNorm output in
+    front of every SRGAN conv) returns None and the caller keeps the six-MFMA arithmetic."""
+    a = getattr(x, "_srk_amax", None)
+    fresh = a is not None and a[1] == x._version and a[2] == _AMAX_EPOCH[0]
+    if fresh and a[0] is not None:
+        return a[0]
+    if not compute and not fresh:
+        return None
+    slots = _amax_alloc(x.device)
+    xs = x if x.is_contiguous() or _is_nhwc_dense(x) else x.contiguous()
+    check(_lib.load().srk_absmax(ptr(xs), xs.numel(), ptr(slots), stream_ptr()), "srk_absmax")
+    try:
+        _tag_amax(x, slots)
+    except Exception:  # noqa: BLE001 -- (a tensor subclass without a __dict__: recomputed next time)
+        pass
+    return slots
+
+
 def _empty_cl(n, c, h, w, like):
     return torch.empty((n, c, h, w), dtype=torch.float32, device=like.device, memory_format=CL)
 
@@ -94,6 +156,9 @@ def to_nhwc(x):
     y = _empty_cl(n, c, h, w, x)
     lib = _lib.load()
     check(lib.srk_nchw_to_nhwc(ptr(x), ptr(y), n, c, h, w, stream_ptr()), "srk_nchw_to_nhwc")
+    a = getattr(x, "_srk_amax", None)   # a permutation keeps the maximum (or the "worth a pass" marker)
+    if a is not None and a[1] == x._version and a[2] == _AMAX_EPOCH[0]:
+        _tag_amax(y, a[0])
     return y
 
 
@@ -201,9 +266,29 @@ def conv_forward_raw(x, wp, bias_p, weight_shape_src, cfg, prelu_w=None, residua
     if residual is not None and tuple(residual.shape) != tuple(y.shape):
         raise RuntimeError("conv: residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
     ep = Epilogue(ptr(bias_p), ptr(prelu_w), ptr(residual), cfg.slope, cfg.act,
-                  0 if prelu_w is None else prelu_w.numel(), cfg.ps_r)
+                  0 if prelu_w is None else prelu_w.numel(), cfg.ps_r, None, None)
+    ya = None
+    if d.algo == _lib.ALGO_MFMA_F16X3:      # asked for by name (ConvCfg.algo): the maximum is computed if nobody left one
+        ep.x_amax = ptr(amax_of(x))
+        ya = _amax_alloc(y.device)
+        ep.y_amax = ptr(ya)
+    elif F16X3 and not x_nchw and d.Cin >= 8 and d.Cout >= 8:
+        # fp32-faithful class on a layer the fp16 kernels cover: three MFMAs per product instead of six
+        if d.algo == _lib.ALGO_MFMA_BF16X6 and lib.srk_conv2d_f16x3_supported(ctypes.byref(d), ctypes.byref(ep), ptr(y)):
+            xa = amax_of(x, compute=F16X3_ALWAYS)
+            if xa is not None:
+                ep.x_amax = ptr(xa)
+                d.algo = _lib.ALGO_MFMA_F16X3
+        if d.algo in (_lib.ALGO_MFMA_F16X3, _lib.ALGO_MFMA_BF16X6):
+            # (a layer of the fp32-faithful class feeds layers of that class: leave them the maximum of the output)
+            ya = _amax_alloc(y.device)      # filled by the kernels of conv_bfd.hip (checked below)
+            ep.y_amax = ptr(ya)
     check(lib.srk_conv2d_forward(ctypes.byref(d), ptr(x), ptr(wp), ptr(y), ctypes.byref(ep), stream_ptr()),
           "srk_conv2d_forward")
+    if ya is not None and lib.srk_last_kernel_name().startswith(b"k_conv_bfd"):
+        _tag_amax(y, ya)
+    elif F16X3 and d.algo in (_lib.ALGO_MFMA, _lib.ALGO_MFMA_BF16X6):
+        _tag_amax(y, None)   # a faithful-class conv whose kernel leaves no maximum: worth one srk_absmax pass downstream
     return y
 
 
@@ -559,8 +644,18 @@ class _ResBlock2(torch.autograd.Function):
         ctx.wpb2 = packed2[2] if packed2 is not None and len(packed2) > 2 else None
         mid = _empty_cl(n, c, h, w, x)
         out = _empty_cl(n, c, h, w, x)
+        algo = _MODES[_PRECISION["mode"]]["train_fwd"]
+        xa = ya = None
+        if F16X3:
+            ya = _amax_alloc(x.device)
+            if algo == _lib.ALGO_MFMA_BF16X6:   # fp32-faithful class: f16x3 (see F16X3 above)
+                xa = amax_of(x, compute=F16X3_ALWAYS)
+                if xa is not None:
+                    algo = _lib.ALGO_MFMA_F16X3
         check(lib.srk_resblock2_forward(n, h, w, c, ptr(x), ptr(wp1), ptr(b1), ptr(wp2), ptr(b2), ptr(mid), ptr(out),
-                                        _MODES[_PRECISION["mode"]]["train_fwd"], stream_ptr()), "srk_resblock2_forward")
+                                        algo, ptr(xa), ptr(ya), stream_ptr()), "srk_resblock2_forward")
+        if ya is not None:
+            _tag_amax(out, ya)
         ctx.refs = (w1, b1, w2, b2)
         ctx.save_for_backward(x, mid)
         return out
@@ -747,6 +842,47 @@ def fork(x):
 # ------------------------------------------------------------------------------------------------
 # Losses (mean reduction), forward + gradient in one pass
 # ------------------------------------------------------------------------------------------------
+# Seeds of a backward pass.  `loss.backward()` makes autograd fill a ones tensor (one ATen launch) and the loss backward
+# multiply its stored gradient by it (srk_scale_dev, a second launch); a data-parallel step seeds with 1/world instead.
+# The train steps of this package know their seed when they compute the loss:
+#   * backward(loss) seeds with a persistent per-device ones tensor, which _Loss.backward recognises (by address) and
+#     answers with the gradient the forward already wrote -- no fill, no scale;
+#   * inside `with loss_seed(value, tensor):` the loss forward folds `value` into that gradient, and a backward seeded with
+#     `tensor` (dp.loss_seed) skips the multiply as well.
+# Any other upstream gradient (a weighted sum of losses, user code) takes the general path.
+_UNIT = {}
+_LOSS_SEED = [None]
+
+
+def unit_seed(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    t = _UNIT.get(idx)
+    if t is None:
+        t = _UNIT[idx] = torch.ones((), dtype=torch.float32, device=torch.device("cuda", idx))
+    return t
+
+
+def backward(losses, seed=None):
+    """torch.autograd.backward(losses) seeded with the persistent ones tensor of the device (or `seed` for each loss)."""
+    losses = list(losses) if isinstance(losses, (list, tuple)) else [losses]
+    g = unit_seed(losses[0].device) if seed is None else seed
+    torch.autograd.backward(losses, [g] * len(losses))
+
+
+class loss_seed(object):
+    """Context: losses computed inside store their gradient already multiplied by `value`; a backward pass seeded with
+    `tensor` (which must hold `value`) then uses it as is."""
+
+    def __init__(self, value, tensor):
+        self.seed = (float(value), tensor)
+
+    def __enter__(self):
+        self.prev, _LOSS_SEED[0] = _LOSS_SEED[0], self.seed
+
+    def __exit__(self, *a):
+        _LOSS_SEED[0] = self.prev
+
+
 class _Loss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target, kind, eps):
@@ -769,7 +905,9 @@ class _Loss(torch.autograd.Function):
         need_grad = ctx.needs_input_grad[0]
         dpred = torch.empty_like(pred) if need_grad else None
         ws = torch.empty(int(lib.srk_loss_workspace_bytes()), dtype=torch.uint8, device=pred.device)
-        check(lib.srk_loss_forward_backward(kind, ptr(pred), ptr(target), strides, n, c, h, w, eps, 1.0, ptr(loss),
+        seed = _LOSS_SEED[0]
+        ctx.seed_ptr, ctx.seed_value = (seed[1].data_ptr(), seed[0]) if seed is not None else (0, 1.0)
+        check(lib.srk_loss_forward_backward(kind, ptr(pred), ptr(target), strides, n, c, h, w, eps, ctx.seed_value, ptr(loss),
                                             ptr(dpred), ptr(ws), stream_ptr()), "srk_loss_forward_backward")
         ctx.dpred = dpred
         return loss
@@ -779,6 +917,14 @@ class _Loss(torch.autograd.Function):
         dpred = ctx.dpred  # (kept on the ctx: a second backward over a retained graph must see it; freed with the graph)
         if dpred is None:
             return None, None, None, None
+        gp = g.data_ptr()
+        if ctx.seed_ptr:
+            if gp == ctx.seed_ptr:      # the seed this loss was computed for: already folded into dpred
+                return dpred, None, None, None
+            # some other upstream gradient: undo the folded seed (dpred = seed * dL/dpred)
+            g = g / ctx.seed_value
+        elif gp == unit_seed(dpred.device).data_ptr():
+            return dpred, None, None, None
         lib = _lib.load()
         out = torch.empty_like(dpred)
         check(lib.srk_scale_dev(ptr(dpred), ptr(g.contiguous()), ptr(out), dpred.numel(), stream_ptr()),

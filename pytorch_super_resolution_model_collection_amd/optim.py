@@ -123,16 +123,38 @@ class PackPlan(object):
             if m.bias is not None and ps_r > 1:
                 b_off = (m.bias.data_ptr() - base) // 4
                 bp_off = take(cout * 4)
-            rows.append([w_off, fo, bo, cout, cin, kh, kw, int(tr), ps_r, b_off, bp_off, 0])
+            rows.append([w_off, fo, bo, cout, cin, kh, kw, int(tr), ps_r, b_off, bp_off, -1, -1, 0])
             self.layers.append((m, fo, nf, bo, nb, bp_off, cout, ps_r))
         self.n = len(rows)
         if self.n == 0:
             return
         dev = flat.data.device
+        # one zeroed 4-byte scratch word per layer for the parallel max|w| pass (fp16 planes of the forward buffers)
+        # (64 bytes apart: atomics on one cache line serialise)
+        self.scratch_off = take(64 * len(rows))
+        for i, r in enumerate(rows):
+            r[11] = self.scratch_off + 64 * i
         self.buf = torch.empty(max(off, 256), dtype=torch.uint8, device=dev)
+        self.scratch = self.buf[self.scratch_off:self.scratch_off + 64 * len(rows)]
+        # fast path (k_pack_fast): plain Conv2d filters are packed tile by tile from LDS, (Cout / 8) * ceil(Cin / 32)
+        # blocks per layer; everything else (first layers, 64 -> 3 convs, deconvs, 9x9 kernels) takes the generic kernel
+        fast = []
+        if os.environ.get("SRK_PACK_FAST", "1") != "0":
+            for i, r in enumerate(rows):
+                cout, cin, kh, kw, tr = r[3], r[4], r[5], r[6], r[7]
+                # (channel counts that leave no padding in either prepared layout: the kernel writes real channels only,
+                #  and the zero groups of a padded contraction axis must exist -- they meet zero activations, 0 x junk)
+                if not tr and kh * kw <= 25 and (cout % 64 == 0 or cout == 32) and (cin % 64 == 0 or cin in (16, 32, 48)) \
+                        and r[1] >= 0 and r[2] >= 0:
+                    r[12] = len(fast)
+                    icc = (cin + 31) // 32
+                    fast += [(i, lb) for lb in range((cout // 8) * icc)]
+        self.n_fast = len(fast)
+        self.fast_blocks = torch.tensor(fast, dtype=torch.int32, device=dev) if fast else None
         self.table = torch.tensor(rows, dtype=torch.int64, device=dev)
         self.epoch = -1
-        biggest = max(r[3] * r[4] * r[5] * r[6] for r in rows)
+        # grid of the generic kernel: sized by the largest filter it still packs itself
+        biggest = max([r[3] * r[4] * r[5] * r[6] for r in rows if r[12] < 0] or [256])
         self.blocks = max(1, min(int(os.environ.get("SRK_PACK_BLOCKS", "512")), (biggest + 255) // 256))
         for m, fo, nf, bo, nb, bp_off, cout, ps_r in self.layers:
             wpf = self.buf[fo:fo + (nf + 3) // 4 * 4].view(torch.float32)
@@ -144,8 +166,9 @@ class PackPlan(object):
         if self.n == 0:
             return
         lib = _lib.load()
-        check(lib.srk_pack_weights_batched(ptr(self.flat.data), ptr(self.buf), ptr(self.table), self.n, self.blocks,
-                                           stream_ptr()), "srk_pack_weights_batched")
+        self.scratch.zero_()
+        check(lib.srk_pack_weights_batched(ptr(self.flat.data), ptr(self.buf), ptr(self.table), self.n, -self.blocks,
+                                           ptr(self.fast_blocks), self.n_fast, stream_ptr()), "srk_pack_weights_batched")
         self.epoch = self.flat.epoch
         for lay in self.layers:  # host-side edits of a parameter (load_state_dict, init) invalidate its views
             m = lay[0]
@@ -191,6 +214,8 @@ class _FlatOptimizer(object):
         packed for the generator phase of the previous one and has not changed since.  Only for callers that tell their
         graph which FlatParams it updates (trainers.GraphedFn(flats=...)): inside a replay nobody can see that somebody
         rewrote the parameters in place, the unconditional pack is what makes that case work by itself."""
+        from . import ops
+        ops.amax_new_step()
         self.flat.zero_grad()
         if repack != "stale" or not self.flat.plan.current():
             self.flat.plan.pack()

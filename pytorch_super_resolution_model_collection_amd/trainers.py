@@ -41,15 +41,24 @@ def _backward(loss, dp):
         with ops.manual_wgrad_flush():
             loss.backward(dp.loss_seed)
     else:
-        loss.backward()
+        ops.backward(loss)       # seeded with the persistent ones tensor: no fill, no scale pass (ops.unit_seed)
         ops.join_side_streams()  # (also flushes weight gradients recorded outside an engine callback)
+
+
+def _seeded(dp):
+    """Context for computing a loss that `_backward(loss, dp)` will seed: under data parallelism the 1/world seed is
+    folded into the loss gradient by the loss kernel itself (ops.loss_seed)."""
+    if dp is not None and dp.active:
+        return ops.loss_seed(1.0 / dp.world, dp.loss_seed)
+    return contextlib.nullcontext()
 
 
 def mse_step(model, opt, dp=None, clip=None):
     """srcnn.py:127-131 / fsrcnn.py:153-157 / vdsr.py:143-150 (clip = 0.4)."""
     def step(inp, target):
         opt.zero_grad()
-        loss = ops.mse_loss(model(inp), target)
+        with _seeded(dp):
+            loss = ops.mse_loss(model(inp), target)
         _backward(loss, dp)
         if dp is not None:
             dp.allreduce_grads()
@@ -64,7 +73,8 @@ def l1_step(model, opt, dp=None):
     """edsr.py:151-155"""
     def step(inp, target):
         opt.zero_grad()
-        loss = ops.l1_loss(model(inp), target)
+        with _seeded(dp):
+            loss = ops.l1_loss(model(inp), target)
         _backward(loss, dp)
         if dp is not None:
             dp.allreduce_grads()
@@ -78,14 +88,15 @@ def lapsrn_step(model, opt, dp=None):
     def step(inp, target2x, target4x):
         opt.zero_grad()
         hr2, hr4 = model(inp)
-        l1 = ops.charbonnier_loss(hr2, target2x)
-        l2 = ops.charbonnier_loss(hr4, target4x)
+        with _seeded(dp):
+            l1 = ops.charbonnier_loss(hr2, target2x)
+            l2 = ops.charbonnier_loss(hr4, target4x)
         seed = dp.loss_seed if (dp is not None and dp.active) else None
         if seed is not None:
             with ops.manual_wgrad_flush():
                 torch.autograd.backward([l1, l2], [seed, seed])
         else:
-            torch.autograd.backward([l1, l2])
+            ops.backward([l1, l2])
         if dp is not None:
             dp.allreduce_grads()
         opt.step()
@@ -194,6 +205,7 @@ def _capture(graph, pool=None):
     THIS thread is capturing is an illegal call that takes the process down -- seen on MI355X as an intermittent abort
     of the first capture after a broadcast / all-reduce (tests/test_dp_gpu.py, single-rank RCCL).  Work the autograd
     thread launches on the capturing stream is captured in either mode."""
+    ops.amax_new_step()   # running maxima computed before the capture must not be baked into it
     return torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local")
 
 
@@ -340,7 +352,8 @@ class GraphedStep(object):
 
     def _fwd_bwd(self):
         self.opt.zero_grad()
-        loss = self.loss_fn(self.model(self.static[0]), *self.static[1:])
+        with _seeded(self.dp):
+            loss = self.loss_fn(self.model(self.static[0]), *self.static[1:])
         _backward(loss, self.dp)
         return loss
 

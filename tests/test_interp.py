@@ -79,6 +79,9 @@ def test_c1_srcnn_pipeline_with_bicubic_preprocessing(gpu):
         assert torch.equal(y_gpu.cpu(), y_cpu)
         loss = float(step(y_gpu, x_gpu))
         oloss = R.step_mse(ora, oopt, y_cpu, x_cpu)
-        assert abs(loss - oloss) <= 2e-5 * abs(oloss)
+        # (lr = 1e-2 moves the loss by up to 90 % per step here, so one ReLU unit within fp32 rounding of zero that the two
+        #  sides decide differently -- gradient off by ~1e-4 in both fp32-faithful arithmetics, tools/_dbg sweep over 8
+        #  seeds: loss error 1e-7 .. 3.4e-5 for f16x3 and bf16x6 alike -- shows in the next step's loss; contract 1e-3)
+        assert abs(loss - oloss) <= 1e-4 * abs(oloss)
     for (n, p), (_, q) in zip(net.named_parameters(), ora.named_parameters()):
         assert float((p.detach().cpu() - q.detach()).abs().max()) <= 2e-4 * float(q.detach().abs().max()) + 1e-7, n

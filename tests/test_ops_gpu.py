@@ -22,7 +22,11 @@ VARIANTS = {"auto": ("auto", {}), "generic": ("generic", {}), "mfma_fp32": ("mfm
             "auto_lds_weights": ("auto", {"SRK_BFD_SMALL": "0"}),
             "auto_global_weights_big": ("auto", {"SRK_BF3_DIRECT": "1", "SRK_BFD_SMALL": "0"}),
             "auto_wave_specialized": ("auto", {"SRK_BFW": "1"}),
-            "bf16x6": ("bf16x6", {}), "bf16x6_big": ("bf16x6", {"SRK_BFD_SMALL": "0"})}
+            "bf16x6": ("bf16x6", {}), "bf16x6_big": ("bf16x6", {"SRK_BFD_SMALL": "0"}),
+            # the fp32-faithful class as f16x3 (two fp16 planes of the power-of-two scaled operands, three MFMAs) wherever
+            # the fp16 kernels cover the layer; every input takes the srk_absmax pass (ops.F16X3_ALWAYS)
+            "f16x3": ("bf16x6", {}), "f16x3_big": ("bf16x6", {"SRK_BFD_SMALL": "0"}),
+            "f16x3_big_4x64": ("bf16x6", {"SRK_BFD_SMALL": "0", "SRK_BFD_F16_CFG": "0"})}
 TOL_ALGO = {"auto": 1e-4, "generic": TOL_TIGHT, "mfma_fp32": TOL_TIGHT, "bf16x6": TOL_TIGHT}
 ACTS = {None: 0, "relu": 1, "lrelu": 3}
 
@@ -40,6 +44,9 @@ def test_conv_forward_backward(gpu, ops_kat, idx, variant, monkeypatch):
         monkeypatch.setenv(k, v)
     pkg = _pkg()
     ops = pkg.ops
+    monkeypatch.setattr(ops, "F16X3_ALWAYS", variant.startswith("f16x3"))
+    if variant.startswith("bf16x6"):
+        monkeypatch.setattr(ops, "F16X3", False)
     tag, cin, cout, k, s, p, tr, op, H, W, N, act = CONV_KATS[idx]
     x, w, b, g = conv_case_inputs(idx)
     xg = x.to(gpu).requires_grad_(True)
@@ -48,6 +55,12 @@ def test_conv_forward_backward(gpu, ops_kat, idx, variant, monkeypatch):
     cfg = ops.ConvCfg(s, p, bool(tr), op, ACTS[act], 0.2 if act == "lrelu" else 0.0, 0, ALGOS[algo])
     y = ops.conv2d(xg, wg, bg, None, cfg)
     assert tuple(y.shape) == tuple(g.shape)
+    if variant.startswith("f16x3") and min(cin, cout) >= 8:
+        kern = pkg._lib.load().srk_last_kernel_name().decode()
+        assert kern.startswith("k_conv_bfd") and ",f16" in kern, kern       # the fp16 kernel did run ...
+        tagged = getattr(y, "_srk_amax", None)                              # ... and left the output's maximum behind
+        assert tagged is not None and tagged[0] is not None
+        assert float(tagged[0].max()) == float(y.detach().abs().max())
     tol = TOL_ALGO[algo]
     assert rel_err(y, ops_kat["conv.%s.y" % tag]) < tol
     y.backward(g.to(gpu))
@@ -559,3 +572,31 @@ def test_wgrad_grouped(gpu, n, N, cin, cout, k, p, H, W, act, bias):
         rc = lib.srk_conv2d_backward_weight_grouped(ctypes.byref(d), 2, arr(xs[:2] + [None] * (n - 2)), arr(dys[:2] + [None] * (n - 2)),
                                                     masks, dup, None, 1.0, L.ptr(ws), ws.numel(), st)
         assert rc == -1 and b"same dw" in lib.srk_last_error_string()
+
+
+@pytest.mark.parametrize("scale_x,scale_w", [(1.0, 0.05), (1e-5, 40.0), (3e4, 1e-6), (1e-30, 1e20)])
+def test_f16x3_is_fp32_faithful_at_any_operand_scale(gpu, scale_x, scale_w):
+    """SRK_ALGO_MFMA_F16X3 (two fp16 planes of the operands scaled by exact powers of two from their running maxima):
+    error against float64 at the level of the exact-fp32 MFMA kernel -- far from fp16's own range in either direction,
+    where unscaled fp16 planes would flush to zero or overflow -- and ReLU decisions that agree wherever float64 can
+    decide them.  The output's running maximum (what the next layer scales by) is exact."""
+    pkg = _pkg()
+    ops, lib = pkg.ops, pkg._lib.load()
+    x = (fill.randn((4, 64, 24, 20), 71).clamp(min=0) * scale_x)
+    w = fill.randn((64, 64, 3, 3), 72) * scale_w
+    b = fill.randn((64,), 73) * (2.4 * scale_x * scale_w)
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1))
+    out = {}
+    for name, algo in (("f16x3", pkg._lib.ALGO_MFMA_F16X3), ("fp32", pkg._lib.ALGO_MFMA), ("bf16x3", pkg._lib.ALGO_MFMA_BF16X3)):
+        cfg = ops.ConvCfg(1, 1, False, 0, 1, 0.0, 0, algo)
+        with torch.no_grad():
+            out[name] = ops.conv2d_infer(x.to(gpu), w.to(gpu), b.to(gpu), None, cfg)
+        if name == "f16x3":
+            assert ",f16" in lib.srk_last_kernel_name().decode()
+            slots = out[name]._srk_amax[0]
+            assert float(slots.max()) == float(out[name].abs().max())
+    err = {k: float((v.cpu().double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()) for k, v in out.items()}
+    assert err["f16x3"] < 6e-7 and err["f16x3"] < 2.0 * err["fp32"] + 1e-8, err     # fp32-class ...
+    assert err["f16x3"] < 0.25 * err["bf16x3"], err                                 # ... an order below the 3-term bf16 split
+    decidable = ref.abs() > 1e-5 * float(ref.pow(2).mean().sqrt())
+    assert bool((((out["f16x3"].cpu() > 0) == (ref > 0)) | ~decidable).all())

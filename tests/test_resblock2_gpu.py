@@ -23,6 +23,8 @@ def _run(pkg, blk, x, dy, fused):
         for p in blk.parameters():
             p.grad = None
         xi = x.clone().requires_grad_(True)
+        if pkg.ops.F16X3:   # as inside a net, where the block's input comes from a conv kernel: worth the srk_absmax pass
+            pkg.ops._tag_amax(xi, None)
         y = blk(xi)
         y.backward(dy)
         torch.cuda.synchronize()
@@ -69,8 +71,12 @@ def test_resblock2_matches_oracle_and_separate_launches(gpu, shape, bias):
     mid_g, out_g = torch.empty_like(xg), torch.empty_like(xg)
     P = pkg._lib.ptr
     wp1, wp2 = pkg.ops.pack_weight_fwd(blk.conv1.weight, False, 0), pkg.ops.pack_weight_fwd(blk.conv2.weight, False, 0)
+    # the fp32-faithful class the module path uses: f16x3 (with the input's running maximum) or bf16x6
+    algo = pkg._lib.ALGO_MFMA_F16X3 if pkg.ops.F16X3 else pkg._lib.ALGO_MFMA_BF16X6
+    xa = pkg.ops.amax_of(xg) if pkg.ops.F16X3 else None
+    ya = torch.zeros(pkg._lib.AMAX_FLOATS, device=gpu)
     rc = lib.srk_resblock2_forward(n, h, w, 64, P(xg), P(wp1), P(blk.conv1.bias), P(wp2), P(blk.conv2.bias), P(mid_g),
-                                   P(out_g), pkg._lib.ALGO_MFMA_BF16X6, pkg._lib.stream_ptr())
+                                   P(out_g), algo, P(xa), P(ya), pkg._lib.stream_ptr())
     assert rc == 0, lib.srk_last_error_string()
     torch.cuda.synchronize()
     z = F.conv2d(x.double(), w1, b1, padding=1)
@@ -104,6 +110,7 @@ def test_resblock2_matches_oracle_and_separate_launches(gpu, shape, bias):
     y0, dx0, g0 = _run(pkg, blk, x.to(gpu), dy.to(gpu), False)
     assert not lib.srk_last_kernel_name().decode().startswith("k_res2<")
     assert torch.equal(y1, out_g) and torch.equal(dx1, dx_g)
+    assert float(ya.max()) == float(out_g.abs().max())      # the running maximum the next layer scales by
     assert_close_elementwise(y1, y0, 2e-6, what="fused forward vs separate launches")
     for k, g in want.items():
         assert_close_elementwise(g1[k], g, 1e-4, what="fused path grad " + k)
@@ -138,7 +145,7 @@ def test_resblock2_only_for_small_problems(gpu):
     wp = pkg.ops.pack_weight_fwd(blk.conv1.weight, False, 0)
     big = torch.empty(1, device=gpu)
     rc = lib.srk_resblock2_forward(128, 32, 32, 64, pkg._lib.ptr(big), pkg._lib.ptr(wp), None, pkg._lib.ptr(wp), None,
-                                   pkg._lib.ptr(big), pkg._lib.ptr(big), 0, pkg._lib.stream_ptr())
+                                   pkg._lib.ptr(big), pkg._lib.ptr(big), 0, None, None, pkg._lib.stream_ptr())
     assert rc != 0 and b"unsupported" in lib.srk_last_error_string()
 
 

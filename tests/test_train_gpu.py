@@ -138,14 +138,17 @@ def test_graphed_step_equals_eager(gpu):
     assert rel_err(opt_b.flat.data, opt_a.flat.data) < 1e-5
 
 
-@pytest.mark.parametrize("model", ["edsr", "fsrcnn", "espcn", "lapsrn", "srgan_g"])
+@pytest.mark.parametrize("model", ["edsr", "fsrcnn", "espcn", "srcnn", "lapsrn", "srgan_g", "srgan_d", "srgan_d_small"])
 def test_pack_plan_equals_per_layer_pack(gpu, model):
     """One srk_pack_weights_batched launch writes byte-for-byte what the per-layer pack calls write
     (fp32 + bf16x3 layouts, forward + data-gradient, pixel-shuffle filter/bias order, deconv)."""
     pkg = _pkg()
     net = {"edsr": lambda: pkg.EDSRNet(3, 64, 4), "fsrcnn": lambda: pkg.FSRCNNNet(1, 3, 56, 12, 4),
-           "espcn": lambda: pkg.ESPCNNet(3, 64, 4), "lapsrn": lambda: pkg.LapSRNNet(1, 64, 4),
-           "srgan_g": lambda: pkg.SRGANGenerator(3, 64, 2)}[model]()
+           "espcn": lambda: pkg.ESPCNNet(3, 64, 4), "srcnn": lambda: pkg.SRCNNNet(3, 64), "lapsrn": lambda: pkg.LapSRNNet(1, 64, 4),
+           "srgan_g": lambda: pkg.SRGANGenerator(3, 64, 2),
+           # 64 .. 512-channel filters (the LDS-tiled fast path) / 8 .. 64 channels (padded layouts: the generic path)
+           "srgan_d": lambda: pkg.SRGANDiscriminator(3, 64, 32),
+           "srgan_d_small": lambda: pkg.SRGANDiscriminator(3, 8, 32)}[model]()
     fill.fill_module(net, 11, 1.0)
     net.to(gpu)
     from pytorch_super_resolution_model_collection_amd._lib import check, load, ptr, stream_ptr

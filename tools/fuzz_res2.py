@@ -27,7 +27,7 @@ for case in range(cases):
     wb1, wb2 = pkg.ops.pack_weight_bwd(w1, False, 0), pkg.ops.pack_weight_bwd(w2, False, 0)
     mid, out, dmid, dx = (torch.empty_like(x) for _ in range(4))
     check(lib.srk_resblock2_forward(n, h, w, 64, ptr(x), ptr(wf1), ptr(b1), ptr(wf2), ptr(b2), ptr(mid), ptr(out),
-                                    ALGO_MFMA_BF16X6, stream_ptr()), "fwd")
+                                    ALGO_MFMA_BF16X6, None, None, stream_ptr()), "fwd")
     check(lib.srk_resblock2_backward_data(n, h, w, 64, ptr(dy), ptr(wb2), ptr(wb1), ptr(mid), ptr(dmid), ptr(dx), 0,
                                           stream_ptr()), "bwd")
     # float64 reference with the kernel's mask

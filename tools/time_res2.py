@@ -22,7 +22,16 @@ mid, out, dmid, dx = (torch.empty_like(x) for _ in range(4))
 
 def fwd():
     check(lib.srk_resblock2_forward(B, H, H, 64, ptr(x), ptr(wf1), ptr(b1), ptr(wf2), ptr(b2), ptr(mid), ptr(out),
-                                    ALGO_MFMA_BF16X6, stream_ptr()), "fwd")
+                                    ALGO_MFMA_BF16X6, None, None, stream_ptr()), "fwd")
+
+
+xa = pkg.ops.amax_of(x)
+ya = torch.zeros(256, device=dev)
+
+
+def fwd16():
+    check(lib.srk_resblock2_forward(B, H, H, 64, ptr(x), ptr(wf1), ptr(b1), ptr(wf2), ptr(b2), ptr(mid), ptr(out),
+                                    pkg._lib.ALGO_MFMA_F16X3, ptr(xa), ptr(ya), stream_ptr()), "fwd16")
 
 
 def bwd():
@@ -30,7 +39,7 @@ def bwd():
                                           stream_ptr()), "bwd")
 
 
-for name, fn in (("forward bf16x6", fwd), ("backward bf16x3", bwd)):
+for name, fn in (("forward bf16x6", fwd), ("forward f16x3", fwd16), ("backward bf16x3", bwd)):
     for _ in range(3):
         fn()
     side, g = torch.cuda.Stream(), torch.cuda.CUDAGraph()
