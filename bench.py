@@ -426,18 +426,26 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
 
 
 def c2_other_precisions(pkg, net, x, steps, warmup, dev):
-    """The same c2 forward in the fp32-faithful modes: bf16x6 (exact 3-way split, 6 bf16 MFMAs per product) and exact
-    fp32 MFMA — what the headline's bf16x3 products (~5e-6 rel) buy."""
+    """The same c2 forward in the fp32-faithful arithmetics -- f16x3 (operands scaled by exact powers of two and split into
+    two fp16 planes, 3 MFMAs per product, ~1e-7 rel: what the 'bf16x6' mode runs wherever the fp16 kernels cover a layer),
+    bf16x6 (exact 3-way bf16 split, 6 MFMAs) and exact fp32 MFMA -- next to the headline's bf16x3 products (~5e-6 rel)."""
     res = {}
     prev = pkg.ops.get_precision()
-    for mode in ("bf16x6", "fp32"):
+    prev_f16 = pkg.ops.F16X3
+    for key, mode, f16 in (("fp32_faithful_f16x3", "bf16x6", True), ("bf16x6", "bf16x6", False), ("fp32", "fp32", prev_f16)):
         try:
             pkg.ops.set_precision(mode)
+            pkg.ops.F16X3 = f16
             with torch.no_grad():
                 sec = time_steps(lambda: net(x), steps, warmup, 1, dev)
-            res["c2_%s_images_per_s" % mode] = round(x.shape[0] * steps / sec, 1)
+            res["c2_%s_images_per_s" % key] = round(x.shape[0] * steps / sec, 1)
+            if key == "fp32_faithful_f16x3":
+                scale = (x.shape[-1] / 256.0) ** 2
+                res["c2_fp32_faithful_f16x3_hbm_roofline_frac"] = round(
+                    ESPCN_BYTES_PER_IMG * scale * x.shape[0] * steps / sec / 1e9 / HBM_PEAK_GBS, 4)
         except Exception as e:  # noqa: BLE001
-            res["c2_%s_error" % mode] = "%s: %s" % (type(e).__name__, str(e)[:200])
+            res["c2_%s_error" % key] = "%s: %s" % (type(e).__name__, str(e)[:200])
+    pkg.ops.F16X3 = prev_f16
     pkg.ops.set_precision(prev)
     return res
 

@@ -182,9 +182,10 @@ int srk_pack_weights_batched(const float* params_base, void* packed_base, const 
 /* max|x| over n floats into an SRK_AMAX_FLOATS buffer (atomic max: zero it first) -- x_amax of a tensor no kernel
  * of this library produced (the network input). */
 int srk_absmax(const float* x, size_t n, float* amax_slots, void* stream);
-/* 1 when srk_conv2d_forward(d, ..., ep) with d->algo = SRK_ALGO_MFMA_F16X3 has a kernel (stride-1 / strided Conv2d and
- * ConvTranspose2d with Cin >= 8, Cout >= 8 and every output group on the 16-byte store path), and when that call
- * fills ep->y_amax. */
+/* 1 when srk_conv2d_forward(d, ..., ep) with d->algo = SRK_ALGO_MFMA_F16X3 has a kernel: Conv2d / ConvTranspose2d with
+ * Cin >= 8, Cout >= 8, and first layers (Cin <= 4 Conv2d, Cout a multiple of 16, also with x_nchw), every output group
+ * on the 16-byte store path.  Those kernels (k_conv_bfd, k_conv_bfw, k_conv_bf3_rows) also fill ep->y_amax -- in every
+ * arithmetic they run, not only f16x3. */
 int srk_conv2d_f16x3_supported(const srk_conv_desc* d, const srk_epilogue* ep, const float* y);
 
 /* ---- convolution (Conv2d / ConvTranspose2d: base_networks.py:42,77,112-113,156; fsrcnn.py:33) */

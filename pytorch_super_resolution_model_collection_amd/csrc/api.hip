@@ -32,7 +32,9 @@ int conv_tapn_gather(const GatherConv& g, const float* in, const float* wp, floa
                      hipStream_t s);
 // conv_bfw.hip
 bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, const float* out, const float* mask_y);
-int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s);
+int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s, bool f16);
+bool conv_bf3_rows_f16_supported(const GatherConv& g, const Epi& ep, const float* out);
+int conv_bf3_rows_f16_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s);
 bool conv_tapk_gather_supported(const GatherConv& g, const Epi& ep, const float* out, const float* mask_y);
 int conv_tapk_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s);
 bool conv_wgrad_tapn_supported(const srk_conv_desc& d, const float* x, const srk_bwd_mask* mask);
@@ -99,7 +101,9 @@ static int forced_algo(int algo) {
 // SRK_ALGO_MFMA_F16X3 (forward gathers only): what the fp16 kernels cover -- the shapes of conv_bfd.hip, minus the
 // layers the few-output-channel kernels take and inputs in a foreign layout
 static bool f16x3_gather_ok(const GatherConv& g, const Epi& ep, const float* in, const float* out) {
-  if (!ep.x_amax || g.in_nchw || g.in_ps_r > 1) return false;
+  if (!ep.x_amax || g.in_ps_r > 1) return false;
+  if (conv_bf3_rows_f16_supported(g, ep, out)) return true;   // first layers (Cin <= 4), also on an NCHW input in place
+  if (g.in_nchw) return false;
   if (!conv_bfd_gather_supported(g, ep) || !conv_epi_all_vector(g.OC, ep, out)) return false;
   if (conv_direct_gather_supported(g, ep) || conv_tapn_gather_supported(g, in, nullptr)) return false;
   return true;
@@ -123,6 +127,11 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
       set_error("%s: SRK_ALGO_MFMA_F16X3 covers forward convs with Cin, Cout >= 8 on the 16-byte store path and needs "
                 "srk_epilogue.x_amax (srk_conv2d_f16x3_supported)", who);
       return SRK_ERR_UNSUPPORTED;
+    }
+    if (conv_bf3_rows_f16_supported(g, ep, out)) return conv_bf3_rows_f16_gather(g, in, wp, out, ep, s);
+    if (conv_bfw_applicable(g, ep, in, out, nullptr)) {  // wave-specialised persistent kernel (ESPCN-size layers)
+      const int rc = conv_bfw_gather(g, in, wp, out, ep, s, true);
+      if (rc >= 0) return rc;
     }
     return conv_bfd_gather(g, in, wp, out, ep, nullptr, 0.f, 4, s);
   }
@@ -163,7 +172,7 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
     if (bfd_ok && (direct_w == 1 || (direct_w == 2 && conv_bfd_small_problem(g))))
       return conv_bfd_gather(g, in, wp, out, ep, mask_y, mask_slope, 2, s);
     if (conv_bfw_applicable(g, ep, in, out, mask_y)) {  // wave-specialised persistent kernel (ESPCN-size layers)
-      const int rc = conv_bfw_gather(g, in, wp, out, ep, s);
+      const int rc = conv_bfw_gather(g, in, wp, out, ep, s, false);
       if (rc >= 0) return rc;
     }
     return conv_bf3_gather(g, in, wp, out, ep, mask_y, mask_slope, s);
@@ -221,7 +230,8 @@ extern "C" int srk_conv2d_forward(const srk_conv_desc* d, const float* x, const 
   if (d->x_nchw) {
     // only the row-packed bf16x3 first-layer kernel reads an NCHW input in place
     const int algo = forced_algo(d->algo);
-    if (!(d->Cin <= 4 && !d->transposed && d->Cout >= 8 && (algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3) &&
+    if (!(d->Cin <= 4 && !d->transposed && d->Cout >= 8 &&
+          (algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3 || algo == SRK_ALGO_MFMA_F16X3) &&
           conv_bf3_gather_supported(g, ep))) {
       set_error("conv2d_forward: x_nchw is only supported by the Cin <= 4 bf16x3 kernel");
       return SRK_ERR_UNSUPPORTED;
@@ -232,11 +242,12 @@ extern "C" int srk_conv2d_forward(const srk_conv_desc* d, const float* x, const 
 }
 
 extern "C" int srk_conv2d_f16x3_supported(const srk_conv_desc* d, const srk_epilogue* ep_in, const float* y) {
-  if (!d || validate_desc(d, "conv2d_f16x3_supported") || d->x_nchw || d->dy_ps_r) return 0;
+  if (!d || validate_desc(d, "conv2d_f16x3_supported") || d->dy_ps_r) return 0;
   Epi ep = make_epi(ep_in);
   static const float dummy = 0.f;
   if (!ep.x_amax) ep.x_amax = &dummy;   // (the question is about the shape; the call itself needs the real slots)
   GatherConv g{d->N, d->H, d->W, d->Cin, d->OH, d->OW, d->Cout, d->KH, d->KW, d->stride, d->pad, d->transposed, 0};
+  g.in_nchw = d->x_nchw;
   return f16x3_gather_ok(g, ep, reinterpret_cast<const float*>(16), y ? y : reinterpret_cast<const float*>(16)) ? 1 : 0;
 }
 

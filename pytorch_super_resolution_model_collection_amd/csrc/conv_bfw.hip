@@ -48,10 +48,11 @@ struct BfwParams {
   const uint4* wq;  // prepared filter planes (h, m)
   int ICc, NB, NPIXp, ntiles;
   int perm;  // consumer lanes {0-3, 12-15} hold the even pixels of an M tile, {4-11} the odd ones (bfw_group_stride)
+  const float* w_descale;  // F16 kernels: trailer {2^-kw, 2^kw} of the fp16 filter section (wq then points at that section)
   int dbg;  // ablation (SRK_DBG): 1 no global loads, 2 no epilogue, 4 no MFMA loop, 16 no LDS commit, 1024 no deferred stores
 };
 
-template <int NTW, int TT, int MTW>
+template <int NTW, int TT, int MTW, bool F16 = false>
 __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_conv_bfw(BfwParams B) {
   constexpr int NCW = 16 / MTW;          // consumer waves: MTW 16-pixel groups each, 256 pixels per block
   constexpr int NTHR = 64 * (NCW + 4);   // + 4 producer waves
@@ -67,6 +68,13 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
   const bool producer = wave >= NCW;
   const int j = lane & 15, kq = lane >> 4;
   const int npx = P.TH * P.TW, npix = P.HH * P.HW;
+  // f16x3 (SRK_ALGO_MFMA_F16X3): activation scale 2^kx from the input's running maximum, descale 2^-(kx + kw)
+  float sx = 1.f, dsc = 1.f;
+  if constexpr (F16) {
+    const int kx = amax_scale_exp(amax_read(P.ep.x_amax));
+    sx = exp2i(kx);
+    dsc = exp2i(-kx) * B.w_descale[0];
+  }
 
   for (int e = tid; e < T * B.ICc * wslot; e += NTHR) {
     const int slot = e / wslot, w = e - slot * wslot;
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
             f[4 + e] = pv1[k][e];
           }
           uint4 pl[2];
-          split8n<2>(f, pl);
+          if constexpr (F16) split8h(f, sx, pl); else split8n<2>(f, pl);
           hal[(0 * 4 + g) * B.NPIXp + hq] = pl[0];
           hal[(1 * 4 + g) * B.NPIXp + hq] = pl[1];
         }
@@ -231,6 +239,7 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
   // for ~2000 cycles per tile -- measured 0.06-0.09 ms per layer; spread out, the stores ride under the MFMAs.)
   // Needs the tap loop unrolled at compile time (TT = taps per chunk; TT = 0: dynamic loop, immediate epilogue).
   f32x4 pend[NTW][MTW];
+  float amax = 0.f;  // running maximum of what this lane stores (ep.y_amax)
   float* pend_base = P.out;  // wave-uniform: P.out + tile origin
   int pend_mask = 0;
   bool pend_live = false;
@@ -288,15 +297,15 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = mfma16(a[0][nt], b[1][mt], acc[nt][mt]);  // w_h * x_m
+          for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = mfma16x<F16>(a[0][nt], b[1][mt], acc[nt][mt]);  // w_h * x_m
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = mfma16(a[1][nt], b[0][mt], acc[nt][mt]);  // w_m * x_h
+          for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = mfma16x<F16>(a[1][nt], b[0][mt], acc[nt][mt]);  // w_m * x_h
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = mfma16(a[0][nt], b[0][mt], acc[nt][mt]);  // w_h * x_h
+          for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = mfma16x<F16>(a[0][nt], b[0][mt], acc[nt][mt]);  // w_h * x_h
       };
       // (sched_barrier: keep the next tap's ds_read_b128s IN FRONT of the current tap's MFMAs -- the machine
       //  scheduler otherwise sinks them behind ~16 MFMAs)
@@ -339,10 +348,13 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
         if (pix_ok[mt] >= 0 && r0 + r < P.PH && c0 + c < P.PW) pend_mask |= 1 << mt;
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
-          f32x4 v = acc[nt][mt] + bias4[nt];
+          f32x4 v = acc[nt][mt];
+          if constexpr (F16) v *= dsc;
+          v += bias4[nt];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : act_slope * v[e];
           pend[nt][mt] = v;
+          if (P.ep.y_amax && ((pend_mask >> mt) & 1)) amax = abs_max4(amax, v);
         }
       }
       pend_live = true;
@@ -353,6 +365,7 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
     }
     __syncthreads();
   }
+  if (P.ep.y_amax) amax_commit(P.ep.y_amax, amax, blockIdx.x + wave);
 }
 
 // LDS stride (in 16-byte slots) between the four 8-channel groups of a halo plane, chosen against the lane groups the LDS
@@ -427,6 +440,13 @@ bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, co
 
 template <int NTW, int TT, int MTW>
 static int bfw_launch_t(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
+  if (B.w_descale) {  // f16x3 arithmetic
+    static LdsLimit limh;
+    limh.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, MTW, true>), lds);
+    note_kernel("k_conv_bfw<%d,%d,%d,f16>", NTW, TT, MTW);
+    hipLaunchKernelGGL((k_conv_bfw<NTW, TT, MTW, true>), dim3(grid), dim3(64 * (16 / MTW + 4)), lds, s, B);
+    return check_launch("conv_bfw");
+  }
   static LdsLimit lim;
   lim.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, MTW>), lds);
   note_kernel("k_conv_bfw<%d,%d,%d>", NTW, TT, MTW);
@@ -450,10 +470,14 @@ static int bfw_launch(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
   return bfw_launch_t<NTW, 0, 4>(B, lds, grid, s);
 }
 
-// returns -1 when no tile fits (the caller falls back to the other kernels)
-int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s) {
+// returns -1 when no tile fits (the caller falls back to the other kernels).  f16: the f16x3 arithmetic (ep.x_amax set)
+int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s,
+                    bool f16) {
   const size_t elems = (size_t)g.KH * g.KW * g.IC * g.OC;
-  const uint4* wq = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wp) + bf3_prepared_offset(elems));
+  const char* prepared = reinterpret_cast<const char*>(wp) + bf3_prepared_offset(elems);
+  const char* fsec = prepared + f16_section_offset(g.IC, g.OC, g.KH * g.KW);
+  const uint4* wq = reinterpret_cast<const uint4*>(f16 ? fsec : prepared);
+  const float* w_descale = f16 ? reinterpret_cast<const float*>(fsec + bf3_main_bytes(g.IC, g.OC, g.KH * g.KW)) : nullptr;
   static int dbg = -1;
   if (dbg < 0) dbg = getenv("SRK_DBG") ? atoi(getenv("SRK_DBG")) : 0;
   return for_each_phase(g, in, wp, out, ep, nullptr, 0.f, [&](const MfmaConvParams& P0) {
@@ -461,6 +485,7 @@ int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float
     B.P = P0;
     MfmaConvParams& P = B.P;
     B.wq = wq;
+    B.w_descale = w_descale;
     B.NB = P.OC;
     B.ICc = (P.IC + 31) / 32;
     B.dbg = dbg;

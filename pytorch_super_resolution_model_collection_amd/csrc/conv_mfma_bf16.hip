@@ -23,6 +23,7 @@
 #include "conv_problem.h"
 #include "conv_tile.h"
 #include "pack_items.h"
+#include "bf16_frag.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -33,6 +34,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct Bf3Params {
   MfmaConvParams P;
+  const float* w_descale;  // k_conv_bf3_rows<.., f16>: trailer {2^-kw, 2^kw} of the fp16 filter section (wq points there)
   const uint4* wq;  // prepared filters
   int ICc;          // 32-channel chunks
   int OCb;          // 64-channel output blocks
@@ -72,7 +74,9 @@ __global__ __launch_bounds__(256) void k_pack_f16_trailer(const float* __restric
 }
 
 __global__ void k_bf3_pack_rows(const float* __restrict__ w, uint4* __restrict__ dst, int Cout, int Cin, int KH, int KW,
-                                int transposed, int ps_r, int bwd, int IC, int OC, int KS, int OCb, int NB);
+                                int transposed, int ps_r, int bwd, int IC, int OC, int KS, int OCb, int NB,
+                                uint4* __restrict__ f16dst, const float* __restrict__ f16trailer);
+__global__ void k_pack_f16_trailer(const float* __restrict__ w, long elems, float* __restrict__ trailer);
 
 static inline int bf3_nb(int OC) { return pk_nb(OC); }
 
@@ -97,8 +101,16 @@ int bf3_pack_prepared(const float* w, void* packed_base, int Cout, int Cin, int 
   if (IC <= 4 && !gather_trans) {  // row-packed layout of k_conv_bf3_rows
     const int KS = (KW + 7) / 8;
     const long items = (long)KH * KS * OCb * 4 * NB;
+    uint4* f16dst = nullptr;
+    float* trailer = nullptr;
+    if (!bwd) {  // forward buffers: fp16 row-packed planes + trailer in the f16 section (k_conv_bf3_rows<.., f16>)
+      char* f16base = reinterpret_cast<char*>(dst) + f16_section_offset(IC, OC, KH * KW);
+      f16dst = reinterpret_cast<uint4*>(f16base);
+      trailer = reinterpret_cast<float*>(f16base + bf3_main_bytes(IC, OC, KH * KW));
+      hipLaunchKernelGGL(k_pack_f16_trailer, dim3(1), dim3(256), 0, s, w, (long)elems, trailer);
+    }
     hipLaunchKernelGGL(k_bf3_pack_rows, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, w, dst, Cout, Cin, KH,
-                       KW, transposed, ps_r, bwd, IC, OC, KS, OCb, NB);
+                       KW, transposed, ps_r, bwd, IC, OC, KS, OCb, NB, f16dst, (const float*)trailer);
     return check_launch("bf3_pack_prepared_rows");
   }
   const long items = (long)KH * KW * ICc * OCb * 4 * NB;
@@ -238,6 +250,7 @@ constexpr int BF3_EPI_STRIDE = 68; // floats per staged output row (64 + 4: conf
 template <int NT, bool VEC_ONLY = false>
 __device__ __forceinline__ void bf3_epilogue(const MfmaConvParams& P, float* smem_f, const f32x4 (&acc)[4][NT], int n,
                                              int r0, int c0, int ocb, int wave, int lane) {
+  float amax = 0.f;  // running maximum of what this lane stores (ep.y_amax; vector store path only)
   const int j = lane & 15, kq = lane >> 4;
   const int npx = P.TH * P.TW;
   __syncthreads();
@@ -270,16 +283,19 @@ __device__ __forceinline__ void bf3_epilogue(const MfmaConvParams& P, float* sme
           const int pr = r0 + r, pc = c0 + c;
           if (pr < P.PH && pc < P.PW) {
             const epi_f4 v = *reinterpret_cast<const epi_f4*>(st + row * BF3_EPI_STRIDE + q4 * 4);
-            if (VEC_ONLY || col.vec)
-              epi_store4_tile(P.ep, col, et, r, c, v, P.out);
-            else
+            if (VEC_ONLY || col.vec) {
+              const epi_f4 o = epi_store4_tile(P.ep, col, et, r, c, v, P.out);
+              if (VEC_ONLY && P.ep.y_amax) amax = abs_max4(amax, o);
+            } else {
               epi_store4_col(P.ep, col, P.OH, P.OW, P.OC, n, P.oy0 + pr * P.os, P.ox0 + pc * P.os, v, P.out);
+            }
           }
         }
       }
     }
     __syncthreads();
   }
+  if (VEC_ONLY && P.ep.y_amax) amax_commit_block(P.ep.y_amax, amax, blockIdx.x, smem_f, (int)(blockDim.x >> 6));
 }
 
 // NT <= 2 (the c2 benchmark's 64->32 layer) must stay within 168 VGPRs: three resident blocks per CU instead of two
@@ -419,11 +435,13 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 && NW == 4) ? 3 : 2) void k_conv_
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bf3_pack_rows(const float* __restrict__ w, uint4* __restrict__ dst, int Cout,
                                                        int Cin, int KH, int KW, int transposed, int ps_r, int bwd,
-                                                       int IC, int OC, int KS, int OCb, int NB) {
+                                                       int IC, int OC, int KS, int OCb, int NB, uint4* __restrict__ f16dst,
+                                                       const float* __restrict__ f16trailer) {
   const long items = (long)KH * KS * OCb * 4 * NB;
   const long it = (long)blockIdx.x * 256 + threadIdx.x;
   if (it >= items) return;
-  pack_bf3_rows_item(it, w, dst, Cout, Cin, KH, KW, transposed, ps_r, bwd, IC, OC, KS, OCb, NB);
+  pack_bf3_rows_item(it, w, dst, Cout, Cin, KH, KW, transposed, ps_r, bwd, IC, OC, KS, OCb, NB, f16dst,
+                     f16dst ? f16trailer[1] : 1.f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -433,6 +451,29 @@ __global__ __launch_bounds__(256) void k_bf3_pack_rows(const float* __restrict__
 //   10 bias_ps_off (bytes, -1 none)  11 reserved
 // Each packed buffer has the srk_pack_weight_fwd / _bwd format (fp32 layout + bf16x3 planes).
 // ---------------------------------------------------------------------------------------------
+// fp16 section of a forward buffer inside the batched pack: destination of the planes and the layer's scale -- from the
+// scratch word of k_pack_batched_amax (`wamax`; the first thread of the layer records the trailer) or from the trailer
+// k_pack_batched_trailers wrote in front of this kernel
+__device__ __forceinline__ void pack_f16_setup(uint4* q, int IC, int OC, int T, const float* wamax, long tid0,
+                                               uint4*& f16dst, float& f16scale) {
+  char* f16base = reinterpret_cast<char*>(q) + pk_f16_offset(IC, OC, T);
+  f16dst = reinterpret_cast<uint4*>(f16base);
+  float* trailer = reinterpret_cast<float*>(f16base + pk_main_bytes(IC, OC, T));
+  if (wamax) {
+    const float a = *wamax;
+    int k = 0;
+    if (a != 0.f) k = 140 - (int)((__float_as_uint(a) >> 23) & 0xff);
+    k = k < -126 ? -126 : (k > 126 ? 126 : k);
+    f16scale = __uint_as_float((unsigned)(127 + k) << 23);
+    if (tid0 == 0) {
+      trailer[0] = __uint_as_float((unsigned)(127 - k) << 23);
+      trailer[1] = f16scale;
+    }
+  } else {
+    f16scale = trailer[1];
+  }
+}
+
 __device__ __forceinline__ void pack_one_dir(const float* w, char* dst, int Cout, int Cin, int KH, int KW,
                                              int transposed, int ps_r, int bwd, long tid0, long stride,
                                              const float* wamax = nullptr) {
@@ -443,34 +484,18 @@ __device__ __forceinline__ void pack_one_dir(const float* w, char* dst, int Cout
   const int OCb = (OC + 63) / 64, NB = OC >= 64 ? 64 : ((OC + 15) / 16) * 16;
   uint4* q = reinterpret_cast<uint4*>(dst + ((elems * 4 + 255) & ~255L));
   const int gather_trans = bwd ? !transposed : transposed;
+  uint4* f16dst = nullptr;
+  float f16scale = 1.f;
   if (IC <= 4 && !gather_trans) {
     const int KS = (KW + 7) / 8;
     const long items = (long)KH * KS * OCb * 4 * NB;
+    if (!bwd) pack_f16_setup(q, IC, OC, KH * KW, wamax, tid0, f16dst, f16scale);
     for (long it = tid0; it < items; it += stride)
-      pack_bf3_rows_item(it, w, q, Cout, Cin, KH, KW, transposed, ps_r, bwd, IC, OC, KS, OCb, NB);
+      pack_bf3_rows_item(it, w, q, Cout, Cin, KH, KW, transposed, ps_r, bwd, IC, OC, KS, OCb, NB, f16dst, f16scale);
   } else {
     const int ICc = (IC + 31) / 32;
     const long items = (long)KH * KW * ICc * OCb * 4 * NB;
-    uint4* f16dst = nullptr;
-    float f16scale = 1.f;
-    if (!bwd) {
-      char* f16base = reinterpret_cast<char*>(q) + pk_f16_offset(IC, OC, KH * KW);
-      f16dst = reinterpret_cast<uint4*>(f16base);
-      float* trailer = reinterpret_cast<float*>(f16base + pk_main_bytes(IC, OC, KH * KW));
-      if (wamax) {  // layer maximum from k_pack_batched_amax: every thread derives the scale, the first one records it
-        const float a = *wamax;
-        int k = 0;
-        if (a != 0.f) k = 140 - (int)((__float_as_uint(a) >> 23) & 0xff);
-        k = k < -126 ? -126 : (k > 126 ? 126 : k);
-        f16scale = __uint_as_float((unsigned)(127 + k) << 23);
-        if (tid0 == 0) {
-          trailer[0] = __uint_as_float((unsigned)(127 - k) << 23);
-          trailer[1] = f16scale;
-        }
-      } else {      // trailer written by k_pack_batched_trailers, launched in front of this kernel
-        f16scale = trailer[1];
-      }
-    }
+    if (!bwd) pack_f16_setup(q, IC, OC, KH * KW, wamax, tid0, f16dst, f16scale);
     for (long it = tid0; it < items; it += stride)
       pack_bf3_item(it, w, q, Cout, Cin, KH, KW, transposed, ps_r, bwd, IC, OC, ICc, OCb, NB, f16dst, f16scale);
   }
@@ -484,8 +509,7 @@ __global__ __launch_bounds__(256) void k_pack_batched_amax(const float* __restri
                                                            const long long* __restrict__ table, int slices) {
   const long long* row = table + (size_t)blockIdx.y * kPackCols;
   if (row[1] < 0 || row[11] < 0) return;
-  const int Cout = (int)row[3], Cin = (int)row[4], KH = (int)row[5], KW = (int)row[6], transposed = (int)row[7];
-  if (Cin <= 4 && !transposed) return;
+  const int Cout = (int)row[3], Cin = (int)row[4], KH = (int)row[5], KW = (int)row[6];
   const long elems = (long)KH * KW * Cin * Cout;
   const float* w = params + row[0];
   __shared__ float sm[4];
@@ -517,8 +541,7 @@ __global__ __launch_bounds__(256) void k_pack_batched_trailers(const float* __re
                                                                const long long* __restrict__ table) {
   const long long* row = table + (size_t)blockIdx.x * kPackCols;
   if (row[1] < 0 || row[11] >= 0) return;
-  const int Cout = (int)row[3], Cin = (int)row[4], KH = (int)row[5], KW = (int)row[6], transposed = (int)row[7];
-  if (Cin <= 4 && !transposed) return;  // row-packed first layers carry no fp16 planes
+  const int Cout = (int)row[3], Cin = (int)row[4], KH = (int)row[5], KW = (int)row[6];
   const long elems = (long)KH * KW * Cin * Cout;
   char* f16base = packed + row[1] + pk_prepared_offset(elems) + pk_f16_offset(Cin, Cout, KH * KW);
   pack_f16_trailer(params + row[0], elems, reinterpret_cast<float*>(f16base + pk_main_bytes(Cin, Cout, KH * KW)));
@@ -692,10 +715,17 @@ int pack_weights_batched(const float* params, void* packed, const long long* tab
   return check_launch("pack_weights_batched");
 }
 
-template <int NT, bool VEC_ONLY = false>
+template <int NT, bool VEC_ONLY = false, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void k_conv_bf3_rows(Bf3Params B) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   const MfmaConvParams& P = B.P;
+  // f16x3 (SRK_ALGO_MFMA_F16X3): the two planes are fp16(x 2^kx) and fp16 of its remainder
+  float sx = 1.f, dsc = 1.f;
+  if constexpr (F16) {
+    const int kx = amax_scale_exp(amax_read(P.ep.x_amax));
+    sx = exp2i(kx);
+    dsc = exp2i(-kx) * B.w_descale[0];
+  }
   uint2* hal = reinterpret_cast<uint2*>(smem4);   // [2 planes][NPIXp] x (4 bf16)
   uint4* wl = smem4 + B.NPIXp;                    // 2 planes * NPIXp * 8 B = NPIXp uint4
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -735,16 +765,30 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3_rows(Bf3Params B) {
             }
         }
       }
-      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-      bf16x4 h, l;
+      if constexpr (F16) {
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        f16x4 h, l;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const __bf16 hh = (__bf16)f[e];
-        h[e] = hh;
-        l[e] = (__bf16)(f[e] - (float)hh);
+        for (int e = 0; e < 4; ++e) {
+          const float xs = f[e] * sx;
+          const _Float16 hh = (_Float16)xs;
+          h[e] = hh;
+          l[e] = (_Float16)(xs - (float)hh);
+        }
+        hal[hp] = __builtin_bit_cast(uint2, h);
+        hal[B.NPIXp + hp] = __builtin_bit_cast(uint2, l);
+      } else {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const __bf16 hh = (__bf16)f[e];
+          h[e] = hh;
+          l[e] = (__bf16)(f[e] - (float)hh);
+        }
+        hal[hp] = __builtin_bit_cast(uint2, h);
+        hal[B.NPIXp + hp] = __builtin_bit_cast(uint2, l);
       }
-      hal[hp] = __builtin_bit_cast(uint2, h);
-      hal[B.NPIXp + hp] = __builtin_bit_cast(uint2, l);
     }
   }
   int hp[4];
@@ -800,15 +844,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3_rows(Bf3Params B) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_bf16(al[mt], bh[nt], acc[mt][nt]);
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16x<F16>(al[mt], bh[nt], acc[mt][nt]);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_bf16(ah[mt], bl[nt], acc[mt][nt]);
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16x<F16>(ah[mt], bl[nt], acc[mt][nt]);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_bf16(ah[mt], bh[nt], acc[mt][nt]);
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16x<F16>(ah[mt], bh[nt], acc[mt][nt]);
       }
       if (q + 1 < Q) {
         uint4* wn = wl + ((q + 1) & 1) * wslot;
@@ -821,6 +865,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3_rows(Bf3Params B) {
         ++u;
       }
     }
+  }
+  if constexpr (F16) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] *= dsc;
   }
   bf3_epilogue<NT, VEC_ONLY>(P, reinterpret_cast<float*>(smem4), acc, n, r0, c0, ocb, wave, lane);
 }
@@ -868,23 +918,26 @@ bool conv_bf3_gather_supported(const GatherConv& g, const Epi& ep) {
   return true;
 }
 
-template <int NT, bool VEC_ONLY>
+template <int NT, bool VEC_ONLY, bool F16 = false>
 static void bf3_launch_rows_v(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s) {
   static LdsLimit lim;
-  lim.ensure(reinterpret_cast<const void*>(&k_conv_bf3_rows<NT, VEC_ONLY>), lds);
-  note_kernel("k_conv_bf3_rows<%d>", NT);
-  hipLaunchKernelGGL((k_conv_bf3_rows<NT, VEC_ONLY>), grid, dim3(256), lds, s, B);
+  lim.ensure(reinterpret_cast<const void*>(&k_conv_bf3_rows<NT, VEC_ONLY, F16>), lds);
+  note_kernel("k_conv_bf3_rows<%d%s>", NT, F16 ? ",f16" : "");
+  hipLaunchKernelGGL((k_conv_bf3_rows<NT, VEC_ONLY, F16>), grid, dim3(256), lds, s, B);
 }
 template <int NT>
 static void bf3_launch_rows(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s) {
-  if (B.P.OC % 16 == 0 && epi_all_vector(B.P))
+  if (B.w_descale)   // f16x3 (the host checked the vector-store condition: conv_bf3_rows_f16_supported)
+    bf3_launch_rows_v<NT, true, true>(B, grid, lds, s);
+  else if (B.P.OC % 16 == 0 && epi_all_vector(B.P))
     bf3_launch_rows_v<NT, true>(B, grid, lds, s);
   else
     bf3_launch_rows_v<NT, false>(B, grid, lds, s);
 }
 
-static int bf3_launch_rows_phase(MfmaConvParams P, const uint4* wq, hipStream_t s) {
+static int bf3_launch_rows_phase(MfmaConvParams P, const uint4* wq, hipStream_t s, const float* w_descale = nullptr) {
   Bf3Params B{};
+  B.w_descale = w_descale;
   const int NT = P.OC >= 64 ? 4 : (P.OC + 15) / 16;
   B.NB = NT * 16;
   B.ICc = (P.KWv + 7) / 8;  // K steps per kernel row
@@ -995,6 +1048,21 @@ int conv_bf3_gather(const GatherConv& g, const float* in, const float* wp, float
   const uint4* wq = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wp) + bf3_prepared_offset(elems));
   return for_each_phase(g, in, wp, out, ep, mask_y, mask_slope,
                         [&](const MfmaConvParams& P) { return bf3_launch_phase(P, wq, s); });
+}
+
+// f16x3 for the row-packed first layers (Cin <= 4 CONV gathers): the fp16 row planes + trailer of the forward buffer
+bool conv_bf3_rows_f16_supported(const GatherConv& g, const Epi& ep, const float* out) {
+  return g.IC <= 4 && !g.trans && g.OC >= 8 && g.OC % 16 == 0 && conv_bf3_gather_supported(g, ep) && !g.in_ps_r &&
+         conv_epi_all_vector(g.OC, ep, out);
+}
+int conv_bf3_rows_f16_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
+                             hipStream_t s) {
+  const size_t elems = (size_t)g.KH * g.KW * g.IC * g.OC;
+  const char* fsec = reinterpret_cast<const char*>(wp) + bf3_prepared_offset(elems) + f16_section_offset(g.IC, g.OC, g.KH * g.KW);
+  const uint4* wq = reinterpret_cast<const uint4*>(fsec);
+  const float* trailer = reinterpret_cast<const float*>(fsec + bf3_main_bytes(g.IC, g.OC, g.KH * g.KW));
+  return for_each_phase(g, in, wp, out, ep, nullptr, 0.f,
+                        [&](const MfmaConvParams& P) { return bf3_launch_rows_phase(P, wq, s, trailer); });
 }
 
 }  // namespace srk

@@ -177,7 +177,8 @@ __device__ __forceinline__ void pack_f16_trailer(const float* __restrict__ w, lo
 // bf16x3 row-packed layout (gather IC <= 4) [kh][ks][ocb][plane][group][co][8]
 __device__ __forceinline__ void pack_bf3_rows_item(long it, const float* __restrict__ w, uint4* __restrict__ dst,
                                                    int Cout, int Cin, int KH, int KW, int transposed, int ps_r, int bwd,
-                                                   int IC, int OC, int KS, int OCb, int NB) {
+                                                   int IC, int OC, int KS, int OCb, int NB,
+                                                   uint4* __restrict__ f16dst = nullptr, float f16scale = 1.f) {
   const int col = (int)(it % NB);
   long r = it / NB;
   const int g = (int)(r % 4);
@@ -211,6 +212,13 @@ __device__ __forceinline__ void pack_bf3_rows_item(long it, const float* __restr
   uint4* blk = dst + ((size_t)(kh * KS + ks) * OCb + ocb) * (size_t)(8 * NB);
   blk[(0 * 4 + g) * NB + col] = hi;
   blk[(1 * 4 + g) * NB + col] = lo;
+  if (f16dst) {  // fp16 planes of w * 2^kw in the same row-packed slots (f16x3 first layers)
+    uint4 fh, fm;
+    pk_split8h(f, f16scale, fh, fm);
+    uint4* fb = f16dst + ((size_t)(kh * KS + ks) * OCb + ocb) * (size_t)(8 * NB);
+    fb[(0 * 4 + g) * NB + col] = fh;
+    fb[(1 * 4 + g) * NB + col] = fm;
+  }
 }
 
 }  // namespace srk

@@ -272,10 +272,11 @@ def conv_forward_raw(x, wp, bias_p, weight_shape_src, cfg, prelu_w=None, residua
         ep.x_amax = ptr(amax_of(x))
         ya = _amax_alloc(y.device)
         ep.y_amax = ptr(ya)
-    elif F16X3 and not x_nchw and d.Cin >= 8 and d.Cout >= 8:
+    elif F16X3 and d.Cout >= 8 and (d.Cin >= 8 or d.Cin <= 4):
         # fp32-faithful class on a layer the fp16 kernels cover: three MFMAs per product instead of six
         if d.algo == _lib.ALGO_MFMA_BF16X6 and lib.srk_conv2d_f16x3_supported(ctypes.byref(d), ctypes.byref(ep), ptr(y)):
-            xa = amax_of(x, compute=F16X3_ALWAYS)
+            # (a first layer's input is the network input: one pass over a <= 4-channel tensor)
+            xa = amax_of(x, compute=F16X3_ALWAYS or d.Cin <= 4)
             if xa is not None:
                 ep.x_amax = ptr(xa)
                 d.algo = _lib.ALGO_MFMA_F16X3
@@ -283,9 +284,12 @@ def conv_forward_raw(x, wp, bias_p, weight_shape_src, cfg, prelu_w=None, residua
             # (a layer of the fp32-faithful class feeds layers of that class: leave them the maximum of the output)
             ya = _amax_alloc(y.device)      # filled by the kernels of conv_bfd.hip (checked below)
             ep.y_amax = ptr(ya)
+    if d.x_nchw and d.algo not in (ALGO_AUTO, _lib.ALGO_MFMA_BF16X3, _lib.ALGO_MFMA_F16X3):
+        x = to_nhwc(x)      # only the bf16x3 / f16x3 first-layer kernels read an NCHW input in place
+        d.x_nchw = 0
     check(lib.srk_conv2d_forward(ctypes.byref(d), ptr(x), ptr(wp), ptr(y), ctypes.byref(ep), stream_ptr()),
           "srk_conv2d_forward")
-    if ya is not None and lib.srk_last_kernel_name().startswith(b"k_conv_bfd"):
+    if ya is not None and lib.srk_last_kernel_name().startswith((b"k_conv_bfd", b"k_conv_bfw", b"k_conv_bf3_rows")):
         _tag_amax(y, ya)
     elif F16X3 and d.algo in (_lib.ALGO_MFMA, _lib.ALGO_MFMA_BF16X6):
         _tag_amax(y, None)   # a faithful-class conv whose kernel leaves no maximum: worth one srk_absmax pass downstream
@@ -693,8 +697,10 @@ def conv2d_infer(x, weight, bias=None, residual=None, cfg=None, prelu_w=None, pa
     require_cuda(x, weight, bias, residual, prelu_w)
     cout, cin, _, _ = _weight_dims(weight, cfg.transposed)
     # the Cin <= 4 bf16x3 first-layer kernel reads the caller's NCHW tensor in place (no layout copy)
+    # (also the f16x3 form of the fp32-faithful class; conv_forward_raw converts the layout if that kernel does not apply)
     x_nchw = (x.dim() == 4 and cin <= 4 and cout >= 8 and not cfg.transposed and not _is_nhwc_dense(x)
-              and _is_nchw_dense(x) and _algo_for(cfg, "infer") == ALGO_AUTO
+              and _is_nchw_dense(x)
+              and (_algo_for(cfg, "infer") == ALGO_AUTO or (F16X3 and _algo_for(cfg, "infer") == _lib.ALGO_MFMA_BF16X6))
               and not os.environ.get("SRK_FORCE_ALGO"))  # (the debugging override may pick a kernel without the in-place NCHW read)
     if not x_nchw:
         x = to_nhwc(x)
