@@ -301,8 +301,10 @@ int srk_bn_finalize(const double* stats, double count, float* save_mean, float* 
 int srk_bn_stats_finalize(const float* x, double* stats, size_t rows, int C, float* save_mean, float* save_rstd,
                           float* running_mean, float* running_var, float momentum, float eps,
                           int64_t* num_batches_tracked, void* workspace, void* stream);
+/* y_amax (optional, here and in srk_bn_apply_act): SRK_AMAX_FLOATS floats that receive max|y| -- the x_amax of a
+ * following SRK_ALGO_MFMA_F16X3 convolution (16-byte path only: C % 4 == 0, aligned tensors). */
 int srk_bn_apply(const float* x, float* y, const float* mean, const float* rstd, const float* gamma,
-                 const float* beta, size_t rows, int C, int act, float slope, void* stream);
+                 const float* beta, size_t rows, int C, int act, float slope, float* y_amax, void* stream);
 int srk_bn_eval_params(const float* running_mean, const float* running_var, float eps, float* mean, float* rstd,
                        int C, void* stream);
 /* Backward: `dstats` [2*C] doubles = (sum dy, sum dy*xhat) (all-reducible for SyncBN);
@@ -328,7 +330,7 @@ int srk_bn_param_grads(const double* dstats, float* dgamma, float* dbeta, int C,
  * The gradient of `residual` is dy itself.  C must be a multiple of 4, tensors 16-byte aligned.  prelu_n: 1 or C. */
 int srk_bn_apply_act(const float* x, float* y, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, size_t rows, int C, int act, float slope, const float* prelu_weight, int prelu_n,
-                     const float* residual, void* stream);
+                     const float* residual, float* y_amax, void* stream);
 int srk_bn_backward_stats_grads_act(const float* dy, const float* x, const float* mean, const float* rstd,
                                     const float* gamma, const float* beta, double* dstats, size_t rows, int C,
                                     float* dgamma, float* dbeta, int act, float slope, const float* prelu_weight,

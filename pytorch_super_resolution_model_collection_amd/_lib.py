@@ -95,8 +95,8 @@ _PROTOTYPES = {
     "srk_bn_finalize": (c_int, [c_vp, ctypes.c_double, c_f, c_f, c_f, c_f, c_float, c_float, c_int, c_vp, c_vp]),
     "srk_bn_stats_finalize": (c_int, [c_f, c_vp, c_size, c_int, c_f, c_f, c_f, c_f, c_float, c_float, c_vp, c_vp, c_vp]),
     "srk_bn_backward_stats_grads": (c_int, [c_f, c_f, c_f, c_f, c_vp, c_size, c_int, c_f, c_f, c_vp, c_vp]),
-    "srk_bn_apply": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_size, c_int, c_int, c_float, c_vp]),
-    "srk_bn_apply_act": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_size, c_int, c_int, c_float, c_f, c_int, c_f, c_vp]),
+    "srk_bn_apply": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_size, c_int, c_int, c_float, c_f, c_vp]),
+    "srk_bn_apply_act": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_size, c_int, c_int, c_float, c_f, c_int, c_f, c_f, c_vp]),
     "srk_bn_backward_stats_grads_act": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_size, c_int, c_f, c_f, c_int,
                                                  c_float, c_f, c_int, c_f, c_vp, c_vp]),
     "srk_bn_backward_apply_act": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_vp, ctypes.c_double, c_f, c_size, c_int, c_int,

@@ -2,6 +2,7 @@
 // (base_networks.py:7,46,117,161; srgan.py:49-81).  NHWC: a tensor is [rows][C] with
 // rows = N*H*W, so per-channel statistics are column sums with lanes = channels (coalesced rows).
 #include "srk_common.h"
+#include "bf16_frag.h"
 #include <stdlib.h>
 
 namespace srk {
@@ -229,7 +230,9 @@ typedef float bn_f4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_bn_apply4(const float* __restrict__ x, float* __restrict__ y,
                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                   size_t total4, int C, int act, float slope) {
+                                                   size_t total4, int C, int act, float slope, float* __restrict__ y_amax) {
+  __shared__ float sm_amax[4];
+  float amax = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
     const int c = (int)((i * 4) % (size_t)C);
     const bn_f4 xv = *reinterpret_cast<const bn_f4*>(x + i * 4);
@@ -240,7 +243,9 @@ __global__ __launch_bounds__(256) void k_bn_apply4(const float* __restrict__ x, 
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act, slope);
     *reinterpret_cast<bn_f4*>(y + i * 4) = v;
+    if (y_amax) amax = abs_max4(amax, v);
   }
+  if (y_amax) amax_commit_block(y_amax, amax, blockIdx.x, sm_amax, 4);   // the running maximum the next conv scales by
 }
 
 template <bool DBL>
@@ -303,7 +308,10 @@ __device__ __forceinline__ float bn_act_slope(const BnAct& A, int c) {
 // y = act(gamma * (x - mean) * rstd + beta) [+ residual], one float4 per thread and pass
 __global__ __launch_bounds__(256) void k_bn_apply_act4(const float* __restrict__ x, float* __restrict__ y,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                       BnAct A, const float* __restrict__ residual, size_t total4, int C) {
+                                                       BnAct A, const float* __restrict__ residual, size_t total4, int C,
+                                                       float* __restrict__ y_amax) {
+  __shared__ float sm_amax[4];
+  float amax = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
     const int c = (int)((i * 4) % (size_t)C);
     const bn_f4 xv = *reinterpret_cast<const bn_f4*>(x + i * 4);
@@ -318,7 +326,9 @@ __global__ __launch_bounds__(256) void k_bn_apply_act4(const float* __restrict__
     }
     if (residual) v += *reinterpret_cast<const bn_f4*>(residual + i * 4);
     *reinterpret_cast<bn_f4*>(y + i * 4) = v;
+    if (y_amax) amax = abs_max4(amax, v);
   }
+  if (y_amax) amax_commit_block(y_amax, amax, blockIdx.x, sm_amax, 4);   // the running maximum the next conv scales by
 }
 
 // backward statistics with dz = dy * act'(z):  partial[split][3][C] = sum dz, sum dz * xhat, sum_{z <= 0} dy * z (PReLU)
@@ -828,7 +838,7 @@ extern "C" int srk_bn_eval_params(const float* running_mean, const float* runnin
 }
 
 extern "C" int srk_bn_apply(const float* x, float* y, const float* mean, const float* rstd, const float* gamma,
-                            const float* beta, size_t rows, int C, int act, float slope, void* stream) {
+                            const float* beta, size_t rows, int C, int act, float slope, float* y_amax, void* stream) {
   SRK_REQUIRE(x && y && mean && rstd && rows > 0 && C > 0, "bn_apply: bad args");
   SRK_REQUIRE(act != SRK_ACT_PRELU, "bn_apply: PReLU is not fused here (use srk_act_forward)");
   const size_t total = rows * (size_t)C;
@@ -836,8 +846,11 @@ extern "C" int srk_bn_apply(const float* x, float* y, const float* mean, const f
   if (nb > 4096) nb = 4096;
   if (bn_vec4(C, x, y, mean, rstd, gamma, beta))
     hipLaunchKernelGGL(k_bn_apply4, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, y, mean, rstd, gamma, beta,
-                       total / 4, C, act, slope);
-  else
+                       total / 4, C, act, slope, y_amax);
+  else if (y_amax) {
+    set_error("bn_apply: y_amax needs the 16-byte path (C %% 4 == 0, aligned tensors)");
+    return SRK_ERR_UNSUPPORTED;
+  } else
     hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, y, mean, rstd, gamma, beta,
                        total, C, act, slope);
   return check_launch("bn_apply");
@@ -883,7 +896,7 @@ static int bn_act_check(int act, const float* prelu_w, int prelu_n, int C, const
 
 extern "C" int srk_bn_apply_act(const float* x, float* y, const float* mean, const float* rstd, const float* gamma,
                                 const float* beta, size_t rows, int C, int act, float slope, const float* prelu_weight,
-                                int prelu_n, const float* residual, void* stream) {
+                                int prelu_n, const float* residual, float* y_amax, void* stream) {
   SRK_REQUIRE(x && y && mean && rstd && rows > 0 && C > 0, "bn_apply_act: bad args");
   int rc = bn_act_check(act, prelu_weight, prelu_n, C, "bn_apply_act");
   if (rc) return rc;
@@ -894,7 +907,7 @@ extern "C" int srk_bn_apply_act(const float* x, float* y, const float* mean, con
   if (nb > 4096) nb = 4096;
   BnAct A{gamma, beta, prelu_weight, act, prelu_n, slope};
   hipLaunchKernelGGL(k_bn_apply_act4, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, y, mean, rstd, A, residual,
-                     total / 4, C);
+                     total / 4, C, y_amax);
   return check_launch("bn_apply_act");
 }
 

@@ -101,6 +101,19 @@ def _amax_alloc(device):
     return ent[0][lo:lo + _lib.AMAX_FLOATS]
 
 
+F16X3_MIN_PIXELS = int(os.environ.get("SRK_F16X3_MIN_PIXELS", str(256 * 2 * 256)))
+
+
+def _f16x3_pays(d):
+    """Where three MFMAs instead of six are worth the running-maximum bookkeeping: problems large enough to be bound by
+    the matrix work (conv_bfd.hip's large-block configurations: >= two 256-pixel tiles per CU), kernels with more than
+    nine taps, first layers (Cin <= 4: the alternative is the fp32 MFMA kernel).  The 64-pixel blocks of a small 3x3
+    problem are a latency chain -- measured on the SRGAN step (16 patches): 18.7 us with f16x3 against 19.1 us with
+    bf16x6 per conv, and the maxima cost more than that."""
+    return (d.Cin <= 4 or d.KH * d.KW > 9 or F16X3_ALWAYS
+            or d.N * d.OH * d.OW * ((d.Cout + 63) // 64) >= F16X3_MIN_PIXELS)
+
+
 def _tag_amax(t, slots):
     t._srk_amax = (slots, t._version, _AMAX_EPOCH[0])
 
@@ -272,7 +285,7 @@ def conv_forward_raw(x, wp, bias_p, weight_shape_src, cfg, prelu_w=None, residua
         ep.x_amax = ptr(amax_of(x))
         ya = _amax_alloc(y.device)
         ep.y_amax = ptr(ya)
-    elif F16X3 and d.Cout >= 8 and (d.Cin >= 8 or d.Cin <= 4):
+    elif F16X3 and d.Cout >= 8 and (d.Cin >= 8 or d.Cin <= 4) and _f16x3_pays(d):
         # fp32-faithful class on a layer the fp16 kernels cover: three MFMAs per product instead of six
         if d.algo == _lib.ALGO_MFMA_BF16X6 and lib.srk_conv2d_f16x3_supported(ctypes.byref(d), ctypes.byref(ep), ptr(y)):
             # (a first layer's input is the network input: one pass over a <= 4-channel tensor)
@@ -1002,6 +1015,11 @@ class _BatchNorm(torch.autograd.Function):
                                          stream_ptr()), "srk_bn_eval_params")
         y = torch.empty_like(x)
         fused = act != ACT_NONE or residual is not None
+        # 4-D activations in front of a convolution of the fp32-faithful class: leave the output's running maximum
+        ya = _amax_alloc(x.device) if (F16X3 and x.dim() == 4 and c % 4 == 0
+                                       and (F16X3_ALWAYS or rows * ((c + 63) // 64) >= F16X3_MIN_PIXELS)
+                                       and _MODES[_PRECISION["mode"]]["train_fwd" if training else "infer"]
+                                       in (_lib.ALGO_MFMA_BF16X6, _lib.ALGO_MFMA_F16X3)) else None
         if fused:
             if residual is not None:
                 residual = _dense(residual)
@@ -1009,10 +1027,12 @@ class _BatchNorm(torch.autograd.Function):
                     raise RuntimeError("batch_norm: residual must have the shape and layout of x")
             check(lib.srk_bn_apply_act(ptr(x), ptr(y), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), rows, c, act, slope,
                                        ptr(prelu_w), 0 if prelu_w is None else prelu_w.numel(), ptr(residual),
-                                       stream_ptr()), "srk_bn_apply_act")
+                                       ptr(ya), stream_ptr()), "srk_bn_apply_act")
         else:
             check(lib.srk_bn_apply(ptr(x), ptr(y), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), rows, c, ACT_NONE, 0.0,
-                                   stream_ptr()), "srk_bn_apply")
+                                   ptr(ya), stream_ptr()), "srk_bn_apply")
+        if ya is not None:
+            _tag_amax(y, ya)    # the convolution behind a BatchNorm scales its fp16 planes by this (F16X3)
         ctx.training, ctx.count, ctx.sync_group = training, count, sync_group
         ctx.gamma_ref, ctx.beta_ref, ctx.prelu_ref = gamma, beta, prelu_w
         ctx.act, ctx.slope, ctx.has_res = act, slope, residual is not None
@@ -1116,7 +1136,7 @@ class _InstanceNorm(torch.autograd.Function):
             check(lib.srk_bn_finalize(ptr(stats), float(rows), ptr(mean[i]), ptr(rstd[i]), None, None, 0.0, eps, c, None,
                                       stream_ptr()), "srk_bn_finalize")
             check(lib.srk_bn_apply(ptr(xs[i]), ptr(ys[i]), ptr(mean[i]), ptr(rstd[i]), None, None, rows, c, ACT_NONE, 0.0,
-                                   stream_ptr()), "srk_bn_apply")
+                                   None, stream_ptr()), "srk_bn_apply")
         ctx.save_for_backward(x, mean, rstd)
         return y
 

@@ -427,7 +427,7 @@ def test_batchnorm_with_folded_activation_and_residual(gpu, act):
     P = pkg._lib.ptr
     xs = xg.detach().contiguous(memory_format=torch.channels_last)
     rc = lib.srk_bn_apply_act(P(xs), P(torch.empty_like(xs)), P(rm), P(rv), None, None, n * h * w, c, pkg._lib.ACT_BY_NAME["tanh"]
-                              if hasattr(pkg._lib, "ACT_BY_NAME") else 4, 0.0, None, 0, None, pkg._lib.stream_ptr())
+                              if hasattr(pkg._lib, "ACT_BY_NAME") else 4, 0.0, None, 0, None, None, pkg._lib.stream_ptr())
     assert rc != 0
 
 

@@ -111,7 +111,9 @@ def test_resblock2_matches_oracle_and_separate_launches(gpu, shape, bias):
     assert not lib.srk_last_kernel_name().decode().startswith("k_res2<")
     assert torch.equal(y1, out_g) and torch.equal(dx1, dx_g)
     assert float(ya.max()) == float(out_g.abs().max())      # the running maximum the next layer scales by
-    assert_close_elementwise(y1, y0, 2e-6, what="fused forward vs separate launches")
+    # (fused: f16x3; the two separate small-problem launches keep bf16x6 -- ops._f16x3_pays: two fp32-faithful arithmetics,
+    #  each within ~1e-6 of max|y| of float64)
+    assert_close_elementwise(y1, y0, 5e-6 if pkg.ops.F16X3 else 2e-6, what="fused forward vs separate launches")
     for k, g in want.items():
         assert_close_elementwise(g1[k], g, 1e-4, what="fused path grad " + k)
     # (a mask element the two paths decide differently moves 9 x 64 gradient elements: allow a handful)
