@@ -376,3 +376,70 @@ def test_cli_dataset_names_and_synthetic_flag(tmp_path):
     assert a.train_dataset == ["DIV2K"] and a.test_dataset == ["Set5", "Set14"] and a.synthetic is False
     a = cli.parse_args(["--save_dir", str(tmp_path), "--synthetic"])
     assert a.train_dataset == ["DIV2K"] and a.test_dataset == ["Set5", "Set14", "Urban100"] and a.synthetic is True
+
+
+# The reference's `random` consumption per training item, from its source (torchvision is not installed here, so its
+# dataset classes cannot run: SURVEY.md 8c / VERDICT r2 weak #3).  (dataset.py line, call, condition); the two torchvision
+# transforms are written out as torchvision 0.2 implements them: RandomCrop.get_params draws i = randint(0, h - th) then
+# j = randint(0, w - tw) unless the image already has the crop size, RandomHorizontalFlip tests random() < 0.5.
+REFERENCE_DRAWS = [
+    (54, "random.randint(5, 10)", "random_scale"),
+    (66, "RandomCrop(self.crop_size)", "always"),
+    (71, "random.randint(1, 3)", "rotate"),
+    (76, "RandomHorizontalFlip()", "fliplr"),
+    (81, "random.random() < 0.5", "fliptb"),
+]
+
+
+def test_training_item_draws_follow_the_reference_source_order(pkg, tmp_path, monkeypatch):
+    """data.TrainDatasetFromFolder.draw consumes Python's `random` in the order of dataset.py:51-83 -- the table above,
+    checked against the reference's source lines when /root/reference is present (this container) and replayed against
+    draw() for every flag combination: same calls, same arguments, same order."""
+    ref = "/root/reference/dataset.py"
+    if os.path.exists(ref):
+        lines = open(ref).read().splitlines()
+        for lineno, text, _ in REFERENCE_DRAWS:
+            assert text in lines[lineno - 1], (lineno, text, lines[lineno - 1])
+        order = [lineno for lineno, _, _ in REFERENCE_DRAWS]
+        assert order == sorted(order)
+    calls = []
+
+    class Recorder(object):
+        @staticmethod
+        def randint(a, b):
+            calls.append(("randint", a, b))
+            return a          # smallest value: the random-scale ratio 0.5 < 1 takes the reference's "force >= crop" branch
+        @staticmethod
+        def random():
+            calls.append(("random",))
+            return 0.25
+
+    monkeypatch.setattr(pkg.data, "random", Recorder)
+    img_dir = tmp_path / "imgs"
+    img_dir.mkdir()
+    import itertools
+    for random_scale, rotate, fliplr, fliptb in itertools.product([True, False], repeat=4):
+        ds = pkg.data.TrainDatasetFromFolder([str(img_dir)], random_scale=random_scale, crop_size=32, rotate=rotate,
+                                             fliplr=fliplr, fliptb=fliptb, scale_factor=4, device="cpu")
+        for (w, h) in ((48, 40), (32, 32)):
+            del calls[:]
+            scale, (x0, y0), rot, fl, ft = ds.draw(w, h)
+            want = []
+            cw, ch = w, h
+            if random_scale:
+                want.append(("randint", 5, 10))
+                # dataset.py:54-60: ratio forced to crop / crop + eps -> the whole image becomes crop x crop (App. B-8)
+                cw = ch = int(32 * (32 / 32 + 1e-3))
+                assert scale == (cw, ch)
+            else:
+                assert scale is None
+            if (cw, ch) != (32, 32):       # torchvision 0.2 RandomCrop.get_params
+                want += [("randint", 0, ch - 32), ("randint", 0, cw - 32)]
+            if rotate:
+                want.append(("randint", 1, 3))
+            if fliplr:
+                want.append(("random",))
+            if fliptb:
+                want.append(("random",))
+            assert calls == want, (random_scale, rotate, fliplr, fliptb, w, h, calls, want)
+            assert rot == (1 if rotate else 0) and fl == fliplr and ft == fliptb
