@@ -39,6 +39,9 @@ def parse_args(argv=None):
     p.add_argument('--epoch_pretrain', type=int, default=50, help='SRGAN generator pre-training epochs (srgan.py:179)')
     p.add_argument('--precision', type=str, default='mixed', choices=['mixed', 'bf16x3', 'bf16x6', 'fp32'])
     p.add_argument('--eager', action='store_true', help='launch every kernel of a train step from Python (default: replay the step as a hipGraph)')
+    p.add_argument('--sync_bn', action='store_true',
+                   help='data-parallel SRGAN: BatchNorm statistics over the GLOBAL batch (all-reduce of the [2C] sums per '
+                        'BatchNorm call; default: per-shard statistics), i.e. the single-process step of the reference')
     p.add_argument('--prune_dead_grads', action='store_true',
                    help='SRGAN: skip the two gradient computations of the reference iteration that nothing reads '
                         '(G gradients of the D step, D parameter gradients of the G step); same parameters after every step')

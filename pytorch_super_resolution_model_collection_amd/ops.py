@@ -977,6 +977,20 @@ def bce_loss(pred, target):
 BN_FUSE_ACT = os.environ.get("SRK_BN_FUSE_ACT", "1") != "0"   # 0: activations / residual adds after a BatchNorm stay passes of their own
 
 
+# Collectives inside a captured step (SyncBN's [2C] sums): a capture cannot hold them, so the capturing side
+# (trainers.GraphedSegments with a _Splitter) cuts its graph there -- end the graph, run the collective eagerly now and at
+# every replay, begin the next graph.  Outside a capture the collective simply runs.
+_SPLITTER = [None]
+
+
+def _collective(fn):
+    sp = _SPLITTER[0]
+    if sp is not None and torch.cuda.is_current_stream_capturing():
+        sp.collective(fn)
+    else:
+        fn()
+
+
 class _BatchNorm(torch.autograd.Function):
     """y = act(bn(x)) [+ residual].  act in {none, relu, lrelu, prelu} and the residual ride in the BatchNorm kernels
     (srk_bn_*_act): the backward recomputes z = gamma * xhat + beta from x, so nothing of the activation is saved."""
@@ -1006,7 +1020,7 @@ class _BatchNorm(torch.autograd.Function):
             else:                    # SyncBN: the [2C] sums are all-reduced between the two phases
                 import torch.distributed as dist
                 check(lib.srk_bn_stats(ptr(x), ptr(stats), rows, c, ptr(ws), stream_ptr()), "srk_bn_stats")
-                dist.all_reduce(stats, group=sync_group)
+                _collective(lambda: dist.all_reduce(stats, group=sync_group))
                 count *= dist.get_world_size(sync_group)
                 check(lib.srk_bn_finalize(ptr(stats), count, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
                                           momentum, eps, c, nbt_p, stream_ptr()), "srk_bn_finalize")
@@ -1070,7 +1084,8 @@ class _BatchNorm(torch.autograd.Function):
                   "srk_bn_backward_stats_grads_act")
             if ctx.training and ctx.sync_group is not None:
                 import torch.distributed as dist
-                dist.all_reduce(dstats, group=ctx.sync_group)
+                grp = ctx.sync_group
+                _collective(lambda: dist.all_reduce(dstats, group=grp))
             dx = torch.empty_like(dy)
             use = dstats if ctx.training else torch.zeros_like(dstats)
             check(lib.srk_bn_backward_apply_act(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(use),
@@ -1083,7 +1098,8 @@ class _BatchNorm(torch.autograd.Function):
                                               ptr(dbeta), ptr(ws), stream_ptr()), "srk_bn_backward_stats_grads")
         if ctx.training and ctx.sync_group is not None:
             import torch.distributed as dist
-            dist.all_reduce(dstats, group=ctx.sync_group)
+            grp = ctx.sync_group
+            _collective(lambda: dist.all_reduce(dstats, group=grp))
         dx = torch.empty_like(dy)
         # eval-mode BN: statistics are constants -> no mean/projection terms in dx
         use = dstats if ctx.training else torch.zeros_like(dstats)

@@ -361,6 +361,9 @@ class SRGAN(_Trainer):
             g_dp, d_dp = dpmod.DataParallel(g_flat), dpmod.DataParallel(d_flat)
             g_dp.broadcast_params()
             d_dp.broadcast_params()
+            if getattr(self.args, "sync_bn", False):   # statistics of the global batch (SURVEY.md 8e caveat)
+                trainers.sync_batchnorm(self.G)
+                trainers.sync_batchnorm(self.D)
         norm = lambda t: utils.norm(t, vgg=True)   # srgan.py:193-194,257-258
 
         self.data_source = "loader"

@@ -209,6 +209,75 @@ def _capture(graph, pool=None):
     return torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local")
 
 
+class _Splitter(object):
+    """Captures a function as a SEQUENCE of hipGraphs cut at the collectives it issues through ops._collective (SyncBN:
+    one all-reduce of the [2C] sums per BatchNorm call and direction): items = [("graph", g) | ("eager", fn), ...].
+    The backward pass runs on the calling thread while capturing (torch.autograd.set_multithreading_enabled(False)):
+    a capture has to be ended by the thread that began it."""
+
+    def __init__(self, pool):
+        self.pool, self.items, self.g = pool, [], None
+
+    def begin(self):
+        self.g = torch.cuda.CUDAGraph()
+        self.g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+
+    def end(self):
+        self.g.capture_end()
+        self.pool = self.g.pool()
+        self.items.append(("graph", self.g))
+        self.g = None
+
+    def collective(self, fn):
+        self.end()
+        fn()                       # (keeps the process group's sequence numbers in step with the other ranks)
+        self.items.append(("eager", fn))
+        self.begin()
+
+    def capture(self, fn, args):
+        ops.amax_new_step()
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        ops._SPLITTER[0] = self
+        try:
+            with torch.cuda.stream(side), torch.autograd.set_multithreading_enabled(False):
+                self.begin()
+                try:
+                    out = fn(*args)
+                finally:
+                    self.end()
+        finally:
+            ops._SPLITTER[0] = None
+        cur.wait_stream(side)
+        return out
+
+
+def _has_sync_bn(segments):
+    for _, dp in segments:
+        mod = getattr(getattr(dp, "flat", None), "module", None)
+        if mod is not None and any(getattr(m, "sync_group", None) is not None for m in mod.modules()):
+            return True
+    return False
+
+
+def sync_batchnorm(module, group=None):
+    """SyncBN (SURVEY.md 8e caveat): every BatchNorm of `module` all-reduces its [2C] sums over `group` (None: the default
+    process group), so a data-parallel step normalises with the statistics of the GLOBAL batch, like the single-process
+    reference; no-op without an initialised process group.  Returns the number of layers switched."""
+    import torch.distributed as dist
+    from .layers import BatchNorm1d, BatchNorm2d
+    if not dist.is_initialized():
+        return 0
+    grp = group if group is not None else dist.group.WORLD
+    n = 0
+    for m in module.modules():
+        if isinstance(m, (BatchNorm2d, BatchNorm1d)):
+            m.sync_group = grp
+            n += 1
+    return n
+
+
 class GraphedSegments(object):
     """A data-parallel train step as hipGraphs split at the gradient exchanges.
 
@@ -229,12 +298,19 @@ class GraphedSegments(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.plan, pool = [], None
+        split = _has_sync_bn(segments)    # SyncBN: the segment's graph is cut again at every statistics all-reduce
         with _no_gc_during_capture():
             for fn, dp in segments:
-                g = torch.cuda.CUDAGraph()
-                with _capture(g, pool=pool):
-                    self.out = fn(*self.static)
-                pool = g.pool()
+                if split:
+                    sp = _Splitter(pool)
+                    self.out = sp.capture(fn, self.static)
+                    pool, g = sp.pool, sp.items
+                else:
+                    g = torch.cuda.CUDAGraph()
+                    with _capture(g, pool=pool):
+                        self.out = fn(*self.static)
+                    pool = g.pool()
+                    g = [("graph", g)]
                 wgraphs, sends, keep = [], [], None
                 if dp is not None and dp.active:
                     keep = ops.pending_wgrad_groups(dp.trunk_chunk_layers)   # holds x / dy / mask tensors of graph `g` alive
@@ -267,8 +343,12 @@ class GraphedSegments(object):
             if b is not s:
                 s.copy_(b, non_blocking=True)
         _repack_touched(self._flats, self._seen)
-        for g, dp, wgraphs, sends, _ in self.plan:
-            g.replay()
+        for items, dp, wgraphs, sends, _ in self.plan:
+            for kind, obj in items:
+                if kind == "graph":
+                    obj.replay()
+                else:
+                    obj()
             if dp is not None and dp.active:
                 works = []
                 if not wgraphs:

@@ -98,7 +98,38 @@ def _worker(rank, world, port, out, backend="gloo"):
         m.running_var.copy_(rv)
     gan_losses_graph = [[float(v) for v in seg(lr_img, hr_img)] for _ in range(2)]
     gan_p_graph = torch.cat([g_opt2.flat.data, d_opt2.flat.data]).cpu()
+    # SyncBN (SURVEY.md 8e caveat): with the [2C] BatchNorm sums all-reduced, the data-parallel step normalises with the
+    # statistics of the GLOBAL batch -- eager, and as graphs cut again at every statistics all-reduce (trainers._Splitter)
+    def bn_state(*nets):
+        return torch.cat([t_.flatten().float() for net_ in nets for m in net_.modules() if isinstance(m, torch.nn.BatchNorm2d)
+                          for t_ in (m.running_mean, m.running_var)]).cpu()
+
+    G3, D3, g_opt3, d_opt3, g_dp3, d_dp3 = make_gan()
+    n_sync = pkg.trainers.sync_batchnorm(G3) + pkg.trainers.sync_batchnorm(D3)
+    s3 = pkg.trainers.srgan_step(G3, D3, g_opt3, d_opt3, g_dp3, d_dp3)
+    sync_losses = [float(v) for v in s3(lr_img, hr_img)]
+    sync_p, sync_bn = torch.cat([g_opt3.flat.data, d_opt3.flat.data]).cpu(), bn_state(G3, D3)
+    G4, D4, g_opt4, d_opt4, g_dp4, d_dp4 = make_gan()
+    pkg.trainers.sync_batchnorm(G4)
+    pkg.trainers.sync_batchnorm(D4)
+    snap4 = [[t_.clone() for t_ in state(o)] for o in (g_opt4, d_opt4)]
+    bn4 = [(m, m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone()) for net_ in (G4, D4)
+           for m in net_.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    seg4 = pkg.trainers.GraphedSegments(pkg.trainers.srgan_segments(G4, D4, g_opt4, d_opt4, g_dp4, d_dp4), (lr_img, hr_img),
+                                        warmup=1)
+    n_items = sum(len(pl[0]) for pl in seg4.plan)
+    for o, saved in zip((g_opt4, d_opt4), snap4):
+        for t_, t0 in zip(state(o), saved):
+            t_.copy_(t0)
+    for m, rm, rv, nb in bn4:
+        m.running_mean.copy_(rm)
+        m.running_var.copy_(rv)
+        m.num_batches_tracked.copy_(nb)
+    sync_losses_graph = [float(v) for v in seg4(lr_img, hr_img)]
+    sync_p_graph, sync_bn_graph = torch.cat([g_opt4.flat.data, d_opt4.flat.data]).cpu(), bn_state(G4, D4)
     res = {"g": g_dp, "p": p_dp, "p_graph": p_graph, "loss": float(dp.allreduce_scalar(loss.detach().clone())),
+           "n_sync": n_sync, "n_items": n_items, "sync_losses": sync_losses, "sync_p": sync_p, "sync_bn": sync_bn,
+           "sync_losses_graph": sync_losses_graph, "sync_p_graph": sync_p_graph, "sync_bn_graph": sync_bn_graph,
            "g_single": g_single, "n_groups": n_groups, "n_sends": sum(len(r_) for r_ in sends),
            "covered": sorted(rg for r_ in sends for rg in r_), "numel": flat_s.grad.numel(),
            "gan_losses": gan_losses, "gan_losses_graph": gan_losses_graph, "gan_p": gan_p, "gan_p_graph": gan_p_graph}
@@ -107,6 +138,12 @@ def _worker(rank, world, port, out, backend="gloo"):
         step1 = pkg.trainers.l1_step(net1, opt1, None)
         l1 = step1(x.to(dev), t.to(dev))
         res.update(g1=flat1.grad.clone().cpu(), p1=flat1.data.clone().cpu(), loss1=float(l1))
+        # ... and the SRGAN step on the global batch of 4 in one process (no DP, plain BatchNorm): what SyncBN must reproduce
+        G1, D1, g_opt1, d_opt1, _, _ = make_gan()
+        full_lr, full_hr = fill.rand((4, 3, 8, 8), 31).to(dev), fill.rand((4, 3, 32, 32), 32).to(dev)
+        l_full = [float(v) for v in pkg.trainers.srgan_step(G1, D1, g_opt1, d_opt1)(full_lr, full_hr)]
+        res.update(full_losses=l_full, full_pg=g_opt1.flat.data.clone().cpu(), full_pd=d_opt1.flat.data.clone().cpu(),
+                   full_bn=bn_state(G1, D1), n_g=g_opt1.flat.data.numel())
     # (plain numpy payloads: the result file must not depend on how torch.save de-duplicates storages)
     import pickle
     with open(out % r, "wb") as fh:
@@ -142,6 +179,25 @@ def _check(r0, r1):
     for a, b in zip(sum(r0["gan_losses"], []), sum(r0["gan_losses_graph"], [])):
         assert abs(a - b) <= 1e-4 * abs(a) + 1e-7
     assert (r0["gan_p_graph"] - r0["gan_p"]).abs().max() <= 1e-4 * r0["gan_p"].abs().max()
+    # SyncBN: replicas identical; graphs cut at the statistics all-reduces == eager; and the two-rank step == the
+    # single-process step on the global batch (losses are means over the global batch: average of the rank losses for
+    # the per-sample terms; parameters and BatchNorm running statistics after the step)
+    assert r0["n_sync"] >= 5 and r0["n_items"] > 3 * r0["n_sync"]        # (forward + backward cuts per BatchNorm call)
+    assert torch.equal(r0["sync_p"], r1["sync_p"]) and torch.equal(r0["sync_p_graph"], r1["sync_p_graph"])
+    assert (r0["sync_p_graph"] - r0["sync_p"]).abs().max() <= 1e-5 * r0["sync_p"].abs().max()
+    assert (r0["sync_bn_graph"] - r0["sync_bn"]).abs().max() <= 1e-6 * r0["sync_bn"].abs().max()
+    for a, b in zip(r0["sync_losses"], r0["sync_losses_graph"]):
+        assert abs(a - b) <= 1e-5 * abs(a) + 1e-7
+    for k in range(2):   # d_loss, g_loss: mean over ranks of the shard means == global mean (equal shards)
+        both = 0.5 * (r0["sync_losses"][k] + r1["sync_losses"][k])
+        assert abs(both - r0["full_losses"][k]) <= 1e-4 * abs(r0["full_losses"][k]), (k, both, r0["full_losses"][k])
+    assert (r0["sync_bn"] - r0["full_bn"]).abs().max() <= 1e-5 * r0["full_bn"].abs().max()
+    n_g = int(r0["n_g"])
+    pd, fd = r0["sync_p"][n_g:], r0["full_pd"]
+    assert (pd - fd).norm() <= 1e-5 * fd.norm()                              # D: SGD, the update is linear in the gradient
+    pg, fg = r0["sync_p"][:n_g], r0["full_pg"]
+    assert (pg - fg).norm() <= 1e-3 * fg.norm()                              # G: Adam's first step is +-lr per element
+
 
 
 def test_dp_two_ranks_match_single_process(gpu, tmp_path):
