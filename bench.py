@@ -152,6 +152,52 @@ def pmc_traffic(kernel_label, batch, lr_size):
     return None
 
 
+def training_roofline(tag, px, layer_px_note):
+    """extra.<tag>_roofline: the three kernels that carry a 64 -> 64 3x3 body layer of a training config (forward, data
+    gradient, weight gradient) from the COMMITTED rocprofv3 passes of this round (profiles/*_<tag>_kernel_stats.csv and
+    *_<tag>_pmc_traffic.json, tools/profile_round.sh: the counters cannot be collected from inside this process):
+    algorithmic bytes per launch (read each operand once, write the result once), HBM bytes the counters saw
+    (FETCH_SIZE x 2 + WRITE_SIZE per the gfx950 note of MI355X_MICROARCH.md), their ratio, and the achieved fraction of the
+    matrix peak (bf16x3 / f16x3: 2.5 PF / 3 MFMAs per product) from the average kernel time of the same run."""
+    import csv
+    import glob
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    stats = sorted(glob.glob(os.path.join(here, "*_%s_kernel_stats.csv" % tag)))
+    traffic = sorted(glob.glob(os.path.join(here, "*_%s_pmc_traffic.json" % tag)))
+    if not stats or not traffic:
+        return None
+    with open(traffic[-1]) as fh:
+        hbm = json.load(fh).get("kernels", {})
+    with open(stats[-1]) as fh:
+        rows = list(csv.DictReader(fh))
+    t = 4.0 * 64 * px                     # one 64-channel fp32 tensor of the layer
+    flop = 2.0 * px * 64 * 64 * 9
+    roles = (("forward", ("k_conv_bfd<2, 2, 2, 2", "k_conv_bfd<2, 2, 2, 3", "k_conv_bfd<4, 4, 1, 2"), 2 * t, "x, y"),
+             ("data_gradient", ("k_conv_bf3<4, 4, true>",), 3 * t, "dy, activation mask, dx"),
+             ("weight_gradient", ("k_wgrad_bf<2, 2, 2, true",), 3 * t, "x, dy, activation mask"))
+    out = {"source": [os.path.basename(stats[-1]), os.path.basename(traffic[-1])], "layer": layer_px_note, "kernels": {}}
+    for role, keys, alg, what in roles:
+        best = None
+        for r in rows:
+            if any(k in r["Name"] for k in keys) and (best is None or float(r["TotalDurationNs"]) > float(best["TotalDurationNs"])):
+                best = r
+        if best is None:
+            continue
+        name = best["Name"]
+        counter = next((v.get("hbm_bytes") for k, v in hbm.items() if k == name), None)
+        us = float(best["AverageNs"]) / 1e3
+        six = "k_conv_bfd<2, 2, 2, 3" in name      # the bf16x6 forward of earlier rounds: six MFMAs per product
+        peak = BF16_MFMA_PEAK_TFLOPS / (6.0 if six else 3.0)
+        out["kernels"][role] = {"kernel": name.replace("void srk::", "").split("(")[0], "avg_us": round(us, 1),
+                                "algorithmic_bytes": int(alg), "algorithmic_operands": what, "counter_hbm_bytes": counter,
+                                "traffic_ratio": round(counter / alg, 3) if counter else None,
+                                "achieved_TFLOPs": round(flop / us / 1e6, 1),
+                                "mfmas_per_product": 6 if six else 3,
+                                "frac_of_mfma_peak": round(flop / us / 1e6 / peak, 4),
+                                "hbm_GBps": round(counter / us / 1e3, 1) if counter else None}
+    return out
+
+
 def cpu_baseline(batch_cap=8, lr_size=256):
     """Oracle ESPCN x4 forward on the host cores (bounded sample: B=8; per thread count 2 warm-ups + best of 3; the
     thread count that gives the best rate is the one reported — all hardware threads oversubscribe oneDNN here)."""
@@ -310,6 +356,9 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
         out["c3_vdsr_x4_train_patches_per_s"] = round(256 * k / sec, 1)
         out["c3_vdsr_ms_per_step"] = round(1e3 * sec / k, 3)
         out["c3_vdsr_bf16_pipe_frac"] = round(bf16_pipe_frac(C3_FWD, 2 * C3_FWD, sec / k / 256, C3_TAIL_FWD), 4)
+        rl = training_roofline("c3", 256 * 41 * 41, "VDSR body layer: conv3x3 64 -> 64 on 256 x 41 x 41 pixels, 31.7 GFLOP")
+        if rl:
+            out["c3_roofline"] = rl
 
     gb = 128
 
@@ -327,6 +376,10 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
         out["c4_edsr_x4_train_patches_per_s_global_batch_128"] = round(gb * k / sec, 1)
         out["c4_edsr_ms_per_step"] = round(1e3 * sec / k, 3)
         out["c4_edsr_bf16_pipe_frac"] = round(bf16_pipe_frac(C4_FWD, 2 * C4_FWD, sec / k / gb, C4_TAIL_FWD) / world, 4)
+        if not multi:
+            rl = training_roofline("c4", 128 * 32 * 32, "EDSR body layer: conv3x3 64 -> 64 on 128 x 32 x 32 pixels, 9.66 GFLOP")
+            if rl:
+                out["c4_roofline"] = rl
         out["c4_scaling"] = ("strong (global batch 128 sharded over %d rank(s); 6.07 MB of gradients per step as bucketed RCCL "
                              "all-reduces issued behind the grouped weight-gradient launches)" % world)
         if nocomm is not None:

@@ -615,6 +615,9 @@ static int bfd_launch_phase(MfmaConvParams P, const uint4* wq, const uint4* wq3,
         static const int cfg = getenv("SRK_BFD_F16_CFG") ? atoi(getenv("SRK_BFD_F16_CFG")) : 1;
         if (cfg == 1) return bfd_launch<2, 2, 2, NP, 1, true, 3>(B, BIG, s);
         if (cfg == 2) return bfd_launch<2, 2, 2, NP, 1, true, 4>(B, BIG, s);
+      } else if constexpr (NP == 2) {
+        static const int cfg3 = getenv("SRK_BFD_X3_CFG") ? atoi(getenv("SRK_BFD_X3_CFG")) : 0;   // experiment: the same block for bf16x3
+        if (cfg3 == 1) return bfd_launch<2, 2, 2, NP, 1, false, 3>(B, BIG, s);
       }
       return bfd_launch<4, 4, 1, NP, 1, F16>(B, BIG, s);
   }

@@ -371,7 +371,8 @@ static int r2_dbg() {
 // x4 train step (tools/shard_step.py, fused vs separate): 16 patches 1.36 vs 1.63 ms, 32: 2.27 vs 2.56, 64: 4.04 vs
 // 4.57, 128 (8 tiles per CU): 7.57 vs 7.08 -> the limit sits at 5 tiles per CU.
 bool conv_res2_supported(int N, int H, int W, int C) {
-  static const int max_tiles = getenv("SRK_RES2_MAX_TILES") ? atoi(getenv("SRK_RES2_MAX_TILES")) : 5 * kNumCU;
+  // (round 3: with the f16x3 forward the fused block also wins at 8 tiles per CU: EDSR batch 128 6.46 -> 6.33 ms)
+  static const int max_tiles = getenv("SRK_RES2_MAX_TILES") ? atoi(getenv("SRK_RES2_MAX_TILES")) : 10 * kNumCU;
   if (C != R2_C || N < 1 || H < 1 || W < 1) return false;
   if ((long)H * W * R2_C >= (1L << 29)) return false;  // 32-bit element offsets inside an image
   const long tiles = (long)N * ((H + R2_TS - 1) / R2_TS) * ((W + R2_TS - 1) / R2_TS);

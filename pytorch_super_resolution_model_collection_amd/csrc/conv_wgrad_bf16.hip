@@ -56,6 +56,10 @@ struct WgBfParams {
   int dbg;  // ablation (SRK_DBG): 2 skip the staging, 4 skip the K loop
   int dy_ps_r, dy_ps_C;  // dY handed over pixel-shuffled [N, YH*r, YW*r, Cout/r^2]: un-shuffled while staging
   int prefetch;          // SPEC: a tile's loads fit the stagers' register batch (WB_PIT x 512 items): load one tile ahead
+  int ring;              // SPEC + prefetch: X halo rows live in a ring of 2 * HH rows shared by vertically adjacent tiles
+                         // (a block walks a CONTIGUOUS range of tiles, rows fastest): a tile below its predecessor loads
+                         // only its TH new rows instead of all TH + KH - 1 (2-row tiles: the X read halves).  CS is then
+                         // the plane stride of the ring, and the dY tiles keep their two buffer sets behind it.
 };
 
 // Grouped launch: the weight gradients of up to WB_MAXGROUP convolutions that share ONE geometry (the 33 body convs
@@ -173,9 +177,23 @@ __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 
   constexpr int NTHR = SPEC ? 256 + WB_SST : 256;
   constexpr int NST = SPEC ? WB_SST : 256;  // staging threads (SPEC: 8 stager waves keep the staging rate of two 256-thread blocks)
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
-  __shared__ int oct_x[WB_MAXOCT], oct_y[WB_MAXOCT];
+  __shared__ int oct_x[WB_MAXOCT], oct_y[WB_MAXOCT], oct_r[WB_MAXOCT], oct_c[WB_MAXOCT];
   __shared__ float bred[NST][4];
   const size_t buf_shorts = (size_t)2 * CIB * P.CS + (size_t)2 * COB * P.DS;  // one buffer set: [2][CIB][CS] + [2][COB][DS]
+  // ring mode: [2][CIB][CS] (the ring, once) followed by two dY sets [2][COB][DS]
+  const bool ring = SPEC && P.ring;
+  const size_t x_shorts = (size_t)2 * CIB * P.CS, yset_shorts = (size_t)2 * COB * P.DS;
+  const int R2 = 2 * P.HH;
+  auto ys_of = [&](int bsel) -> unsigned short* {
+    return ring ? smem16 + x_shorts + (size_t)bsel * yset_shorts : smem16 + (size_t)bsel * buf_shorts + x_shorts;
+  };
+  auto xs_of = [&](int bsel) -> unsigned short* { return ring ? smem16 : smem16 + (size_t)bsel * buf_shorts; };
+  // ring base of the next tile: a tile that continues its predecessor's column moves on by TH rows, anything else
+  // (first tile of the block, top of a column) takes the other half of the ring
+  auto ring_next = [&](int prev, bool first) {
+    const int b = prev + (first ? P.HH : P.TH);
+    return b >= R2 ? b - R2 : b;
+  };
   const int tid0 = threadIdx.x, lane = tid0 & 63, wave = tid0 >> 6;
   const bool stager = !SPEC || wave >= 4;    // stages tiles
   const bool worker = !SPEC || wave < 4;     // runs the K loop, owns accumulators
@@ -216,15 +234,19 @@ __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 
       const int orow = o / P.TWo, oc = o - orow * P.TWo;
       oct_x[o] = orow * P.HWp + oc * 8;
       oct_y[o] = o * 8;
+      oct_r[o] = orow;
+      oct_c[o] = oc * 8;
     } else {  // K padding: multiply by the zero octet appended to every dY plane
       oct_x[o] = 0;
       oct_y[o] = P.TH * P.TW;
+      oct_r[o] = 0;
+      oct_c[o] = 0;
     }
   }
   for (int e = tid0; e < (SPEC ? 2 : 1) * 2 * COB * 4; e += NTHR) {  // zero octets (never overwritten by the staging)
     const int bsel = e / (2 * COB * 4), e2 = e - bsel * (2 * COB * 4);
     const int pc = e2 >> 2, w = e2 & 3;
-    unsigned short* ysb = smem16 + bsel * buf_shorts + (size_t)2 * CIB * P.CS;
+    unsigned short* ysb = ys_of(bsel);
     reinterpret_cast<unsigned*>(ysb + (size_t)pc * P.DS + P.TH * P.TW)[w] = 0u;
   }
 
@@ -357,11 +379,18 @@ __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 
   f32x4 pxa[SPEC ? WB_PIT : 1], pxb[SPEC ? WB_PIT : 1], pya[SPEC ? WB_PIT : 1], pyb[SPEC ? WB_PIT : 1];
   f32x4 pma[SPEC ? WB_PIT : 1], pmb[SPEC ? WB_PIT : 1];
   auto tile_origin = [&](int tile, int& n, int& r0, int& c0) {
-    int b = tile;
-    const int txi = b % P.tiles_x;
-    b /= P.tiles_x;
-    const int tyi = b % P.tiles_y;
-    n = b / P.tiles_y;
+    int b = tile, txi, tyi;
+    if (ring) {  // rows fastest: consecutive tiles are vertically adjacent
+      tyi = b % P.tiles_y;
+      b /= P.tiles_y;
+      txi = b % P.tiles_x;
+      n = b / P.tiles_x;
+    } else {
+      txi = b % P.tiles_x;
+      b /= P.tiles_x;
+      tyi = b % P.tiles_y;
+      n = b / P.tiles_y;
+    }
     r0 = tyi * P.TH;
     c0 = txi * P.TW;
   };
@@ -386,7 +415,9 @@ __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 
   // (rows above / below the image fall outside it and read as zero, columns left / right get an out-of-range offset),
   // so there is no per-load branch either.  The staging waves are bound by their VALU issue slots (2.1 us per tile
   // with the offsets recomputed per tile: magic divisions, 32-bit multiplies and exec-mask branches around each load).
-  int x_rel[SPEC ? WB_PIT : 1], x_dst[SPEC ? WB_PIT : 1], x_hx[SPEC ? WB_PIT : 1];
+  int x_rel[SPEC ? WB_PIT : 1], x_dst[SPEC ? WB_PIT : 1], x_hx[SPEC ? WB_PIT : 1], x_hy[SPEC ? WB_PIT : 1];
+  int x_q = 0;                         // ring: LDS offset of the thread's channel group
+  int st_base[2] = {0, 0}, st_cont[2] = {0, 0}, st_prev = P.HH;   // ring: base / "continues its column" of the tiles in flight
   int y_rel[SPEC ? WB_PIT : 1], y_dst[SPEC ? WB_PIT : 1], y_c[SPEC ? WB_PIT : 1];
   unsigned y_srow = 0, y_scol = 0;
   if constexpr (SPEC) {
@@ -404,7 +435,9 @@ __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 
           x_rel[k] = ((hy * P.XW + hx) * P.Cin + ch) * 4;
           x_dst[k] = act ? (q * 4) * P.CS + hy * P.HWp + hx : -1;
           x_hx[k] = hx;
+          x_hy[k] = hy;
         }
+        x_q = (q * 4) * P.CS;
       }
       {
         constexpr int QN = COB / 4, PSTEP = NST / QN;
@@ -424,11 +457,19 @@ __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 
       }
     }
   }
-  auto issue = [&](int tile) {
+  auto issue = [&](int tile, int j) {
     if constexpr (SPEC) {
       int n, r0, c0;
       tile_origin(tile, n, r0, c0);
       constexpr unsigned OOB = 0x80000000u;
+      int skip_rows = 0;   // ring: halo rows [0, skip_rows) are already in LDS (the predecessor's last rows)
+      if (ring) {
+        const bool first = j == 0 || (tile % P.tiles_y) == 0;
+        st_prev = ring_next(st_prev, first);
+        st_base[j & 1] = st_prev;
+        st_cont[j & 1] = first ? 0 : 1;
+        skip_rows = first ? 0 : P.HH - P.TH;
+      }
       {
         const size_t img = (size_t)P.XH * P.XW * P.Cin;
         const __amdgpu_buffer_rsrc_t rx = wb_rsrc(Lx + (size_t)n * img, (unsigned)(img * 4));
@@ -439,7 +480,7 @@ __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 
         for (int k = 0; k < WB_PIT; ++k) {
           const unsigned o = (unsigned)(obase + x_rel[k]);
           const int ix = bx0 + x_hx[k];
-          const bool act = x_dst[k] >= 0;
+          const bool act = x_dst[k] >= 0 && x_hy[k] >= skip_rows;
           pxa[k] = wb_bload(rx, act && (unsigned)ix < (unsigned)P.XW ? o : OOB);
           pxb[k] = wb_bload(rx, act && (unsigned)(ix + 1) < (unsigned)P.XW ? o + pstride : OOB);
         }
@@ -468,14 +509,17 @@ __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 
   };
   auto commit = [&](int bsel) {
     if constexpr (SPEC) {
-      unsigned short* xs = smem16 + bsel * buf_shorts;
-      unsigned short* ys = xs + (size_t)2 * CIB * P.CS;
+      unsigned short* xs = xs_of(bsel);
+      unsigned short* ys = ys_of(bsel);
+      const int rbase = st_base[bsel], skip_rows = (ring && st_cont[bsel]) ? P.HH - P.TH : 0;
 #pragma unroll
       for (int k = 0; k < WB_PIT; ++k) {
-        if (x_dst[k] >= 0) {
+        if (x_dst[k] >= 0 && x_hy[k] >= skip_rows) {
           unsigned hi[4], lo[4];
           wb_split_pair(pxa[k], pxb[k], hi, lo);
-          unsigned short* dst = xs + x_dst[k];
+          int slot = rbase + x_hy[k];
+          slot = slot >= R2 ? slot - R2 : slot;
+          unsigned short* dst = xs + (ring ? x_q + slot * P.HWp + x_hx[k] : x_dst[k]);
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             *reinterpret_cast<unsigned*>(dst + (size_t)c * P.CS) = hi[c];
@@ -508,15 +552,16 @@ __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 
     }
   };
   // ---- K loop of the tile in buffer set `bsel` (4 working waves)
-  auto kloop = [&](int bsel) {
-    const unsigned short* xs = smem16 + bsel * buf_shorts;
-    const unsigned short* ys = xs + (size_t)2 * CIB * P.CS;
+  auto kloop = [&](int bsel, int rbase) {
+    const unsigned short* xs = xs_of(bsel);
+    const unsigned short* ys = ys_of(bsel);
     const unsigned short* xa_h = xs + (size_t)(cit * 16 + i) * P.CS;
     const unsigned short* xa_l = xa_h + (size_t)CIB * P.CS;
     const unsigned short* yb_h = ys + (size_t)(cow * NTW * 16 + i) * P.DS;
     const unsigned short* yb_l = yb_h + (size_t)COB * P.DS;
     for (int ks = 0; ks < ((P.dbg & 4) ? 0 : P.nks); ++ks) {
       const int ox = oct_x[ks * 4 + kq], oy = oct_y[ks * 4 + kq];
+      const int orw = ring ? rbase + oct_r[ks * 4 + kq] : 0, ocl = ring ? oct_c[ks * 4 + kq] : 0;
       uint4 bh[NTW], bl[NTW];
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
@@ -526,8 +571,14 @@ __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         if (u < P.KH) {
-          const unsigned short* ph = xa_h + ox + u * P.HWp;
-          const unsigned short* pl = xa_l + ox + u * P.HWp;
+          int xo = ox + u * P.HWp;
+          if (ring) {  // halo row orow + u of the tile sits in ring slot (base + orow + u) mod 2 HH
+            int slot = orw + u;
+            slot = slot >= R2 ? slot - R2 : slot;
+            xo = slot * P.HWp + ocl;
+          }
+          const unsigned short* ph = xa_h + xo;
+          const unsigned short* pl = xa_l + xo;
           const uint4 qh = *reinterpret_cast<const uint4*>(ph);
           const uint4 ql = *reinterpret_cast<const uint4*>(pl);
           const unsigned eh = *reinterpret_cast<const unsigned*>(ph + 8);
@@ -566,28 +617,35 @@ __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 
       __syncthreads();  // previous tile fully consumed (tables / zero octets visible on the first pass)
       stage(tile, 0);
       __syncthreads();
-      kloop(0);
+      kloop(0, 0);
     }
   } else {
-    const int ntb = (bx < P.ntiles) ? (P.ntiles - bx + P.G - 1) / P.G : 0;
+    // tiles of this block: every G-th one, or (ring) a contiguous range in rows-fastest order
+    const int per = (P.ntiles + P.G - 1) / P.G;
+    const int first_tile = ring ? bx * per : bx, tstep = ring ? 1 : P.G;
+    int ntb = (bx < P.ntiles) ? (P.ntiles - bx + P.G - 1) / P.G : 0;
+    if (ring) {
+      ntb = P.ntiles - first_tile;
+      ntb = ntb < 0 ? 0 : (ntb > per ? per : ntb);
+    }
     __syncthreads();  // tables / zero octets visible
     // Two loops, one per role, with the same barriers (1 + ntb): the stagers' prefetch registers and the workers'
     // accumulators are never live in the same wave.
     if (stager) {
       if (P.prefetch && !(P.dbg & 2)) {
         if (ntb > 0) {
-          issue(bx);
+          issue(first_tile, 0);
           commit(0);
-          if (ntb > 1) issue(bx + P.G);
+          if (ntb > 1) issue(first_tile + tstep, 1);
         }
         __syncthreads();
         for (int it = 0; it < ntb; ++it) {
           if (it + 1 < ntb) commit((it + 1) & 1);        // tile it+1: its loads were issued an iteration ago
-          if (it + 2 < ntb) issue(bx + (it + 2) * P.G);  // tile it+2: lands under the K loop of tile it+1
+          if (it + 2 < ntb) issue(first_tile + (it + 2) * tstep, it + 2);  // tile it+2: lands under the K loop of tile it+1
           __syncthreads();
         }
       } else {
-        if (ntb > 0) stage(bx, 0);
+        if (ntb > 0) stage(bx, 0);     // (no ring without the prefetch path: the host never sets both)
         __syncthreads();
         for (int it = 0; it < ntb; ++it) {
           if (it + 1 < ntb) stage(bx + (it + 1) * P.G, (it + 1) & 1);
@@ -596,8 +654,10 @@ __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 
       }
     } else {
       __syncthreads();
+      int wprev = P.HH;
       for (int it = 0; it < ntb; ++it) {
-        kloop(it & 1);
+        if (ring) wprev = ring_next(wprev, it == 0 || ((first_tile + it) % P.tiles_y) == 0);
+        kloop(it & 1, wprev);
         __syncthreads();
       }
     }
@@ -739,6 +799,16 @@ static int wb_prefetch_ok(const WbPlan& pl, const srk_conv_desc& d) {
   return x_items <= (long)WB_PIT * WB_SST && y_items <= (long)WB_PIT * WB_SST && ximg < (1L << 31) && yimg < (1L << 31);
 }
 
+// Ring mode of the wave-specialised kernel (WgBfParams.ring): plane stride of the 2 * HH-row ring and the LDS it needs
+// (ring + two dY buffer sets); 0 when it does not apply.  SRK_WG_RING=0: off.
+static size_t wb_ring_setup(const WbPlan& pl, bool spec, int prefetch, int& cs_ring) {
+  static const int ring_env = getenv("SRK_WG_RING") ? atoi(getenv("SRK_WG_RING")) : 1;
+  if (!ring_env || !spec || !prefetch) return 0;
+  cs_ring = round_8odd(2 * pl.HH * pl.HWp);
+  const size_t bytes = ((size_t)2 * pl.CIB * cs_ring + (size_t)2 * 2 * pl.COB * pl.DS) * 2;
+  return bytes + 8 * 1024 <= 160 * 1024 ? bytes : 0;
+}
+
 bool conv_wgrad_bf_supported(const srk_conv_desc& d) { return wb_plan(d).ok; }
 
 size_t conv_wgrad_bf_ws(const srk_conv_desc& d) {
@@ -873,6 +943,16 @@ int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const
   }
   P.G = G;
   dim3 grid(G, pl.gy, pl.gz);
+  size_t lds_half = pl.lds;   // (the specialised launch asks for 2 x this)
+  {
+    int cs_ring = 0;
+    const size_t ring_bytes = wb_ring_setup(pl, spec, P.prefetch, cs_ring);
+    if (ring_bytes) {
+      P.ring = 1;
+      P.CS = cs_ring;
+      lds_half = (ring_bytes + 1) / 2;
+    }
+  }
   {
     static int dbg = -1;
     if (dbg < 0) {
@@ -881,13 +961,14 @@ int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const
     }
     P.dbg = dbg;
     if (dbg & 32)
-      fprintf(stderr, "[srk] k_wgrad_bf cfg %d%s: tile %d x %d (%d K steps), %d tiles over %d x %d x %d blocks, lds %zu B\n",
-              pl.cfg, spec ? " (wave-specialised)" : "", pl.TH, pl.TW, pl.nks, pl.ntiles, G, pl.gy, pl.gz, spec ? 2 * pl.lds : pl.lds);
+      fprintf(stderr, "[srk] k_wgrad_bf cfg %d%s%s: tile %d x %d (%d K steps), %d tiles over %d x %d x %d blocks, lds %zu B\n",
+              pl.cfg, spec ? " (wave-specialised)" : "", P.ring ? " (X ring)" : "", pl.TH, pl.TW, pl.nks, pl.ntiles, G, pl.gy,
+              pl.gz, spec ? 2 * lds_half : pl.lds);
   }
   switch (pl.cfg) {
-    case 0: wb_launch<2, 2, 2>(P, grid, pl.lds, spec, s); break;
-    case 1: wb_launch<4, 1, 2>(P, grid, pl.lds, spec, s); break;
-    default: wb_launch<4, 1, 1>(P, grid, pl.lds, spec, s); break;
+    case 0: wb_launch<2, 2, 2>(P, grid, lds_half, spec, s); break;
+    case 1: wb_launch<4, 1, 2>(P, grid, lds_half, spec, s); break;
+    default: wb_launch<4, 1, 1>(P, grid, lds_half, spec, s); break;
   }
   int rc = check_launch("conv_wgrad_bf");
   if (rc) return rc;
@@ -991,10 +1072,20 @@ int conv_wgrad_bf_grouped(const srk_conv_desc& d, int n, const float* const* xs,
               pl.cfg, spec ? " (wave-specialised)" : "", n, G, pl.TH, pl.TW, pl.ntiles, n * G, pl.gy, pl.gz);
   }
   dim3 grid(n * G, pl.gy, pl.gz);
+  size_t lds_half = pl.lds;
+  {
+    int cs_ring = 0;
+    const size_t ring_bytes = wb_ring_setup(pl, spec, P.prefetch, cs_ring);
+    if (ring_bytes) {
+      P.ring = 1;
+      P.CS = cs_ring;
+      lds_half = (ring_bytes + 1) / 2;
+    }
+  }
   switch (pl.cfg) {
-    case 0: wb_launch_grouped<2, 2, 2>(P, GR, grid, pl.lds, spec, s); break;
-    case 1: wb_launch_grouped<4, 1, 2>(P, GR, grid, pl.lds, spec, s); break;
-    default: wb_launch_grouped<4, 1, 1>(P, GR, grid, pl.lds, spec, s); break;
+    case 0: wb_launch_grouped<2, 2, 2>(P, GR, grid, lds_half, spec, s); break;
+    case 1: wb_launch_grouped<4, 1, 2>(P, GR, grid, lds_half, spec, s); break;
+    default: wb_launch_grouped<4, 1, 1>(P, GR, grid, lds_half, spec, s); break;
   }
   int rc = check_launch("conv_wgrad_bf_grouped");
   if (rc) return rc;

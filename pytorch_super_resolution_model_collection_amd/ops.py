@@ -855,7 +855,12 @@ class _Fork(torch.autograd.Function):
 
 
 def fork(x):
-    return _Fork.apply(x)
+    a, b = _Fork.apply(x)
+    t = getattr(x, "_srk_amax", None)      # the views carry the running maximum of the tensor they alias
+    if t is not None and t[1] == x._version and t[2] == _AMAX_EPOCH[0]:
+        _tag_amax(a, t[0])
+        _tag_amax(b, t[0])
+    return a, b
 
 
 # ------------------------------------------------------------------------------------------------
