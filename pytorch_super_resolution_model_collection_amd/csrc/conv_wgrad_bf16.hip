@@ -170,7 +170,10 @@ __device__ __forceinline__ f32x4 wb_load4(const float* __restrict__ src, const f
 // (global loads, masking, bf16 split, transposed stores) WHILE waves 0-3 run the K loop of tile t; one barrier per tile.
 // The per-tile kernel's two phases are about equally long and co-resident blocks run them in lockstep; here they
 // overlap by construction, and one block per CU halves the number of partial slabs.
-template <int CIT, int COW, int NTW, bool SPEC, bool GRP>
+// K33: 3x3 kernels (every body layer) get a K loop without the runtime tap tests: the fragment reads of a whole K step are
+// issued together and the 27 * NTW MFMAs follow without control flow in between (the generic loop reads each row shift's
+// fragments right in front of its MFMAs, behind a branch: two exposed LDS round trips per 18 MFMAs).
+template <int CIT, int COW, int NTW, bool SPEC, bool GRP, bool K33 = false>
 __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 256 : 2) void k_wgrad_bf(WgBfParams P,
                                                                              typename WgGroupArg<GRP>::type GR) {
   constexpr int CIB = CIT * 16, COB = COW * NTW * 16;
@@ -559,6 +562,59 @@ __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 
     const unsigned short* xa_l = xa_h + (size_t)CIB * P.CS;
     const unsigned short* yb_h = ys + (size_t)(cow * NTW * 16 + i) * P.DS;
     const unsigned short* yb_l = yb_h + (size_t)COB * P.DS;
+    if constexpr (K33) {
+      for (int ks = 0; ks < ((P.dbg & 4) ? 0 : P.nks); ++ks) {
+        const int ox = oct_x[ks * 4 + kq], oy = oct_y[ks * 4 + kq];
+        const int orw = ring ? rbase + oct_r[ks * 4 + kq] : 0, ocl = ring ? oct_c[ks * 4 + kq] : 0;
+        uint4 bh[NTW], bl[NTW], qh[3], ql[3];
+        unsigned eh[3], el[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          int xo = ox + u * P.HWp;
+          if (ring) {
+            int slot = orw + u;
+            slot = slot >= R2 ? slot - R2 : slot;
+            xo = slot * P.HWp + ocl;
+          }
+          qh[u] = *reinterpret_cast<const uint4*>(xa_h + xo);
+          ql[u] = *reinterpret_cast<const uint4*>(xa_l + xo);
+          eh[u] = *reinterpret_cast<const unsigned*>(xa_h + xo + 8);
+          el[u] = *reinterpret_cast<const unsigned*>(xa_l + xo + 8);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          bh[nt] = *reinterpret_cast<const uint4*>(yb_h + (size_t)nt * 16 * P.DS + oy);
+          bl[nt] = *reinterpret_cast<const uint4*>(yb_l + (size_t)nt * 16 * P.DS + oy);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          // the three column shifts of this row, then pass-major over its 3 * NTW accumulators: two MFMAs on one
+          // accumulator are 3 * NTW issues apart (back to back they wait for each other's result)
+          uint4 ah[3], al[3];
+          ah[0] = qh[u];
+          al[0] = ql[u];
+          ah[1] = make_uint4(__builtin_amdgcn_alignbit(qh[u].y, qh[u].x, 16), __builtin_amdgcn_alignbit(qh[u].z, qh[u].y, 16),
+                             __builtin_amdgcn_alignbit(qh[u].w, qh[u].z, 16), __builtin_amdgcn_alignbit(eh[u], qh[u].w, 16));
+          al[1] = make_uint4(__builtin_amdgcn_alignbit(ql[u].y, ql[u].x, 16), __builtin_amdgcn_alignbit(ql[u].z, ql[u].y, 16),
+                             __builtin_amdgcn_alignbit(ql[u].w, ql[u].z, 16), __builtin_amdgcn_alignbit(el[u], ql[u].w, 16));
+          ah[2] = make_uint4(qh[u].y, qh[u].z, qh[u].w, eh[u]);
+          al[2] = make_uint4(ql[u].y, ql[u].z, ql[u].w, el[u]);
+#pragma unroll
+          for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[u][v][nt] = wb_mfma(al[v], bh[nt], acc[u][v][nt]);
+#pragma unroll
+          for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[u][v][nt] = wb_mfma(ah[v], bl[nt], acc[u][v][nt]);
+#pragma unroll
+          for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[u][v][nt] = wb_mfma(ah[v], bh[nt], acc[u][v][nt]);
+        }
+      }
+      return;
+    }
     for (int ks = 0; ks < ((P.dbg & 4) ? 0 : P.nks); ++ks) {
       const int ox = oct_x[ks * 4 + kq], oy = oct_y[ks * 4 + kq];
       const int orw = ring ? rbase + oct_r[ks * 4 + kq] : 0, ocl = ring ? oct_c[ks * 4 + kq] : 0;
@@ -817,8 +873,19 @@ size_t conv_wgrad_bf_ws(const srk_conv_desc& d) {
   return (size_t)pl.G * d.KH * d.KW * d.Cin * d.Cout * sizeof(float) + conv_bias_grad_ws(d);
 }
 
+static bool wb_k33(const WgBfParams& P) {
+  static const int env = getenv("SRK_WG_K33") ? atoi(getenv("SRK_WG_K33")) : 1;
+  return env && P.KH == 3 && P.KW == 3;
+}
+
 template <int CIT, int COW, int NTW>
 static void wb_launch(const WgBfParams& P, dim3 grid, size_t lds, bool spec, hipStream_t s) {
+  if (spec && wb_k33(P)) {
+    static LdsLimit lim3;
+    lim3.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, true, false, true>), 2 * lds);
+    hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, true, false, true>), grid, dim3(256 + WB_SST), 2 * lds, s, P, WgNoGroup{0});
+    return;
+  }
   if (spec) {
     static LdsLimit lim2;
     lim2.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, true, false>), 2 * lds);
@@ -832,6 +899,12 @@ static void wb_launch(const WgBfParams& P, dim3 grid, size_t lds, bool spec, hip
 
 template <int CIT, int COW, int NTW>
 static void wb_launch_grouped(const WgBfParams& P, const WgGroup& GR, dim3 grid, size_t lds, bool spec, hipStream_t s) {
+  if (spec && wb_k33(P)) {
+    static LdsLimit lim3;
+    lim3.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, true, true, true>), 2 * lds);
+    hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, true, true, true>), grid, dim3(256 + WB_SST), 2 * lds, s, P, GR);
+    return;
+  }
   if (spec) {
     static LdsLimit lim2;
     lim2.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, true, true>), 2 * lds);

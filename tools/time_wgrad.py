@@ -11,6 +11,7 @@ SHAPES = {"edsr128": (128, 64, 32, 32, 64, 3, 1), "vdsr": (256, 64, 41, 41, 64, 
 dev = torch.device("cuda:0")
 for name in (sys.argv[1:] or list(SHAPES)):
     N, cin, H, W, cout, k, pad = SHAPES[name]
+    torch.manual_seed(3)
     x = torch.randn(N, cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
     dy = torch.randn(N, cout, H, W, device=dev).contiguous(memory_format=torch.channels_last)
     dw = torch.zeros(cout, cin, k, k, device=dev); db = torch.zeros(cout, device=dev)
