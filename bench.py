@@ -152,7 +152,7 @@ def pmc_traffic(kernel_label, batch, lr_size):
     return None
 
 
-def training_roofline(tag, px, layer_px_note):
+def training_roofline(tag, px, layer_px_note, layers_per_step=1, steps=5):
     """extra.<tag>_roofline: the three kernels that carry a 64 -> 64 3x3 body layer of a training config (forward, data
     gradient, weight gradient) from the COMMITTED rocprofv3 passes of this round (profiles/*_<tag>_kernel_stats.csv and
     *_<tag>_pmc_traffic.json, tools/profile_round.sh: the counters cannot be collected from inside this process):
@@ -172,11 +172,17 @@ def training_roofline(tag, px, layer_px_note):
         rows = list(csv.DictReader(fh))
     t = 4.0 * 64 * px                     # one 64-channel fp32 tensor of the layer
     flop = 2.0 * px * 64 * 64 * 9
-    roles = (("forward", ("k_conv_bfd<2, 2, 2, 2", "k_conv_bfd<2, 2, 2, 3", "k_conv_bfd<4, 4, 1, 2"), 2 * t, "x, y"),
-             ("data_gradient", ("k_conv_bf3<4, 4, true>",), 3 * t, "dy, activation mask, dx"),
-             ("weight_gradient", ("k_wgrad_bf<2, 2, 2, true",), 3 * t, "x, dy, activation mask"))
+    # (role, kernel-name keys, algorithmic bytes per LAYER, operands, layers' worth of FLOPs per launch or None = from calls)
+    roles = [("forward", ("k_conv_bfd<2, 2, 2, 2", "k_conv_bfd<2, 2, 2, 3", "k_conv_bfd<4, 4, 1, 2"), 2 * t, "x, y", 1.0),
+             ("data_gradient", ("k_conv_bf3<4, 4, true>",), 3 * t, "dy, activation mask, dx", 1.0),
+             ("weight_gradient", ("k_wgrad_bf<2, 2, 2, true",), 3 * t, "x, dy, activation mask", None),
+             # residual blocks fused per tile (conv -> ReLU -> conv -> + skip in one launch): useful work of two layers
+             ("fused_block_forward", ("k_res2<2, false", "k_res2<3, false"), 3 * t, "x, intermediate, y", 2.0),
+             ("fused_block_data_gradient", ("k_res2<2, true",), 4 * t, "dy, saved intermediate, its gradient, dx", 2.0)]
+    if any("k_res2<" in r["Name"] for r in rows):   # body layers run fused per block: no stand-alone forward / data gradient
+        roles = [r for r in roles if r[0] not in ("forward", "data_gradient")]
     out = {"source": [os.path.basename(stats[-1]), os.path.basename(traffic[-1])], "layer": layer_px_note, "kernels": {}}
-    for role, keys, alg, what in roles:
+    for role, keys, alg, what, nlay in roles:
         best = None
         for r in rows:
             if any(k in r["Name"] for k in keys) and (best is None or float(r["TotalDurationNs"]) > float(best["TotalDurationNs"])):
@@ -186,14 +192,18 @@ def training_roofline(tag, px, layer_px_note):
         name = best["Name"]
         counter = next((v.get("hbm_bytes") for k, v in hbm.items() if k == name), None)
         us = float(best["AverageNs"]) / 1e3
+        if nlay is None:   # weight gradients are launched per layer or grouped over several layers of one geometry
+            nlay = max(1.0, round(layers_per_step * steps / float(best["Calls"]))) if "true, true" in name else 1.0
+        lay_alg, lay_flop = alg * (nlay if role == "weight_gradient" else 1.0), flop * nlay
         six = "k_conv_bfd<2, 2, 2, 3" in name      # the bf16x6 forward of earlier rounds: six MFMAs per product
         peak = BF16_MFMA_PEAK_TFLOPS / (6.0 if six else 3.0)
         out["kernels"][role] = {"kernel": name.replace("void srk::", "").split("(")[0], "avg_us": round(us, 1),
-                                "algorithmic_bytes": int(alg), "algorithmic_operands": what, "counter_hbm_bytes": counter,
-                                "traffic_ratio": round(counter / alg, 3) if counter else None,
-                                "achieved_TFLOPs": round(flop / us / 1e6, 1),
+                                "layers_per_launch": nlay,
+                                "algorithmic_bytes": int(lay_alg), "algorithmic_operands": what, "counter_hbm_bytes": counter,
+                                "traffic_ratio": round(counter / lay_alg, 3) if counter else None,
+                                "achieved_TFLOPs": round(lay_flop / us / 1e6, 1),
                                 "mfmas_per_product": 6 if six else 3,
-                                "frac_of_mfma_peak": round(flop / us / 1e6 / peak, 4),
+                                "frac_of_mfma_peak": round(lay_flop / us / 1e6 / peak, 4),
                                 "hbm_GBps": round(counter / us / 1e3, 1) if counter else None}
     return out
 
@@ -356,7 +366,7 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
         out["c3_vdsr_x4_train_patches_per_s"] = round(256 * k / sec, 1)
         out["c3_vdsr_ms_per_step"] = round(1e3 * sec / k, 3)
         out["c3_vdsr_bf16_pipe_frac"] = round(bf16_pipe_frac(C3_FWD, 2 * C3_FWD, sec / k / 256, C3_TAIL_FWD), 4)
-        rl = training_roofline("c3", 256 * 41 * 41, "VDSR body layer: conv3x3 64 -> 64 on 256 x 41 x 41 pixels, 31.7 GFLOP")
+        rl = training_roofline("c3", 256 * 41 * 41, "VDSR body layer: conv3x3 64 -> 64 on 256 x 41 x 41 pixels, 31.7 GFLOP", 18)
         if rl:
             out["c3_roofline"] = rl
 
@@ -377,7 +387,7 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
         out["c4_edsr_ms_per_step"] = round(1e3 * sec / k, 3)
         out["c4_edsr_bf16_pipe_frac"] = round(bf16_pipe_frac(C4_FWD, 2 * C4_FWD, sec / k / gb, C4_TAIL_FWD) / world, 4)
         if not multi:
-            rl = training_roofline("c4", 128 * 32 * 32, "EDSR body layer: conv3x3 64 -> 64 on 128 x 32 x 32 pixels, 9.66 GFLOP")
+            rl = training_roofline("c4", 128 * 32 * 32, "EDSR body layer: conv3x3 64 -> 64 on 128 x 32 x 32 pixels, 9.66 GFLOP", 33)
             if rl:
                 out["c4_roofline"] = rl
         out["c4_scaling"] = ("strong (global batch 128 sharded over %d rank(s); 6.07 MB of gradients per step as bucketed RCCL "

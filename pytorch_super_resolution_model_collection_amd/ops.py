@@ -106,11 +106,11 @@ F16X3_MIN_PIXELS = int(os.environ.get("SRK_F16X3_MIN_PIXELS", str(256 * 2 * 256)
 
 def _f16x3_pays(d):
     """Where three MFMAs instead of six are worth the running-maximum bookkeeping: problems large enough to be bound by
-    the matrix work (conv_bfd.hip's large-block configurations: >= two 256-pixel tiles per CU), kernels with more than
-    nine taps, first layers (Cin <= 4: the alternative is the fp32 MFMA kernel).  The 64-pixel blocks of a small 3x3
+    the matrix work (conv_bfd.hip's large-block configurations: >= two 256-pixel tiles per CU; first layers of that size
+    leave the fp32 MFMA kernel for the row-packed one) and kernels with more than nine taps.  The 64-pixel blocks of a small 3x3
     problem are a latency chain -- measured on the SRGAN step (16 patches): 18.7 us with f16x3 against 19.1 us with
     bf16x6 per conv, and the maxima cost more than that."""
-    return (d.Cin <= 4 or d.KH * d.KW > 9 or F16X3_ALWAYS
+    return (d.KH * d.KW > 9 or F16X3_ALWAYS
             or d.N * d.OH * d.OW * ((d.Cout + 63) // 64) >= F16X3_MIN_PIXELS)
 
 
