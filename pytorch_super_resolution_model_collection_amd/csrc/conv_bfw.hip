@@ -418,6 +418,7 @@ static bool bfw_pick_tile(int maxpix, int PH, int PW, int KHv, int KWv, long cap
 // + two halo buffers within the LDS, every output group on the 16-byte store path, and a problem large enough to
 // keep one persistent block per CU busy for several tiles.  SRK_BFW: 0 never, 1 whenever applicable, unset = automatic.
 bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, const float* out, const float* mask_y) {
+  // (read per dispatch, ~0.1 us: the conv KAT variants of tests/test_ops_gpu.py switch it inside one process)
   const char* e = getenv("SRK_BFW");
   const int mode = e ? atoi(e) : 2;
   if (mode == 0 || mask_y || g.trans || g.stride != 1 || g.in_nchw || g.in_ps_r > 1) return false;

@@ -956,6 +956,51 @@ class _Loss(torch.autograd.Function):
         return out, None, None, None
 
 
+_CONSTS = {}
+
+
+def _const_scalar(value, device):
+    """A persistent 0-dim device tensor holding `value` (loss weights, label rows): no fill launch per step."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (float(value), idx)
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.full((), float(value), dtype=torch.float32, device=torch.device("cuda", idx))
+    return t
+
+
+def const_rows(value, rows, device):
+    """Persistent [rows, 1] label tensor (torch.ones(B, 1) / zeros(B, 1) of srgan.py:264-265 without a fill per step)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (float(value), int(rows), idx)
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.full((int(rows), 1), float(value), dtype=torch.float32, device=torch.device("cuda", idx))
+    return t
+
+
+class _LossSum(torch.autograd.Function):
+    """a * l1 + b * l2 of two scalar losses with srk_axpby (D_loss = real + fake, G_loss = mse + 1e-3 * GAN:
+    srgan.py:283,306); seeded by the unit seed, the backward hands out persistent constants -- no ATen arithmetic in
+    the captured step."""
+
+    @staticmethod
+    def forward(ctx, l1, l2, a, b):
+        ctx.ab = (float(a), float(b))
+        return _axpby(l1.reshape(1), l2.reshape(1), float(a), float(b)).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.ab
+        if g.data_ptr() == unit_seed(g.device).data_ptr():
+            return (g if a == 1.0 else _const_scalar(a, g.device)), (g if b == 1.0 else _const_scalar(b, g.device)), None, None
+        return (g if a == 1.0 else g * a), (g if b == 1.0 else g * b), None, None
+
+
+def loss_sum(l1, l2, a=1.0, b=1.0):
+    return _LossSum.apply(l1, l2, a, b)
+
+
 def mse_loss(pred, target):
     """nn.MSELoss() (srcnn.py:84-86,129; vdsr.py:145; srgan.py:205,300)."""
     return _Loss.apply(pred, target, _lib.LOSS_MSE, 0.0)

@@ -133,11 +133,12 @@ def srgan_step(G, D, g_opt, d_opt, g_dp=None, d_dp=None, feature_extractor=None,
 
     def step(lr_img, hr_img):
         b = lr_img.shape[0]
-        real = torch.ones(b, 1, device=lr_img.device)
-        fake = torch.zeros(b, 1, device=lr_img.device)
+        real = ops.const_rows(1.0, b, lr_img.device)     # persistent label rows and srk_axpby loss sums: the captured
+        fake = ops.const_rows(0.0, b, lr_img.device)     # step holds no ATen arithmetic node
         d_opt.zero_grad(repack=repack)
         recon_d = G(lr_img)      # (in grad mode either way: the same kernels and precision class as the reference path)
-        d_loss = ops.bce_loss(D(hr_img), real) + ops.bce_loss(D(recon_d.detach() if prune_dead_grads else recon_d), fake)
+        d_loss = ops.loss_sum(ops.bce_loss(D(hr_img), real),
+                              ops.bce_loss(D(recon_d.detach() if prune_dead_grads else recon_d), fake))
         del recon_d
         _backward(d_loss, d_dp)
         if d_dp is not None:
@@ -153,13 +154,13 @@ def srgan_step(G, D, g_opt, d_opt, g_dp=None, d_dp=None, feature_extractor=None,
                 freeze_d(False)
         else:
             gan_loss = ops.bce_loss(D(recon), real)
-        g_loss = ops.mse_loss(recon, hr_img) + 1e-3 * gan_loss
+        g_loss = ops.loss_sum(ops.mse_loss(recon, hr_img), gan_loss, 1.0, 1e-3)
         if feature_extractor is not None:
             with torch.no_grad():   # srgan.py:301-305 (the inputs are already normalised once, as in the reference)
                 real_feature = feature_extractor(utils.norm(hr_img, vgg=True))
                 fake_feature = feature_extractor(utils.norm(recon.detach(), vgg=True))
                 vgg_loss = ops.mse_loss(fake_feature, real_feature)
-            g_loss = g_loss + 6e-3 * vgg_loss
+            g_loss = ops.loss_sum(g_loss, vgg_loss, 1.0, 6e-3)
         _backward(g_loss, g_dp)
         if g_dp is not None:
             g_dp.allreduce_grads()
@@ -176,19 +177,19 @@ def srgan_segments(G, D, g_opt, d_opt, g_dp=None, d_dp=None, lazy_pack=False):
 
     def seg_d(lr_img, hr_img):
         b = lr_img.shape[0]
-        real = torch.ones(b, 1, device=lr_img.device)
-        fake = torch.zeros(b, 1, device=lr_img.device)
+        real = ops.const_rows(1.0, b, lr_img.device)
+        fake = ops.const_rows(0.0, b, lr_img.device)
         d_opt.zero_grad(repack=repack)
-        out["d"] = ops.bce_loss(D(hr_img), real) + ops.bce_loss(D(G(lr_img)), fake)
+        out["d"] = ops.loss_sum(ops.bce_loss(D(hr_img), real), ops.bce_loss(D(G(lr_img)), fake))
         _backward(out["d"], d_dp)
         return out["d"]
 
     def seg_g(lr_img, hr_img):
-        real = torch.ones(lr_img.shape[0], 1, device=lr_img.device)
+        real = ops.const_rows(1.0, lr_img.shape[0], lr_img.device)
         d_opt.step()
         g_opt.zero_grad(repack=repack)
         recon = G(lr_img)
-        out["g"] = ops.mse_loss(recon, hr_img) + 1e-3 * ops.bce_loss(D(recon), real)
+        out["g"] = ops.loss_sum(ops.mse_loss(recon, hr_img), ops.bce_loss(D(recon), real), 1.0, 1e-3)
         _backward(out["g"], g_dp)
         return out["g"]
 
