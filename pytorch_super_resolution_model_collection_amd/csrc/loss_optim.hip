@@ -64,6 +64,30 @@ __global__ __launch_bounds__(256) void k_loss_partial(int kind, const float* __r
   if (threadIdx.x == 0) partials[blockIdx.x] = tot;
 }
 
+// 16-byte form for dense, aligned tensors (pred, target and dpred in one layout): four elements per thread and pass
+typedef float loss_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_loss_partial4(int kind, const float* __restrict__ pred,
+                                                       const float* __restrict__ target, size_t total4, float eps,
+                                                       float gscale, float* __restrict__ dpred,
+                                                       double* __restrict__ partials) {
+  __shared__ double sm[4];
+  float acc = 0.f;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (size_t)gridDim.x * 256) {
+    const loss_f4 p = reinterpret_cast<const loss_f4*>(pred)[e], t = reinterpret_cast<const loss_f4*>(target)[e];
+    loss_f4 g;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v, gg;
+      loss_term(kind, p[k], t[k], eps, v, gg);
+      acc += v;
+      g[k] = gg * gscale;
+    }
+    if (dpred) reinterpret_cast<loss_f4*>(dpred)[e] = g;
+  }
+  const double tot = block_sum_256_d((double)acc, sm);
+  if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
 __global__ __launch_bounds__(256) void k_loss_final(const double* __restrict__ partials, int nparts, double inv_count,
                                                     float* __restrict__ loss) {
   __shared__ double sm[4];
@@ -210,8 +234,15 @@ extern "C" int srk_loss_forward_backward(int kind, const float* pred, const floa
              (target_strides[2] == sh || H == 1) && (target_strides[3] == sw || W == 1);
     sn = target_strides[0]; sc = target_strides[1]; sh = target_strides[2]; sw = target_strides[3];
   }
-  const unsigned nb = red_grid(total);
+  unsigned nb = red_grid(total);
   hipStream_t s = (hipStream_t)stream;
+  const bool vec = contig && (total & 3) == 0 && (((uintptr_t)pred | (uintptr_t)target | (uintptr_t)dpred) & 15) == 0;
+  if (vec) {   // (the summation order differs from the scalar kernel's: partials of 4-element groups)
+    size_t b = (total / 4 + 255) / 256;
+    nb = (unsigned)(b > kMaxPartials ? kMaxPartials : (b < 1 ? 1 : b));
+    hipLaunchKernelGGL(k_loss_partial4, dim3(nb), dim3(256), 0, s, kind, pred, target, total / 4, eps,
+                       grad_scale / (float)total, dpred, (double*)workspace);
+  } else
   hipLaunchKernelGGL(k_loss_partial, dim3(nb), dim3(256), 0, s, kind, pred, target, sn, sc, sh, sw, contig, C, H, W,
                      total, eps, grad_scale / (float)total, dpred, (double*)workspace);
   hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(256), 0, s, (const double*)workspace, (int)nb, 1.0 / (double)total,

@@ -33,6 +33,19 @@ def _no_gc_during_capture():
             gc.enable()
 
 
+def _static_buffers(example_inputs):
+    """Static input buffers of a captured step.  4-D image batches are kept channels_last: the copy of a new batch into
+    the buffer (one strided copy either way) then delivers the layout the first convolution reads, and the captured step
+    holds no layout kernel."""
+    out = []
+    for t in example_inputs:
+        if t.dim() == 4 and t.is_floating_point():
+            out.append(torch.empty_like(t, memory_format=torch.channels_last).copy_(t))
+        else:
+            out.append(torch.empty_like(t).copy_(t))
+    return out
+
+
 def _backward(loss, dp):
     """loss.backward() of the reference (edsr.py:154 ...).  Single GPU: the deferred weight gradients are launched
     (grouped) when the autograd engine finishes the pass.  Data parallel: they stay pending so that dp.exchange() can
@@ -289,7 +302,7 @@ class GraphedSegments(object):
     group computes.  Call with new batches (copied into the static buffers); returns what the last fn returned."""
 
     def __init__(self, segments, example_inputs, warmup=2, eager_step=None):
-        self.static = [torch.empty_like(t).copy_(t) for t in example_inputs]
+        self.static = _static_buffers(example_inputs)
         self.segments = segments
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -402,7 +415,7 @@ class GraphedStep(object):
             self.seg = GraphedSegments([(self._fwd_bwd_args, dp), (self._update_args, None)], example_inputs, warmup=warmup)
             self.static = self.seg.static
             return
-        self.static = [torch.empty_like(t).copy_(t) for t in example_inputs]
+        self.static = _static_buffers(example_inputs)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -481,7 +494,7 @@ class GraphedFn(object):
     def __init__(self, fn, example_inputs, warmup=3, flats=()):
         self.fn = fn
         self.flats = list(flats)   # FlatParams the step updates (their PackPlans are invalidated after every replay)
-        self.static = [torch.empty_like(t).copy_(t) for t in example_inputs]
+        self.static = _static_buffers(example_inputs)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
