@@ -52,6 +52,28 @@ def parse():
     return ap.parse_args()
 
 
+_JSON_FD = [None]
+
+
+def claim_stdout():
+    """stdout carries ONE JSON line and nothing else: RCCL prints a version banner through C stdio (which, with stdout a
+    pipe, would surface after the line, at exit), libraries may print more.  File descriptor 1 is pointed at stderr for
+    the whole run and the line is written to a private duplicate of the original stdout."""
+    if _JSON_FD[0] is None:
+        sys.stdout.flush()
+        _JSON_FD[0] = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_json(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD[0] is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD[0], line)
+
+
 def barrier_sync(world):
     torch.cuda.synchronize()
     if world > 1 or torch.distributed.is_initialized():
@@ -272,7 +294,7 @@ def extras_watchdog(result, extra, rank, seconds):
                                      "section running when the watchdog fired: %s (for %.0f s)"
                                      % (seconds, PROGRESS["section"], time.perf_counter() - PROGRESS["since"]))
             result["extra"] = dict(extra)
-            print(json.dumps(result), flush=True)
+            emit_json(result)
         sys.stdout.flush()
         os._exit(0)
 
@@ -515,6 +537,7 @@ def c2_other_precisions(pkg, net, x, steps, warmup, dev):
 
 def main():
     args = parse()
+    claim_stdout()
     import __graft_entry__
     if int(os.environ.get("LOCAL_RANK", "0")) == 0:
         __graft_entry__.build()
@@ -633,7 +656,7 @@ def main():
             result["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(lr_size=args.lr_size)
-        print(json.dumps(result))
+        emit_json(result)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
