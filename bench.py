@@ -37,6 +37,14 @@ ESPCN_BYTES_PER_IMG = 61.11e6  # per-layer compulsory activati
 ESPCN_FLOP_PER_IMG = 4.614e9
 
 
+DTYPE_NOTE = {
+    "mixed": "f32 storage/accumulate; fp32-faithful products on the fp16 matrix cores: operands scaled by exact powers of "
+             "two, split into two fp16 planes, 3 MFMAs per product (f16x3, ~3e-7 rms vs fp64, like fp32 MFMA)",
+    "bf16x6": "f32 storage/accumulate; fp32-faithful products (f16x3 / bf16x6 operand splits, ~3e-7 rms)",
+    "bf16x3": "f32 storage/accumulate; products by 3-term bf16 split on bf16 MFMA (bf16x3, ~5e-6 rel)",
+    "fp32": "f32"}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,11 +173,26 @@ def pmc_traffic(kernel_label, batch, lr_size):
         return None
     with open(files[-1]) as fh:
         kernels = json.load(fh).get("kernels", {})
-    want = kernel_label.split(" ")[0].replace(" ", "")      # "k_conv_bfw<2,9,2>" == "srk::k_conv_bfw<2, 9, 2>(...)"
-    for name, rec in kernels.items():
+    def targs(name):
+        """(kernel, leading integer template arguments, f16 flag).  The dispatcher's label carries the integers and an
+        "f16" marker; rocprofv3 prints every template argument (the f16 flag is the last one of these kernels)."""
         name = name.replace(" ", "")
-        i = name.find("::" + want)
-        if i >= 0 and rec.get("hbm_bytes"):
+        i = name.find("<")
+        if i < 0:
+            return name.split("(")[0].split("::")[-1], [], False
+        j = name.find(">", i)
+        base = name[:i].split("::")[-1].replace("void", "")
+        args = name[i + 1:j].split(",")
+        ints = []
+        for a in args:
+            if not a.lstrip("-").isdigit():
+                break
+            ints.append(a)
+        return base, ints, ("f16" in args) or (len(args) > len(ints) and args[-1] == "true")
+
+    want = targs(kernel_label.split(" ")[0])
+    for name, rec in kernels.items():
+        if rec.get("hbm_bytes") and targs(name) == want:
             return int(rec["hbm_bytes"])
     return None
 
@@ -511,22 +534,22 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
 
 
 def c2_other_precisions(pkg, net, x, steps, warmup, dev):
-    """The same c2 forward in the fp32-faithful arithmetics -- f16x3 (operands scaled by exact powers of two and split into
-    two fp16 planes, 3 MFMAs per product, ~1e-7 rel: what the 'bf16x6' mode runs wherever the fp16 kernels cover a layer),
-    bf16x6 (exact 3-way bf16 split, 6 MFMAs) and exact fp32 MFMA -- next to the headline's bf16x3 products (~5e-6 rel)."""
+    """The same c2 forward in the other arithmetics, next to the headline's fp32-faithful f16x3 products: bf16x3 (3-term
+    bf16 split, ~5e-6 rel: the fast option, the headline of rounds 1 and 2), bf16x6 (exact 3-way bf16 split, 6 MFMAs: the
+    fp32-faithful class before f16x3) and exact fp32 MFMA."""
     res = {}
     prev = pkg.ops.get_precision()
     prev_f16 = pkg.ops.F16X3
-    for key, mode, f16 in (("fp32_faithful_f16x3", "bf16x6", True), ("bf16x6", "bf16x6", False), ("fp32", "fp32", prev_f16)):
+    for key, mode, f16 in (("bf16x3", "bf16x3", prev_f16), ("bf16x6", "bf16x6", False), ("fp32", "fp32", prev_f16)):
         try:
             pkg.ops.set_precision(mode)
             pkg.ops.F16X3 = f16
             with torch.no_grad():
                 sec = time_steps(lambda: net(x), steps, warmup, 1, dev)
             res["c2_%s_images_per_s" % key] = round(x.shape[0] * steps / sec, 1)
-            if key == "fp32_faithful_f16x3":
+            if key == "bf16x3":
                 scale = (x.shape[-1] / 256.0) ** 2
-                res["c2_fp32_faithful_f16x3_hbm_roofline_frac"] = round(
+                res["c2_bf16x3_hbm_roofline_frac"] = round(
                     ESPCN_BYTES_PER_IMG * scale * x.shape[0] * steps / sec / 1e9 / HBM_PEAK_GBS, 4)
         except Exception as e:  # noqa: BLE001
             res["c2_%s_error" % key] = "%s: %s" % (type(e).__name__, str(e)[:200])
@@ -610,8 +633,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * sec / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 storage/accumulate; products by 3-term bf16 split on bf16 MFMA (bf16x3, ~5e-6 rel)" if bf3
-                     else "f32", "data": "synthetic",
+            "dtype": DTYPE_NOTE.get(pkg.ops.get_precision() if pkg.ops.F16X3 or pkg.ops.get_precision() != "mixed"
+                                    else "bf16x6", "f32"), "data": "synthetic",
             "config": {"workload": "c2: ESPCN x4 inference, %dx%d LR, batch %d per GPU, fp32, random-init N(0,0.02)"
                                    % (H, H, args.batch),
                        "parallelism": "replicas x%d (no collective)" % world},
@@ -619,8 +642,8 @@ def main():
                          "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
                          "traffic": pmc_traffic(names[dom], args.batch, H),
-                         "note": "achieved = algorithmic conv FLOPs / live HIP-event kernel time; peak = bf16 dense "
-                                 "MFMA peak / 3 (three bf16 MFMAs per fp32-equivalent product)" if bf3 else
+                         "note": "achieved = algorithmic conv FLOPs / live HIP-event kernel time; peak = dense 16-bit "
+                                 "MFMA peak / 3 (three fp16 / bf16 MFMAs per fp32-equivalent product)" if bf3 else
                                  "achieved = algorithmic conv FLOPs / live HIP-event kernel time; peak = fp32 MFMA",
                          "kernel_ms": round(layer_ms[dom], 4),
                          "layer_ms": [round(m, 4) for m in layer_ms], "layer_kernels": names,

@@ -21,7 +21,9 @@ CL = torch.channels_last
 #   train_fwd forward that will be differentiated
 #   bwd       data gradient
 # Modes:
-#   "mixed"  (default) infer = bf16x3, train_fwd = bf16x6 (exact 3-way operand split, 6 bf16 MFMAs per
+#   "mixed"  (default; round 3: infer = the fp32-faithful class too -- f16x3 costs ~10 % over bf16x3 on the c2 net, and a
+#            drop-in for an fp32 reference should not default to narrower products; "bf16x3" is the fast option)
+#            train_fwd = fp32-faithful class: f16x3 where it pays, else bf16x6 (exact 3-way operand split, 6 bf16 MFMAs per
 #            product: measured 3.5e-7 rms / 8.8e-7 max error vs fp64 — tighter than the fp32 MFMA
 #            kernel's 4.3e-7 / 1.2e-6 — at 1.5-2x its speed; shapes it does not cover run exact fp32),
 #            bwd = bf16x3.  The training forward stays fp32-faithful so that ReLU / LeakyReLU masks are
@@ -37,7 +39,7 @@ CL = torch.channels_last
 #   "bf16x3" everything on the 3-term bf16 split (fastest; forward error ~1e-5, gradients subject to
 #            the mask-flip sensitivity above).
 #   "fp32"   everything exact fp32 (summation-order-level agreement with ATen/oneDNN).
-_MODES = {"mixed": {"infer": ALGO_AUTO, "train_fwd": _lib.ALGO_MFMA_BF16X6, "bwd": ALGO_AUTO,
+_MODES = {"mixed": {"infer": _lib.ALGO_MFMA_BF16X6, "train_fwd": _lib.ALGO_MFMA_BF16X6, "bwd": ALGO_AUTO,
                     "train_fwd_tail": ALGO_AUTO},
           # fp32-faithful products everywhere they exist (inference included): what "mixed" costs when bf16x3's ~5e-6 is
           # not acceptable for the forward either
