@@ -32,7 +32,8 @@ int conv_tapn_gather(const GatherConv& g, const float* in, const float* wp, floa
                      hipStream_t s);
 // conv_bfw.hip
 bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, const float* out, const float* mask_y);
-int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s, bool f16);
+int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, const float* mask_y,
+                    float mask_slope, hipStream_t s, bool f16);
 bool conv_bf3_rows_f16_supported(const GatherConv& g, const Epi& ep, const float* out);
 int conv_bf3_rows_f16_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s);
 bool conv_tapk_gather_supported(const GatherConv& g, const Epi& ep, const float* out, const float* mask_y);
@@ -130,7 +131,7 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
     }
     if (conv_bf3_rows_f16_supported(g, ep, out)) return conv_bf3_rows_f16_gather(g, in, wp, out, ep, s);
     if (conv_bfw_applicable(g, ep, in, out, nullptr)) {  // wave-specialised persistent kernel (ESPCN-size layers)
-      const int rc = conv_bfw_gather(g, in, wp, out, ep, s, true);
+      const int rc = conv_bfw_gather(g, in, wp, out, ep, nullptr, 0.f, s, true);
       if (rc >= 0) return rc;
     }
     return conv_bfd_gather(g, in, wp, out, ep, nullptr, 0.f, 4, s);
@@ -172,7 +173,7 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
     if (bfd_ok && (direct_w == 1 || (direct_w == 2 && conv_bfd_small_problem(g))))
       return conv_bfd_gather(g, in, wp, out, ep, mask_y, mask_slope, 2, s);
     if (conv_bfw_applicable(g, ep, in, out, mask_y)) {  // wave-specialised persistent kernel (ESPCN-size layers)
-      const int rc = conv_bfw_gather(g, in, wp, out, ep, s, false);
+      const int rc = conv_bfw_gather(g, in, wp, out, ep, mask_y, mask_slope, s, false);
       if (rc >= 0) return rc;
     }
     return conv_bf3_gather(g, in, wp, out, ep, mask_y, mask_slope, s);

@@ -79,25 +79,31 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
-// one atomic per wave, and only while the wave's maximum still raises its slot
-__device__ __forceinline__ void amax_commit(float* __restrict__ slots, float lane_max, int slot_hint) {
+// Committing a maximum: the slot is read EARLY (amax_peek, before the stores of the epilogue, so that the tail of a
+// short-lived block does not wait for a memory round trip that nothing overlaps) and the atomic is issued only when the
+// maximum still raises that (possibly stale, never too high) value.  Whole bookkeeping on the c2 first layer
+// (15876 blocks): ~10 us of 320 (tools/time_yamax.py).
+__device__ __forceinline__ float amax_peek(const float* __restrict__ slots, int slot_hint) {
+  // agent-scope atomic load: served by L2, where the atomics land (a plain or nontemporal load may hit a stale line
+  // of the CU's vector L1 for the whole kernel, and then every wave issues its atomic)
+  return slots ? __hip_atomic_load(slots + (slot_hint & 15) * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+}
+// one atomic per wave
+__device__ __forceinline__ void amax_commit(float* __restrict__ slots, float lane_max, int slot_hint, float peeked) {
   const float m = wave_max(lane_max);
-  if ((threadIdx.x & 63) == 0) {
-    float* p = slots + (slot_hint & 15) * 16;
-    if (m > __builtin_nontemporal_load(p)) atomicMax(reinterpret_cast<unsigned*>(p), __float_as_uint(m));
-  }
+  if ((threadIdx.x & 63) == 0 && m > peeked)
+    atomicMax(reinterpret_cast<unsigned*>(slots + (slot_hint & 15) * 16), __float_as_uint(m));
 }
 // one atomic per BLOCK (kernels whose epilogue may use a barrier): `sm` = one float per wave
 __device__ __forceinline__ void amax_commit_block(float* __restrict__ slots, float lane_max, int slot_hint, float* sm,
-                                                  int nwaves) {
+                                                  int nwaves, float peeked) {
   const float m = wave_max(lane_max);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
     float b = sm[0];
     for (int i = 1; i < nwaves; ++i) b = fmaxf(b, sm[i]);
-    float* p = slots + (slot_hint & 15) * 16;
-    if (b > __builtin_nontemporal_load(p)) atomicMax(reinterpret_cast<unsigned*>(p), __float_as_uint(b));
+    if (b > peeked) atomicMax(reinterpret_cast<unsigned*>(slots + (slot_hint & 15) * 16), __float_as_uint(b));
   }
 }
 __device__ __forceinline__ float abs_max4(float cur, const f32x4& v) {

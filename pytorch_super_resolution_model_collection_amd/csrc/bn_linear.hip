@@ -233,6 +233,7 @@ __global__ __launch_bounds__(256) void k_bn_apply4(const float* __restrict__ x, 
                                                    size_t total4, int C, int act, float slope, float* __restrict__ y_amax) {
   __shared__ float sm_amax[4];
   float amax = 0.f;
+  const float peeked = amax_peek(y_amax, blockIdx.x);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
     const int c = (int)((i * 4) % (size_t)C);
     const bn_f4 xv = *reinterpret_cast<const bn_f4*>(x + i * 4);
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void k_bn_apply4(const float* __restrict__ x, 
     *reinterpret_cast<bn_f4*>(y + i * 4) = v;
     if (y_amax) amax = abs_max4(amax, v);
   }
-  if (y_amax) amax_commit_block(y_amax, amax, blockIdx.x, sm_amax, 4);   // the running maximum the next conv scales by
+  if (y_amax) amax_commit_block(y_amax, amax, blockIdx.x, sm_amax, 4, peeked);   // the running maximum the next conv scales by
 }
 
 template <bool DBL>
@@ -312,6 +313,7 @@ __global__ __launch_bounds__(256) void k_bn_apply_act4(const float* __restrict__
                                                        float* __restrict__ y_amax) {
   __shared__ float sm_amax[4];
   float amax = 0.f;
+  const float peeked = amax_peek(y_amax, blockIdx.x);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
     const int c = (int)((i * 4) % (size_t)C);
     const bn_f4 xv = *reinterpret_cast<const bn_f4*>(x + i * 4);
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(256) void k_bn_apply_act4(const float* __restrict__
     *reinterpret_cast<bn_f4*>(y + i * 4) = v;
     if (y_amax) amax = abs_max4(amax, v);
   }
-  if (y_amax) amax_commit_block(y_amax, amax, blockIdx.x, sm_amax, 4);   // the running maximum the next conv scales by
+  if (y_amax) amax_commit_block(y_amax, amax, blockIdx.x, sm_amax, 4, peeked);   // the running maximum the next conv scales by
 }
 
 // backward statistics with dz = dy * act'(z):  partial[split][3][C] = sum dz, sum dz * xhat, sum_{z <= 0} dy * z (PReLU)

@@ -149,6 +149,7 @@ template <int NTW, int NPW, int NOW>
 __device__ __forceinline__ void bfd_epilogue(const MfmaConvParams& P, float* smem_f, const f32x4 (&acc)[4][NTW], int n,
                                              int r0, int c0, int ocb, int pw, int ow, int lane, bool active = true) {
   float amax = 0.f;
+  const float peeked = amax_peek(P.ep.y_amax, blockIdx.x + (threadIdx.x >> 6));
   const int j = lane & 15, kq = lane >> 4;
   const int npx = P.TH * P.TW;
   __syncthreads();
@@ -194,7 +195,7 @@ __device__ __forceinline__ void bfd_epilogue(const MfmaConvParams& P, float* sme
     }
     __syncthreads();
   }
-  if (P.ep.y_amax) amax_commit_block(P.ep.y_amax, amax, blockIdx.x, smem_f, (int)(blockDim.x >> 6));  // (slab is free)
+  if (P.ep.y_amax) amax_commit(P.ep.y_amax, amax, blockIdx.x + (threadIdx.x >> 6), peeked);
 }
 
 // Direct epilogue of the transposed product (C/D: col = lane & 15 = pixel of the M tile, rows kq*4 + reg = 4
@@ -211,6 +212,7 @@ __device__ __forceinline__ void bfd_epilogue_direct(const MfmaConvParams& P, con
   const int tw_magic = div_small_magic(P.TW);
   const EpiTile et = epi_tile_setup(P, n, r0, c0);
   float amax = 0.f;
+  const float peeked = amax_peek(P.ep.y_amax, blockIdx.x + (threadIdx.x >> 6));
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
     const int oc4 = ocb + (ow * NTW + nt) * 16 + kq * 4;
@@ -228,7 +230,7 @@ __device__ __forceinline__ void bfd_epilogue_direct(const MfmaConvParams& P, con
       }
     }
   }
-  if (P.ep.y_amax) amax_commit(P.ep.y_amax, amax, blockIdx.x + (threadIdx.x >> 6));
+  if (P.ep.y_amax) amax_commit(P.ep.y_amax, amax, blockIdx.x + (threadIdx.x >> 6), peeked);
 }
 
 // KS = 2 (small problems with every chunk staged up front): a second set of NPW*NOW waves takes the odd channel

@@ -49,10 +49,14 @@ struct BfwParams {
   int ICc, NB, NPIXp, ntiles;
   int perm;  // consumer lanes {0-3, 12-15} hold the even pixels of an M tile, {4-11} the odd ones (bfw_group_stride)
   const float* w_descale;  // F16 kernels: trailer {2^-kw, 2^kw} of the fp16 filter section (wq then points at that section)
+  // Output-channel slices: a layer whose whole filter does not fit (64 -> 64: 147 KB) runs as nsl slices of NB = OC / nsl
+  // channels; slice sl of tile range i is block 8 * (nsl * i + sl) + xcd -- the nsl blocks that walk the same tiles are
+  // neighbours on one XCD and start together, so the halo the first one pulls into that XCD's L2 serves the others.
+  int nsl, NBfull, OCb;
   int dbg;  // ablation (SRK_DBG): 1 no global loads, 2 no epilogue, 4 no MFMA loop, 16 no LDS commit, 1024 no deferred stores
 };
 
-template <int NTW, int TT, int MTW, bool F16 = false>
+template <int NTW, int TT, int MTW, bool F16 = false, bool MASK = false>
 __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_conv_bfw(BfwParams B) {
   constexpr int NCW = 16 / MTW;          // consumer waves: MTW 16-pixel groups each, 256 pixels per block
   constexpr int NTHR = 64 * (NCW + 4);   // + 4 producer waves
@@ -76,12 +80,18 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
     dsc = exp2i(-kx) * B.w_descale[0];
   }
 
+  const int nsl = B.nsl;
+  const int xcd = blockIdx.x & 7;
+  const int sl = (blockIdx.x >> 3) % nsl, bi = (blockIdx.x >> 3) / nsl;  // slice, block index inside the XCD
   for (int e = tid; e < T * B.ICc * wslot; e += NTHR) {
     const int slot = e / wslot, w = e - slot * wslot;
     const int t = slot / B.ICc, cc = slot - t * B.ICc;
     const int u = t / P.KWv, v = t - u * P.KWv;
     const int tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
-    wl[e] = B.wq[(size_t)(tapw * B.ICc + cc) * (size_t)wslot + w];
+    const int pg = w / NB, o = w - pg * NB;  // (plane, group) row of the slot, channel inside the slice
+    // packed layout [tap][chunk][64-channel block][plane][group][NBfull channels]
+    const int oc = sl * NB + o, ocb = oc / B.NBfull;
+    wl[e] = B.wq[((size_t)(tapw * B.ICc + cc) * B.OCb + ocb) * (size_t)(8 * B.NBfull) + pg * B.NBfull + (oc - ocb * B.NBfull)];
   }
   // tiles of this block: XCD-aware order (consecutive block ids go round-robin over the 8 XCDs / L2s; give each XCD
   // a contiguous range of tiles so neighbouring tiles share halo rows in one L2)
@@ -89,15 +99,13 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
   int first, count;
   {
     const int per_x = B.ntiles >> 3, rem_x = B.ntiles & 7;  // tiles per XCD
-    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;   // block index inside the XCD
-    const int nb_x = (nblk + 7 - xcd) >> 3;                 // blocks on this XCD
+    const int nb_x = ((nblk + 7 - xcd) >> 3) / nsl;         // blocks per slice on this XCD (host: grid % (8 nsl) == 0)
     const int tiles_x = per_x + (xcd < rem_x ? 1 : 0);
     const int start_x = xcd * per_x + (xcd < rem_x ? xcd : rem_x);
     first = start_x + bi;  // block bi takes tiles start_x + bi, + nb_x, ...
     count = bi < tiles_x ? (tiles_x - bi + nb_x - 1) / nb_x : 0;
-    (void)nb_x;
   }
-  const int tstride = (nblk + 7 - (blockIdx.x & 7)) >> 3;
+  const int tstride = ((nblk + 7 - xcd) >> 3) / nsl;
   const int S = count * B.ICc;  // stages of this block
 
   auto decode = [&](int s, int& n, int& r0, int& c0, int& cc) {
@@ -125,6 +133,7 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
     const int hy0 = hp0 / P.HW, hx0 = hp0 - hy0 * P.HW;
     const int dyp = 64 / P.HW, dxp = 64 - dyp * P.HW;
     f32x4 pv0[BFW_IT], pv1[BFW_IT];
+    f32x4 mk0[MASK ? BFW_IT : 1], mk1[MASK ? BFW_IT : 1];  // MASK: y of the forward layer (dx = conv^T(dy * act'(y)))
     auto issue = [&](int s) {
       if (B.dbg & 1) return;
       int n, r0, c0, cc;
@@ -132,17 +141,22 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
       const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
       const int ch = cc * 32 + g * 8;
       const bool ch_on = ch + 7 < P.IC;
-      const float* __restrict__ inb = P.in + (size_t)n * P.IH * P.IW * P.IC + ch;
+      const size_t ibase = (size_t)n * P.IH * P.IW * P.IC + ch;
       int hy = hy0, hx = hx0;
 #pragma unroll
       for (int k = 0; k < BFW_IT; ++k) {
         pv0[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
         pv1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (MASK) mk0[k] = mk1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int iy = iyb + hy, ix = ixb + hx;
         if (hp0 + 64 * k < npix && ch_on && (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW) {
-          const float* src = inb + ((size_t)iy * P.IW + ix) * P.IC;
-          pv0[k] = *reinterpret_cast<const f32x4*>(src);
-          pv1[k] = *reinterpret_cast<const f32x4*>(src + 4);
+          const size_t off = ibase + ((size_t)iy * P.IW + ix) * P.IC;
+          pv0[k] = *reinterpret_cast<const f32x4*>(P.in + off);
+          pv1[k] = *reinterpret_cast<const f32x4*>(P.in + off + 4);
+          if constexpr (MASK) {
+            mk0[k] = *reinterpret_cast<const f32x4*>(P.mask_y + off);
+            mk1[k] = *reinterpret_cast<const f32x4*>(P.mask_y + off + 4);
+          }
         }
         hy += dyp;
         hx += dxp;
@@ -163,6 +177,10 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
           for (int e = 0; e < 4; ++e) {
             f[e] = pv0[k][e];
             f[4 + e] = pv1[k][e];
+            if constexpr (MASK) {
+              f[e] = mk0[k][e] > 0.f ? f[e] : f[e] * P.mask_slope;
+              f[4 + e] = mk1[k][e] > 0.f ? f[4 + e] : f[4 + e] * P.mask_slope;
+            }
           }
           uint4 pl[2];
           if constexpr (F16) split8h(f, sx, pl); else split8n<2>(f, pl);
@@ -225,7 +243,7 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
     }
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-      const EpiCol cl = epi_col_setup(P.ep, P.OW, P.OC, nt * 16 + kq * 4);
+      const EpiCol cl = epi_col_setup(P.ep, P.OW, P.OC, sl * NB + nt * 16 + kq * 4);
       coff[nt] = (int)cl.off_oc;
       bias4[nt] = cl.bias;
     }
@@ -365,7 +383,7 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
     }
     __syncthreads();
   }
-  if (P.ep.y_amax) amax_commit(P.ep.y_amax, amax, blockIdx.x + wave);
+  if (P.ep.y_amax) amax_commit(P.ep.y_amax, amax, blockIdx.x + wave, amax_peek(P.ep.y_amax, blockIdx.x + wave));  // (persistent: once)
 }
 
 // LDS stride (in 16-byte slots) between the four 8-channel groups of a halo plane, chosen against the lane groups the LDS
@@ -414,23 +432,36 @@ static bool bfw_pick_tile(int maxpix, int PH, int PW, int KHv, int KWv, long cap
   return found;
 }
 
-// Applicability: stride-1 CONV gathers, IC a multiple of 8 (16-byte channel groups), OC = 16 * {1..4}, filter planes
-// + two halo buffers within the LDS, every output group on the 16-byte store path, and a problem large enough to
-// keep one persistent block per CU busy for several tiles.  SRK_BFW: 0 never, 1 whenever applicable, unset = automatic.
+// Output-channel slices of a layer (BfwParams.nsl): 1 while the whole filter fits, else 32-channel slices (3x3 only)
+static inline int bfw_slices(const GatherConv& g) {
+  const int T = g.KH * g.KW;
+  if (g.OC <= 48 || (g.OC == 64 && (size_t)T * ((g.IC + 31) / 32) * 8 * g.OC * 16 <= 100 * 1024)) return 1;
+  return (T == 9 && g.OC % 32 == 0) ? g.OC / 32 : 0;
+}
+
+// Applicability: stride-1 gathers (CONV, or TRANS = the data gradient of a stride-1 conv: flipped taps), IC a multiple
+// of 8 (16-byte channel groups), OC = 16 * {1..4} or 32-channel slices of a wider 3x3 layer, filter planes (of a slice)
+// + two halo buffers within the LDS, every output group on the 16-byte store path, and a problem large enough to keep
+// one persistent block per CU busy for several tiles.  The activation-gradient mask (mask_y) is applied by the
+// producers of the 32-channel 3x3 variant.  SRK_BFW: 0 never, 1 whenever applicable, unset = automatic.
 bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, const float* out, const float* mask_y) {
   // (read per dispatch, ~0.1 us: the conv KAT variants of tests/test_ops_gpu.py switch it inside one process)
   const char* e = getenv("SRK_BFW");
   const int mode = e ? atoi(e) : 2;
-  if (mode == 0 || mask_y || g.trans || g.stride != 1 || g.in_nchw || g.in_ps_r > 1) return false;
+  if (mode == 0 || g.stride != 1 || g.in_nchw || g.in_ps_r > 1) return false;
   if (g.IC < 8 || g.IC % 8 != 0 || (uintptr_t)in % 16 != 0) return false;
-  if (g.OC % 16 != 0 || g.OC < 16 || g.OC > 64) return false;
+  if (g.OC % 16 != 0 || g.OC < 16) return false;
   const int T = g.KH * g.KW;
-  if (T > BFW_MAXTAPS - 1 || (T != 9 && g.OC > 48)) return false;  // (the 64-channel dynamic-tap variant spills)
+  const int nsl = bfw_slices(g);
+  if (nsl == 0) return false;
+  const int NB = g.OC / nsl;
+  if (T > BFW_MAXTAPS - 1 || (T != 9 && NB > 48)) return false;  // (the 64-channel dynamic-tap variant spills)
+  if (mask_y && (NB != 32 || T != 9 || (uintptr_t)mask_y % 16 != 0)) return false;
   if (!conv_epi_all_vector(g.OC, ep, out)) return false;
   if (ep.residual || (ep.act == SRK_ACT_PRELU && ep.prelu_n > 1)) return false;
   if (ep.act != SRK_ACT_NONE && ep.act != SRK_ACT_RELU && ep.act != SRK_ACT_LRELU && ep.act != SRK_ACT_PRELU) return false;
   if ((long)g.N * g.OH * g.OW * g.OC >= (1L << 31)) return false;  // 32-bit in-tile output offsets
-  const size_t wbytes = (size_t)T * ((g.IC + 31) / 32) * 8 * g.OC * 16;
+  const size_t wbytes = (size_t)T * ((g.IC + 31) / 32) * 8 * NB * 16;
   if (wbytes > 100 * 1024) return false;
   if ((long)g.N * g.OH * g.OW >= (1L << 30) || (long)g.IH * g.IW * g.IC >= (1L << 30)) return false;
   if (mode == 1) return true;
@@ -441,6 +472,16 @@ bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, co
 
 template <int NTW, int TT, int MTW>
 static int bfw_launch_t(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
+  if constexpr (NTW == 2 && TT == 9 && MTW == 2) {
+    if (B.P.mask_y) {  // data gradient behind an activation (bf16x3)
+      static LdsLimit limm;
+      limm.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, MTW, false, true>), lds);
+      note_kernel("k_conv_bfw<%d,%d,%d,mask>", NTW, TT, MTW);
+      hipLaunchKernelGGL((k_conv_bfw<NTW, TT, MTW, false, true>), dim3(grid), dim3(64 * (16 / MTW + 4)), lds, s, B);
+      return check_launch("conv_bfw");
+    }
+  }
+  if (B.P.mask_y) return -1;
   if (B.w_descale) {  // f16x3 arithmetic
     static LdsLimit limh;
     limh.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, MTW, true>), lds);
@@ -472,8 +513,8 @@ static int bfw_launch(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
 }
 
 // returns -1 when no tile fits (the caller falls back to the other kernels).  f16: the f16x3 arithmetic (ep.x_amax set)
-int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s,
-                    bool f16) {
+int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep,
+                    const float* mask_y, float mask_slope, hipStream_t s, bool f16) {
   const size_t elems = (size_t)g.KH * g.KW * g.IC * g.OC;
   const char* prepared = reinterpret_cast<const char*>(wp) + bf3_prepared_offset(elems);
   const char* fsec = prepared + f16_section_offset(g.IC, g.OC, g.KH * g.KW);
@@ -481,13 +522,18 @@ int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float
   const float* w_descale = f16 ? reinterpret_cast<const float*>(fsec + bf3_main_bytes(g.IC, g.OC, g.KH * g.KW)) : nullptr;
   static int dbg = -1;
   if (dbg < 0) dbg = getenv("SRK_DBG") ? atoi(getenv("SRK_DBG")) : 0;
-  return for_each_phase(g, in, wp, out, ep, nullptr, 0.f, [&](const MfmaConvParams& P0) {
+  const int nsl = bfw_slices(g);
+  if (nsl == 0) return -1;
+  return for_each_phase(g, in, wp, out, ep, mask_y, mask_slope, [&](const MfmaConvParams& P0) {
     BfwParams B{};
     B.P = P0;
     MfmaConvParams& P = B.P;
     B.wq = wq;
     B.w_descale = w_descale;
-    B.NB = P.OC;
+    B.nsl = nsl;
+    B.NBfull = P.OC >= 64 ? 64 : P.OC;   // (pack_items.h: pk_nb; OC is a multiple of 16 here)
+    B.OCb = (P.OC + 63) / 64;
+    B.NB = P.OC / nsl;
     B.ICc = (P.IC + 31) / 32;
     B.dbg = dbg;
     const int T = P.KHv * P.KWv;
@@ -508,11 +554,18 @@ int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float
     if (ntiles >= (1L << 30)) return -1;
     B.ntiles = (int)ntiles;
     int grid = kNumCU;
-    if (grid > ntiles) grid = (int)ntiles;
+    if (nsl > 1) {  // whole groups of nsl neighbouring blocks on every XCD (a group without tiles just exits)
+      grid -= grid % (8 * nsl);
+      const long want = ((ntiles + 7) / 8) * 8 * nsl;
+      if (grid == 0) return -1;
+      if (want < grid) grid = (int)want;
+    } else if (grid > ntiles) {
+      grid = (int)ntiles;
+    }
     if (dbg & 32)
-      fprintf(stderr, "[srk] k_conv_bfw<%d>: lds %zu B (filter %zu), grid %d of %ld tiles, tile %dx%d halo %dx%d\n", P.OC / 16,
-              lds, wbytes, grid, ntiles, P.TH, P.TW, P.HH, P.HW);
-    switch (P.OC / 16) {
+      fprintf(stderr, "[srk] k_conv_bfw<%d>: lds %zu B (filter %zu), grid %d of %ld tiles x %d slices, tile %dx%d halo %dx%d\n",
+              B.NB / 16, lds, wbytes, grid, ntiles, nsl, P.TH, P.TW, P.HH, P.HW);
+    switch (B.NB / 16) {
       case 1: return bfw_launch<1>(B, lds, grid, s);
       case 2: return bfw_launch<2>(B, lds, grid, s);
       case 3: return bfw_launch<3>(B, lds, grid, s);

@@ -251,6 +251,7 @@ template <int NT, bool VEC_ONLY = false>
 __device__ __forceinline__ void bf3_epilogue(const MfmaConvParams& P, float* smem_f, const f32x4 (&acc)[4][NT], int n,
                                              int r0, int c0, int ocb, int wave, int lane) {
   float amax = 0.f;  // running maximum of what this lane stores (ep.y_amax; vector store path only)
+  const float peeked = VEC_ONLY ? amax_peek(P.ep.y_amax, blockIdx.x + wave) : 0.f;
   const int j = lane & 15, kq = lane >> 4;
   const int npx = P.TH * P.TW;
   __syncthreads();
@@ -295,7 +296,7 @@ __device__ __forceinline__ void bf3_epilogue(const MfmaConvParams& P, float* sme
     }
     __syncthreads();
   }
-  if (VEC_ONLY && P.ep.y_amax) amax_commit_block(P.ep.y_amax, amax, blockIdx.x, smem_f, (int)(blockDim.x >> 6));
+  if (VEC_ONLY && P.ep.y_amax) amax_commit(P.ep.y_amax, amax, blockIdx.x + wave, peeked);  // per wave: no barrier at the tail
 }
 
 // NT <= 2 (the c2 benchmark's 64->32 layer) must stay within 168 VGPRs: three resident blocks per CU instead of two

@@ -333,6 +333,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
   }
   // swap halves again (the region of the input halo is free: nothing reads it after the barrier above)
   f32x4* red2 = reinterpret_cast<f32x4*>(smem4) + (size_t)(ow * 4) * 64 + lane;  // [4 ow][4 tiles][64 lanes]
+  const float peeked = amax_peek(R.y_amax, blockIdx.x);  // (early: see amax_commit)
   if (kgrp == 0) {
     red2[2 * 64] = acc2[2];
     red2[3 * 64] = acc2[3];
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
       if (R.y_amax) oamax = abs_max4(oamax, v);
     }
   }
-  if (R.y_amax) amax_commit_block(R.y_amax, oamax, blockIdx.x, r2_amx, 8);
+  if (R.y_amax) amax_commit_block(R.y_amax, oamax, blockIdx.x, r2_amx, 8, peeked);
 }
 #undef SRK_R2_PASSES
 #undef mfma16

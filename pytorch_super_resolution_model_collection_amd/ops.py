@@ -295,7 +295,7 @@ def conv_forward_raw(x, wp, bias_p, weight_shape_src, cfg, prelu_w=None, residua
             if xa is not None:
                 ep.x_amax = ptr(xa)
                 d.algo = _lib.ALGO_MFMA_F16X3
-        if d.algo in (_lib.ALGO_MFMA_F16X3, _lib.ALGO_MFMA_BF16X6):
+        if d.algo in (_lib.ALGO_MFMA_F16X3, _lib.ALGO_MFMA_BF16X6) and not os.environ.get("SRK_NO_YAMAX"):
             # (a layer of the fp32-faithful class feeds layers of that class: leave them the maximum of the output)
             ya = _amax_alloc(y.device)      # filled by the kernels of conv_bfd.hip (checked below)
             ep.y_amax = ptr(ya)
@@ -516,7 +516,7 @@ class _Conv2d(torch.autograd.Function):
                 check(lib.srk_pixel_shuffle_backward(ptr(dy), ptr(dyc), d.N, d.OH, d.OW, d.Cout // (r * r), r,
                                                      stream_ptr()), "srk_pixel_shuffle_backward")
         mask = None
-        if y is not None:
+        if y is not None and not os.environ.get("SRK_EXP_NOMASK"):
             mask = BwdMask(ptr(y), cfg.slope if cfg.act == ACT_LRELU else 0.0)
         mref = ctypes.byref(mask) if mask is not None else None
         dx = dw = db = None

@@ -180,6 +180,85 @@ def test_conv_wave_specialized(gpu, monkeypatch, cin, cout, k, p, H, W, N, act, 
     assert rel_err(y, ref.float()) < 1e-4
 
 
+@pytest.mark.parametrize("cin,cout,H,W,N,act,ps", [
+    (64, 64, 41, 41, 3, "relu", 0),     # VDSR body layer: two 32-channel slices (the whole filter is 147 KB)
+    (64, 256, 16, 24, 2, None, 2),      # EDSR up-sampler: eight slices over four 64-channel filter blocks, PS store
+    (32, 96, 19, 19, 1, "lrelu", 0),    # three slices, one chunk
+    (64, 128, 9, 50, 1, None, 0),       # fewer tiles than XCDs: slice groups without work
+])
+def test_conv_wave_specialized_channel_slices(gpu, monkeypatch, cin, cout, H, W, N, act, ps):
+    """k_conv_bfw on layers wider than its LDS-resident filter allows: 32-channel slices on neighbouring blocks
+    (BfwParams.nsl).  Same arithmetic and accumulation order as the per-tile bf16x3 kernel -> equal outputs; and both
+    vs torch fp64."""
+    pkg = _pkg()
+    ops = pkg.ops
+    x = fill.randn((N, cin, H, W), 191)
+    w = fill.randn((cout, cin, 3, 3), 192, (2.0 / (cin * 9)) ** 0.5)
+    b = fill.randn((cout,), 193, 0.1)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    if act == "relu":
+        ref = torch.relu(ref)
+    elif act == "lrelu":
+        ref = torch.nn.functional.leaky_relu(ref, 0.2)
+    if ps:
+        ref = torch.nn.functional.pixel_shuffle(ref, ps)
+    code = {None: 0, "relu": 1, "lrelu": 3}[act]
+    cfg = ops.ConvCfg(1, 1, False, 0, code, 0.2 if act == "lrelu" else 0.0, ps, ALGOS["auto"])
+    monkeypatch.setenv("SRK_BF3_DIRECT", "0")   # reference kernel: the per-tile k_conv_bf3 (same summation order)
+    outs = {}
+    ops.set_precision("bf16x3")
+    try:
+        for mode in ("0", "1"):
+            monkeypatch.setenv("SRK_BFW", mode)
+            with torch.no_grad():
+                outs[mode] = ops.conv2d_infer(x.to(gpu), w.to(gpu), b.to(gpu), None, cfg)
+            name = pkg._lib.load().srk_last_kernel_name().decode()
+            assert name.startswith("k_conv_bfw<2,9,2") == (mode == "1"), name
+    finally:
+        ops.set_precision("mixed")
+    assert torch.equal(outs["0"], outs["1"])
+    assert rel_err(outs["1"], ref.float()) < 1e-4
+
+
+@pytest.mark.parametrize("cin,cout,H,W,N,act", [
+    (64, 64, 41, 41, 3, "relu"),      # VDSR body layer
+    (64, 64, 20, 33, 2, "lrelu"),     # slope on the masked side
+    (32, 64, 24, 24, 2, "relu"),      # data gradient 64 -> 32: one slice, masked producers
+    (64, 64, 17, 17, 2, None),        # no activation: plain producers, flipped taps only
+])
+def test_conv_wave_specialized_data_gradient(gpu, monkeypatch, cin, cout, H, W, N, act):
+    """Data gradient of a stride-1 conv behind a fused activation on k_conv_bfw: TRANS gather (flipped taps), the
+    activation-gradient mask applied by the producer waves, output-channel slices; vs torch fp64 and equal to the
+    per-tile kernel."""
+    pkg = _pkg()
+    ops = pkg.ops
+    ops.set_precision("mixed")
+    x = fill.randn((N, cin, H, W), 201)
+    w = fill.randn((cout, cin, 3, 3), 202, (2.0 / (cin * 9)) ** 0.5)
+    b = fill.randn((cout,), 203, 0.1)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    ref = torch.nn.functional.conv2d(xr, wr, br, 1, 1)
+    if act == "relu":
+        ref = torch.relu(ref)
+    elif act == "lrelu":
+        ref = torch.nn.functional.leaky_relu(ref, 0.2)
+    g = fill.randn(tuple(ref.shape), 204)
+    ref.backward(g.double())
+    code = {None: 0, "relu": 1, "lrelu": 3}[act]
+    monkeypatch.setenv("SRK_BF3_DIRECT", "0")   # reference kernel: the per-tile k_conv_bf3 (same summation order)
+    grads = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SRK_BFW", mode)
+        xg, wg, bg = (t.to(gpu).requires_grad_(True) for t in (x, w, b))
+        y = ops.conv2d(xg, wg, bg, None, ops.ConvCfg(1, 1, False, 0, code, 0.2 if act == "lrelu" else 0.0, 0))
+        y.backward(g.to(gpu))
+        ops.flush_wgrads()
+        grads[mode] = xg.grad.clone()
+        assert rel_err(wg.grad, wr.grad.float()) < 1e-4
+    assert torch.equal(grads["0"], grads["1"])
+    assert rel_err(grads["1"], xr.grad.float()) < 1e-4
+
+
 @pytest.mark.parametrize("cin,cout,k,s,p,op,H,W", [
     (64, 8, 9, 4, 3, 1, 8, 8),     # data gradient = 9x9 stride-4 gather over 64 channels: halo chunk > half the LDS
     (56, 32, 8, 4, 2, 0, 6, 9),
