@@ -179,7 +179,7 @@ def pmc_traffic(kernel_label, batch, lr_size):
         name = name.replace(" ", "")
         i = name.find("<")
         if i < 0:
-            return name.split("(")[0].split("::")[-1], [], False
+            return name.split("(")[0].split("::")[-1], [], False, False
         j = name.find(">", i)
         base = name[:i].split("::")[-1].replace("void", "")
         args = name[i + 1:j].split(",")
@@ -188,7 +188,14 @@ def pmc_traffic(kernel_label, batch, lr_size):
             if not a.lstrip("-").isdigit():
                 break
             ints.append(a)
-        return base, ints, ("f16" in args) or (len(args) > len(ints) and args[-1] == "true")
+        rest = args[len(ints):]
+        if "f16" in rest or "mask" in rest or not rest:          # the dispatcher's label
+            return base, ints, "f16" in rest, "mask" in rest
+        if base == "k_conv_bfw":                                  # <NTW, TT, MTW, F16, MASK>
+            return base, ints, rest[0] == "true", len(rest) > 1 and rest[1] == "true"
+        if base == "k_conv_bf3_rows":                             # <NT, VEC_ONLY, F16>
+            return base, ints, rest[-1] == "true", False
+        return base, ints, rest[0] == "true", False               # k_conv_rowsw<NTW, QT, F16>, ...
 
     want = targs(kernel_label.split(" ")[0])
     for name, rec in kernels.items():
@@ -218,8 +225,9 @@ def training_roofline(tag, px, layer_px_note, layers_per_step=1, steps=5):
     t = 4.0 * 64 * px                     # one 64-channel fp32 tensor of the layer
     flop = 2.0 * px * 64 * 64 * 9
     # (role, kernel-name keys, algorithmic bytes per LAYER, operands, layers' worth of FLOPs per launch or None = from calls)
-    roles = [("forward", ("k_conv_bfd<2, 2, 2, 2", "k_conv_bfd<2, 2, 2, 3", "k_conv_bfd<4, 4, 1, 2"), 2 * t, "x, y", 1.0),
-             ("data_gradient", ("k_conv_bf3<4, 4, true>",), 3 * t, "dy, activation mask, dx", 1.0),
+    roles = [("forward", ("k_conv_bfw<2, 9, 2, true, false>", "k_conv_bfd<2, 2, 2, 2", "k_conv_bfd<2, 2, 2, 3", "k_conv_bfd<4, 4, 1, 2"),
+              2 * t, "x, y", 1.0),
+             ("data_gradient", ("k_conv_bfw<2, 9, 2, false, true>", "k_conv_bf3<4, 4, true>"), 3 * t, "dy, activation mask, dx", 1.0),
              ("weight_gradient", ("k_wgrad_bf<2, 2, 2, true",), 3 * t, "x, dy, activation mask", None),
              # residual blocks fused per tile (conv -> ReLU -> conv -> + skip in one launch): useful work of two layers
              ("fused_block_forward", ("k_res2<2, false", "k_res2<3, false"), 3 * t, "x, intermediate, y", 2.0),

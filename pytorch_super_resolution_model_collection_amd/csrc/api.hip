@@ -34,6 +34,8 @@ int conv_tapn_gather(const GatherConv& g, const float* in, const float* wp, floa
 bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, const float* out, const float* mask_y);
 int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, const float* mask_y,
                     float mask_slope, hipStream_t s, bool f16);
+bool conv_rowsw_applicable(const GatherConv& g, const Epi& ep, const float* in, const float* out, const float* mask_y);
+int conv_rowsw_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s, bool f16);
 bool conv_bf3_rows_f16_supported(const GatherConv& g, const Epi& ep, const float* out);
 int conv_bf3_rows_f16_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s);
 bool conv_tapk_gather_supported(const GatherConv& g, const Epi& ep, const float* out, const float* mask_y);
@@ -129,7 +131,13 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
                 "srk_epilogue.x_amax (srk_conv2d_f16x3_supported)", who);
       return SRK_ERR_UNSUPPORTED;
     }
-    if (conv_bf3_rows_f16_supported(g, ep, out)) return conv_bf3_rows_f16_gather(g, in, wp, out, ep, s);
+    if (conv_bf3_rows_f16_supported(g, ep, out)) {
+      if (conv_rowsw_applicable(g, ep, in, out, nullptr)) {  // persistent wave-specialised form (benchmark-size first layers)
+        const int rc = conv_rowsw_gather(g, in, wp, out, ep, s, true);
+        if (rc >= 0) return rc;
+      }
+      return conv_bf3_rows_f16_gather(g, in, wp, out, ep, s);
+    }
     if (conv_bfw_applicable(g, ep, in, out, nullptr)) {  // wave-specialised persistent kernel (ESPCN-size layers)
       const int rc = conv_bfw_gather(g, in, wp, out, ep, nullptr, 0.f, s, true);
       if (rc >= 0) return rc;
@@ -174,6 +182,10 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
       return conv_bfd_gather(g, in, wp, out, ep, mask_y, mask_slope, 2, s);
     if (conv_bfw_applicable(g, ep, in, out, mask_y)) {  // wave-specialised persistent kernel (ESPCN-size layers)
       const int rc = conv_bfw_gather(g, in, wp, out, ep, mask_y, mask_slope, s, false);
+      if (rc >= 0) return rc;
+    }
+    if (conv_rowsw_applicable(g, ep, in, out, mask_y)) {  // ... and its row-packed form for first layers (Cin <= 4)
+      const int rc = conv_rowsw_gather(g, in, wp, out, ep, s, false);
       if (rc >= 0) return rc;
     }
     return conv_bf3_gather(g, in, wp, out, ep, mask_y, mask_slope, s);

@@ -108,16 +108,41 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
   const int tstride = ((nblk + 7 - xcd) >> 3) / nsl;
   const int S = count * B.ICc;  // stages of this block
 
-  auto decode = [&](int s, int& n, int& r0, int& c0, int& cc) {
-    const int ti = s / B.ICc;
-    cc = s - ti * B.ICc;
-    const int tile = first + ti * tstride;
-    const int txi = tile % P.tiles_x;
-    const int q = tile / P.tiles_x;
-    const int tyi = q % P.tiles_y;
-    n = q / P.tiles_y;
-    r0 = tyi * P.TH;
-    c0 = txi * P.TW;
+  // Stage walk (tile first + i * tstride, chunk cc) without divisions in the loop: a 32-bit division is ~40 VALU
+  // instructions, and the per-stage decode had four of them in every wave.  The tile step is split once into (images,
+  // tile rows, tile columns); an advance is add + carry on wave-uniform values.  decode() returns the stages in order.
+  const int img_tiles = P.tiles_x * P.tiles_y;
+  const int st_n = tstride / img_tiles, st_y = (tstride - st_n * img_tiles) / P.tiles_x,
+            st_x = tstride - st_n * img_tiles - st_y * P.tiles_x;
+  int w_n, w_y, w_x, w_cc = 0;
+  {
+    w_n = first / img_tiles;
+    const int q = first - w_n * img_tiles;
+    w_y = q / P.tiles_x;
+    w_x = q - w_y * P.tiles_x;
+    w_n = __builtin_amdgcn_readfirstlane(w_n);
+    w_y = __builtin_amdgcn_readfirstlane(w_y);
+    w_x = __builtin_amdgcn_readfirstlane(w_x);
+  }
+  auto decode = [&](int& n, int& r0, int& c0, int& cc) {
+    n = w_n;
+    r0 = w_y * P.TH;
+    c0 = w_x * P.TW;
+    cc = w_cc;
+    if (++w_cc == B.ICc) {
+      w_cc = 0;
+      w_x += st_x;
+      w_y += st_y;
+      w_n += st_n;
+      if (w_x >= P.tiles_x) {
+        w_x -= P.tiles_x;
+        ++w_y;
+      }
+      if (w_y >= P.tiles_y) {
+        w_y -= P.tiles_y;
+        ++w_n;
+      }
+    }
   };
 
   if (producer) {
@@ -134,10 +159,10 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
     const int dyp = 64 / P.HW, dxp = 64 - dyp * P.HW;
     f32x4 pv0[BFW_IT], pv1[BFW_IT];
     f32x4 mk0[MASK ? BFW_IT : 1], mk1[MASK ? BFW_IT : 1];  // MASK: y of the forward layer (dx = conv^T(dy * act'(y)))
-    auto issue = [&](int s) {
-      if (B.dbg & 1) return;
+    auto issue = [&]() {
       int n, r0, c0, cc;
-      decode(s, n, r0, c0, cc);
+      decode(n, r0, c0, cc);
+      if (B.dbg & 1) return;
       const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
       const int ch = cc * 32 + g * 8;
       const bool ch_on = ch + 7 < P.IC;
@@ -190,15 +215,15 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
       }
     };
     if (S > 0 && T > 0) {
-      issue(0);
+      issue();
       commit(hal0);
-      if (S > 1) issue(1);
+      if (S > 1) issue();
     }
     __syncthreads();  // filter, tap table and stage 0 visible
     for (int s = 0; s < S; ++s) {
       if (T > 0) {
         if (s + 1 < S) commit(hal0 + (size_t)((s + 1) & 1) * hbuf);
-        if (s + 2 < S) issue(s + 2);
+        if (s + 2 < S) issue();
       }
       __syncthreads();
     }
@@ -276,7 +301,7 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
   __syncthreads();  // filter and stage 0 visible
   for (int s = 0; s < S; ++s) {
     int n, r0, c0, cc;
-    decode(s, n, r0, c0, cc);
+    decode(n, r0, c0, cc);
     if (cc == 0) {
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt)

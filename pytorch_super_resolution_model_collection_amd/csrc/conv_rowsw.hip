@@ -1,0 +1,469 @@
+// Wave-specialised persistent form of the row-packed first-layer kernel (k_conv_bf3_rows: Cin <= 4, the K dimension
+// of an MFMA step = 8 taps of one kernel row x 4 channels) for problems of benchmark size (the 3 -> 64 5x5 layer of
+// ESPCN on 64 x 256x256: 16384 tiles, 1.04 GB of output).
+//
+// Why: the per-tile kernel's phases do not overlap.  SRK_ROWS_DBG ablations on that layer (320 us): without the halo
+// loads 232 us (the 19 MB input costs 90 us of pure latency: every block waits for its own few loads), without the
+// epilogue 170, without the MFMAs 243, loop skeleton + per-step filter copies alone 63; a linear fill of the output
+// runs in 180 us on the same box (tools/micro/store_pattern.hip: 64-byte segments per pixel store as fast as whole
+// lines).  Here, as in k_conv_bfw:
+//   * one persistent block per CU, the filter planes of its 32-channel slice copied to LDS once;
+//   * 4 producer waves stage the halo of tile s+1 (one thread per pixel: <= 4 floats -> {h, l} 16-bit planes, 16 bytes
+//     per pixel) while 8 consumer waves run the MFMAs of tile s; the loads of tile s+2 are already in flight;
+//   * consumers (32 pixels x 32 channels each, transposed product: a lane holds 4 consecutive channels of a pixel)
+//     store the finished tile from registers, one or two 16-byte stores between the K steps of the next tile.
+// Output-channel slices (nsl = OC / 32) sit on neighbouring blocks of one XCD; the input is so small that staging it
+// once per slice costs nothing.  Arithmetic and summation order are those of k_conv_bf3_rows (bf16x3 / f16x3).
+#include "srk_common.h"
+#include "conv_problem.h"
+#include "conv_tile.h"
+#include "bf16_frag.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace srk {
+
+template <int I0, int I1, typename F>
+__device__ __forceinline__ void rw_static_for(F&& f) {
+  if constexpr (I0 < I1) {
+    f(std::integral_constant<int, I0>{});
+    rw_static_for<I0 + 1, I1>(f);
+  }
+}
+
+constexpr int RW_IT = 2;  // staging register batches: halos of <= 512 * 2 pixels
+
+struct RowswParams {
+  MfmaConvParams P;
+  const uint4* wq;         // row-packed planes [kh][ks][64-channel block][plane][group][NBfull] (bf16, or the fp16 section)
+  const float* w_descale;  // F16: trailer {2^-kw, 2^kw} of the fp16 section
+  int KS, NBfull, OCb, NPIXp, ntiles, nsl;
+  unsigned out_bytes;
+  int dbg;  // ablation (SRK_ROWSW_DBG): 1 no global loads, 2 no stores, 4 no MFMA loop, 16 no LDS commit
+};
+
+// add-and-carry walk over the tiles first, first + step, ... of a block (wave-uniform, scalar registers): a 32-bit
+// division is ~40 VALU instructions = 160 SIMD cycles per wave, and the per-stage decode had three of them
+struct RowswWalk {
+  int n, y, x;
+  __device__ __forceinline__ void init(int tile, int tiles_x, int img_tiles) {
+    n = tile / img_tiles;
+    const int q = tile - n * img_tiles;
+    y = q / tiles_x;
+    x = q - y * tiles_x;
+    n = __builtin_amdgcn_readfirstlane(n);
+    y = __builtin_amdgcn_readfirstlane(y);
+    x = __builtin_amdgcn_readfirstlane(x);
+  }
+  __device__ __forceinline__ void advance(int st_n, int st_y, int st_x, int tiles_x, int tiles_y) {
+    x += st_x;
+    y += st_y;
+    n += st_n;
+    if (x >= tiles_x) {
+      x -= tiles_x;
+      ++y;
+    }
+    if (y >= tiles_y) {
+      y -= tiles_y;
+      ++n;
+    }
+  }
+};
+
+template <int NTW, int QT, bool F16>
+__global__ __launch_bounds__(512, 2) void k_conv_rowsw(RowswParams B) {
+  constexpr bool WREG = NTW * QT <= 12;
+  constexpr int NCW = 8, MTW = 2, NTHR = 512, NB = 16 * NTW;
+  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+  const MfmaConvParams& P = B.P;
+  constexpr int wslot = 8 * NB;  // uint4 per K step: [plane 2][group 4][NB]
+  uint4* wl = smem4;
+  uint4* hal0 = smem4 + QT * wslot;  // 2 buffers x NPIXp pixels x {h: 4 x 16 bit, l: 4 x 16 bit}
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int npx = P.TH * P.TW, npix = P.HH * P.HW;
+  float sx = 1.f, dsc = 1.f;
+  if constexpr (F16) {
+    const int kx = amax_scale_exp(amax_read(P.ep.x_amax));
+    sx = exp2i(kx);
+    dsc = exp2i(-kx) * B.w_descale[0];
+  }
+  const int nsl = B.nsl;
+  const int xcd = blockIdx.x & 7;
+  const int sl = (blockIdx.x >> 3) % nsl, bi = (blockIdx.x >> 3) / nsl;
+  for (int e = tid; e < QT * wslot; e += NTHR) {
+    const int q = e / wslot, w = e - q * wslot;
+    const int pg = w / NB, o = w - pg * NB;
+    const int oc = sl * NB + o, ocb = oc / B.NBfull;
+    wl[e] = B.wq[((size_t)q * B.OCb + ocb) * (size_t)(8 * B.NBfull) + pg * B.NBfull + (oc - ocb * B.NBfull)];
+  }
+  // pixels past the halo (the padded tap slots of the last row read them; they meet zero filter taps and must be finite)
+  for (int e = tid; e < 2 * (B.NPIXp - npix); e += NTHR) {
+    const int b = e / (B.NPIXp - npix), i = e - b * (B.NPIXp - npix);
+    hal0[(size_t)b * B.NPIXp + npix + i] = make_uint4(0, 0, 0, 0);
+  }
+  // tiles of this block: XCD-aware contiguous ranges (see k_conv_bfw)
+  const int nblk = gridDim.x;
+  int first, count;
+  const int nb_x = ((nblk + 7 - xcd) >> 3) / nsl;
+  {
+    const int per_x = B.ntiles >> 3, rem_x = B.ntiles & 7;
+    const int tiles_x = per_x + (xcd < rem_x ? 1 : 0);
+    const int start_x = xcd * per_x + (xcd < rem_x ? xcd : rem_x);
+    first = start_x + bi;
+    count = bi < tiles_x ? (tiles_x - bi + nb_x - 1) / nb_x : 0;
+  }
+  const int S = count;
+  const int img_tiles = P.tiles_x * P.tiles_y;
+  const int st_n = nb_x / img_tiles, st_y = (nb_x - st_n * img_tiles) / P.tiles_x, st_x = nb_x - st_n * img_tiles - st_y * P.tiles_x;
+  RowswWalk wi, wc;  // tile of the next issue() / of the next compute stage
+  wi.init(first, P.tiles_x, img_tiles);
+  wc = wi;
+
+  // ---- staging (every thread: pixels tid, tid + 512 of the halo): loads one stage ahead of the LDS commit ----------
+  float pv[RW_IT][4];
+  int hy0[RW_IT], hx0[RW_IT];
+#pragma unroll
+  for (int k = 0; k < RW_IT; ++k) {
+    const int hq = tid + NTHR * k;
+    hy0[k] = hq / P.HW;
+    hx0[k] = hq - hy0[k] * P.HW;
+  }
+  // Loads are unconditional and branch-free (clamped addresses; out-of-image pixels are zeroed by a select at commit
+  // time): a load under a divergent branch gets an s_waitcnt vmcnt(0) at the join, which serialises the memory
+  // latency of every pixel slot into the stage.
+  const size_t plane = (size_t)P.IH * P.IW;
+  const size_t est = P.in_nchw ? plane : 1;  // element stride between the channels of a pixel
+  const size_t e1 = P.IC > 1 ? est : 0, e2 = P.IC > 2 ? 2 * est : 0, e3 = P.IC > 3 ? 3 * est : 0;
+  int vmask = 0;  // bit k: slot k is a pixel of the halo inside the image
+  auto issue = [&]() {
+    const int n = wi.n, iyb = wi.y * P.TH + P.iy0, ixb = wi.x * P.TW + P.ix0;
+    wi.advance(st_n, st_y, st_x, P.tiles_x, P.tiles_y);
+    if (B.dbg & 1) return;
+    vmask = 0;
+    const float* img = P.in + (size_t)n * P.IC * plane;
+#pragma unroll
+    for (int k = 0; k < RW_IT; ++k) {
+      const int iy = iyb + hy0[k], ix = ixb + hx0[k];
+      const bool ok = tid + NTHR * k < npix && (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW;
+      vmask |= ok ? (1 << k) : 0;
+      const int cy = min(max(iy, 0), P.IH - 1), cx = min(max(ix, 0), P.IW - 1);
+      const size_t pix = (size_t)cy * P.IW + cx;
+      const float* src = img + (P.in_nchw ? pix : pix * P.IC);
+      pv[k][0] = src[0];
+      pv[k][1] = src[e1];
+      pv[k][2] = src[e2];
+      pv[k][3] = src[e3];
+    }
+  };
+  auto commit = [&](uint4* hal) {
+    if (B.dbg & 16) return;
+#pragma unroll
+    for (int k = 0; k < RW_IT; ++k) {
+      const int hq = tid + NTHR * k;
+      if (hq < npix) {
+        uint2 hu, lu;
+        if constexpr (F16) {
+          typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+          f16x4 h, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xs = (((vmask >> k) & 1) && e < P.IC) ? pv[k][e] * sx : 0.f;
+            const _Float16 hh = (_Float16)xs;
+            h[e] = hh;
+            l[e] = (_Float16)(xs - (float)hh);
+          }
+          hu = __builtin_bit_cast(uint2, h);
+          lu = __builtin_bit_cast(uint2, l);
+        } else {
+          typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+          bf16x4 h, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xv = (((vmask >> k) & 1) && e < P.IC) ? pv[k][e] : 0.f;
+            const __bf16 hh = (__bf16)xv;
+            h[e] = hh;
+            l[e] = (__bf16)(xv - (float)hh);
+          }
+          hu = __builtin_bit_cast(uint2, h);
+          lu = __builtin_bit_cast(uint2, l);
+        }
+        hal[hq] = make_uint4(hu.x, hu.y, lu.x, lu.y);
+      }
+    }
+  };
+
+  // ---- MFMA side ---------------------------------------------------------------------------------------------------
+  const int pw = wave;
+  int hp[MTW];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) {
+    int m = pw * (16 * MTW) + mt * 16 + j;
+    if (m >= npx) m = 0;
+    const int r = m / P.TW, c = m - r * P.TW;
+    hp[mt] = r * P.HW + c + 2 * kq;  // K slots kq*8 .. kq*8+7 = taps 2kq, 2kq+1 of the row x 4 channels
+  }
+  int wrow[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) wrow[nt] = kq * NB + nt * 16 + j;
+  f32x4 bias4[NTW];
+  int coff[NTW], poff[MTW], pix_ok[MTW];
+  {
+    const EpiTile e0 = epi_tile_setup(P, 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+      const int m = pw * (16 * MTW) + mt * 16 + j;
+      const int r = m / P.TW, c = m - r * P.TW;
+      pix_ok[mt] = m < npx ? ((r << 16) | c) : -1;
+      poff[mt] = r * e0.RS + c * e0.CS;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const EpiCol cl = epi_col_setup(P.ep, P.OW, P.OC, sl * NB + nt * 16 + kq * 4);
+      coff[nt] = (int)cl.off_oc;
+      bias4[nt] = cl.bias;
+    }
+  }
+  const float act_slope = P.ep.act == SRK_ACT_NONE ? 1.f
+                          : P.ep.act == SRK_ACT_RELU ? 0.f
+                          : P.ep.act == SRK_ACT_PRELU ? P.ep.prelu_w[0] : P.ep.slope;
+  f32x4 acc[NTW][MTW], pend[NTW][MTW];
+  float amax = 0.f;
+  // Deferred stores are UNCONDITIONAL buffer stores (pixels outside the tile / the image, and the first stage with nothing
+  // parked, carry an out-of-range offset that the buffer unit drops): a store under a branch is one the compiler cannot
+  // count, and the staging loads' s_waitcnt then degrades to vmcnt(0) -- every stage waited for the write
+  // acknowledgements of the previous tile (measured: 300 -> ... us on the c2 first layer).
+  constexpr unsigned kDrop = 0x80000000u;  // (host: the output tensor is smaller than 2 GiB)
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(P.out, 0, B.out_bytes, 0x00020000);
+  unsigned pend_voff[MTW];  // byte offset of the lane's pixel mt (channel group 0 of the slice), or kDrop
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) pend_voff[mt] = kDrop;
+  constexpr int NST = NTW * MTW;
+  // the parked tile leaves in the FIRST K steps of the next one: loads and stores share vmcnt and complete out of order
+  // with each other, so the staging commit at the end of the stage waits for every store issued before it -- by then
+  // they are two K steps old
+  constexpr int SPREAD = QT > 2 ? QT - 2 : 1;
+  constexpr int PER_STEP = (NST + SPREAD - 1) / SPREAD;
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  auto store_slot = [&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int mt = q / NTW, nt = q - mt * NTW;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, pend[nt][mt]), orsrc, (int)(pend_voff[mt] + 4u * (unsigned)coff[nt]), 0, 0);
+  };
+  if (S > 0) {
+    issue();
+    commit(hal0);
+    if (S > 1) issue();
+  }
+  // everything loaded before the loop must have landed before it: a first use inside the loop puts an
+  // s_waitcnt vmcnt(0) into every iteration (it would wait for the previous tile's store acknowledgements)
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) asm volatile("" ::"v"(bias4[nt]));
+  asm volatile("" ::"v"(act_slope));
+  __syncthreads();  // filter and tile 0 visible
+  // WREG: the lane's filter fragments of every K step stay in registers for the whole kernel (QT * 2 * NTW x 16 bytes);
+  // with them in LDS each wave re-reads the whole filter per 32 pixels and the LDS pipe is as busy as the MFMA pipe
+  uint4 wreg[WREG ? QT : 1][2][NTW];
+  if constexpr (WREG) {
+#pragma unroll
+    for (int q = 0; q < QT; ++q)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        wreg[q][0][nt] = wl[q * wslot + wrow[nt]];
+        wreg[q][1][nt] = wl[q * wslot + 4 * NB + wrow[nt]];
+      }
+  }
+  for (int s = 0; s < S; ++s) {
+    const int n = wc.n, r0 = wc.y * P.TH, c0 = wc.x * P.TW;
+    wc.advance(st_n, st_y, st_x, P.tiles_x, P.tiles_y);
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {  // (waves past the end of a ragged tile run on pixel 0 and drop their stores: no branch around the stores)
+      const uint4* hal = hal0 + (size_t)(s & 1) * B.NPIXp;
+      uint4 fa[WREG ? 1 : 2][2][NTW], fb[2][2][MTW];  // [buffer][plane][tile]
+      int toff = 0, ks = 0, qq = 0;
+      auto load_frags = [&](uint4 (&a)[2][NTW], uint4 (&b)[2][MTW]) {
+        const uint4* hb = hal + toff;
+        const uint4* wt = wl + qq * wslot;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          const uint4 p0 = hb[hp[mt]], p1 = hb[hp[mt] + 1];
+          b[0][mt] = make_uint4(p0.x, p0.y, p1.x, p1.y);
+          b[1][mt] = make_uint4(p0.z, p0.w, p1.z, p1.w);
+        }
+        if constexpr (!WREG) {
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) {
+            a[0][nt] = wt[wrow[nt]];
+            a[1][nt] = wt[4 * NB + wrow[nt]];
+          }
+        }
+        ++qq;
+        toff += 8;
+        if (++ks == B.KS) {
+          ks = 0;
+          toff += P.HW - 8 * B.KS;
+        }
+      };
+      auto mfmas = [&](const uint4 (&a)[2][NTW], const uint4 (&b)[2][MTW]) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = mfma16x<F16>(a[0][nt], b[1][mt], acc[nt][mt]);  // w_h * x_l
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = mfma16x<F16>(a[1][nt], b[0][mt], acc[nt][mt]);  // w_l * x_h
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = mfma16x<F16>(a[0][nt], b[0][mt], acc[nt][mt]);  // w_h * x_h
+      };
+      if (!(B.dbg & 4)) load_frags(fa[0], fb[0]);
+      if (!(B.dbg & 4)) rw_static_for<0, QT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if (t + 1 < QT) load_frags(fa[WREG ? 0 : ((t + 1) & 1)], fb[(t + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (WREG) mfmas(wreg[t], fb[t & 1]); else mfmas(fa[t & 1], fb[t & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        rw_static_for<(t * PER_STEP < NST ? t * PER_STEP : NST), ((t + 1) * PER_STEP < NST ? (t + 1) * PER_STEP : NST)>(
+            [&](auto qc) { store_slot(qc); });
+      });
+      if (s + 1 < S) commit(hal0 + (size_t)((s + 1) & 1) * B.NPIXp);  // (that buffer was last read in stage s - 1)
+      if (s + 2 < S) issue();
+      // tile finished: park it (C/D col = lane & 15 = pixel, rows kq*4 + reg = 4 consecutive channels per M tile)
+      const unsigned tile_off = 4u * (unsigned)epi_tile_setup(P, n, r0, c0).off0;
+      int pend_mask = 0;
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) {
+        const int r = pix_ok[mt] >> 16, c = pix_ok[mt] & 0xffff;
+        const bool ok = pix_ok[mt] >= 0 && r0 + r < P.PH && c0 + c < P.PW && !(B.dbg & 2);
+        if (ok) pend_mask |= 1 << mt;
+        pend_voff[mt] = ok ? tile_off + 4u * (unsigned)poff[mt] : kDrop;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          f32x4 v = acc[nt][mt];
+          if constexpr (F16) v *= dsc;
+          v += bias4[nt];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : act_slope * v[e];
+          pend[nt][mt] = v;
+          if (P.ep.y_amax && ((pend_mask >> mt) & 1)) amax = abs_max4(amax, v);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  rw_static_for<0, NST>([&](auto qc) { store_slot(qc); });  // the last tile (S = 0: nothing parked, dropped)
+  if (P.ep.y_amax) amax_commit(P.ep.y_amax, amax, blockIdx.x + wave, amax_peek(P.ep.y_amax, blockIdx.x + wave));
+}
+
+// the tile (<= 256 pixels) that covers PH x PW with the fewest tiles and a halo of at most cap_px pixels
+static bool rowsw_pick_tile(int PH, int PW, int KHv, int KWv, long cap_px, TilePick& best) {
+  bool found = false;
+  long best_tiles = 0, best_halo = 0;
+  const int maxTW = PW < 256 ? PW : 256;
+  for (int TW = 1; TW <= maxTW; ++TW) {
+    int TH = 256 / TW;
+    if (TH > PH) TH = PH;
+    for (; TH >= 1; --TH) {
+      const int HH = TH - 1 + KHv, HWd = TW - 1 + KWv;
+      if ((long)HH * HWd > cap_px) continue;
+      const long tiles = (long)cdiv(PH, TH) * cdiv(PW, TW);
+      const long halo = (long)HH * HWd * tiles;
+      if (!found || tiles < best_tiles || (tiles == best_tiles && halo < best_halo)) {
+        found = true;
+        best_tiles = tiles;
+        best_halo = halo;
+        best = TilePick{TH, TW, (int)cdiv(PH, TH), (int)cdiv(PW, TW), HH, HWd, (double)PH * PW / ((double)tiles * 256.0)};
+      }
+      break;
+    }
+  }
+  return found;
+}
+
+static inline int rowsw_steps(const GatherConv& g) { return g.KH * ((g.KW + 7) / 8); }
+
+// Applicability: stride-1 CONV gathers with Cin <= 4 (NHWC or NCHW in place), OC a multiple of 64, 3 or 5 K steps
+// (3x3 and 5x5 filters), every output group on the 16-byte store path, the branch-free activations, an output below
+// 2 GiB, and at least two 256-pixel tiles per CU.  SRK_ROWSW: 0 never, 1 whenever applicable, unset = automatic.
+bool conv_rowsw_applicable(const GatherConv& g, const Epi& ep, const float* in, const float* out, const float* mask_y) {
+  const char* e = getenv("SRK_ROWSW");
+  const int mode = e ? atoi(e) : 2;
+  if (mode == 0 || mask_y || g.trans || g.stride != 1 || g.in_ps_r > 1 || g.IC > 4 || g.IC < 1) return false;
+  if (g.OC % 64 != 0 || g.OC < 64) return false;
+  const int Q = rowsw_steps(g);
+  if (Q != 3 && Q != 5) return false;
+  if (!conv_epi_all_vector(g.OC, ep, out)) return false;
+  if (ep.residual || (ep.act == SRK_ACT_PRELU && ep.prelu_n > 1)) return false;
+  if (ep.act != SRK_ACT_NONE && ep.act != SRK_ACT_RELU && ep.act != SRK_ACT_LRELU && ep.act != SRK_ACT_PRELU) return false;
+  if ((long)g.N * g.OH * g.OW * g.OC >= (1L << 29)) return false;  // 32-bit byte offsets into an output below 2 GiB (kDrop)
+  if ((long)g.N * g.OH * g.OW >= (1L << 30) || (long)g.IH * g.IW * g.IC >= (1L << 30)) return false;
+  (void)in;
+  if (mode == 1) return true;
+  return (long)g.N * g.OH * g.OW >= 256L * 2 * kNumCU;
+}
+
+template <int NTW, int QT>
+static int rowsw_launch(const RowswParams& B, size_t lds, int grid, hipStream_t s) {
+  if (B.w_descale) {
+    static LdsLimit limh;
+    limh.ensure(reinterpret_cast<const void*>(&k_conv_rowsw<NTW, QT, true>), lds);
+    note_kernel("k_conv_rowsw<%d,%d,f16>", NTW, QT);
+    hipLaunchKernelGGL((k_conv_rowsw<NTW, QT, true>), dim3(grid), dim3(512), lds, s, B);
+    return check_launch("conv_rowsw");
+  }
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&k_conv_rowsw<NTW, QT, false>), lds);
+  note_kernel("k_conv_rowsw<%d,%d>", NTW, QT);
+  hipLaunchKernelGGL((k_conv_rowsw<NTW, QT, false>), dim3(grid), dim3(512), lds, s, B);
+  return check_launch("conv_rowsw");
+}
+
+// returns -1 when no tile fits (the caller falls back to k_conv_bf3_rows).  f16: the f16x3 arithmetic (ep.x_amax set)
+int conv_rowsw_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s,
+                      bool f16) {
+  const size_t elems = (size_t)g.KH * g.KW * g.IC * g.OC;
+  const char* prepared = reinterpret_cast<const char*>(wp) + bf3_prepared_offset(elems);
+  const char* fsec = prepared + f16_section_offset(g.IC, g.OC, g.KH * g.KW);
+  const uint4* wq = reinterpret_cast<const uint4*>(f16 ? fsec : prepared);
+  const float* w_descale = f16 ? reinterpret_cast<const float*>(fsec + bf3_main_bytes(g.IC, g.OC, g.KH * g.KW)) : nullptr;
+  return for_each_phase(g, in, wp, out, ep, nullptr, 0.f, [&](const MfmaConvParams& P0) {
+    RowswParams B{};
+    B.P = P0;
+    MfmaConvParams& P = B.P;
+    B.wq = wq;
+    B.w_descale = w_descale;
+    B.KS = (P.KWv + 7) / 8;
+    B.NBfull = P.OC >= 64 ? 64 : P.OC;
+    B.OCb = (P.OC + 63) / 64;
+    const int Q = P.KHv * B.KS;
+    // 64-channel slices.  (32-channel slices double the number of stages, and with them the per-stage park / staging /
+    // barrier work: measured 366 us against 289 us on the c2 first layer, even with the filter in registers.)
+    constexpr int ntw = 4;
+    B.nsl = P.OC / (16 * ntw);
+    static const int dbg = getenv("SRK_ROWSW_DBG") ? atoi(getenv("SRK_ROWSW_DBG")) : 0;
+    B.dbg = dbg;
+    TilePick best{};
+    if (P.is != 1 || !rowsw_pick_tile(P.PH, P.PW, P.KHv, P.KWv, 768, best)) return -1;
+    P.TH = best.TH; P.TW = best.TW; P.tiles_y = best.tiles_y; P.tiles_x = best.tiles_x; P.HH = best.HH; P.HW = best.HW;
+    B.NPIXp = best.HH * best.HW + 16;  // +16: the last row's padded tap slots read past the halo
+    const size_t lds = ((size_t)Q * 8 * 16 * ntw + (size_t)2 * B.NPIXp) * 16;
+    const long ntiles = (long)P.tiles_x * P.tiles_y * P.N;
+    if (ntiles >= (1L << 30)) return -1;
+    B.ntiles = (int)ntiles;
+    B.out_bytes = (unsigned)((size_t)P.N * P.OH * P.OW * P.OC * sizeof(float));
+    int grid = kNumCU - kNumCU % (8 * B.nsl);
+    const long want = ((ntiles + 7) / 8) * 8 * B.nsl;
+    if (grid == 0) return -1;
+    if (want < grid) grid = (int)want;
+    if (Q == 3) return rowsw_launch<4, 3>(B, lds, grid, s);
+    if (Q == 5) return rowsw_launch<4, 5>(B, lds, grid, s);
+    return -1;
+  });
+}
+
+}  // namespace srk

@@ -304,7 +304,7 @@ def conv_forward_raw(x, wp, bias_p, weight_shape_src, cfg, prelu_w=None, residua
         d.x_nchw = 0
     check(lib.srk_conv2d_forward(ctypes.byref(d), ptr(x), ptr(wp), ptr(y), ctypes.byref(ep), stream_ptr()),
           "srk_conv2d_forward")
-    if ya is not None and lib.srk_last_kernel_name().startswith((b"k_conv_bfd", b"k_conv_bfw", b"k_conv_bf3_rows")):
+    if ya is not None and lib.srk_last_kernel_name().startswith((b"k_conv_bfd", b"k_conv_bfw", b"k_conv_bf3_rows", b"k_conv_rowsw")):
         _tag_amax(y, ya)
     elif F16X3 and d.algo in (_lib.ALGO_MFMA, _lib.ALGO_MFMA_BF16X6):
         _tag_amax(y, None)   # a faithful-class conv whose kernel leaves no maximum: worth one srk_absmax pass downstream

@@ -180,6 +180,48 @@ def test_conv_wave_specialized(gpu, monkeypatch, cin, cout, k, p, H, W, N, act, 
     assert rel_err(y, ref.float()) < 1e-4
 
 
+@pytest.mark.parametrize("cin,cout,k,p,H,W,N,act,mode", [
+    (3, 64, 5, 0, 40, 44, 2, "relu", "mixed"),      # ESPCN first layer (c2), f16x3, NCHW input read in place
+    (3, 64, 5, 0, 40, 44, 2, "relu", "bf16x3"),
+    (3, 64, 3, 1, 41, 41, 3, "relu", "mixed"),      # VDSR / EDSR first layer: 3 K steps (filter in registers), padding
+    (1, 64, 5, 2, 19, 70, 1, "lrelu", "bf16x3"),    # one channel, ragged tiles
+    (4, 128, 3, 1, 17, 23, 2, None, "bf16x3"),      # four channels, two 64-channel slices
+    (3, 64, 5, 2, 8, 300, 1, None, "mixed"),        # fewer tiles than XCDs
+    (2, 64, 3, 0, 33, 18, 5, "relu", "mixed"),      # two channels, no padding
+])
+def test_conv_first_layer_wave_specialized(gpu, monkeypatch, cin, cout, k, p, H, W, N, act, mode):
+    """k_conv_rowsw (persistent, producer / consumer waves, deferred stores) forced onto small problems, against the
+    per-tile row-packed kernel it replaces at benchmark size (same arithmetic and summation order: equal outputs) and
+    torch fp64."""
+    pkg = _pkg()
+    ops = pkg.ops
+    x = fill.randn((N, cin, H, W), 291)
+    w = fill.randn((cout, cin, k, k), 292, (2.0 / (cin * k * k)) ** 0.5)
+    b = fill.randn((cout,), 293, 0.1)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 1, p)
+    if act == "relu":
+        ref = torch.relu(ref)
+    elif act == "lrelu":
+        ref = torch.nn.functional.leaky_relu(ref, 0.2)
+    code = {None: 0, "relu": 1, "lrelu": 3}[act]
+    cfg = ops.ConvCfg(1, p, False, 0, code, 0.2 if act == "lrelu" else 0.0, 0, ALGOS["auto"])
+    outs = {}
+    monkeypatch.setattr(ops, "F16X3_ALWAYS", True)   # (small problems: the size policy would keep the fp32 MFMA kernel)
+    ops.set_precision(mode)
+    try:
+        for sw in ("0", "1"):
+            monkeypatch.setenv("SRK_ROWSW", sw)
+            with torch.no_grad():
+                outs[sw] = ops.conv2d_infer(x.to(gpu), w.to(gpu), b.to(gpu), None, cfg)
+            name = pkg._lib.load().srk_last_kernel_name().decode()
+            assert name.startswith("k_conv_rowsw<" if sw == "1" else "k_conv_bf3_rows<"), name
+            assert ("f16" in name) == (mode == "mixed"), name
+    finally:
+        ops.set_precision("mixed")
+    assert torch.equal(outs["0"], outs["1"])
+    assert rel_err(outs["1"], ref.float()) < (2e-6 if mode == "mixed" else 1e-4)
+
+
 @pytest.mark.parametrize("cin,cout,H,W,N,act,ps", [
     (64, 64, 41, 41, 3, "relu", 0),     # VDSR body layer: two 32-channel slices (the whole filter is 147 KB)
     (64, 256, 16, 24, 2, None, 2),      # EDSR up-sampler: eight slices over four 64-channel filter blocks, PS store

@@ -14,12 +14,16 @@ pkg.ops.set_precision("mixed")
 
 
 def t(fn, n=60):
+    """us per call, calls queued back to back (one call bracketed by events would include the host's launch path)"""
     for _ in range(3): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     best = 1e9
-    for _ in range(n):
-        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1))
+    for _ in range(3):
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n // 3): fn()
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / (n // 3))
     return best * 1e3
 
 
@@ -35,3 +39,7 @@ with torch.no_grad():
             else: os.environ.pop("SRK_NO_YAMAX", None)
             us = t(lambda: l(hs[i]))
             print("layer %d  NO_YAMAX=%-1s  %8.1f us  %s" % (i, v, us, lib.srk_last_kernel_name().decode()))
+    for sw in ("0", "1", "0", "1"):
+        os.environ["SRK_ROWSW"] = sw
+        us = t(lambda: net.layers[0](hs[0]), 60)
+        print("layer 0 SRK_ROWSW=%s  %8.1f us  %s" % (sw, us, lib.srk_last_kernel_name().decode()))
