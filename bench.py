@@ -191,7 +191,7 @@ def pmc_traffic(kernel_label, batch, lr_size):
         rest = args[len(ints):]
         if "f16" in rest or "mask" in rest or not rest:          # the dispatcher's label
             return base, ints, "f16" in rest, "mask" in rest
-        if base == "k_conv_bfw":                                  # <NTW, TT, MTW, F16, MASK>
+        if base == "k_conv_bfw":                                  # <NTW, TT, MTW, F16, MASK, OMASK>
             return base, ints, rest[0] == "true", len(rest) > 1 and rest[1] == "true"
         if base == "k_conv_bf3_rows":                             # <NT, VEC_ONLY, F16>
             return base, ints, rest[-1] == "true", False
@@ -225,9 +225,9 @@ def training_roofline(tag, px, layer_px_note, layers_per_step=1, steps=5):
     t = 4.0 * 64 * px                     # one 64-channel fp32 tensor of the layer
     flop = 2.0 * px * 64 * 64 * 9
     # (role, kernel-name keys, algorithmic bytes per LAYER, operands, layers' worth of FLOPs per launch or None = from calls)
-    roles = [("forward", ("k_conv_bfw<2, 9, 2, true, false>", "k_conv_bfd<2, 2, 2, 2", "k_conv_bfd<2, 2, 2, 3", "k_conv_bfd<4, 4, 1, 2"),
+    roles = [("forward", ("k_conv_bfw<2, 9, 2, true, false", "k_conv_bfd<2, 2, 2, 2", "k_conv_bfd<2, 2, 2, 3", "k_conv_bfd<4, 4, 1, 2"),
               2 * t, "x, y", 1.0),
-             ("data_gradient", ("k_conv_bfw<2, 9, 2, false, true>", "k_conv_bf3<4, 4, true>"), 3 * t, "dy, activation mask, dx", 1.0),
+             ("data_gradient", ("k_conv_bfw<2, 9, 2, false, ", "k_conv_bf3<4, 4, true>"), 3 * t, "dy, one activation (mask of dy, or of dx for the layer below), dx", 1.0),
              ("weight_gradient", ("k_wgrad_bf<2, 2, 2, true",), 3 * t, "x, dy, activation mask", None),
              # residual blocks fused per tile (conv -> ReLU -> conv -> + skip in one launch): useful work of two layers
              ("fused_block_forward", ("k_res2<2, false", "k_res2<3, false"), 3 * t, "x, intermediate, y", 2.0),

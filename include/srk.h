@@ -196,6 +196,16 @@ int srk_conv2d_forward(const srk_conv_desc* d, const float* x, const float* w_pa
  * gradient) as dispatched from loss.backward() — edsr.py:154, vdsr.py:146, srgan.py:286,309. */
 int srk_conv2d_backward_data(const srk_conv_desc* d, const float* dy, const float* w_packed_bwd, float* dx,
                              const srk_bwd_mask* mask, const float* add_to, void* stream);
+/* The same gradient, already multiplied by the ReLU gradient of the layer that PRODUCED x (`x_relu` = this conv's
+ * input x, the output of an upstream conv + ReLU: dx <- dx * (x_relu > 0)).  The upstream layer's backward
+ * (aten::threshold_backward inside loss.backward(), vdsr.py:146) would apply exactly this mask to its dy -- reading x
+ * once more in its data-gradient AND its weight-gradient kernel; applied here it costs one read at the output tile,
+ * and that layer's srk_conv2d_backward_* calls take mask = NULL.  Only where the wave-specialised kernel runs the
+ * gradient (srk_conv2d_backward_data_relu_supported: stride-1 3x3 Conv2d, Cout <= 64 ... of benchmark size);
+ * SRK_ERR_UNSUPPORTED otherwise. */
+int srk_conv2d_backward_data_relu_supported(const srk_conv_desc* d, const float* dy, const float* dx, const srk_bwd_mask* mask);
+int srk_conv2d_backward_data_relu(const srk_conv_desc* d, const float* dy, const float* w_packed_bwd, float* dx,
+                                  const srk_bwd_mask* mask, const float* x_relu, void* stream);
 /* dw (torch layout, see srk_pack_weight_*) and db (may be NULL).  beta = 0 overwrites,
  * beta = 1 accumulates into dw/db (shared weights: lapsrn.py:40,44).  `workspace` holds the
  * split-K partial sums; size from srk_conv2d_backward_weight_workspace_bytes. */

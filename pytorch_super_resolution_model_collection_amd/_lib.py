@@ -64,6 +64,9 @@ _PROTOTYPES = {
     "srk_conv2d_forward": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, c_f, ctypes.POINTER(Epilogue), c_vp]),
     "srk_conv2d_backward_data": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, c_f, ctypes.POINTER(BwdMask), c_f,
                                          c_vp]),
+    "srk_conv2d_backward_data_relu_supported": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, ctypes.POINTER(BwdMask)]),
+    "srk_conv2d_backward_data_relu": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, c_f, ctypes.POINTER(BwdMask), c_f,
+                                              c_vp]),
     "srk_conv2d_backward_weight_workspace_bytes": (c_size, [ctypes.POINTER(ConvDesc)]),
     "srk_conv2d_backward_weight": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, ctypes.POINTER(BwdMask), c_f, c_f,
                                            c_float, c_vp, c_size, c_vp]),

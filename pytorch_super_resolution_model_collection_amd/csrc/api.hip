@@ -284,6 +284,43 @@ extern "C" int srk_conv2d_backward_data(const srk_conv_desc* d, const float* dy,
                     (hipStream_t)stream, "conv2d_backward_data");
 }
 
+static GatherConv bwd_data_gather(const srk_conv_desc* d) {
+  return GatherConv{d->N, d->OH, d->OW, d->Cout, d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad, !d->transposed, 0, 0};
+}
+
+extern "C" int srk_conv2d_backward_data_relu_supported(const srk_conv_desc* d, const float* dy, const float* dx,
+                                                       const srk_bwd_mask* mask) {
+  if (!d || validate_desc(d, "conv2d_backward_data_relu_supported") || d->dy_ps_r > 1) return 0;
+  const int algo = forced_algo(d->algo);
+  if (algo != SRK_ALGO_AUTO && algo != SRK_ALGO_MFMA_BF16X3) return 0;
+  const GatherConv g = bwd_data_gather(d);
+  Epi ep{};
+  ep.out_relu = dx ? dx : reinterpret_cast<const float*>(16);   // (any aligned non-null pointer: only its presence matters)
+  const float* a16 = reinterpret_cast<const float*>(16);
+  return conv_bfw_applicable(g, ep, dy ? dy : a16, dx ? dx : a16, mask ? mask->y : nullptr) ? 1 : 0;
+}
+
+extern "C" int srk_conv2d_backward_data_relu(const srk_conv_desc* d, const float* dy, const float* w_packed_bwd, float* dx,
+                                             const srk_bwd_mask* mask, const float* x_relu, void* stream) {
+  int rc = validate_desc(d, "conv2d_backward_data_relu");
+  if (rc) return rc;
+  SRK_REQUIRE(dy && w_packed_bwd && dx && x_relu, "conv2d_backward_data_relu: null tensor pointer");
+  SRK_REQUIRE((uintptr_t)x_relu % 16 == 0, "conv2d_backward_data_relu: x_relu must be 16-byte aligned");
+  if (!srk_conv2d_backward_data_relu_supported(d, dy, dx, mask)) {
+    set_error("conv2d_backward_data_relu: only where the wave-specialised kernel applies (srk_conv2d_backward_data_relu_supported)");
+    return SRK_ERR_UNSUPPORTED;
+  }
+  const GatherConv g = bwd_data_gather(d);
+  Epi ep{};
+  ep.out_relu = x_relu;
+  rc = conv_bfw_gather(g, dy, w_packed_bwd, dx, ep, mask ? mask->y : nullptr, mask ? mask->slope : 0.f, (hipStream_t)stream, false);
+  if (rc < 0) {
+    set_error("conv2d_backward_data_relu: no tile of the wave-specialised kernel fits this problem");
+    return SRK_ERR_UNSUPPORTED;
+  }
+  return rc;
+}
+
 extern "C" int srk_resblock2_supported(int N, int H, int W, int C) { return conv_res2_supported(N, H, W, C) ? 1 : 0; }
 
 static int resblock2_planes(int algo, const char* who) {

@@ -56,7 +56,7 @@ struct BfwParams {
   int dbg;  // ablation (SRK_DBG): 1 no global loads, 2 no epilogue, 4 no MFMA loop, 16 no LDS commit, 1024 no deferred stores
 };
 
-template <int NTW, int TT, int MTW, bool F16 = false, bool MASK = false>
+template <int NTW, int TT, int MTW, bool F16 = false, bool MASK = false, bool OMASK = false>
 __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_conv_bfw(BfwParams B) {
   constexpr int NCW = 16 / MTW;          // consumer waves: MTW 16-pixel groups each, 256 pixels per block
   constexpr int NTHR = 64 * (NCW + 4);   // + 4 producer waves
@@ -282,6 +282,11 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
   // for ~2000 cycles per tile -- measured 0.06-0.09 ms per layer; spread out, the stores ride under the MFMAs.)
   // Needs the tap loop unrolled at compile time (TT = taps per chunk; TT = 0: dynamic loop, immediate epilogue).
   f32x4 pend[NTW][MTW];
+  // OMASK (ep.out_relu: the data gradient leaves already multiplied by the ReLU gradient of the layer that produced this
+  // conv's input): that tensor's values at the tile's output positions are requested when the tile's LAST chunk stage
+  // begins -- unconditional loads, clamped to the tensor's first element for positions outside the tile -- and meet the
+  // accumulators when the tile is parked, nine taps later.
+  f32x4 om[OMASK ? NTW : 1][OMASK ? MTW : 1];
   float amax = 0.f;  // running maximum of what this lane stores (ep.y_amax)
   float* pend_base = P.out;  // wave-uniform: P.out + tile origin
   int pend_mask = 0;
@@ -307,6 +312,19 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
       for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (OMASK) {
+      if (cc == B.ICc - 1 && wave_live) {
+        const float* ob = P.ep.out_relu + epi_tile_setup(P, n, r0, c0).off0;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          const int r = pix_ok[mt] >> 16, c = pix_ok[mt] & 0xffff;
+          const bool ok = pix_ok[mt] >= 0 && r0 + r < P.PH && c0 + c < P.PW;
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt)
+            om[nt][mt] = *reinterpret_cast<const f32x4*>(ok ? ob + (coff[nt] + poff[mt]) : P.ep.out_relu);
+        }
+      }
     }
     if (wave_live && T > 0 && !(B.dbg & 4)) {
       const uint4* hal = hal0 + (size_t)(s & 1) * hbuf;
@@ -396,6 +414,10 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
           v += bias4[nt];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : act_slope * v[e];
+          if constexpr (OMASK) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = om[nt][mt][e] > 0.f ? v[e] : 0.f;
+          }
           pend[nt][mt] = v;
           if (P.ep.y_amax && ((pend_mask >> mt) & 1)) amax = abs_max4(amax, v);
         }
@@ -482,6 +504,7 @@ bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, co
   const int NB = g.OC / nsl;
   if (T > BFW_MAXTAPS - 1 || (T != 9 && NB > 48)) return false;  // (the 64-channel dynamic-tap variant spills)
   if (mask_y && (NB != 32 || T != 9 || (uintptr_t)mask_y % 16 != 0)) return false;
+  if (ep.out_relu && (NB != 32 || T != 9 || ep.ps_r > 1 || ep.act != SRK_ACT_NONE || (uintptr_t)ep.out_relu % 16 != 0)) return false;
   if (!conv_epi_all_vector(g.OC, ep, out)) return false;
   if (ep.residual || (ep.act == SRK_ACT_PRELU && ep.prelu_n > 1)) return false;
   if (ep.act != SRK_ACT_NONE && ep.act != SRK_ACT_RELU && ep.act != SRK_ACT_LRELU && ep.act != SRK_ACT_PRELU) return false;
@@ -497,16 +520,31 @@ bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, co
 
 template <int NTW, int TT, int MTW>
 static int bfw_launch_t(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
-  if constexpr (NTW == 2 && TT == 9 && MTW == 2) {
-    if (B.P.mask_y) {  // data gradient behind an activation (bf16x3)
+  if constexpr (NTW == 2 && TT == 9 && MTW == 2) {  // data gradients (bf16x3): mask on dy and / or ReLU gradient on dx
+    const dim3 blk(64 * (16 / MTW + 4));
+    if (B.P.mask_y && B.P.ep.out_relu) {
+      static LdsLimit limb;
+      limb.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, MTW, false, true, true>), lds);
+      note_kernel("k_conv_bfw<%d,%d,%d,mask,relu>", NTW, TT, MTW);
+      hipLaunchKernelGGL((k_conv_bfw<NTW, TT, MTW, false, true, true>), dim3(grid), blk, lds, s, B);
+      return check_launch("conv_bfw");
+    }
+    if (B.P.mask_y) {
       static LdsLimit limm;
-      limm.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, MTW, false, true>), lds);
+      limm.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, MTW, false, true, false>), lds);
       note_kernel("k_conv_bfw<%d,%d,%d,mask>", NTW, TT, MTW);
-      hipLaunchKernelGGL((k_conv_bfw<NTW, TT, MTW, false, true>), dim3(grid), dim3(64 * (16 / MTW + 4)), lds, s, B);
+      hipLaunchKernelGGL((k_conv_bfw<NTW, TT, MTW, false, true, false>), dim3(grid), blk, lds, s, B);
+      return check_launch("conv_bfw");
+    }
+    if (B.P.ep.out_relu) {
+      static LdsLimit limo;
+      limo.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, MTW, false, false, true>), lds);
+      note_kernel("k_conv_bfw<%d,%d,%d,relu>", NTW, TT, MTW);
+      hipLaunchKernelGGL((k_conv_bfw<NTW, TT, MTW, false, false, true>), dim3(grid), blk, lds, s, B);
       return check_launch("conv_bfw");
     }
   }
-  if (B.P.mask_y) return -1;
+  if (B.P.mask_y || B.P.ep.out_relu) return -1;
   if (B.w_descale) {  // f16x3 arithmetic
     static LdsLimit limh;
     limh.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, MTW, true>), lds);

@@ -25,6 +25,7 @@ struct Epi {
   int ps_r;
   const float* x_amax;  // SRK_AMAX_SLOTS floats (f16x3 kernels)
   float* y_amax;        // optional running max of |out| (kernels that support it)
+  const float* out_relu;  // optional: out <- out * (out_relu > 0), a tensor of out's shape (k_conv_bfw<2,9,2> only)
 };
 
 inline Epi make_epi(const srk_epilogue* e) {

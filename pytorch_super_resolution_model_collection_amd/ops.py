@@ -177,6 +177,27 @@ def to_nhwc(x):
     return y
 
 
+# ---- pre-masked gradients ---------------------------------------------------------------------------------------------
+# A conv with a fused ReLU multiplies its incoming dy by (y > 0) in BOTH backward kernels, reading y twice more.  When the
+# consumer of y is another conv whose data gradient runs on the wave-specialised kernel, that kernel applies the mask to
+# the dx it writes instead (srk_conv2d_backward_data_relu: y is its own input x, read once at the output tile) and marks
+# the tensor: `_srk_premasked = (address of y, version of dx)`.  The upstream backward skips its masks only if the
+# gradient it receives carries the mark for ITS y and is untouched since (autograd's fan-in accumulation adds in place
+# and bumps the version; a fresh sum carries no mark).  ReLU only: its 0/1 mask is idempotent, so a mark that got lost
+# merely costs the second application.  SRK_PREMASK=0 switches the protocol off.
+PREMASK = os.environ.get("SRK_PREMASK", "1") != "0"
+PREMASK_STATS = {"masked_dx": 0, "masks_skipped": 0}   # (tests: how often each half of the protocol ran)
+
+
+def _is_relu_output(x):
+    return PREMASK and getattr(x, "_srk_relu_out", None) == x._version
+
+
+def _premasked_for(dy, y):
+    t = getattr(dy, "_srk_premasked", None)
+    return PREMASK and t is not None and t == (y.data_ptr(), dy._version)
+
+
 def to_nchw(x):
     """channels_last tensor -> NCHW-contiguous copy (srk_nhwc_to_nchw). Used before Linear layers."""
     require_cuda(x)
@@ -486,6 +507,9 @@ class _Conv2d(torch.autograd.Function):
         ctx.weight_ref = weight
         ctx.bias_ref = bias
         need_mask = cfg.act in (ACT_RELU, ACT_LRELU)
+        ctx.x_relu_out = _is_relu_output(x)      # x = relu(conv(..)): this conv's dx may leave pre-masked (see PREMASK)
+        if cfg.act == ACT_RELU and residual is None and cfg.ps_r <= 1:
+            y._srk_relu_out = y._version
         ctx.save_for_backward(x, weight, y if need_mask else None)
         return y
 
@@ -494,6 +518,8 @@ class _Conv2d(torch.autograd.Function):
         lib = _lib.load()
         cfg = ctx.cfg
         x, weight, y = ctx.saved_tensors
+        premasked = y is not None and cfg.act == ACT_RELU and _premasked_for(dy, y)
+        PREMASK_STATS["masks_skipped"] += 1 if premasked else 0
         dy = to_nhwc(dy if (_is_nchw_dense(dy) or _is_nhwc_dense(dy)) else dy.contiguous())
         d = _make_desc(x.shape, weight, cfg, "bwd")
         dres = dy if ctx.has_res else None
@@ -516,7 +542,7 @@ class _Conv2d(torch.autograd.Function):
                 check(lib.srk_pixel_shuffle_backward(ptr(dy), ptr(dyc), d.N, d.OH, d.OW, d.Cout // (r * r), r,
                                                      stream_ptr()), "srk_pixel_shuffle_backward")
         mask = None
-        if y is not None and not os.environ.get("SRK_EXP_NOMASK"):
+        if y is not None and not premasked:
             mask = BwdMask(ptr(y), cfg.slope if cfg.act == ACT_LRELU else 0.0)
         mref = ctypes.byref(mask) if mask is not None else None
         dx = dw = db = None
@@ -567,8 +593,15 @@ class _Conv2d(torch.autograd.Function):
                 if tuple(add_to.shape) != tuple(dx.shape):
                     raise RuntimeError("conv backward: skip gradient %s does not match dx %s"
                                        % (tuple(add_to.shape), tuple(dx.shape)))
-            check(lib.srk_conv2d_backward_data(ctypes.byref(d), ptr(dyc), ptr(wpb), ptr(dx), mref, ptr(add_to),
-                                               stream_ptr()), "srk_conv2d_backward_data")
+            if (ctx.x_relu_out and add_to is None and d.dy_ps_r <= 1
+                    and lib.srk_conv2d_backward_data_relu_supported(ctypes.byref(d), ptr(dyc), ptr(dx), mref)):
+                check(lib.srk_conv2d_backward_data_relu(ctypes.byref(d), ptr(dyc), ptr(wpb), ptr(dx), mref, ptr(x),
+                                                        stream_ptr()), "srk_conv2d_backward_data_relu")
+                dx._srk_premasked = (x.data_ptr(), dx._version)
+                PREMASK_STATS["masked_dx"] += 1
+            else:
+                check(lib.srk_conv2d_backward_data(ctypes.byref(d), ptr(dyc), ptr(wpb), ptr(dx), mref, ptr(add_to),
+                                                   stream_ptr()), "srk_conv2d_backward_data")
         if need_w and not flat_mode:
             ws_bytes = lib.srk_conv2d_backward_weight_workspace_bytes(ctypes.byref(d))
             ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=dy.device)

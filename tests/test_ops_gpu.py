@@ -301,6 +301,55 @@ def test_conv_wave_specialized_data_gradient(gpu, monkeypatch, cin, cout, H, W, 
     assert rel_err(grads["1"], xr.grad.float()) < 1e-4
 
 
+@pytest.mark.parametrize("fan_out", [False, True])
+def test_premasked_gradients(gpu, monkeypatch, fan_out):
+    """Chain of conv + ReLU layers whose data gradients run on k_conv_bfw: each dx leaves multiplied by the ReLU gradient
+    of the layer below (srk_conv2d_backward_data_relu) and that layer skips its own masks.  Same numbers as with the
+    masks applied by every layer itself (multiplications by 0 / 1 commute with nothing in between) and vs torch fp64.
+    fan_out: the middle activation also feeds a skip connection -- its gradient is a sum, the mark must not survive."""
+    pkg = _pkg()
+    ops = pkg.ops
+    monkeypatch.setenv("SRK_BFW", "1")
+    monkeypatch.setenv("SRK_BF3_DIRECT", "0")   # (small problems: keep the K-split blocks of k_conv_bfd out of the comparison)
+    ops.set_precision("mixed")
+    N, C, H, W = 2, 64, 20, 33
+    x = fill.randn((N, C, H, W), 301)
+    ws = [fill.randn((C, C, 3, 3), 302 + i, (2.0 / (C * 9)) ** 0.5) for i in range(4)]
+    g = fill.randn((N, C, H, W), 310)
+
+    def chain(xx, ww, conv):
+        h1 = conv(xx, ww[0])
+        h2 = conv(h1, ww[1])
+        h3 = conv(h2, ww[2])
+        out = conv(h3, ww[3])
+        return out + h2 if fan_out else out
+
+    xr = x.double().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) for w in ws]
+    chain(xr, wr, lambda a, w: torch.relu(torch.nn.functional.conv2d(a, w, None, 1, 1))).backward(g.double())
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(ops, "PREMASK", on)
+        ops.PREMASK_STATS.update(masked_dx=0, masks_skipped=0)
+        xg = x.to(gpu).requires_grad_(True)
+        wg = [w.to(gpu).requires_grad_(True) for w in ws]
+        cfg = ops.ConvCfg(1, 1, False, 0, 1, 0.0, 0)
+        out = chain(xg, wg, lambda a, w: ops.conv2d(a, w, None, None, cfg))
+        out.backward(g.to(gpu))
+        ops.flush_wgrads()
+        res[on] = [xg.grad.clone()] + [w.grad.clone() for w in wg]
+        if on:   # three data gradients write into a ReLU output; without the skip all three marks reach their layer
+            assert ops.PREMASK_STATS["masked_dx"] == 3
+            assert ops.PREMASK_STATS["masks_skipped"] == (2 if fan_out else 3)
+        else:
+            assert ops.PREMASK_STATS == {"masked_dx": 0, "masks_skipped": 0}
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
+    assert rel_err(res[True][0], xr.grad.float()) < 1e-4
+    for a, w in zip(res[True][1:], wr):
+        assert rel_err(a, w.grad.float()) < 1e-4
+
+
 @pytest.mark.parametrize("cin,cout,k,s,p,op,H,W", [
     (64, 8, 9, 4, 3, 1, 8, 8),     # data gradient = 9x9 stride-4 gather over 64 channels: halo chunk > half the LDS
     (56, 32, 8, 4, 2, 0, 6, 9),
