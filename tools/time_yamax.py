@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-layer cost of the running-maximum bookkeeping (ep.y_amax) in the c2 (ESPCN x4, 64 x 256x256) f16x3 kernels:
-each layer timed alone on a fixed, tagged input with and without SRK_NO_YAMAX=1.   python tools/time_yamax.py"""
+each layer timed alone on a fixed, tagged input with and without SRK_NO_YAMAX=1; then the first layer on the per-tile
+(SRK_ROWSW=0) and the persistent (SRK_ROWSW=1) row-packed kernel.   python tools/time_yamax.py"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
