@@ -112,9 +112,18 @@ def test_srgan_adversarial_step(gpu, train_golden):
     _check_params(D, train_golden, "srgan.D", 5e-4)
 
 
-def test_graphed_step_equals_eager(gpu):
-    """hipGraph-captured step (zero_grad+fwd+loss+bwd+clip+SGD) reproduces the eager trajectory."""
+@pytest.mark.parametrize("forced", [False, True], ids=["default_kernels", "wave_specialised_kernels"])
+def test_graphed_step_equals_eager(gpu, monkeypatch, forced):
+    """hipGraph-captured step (zero_grad+fwd+loss+bwd+clip+SGD) reproduces the eager trajectory.  forced: the kernels a
+    benchmark-size VDSR step runs (k_conv_bfw channel slices forward and backward, pre-masked gradients, the persistent
+    first-layer kernel) on this small problem -- the marks that let a layer skip its masks are decided at capture time."""
     pkg = _pkg()
+    if forced:
+        monkeypatch.setenv("SRK_BFW", "1")
+        monkeypatch.setenv("SRK_ROWSW", "1")
+        monkeypatch.setenv("SRK_BF3_DIRECT", "0")
+        monkeypatch.setattr(pkg.ops, "F16X3_ALWAYS", True)
+        pkg.ops.PREMASK_STATS.update(masked_dx=0, masks_skipped=0)
     batches = [(B((4, 3, 17, 17), 50 + i).to(gpu), B((4, 3, 17, 17), 60 + i).to(gpu)) for i in range(4)]
 
     def make():
@@ -136,6 +145,8 @@ def test_graphed_step_equals_eager(gpu):
     losses = [float(g(*b)) for b in batches]
     assert rel_err(np.array(losses), np.array(ref_losses)) < 1e-5
     assert rel_err(opt_b.flat.data, opt_a.flat.data) < 1e-5
+    if forced:
+        assert pkg.ops.PREMASK_STATS["masked_dx"] > 0 and pkg.ops.PREMASK_STATS["masks_skipped"] > 0
 
 
 @pytest.mark.parametrize("model", ["edsr", "fsrcnn", "espcn", "srcnn", "lapsrn", "srgan_g", "srgan_d", "srgan_d_small"])
