@@ -32,7 +32,22 @@ inline int check_launch(const char* what) {
   } while (0)
 
 constexpr int kWave = 64;
-constexpr int kNumCU = 256;
+// Compute units of the current device (MI355X: 256), asked once per device: grids of the persistent kernels and the
+// small- / large-problem thresholds follow the part the library runs on instead of a compile-time constant.
+inline int num_cu() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = cached[dev].load(std::memory_order_relaxed);
+  if (n > 0) return n;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    n = 256;
+  }
+  cached[dev].store(n, std::memory_order_relaxed);
+  return n;
+}
+#define kNumCU (::srk::num_cu())
 constexpr int kMaxDynLds = 160 * 1024;  // gfx950: 160 KB of LDS per CU, all of it usable by one workgroup
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel.  Every launcher that needs more than
