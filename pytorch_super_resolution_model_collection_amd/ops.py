@@ -185,17 +185,37 @@ def to_nhwc(x):
 # gradient it receives carries the mark for ITS y and is untouched since (autograd's fan-in accumulation adds in place
 # and bumps the version; a fresh sum carries no mark).  ReLU only: its 0/1 mask is idempotent, so a mark that got lost
 # merely costs the second application.  SRK_PREMASK=0 switches the protocol off.
+# The gradient of an INTERMEDIATE activation is not what autograd defines while the protocol runs (it is already
+# multiplied by the ReLU gradient of its producer), so the protocol is active only inside `premasked_gradients()` -- the
+# backward passes of this package's own training steps (trainers._backward), where only parameter gradients are read.
+# A plain loss.backward(), torch.autograd.grad(loss, activation) or tensor.retain_grad() outside it sees standard gradients.
 PREMASK = os.environ.get("SRK_PREMASK", "1") != "0"
 PREMASK_STATS = {"masked_dx": 0, "masks_skipped": 0}   # (tests: how often each half of the protocol ran)
+_PREMASK_DEPTH = [0]
+
+
+class premasked_gradients(object):
+    """Backward passes inside this context may hand pre-masked gradients from layer to layer (see PREMASK)."""
+
+    def __enter__(self):
+        _PREMASK_DEPTH[0] += 1
+        return self
+
+    def __exit__(self, *a):
+        _PREMASK_DEPTH[0] -= 1
+
+
+def _premask_on():
+    return PREMASK and _PREMASK_DEPTH[0] > 0
 
 
 def _is_relu_output(x):
-    return PREMASK and getattr(x, "_srk_relu_out", None) == x._version
+    return getattr(x, "_srk_relu_out", None) == x._version
 
 
 def _premasked_for(dy, y):
     t = getattr(dy, "_srk_premasked", None)
-    return PREMASK and t is not None and t == (y.data_ptr(), dy._version)
+    return _premask_on() and t is not None and t == (y.data_ptr(), dy._version)
 
 
 def to_nchw(x):
@@ -593,7 +613,7 @@ class _Conv2d(torch.autograd.Function):
                 if tuple(add_to.shape) != tuple(dx.shape):
                     raise RuntimeError("conv backward: skip gradient %s does not match dx %s"
                                        % (tuple(add_to.shape), tuple(dx.shape)))
-            if (ctx.x_relu_out and add_to is None and d.dy_ps_r <= 1
+            if (ctx.x_relu_out and _premask_on() and add_to is None and d.dy_ps_r <= 1 and not x.retains_grad
                     and lib.srk_conv2d_backward_data_relu_supported(ctypes.byref(d), ptr(dyc), ptr(dx), mref)):
                 check(lib.srk_conv2d_backward_data_relu(ctypes.byref(d), ptr(dyc), ptr(wpb), ptr(dx), mref, ptr(x),
                                                         stream_ptr()), "srk_conv2d_backward_data_relu")

@@ -50,11 +50,13 @@ def _backward(loss, dp):
     """loss.backward() of the reference (edsr.py:154 ...).  Single GPU: the deferred weight gradients are launched
     (grouped) when the autograd engine finishes the pass.  Data parallel: they stay pending so that dp.exchange() can
     interleave the grouped launches with the gradient buckets; the backward is seeded with 1/world."""
+    # (premasked_gradients: a train step reads parameter gradients only, so activation gradients may travel pre-masked)
     if dp is not None and dp.active:
-        with ops.manual_wgrad_flush():
+        with ops.manual_wgrad_flush(), ops.premasked_gradients():
             loss.backward(dp.loss_seed)
     else:
-        ops.backward(loss)       # seeded with the persistent ones tensor: no fill, no scale pass (ops.unit_seed)
+        with ops.premasked_gradients():
+            ops.backward(loss)   # seeded with the persistent ones tensor: no fill, no scale pass (ops.unit_seed)
         ops.join_side_streams()  # (also flushes weight gradients recorded outside an engine callback)
 
 
@@ -107,9 +109,11 @@ def lapsrn_step(model, opt, dp=None):
         seed = dp.loss_seed if (dp is not None and dp.active) else None
         if seed is not None:
             with ops.manual_wgrad_flush():
-                torch.autograd.backward([l1, l2], [seed, seed])
+                with ops.premasked_gradients():
+                    torch.autograd.backward([l1, l2], [seed, seed])
         else:
-            ops.backward([l1, l2])
+            with ops.premasked_gradients():
+                ops.backward([l1, l2])
         if dp is not None:
             dp.allreduce_grads()
         opt.step()

@@ -335,7 +335,8 @@ def test_premasked_gradients(gpu, monkeypatch, fan_out):
         wg = [w.to(gpu).requires_grad_(True) for w in ws]
         cfg = ops.ConvCfg(1, 1, False, 0, 1, 0.0, 0)
         out = chain(xg, wg, lambda a, w: ops.conv2d(a, w, None, None, cfg))
-        out.backward(g.to(gpu))
+        with ops.premasked_gradients():     # (what trainers._backward does; a plain backward() never pre-masks: below)
+            out.backward(g.to(gpu))
         ops.flush_wgrads()
         res[on] = [xg.grad.clone()] + [w.grad.clone() for w in wg]
         if on:   # three data gradients write into a ReLU output; without the skip all three marks reach their layer
@@ -345,6 +346,18 @@ def test_premasked_gradients(gpu, monkeypatch, fan_out):
             assert ops.PREMASK_STATS == {"masked_dx": 0, "masks_skipped": 0}
     for a, b in zip(res[False], res[True]):
         assert torch.equal(a, b)
+    # outside the context the gradient of an intermediate activation is the standard one (nothing pre-masked)
+    monkeypatch.setattr(ops, "PREMASK", True)
+    ops.PREMASK_STATS.update(masked_dx=0, masks_skipped=0)
+    xg = x.to(gpu).requires_grad_(True)
+    wg = [w.to(gpu) for w in ws]
+    h1 = ops.conv2d(xg, wg[0], None, None, ops.ConvCfg(1, 1, False, 0, 1, 0.0, 0))
+    h1.retain_grad()
+    ops.conv2d(h1, wg[1], None, None, ops.ConvCfg(1, 1, False, 0, 1, 0.0, 0)).backward(g.to(gpu))
+    h1r = torch.relu(torch.nn.functional.conv2d(x.double(), ws[0].double(), None, 1, 1)).requires_grad_(True)
+    torch.relu(torch.nn.functional.conv2d(h1r, ws[1].double(), None, 1, 1)).backward(g.double())
+    assert ops.PREMASK_STATS == {"masked_dx": 0, "masks_skipped": 0}
+    assert rel_err(h1.grad, h1r.grad.float()) < 1e-4
     assert rel_err(res[True][0], xr.grad.float()) < 1e-4
     for a, w in zip(res[True][1:], wr):
         assert rel_err(a, w.grad.float()) < 1e-4
