@@ -53,6 +53,7 @@ struct BfwParams {
   // channels; slice sl of tile range i is block 8 * (nsl * i + sl) + xcd -- the nsl blocks that walk the same tiles are
   // neighbours on one XCD and start together, so the halo the first one pulls into that XCD's L2 serves the others.
   int nsl, NBfull, OCb;
+  unsigned out_bytes;  // size of the output tensor (buffer descriptor of the consumers' stores)
   int dbg;  // ablation (SRK_DBG): 1 no global loads, 2 no epilogue, 4 no MFMA loop, 16 no LDS commit, 1024 no deferred stores
 };
 
@@ -288,7 +289,16 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
   // accumulators when the tile is parked, nine taps later.
   f32x4 om[OMASK ? NTW : 1][OMASK ? MTW : 1];
   float amax = 0.f;  // running maximum of what this lane stores (ep.y_amax)
-  float* pend_base = P.out;  // wave-uniform: P.out + tile origin
+  // Stores go through a buffer descriptor of the output with 32-bit byte offsets, unconditionally: a pixel outside the
+  // tile / the image carries an offset beyond the tensor, which the buffer unit drops.  (With 64-bit addresses under
+  // exec-mask branches the 48-channel f16 variant spilled two offset registers; the reload in front of a deferred store
+  // came with an s_waitcnt vmcnt(0), i.e. a wait for the acknowledgement of every earlier store, in every stage.)
+  constexpr unsigned kDrop = 0x80000000u;  // (host: outputs below 2 GiB)
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(P.out, 0, B.out_bytes, 0x00020000);
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  unsigned pend_voff[MTW];  // byte offset of the lane's pixel mt of the parked tile, or kDrop
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) pend_voff[mt] = kDrop;
   int pend_mask = 0;
   bool pend_live = false;
   constexpr int NST = NTW * MTW;             // stores per tile and lane, slot q = mt * NTW + nt
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
   auto store_slot = [&](auto qc) {
     constexpr int q = decltype(qc)::value;
     constexpr int mt = q / NTW, nt = q - mt * NTW;
-    if ((pend_mask >> mt) & 1) *reinterpret_cast<f32x4*>(pend_base + (coff[nt] + poff[mt])) = pend[nt][mt];
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, pend[nt][mt]), orsrc, (int)(pend_voff[mt] + 4u * (unsigned)coff[nt]), 0, 0);
   };
   auto flush_from = [&](auto q0c) {  // slots q0 .. NST-1
     constexpr int q0 = decltype(q0c)::value;
@@ -401,12 +411,14 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
     if (cc == B.ICc - 1 && wave_live && !(B.dbg & 2)) {
       // tile finished (C/D col = lane & 15 = pixel, rows kq*4 + reg = 4 consecutive channels per M tile): park it
       if (pend_live) flush_from(std::integral_constant<int, 0>{});  // (cannot happen with TT > 0)
-      pend_base = P.out + epi_tile_setup(P, n, r0, c0).off0;
+      const unsigned tile_off = 4u * (unsigned)epi_tile_setup(P, n, r0, c0).off0;
       pend_mask = 0;
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt) {
         const int r = pix_ok[mt] >> 16, c = pix_ok[mt] & 0xffff;
-        if (pix_ok[mt] >= 0 && r0 + r < P.PH && c0 + c < P.PW) pend_mask |= 1 << mt;
+        const bool pok = pix_ok[mt] >= 0 && r0 + r < P.PH && c0 + c < P.PW;
+        if (pok) pend_mask |= 1 << mt;
+        pend_voff[mt] = pok ? tile_off + 4u * (unsigned)poff[mt] : kDrop;
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
           f32x4 v = acc[nt][mt];
@@ -508,7 +520,7 @@ bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, co
   if (!conv_epi_all_vector(g.OC, ep, out)) return false;
   if (ep.residual || (ep.act == SRK_ACT_PRELU && ep.prelu_n > 1)) return false;
   if (ep.act != SRK_ACT_NONE && ep.act != SRK_ACT_RELU && ep.act != SRK_ACT_LRELU && ep.act != SRK_ACT_PRELU) return false;
-  if ((long)g.N * g.OH * g.OW * g.OC >= (1L << 31)) return false;  // 32-bit in-tile output offsets
+  if ((long)g.N * g.OH * g.OW * g.OC >= (1L << 29)) return false;  // 32-bit byte offsets into an output below 2 GiB (kDrop)
   const size_t wbytes = (size_t)T * ((g.IC + 31) / 32) * 8 * NB * 16;
   if (wbytes > 100 * 1024) return false;
   if ((long)g.N * g.OH * g.OW >= (1L << 30) || (long)g.IH * g.IW * g.IC >= (1L << 30)) return false;
@@ -616,6 +628,7 @@ int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float
     const long ntiles = (long)P.tiles_x * P.tiles_y * P.N;
     if (ntiles >= (1L << 30)) return -1;
     B.ntiles = (int)ntiles;
+    B.out_bytes = (unsigned)((size_t)P.N * P.OH * P.OW * P.OC * sizeof(float));
     int grid = kNumCU;
     if (nsl > 1) {  // whole groups of nsl neighbouring blocks on every XCD (a group without tiles just exits)
       grid -= grid % (8 * nsl);
