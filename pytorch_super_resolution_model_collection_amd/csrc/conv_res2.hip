@@ -225,9 +225,16 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
     const bool inimg = mt < R2_MT1 && m < R2_NMID && (unsigned)iy < (unsigned)R.H && (unsigned)ix < (unsigned)R.W;
     moff[q] = inimg ? (int)(((size_t)iy * R.W + ix) * R2_C) + ch4 : -1;
     mcen[q] = inimg && r >= 1 && r <= R2_TS && c >= 1 && c <= R2_TS;
+    // (unconditional, from a clamped address: a load under a divergent branch is followed by s_waitcnt vmcnt(0) at the
+    //  join, which would serialise the latencies of these loads; a pixel outside the image is zeroed below anyway)
     gt[q] = (f32x4){1.f, 1.f, 1.f, 1.f};
-    if (BWD && inimg) gt[q] = *reinterpret_cast<const f32x4*>(R.gate + img + moff[q]);
+    if constexpr (BWD) gt[q] = *reinterpret_cast<const f32x4*>(R.gate + img + (inimg ? moff[q] : ch4));
   }
+  // biases: requested here, complete before the epilogues that use them (a first use inside those conditional store
+  // sequences put an s_waitcnt vmcnt(0) -- a wait for the previous store's acknowledgement -- in front of every store)
+  f32x4 b1 = {0.f, 0.f, 0.f, 0.f}, b2 = {0.f, 0.f, 0.f, 0.f};
+  if (!BWD && R.bias1) b1 = *reinterpret_cast<const f32x4*>(R.bias1 + ch4);
+  if (!BWD && R.bias2) b2 = *reinterpret_cast<const f32x4*>(R.bias2 + ch4);
   __syncthreads();  // every wave is done with the input halo
   f32x4* red = reinterpret_cast<f32x4*>(smem4) + (size_t)(ow * R2_MT1) * 64 + lane;  // [4 ow][7 tiles][64 lanes]
   if (kgrp == 0) {
@@ -240,8 +247,8 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
   __syncthreads();
   float smid = 1.f, dsc2 = 1.f;
   {
-    f32x4 b1 = {0.f, 0.f, 0.f, 0.f};
-    if (!BWD && R.bias1) b1 = *reinterpret_cast<const f32x4*>(R.bias1 + ch4);
+    asm volatile("" ::"v"(b1), "v"(b2));
+    if constexpr (BWD) asm volatile("" ::"v"(gt[0]), "v"(gt[1]), "v"(gt[2]), "v"(gt[3]));
     const int ch2 = ow >> 1, g2 = (ow & 1) * 2 + (kq >> 1);
     f32x4 vv[4];
     float lmax = 0.f;
@@ -299,8 +306,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
     const int iy = r0 + (m >> 3), ix = c0 + (m & 7);
     const bool ok = iy < R.H && ix < R.W;
     ooff[q] = ok ? (int)(((size_t)iy * R.W + ix) * R2_C) + ch4 : -1;
-    res[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (ok) res[q] = *reinterpret_cast<const f32x4*>(inb + ooff[q]);
+    res[q] = *reinterpret_cast<const f32x4*>(inb + (ok ? ooff[q] : ch4));  // (unconditional: see gt; unused when !ok)
   }
   __syncthreads();  // mid planes complete
 
@@ -342,8 +348,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
     red2[1 * 64] = acc2[1];
   }
   __syncthreads();
-  f32x4 b2 = {0.f, 0.f, 0.f, 0.f};
-  if (!BWD && R.bias2) b2 = *reinterpret_cast<const f32x4*>(R.bias2 + ch4);
+  asm volatile("" ::"v"(res[0]), "v"(res[1]));  // (landed during the second conv: no wait between the stores below)
   float oamax = 0.f;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
