@@ -37,10 +37,17 @@ __global__ __launch_bounds__(256) void k_bn_colsum(const float* __restrict__ a, 
     for (size_t rb = r0 + w; rb < r1; rb += 4 * U) {
       float va[U], vx[U];
 #pragma unroll
+      for (int u = 0; u < U; ++u) {   // (unconditional loads of a clamped row + select below: a load under a branch the
+        const size_t r = rb + 4 * (size_t)u;            //  compiler cannot prove uniform is followed by s_waitcnt vmcnt(0),
+        const size_t rc = r < r1 ? r : r1 - 1;          //  and the "one load round" became 16 serialised round trips)
+        va[u] = a[rc * C + c];
+        if (MODE == 1) vx[u] = x[rc * C + c];
+      }
+#pragma unroll
       for (int u = 0; u < U; ++u) {
-        const size_t r = rb + 4 * (size_t)u;
-        va[u] = r < r1 ? a[r * C + c] : 0.f;
-        if (MODE == 1) vx[u] = r < r1 ? x[r * C + c] : mu;
+        const bool in = rb + 4 * (size_t)u < r1;
+        va[u] = in ? va[u] : 0.f;
+        if (MODE == 1) vx[u] = in ? vx[u] : mu;
       }
       if (DBL || MODE == 0) {
         // backward statistics feed a difference that cancels to ~1e-4 of its mass when a BatchNorm follows another
@@ -120,10 +127,13 @@ __global__ __launch_bounds__(256) void k_bn_reduce_fused(const double* __restric
       double va[U], vb[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int k = kb + 4 * u;
-        va[u] = k < nsplit ? partial[(size_t)k * 2 * C + c] : 0.0;
-        vb[u] = k < nsplit ? partial[(size_t)k * 2 * C + C + c] : 0.0;
+        const int k = kb + 4 * u, kc = k < nsplit ? k : nsplit - 1;   // (clamped unconditional loads + select: see k_bn_colsum)
+        va[u] = partial[(size_t)kc * 2 * C + c];
+        vb[u] = partial[(size_t)kc * 2 * C + C + c];
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (kb + 4 * u >= nsplit) va[u] = vb[u] = 0.0;
 #pragma unroll
       for (int u = 0; u < U; u += 2) {
         a0 += va[u];
@@ -353,10 +363,16 @@ __global__ __launch_bounds__(256) void k_bn_colsum_act(const float* __restrict__
       float va[U], vx[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const size_t r = rb + 4 * (size_t)u;
-        va[u] = r < r1 ? dy[r * C + c] : 0.f;
-        vx[u] = r < r1 ? x[r * C + c] : mu;
+        const size_t r = rb + 4 * (size_t)u, rc = r < r1 ? r : r1 - 1;   // (clamped unconditional loads + select)
+        va[u] = dy[rc * C + c];
+        vx[u] = x[rc * C + c];
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (rb + 4 * (size_t)u >= r1) {
+          va[u] = 0.f;
+          vx[u] = mu;
+        }
       double d0 = 0.0, d1 = 0.0, d2 = 0.0;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -402,8 +418,11 @@ __global__ __launch_bounds__(256) void k_bn_reduce_act(const double* __restrict_
       for (int u = 0; u < U; ++u) {
         const int k = kb + 4 * u;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) v[u][q] = k < nsplit ? partial[(size_t)k * 3 * C + q * C + c] : 0.0;
+        for (int q = 0; q < 3; ++q) v[u][q] = partial[(size_t)(k < nsplit ? k : nsplit - 1) * 3 * C + q * C + c];
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (kb + 4 * u >= nsplit) v[u][0] = v[u][1] = v[u][2] = 0.0;
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll

@@ -311,13 +311,18 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_tapn(WgTapnParams P) {
       }
     }
     // x fragments: float4 = channels 4j..4j+3 of pixel cb + e
+    // (unconditional loads from clamped addresses, zeroed afterwards: under the divergent branch each load was followed
+    //  by an s_waitcnt vmcnt(0) -- eight serialised round trips per K step)
     f32x4 araw[8];
-    const float* __restrict__ xs = P.x + ((size_t)(n * P.H + r) * P.W) * P.Cin + 4 * j;
+    const float* __restrict__ xs = P.x + ((size_t)(n * P.H + r) * P.W) * P.Cin + (ch_on ? 4 * j : 0);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      araw[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (ch_on && cb + e < P.W) araw[e] = *reinterpret_cast<const f32x4*>(xs + (size_t)(cb + e) * P.Cin);
+      const int cx = cb + e < P.W ? cb + e : P.W - 1;
+      araw[e] = *reinterpret_cast<const f32x4*>(xs + (size_t)cx * P.Cin);
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (!(ch_on && cb + e < P.W)) araw[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
     uint4 bfr[2][2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -459,15 +464,16 @@ __global__ __launch_bounds__(256) void k_conv_tapk(MfmaConvParams P, int groups_
     float f[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      f[e] = 0.f;
-      if (kuv[e] >= 0) {
-        const int k = kq * 8 + e;
-        const int t = k / P.IC, c = k - t * P.IC;
-        const int u = t / P.KWv, v = t - u * P.KWv;
-        const int tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
-        f[e] = P.wp[((size_t)tapw * P.IC + c) * P.OC + 16 * i + j];
-      }
+      // (unconditional load of slot 0 for padding slots + select: loads under a divergent branch are each followed by an
+      //  s_waitcnt vmcnt(0) at the join -- 6 serialised round trips in the prologue of every block)
+      const int k = kuv[e] >= 0 ? kq * 8 + e : 0;
+      const int t = k / P.IC, c = k - t * P.IC;
+      const int u = t / P.KWv, v = t - u * P.KWv;
+      const int tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
+      f[e] = P.wp[((size_t)tapw * P.IC + c) * P.OC + 16 * i + j];
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = kuv[e] >= 0 ? f[e] : 0.f;
     split8n<2>(f, af[i]);
   }
   // two pixel groups per iteration: 16 independent gathers in flight before the first conversion
