@@ -356,10 +356,15 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 && NW == 4) ? 3 : 2) void k_conv_
       int wtap = P.wh0 * P.KW_full + P.ww0;  // weight tap of (u, v) = (0, 0)
       if (!(B.dbg & 1)) bf3_stage_halo<NTHR>(B, hal, n, r0, c0, cc * 32);
       {
+        // (loads unconditional from a clamped index, only the LDS writes conditional: load + write under one branch
+        //  compiled to load, s_waitcnt vmcnt(0), write -- per copy, one after the other)
         const uint4* src = wbase + (size_t)wtap * wtap_stride;
+        uint4 w0[WCP];
+#pragma unroll
+        for (int c = 0; c < WCP; ++c) w0[c] = src[tid + c * NTHR < wslot ? tid + c * NTHR : 0];
 #pragma unroll
         for (int c = 0; c < WCP; ++c)
-          if (tid + c * NTHR < wslot) wl[tid + c * NTHR] = src[tid + c * NTHR];
+          if (tid + c * NTHR < wslot) wl[tid + c * NTHR] = w0[c];
       }
       __syncthreads();
       int toff = 0, tv = 0;
@@ -813,8 +818,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3_rows(Bf3Params B) {
   if (Q > 0) {
     {
       const uint4* src = wsrc(0);
-      if (w0_ok) wl[tid] = src[tid];
-      if (w1_ok) wl[tid + 256] = src[tid + 256];
+      const uint4 w0 = src[w0_ok ? tid : 0], w1 = src[w1_ok ? tid + 256 : 0];  // (unconditional loads: see k_conv_bf3)
+      if (w0_ok) wl[tid] = w0;
+      if (w1_ok) wl[tid + 256] = w1;
     }
     __syncthreads();
     int u = 0, ks = 0;
