@@ -677,7 +677,14 @@ __global__ __launch_bounds__(512) void k_linear_fwd_wide(const float* __restrict
   const float* wr[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) wr[k] = w + (size_t)(o0 + k < Out ? o0 + k : Out - 1) * In;
-  for (int i = tid * 4; i < In; i += 512 * 4) {
+  // The blocks walk their rows in ROTATED order (block b starts at step b mod nsteps): rows are In * 4 bytes apart -- a
+  // multiple of 8 KB for the 18432-wide layer -- so with every block at the same column the 1024 row streams sat on
+  // the same few HBM channels at any moment (0.8 TB/s for a plain weight stream).
+  const int nsteps = (In + 512 * 4 - 1) / (512 * 4);
+  int step = blockIdx.x % nsteps;
+  for (int it = 0; it < nsteps; ++it, step = step + 1 == nsteps ? 0 : step + 1) {
+    const int i = step * 512 * 4 + tid * 4;
+    if (i >= In) continue;
     lf4 wv[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) wv[k] = *reinterpret_cast<const lf4*>(wr[k] + i);
@@ -773,27 +780,35 @@ __global__ __launch_bounds__(256) void k_linear_dw_wide(const float* __restrict_
 #pragma unroll
   for (int k = 0; k < 16; ++k) acc[k] = (lf4){0.f, 0.f, 0.f, 0.f};
   for (int b0 = 0; b0 < B; b0 += LW_BT) {
+    // (every load unconditional, from a clamped row; rows past the batch get a zero dy: a conditional load is followed by
+    //  s_waitcnt vmcnt(0) and this kernel is nothing but loads)
     lf4 xv[LW_BT];
 #pragma unroll
     for (int r = 0; r < LW_BT; ++r)
-      xv[r] = b0 + r < B ? *reinterpret_cast<const lf4*>(x + (size_t)(b0 + r) * In + i) : (lf4){0.f, 0.f, 0.f, 0.f};
+      xv[r] = *reinterpret_cast<const lf4*>(x + (size_t)(b0 + r < B ? b0 + r : B - 1) * In + i);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int o = o0 + k < Out ? o0 + k : Out - 1;
 #pragma unroll
       for (int r = 0; r < LW_BT; ++r) {
-        const float g = b0 + r < B ? dy[(size_t)(b0 + r) * Out + o] : 0.f;
+        float g = dy[(size_t)(b0 + r < B ? b0 + r : B - 1) * Out + o];
+        g = b0 + r < B ? g : 0.f;
         acc[k] += g * xv[r];
       }
     }
   }
+  // read-modify-write of 16 rows: all reads first (a row past Out re-reads the last one and is not written)
+  if (beta != 0.f) {
+    lf4 old[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    if (o0 + k < Out) {
-      lf4* dst = reinterpret_cast<lf4*>(dw + (size_t)(o0 + k) * In + i);
-      *dst = beta != 0.f ? beta * *dst + acc[k] : acc[k];
-    }
+    for (int k = 0; k < 16; ++k)
+      old[k] = *reinterpret_cast<const lf4*>(dw + (size_t)(o0 + k < Out ? o0 + k : Out - 1) * In + i);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] += beta * old[k];
   }
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (o0 + k < Out) *reinterpret_cast<lf4*>(dw + (size_t)(o0 + k) * In + i) = acc[k];
 }
 
 static bool linear_wide(const void* a, const void* b, const void* c, int In, int Out) {
