@@ -109,31 +109,33 @@ __global__ __launch_bounds__(256) void k_bn_reduce(const double* __restrict__ pa
 // k_bn_reduce fused with what consumes the reduced sums (one launch less per BatchNorm call and direction):
 //   MODE 0 (forward):  + k_bn_finalize  (mean / rstd / running statistics / num_batches_tracked)
 //   MODE 1 (backward): + k_bn_param_grads (dbeta += sum dy, dgamma += sum dy * xhat)
-// 64 channels per block, lane = channel; the 4 waves take every 4th split, combined through LDS in a fixed order.
-template <int MODE>
-__global__ __launch_bounds__(256) void k_bn_reduce_fused(const double* __restrict__ partial, double* __restrict__ stats,
+// 64 channels per block, lane = channel; the NW waves take every NW-th split, combined through LDS in a fixed order.
+// (NW = 16 for more than 64 splits: with 4 waves the 512 splits of a large activation were 8 dependent L2 round trips
+// of ONE block -- the kernel is a latency chain, 8.8 us average on the SRGAN step.)
+template <int MODE, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_bn_reduce_fused(const double* __restrict__ partial, double* __restrict__ stats,
                                                          int nsplit, int C, double count, float* __restrict__ o0,
                                                          float* __restrict__ o1, float* __restrict__ rm,
                                                          float* __restrict__ rv, float momentum, float eps,
                                                          long long* __restrict__ nbt) {
-  __shared__ double sm[2][4][64];
+  __shared__ double sm[2][NW][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
   if (c < C) {
-    // 16 splits per wave in flight (every load issued before the first add): one L2 round trip per 64 splits
+    // 16 splits per wave in flight (every load issued before the first add): one L2 round trip per 16 NW splits
     constexpr int U = 16;
-    for (int kb = w; kb < nsplit; kb += 4 * U) {
+    for (int kb = w; kb < nsplit; kb += NW * U) {
       double va[U], vb[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int k = kb + 4 * u, kc = k < nsplit ? k : nsplit - 1;   // (clamped unconditional loads + select: see k_bn_colsum)
+        const int k = kb + NW * u, kc = k < nsplit ? k : nsplit - 1;   // (clamped unconditional loads + select: see k_bn_colsum)
         va[u] = partial[(size_t)kc * 2 * C + c];
         vb[u] = partial[(size_t)kc * 2 * C + C + c];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (kb + 4 * u >= nsplit) va[u] = vb[u] = 0.0;
+        if (kb + NW * u >= nsplit) va[u] = vb[u] = 0.0;
 #pragma unroll
       for (int u = 0; u < U; u += 2) {
         a0 += va[u];
@@ -147,8 +149,12 @@ __global__ __launch_bounds__(256) void k_bn_reduce_fused(const double* __restric
   sm[1][w][lane] = b0 + b1;
   __syncthreads();
   if (w != 0 || c >= C) return;
-  const double s0 = (sm[0][0][lane] + sm[0][1][lane]) + (sm[0][2][lane] + sm[0][3][lane]);
-  const double s1 = (sm[1][0][lane] + sm[1][1][lane]) + (sm[1][2][lane] + sm[1][3][lane]);
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int q = 0; q < NW; q += 4) {
+    s0 += (sm[0][q][lane] + sm[0][q + 1][lane]) + (sm[0][q + 2][lane] + sm[0][q + 3][lane]);
+    s1 += (sm[1][q][lane] + sm[1][q + 1][lane]) + (sm[1][q + 2][lane] + sm[1][q + 3][lane]);
+  }
   stats[c] = s0;
   stats[C + c] = s1;
   if (MODE == 0) {
@@ -402,27 +408,28 @@ __global__ __launch_bounds__(256) void k_bn_colsum_act(const float* __restrict__
 }
 
 // reduce of the above + dbeta += sum dz, dgamma += sum dz * xhat, dprelu += sum_{z<=0} dy * z; stats[2C] as usual
-__global__ __launch_bounds__(256) void k_bn_reduce_act(const double* __restrict__ partial, double* __restrict__ stats,
-                                                       int nsplit, int C, float* __restrict__ dgamma,
-                                                       float* __restrict__ dbeta, float* __restrict__ dprelu, int prelu_n) {
-  __shared__ double sm[3][4][64];
+template <int NW>   // waves per block (16 for many splits: see k_bn_reduce_fused)
+__global__ __launch_bounds__(64 * NW) void k_bn_reduce_act(const double* __restrict__ partial, double* __restrict__ stats,
+                                                          int nsplit, int C, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, float* __restrict__ dprelu, int prelu_n) {
+  __shared__ double sm[3][NW][64];
   __shared__ float psum[64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   double a[3] = {0.0, 0.0, 0.0};
   if (c < C) {
     constexpr int U = 8;
-    for (int kb = w; kb < nsplit; kb += 4 * U) {
+    for (int kb = w; kb < nsplit; kb += NW * U) {
       double v[U][3];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int k = kb + 4 * u;
+        const int k = kb + NW * u;
 #pragma unroll
         for (int q = 0; q < 3; ++q) v[u][q] = partial[(size_t)(k < nsplit ? k : nsplit - 1) * 3 * C + q * C + c];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (kb + 4 * u >= nsplit) v[u][0] = v[u][1] = v[u][2] = 0.0;
+        if (kb + NW * u >= nsplit) v[u][0] = v[u][1] = v[u][2] = 0.0;
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -436,7 +443,9 @@ __global__ __launch_bounds__(256) void k_bn_reduce_act(const double* __restrict_
   double s[3] = {0.0, 0.0, 0.0};
   if (c < C) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) s[q] = (sm[q][0][lane] + sm[q][1][lane]) + (sm[q][2][lane] + sm[q][3][lane]);
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int g = 0; g < NW; g += 4) s[q] += (sm[q][g][lane] + sm[q][g + 1][lane]) + (sm[q][g + 2][lane] + sm[q][g + 3][lane]);
     stats[c] = s[0];
     stats[C + c] = s[1];
     if (dbeta) dbeta[c] += (float)s[0];
@@ -528,12 +537,19 @@ static int bn_colsum(int mode, const float* a, const float* x, const float* mean
     hipLaunchKernelGGL((k_bn_colsum<1, false>), grid, dim3(256), 0, s, a, x, mean, rstd, (double*)ws, rows, C, rps);
   else
     hipLaunchKernelGGL((k_bn_colsum<1, true>), grid, dim3(256), 0, s, a, x, mean, rstd, (double*)ws, rows, C, rps);
-  if (fu.mode == 0)
-    hipLaunchKernelGGL(k_bn_reduce_fused<0>, dim3(cdiv(C, 64)), dim3(256), 0, s, (const double*)ws, out, splits, C, fu.count,
-                       fu.o0, fu.o1, fu.rm, fu.rv, fu.momentum, fu.eps, fu.nbt);
+  const bool wide = splits > 64;
+  if (fu.mode == 0 && wide)
+    hipLaunchKernelGGL((k_bn_reduce_fused<0, 16>), dim3(cdiv(C, 64)), dim3(1024), 0, s, (const double*)ws, out, splits, C,
+                       fu.count, fu.o0, fu.o1, fu.rm, fu.rv, fu.momentum, fu.eps, fu.nbt);
+  else if (fu.mode == 0)
+    hipLaunchKernelGGL((k_bn_reduce_fused<0, 4>), dim3(cdiv(C, 64)), dim3(256), 0, s, (const double*)ws, out, splits, C,
+                       fu.count, fu.o0, fu.o1, fu.rm, fu.rv, fu.momentum, fu.eps, fu.nbt);
+  else if (fu.mode == 1 && wide)
+    hipLaunchKernelGGL((k_bn_reduce_fused<1, 16>), dim3(cdiv(C, 64)), dim3(1024), 0, s, (const double*)ws, out, splits, C, 0.0,
+                       fu.o0, fu.o1, nullptr, nullptr, 0.f, 0.f, nullptr);
   else if (fu.mode == 1)
-    hipLaunchKernelGGL(k_bn_reduce_fused<1>, dim3(cdiv(C, 64)), dim3(256), 0, s, (const double*)ws, out, splits, C, 0.0, fu.o0,
-                       fu.o1, nullptr, nullptr, 0.f, 0.f, nullptr);
+    hipLaunchKernelGGL((k_bn_reduce_fused<1, 4>), dim3(cdiv(C, 64)), dim3(256), 0, s, (const double*)ws, out, splits, C, 0.0,
+                       fu.o0, fu.o1, nullptr, nullptr, 0.f, 0.f, nullptr);
   else
     hipLaunchKernelGGL(k_bn_reduce, dim3(cdiv(2 * C, 64)), dim3(256), 0, s, (const double*)ws, out, splits, 2 * C);
   return check_launch("bn_colsum");
@@ -963,8 +979,12 @@ extern "C" int srk_bn_backward_stats_grads_act(const float* dy, const float* x, 
   BnAct A{gamma, beta, prelu_weight, act, prelu_n, slope};
   hipLaunchKernelGGL(k_bn_colsum_act, dim3(cdiv(C, 64), splits), dim3(256), 0, s, dy, x, mean, rstd, A, (double*)workspace,
                      rows, C, rps);
-  hipLaunchKernelGGL(k_bn_reduce_act, dim3(cdiv(C, 64)), dim3(256), 0, s, (const double*)workspace, dstats, splits, C,
-                     dgamma, dbeta, act == SRK_ACT_PRELU ? dprelu : nullptr, prelu_n);
+  if (splits > 64)
+    hipLaunchKernelGGL(k_bn_reduce_act<16>, dim3(cdiv(C, 64)), dim3(1024), 0, s, (const double*)workspace, dstats, splits, C,
+                       dgamma, dbeta, act == SRK_ACT_PRELU ? dprelu : nullptr, prelu_n);
+  else
+    hipLaunchKernelGGL(k_bn_reduce_act<4>, dim3(cdiv(C, 64)), dim3(256), 0, s, (const double*)workspace, dstats, splits, C,
+                       dgamma, dbeta, act == SRK_ACT_PRELU ? dprelu : nullptr, prelu_n);
   return check_launch("bn_backward_stats_grads_act");
 }
 
