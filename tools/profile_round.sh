@@ -10,7 +10,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-C2="python $ROOT/bench.py --steps 10 --warmup 3 --no-extra --no-cpu-baseline"
+C2="python $ROOT/bench.py --steps 40 --warmup 5 --no-extra --no-cpu-baseline"   # (enough steps that the cold first launches do not carry the rocprofv3 average)
 C4="python $ROOT/tools/edsr_b16.py 128"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2_kt -o c2 -- $C2 > $OUT/c2_kt.log 2>&1
