@@ -264,6 +264,45 @@ def training_roofline(tag, px, layer_px_note, layers_per_step=1, steps=5):
     return out
 
 
+def pixel_shuffle_rates(pkg, dev, batch, lr_size):
+    """The standalone pixel-shuffle kernel (base_networks.py:157,181; SURVEY 8d: 23.62 MB per c2 image) at the c2 shape:
+    [B, 48, 248, 248] -> [B, 3, 992, 992], forward and backward, HIP events on the launch stream, 8 bytes per element
+    algorithmic.  The product path fuses the shuffle into the last conv's store; this is the unfused kernel."""
+    hw = lr_size - 8
+    x = torch.rand(batch, 48, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+    out = {}
+    with torch.no_grad():
+        for key, fn in (("fwd", lambda: pkg.ops.pixel_shuffle(x, 4)),):
+            y = fn()
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            out["ps_kernel_GBps"] = round(2 * 4 * x.numel() * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        g = y
+        lib = pkg._lib.load()
+        dx = torch.empty_like(x)
+
+        def bwd():
+            pkg._lib.check(lib.srk_pixel_shuffle_backward(pkg._lib.ptr(g), pkg._lib.ptr(dx), batch, hw, hw, 3, 4,
+                                                          pkg._lib.stream_ptr()), "srk_pixel_shuffle_backward")
+        for _ in range(3):
+            bwd()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            bwd()
+        e1.record()
+        torch.cuda.synchronize()
+        out["ps_kernel_backward_GBps"] = round(2 * 4 * x.numel() * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+    out["ps_kernel_shape"] = "[%d, 48, %d, %d] fp32 NHWC -> [%d, 3, %d, %d], r = 4" % (batch, hw, hw, batch, 4 * hw, 4 * hw)
+    return out
+
+
 def cpu_baseline(batch_cap=8, lr_size=256):
     """Oracle ESPCN x4 forward on the host cores (bounded sample: B=8; per thread count 2 warm-ups + best of 3; the
     thread count that gives the best rate is the one reported — all hardware threads oversubscribe oneDNN here)."""
@@ -288,9 +327,10 @@ def cpu_baseline(batch_cap=8, lr_size=256):
         physical = psutil.cpu_count(logical=False)
     except Exception:  # noqa: BLE001
         physical = None
-    # "cores" = the torch threads the reported (best) run used, as the bench contract defines it; the box's hardware is beside it
-    return {"value": round(batch_cap / best, 2), "unit": "images/s", "cores": best_threads, "threads": best_threads,
-            "physical_cores": physical, "host_threads": ncpu, "kind": "port",
+    # "cores" = the torch threads the reported (best) run used -- the bench contract's definition of the field; what the
+    # host has is listed as host_* beside it
+    return {"value": round(batch_cap / best, 2), "unit": "images/s", "cores": best_threads,
+            "host_physical_cores": physical, "host_threads": ncpu, "kind": "port",
             "sample": "oracle ESPCN x4 forward (stock torch.nn CPU fp32), batch %d of %dx%d LR, best of 3 at the best of "
                       "%s threads" % (batch_cap, lr_size, lr_size, sorted({ncpu, ncpu // 2, ncpu // 4, 32, 16, 8}))}
 
@@ -303,13 +343,26 @@ C3_FWD, C4_FWD = 2.2425e9, 4.0615e9
 # VDSR's reconstruction conv; EDSR's body-end, 2 upsampler and reconstruction convs (75.5 + 302 + 1208 + 56.6 MFLOP)
 C3_TAIL_FWD, C4_TAIL_FWD = 5.81e6, 1.6421e9
 C5_G_FWD, C5_D_FWD = 4.543e9, 3.1437e9
+C5_STEP = 55.6e9     # SRGAN adversarial step as the reference executes it, per sample
 
 
-def bf16_pipe_frac(fwd_flop, bwd_flop, seconds_per_sample, fwd_x3_flop=0.0):
-    """(MFMAs issued x 16384 FLOP) / time / 2.5 PF for a training sample: fwd_flop of forward convs (fwd_x3_flop of them
-    on bf16x3, the rest on bf16x6), bwd_flop of backward convs (data + weight gradient together, bf16x3)."""
-    return (6.0 * (fwd_flop - fwd_x3_flop) + 3.0 * fwd_x3_flop + 3.0 * bwd_flop) / seconds_per_sample / \
-        (BF16_MFMA_PEAK_TFLOPS * 1e12)
+def mfma3_peak_frac(train_flop_per_sample, seconds_per_sample):
+    """Algorithmic conv FLOPs of a training sample (forward + data gradient + weight gradient = 3 x forward; c5: SURVEY.md's
+    55.6 GFLOP) / time / (2.5 PF / 3): the fraction of the matrix peak at THREE 16-bit MFMAs per fp32-equivalent product,
+    which is what every large kernel of the training path issues (f16x3 forward, bf16x3 / f16x3 backward).  Reproducible by
+    hand from ms_per_step; layers that still run six MFMAs (small problems: bf16x6) or the fp32 pipe count at their
+    algorithmic FLOPs, i.e. they lower this number, they do not inflate it."""
+    return train_flop_per_sample / seconds_per_sample / (BF16X3_PEAK_TFLOPS * 1e12)
+
+
+ARITHMETIC = {
+    "c3": "fp32 storage / accumulation; forward f16x3 (fp32-faithful, 3 MFMAs; reconstruction conv bf16x3), data and weight "
+          "gradients %s, SGD + clip in fp32",
+    "c4": "fp32 storage / accumulation; forward f16x3 in the residual trunk (fused blocks), bf16x3 in the activation-free tail "
+          "(body-end, up-sampler, reconstruction convs); data and weight gradients %s; Adam in fp32",
+    "c4_shard16": "as c4; at 16 patches the small-problem forward convs outside the fused blocks run bf16x6 (6 MFMAs)",
+    "c5": "fp32 storage / accumulation; forward bf16x6 (small 3x3 problems) / f16x3 (large discriminator layers), data and "
+          "weight gradients %s (stride-2 weight gradients: see c5_notes), BatchNorm statistics in double"}
 
 
 PROGRESS = {"section": "start", "since": 0.0}   # which side metric is running (read by the watchdog)
@@ -338,7 +391,7 @@ def extras_watchdog(result, extra, rank, seconds):
     return t
 
 
-def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
+def train_extra(pkg, dev, rank, world, nsteps=20, out=None, cpu_baselines=True):
     """Side metrics: c1 (SRCNN step incl. the bicubic pre-step) and c3 (VDSR x4, 41x41, batch 256) on one GPU; c4 EDSR x4
     training with global batch 128 sharded over the ranks (strong scaling; grouped weight gradients + overlapped bucketed
     RCCL exchange) and with 128 per GPU (weak); the 16-patch shard step that bounds 8-GPU strong scaling; c5 SRGAN."""
@@ -421,7 +474,8 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
         sec, k, _ = run("vdsr", net, x, t, pkg.ops.mse_loss, 0.4, False)
         out["c3_vdsr_x4_train_patches_per_s"] = round(256 * k / sec, 1)
         out["c3_vdsr_ms_per_step"] = round(1e3 * sec / k, 3)
-        out["c3_vdsr_bf16_pipe_frac"] = round(bf16_pipe_frac(C3_FWD, 2 * C3_FWD, sec / k / 256, C3_TAIL_FWD), 4)
+        out["c3_vdsr_mfma3_peak_frac"] = round(mfma3_peak_frac(3 * C3_FWD, sec / k / 256), 4)
+        out["c3_arithmetic"] = ARITHMETIC["c3"] % pkg.ops.backward_arithmetic()
         rl = training_roofline("c3", 256 * 41 * 41, "VDSR body layer: conv3x3 64 -> 64 on 256 x 41 x 41 pixels, 31.7 GFLOP", 18)
         if rl:
             out["c3_roofline"] = rl
@@ -441,7 +495,8 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
         sec, k, nocomm = run("edsr", edsr(), x, t, pkg.ops.l1_loss, None, True)
         out["c4_edsr_x4_train_patches_per_s_global_batch_128"] = round(gb * k / sec, 1)
         out["c4_edsr_ms_per_step"] = round(1e3 * sec / k, 3)
-        out["c4_edsr_bf16_pipe_frac"] = round(bf16_pipe_frac(C4_FWD, 2 * C4_FWD, sec / k / gb, C4_TAIL_FWD) / world, 4)
+        out["c4_edsr_mfma3_peak_frac"] = round(mfma3_peak_frac(3 * C4_FWD, sec / k / gb) / world, 4)
+        out["c4_arithmetic"] = ARITHMETIC["c4"] % pkg.ops.backward_arithmetic()
         if not multi:
             rl = training_roofline("c4", 128 * 32 * 32, "EDSR body layer: conv3x3 64 -> 64 on 128 x 32 x 32 pixels, 9.66 GFLOP", 33)
             if rl:
@@ -471,6 +526,8 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
         t = torch.rand(16, 3, 128, 128, generator=g).to(dev)
         sec, k, _ = run("edsr", edsr(), x, t, pkg.ops.l1_loss, None, False)
         out["c4_shard16_ms_per_step"] = round(1e3 * sec / k, 3)
+        out["c4_shard16_mfma3_peak_frac"] = round(mfma3_peak_frac(3 * C4_FWD, sec / k / 16), 4)
+        out["c4_shard16_arithmetic"] = ARITHMETIC["c4_shard16"]
         if "c4_edsr_ms_per_step" in out and world == 1:
             out["c4_strong_scaling_ceiling_at_8_gpus"] = round(out["c4_edsr_ms_per_step"] / out["c4_shard16_ms_per_step"], 2)
 
@@ -514,8 +571,8 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
         sec = time_steps(lambda: sstep(lr_img, hr_img), k, 5, world, dev)
         out["c5_srgan_x4_adv_step_patches_per_s_batch_16_per_gpu"] = round(world * 16 * k / sec, 1)
         out["c5_srgan_ms_per_step"] = round(1e3 * sec / k, 3)
-        fwd = 2 * C5_G_FWD + 3 * C5_D_FWD      # as executed by the reference: G fwd x2, D fwd x3, ...
-        out["c5_srgan_bf16_pipe_frac"] = round(bf16_pipe_frac(fwd, 2 * fwd, sec / k / 16), 4)
+        out["c5_srgan_mfma3_peak_frac"] = round(mfma3_peak_frac(C5_STEP, sec / k / 16), 4)
+        out["c5_arithmetic"] = ARITHMETIC["c5"] % pkg.ops.backward_arithmetic()
         if not multi:
             # NOT the c5 metric: the same iteration without the two gradient computations whose results the reference
             # discards (G's in the D step, D's parameter gradients in the G step; `main.py --prune_dead_grads`) -- same
@@ -528,9 +585,48 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None):
             sec_p = time_steps(lambda: pstep(lr_img, hr_img), k, 5, 1, dev)
             out["c5_srgan_ms_per_step_dead_gradients_pruned_not_the_metric"] = round(1e3 * sec_p / k, 3)
 
+    def cpu_train():
+        # the reference's CPU path beside c3 / c4 / c5: the oracle's train steps (stock torch.nn, the
+        # reference's loss / optimizer lines) on bounded batches -- VDSR 32 of 256, EDSR 16 (one rank's shard of 128), SRGAN 4
+        # of 16 -- one warm-up + best of 2 per thread count; the best thread count is reported
+        from oracle import fill, ref_modules as R
+        ncpu = os.cpu_count() or 1
+        sweep = sorted({t for t in (16, 32, 64) if t <= ncpu} or {ncpu})
+
+        def best_of(fn, batch):
+            best, best_thr = None, 0
+            for nthr in sweep:
+                torch.set_num_threads(nthr)
+                for i in range(3):
+                    t0 = time.perf_counter()
+                    fn()
+                    dt = time.perf_counter() - t0
+                    if i >= 1 and (best is None or dt < best):
+                        best, best_thr = dt, nthr
+            return round(batch / best, 1), best_thr
+
+        net = fill.fill_module(R.VDSR(3, 64, 18))
+        opt = R.make_optimizer("vdsr", net.parameters(), 1e-5)
+        x, t = fill.rand((32, 3, 41, 41), 1234), fill.rand((32, 3, 41, 41), 1235)
+        out["c3_cpu_oracle_patches_per_s"], out["c3_cpu_oracle_threads"] = best_of(lambda: R.step_mse(net, opt, x, t, 0.4), 32)
+        out["c3_cpu_oracle_sample"] = "oracle VDSR step (MSE, SGD momentum + weight decay, clip 0.4), batch 32 of 256, 41x41"
+        net = fill.fill_module(R.EDSR(3, 64, 16), gain=0.5)
+        opt = R.make_optimizer("edsr", net.parameters(), 1e-5)
+        x, t = fill.rand((16, 3, 32, 32), 1234), fill.rand((16, 3, 128, 128), 1235)
+        out["c4_cpu_oracle_patches_per_s"], out["c4_cpu_oracle_threads"] = best_of(lambda: R.step_l1(net, opt, x, t), 16)
+        out["c4_cpu_oracle_sample"] = "oracle EDSR x4 step (L1, Adam), batch 16 = one rank's shard of 128, 32x32 -> 128x128"
+        G, D = fill.fill_module(R.Generator(3, 64, 16), gain=0.5), fill.fill_module(R.Discriminator(3, 64, 128))
+        g_opt = R.make_optimizer("srgan_g", G.parameters(), 1e-4)
+        d_opt = R.make_optimizer("srgan_d", D.parameters(), 1e-4)
+        x, t = fill.rand((4, 3, 32, 32), 1234), fill.rand((4, 3, 128, 128), 1235)
+        out["c5_cpu_oracle_patches_per_s"], out["c5_cpu_oracle_threads"] = best_of(lambda: R.step_srgan(G, D, g_opt, d_opt, x, t), 4)
+        out["c5_cpu_oracle_sample"] = "oracle SRGAN adversarial step (D then G, srgan.py:249-310), batch 4 of 16, 32x32 -> 128x128"
+        out["cpu_oracle_host_threads"] = ncpu
+
     # every side metric is isolated: a failure is reported in the JSON instead of losing the headline line
     sections = ([("c1", c1), ("c3", c3)] if not multi else []) + [("c4_strong", c4_strong)] + \
-               ([("c4_shard16", c4_shard16)] if not multi else [("c4_weak", c4_weak)]) + [("c5", c5)]
+               ([("c4_shard16", c4_shard16)] if not multi else [("c4_weak", c4_weak)]) + [("c5", c5)] + \
+               ([("cpu_train", cpu_train)] if not multi and rank == 0 and cpu_baselines else [])
     for name, fn in sections:
         PROGRESS["section"], PROGRESS["since"] = name, time.perf_counter()
         try:
@@ -682,7 +778,17 @@ def main():
             dog = extras_watchdog(result, extra, rank, int(os.environ.get("SRK_BENCH_EXTRA_TIMEOUT", "420")))
         if world == 1 and pkg.ops.get_precision() == "mixed":
             extra.update(c2_other_precisions(pkg, net, x, max(5, args.steps // 2), 2, dev))
-        train_extra(pkg, dev, rank, world, args.extra_steps, extra)
+        if world == 1:
+            try:
+                extra.update(pixel_shuffle_rates(pkg, dev, args.batch, args.lr_size))
+                if copy_gbps:
+                    extra["ps_kernel_frac_of_measured_copy"] = round(extra["ps_kernel_GBps"] / copy_gbps, 3)
+                # the fused form: the last conv of c2 reads 32 channels and writes the 48 shuffled ones
+                hw = args.lr_size - 8
+                extra["c2_conv3_ps_store_GBps"] = round(4.0 * args.batch * ((hw + 2) ** 2 * 32 + hw * hw * 48) / (layer_ms[2] * 1e-3) / 1e9, 1)
+            except Exception as e:  # noqa: BLE001
+                extra["ps_kernel_error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
+        train_extra(pkg, dev, rank, world, args.extra_steps, extra, cpu_baselines=not args.no_cpu_baseline)
         if dog is not None:
             dog.cancel()
     if rank == 0:

@@ -116,7 +116,7 @@ typedef struct srk_epilogue {
   const float* x_amax;       /* SRK_ALGO_MFMA_F16X3: SRK_AMAX_FLOATS floats, max over the slots >= max|x| (NULL otherwise) */
   float* y_amax;             /* optional: SRK_AMAX_FLOATS floats that receive (atomic max) max|y| of this call's output
                                 -- the next layer's x_amax.  Honoured by the kernels listed at srk_conv2d_f16x3_supported;
-                                check srk_conv2d_writes_amax() */
+                                ask srk_last_conv_wrote_amax() after the call */
 } srk_epilogue;
 
 /* Activation-gradient prologue of the backward kernels: the incoming gradient dy is
@@ -135,6 +135,10 @@ const char* srk_last_error_string(void); /* thread-local, valid until the next f
 /* Name (with template arguments) of the kernel the calling thread's last srk_conv2d_forward / _backward_data call
  * dispatched to, e.g. "k_conv_bfw<2,9,2>" — what a measurement should quote (thread-local, never NULL). */
 const char* srk_last_kernel_name(void);
+/* 1 when the calling thread's last srk_conv2d_forward launched a kernel that keeps the running maximum of its output in
+ * srk_epilogue.y_amax (and y_amax was given), else 0: the caller may hand the slots to the next layer as x_amax only
+ * then (base_networks.py:101-104: a ConvBlock's output is the next block's input). */
+int srk_last_conv_wrote_amax(void);
 /* Output spatial size of a conv / transposed conv along one axis (torch semantics). */
 int srk_conv_out_dim(int in, int k, int stride, int pad, int transposed, int out_pad);
 

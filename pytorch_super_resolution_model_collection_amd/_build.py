@@ -17,6 +17,13 @@ SOURCES = ["api.hip", "elementwise.hip", "loss_optim.hip", "conv_generic.hip", "
 HEADERS = ["srk_common.h", "conv_problem.h", "conv_tile.h", "pack_items.h", os.path.join("..", "..", "include", "srk.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+# SRK_BUILD_EXPERIMENTS=1: compile the experiment switches in (SRK_DBG ablation bits, forced tiles / block shapes --
+# csrc/srk_common.h SRK_EXP_INT); the release library carries their defaults as constants.  The stamp file records which
+# flavour the objects in csrc/build are, so switching flavours rebuilds.
+EXPERIMENTS = os.environ.get("SRK_BUILD_EXPERIMENTS", "0") == "1"
+if EXPERIMENTS:
+    FLAGS = FLAGS + ["-DSRK_EXPERIMENTS"]
+STAMP = os.path.join(CSRC, "build", "flavour.txt")
 
 
 def _hipcc():
@@ -30,9 +37,22 @@ def _mtime(p):
     return os.path.getmtime(p) if os.path.exists(p) else 0.0
 
 
+def _flavour():
+    return "experiments" if EXPERIMENTS else "release"
+
+
+def _stamp_ok():
+    try:
+        with open(STAMP) as fh:
+            return fh.read().strip() == _flavour()
+    except OSError:
+        # no stamp: a library somebody built elsewhere (it travelled with a gpurun snapshot) is taken as it is
+        return not EXPERIMENTS
+
+
 def needs_build():
     newest = max(_mtime(os.path.join(CSRC, f)) for f in SOURCES + HEADERS)
-    return _mtime(LIB) < max(newest, _mtime(__file__))
+    return _mtime(LIB) < max(newest, _mtime(__file__)) or not _stamp_ok()
 
 
 def build(force=False, verbose=True):
@@ -41,6 +61,8 @@ def build(force=False, verbose=True):
         return LIB
     bdir = os.path.join(CSRC, "build")
     os.makedirs(bdir, exist_ok=True)
+    if not _stamp_ok():
+        force = True
     hipcc = _hipcc()
     hdr_time = max(_mtime(os.path.join(CSRC, h)) for h in HEADERS)
 
@@ -64,6 +86,8 @@ def build(force=False, verbose=True):
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
     os.replace(tmp, LIB)
+    with open(STAMP, "w") as fh:
+        fh.write(_flavour() + "\n")
     if verbose:
         print("built", LIB)
     return LIB

@@ -53,6 +53,7 @@ _PROTOTYPES = {
     "srk_status_string": (ctypes.c_char_p, [c_int]),
     "srk_last_error_string": (ctypes.c_char_p, []),
     "srk_last_kernel_name": (ctypes.c_char_p, []),
+    "srk_last_conv_wrote_amax": (c_int, []),
     "srk_conv_out_dim": (c_int, [c_int] * 6),
     "srk_nchw_to_nhwc": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_vp]),
     "srk_nhwc_to_nchw": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_vp]),
@@ -158,6 +159,9 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+ERR_UNSUPPORTED = -2   # SRK_ERR_UNSUPPORTED (include/srk.h)
 
 
 def check(rc, what):

@@ -26,6 +26,48 @@ void note_kernel(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- environment switches: one getenv per variable and process (see srk_common.h) ----
+namespace {
+struct EnvSlot { const char* name; const char* val; };
+constexpr int kEnvSlots = 64;
+EnvSlot g_env[kEnvSlots];
+std::atomic<int> g_env_n{0};
+std::atomic<int> g_env_lock{0};
+}  // namespace
+
+const char* env_str(const char* name) {
+  static const bool live = getenv("SRK_ENV_LIVE") != nullptr;
+  if (live) return getenv(name);
+  const int n = g_env_n.load(std::memory_order_acquire);
+  for (int i = 0; i < n; ++i)
+    if (g_env[i].name == name || !strcmp(g_env[i].name, name)) return g_env[i].val;
+  while (g_env_lock.exchange(1, std::memory_order_acquire)) {}
+  const int m = g_env_n.load(std::memory_order_relaxed);
+  const char* v = nullptr;
+  bool found = false;
+  for (int i = 0; i < m && !found; ++i)
+    if (!strcmp(g_env[i].name, name)) { v = g_env[i].val; found = true; }
+  if (!found) {
+    const char* e = getenv(name);
+    v = e ? strdup(e) : nullptr;
+    if (m < kEnvSlots) {
+      g_env[m] = EnvSlot{name, v};
+      g_env_n.store(m + 1, std::memory_order_release);
+    }
+  }
+  g_env_lock.store(0, std::memory_order_release);
+  return v;
+}
+
+int env_int(const char* name, int dflt) {
+  const char* e = env_str(name);
+  return e ? atoi(e) : dflt;
+}
+
+static thread_local int g_amax_written = 0;
+
+void note_amax_written(bool written) { g_amax_written = written ? 1 : 0; }
+
 // conv_tapn.hip
 bool conv_tapn_gather_supported(const GatherConv& g, const float* in, const float* mask_y);
 int conv_tapn_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, bool x6,
@@ -91,7 +133,7 @@ static int validate_desc(const srk_conv_desc* d, const char* who) {
 
 static int forced_algo(int algo) {
   if (algo != SRK_ALGO_AUTO) return algo;
-  const char* e = getenv("SRK_FORCE_ALGO");  // debugging aid: generic|mfma|direct
+  const char* e = env_str("SRK_FORCE_ALGO");  // debugging aid: generic|mfma|direct
   if (!e) return SRK_ALGO_AUTO;
   if (!strcmp(e, "generic")) return SRK_ALGO_GENERIC;
   if (!strcmp(e, "mfma")) return SRK_ALGO_MFMA;
@@ -176,7 +218,7 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
     return conv_direct_gather(g, in, wp, out, ep, mask_y, mask_slope, s);
   if (algo == SRK_ALGO_MFMA_BF16X3 || (algo == SRK_ALGO_AUTO && bf3_ok)) {
     // filters-from-global variant: small problems (channel-split 64-pixel blocks), or on request
-    const char* e = getenv("SRK_BF3_DIRECT");  // 0 = never, 1 = always, unset = small problems only
+    const char* e = env_str("SRK_BF3_DIRECT");  // 0 = never, 1 = always, unset = small problems only
     const int direct_w = e ? (atoi(e) ? 1 : 0) : 2;
     if (bfd_ok && (direct_w == 1 || (direct_w == 2 && conv_bfd_small_problem(g))))
       return conv_bfd_gather(g, in, wp, out, ep, mask_y, mask_slope, 2, s);
@@ -216,6 +258,8 @@ extern "C" const char* srk_last_error_string(void) { return g_err; }
 
 extern "C" const char* srk_last_kernel_name(void) { return g_kernel; }
 
+extern "C" int srk_last_conv_wrote_amax(void) { return g_amax_written; }
+
 extern "C" int srk_conv_out_dim(int in, int k, int stride, int pad, int transposed, int out_pad) {
   if (in <= 0 || k <= 0 || stride <= 0 || pad < 0) return -1;
   if (!transposed) return (in + 2 * pad - k) / stride + 1;
@@ -224,6 +268,7 @@ extern "C" int srk_conv_out_dim(int in, int k, int stride, int pad, int transpos
 
 extern "C" int srk_conv2d_forward(const srk_conv_desc* d, const float* x, const float* w_packed_fwd, float* y,
                                   const srk_epilogue* ep_in, void* stream) {
+  note_amax_written(false);
   int rc = validate_desc(d, "conv2d_forward");
   if (rc) return rc;
   SRK_REQUIRE(x && w_packed_fwd && y, "conv2d_forward: null tensor pointer");
@@ -382,7 +427,7 @@ extern "C" int srk_conv2d_backward_weight(const srk_conv_desc* d, const float* x
   // AUTO / BF16X3: bf16x3 MFMA kernel where it applies (stride-1 convs up to 3x3); MFMA / BF16X6 / DIRECT: the
   // exact fp32 MFMA kernel; GENERIC: the plain kernel
   const int algo = forced_algo(d->algo);
-  const char* wb = getenv("SRK_WGRAD_BF16");  // 0 disables the bf16x3 weight-gradient kernels
+  const char* wb = env_str("SRK_WGRAD_BF16");  // 0 disables the bf16x3 weight-gradient kernels
   if ((algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3) && !(wb && atoi(wb) == 0) &&
       conv_wgrad_tapn_supported(*d, x, mask))  // few-output-channel reconstruction convs
     return conv_wgrad_tapn(*d, x, dy, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);
@@ -400,8 +445,8 @@ extern "C" int srk_conv2d_backward_weight(const srk_conv_desc* d, const float* x
 
 static bool wgrad_group_uses_bf(const srk_conv_desc& d) {
   const int algo = forced_algo(d.algo);
-  const char* wb = getenv("SRK_WGRAD_BF16");
-  const char* gg = getenv("SRK_WGRAD_GROUPED");  // 0: grouped calls run layer by layer (A/B against the per-layer kernels)
+  const char* wb = env_str("SRK_WGRAD_BF16");
+  const char* gg = env_str("SRK_WGRAD_GROUPED");  // 0: grouped calls run layer by layer (A/B against the per-layer kernels)
   return (algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3) && !(wb && atoi(wb) == 0) && !(gg && atoi(gg) == 0) &&
          d.dy_ps_r == 0 && !conv_wgrad_tapn_supported(d, nullptr, nullptr) && conv_wgrad_bf_supported(d);
 }

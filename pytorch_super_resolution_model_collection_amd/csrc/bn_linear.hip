@@ -512,8 +512,7 @@ __global__ __launch_bounds__(256) void k_bn_param_grads(const double* __restrict
 
 // SRK_BN_F32=1 (debugging / A-B only): the backward arithmetic of round 1 (fp32 per-element terms)
 static bool bn_fp32_backward() {
-  static const bool v = [] { const char* e = getenv("SRK_BN_F32"); return e && e[0] == '1'; }();
-  return v;
+  return env_int("SRK_BN_F32", 0) == 1;
 }
 
 struct BnFused {   // fused tail of bn_colsum: what the reduce kernel also computes
@@ -828,7 +827,7 @@ __global__ __launch_bounds__(256) void k_linear_dw_wide(const float* __restrict_
 }
 
 static bool linear_wide(const void* a, const void* b, const void* c, int In, int Out) {
-  static const int off = getenv("SRK_LINEAR_WIDE") ? atoi(getenv("SRK_LINEAR_WIDE")) == 0 : 0;
+  const bool off = env_int("SRK_LINEAR_WIDE", 1) == 0;
   if (off || (In & 3) || In < 2048 || Out < 64) return false;
   return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0;
 }

@@ -486,6 +486,7 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, OCCX ? OCCX : (bfd_occ<NTW, NP
 // ---------------------------------------------------------------------------------------------
 template <int NTW, int NPW, int NOW, int NP, int PF, bool F16 = false, int OCCX = 0>
 static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
+  note_amax_written(B.P.ep.y_amax != nullptr);   // both epilogues keep the running maximum of what they store
   MfmaConvParams& P = B.P;
   const int maxpix = 64 * NPW;
   TilePick best{};
@@ -519,7 +520,7 @@ static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
   dim3 grid((unsigned)((size_t)P.tiles_x * P.tiles_y * P.N), B.OCb);
   if constexpr (NPW == 1) {
     // small-problem blocks with >= 2 staged chunks: split the chunks over two wave groups (SRK_BFD_KSPLIT=0: off)
-    static const int ksplit = getenv("SRK_BFD_KSPLIT") ? atoi(getenv("SRK_BFD_KSPLIT")) : 1;
+    const int ksplit = env_int("SRK_BFD_KSPLIT", 1);
     const size_t red_bytes = (size_t)NOW * 4 * NTW * 64 * 16;
     // only while the grid leaves the CUs with one block each: with two resident blocks the other block already hides the
     // latency and the split just adds the reduction (B = 32 EDSR shard: 3.28 -> 3.55 ms with it, B = 16: 2.63 -> 2.37 ms)
@@ -565,18 +566,13 @@ bool conv_bfd_gather_supported(const GatherConv& g, const Epi& ep) {
 }
 
 static int bfd_dbg() {
-  static int dbg = -1;
-  if (dbg < 0) {
-    const char* e = getenv("SRK_DBG");
-    dbg = e ? atoi(e) : 0;
-  }
-  return dbg;
+  return SRK_EXP_INT("SRK_DBG", 0);
 }
 
 // small problem: fewer pixels than two resident 256-pixel tiles per CU -> 64-pixel blocks whose waves
 // split the output channels
 bool conv_bfd_small_problem(const GatherConv& g) {
-  const char* e = getenv("SRK_BFD_SMALL");  // tests: 0 / 1 force the large / small block configuration
+  const char* e = env_str("SRK_BFD_SMALL");  // tests: 0 / 1 force the large / small block configuration
   if (e) return atoi(e) != 0;
   const int st = g.trans ? g.stride : 1;
   const long px = (long)g.N * ((g.OH + st - 1) / st) * ((g.OW + st - 1) / st) * ((g.OC + 63) / 64);
@@ -614,11 +610,11 @@ static int bfd_launch_phase(MfmaConvParams P, const uint4* wq, const uint4* wq3,
       if constexpr (F16) {
         // experiment switch (SRK_BFD_F16_CFG): 0 = the bf16x3 block (4 pixel-waves x 64 channels, 2 waves per SIMD),
         // 1 / 2 = the bf16x6 block shape (2 x 2 waves of 64 px x 32 ch) compiled for 3 / 4 waves per SIMD
-        static const int cfg = getenv("SRK_BFD_F16_CFG") ? atoi(getenv("SRK_BFD_F16_CFG")) : 1;
+        const int cfg = env_int("SRK_BFD_F16_CFG", 1);
         if (cfg == 1) return bfd_launch<2, 2, 2, NP, 1, true, 3>(B, BIG, s);
         if (cfg == 2) return bfd_launch<2, 2, 2, NP, 1, true, 4>(B, BIG, s);
       } else if constexpr (NP == 2) {
-        static const int cfg3 = getenv("SRK_BFD_X3_CFG") ? atoi(getenv("SRK_BFD_X3_CFG")) : 0;   // experiment: the same block for bf16x3
+        const int cfg3 = SRK_EXP_INT("SRK_BFD_X3_CFG", 0);   // experiment: the same block for bf16x3
         if (cfg3 == 1) return bfd_launch<2, 2, 2, NP, 1, false, 3>(B, BIG, s);
       }
       return bfd_launch<4, 4, 1, NP, 1, F16>(B, BIG, s);

@@ -504,8 +504,7 @@ static inline int bfw_slices(const GatherConv& g) {
 // one persistent block per CU busy for several tiles.  The activation-gradient mask (mask_y) is applied by the
 // producers of the 32-channel 3x3 variant.  SRK_BFW: 0 never, 1 whenever applicable, unset = automatic.
 bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, const float* out, const float* mask_y) {
-  // (read per dispatch, ~0.1 us: the conv KAT variants of tests/test_ops_gpu.py switch it inside one process)
-  const char* e = getenv("SRK_BFW");
+  const char* e = env_str("SRK_BFW");
   const int mode = e ? atoi(e) : 2;
   if (mode == 0 || g.stride != 1 || g.in_nchw || g.in_ps_r > 1) return false;
   if (g.IC < 8 || g.IC % 8 != 0 || (uintptr_t)in % 16 != 0) return false;
@@ -532,6 +531,7 @@ bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, co
 
 template <int NTW, int TT, int MTW>
 static int bfw_launch_t(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
+  note_amax_written(B.P.ep.y_amax != nullptr);
   if constexpr (NTW == 2 && TT == 9 && MTW == 2) {  // data gradients (bf16x3): mask on dy and / or ReLU gradient on dx
     const dim3 blk(64 * (16 / MTW + 4));
     if (B.P.mask_y && B.P.ep.out_relu) {
@@ -576,7 +576,7 @@ static int bfw_launch(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
   // -1 % / -3.5 % on the c2 64->32 / 32->48 layers vs 4 x 64 pixels) while the kernel fits 168 VGPRs (<= 48 output
   // channels); 64 channels: 4 x 64 pixels.  3x3 kernels get the unrolled tap loop with deferred stores; with 64-pixel
   // consumer waves and > 32 channels that variant spills (256 VGPRs) and the dynamic loop is used.
-  static const int mtw_env = getenv("SRK_BFW_MTW") ? atoi(getenv("SRK_BFW_MTW")) : 0;  // experiment: 2 or 4
+  const int mtw_env = SRK_EXP_INT("SRK_BFW_MTW", 0);  // experiment: 2 or 4
   const bool t9 = B.P.KHv * B.P.KWv == 9;
   const int mtw = mtw_env ? mtw_env : (NTW <= 3 ? 2 : 4);
   if (mtw == 2 && NTW <= 3) {
@@ -595,8 +595,7 @@ int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float
   const char* fsec = prepared + f16_section_offset(g.IC, g.OC, g.KH * g.KW);
   const uint4* wq = reinterpret_cast<const uint4*>(f16 ? fsec : prepared);
   const float* w_descale = f16 ? reinterpret_cast<const float*>(fsec + bf3_main_bytes(g.IC, g.OC, g.KH * g.KW)) : nullptr;
-  static int dbg = -1;
-  if (dbg < 0) dbg = getenv("SRK_DBG") ? atoi(getenv("SRK_DBG")) : 0;
+  const int dbg = SRK_EXP_INT("SRK_DBG", 0);
   const int nsl = bfw_slices(g);
   if (nsl == 0) return -1;
   return for_each_phase(g, in, wp, out, ep, mask_y, mask_slope, [&](const MfmaConvParams& P0) {
@@ -616,8 +615,8 @@ int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float
     const long lds_cap = 160L * 1024 - 512;
     long px_cap = (lds_cap - (long)wbytes) / (2 * 128);  // halo pixels per buffer (128 bytes each)
     if (px_cap > 64 * BFW_IT) px_cap = 64 * BFW_IT;
-    static const int perm = getenv("SRK_BFW_PERM") ? atoi(getenv("SRK_BFW_PERM")) : 1;
-    static const int w16 = getenv("SRK_BFW_W16") ? atoi(getenv("SRK_BFW_W16")) : 0;
+    const int perm = SRK_EXP_INT("SRK_BFW_PERM", 1);
+    const int w16 = SRK_EXP_INT("SRK_BFW_W16", 0);
     B.perm = perm;
     TilePick best{};
     if (px_cap < 64 || P.is != 1) return -1;

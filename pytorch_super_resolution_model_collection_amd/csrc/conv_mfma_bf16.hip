@@ -521,8 +521,11 @@ __global__ __launch_bounds__(256) void k_pack_batched_amax(const float* __restri
   const float* w = params + row[0];
   __shared__ float sm[4];
   float a = 0.f;
-  if ((long)blockIdx.x * 1024 >= elems) return;   // (whole block: nothing of this layer left for the slice)
-  if ((reinterpret_cast<uintptr_t>(w) & 15) == 0) {   // flat parameter buffers keep every tensor 16-byte aligned
+  const bool vec = (reinterpret_cast<uintptr_t>(w) & 15) == 0;   // flat parameter buffers keep every tensor 16-byte aligned
+  // (whole block: nothing of this layer left for the slice -- a block's first element is 1024 x its index on the float4
+  // path, 256 x its index on the scalar path of an unaligned tensor)
+  if ((long)blockIdx.x * (vec ? 1024 : 256) >= elems) return;
+  if (vec) {
     typedef float pa_f4 __attribute__((ext_vector_type(4)));
     const long n4 = elems >> 2;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)slices * 256) {
@@ -930,7 +933,8 @@ template <int NT, bool VEC_ONLY, bool F16 = false>
 static void bf3_launch_rows_v(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s) {
   static LdsLimit lim;
   lim.ensure(reinterpret_cast<const void*>(&k_conv_bf3_rows<NT, VEC_ONLY, F16>), lds);
-  note_kernel("k_conv_bf3_rows<%d%s>", NT, F16 ? ",f16" : "");
+  note_kernel("k_conv_bf3_rows<%d%s%s>", NT, F16 ? ",f16" : "", VEC_ONLY ? "" : ",scalar");
+  note_amax_written(VEC_ONLY && B.P.ep.y_amax != nullptr);   // (the scalar-store variant keeps no maximum)
   hipLaunchKernelGGL((k_conv_bf3_rows<NT, VEC_ONLY, F16>), grid, dim3(256), lds, s, B);
 }
 template <int NT>
@@ -961,7 +965,7 @@ static int bf3_launch_rows_phase(MfmaConvParams P, const uint4* wq, hipStream_t 
   P.TH = best.TH; P.TW = best.TW; P.tiles_y = best.tiles_y; P.tiles_x = best.tiles_x; P.HH = best.HH; P.HW = best.HW;
   B.NPIXp = (best.HH * best.HW + 16 + 15) & ~15;  // +16: the last row's padded kw slots read past the halo
   B.P = P;
-  { const char* e = getenv("SRK_ROWS_DBG"); B.dbg = e ? atoi(e) : 0; }   // ablation: 1 no halo loads, 2 no epilogue, 4 no MFMAs, 64 no global stores
+  B.dbg = SRK_EXP_INT("SRK_ROWS_DBG", 0);   // ablation: 1 no halo loads, 2 no epilogue, 4 no MFMAs, 64 no global stores
   size_t lds = (size_t)B.NPIXp * 16 + wbytes;
   const size_t epi_bytes = (size_t)4 * 32 * BF3_EPI_STRIDE * sizeof(float);
   if (lds < epi_bytes) lds = epi_bytes;
@@ -1032,13 +1036,8 @@ static int bf3_launch_phase(MfmaConvParams P, const uint4* wq, hipStream_t s) {
   B.ICc = (P.IC + 31) / 32;
   B.OCb = (P.OC + 63) / 64;
   B.wq = wq;
-  static int dbg = -1, nw = -1;
-  if (dbg < 0) {
-    const char* e = getenv("SRK_DBG");
-    dbg = e ? atoi(e) : 0;
-    const char* w = getenv("SRK_BF3_WAVES");  // waves per block: 4 (256-px tiles), 2 or 1 — more, smaller blocks per CU
-    nw = w ? atoi(w) : 0;  // 0 = automatic
-  }
+  const int dbg = SRK_EXP_INT("SRK_DBG", 0);
+  const int nw = SRK_EXP_INT("SRK_BF3_WAVES", 0);  // waves per block: 4 (256-px tiles), 2 or 1 -- more, smaller blocks per CU; 0 = automatic
   int use = nw;
   if (nw <= 0) {
     // small problems (strong-scaled shards): fewer pixels than 2 resident 256-pixel tiles per CU ->

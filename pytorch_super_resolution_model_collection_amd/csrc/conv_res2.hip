@@ -368,8 +368,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
 #undef mfma16
 
 static int r2_dbg() {
-  static const int dbg = getenv("SRK_DBG") ? atoi(getenv("SRK_DBG")) : 0;
-  return dbg;
+  return SRK_EXP_INT("SRK_DBG", 0);
 }
 
 // Small problems only: the tile does 1.56x the first conv's matrix work, which is free while a CU has a few tiles and
@@ -378,7 +377,7 @@ static int r2_dbg() {
 // 4.57, 128 (8 tiles per CU): 7.57 vs 7.08 -> the limit sits at 5 tiles per CU.
 bool conv_res2_supported(int N, int H, int W, int C) {
   // (round 3: with the f16x3 forward the fused block also wins at 8 tiles per CU: EDSR batch 128 6.46 -> 6.33 ms)
-  static const int max_tiles = getenv("SRK_RES2_MAX_TILES") ? atoi(getenv("SRK_RES2_MAX_TILES")) : 10 * kNumCU;
+  const int max_tiles = env_int("SRK_RES2_MAX_TILES", 10 * kNumCU);
   if (C != R2_C || N < 1 || H < 1 || W < 1) return false;
   if ((long)H * W * R2_C >= (1L << 29)) return false;  // 32-bit element offsets inside an image
   const long tiles = (long)N * ((H + R2_TS - 1) / R2_TS) * ((W + R2_TS - 1) / R2_TS);

@@ -391,7 +391,7 @@ static inline int rowsw_steps(const GatherConv& g) { return g.KH * ((g.KW + 7) /
 // (3x3 and 5x5 filters), every output group on the 16-byte store path, the branch-free activations, an output below
 // 2 GiB, and at least two 256-pixel tiles per CU.  SRK_ROWSW: 0 never, 1 whenever applicable, unset = automatic.
 bool conv_rowsw_applicable(const GatherConv& g, const Epi& ep, const float* in, const float* out, const float* mask_y) {
-  const char* e = getenv("SRK_ROWSW");
+  const char* e = env_str("SRK_ROWSW");
   const int mode = e ? atoi(e) : 2;
   if (mode == 0 || mask_y || g.trans || g.stride != 1 || g.in_ps_r > 1 || g.IC > 4 || g.IC < 1) return false;
   if (g.OC % 64 != 0 || g.OC < 64) return false;
@@ -409,6 +409,7 @@ bool conv_rowsw_applicable(const GatherConv& g, const Epi& ep, const float* in, 
 
 template <int NTW, int QT>
 static int rowsw_launch(const RowswParams& B, size_t lds, int grid, hipStream_t s) {
+  note_amax_written(B.P.ep.y_amax != nullptr);
   if (B.w_descale) {
     static LdsLimit limh;
     limh.ensure(reinterpret_cast<const void*>(&k_conv_rowsw<NTW, QT, true>), lds);
@@ -445,7 +446,7 @@ int conv_rowsw_gather(const GatherConv& g, const float* in, const float* wp, flo
     // barrier work: measured 366 us against 289 us on the c2 first layer, even with the filter in registers.)
     constexpr int ntw = 4;
     B.nsl = P.OC / (16 * ntw);
-    static const int dbg = getenv("SRK_ROWSW_DBG") ? atoi(getenv("SRK_ROWSW_DBG")) : 0;
+    const int dbg = SRK_EXP_INT("SRK_ROWSW_DBG", 0);
     B.dbg = dbg;
     TilePick best{};
     if (P.is != 1 || !rowsw_pick_tile(P.PH, P.PW, P.KHv, P.KWv, 768, best)) return -1;

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void k_conv_tapn(MfmaConvParams
 }
 
 bool conv_tapn_gather_supported(const GatherConv& g, const float* in, const float* mask_y) {
-  static const int off = getenv("SRK_TAPN") ? !atoi(getenv("SRK_TAPN")) : 0;  // SRK_TAPN=0: use k_conv_direct
+  const bool off = env_int("SRK_TAPN", 1) == 0;  // SRK_TAPN=0: use k_conv_direct
   if (off) return false;
   if (g.OC < 1 || g.OC > 3 || g.KH * g.KW > 121) return false;  // larger kernels: several 32-column tap groups
   if (g.IC != 32 && g.IC != 64) return false;
@@ -388,7 +388,7 @@ static int wgrad_tapn_blocks(const srk_conv_desc& d) {
 }
 
 bool conv_wgrad_tapn_supported(const srk_conv_desc& d, const float* x, const srk_bwd_mask* mask) {
-  static const int off = getenv("SRK_TAPN") ? !atoi(getenv("SRK_TAPN")) : 0;
+  const bool off = env_int("SRK_TAPN", 1) == 0;
   if (off) return false;
   if (d.transposed || d.stride != 1 || d.dy_ps_r > 1 || (mask && mask->y)) return false;
   if (d.Cout < 1 || d.Cout > 3 || d.KH * d.KW * d.Cout > 32) return false;
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void k_conv_tapk(MfmaConvParams P, int groups_
 bool conv_tapk_gather_supported(const GatherConv& g, const Epi& ep, const float* out, const float* mask_y) {
   if (ep.bias || ep.act != SRK_ACT_NONE || ep.ps_r > 1 || (uintptr_t)out % 16 != 0 || (uintptr_t)ep.residual % 16 != 0)
     return false;
-  static const int off = getenv("SRK_TAPN") ? !atoi(getenv("SRK_TAPN")) : 0;
+  const bool off = env_int("SRK_TAPN", 1) == 0;
   if (off) return false;
   if (!g.trans || g.stride != 1) return false;  // CONV gathers with IC <= 4 have the row-packed kernel
   if (g.IC < 1 || g.IC > 3 || g.KH * g.KW * g.IC > 32) return false;

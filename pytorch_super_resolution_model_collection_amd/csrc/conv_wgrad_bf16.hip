@@ -793,7 +793,7 @@ static WbPlan wb_plan(const srk_conv_desc& d) {
   // pixels per padded K step (e.g. 41-wide VDSR patches: 2 x 48 -> 83 % instead of 4 x 32 -> 60 %); ties -> taller
   // tiles (less halo per pixel).
   double best_eff = -1.0;
-  static const char* tile_env = getenv("SRK_WG_TILE");  // experiment: "TH,TWo" forces the tile shape
+  const char* tile_env = SRK_EXP_STR("SRK_WG_TILE");  // experiment: "TH,TWo" forces the tile shape
   int force_th = 0, force_two = 0;
   if (tile_env) sscanf(tile_env, "%d,%d", &force_th, &force_two);
   for (int TWo = 1; TWo <= 6 && (TWo - 1) * 8 < d.OW; ++TWo) {
@@ -831,12 +831,8 @@ static WbPlan wb_plan(const srk_conv_desc& d) {
   pl.ntiles = (int)nt;
   pl.gy = cdiv(d.Cin, pl.CIB);
   pl.gz = cdiv(d.Cout, pl.COB);
-  static int blocks_per_cu = 0;
-  if (!blocks_per_cu) {
-    const char* e = getenv("SRK_WG_BLOCKS");  // experiment: resident blocks per CU (slab count vs overlap)
-    blocks_per_cu = e ? atoi(e) : 2;
-    if (blocks_per_cu < 1) blocks_per_cu = 1;
-  }
+  int blocks_per_cu = SRK_EXP_INT("SRK_WG_BLOCKS", 2);  // experiment: resident blocks per CU (slab count vs overlap)
+  if (blocks_per_cu < 1) blocks_per_cu = 1;
   int g = (blocks_per_cu * kNumCU) / (pl.gy * pl.gz);
   if (g < 1) g = 1;
   pl.G = pl.ntiles < g ? pl.ntiles : g;
@@ -846,7 +842,7 @@ static WbPlan wb_plan(const srk_conv_desc& d) {
 
 // SPEC stagers prefetch one tile ahead when a tile's pixel pairs fit their register batches (WB_PIT x 512 items per tensor)
 static int wb_prefetch_ok(const WbPlan& pl, const srk_conv_desc& d) {
-  static const int env = getenv("SRK_WGRAD_PREFETCH") ? atoi(getenv("SRK_WGRAD_PREFETCH")) : 1;
+  const int env = env_int("SRK_WGRAD_PREFETCH", 1);
   if (!env) return 0;
   const long x_items = (long)pl.HH * ((pl.TW + d.KW) >> 1) * (pl.CIB / 4);
   const long y_items = (long)pl.TH * (pl.TW >> 1) * (pl.COB / 4);
@@ -858,7 +854,7 @@ static int wb_prefetch_ok(const WbPlan& pl, const srk_conv_desc& d) {
 // Ring mode of the wave-specialised kernel (WgBfParams.ring): plane stride of the 2 * HH-row ring and the LDS it needs
 // (ring + two dY buffer sets); 0 when it does not apply.  SRK_WG_RING=0: off.
 static size_t wb_ring_setup(const WbPlan& pl, bool spec, int prefetch, int& cs_ring) {
-  static const int ring_env = getenv("SRK_WG_RING") ? atoi(getenv("SRK_WG_RING")) : 1;
+  const int ring_env = env_int("SRK_WG_RING", 1);
   if (!ring_env || !spec || !prefetch) return 0;
   cs_ring = round_8odd(2 * pl.HH * pl.HWp);
   const size_t bytes = ((size_t)2 * pl.CIB * cs_ring + (size_t)2 * 2 * pl.COB * pl.DS) * 2;
@@ -874,7 +870,7 @@ size_t conv_wgrad_bf_ws(const srk_conv_desc& d) {
 }
 
 static bool wb_k33(const WgBfParams& P) {
-  static const int env = getenv("SRK_WG_K33") ? atoi(getenv("SRK_WG_K33")) : 1;
+  const int env = env_int("SRK_WG_K33", 1);
   return env && P.KH == 3 && P.KW == 3;
 }
 
@@ -1003,7 +999,7 @@ int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const
   P.prefetch = wb_prefetch_ok(pl, d) && P.vec_x && P.vec_y;  // 16-byte channel groups only
   // wave-specialised variant: one 512-thread block per CU with two LDS buffer sets, when every block has >= 2 tiles
   // to pipeline (SRK_WGRAD_SPEC=0: never)
-  static const int spec_env = getenv("SRK_WGRAD_SPEC") ? atoi(getenv("SRK_WGRAD_SPEC")) : 1;
+  const int spec_env = env_int("SRK_WGRAD_SPEC", 1);
   int G = pl.G;
   bool spec = false;
   if (spec_env && 2 * pl.lds + 8 * 1024 <= 160 * 1024) {
@@ -1027,11 +1023,7 @@ int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const
     }
   }
   {
-    static int dbg = -1;
-    if (dbg < 0) {
-      const char* e = getenv("SRK_DBG");
-      dbg = e ? atoi(e) : 0;
-    }
+    const int dbg = SRK_EXP_INT("SRK_DBG", 0);
     P.dbg = dbg;
     if (dbg & 32)
       fprintf(stderr, "[srk] k_wgrad_bf cfg %d%s%s: tile %d x %d (%d K steps), %d tiles over %d x %d x %d blocks, lds %zu B\n",
@@ -1057,8 +1049,8 @@ int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const
 // wave-specialised variant), writes one slab, and 33 layers cost two launches instead of 66.
 // ---------------------------------------------------------------------------------------------
 static int wb_group_G(const WbPlan& pl, int n, bool& spec) {
-  static const int spec_env = getenv("SRK_WGRAD_SPEC") ? atoi(getenv("SRK_WGRAD_SPEC")) : 1;
-  static const int g_env = getenv("SRK_WG_GROUP_G") ? atoi(getenv("SRK_WG_GROUP_G")) : 0;  // experiment: slabs per layer
+  const int spec_env = env_int("SRK_WGRAD_SPEC", 1);
+  const int g_env = SRK_EXP_INT("SRK_WG_GROUP_G", 0);  // experiment: slabs per layer
   const int per = n * pl.gy * pl.gz;  // (layer, channel-chunk) pairs
   // one block per CU (wave-specialised, two LDS buffer sets) when every block gets >= 2 tiles; else two per CU
   int g1 = kNumCU / per;
@@ -1134,11 +1126,7 @@ int conv_wgrad_bf_grouped(const srk_conv_desc& d, int n, const float* const* xs,
   P.dy_ps_r = 0; P.dy_ps_C = d.Cout;
   P.prefetch = wb_prefetch_ok(pl, d) && P.vec_x && P.vec_y;  // 16-byte channel groups only
   {
-    static int dbg = -1;
-    if (dbg < 0) {
-      const char* e = getenv("SRK_DBG");
-      dbg = e ? atoi(e) : 0;
-    }
+    const int dbg = SRK_EXP_INT("SRK_DBG", 0);
     P.dbg = dbg;
     if (dbg & 32)
       fprintf(stderr, "[srk] k_wgrad_bf grouped cfg %d%s: %d layers x %d slabs, tile %d x %d, %d tiles per layer, grid %d x %d x %d\n",

@@ -478,7 +478,7 @@ static WgPlan plan(const srk_conv_desc& d) {
     // one slab per tile makes the slabs -- written here, read back by the reduce -- the dominant traffic.  Cap the
     // slab count at what fills the GPU (2 blocks per CU) together with the channel blocks of the grid: SRGAN adversarial
     // step 16.49 -> 15.78 ms (0 = one slab per tile: 16.49, 1: 16.12, 4: 15.99).
-    static const int per_cu = getenv("SRK_WG_MFMA_BLOCKS") ? atoi(getenv("SRK_WG_MFMA_BLOCKS")) : 2;
+    const int per_cu = env_int("SRK_WG_MFMA_BLOCKS", 2);
     if (per_cu > 0 && !pl.smallcin) {
       const int chan_blocks = cdiv(d.Cin, 64) * cdiv(d.Cout, pl.NTC * 16);
       int g = (per_cu * kNumCU + chan_blocks - 1) / chan_blocks;
@@ -583,7 +583,7 @@ int conv_wgrad_mfma(const srk_conv_desc& d, const float* x, const float* dy, con
                     float* db, float beta, void* ws, size_t ws_bytes, hipStream_t s) {
   {
     srk_conv_desc ds;
-    const char* e = getenv("SRK_WGRAD_SWAP");  // 0 disables the role-swapped small-Cout path
+    const char* e = env_str("SRK_WGRAD_SWAP");  // 0 disables the role-swapped small-Cout path
     if (!(e && atoi(e) == 0) && !(mask && mask->y) && swap_small_cout(d, ds) && plan(ds).ok && plan(ds).smallcin)
       return conv_wgrad_small_cout(d, ds, x, dy, dw, db, beta, ws, ws_bytes, s);
   }

@@ -99,6 +99,115 @@ __global__ __launch_bounds__(256) void k_pixel_shuffle(const float* __restrict__
   }
 }
 
+// Tiled form for the (r, C) pairs the reference's nets use (espcn.py:26 / base_networks.py:157,181: r = scale factor with
+// C = 3 or 1 image channels, r = 2 with C = 64 feature channels).  One block moves a run of WT input pixels of one image
+// row: WT * C * r * r consecutive floats on the x side, r runs of WT * r * C consecutive floats (output rows h r .. h r + r - 1)
+// on the y side -- both sides are read / written as whole 16-byte vectors of consecutive addresses, the permutation
+// happens in LDS (x-side layout, word = w * Cin + c r^2 + i r + j) with every division by a compile-time constant.
+// HBM traffic = the 8 bytes per element the permutation needs; the round-1 kernel above (one element per thread behind
+// 64-bit divisions, 4-byte gathers) stays as the fallback for other shapes and unaligned tensors.
+template <int R, int C, bool FWD>
+__global__ __launch_bounds__(256) void k_pixel_shuffle_tile(const float* __restrict__ src, float* __restrict__ dst, int H,
+                                                            int W, int WT, int nwt) {
+  constexpr int RR = R * R, CIN = C * RR, RC = R * C;
+  constexpr bool VX = CIN % 4 == 0;   // x-side runs start on 16-byte boundaries
+  constexpr bool VY = RC % 4 == 0;    // y-side runs do
+  typedef float ps_f4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float ps_sm[];
+  int b = blockIdx.x;
+  const int wt = b % nwt;
+  b /= nwt;                            // b = n * H + h
+  const int w0 = wt * WT;
+  const int cnt = min(WT, W - w0);
+  const int tid = threadIdx.x;
+  const float* xs = FWD ? src : dst;   // (only for the address arithmetic below)
+  (void)xs;
+  const size_t x_off = ((size_t)b * W + w0) * CIN;             // x-side run of this block
+  const size_t y_row0 = ((size_t)b * R * W * R + (size_t)w0 * R) * C;   // y-side run of output row i = 0; + i * W * RC per row
+  const int nx = cnt * CIN, ny = cnt * RC;
+  auto word = [&](int i, int o) {      // LDS word of y-side element o of output row i
+    const int pix = o / C, c = o - pix * C;
+    const int w = pix / R, j = pix - w * R;
+    return w * CIN + c * RR + i * R + j;
+  };
+  if (FWD) {
+    if (VX) {
+      for (int q = tid; q < nx / 4; q += 256)
+        reinterpret_cast<ps_f4*>(ps_sm)[q] = reinterpret_cast<const ps_f4*>(src + x_off)[q];
+    } else {
+      for (int q = tid; q < nx; q += 256) ps_sm[q] = src[x_off + q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      float* row = dst + y_row0 + (size_t)i * W * RC;
+      if (VY) {
+        for (int q = tid; q < ny / 4; q += 256) {
+          ps_f4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ps_sm[word(i, 4 * q + e)];
+          reinterpret_cast<ps_f4*>(row)[q] = v;
+        }
+      } else {
+        for (int q = tid; q < ny; q += 256) row[q] = ps_sm[word(i, q)];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const float* row = src + y_row0 + (size_t)i * W * RC;
+      if (VY) {
+        for (int q = tid; q < ny / 4; q += 256) {
+          const ps_f4 v = reinterpret_cast<const ps_f4*>(row)[q];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ps_sm[word(i, 4 * q + e)] = v[e];
+        }
+      } else {
+        for (int q = tid; q < ny; q += 256) ps_sm[word(i, q)] = row[q];
+      }
+    }
+    __syncthreads();
+    if (VX) {
+      for (int q = tid; q < nx / 4; q += 256)
+        reinterpret_cast<ps_f4*>(dst + x_off)[q] = reinterpret_cast<const ps_f4*>(ps_sm)[q];
+    } else {
+      for (int q = tid; q < nx; q += 256) dst[x_off + q] = ps_sm[q];
+    }
+  }
+}
+
+template <int R, int C>
+static bool ps_tile_launch(const float* src, float* dst, int N, int H, int W, bool fwd, hipStream_t s) {
+  constexpr int CIN = C * R * R;
+  // ~3 K floats per block (12 KB of LDS: a dozen resident blocks per CU cover each other's load latency), whole pixels,
+  // a multiple of 4 of them so that every run keeps its 16-byte alignment
+  int WT = (3072 / CIN) & ~3;
+  if (WT < 4) WT = 4;
+  if (WT > W) WT = W;
+  const int nwt = (W + WT - 1) / WT;
+  const size_t blocks = (size_t)N * H * nwt;
+  if (blocks > 0x7fffffffu) return false;
+  const size_t lds = (size_t)WT * CIN * sizeof(float);
+  if (fwd)
+    hipLaunchKernelGGL((k_pixel_shuffle_tile<R, C, true>), dim3((unsigned)blocks), dim3(256), lds, s, src, dst, H, W, WT, nwt);
+  else
+    hipLaunchKernelGGL((k_pixel_shuffle_tile<R, C, false>), dim3((unsigned)blocks), dim3(256), lds, s, src, dst, H, W, WT, nwt);
+  return true;
+}
+
+// true: the tiled kernel took the call
+static bool ps_tile(const float* src, float* dst, int N, int H, int W, int C, int r, bool fwd, hipStream_t s) {
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15) != 0 || env_int("SRK_PS_TILE", 1) == 0) return false;
+  // (a side is vectorised only when its pixel size is a multiple of 16 bytes -- then every run start is aligned)
+  if ((long)W * C * r * r >= (1L << 30)) return false;
+#define SRK_PS_CASE(RV, CV) if (r == RV && C == CV) return ps_tile_launch<RV, CV>(src, dst, N, H, W, fwd, s);
+  SRK_PS_CASE(2, 1) SRK_PS_CASE(3, 1) SRK_PS_CASE(4, 1) SRK_PS_CASE(8, 1)
+  SRK_PS_CASE(2, 3) SRK_PS_CASE(3, 3) SRK_PS_CASE(4, 3) SRK_PS_CASE(8, 3)
+  SRK_PS_CASE(2, 64) SRK_PS_CASE(2, 32) SRK_PS_CASE(2, 16) SRK_PS_CASE(4, 16) SRK_PS_CASE(3, 64)
+#undef SRK_PS_CASE
+  return false;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Activations
 // ---------------------------------------------------------------------------------------------
@@ -270,6 +379,7 @@ extern "C" int srk_pixel_shuffle_forward(const float* x, float* y, int N, int H,
   SRK_REQUIRE(x && y, "pixel_shuffle_forward: null pointer");
   SRK_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && r >= 1, "pixel_shuffle_forward: bad dims");
   const size_t total = (size_t)N * H * W * C * r * r;
+  if (ps_tile(x, y, N, H, W, C, r, true, (hipStream_t)stream)) return check_launch("pixel_shuffle_forward");
   hipLaunchKernelGGL(k_pixel_shuffle<true>, dim3(ew_grid(total, 256 * 4)), dim3(256), 0, (hipStream_t)stream, x, y, H,
                      W, C, r, total);
   return check_launch("pixel_shuffle_forward");
@@ -279,6 +389,7 @@ extern "C" int srk_pixel_shuffle_backward(const float* dy, float* dx, int N, int
   SRK_REQUIRE(dy && dx, "pixel_shuffle_backward: null pointer");
   SRK_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && r >= 1, "pixel_shuffle_backward: bad dims");
   const size_t total = (size_t)N * H * W * C * r * r;
+  if (ps_tile(dy, dx, N, H, W, C, r, false, (hipStream_t)stream)) return check_launch("pixel_shuffle_backward");
   hipLaunchKernelGGL(k_pixel_shuffle<false>, dim3(ew_grid(total, 256 * 4)), dim3(256), 0, (hipStream_t)stream, dy, dx,
                      H, W, C, r, total);
   return check_launch("pixel_shuffle_backward");

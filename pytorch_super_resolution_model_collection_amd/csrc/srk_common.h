@@ -13,6 +13,25 @@ void set_error(const char* fmt, ...);
 // Records the kernel a conv entry point just launched (thread-local; read back through srk_last_kernel_name()) so that
 // measurements can name the kernel that actually ran instead of guessing it from the shape.
 void note_kernel(const char* fmt, ...);
+// A conv launcher whose kernel keeps the running maximum of what it stores (srk_epilogue.y_amax) says so here; read back
+// through srk_last_conv_wrote_amax().  Reset by every srk_conv2d_forward call.
+void note_amax_written(bool written);
+
+// Environment switches.  env_int / env_str read a variable ONCE per process and answer from a table
+// afterwards -- a dispatch must not pay getenv's environment scan -- unless SRK_ENV_LIVE is set when the library is first
+// used: the test-suite flips switches between calls of one process (tests/conftest.py sets it).
+const char* env_str(const char* name);
+int env_int(const char* name, int dflt);
+// Experiment switches (ablation bits, alternative block shapes, forced tiles): compiled into the library only with
+// -DSRK_EXPERIMENTS (SRK_BUILD_EXPERIMENTS=1 python -m ..._build --force, which tools/ab.sh and the ablation tools need);
+// the release library carries the defaults as constants.
+#ifdef SRK_EXPERIMENTS
+#define SRK_EXP_INT(name, dflt) (::srk::env_int(name, dflt))
+#define SRK_EXP_STR(name) (::srk::env_str(name))
+#else
+#define SRK_EXP_INT(name, dflt) (dflt)
+#define SRK_EXP_STR(name) (static_cast<const char*>(nullptr))
+#endif
 
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();

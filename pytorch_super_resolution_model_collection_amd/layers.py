@@ -39,7 +39,7 @@ class _PackCache(object):
         self.val = None
 
     def get(self, weight, bias, transposed, ps_r):
-        key = (weight.data_ptr(), weight._version, None if bias is None else (bias.data_ptr(), bias._version),
+        key = (weight.data_ptr(), ops._ver(weight), None if bias is None else (bias.data_ptr(), ops._ver(bias)),
                transposed, ps_r, _WEIGHT_EPOCH[0], str(weight.device))
         if key != self.key:
             self.val = (ops.pack_weight_fwd(weight.detach(), transposed, ps_r),
@@ -62,7 +62,7 @@ def _plan_views(m, ps_r):
         # whole model with one launch instead of two small pack launches per layer and direction
         owner.pack()
         owner, plan_ps, wpf, bp, wpb, wver, bver = m._plan
-    if m.weight._version != wver or (m.bias is not None and m.bias._version != bver):
+    if ops._ver(m.weight) != wver or (m.bias is not None and ops._ver(m.bias) != bver):
         return None
     return (wpf, bp if (ps_r > 1 and m.bias is not None) else m.bias, wpb)
 

@@ -62,6 +62,12 @@ def get_precision():
     return _PRECISION["mode"]
 
 
+def backward_arithmetic():
+    """What the data- and weight-gradient products run on in the current mode (bench.py states it next to every training
+    number)."""
+    return "exact fp32 MFMA" if _PRECISION["mode"] == "fp32" else "bf16x3 (3 MFMAs, ~5e-6 rms)"
+
+
 def _algo_for(cfg, role):
     return cfg.algo if cfg.algo != ALGO_AUTO else _MODES[_PRECISION["mode"]][role]
 
@@ -116,8 +122,15 @@ def _f16x3_pays(d):
             or d.N * d.OH * d.OW * ((d.Cout + 63) // 64) >= F16X3_MIN_PIXELS)
 
 
+def _ver(t):
+    """Version counter of `t` for the "unchanged since it was tagged" tests below.  Tensors created under
+    torch.inference_mode() track none (reading `_version` raises): the constant stands in, i.e. a tag on an inference
+    tensor is trusted for the tensor's lifetime -- nothing in this package writes an activation in place."""
+    return -1 if t.is_inference() else t._version
+
+
 def _tag_amax(t, slots):
-    t._srk_amax = (slots, t._version, _AMAX_EPOCH[0])
+    t._srk_amax = (slots, _ver(t), _AMAX_EPOCH[0])
 
 
 def amax_of(x, compute=True):
@@ -126,7 +139,7 @@ def amax_of(x, compute=True):
     (the first layer of a net: one pass buys f16x3 for the whole trunk behind it); anything else (a BatchNorm output in
     front of every SRGAN conv) returns None and the caller keeps the six-MFMA arithmetic."""
     a = getattr(x, "_srk_amax", None)
-    fresh = a is not None and a[1] == x._version and a[2] == _AMAX_EPOCH[0]
+    fresh = a is not None and a[1] == _ver(x) and a[2] == _AMAX_EPOCH[0]
     if fresh and a[0] is not None:
         return a[0]
     if not compute and not fresh:
@@ -172,7 +185,7 @@ def to_nhwc(x):
     lib = _lib.load()
     check(lib.srk_nchw_to_nhwc(ptr(x), ptr(y), n, c, h, w, stream_ptr()), "srk_nchw_to_nhwc")
     a = getattr(x, "_srk_amax", None)   # a permutation keeps the maximum (or the "worth a pass" marker)
-    if a is not None and a[1] == x._version and a[2] == _AMAX_EPOCH[0]:
+    if a is not None and a[1] == _ver(x) and a[2] == _AMAX_EPOCH[0]:
         _tag_amax(y, a[0])
     return y
 
@@ -210,12 +223,12 @@ def _premask_on():
 
 
 def _is_relu_output(x):
-    return getattr(x, "_srk_relu_out", None) == x._version
+    return getattr(x, "_srk_relu_out", None) == _ver(x)
 
 
 def _premasked_for(dy, y):
     t = getattr(dy, "_srk_premasked", None)
-    return _premask_on() and t is not None and t == (y.data_ptr(), dy._version)
+    return _premask_on() and t is not None and t == (y.data_ptr(), _ver(dy))
 
 
 def to_nchw(x):
@@ -345,7 +358,7 @@ def conv_forward_raw(x, wp, bias_p, weight_shape_src, cfg, prelu_w=None, residua
         d.x_nchw = 0
     check(lib.srk_conv2d_forward(ctypes.byref(d), ptr(x), ptr(wp), ptr(y), ctypes.byref(ep), stream_ptr()),
           "srk_conv2d_forward")
-    if ya is not None and lib.srk_last_kernel_name().startswith((b"k_conv_bfd", b"k_conv_bfw", b"k_conv_bf3_rows", b"k_conv_rowsw")):
+    if ya is not None and lib.srk_last_conv_wrote_amax():
         _tag_amax(y, ya)
     elif F16X3 and d.algo in (_lib.ALGO_MFMA, _lib.ALGO_MFMA_BF16X6):
         _tag_amax(y, None)   # a faithful-class conv whose kernel leaves no maximum: worth one srk_absmax pass downstream
@@ -529,7 +542,7 @@ class _Conv2d(torch.autograd.Function):
         need_mask = cfg.act in (ACT_RELU, ACT_LRELU)
         ctx.x_relu_out = _is_relu_output(x)      # x = relu(conv(..)): this conv's dx may leave pre-masked (see PREMASK)
         if cfg.act == ACT_RELU and residual is None and cfg.ps_r <= 1:
-            y._srk_relu_out = y._version
+            y._srk_relu_out = _ver(y)
         ctx.save_for_backward(x, weight, y if need_mask else None)
         return y
 
@@ -615,10 +628,17 @@ class _Conv2d(torch.autograd.Function):
                                        % (tuple(add_to.shape), tuple(dx.shape)))
             if (ctx.x_relu_out and _premask_on() and add_to is None and d.dy_ps_r <= 1 and not x.retains_grad
                     and lib.srk_conv2d_backward_data_relu_supported(ctypes.byref(d), ptr(dyc), ptr(dx), mref)):
-                check(lib.srk_conv2d_backward_data_relu(ctypes.byref(d), ptr(dyc), ptr(wpb), ptr(dx), mref, ptr(x),
-                                                        stream_ptr()), "srk_conv2d_backward_data_relu")
-                dx._srk_premasked = (x.data_ptr(), dx._version)
-                PREMASK_STATS["masked_dx"] += 1
+                rc = lib.srk_conv2d_backward_data_relu(ctypes.byref(d), ptr(dyc), ptr(wpb), ptr(dx), mref, ptr(x),
+                                                       stream_ptr())
+                if rc == _lib.ERR_UNSUPPORTED:
+                    # the applicability test passed but no tile of the wave-specialised kernel fits this problem: the
+                    # standard data gradient, dx unmarked (the layer below applies its own mask) -- as the forward does
+                    check(lib.srk_conv2d_backward_data(ctypes.byref(d), ptr(dyc), ptr(wpb), ptr(dx), mref, None,
+                                                       stream_ptr()), "srk_conv2d_backward_data")
+                else:
+                    check(rc, "srk_conv2d_backward_data_relu")
+                    dx._srk_premasked = (x.data_ptr(), _ver(dx))
+                    PREMASK_STATS["masked_dx"] += 1
             else:
                 check(lib.srk_conv2d_backward_data(ctypes.byref(d), ptr(dyc), ptr(wpb), ptr(dx), mref, ptr(add_to),
                                                    stream_ptr()), "srk_conv2d_backward_data")
@@ -912,7 +932,7 @@ class _Fork(torch.autograd.Function):
 def fork(x):
     a, b = _Fork.apply(x)
     t = getattr(x, "_srk_amax", None)      # the views carry the running maximum of the tensor they alias
-    if t is not None and t[1] == x._version and t[2] == _AMAX_EPOCH[0]:
+    if t is not None and t[1] == _ver(x) and t[2] == _AMAX_EPOCH[0]:
         _tag_amax(a, t[0])
         _tag_amax(b, t[0])
     return a, b
@@ -1135,7 +1155,10 @@ class _BatchNorm(torch.autograd.Function):
         y = torch.empty_like(x)
         fused = act != ACT_NONE or residual is not None
         # 4-D activations in front of a convolution of the fp32-faithful class: leave the output's running maximum
-        ya = _amax_alloc(x.device) if (F16X3 and x.dim() == 4 and c % 4 == 0
+        # (only on the kernels' 16-byte path -- C % 4 == 0, aligned tensors; an unaligned view takes the scalar kernel,
+        # which keeps no maximum: the convolution behind it then stays on the six-MFMA arithmetic)
+        vec_ok = c % 4 == 0 and all(t is None or t.data_ptr() % 16 == 0 for t in (x, gamma, beta, residual))
+        ya = _amax_alloc(x.device) if (F16X3 and x.dim() == 4 and vec_ok
                                        and (F16X3_ALWAYS or rows * ((c + 63) // 64) >= F16X3_MIN_PIXELS)
                                        and _MODES[_PRECISION["mode"]]["train_fwd" if training else "infer"]
                                        in (_lib.ALGO_MFMA_BF16X6, _lib.ALGO_MFMA_F16X3)) else None

@@ -170,10 +170,11 @@ class PackPlan(object):
         check(lib.srk_pack_weights_batched(ptr(self.flat.data), ptr(self.buf), ptr(self.table), self.n, -self.blocks,
                                            ptr(self.fast_blocks), self.n_fast, stream_ptr()), "srk_pack_weights_batched")
         self.epoch = self.flat.epoch
+        from . import ops
         for lay in self.layers:  # host-side edits of a parameter (load_state_dict, init) invalidate its views
             m = lay[0]
-            m._plan[5] = m.weight._version
-            m._plan[6] = -1 if m.bias is None else m.bias._version
+            m._plan[5] = ops._ver(m.weight)
+            m._plan[6] = -1 if m.bias is None else ops._ver(m.bias)
 
     def current(self):
         return self.n > 0 and self.epoch == self.flat.epoch

@@ -8,6 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# libsrk.so reads its environment switches once per process (csrc/api.hip env_str) -- except under SRK_ENV_LIVE, which the
+# test-suite needs: the kernel-variant tests flip SRK_FORCE_ALGO / SRK_BFW / ... between calls of one process.
+os.environ.setdefault("SRK_ENV_LIVE", "1")
 
 # north_star tolerance: outputs within 1e-3 (relative, fp32) of the reference's CPU path.
 TOL_CONTRACT = 1e-3

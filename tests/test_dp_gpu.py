@@ -303,3 +303,28 @@ def test_rccl_single_rank_under_the_dp_step(gpu, tmp_path):
         tt = sorted(r[name]["times"][2:])
         assert tt[-1] < 20 * tt[len(tt) // 2] + 0.05, (name, r[name]["times"])   # no multi-second replay
     assert all(np.isfinite(v) for row in r["gan_losses"] for v in row)
+
+
+def test_bench_runs_its_multi_rank_code_path_on_one_gpu(gpu):
+    """bench.py's N > 1 sections (strong- and weak-scaled c4 with the overlapped RCCL exchange, c5 as graphs split at both
+    exchanges, the side-metric watchdog, the rank spans) driven end to end on ONE GPU: SRK_DP_FORCE_COMM=1 makes a one-rank
+    process group over backend "nccl", so every collective of the data-parallel paths really runs.  The numbers mean nothing;
+    the point is that the first real 8-GPU run cannot die on plumbing: rc 0, ONE JSON line on stdout, the N > 1 keys present."""
+    import json
+    import subprocess
+    env = dict(os.environ, SRK_DP_FORCE_COMM="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29300 + os.getpid() % 300),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", SRK_BENCH_EXTRA_TIMEOUT="600")
+    env.pop("SRK_ENV_LIVE", None)     # the product configuration: switches read once
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                        "--extra-steps", "5", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    ex = rec["extra"]
+    assert rec["n_gpus"] == 1 and rec["value"] > 0
+    assert ex["rccl_ranks_seen"] == 1 and ex["dist_backend"] == "nccl"
+    for key in ("c4_exposed_comm_ms", "c4_ms_per_step_without_exchange", "c4_rank_local_ms_per_step_min_max",
+                "c4_weak_ms_per_step", "c4_gradient_bytes_per_step", "c5_srgan_ms_per_step"):
+        assert key in ex, (key, sorted(ex))
+    assert not [k for k in ex if k.endswith("_error")], {k: v for k, v in ex.items() if k.endswith("_error")}

@@ -420,6 +420,23 @@ def test_pixel_shuffle(gpu, ops_kat, r):
     assert rel_err(x.grad, ops_kat["ps.r%d.dx" % r]) == 0.0
 
 
+@pytest.mark.parametrize("r,C,N,H,W", [(4, 3, 2, 5, 70), (4, 3, 1, 3, 248), (2, 64, 2, 6, 13), (3, 3, 2, 4, 115), (2, 3, 1, 7, 257),
+                                       (2, 1, 3, 5, 40), (4, 1, 1, 2, 1000), (8, 3, 1, 2, 19), (2, 5, 1, 3, 9), (3, 64, 1, 2, 7)])
+@pytest.mark.parametrize("tile", ["1", "0"])
+def test_pixel_shuffle_tiled_kernel(gpu, monkeypatch, r, C, N, H, W, tile):
+    """The tiled pixel-shuffle kernel (16-byte runs on both sides, permutation in LDS; base_networks.py:157,181) on the (r, C)
+    pairs it is instantiated for, with ragged last tiles, and the gather kernel it falls back to ((2, 5): no instance;
+    SRK_PS_TILE=0): both directions bit-equal to torch's pixel_shuffle / pixel_unshuffle."""
+    pkg = _pkg()
+    monkeypatch.setenv("SRK_PS_TILE", tile)
+    x = fill.randn((N, C * r * r, H, W), 17 + r).to(gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = pkg.ops.pixel_shuffle(x, r)
+    assert torch.equal(y, torch.nn.functional.pixel_shuffle(x.detach(), r))
+    g = fill.randn(tuple(y.shape), 23).to(gpu)
+    y.backward(g)
+    assert torch.equal(x.grad, torch.nn.functional.pixel_unshuffle(g, r))
+
+
 @pytest.mark.parametrize("name", ["relu", "prelu", "prelu_c", "lrelu", "tanh", "sigmoid"])
 def test_activation(gpu, ops_kat, name):
     pkg = _pkg()
@@ -783,3 +800,105 @@ def test_f16x3_is_fp32_faithful_at_any_operand_scale(gpu, scale_x, scale_w):
     assert err["f16x3"] < 0.25 * err["bf16x3"], err                                 # ... an order below the 3-term bf16 split
     decidable = ref.abs() > 1e-5 * float(ref.pow(2).mean().sqrt())
     assert bool((((out["f16x3"].cpu() > 0) == (ref > 0)) | ~decidable).all())
+
+
+def test_forward_under_inference_mode(gpu):
+    """Tensors created under torch.inference_mode() track no version counter (reading `_version` raises): the running-
+    maximum / ReLU-output tags must not touch it.  The default precision runs every inference forward through the tagged
+    f16x3 / bf16x6 path, so this is simply `with torch.inference_mode(): net(x)` -- same values as under no_grad."""
+    pkg = _pkg()
+    torch.manual_seed(5)
+    net = pkg.ESPCNNet(3, 64, 4)
+    net.weight_init()
+    net.to(gpu).eval()
+    x = torch.rand(2, 3, 40, 36, device=gpu)
+    with torch.no_grad():
+        ref = net(x)
+    with torch.inference_mode():
+        xi = x.clone()                       # an inference tensor as the network input, too
+        assert xi.is_inference()
+        y = net(xi)
+        assert torch.equal(y, ref)
+        # ops that tag / test tags directly: fork, to_nhwc, a block with a fused skip
+        a, b = pkg.ops.fork(y)
+        assert a.data_ptr() == y.data_ptr() and b.data_ptr() == y.data_ptr()
+        edsr = pkg.EDSRNet(3, 64, 2)
+        edsr.weight_init()
+        edsr.to(gpu).eval()
+        assert torch.isfinite(edsr(xi)).all()
+
+
+def test_pack_batched_amax_scans_an_unaligned_layer_completely(gpu):
+    """srk_pack_weights_batched with a weight offset that is not 16-byte aligned takes the scalar max|w| scan (256 floats
+    per block and stride): its blocks must cover the whole layer.  The largest weight sits at the END of a 2016-element
+    filter; the fp16 planes (scaled by 2^kw from that maximum) must equal those of the same filter packed from an aligned
+    offset -- an under-estimated maximum would overflow them to inf."""
+    pkg = _pkg()
+    lib = pkg._lib.load()
+    cout, cin, k = 8, 28, 3
+    elems = cout * cin * k * k
+    w = fill.randn((elems,), 91) * 0.05
+    w[-1] = 900.0
+    params = torch.zeros(2 * elems + 64, dtype=torch.float32, device=gpu)
+    params[4:4 + elems] = w.to(gpu)                   # aligned copy (offset 4 floats = 16 bytes)
+    params[elems + 33:elems + 33 + elems] = w.to(gpu)  # unaligned copy (offset % 4 == 1)
+    nf = int(lib.srk_packed_weight_bytes(cout, cin, k, k, 0))
+    nb = int(lib.srk_packed_weight_bytes(cout, cin, k, k, 1))
+    pad = lambda n: (n + 255) // 256 * 256
+    offs, rows, off = [], [], 0
+    for w_off in (4, elems + 33):
+        fo, bo = off, off + pad(nf)
+        off = bo + pad(nb)
+        offs.append((fo, bo))
+        rows.append([w_off, fo, bo, cout, cin, k, k, 0, 0, -1, -1, -1, -1, 0])
+    scratch = off
+    for i, r in enumerate(rows):
+        r[11] = scratch + 64 * i
+    buf = torch.zeros(scratch + 256, dtype=torch.uint8, device=gpu)
+    table = torch.tensor(rows, dtype=torch.int64, device=gpu)
+    rc = lib.srk_pack_weights_batched(pkg._lib.ptr(params), pkg._lib.ptr(buf), pkg._lib.ptr(table), 2, -8, None, 0,
+                                      pkg._lib.stream_ptr())
+    assert rc == 0, lib.srk_last_error_string()
+    torch.cuda.synchronize()
+    a = buf[offs[0][0]:offs[0][0] + nf].cpu()
+    b = buf[offs[1][0]:offs[1][0] + nf].cpu()
+    assert torch.equal(a, b)
+    assert torch.isfinite(a[:nf // 2 * 2].view(torch.float16).float()).all()   # (no plane overflowed)
+    assert torch.equal(buf[offs[0][1]:offs[0][1] + nb].cpu(), buf[offs[1][1]:offs[1][1] + nb].cpu())
+
+
+def test_conv_says_whether_it_wrote_the_running_maximum(gpu, monkeypatch):
+    """srk_last_conv_wrote_amax(): 1 after a forward whose kernel keeps the running maximum of its output in y_amax, 0 after
+    one that does not (exact-fp32 kernels) -- ops.conv_forward_raw tags the output with the slots only in the first
+    case, instead of inferring it from the kernel's name."""
+    pkg = _pkg()
+    ops, lib = pkg.ops, pkg._lib.load()
+    x = fill.randn((2, 64, 20, 20), 3).to(gpu)
+    w = (fill.randn((64, 64, 3, 3), 4) * 0.05).to(gpu)
+    with torch.no_grad():
+        y = ops.conv2d_infer(x, w, None, None, ops.ConvCfg(1, 1, False, 0, 1, 0.0, 0, pkg._lib.ALGO_MFMA_BF16X6))
+        assert lib.srk_last_conv_wrote_amax() == 1
+        assert y._srk_amax[0] is not None and float(y._srk_amax[0].max()) == float(y.abs().max())
+        y = ops.conv2d_infer(x, w, None, None, ops.ConvCfg(1, 1, False, 0, 1, 0.0, 0, pkg._lib.ALGO_MFMA))
+        assert lib.srk_last_conv_wrote_amax() == 0
+        assert getattr(y, "_srk_amax", (None,))[0] is None
+
+
+def test_batchnorm_on_an_unaligned_view_takes_the_scalar_path(gpu):
+    """A BatchNorm whose input is not 16-byte aligned cannot use the float4 kernels (which keep the running maximum of
+    their output): the forward must fall back to the scalar apply kernel instead of raising."""
+    pkg = _pkg()
+    ops = pkg.ops
+    base = torch.randn(1 + 2 * 8 * 8 * 8, device=gpu)
+    x = base[1:].view(2, 8, 8, 8).permute(0, 3, 1, 2)        # [2, 8, 8, 8] NCHW view of NHWC storage at a 4-byte offset
+    assert x.data_ptr() % 16 != 0 and ops._is_nhwc_dense(x)
+    gamma, beta = torch.rand(8, device=gpu) + 0.5, torch.rand(8, device=gpu)
+    rm, rv = torch.zeros(8, device=gpu), torch.ones(8, device=gpu)
+    prev = ops.F16X3_ALWAYS
+    ops.F16X3_ALWAYS = True       # (the small problem would not ask for the maximum otherwise)
+    try:
+        y = ops.batch_norm(x, gamma, beta, rm, rv, True)
+    finally:
+        ops.F16X3_ALWAYS = prev
+    ref = torch.nn.functional.batch_norm(x.contiguous(), None, None, gamma, beta, True)
+    assert rel_err(y, ref) < 1e-5
