@@ -229,6 +229,15 @@ size_t srk_conv2d_backward_weight_grouped_workspace_bytes(const srk_conv_desc* d
 int srk_conv2d_backward_weight_grouped(const srk_conv_desc* d, int n, const float* const* x, const float* const* dy,
                                        const srk_bwd_mask* masks, float* const* dw, float* const* db, float beta,
                                        void* workspace, size_t workspace_bytes, void* stream);
+/* Deferred slab reductions.  Every weight-gradient call above ends in a short launch that sums its split-K partial slabs
+ * into dw / db.  After srk_wgrad_reduce_defer(1) the calls of this thread queue that reduction instead, and
+ * srk_wgrad_reduce_flush(stream) runs everything queued as ONE launch (each reduction in its own summation order: same
+ * results bit for bit) -- the end of loss.backward() (edsr.py:154, srgan.py:286,309) is a handful to dozens of such calls.
+ * Contract while deferring: every call gets its OWN workspace, alive and untouched until the flush, all calls and the
+ * flush use one stream; a second update of a queued dw / db flushes first.  srk_wgrad_reduce_defer returns the previous
+ * setting; switching it off does not flush. */
+int srk_wgrad_reduce_defer(int on);
+int srk_wgrad_reduce_flush(void* stream);
 
 /* ---- residual block, both convolutions in one launch (base_networks.py:109-150 with norm=None, activation='relu':
  * edsr.py:37-45 builds its body from it) ------------------------------------------------------------------------------
@@ -290,8 +299,9 @@ int srk_loss_forward_backward(int kind, const float* pred, const float* target, 
 int srk_sgd_step(float* p, const float* g, float* momentum_buf, size_t n, float lr, float momentum,
                  float weight_decay, int nesterov, int first_step, const float* lr_dev, const float* grad_scale_dev,
                  void* stream);
-/* torch.optim.Adam (betas, eps, no amsgrad): `step_dev` is a device int32 step counter that the
- * kernel launch increments (bias correction uses the incremented value). */
+/* torch.optim.Adam (betas, eps, no amsgrad): `step_dev` points at TWO device int32 {step count, 0}: the kernel works
+ * with count + 1 (bias correction) and stores it when its last block finishes; the second word is the kernel's
+ * arrival ticket and is 0 between launches. */
 int srk_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int32_t* step_dev, const float* lr_dev,
                   const float* grad_scale_dev, void* stream);

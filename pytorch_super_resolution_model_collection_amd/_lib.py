@@ -60,6 +60,8 @@ _PROTOTYPES = {
     "srk_pack_weight_fwd": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "srk_pack_weight_bwd": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "srk_pack_bias_ps": (c_int, [c_f, c_f, c_int, c_int, c_vp]),
+    "srk_wgrad_reduce_defer": (c_int, [c_int]),
+    "srk_wgrad_reduce_flush": (c_int, [c_vp]),
     "srk_pack_weights_batched": (c_int, [c_f, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     "srk_packed_weight_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
     "srk_conv2d_forward": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, c_f, ctypes.POINTER(Epilogue), c_vp]),

@@ -72,6 +72,10 @@ void note_amax_written(bool written) { g_amax_written = written ? 1 : 0; }
 bool conv_tapn_gather_supported(const GatherConv& g, const float* in, const float* mask_y);
 int conv_tapn_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, bool x6,
                      hipStream_t s);
+// conv_c64.hip
+bool conv_c64_applicable(const GatherConv& g, const Epi& ep, const float* in, const float* out, const float* mask_y);
+int conv_c64_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, int planes,
+                    hipStream_t s);
 // conv_bfw.hip
 bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, const float* out, const float* mask_y);
 int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, const float* mask_y,
@@ -95,6 +99,8 @@ size_t conv_generic_wgrad_ws(const srk_conv_desc& d);
 int conv_generic_wgrad(const srk_conv_desc& d, const float* x, const float* dy, const srk_bwd_mask* mask, float* dw,
                        float* db, float beta, void* ws, size_t ws_bytes, hipStream_t s);
 // conv_wgrad_mfma.hip
+bool wgrad_reduce_deferring();
+int wgrad_reduce_flush(hipStream_t s);
 bool conv_wgrad_mfma_supported(const srk_conv_desc& d);
 size_t conv_wgrad_mfma_ws(const srk_conv_desc& d);
 int conv_wgrad_mfma(const srk_conv_desc& d, const float* x, const float* dy, const srk_bwd_mask* mask, float* dw,
@@ -180,6 +186,8 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
       }
       return conv_bf3_rows_f16_gather(g, in, wp, out, ep, s);
     }
+    if (conv_c64_applicable(g, ep, in, out, nullptr))   // small 64 -> 64 3x3 problems: one 8x8 tile per block
+      return conv_c64_gather(g, in, wp, out, ep, 4, s);
     if (conv_bfw_applicable(g, ep, in, out, nullptr)) {  // wave-specialised persistent kernel (ESPCN-size layers)
       const int rc = conv_bfw_gather(g, in, wp, out, ep, nullptr, 0.f, s, true);
       if (rc >= 0) return rc;
@@ -206,6 +214,7 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
   // the bfd kernels are compiled without the scalar store fallback
   const bool bfd_ok = conv_bfd_gather_supported(g, ep) && conv_epi_all_vector(g.OC, ep, out);
   if (algo == SRK_ALGO_MFMA_BF16X6) {  // fp32-faithful class: bf16x6 where it applies, else the exact fp32 kernels
+    if (conv_c64_applicable(g, ep, in, out, mask_y)) return conv_c64_gather(g, in, wp, out, ep, 3, s);
     if (bfd_ok && !direct_ok) return conv_bfd_gather(g, in, wp, out, ep, mask_y, mask_slope, 3, s);
     algo = SRK_ALGO_MFMA;
   }
@@ -220,6 +229,8 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
     // filters-from-global variant: small problems (channel-split 64-pixel blocks), or on request
     const char* e = env_str("SRK_BF3_DIRECT");  // 0 = never, 1 = always, unset = small problems only
     const int direct_w = e ? (atoi(e) ? 1 : 0) : 2;
+    // small 64 -> 64 3x3 problems without activation / mask (SRGAN's BatchNorm-separated convs and their data gradients)
+    if (direct_w != 0 && conv_c64_applicable(g, ep, in, out, mask_y)) return conv_c64_gather(g, in, wp, out, ep, 2, s);
     if (bfd_ok && (direct_w == 1 || (direct_w == 2 && conv_bfd_small_problem(g))))
       return conv_bfd_gather(g, in, wp, out, ep, mask_y, mask_slope, 2, s);
     if (conv_bfw_applicable(g, ep, in, out, mask_y)) {  // wave-specialised persistent kernel (ESPCN-size layers)
@@ -489,6 +500,8 @@ extern "C" int srk_conv2d_backward_weight_grouped(const srk_conv_desc* d, int n,
       rc = conv_wgrad_bf_grouped(*d, m, x + l0, dy + l0, masks ? masks + l0 : nullptr, dw + l0, db ? db + l0 : nullptr, beta,
                                  workspace, workspace_bytes, (hipStream_t)stream);
       if (rc) return rc;
+      // (deferred reductions read the slabs at the flush: the next chunk writes the same workspace)
+      if (l0 + m < n && wgrad_reduce_deferring() && (rc = wgrad_reduce_flush((hipStream_t)stream))) return rc;
     }
     return SRK_OK;
   }
@@ -496,6 +509,7 @@ extern "C" int srk_conv2d_backward_weight_grouped(const srk_conv_desc* d, int n,
     rc = srk_conv2d_backward_weight(d, x[l], dy[l], (masks && masks[l].y) ? &masks[l] : nullptr, dw[l], db ? db[l] : nullptr,
                                     beta, workspace, workspace_bytes, stream);
     if (rc) return rc;
+    if (l + 1 < n && wgrad_reduce_deferring() && (rc = wgrad_reduce_flush((hipStream_t)stream))) return rc;
   }
   return SRK_OK;
 }

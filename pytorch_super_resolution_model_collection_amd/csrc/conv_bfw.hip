@@ -55,12 +55,23 @@ struct BfwParams {
   int nsl, NBfull, OCb;
   unsigned out_bytes;  // size of the output tensor (buffer descriptor of the consumers' stores)
   int dbg;  // ablation (SRK_DBG): 1 no global loads, 2 no epilogue, 4 no MFMA loop, 16 no LDS commit, 1024 no deferred stores
+  long long* prof;  // experiments build only (srk_debug_bfw_prof): per block 16 int64 -- clock64() sums of the first producer
+                    // wave {commit, issue, barrier wait, stages} and of consumer wave 0 {tap loop, park, barrier wait, stages}
 };
 
-template <int NTW, int TT, int MTW, bool F16 = false, bool MASK = false, bool OMASK = false>
-__global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_conv_bfw(BfwParams B) {
+#ifdef SRK_EXPERIMENTS
+#define BFW_CLK() clock64()
+static long long* g_bfw_prof = nullptr;
+#else
+#define BFW_CLK() 0ll
+#endif
+
+template <int NTW, int TT, int MTW, bool F16 = false, bool MASK = false, bool OMASK = false, int NPW = 4>
+__global__ __launch_bounds__(64 * (16 / MTW + NPW), (16 / MTW + NPW) / 4) void k_conv_bfw(BfwParams B) {
   constexpr int NCW = 16 / MTW;          // consumer waves: MTW 16-pixel groups each, 256 pixels per block
-  constexpr int NTHR = 64 * (NCW + 4);   // + 4 producer waves
+  constexpr int NTHR = 64 * (NCW + NPW);   // + NPW producer waves (4; 8: round-4 experiment, SRK_BFW_NPW)
+  constexpr int PSTEP = 16 * NPW;        // halo pixels the producers cover per register batch
+  constexpr int PIT = BFW_IT * 4 / NPW;  // register batches per producer thread
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   const MfmaConvParams& P = B.P;
   const int NB = B.NB;
@@ -157,9 +168,9 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
     const int ptid = tid - 64 * NCW;
     const int g = ptid & 3, hp0 = ptid >> 2;
     const int hy0 = hp0 / P.HW, hx0 = hp0 - hy0 * P.HW;
-    const int dyp = 64 / P.HW, dxp = 64 - dyp * P.HW;
-    f32x4 pv0[BFW_IT], pv1[BFW_IT];
-    f32x4 mk0[MASK ? BFW_IT : 1], mk1[MASK ? BFW_IT : 1];  // MASK: y of the forward layer (dx = conv^T(dy * act'(y)))
+    const int dyp = PSTEP / P.HW, dxp = PSTEP - dyp * P.HW;
+    f32x4 pv0[PIT], pv1[PIT];
+    f32x4 mk0[MASK ? PIT : 1], mk1[MASK ? PIT : 1];  // MASK: y of the forward layer (dx = conv^T(dy * act'(y)))
     auto issue = [&]() {
       int n, r0, c0, cc;
       decode(n, r0, c0, cc);
@@ -170,12 +181,12 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
       const size_t ibase = (size_t)n * P.IH * P.IW * P.IC + ch;
       int hy = hy0, hx = hx0;
 #pragma unroll
-      for (int k = 0; k < BFW_IT; ++k) {
+      for (int k = 0; k < PIT; ++k) {
         pv0[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
         pv1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if constexpr (MASK) mk0[k] = mk1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int iy = iyb + hy, ix = ixb + hx;
-        if (hp0 + 64 * k < npix && ch_on && (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW) {
+        if (hp0 + PSTEP * k < npix && ch_on && (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW) {
           const size_t off = ibase + ((size_t)iy * P.IW + ix) * P.IC;
           pv0[k] = *reinterpret_cast<const f32x4*>(P.in + off);
           pv1[k] = *reinterpret_cast<const f32x4*>(P.in + off + 4);
@@ -195,8 +206,8 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
     auto commit = [&](uint4* hal) {
       if (B.dbg & 16) return;
 #pragma unroll
-      for (int k = 0; k < BFW_IT; ++k) {
-        const int hq = hp0 + 64 * k;
+      for (int k = 0; k < PIT; ++k) {
+        const int hq = hp0 + PSTEP * k;
         if (hq < npix) {
           float f[8];
 #pragma unroll
@@ -221,13 +232,31 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
       if (S > 1) issue();
     }
     __syncthreads();  // filter, tap table and stage 0 visible
+    long long pt_commit = 0, pt_issue = 0, pt_wait = 0;
+    const long long pt_begin = BFW_CLK();
     for (int s = 0; s < S; ++s) {
+      const long long c0 = BFW_CLK();
       if (T > 0) {
         if (s + 1 < S) commit(hal0 + (size_t)((s + 1) & 1) * hbuf);
+      }
+      const long long c1 = BFW_CLK();
+      if (T > 0) {
         if (s + 2 < S) issue();
       }
+      const long long c2 = BFW_CLK();
       __syncthreads();
+      const long long c3 = BFW_CLK();
+      pt_commit += c1 - c0;
+      pt_issue += c2 - c1;
+      pt_wait += c3 - c2;
     }
+#ifdef SRK_EXPERIMENTS
+    if (B.prof && tid == 64 * NCW) {
+      long long* pr = B.prof + (size_t)blockIdx.x * 16;
+      pr[0] = pt_commit; pr[1] = pt_issue; pr[2] = pt_wait; pr[3] = S; pr[4] = BFW_CLK() - pt_begin;
+    }
+#endif
+    (void)pt_commit; (void)pt_issue; (void)pt_wait; (void)pt_begin;
     return;
   }
 
@@ -314,7 +343,10 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
     srk_static_for<q0, NST>([&](auto qc) { store_slot(qc); });
   };
   __syncthreads();  // filter and stage 0 visible
+  long long ct_taps = 0, ct_park = 0, ct_wait = 0;
+  const long long ct_begin = BFW_CLK();
   for (int s = 0; s < S; ++s) {
+    const long long k0 = BFW_CLK();
     int n, r0, c0, cc;
     decode(n, r0, c0, cc);
     if (cc == 0) {
@@ -408,6 +440,7 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
         if (t < T) mfmas(fa[0], fb[0]);
       }
     }
+    const long long k1 = BFW_CLK();
     if (cc == B.ICc - 1 && wave_live && !(B.dbg & 2)) {
       // tile finished (C/D col = lane & 15 = pixel, rows kq*4 + reg = 4 consecutive channels per M tile): park it
       if (pend_live) flush_from(std::integral_constant<int, 0>{});  // (cannot happen with TT > 0)
@@ -440,8 +473,20 @@ __global__ __launch_bounds__(64 * (16 / MTW + 4), (16 / MTW + 4) / 4) void k_con
         pend_live = false;
       }
     }
+    const long long k2 = BFW_CLK();
     __syncthreads();
+    const long long k3 = BFW_CLK();
+    ct_taps += k1 - k0;
+    ct_park += k2 - k1;
+    ct_wait += k3 - k2;
   }
+#ifdef SRK_EXPERIMENTS
+  if (B.prof && tid == 0) {
+    long long* pr = B.prof + (size_t)blockIdx.x * 16 + 8;
+    pr[0] = ct_taps; pr[1] = ct_park; pr[2] = ct_wait; pr[3] = S; pr[4] = BFW_CLK() - ct_begin;
+  }
+#endif
+  (void)ct_taps; (void)ct_park; (void)ct_wait; (void)ct_begin;
   if (P.ep.y_amax) amax_commit(P.ep.y_amax, amax, blockIdx.x + wave, amax_peek(P.ep.y_amax, blockIdx.x + wave));  // (persistent: once)
 }
 
@@ -557,6 +602,17 @@ static int bfw_launch_t(const BfwParams& B, size_t lds, int grid, hipStream_t s)
     }
   }
   if (B.P.mask_y || B.P.ep.out_relu) return -1;
+#ifdef SRK_EXPERIMENTS
+  if constexpr (NTW == 2 && TT == 9 && MTW == 2) {
+    if (B.w_descale && SRK_EXP_INT("SRK_BFW_NPW", 4) == 8) {   // experiment: 8 producer waves (16-wave blocks)
+      static LdsLimit lim8;
+      lim8.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, MTW, true, false, false, 8>), lds);
+      note_kernel("k_conv_bfw<%d,%d,%d,f16,npw8>", NTW, TT, MTW);
+      hipLaunchKernelGGL((k_conv_bfw<NTW, TT, MTW, true, false, false, 8>), dim3(grid), dim3(64 * (16 / MTW + 8)), lds, s, B);
+      return check_launch("conv_bfw");
+    }
+  }
+#endif
   if (B.w_descale) {  // f16x3 arithmetic
     static LdsLimit limh;
     limh.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, MTW, true>), lds);
@@ -610,6 +666,9 @@ int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float
     B.NB = P.OC / nsl;
     B.ICc = (P.IC + 31) / 32;
     B.dbg = dbg;
+#ifdef SRK_EXPERIMENTS
+    B.prof = g_bfw_prof;
+#endif
     const int T = P.KHv * P.KWv;
     const size_t wbytes = (size_t)T * B.ICc * 8 * B.NB * 16;
     const long lds_cap = 160L * 1024 - 512;
@@ -650,3 +709,8 @@ int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float
 }
 
 }  // namespace srk
+
+#ifdef SRK_EXPERIMENTS
+// experiments build only: device buffer of 16 int64 per block for the role-time sums of the next k_conv_bfw launches
+extern "C" void srk_debug_bfw_prof(void* p) { srk::g_bfw_prof = static_cast<long long*>(p); }
+#endif

@@ -21,6 +21,7 @@
 #include "srk_common.h"
 #include "conv_problem.h"
 #include "conv_tile.h"
+#include "bf16_frag.h"   // amax_peek / amax_commit / abs_max4
 #include <type_traits>
 
 namespace srk {
@@ -123,6 +124,11 @@ __device__ __forceinline__ void store_tile(const MfmaConvParams& P, float* smem_
   constexpr int RPI = 64 / Q4;
   const int row0 = lane / Q4, q4 = lane - row0 * Q4;
   const int oc4 = ocb + q4 * 4;
+  // running maximum of what the block stores (ep.y_amax: the next layer's f16x3 scale -- a first layer on this kernel used
+  // to cost the trunk behind it an srk_absmax pass); valid when every channel group takes the 16-byte path, which the
+  // host checks before it reports the maximum as written (conv_mfma_gather)
+  float amax = 0.f;
+  const float peeked = amax_peek(P.ep.y_amax, blockIdx.x + wave);
   if (row0 < RPI && oc4 < P.OC) {
     const int tw_magic = div_small_magic(P.TW);
     const EpiCol col = epi_col_setup(P.ep, P.OW, P.OC, oc4);
@@ -134,11 +140,13 @@ __device__ __forceinline__ void store_tile(const MfmaConvParams& P, float* smem_
         const int pr = r0 + r, pc = c0 + c;
         if (pr < P.PH && pc < P.PW) {
           const epi_f4 v = *reinterpret_cast<const epi_f4*>(st + row * EPI_STRIDE + q4 * 4);
-          epi_store4_col(P.ep, col, P.OH, P.OW, P.OC, n, P.oy0 + pr * P.os, P.ox0 + pc * P.os, v, P.out);
+          const epi_f4 o = epi_store4_col(P.ep, col, P.OH, P.OW, P.OC, n, P.oy0 + pr * P.os, P.ox0 + pc * P.os, v, P.out);
+          if (P.ep.y_amax) amax = abs_max4(amax, o);
         }
       }
     }
   }
+  if (P.ep.y_amax) amax_commit(P.ep.y_amax, amax, blockIdx.x + wave, peeked);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -437,6 +445,7 @@ static void ensure_lds(const void* fn, LdsLimit& lim, size_t lds) { lim.ensure(f
 template <int NT>
 static void launch_variant(bool tapgroup, const MfmaConvParams& P, dim3 grid, size_t lds, hipStream_t s) {
   static LdsLimit cur_tg, cur_main;
+  note_amax_written(P.ep.y_amax != nullptr && epi_all_vector(P));   // (store_tile: the vector path keeps the maximum)
   if (tapgroup) {
     ensure_lds(reinterpret_cast<const void*>(&k_conv_mfma_tg<NT>), cur_tg, lds);
     note_kernel("k_conv_mfma_tg<%d>", NT);

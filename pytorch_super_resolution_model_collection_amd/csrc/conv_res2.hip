@@ -26,13 +26,30 @@
 namespace srk {
 
 constexpr int R2_C = 64;       // channels in = mid = out
-constexpr int R2_TS = 8;       // output tile side
-constexpr int R2_H1 = 12;      // input halo side (tile + 2 + 2)
-constexpr int R2_NPIX1 = 144;  // input halo pixels (multiple of 16)
-constexpr int R2_MW = 10;      // mid region side (tile + 1 + 1)
-constexpr int R2_NMID = 100;
-constexpr int R2_NPIX2 = 112;  // mid pixels rounded up to 16
-constexpr int R2_MT1 = 7;      // 16-pixel tiles of the mid region
+constexpr int R2_TS = 8;       // output tile width (and the height of the standard tile)
+constexpr int R2_H1 = 12;      // input halo width (tile + 2 + 2)
+constexpr int R2_MW = 10;      // mid region width (tile + 1 + 1)
+// Tile = TH rows x 8 columns.  TH = 8: the standard tile (12 x 12 input halo, 10 x 10 intermediate in 7 MFMA row tiles).
+// TH = 4 (round 4 experiment, compiled with -DSRK_EXPERIMENTS only): a problem that leaves a CU with ONE 8 x 8 tile (the
+// 16-patch EDSR shard of 8-GPU strong scaling: 256 tiles) as twice as many half tiles -- 8 x 12 halo, 6 x 10 intermediate
+// in 4 row tiles, 12 instead of 11 MFMA row tiles per 64 output pixels -- so that every CU holds TWO resident blocks
+// whose phases could overlap.  Measured (tools/res2_prof.py, clock64 stamps; EDSR shard step): forward 16.2 -> 16.5 us,
+// backward 15.2 -> 14.8 us, step 1.199 -> 1.212 ms: the two co-resident blocks stretch each other's tap phases by what
+// they hide of each other's barriers (conv1 taps 9.5 k ticks alone, 8.9 k for HALF the pixels with a neighbour): the CU's
+// LDS / MFMA issue, not exposed latency, is what a lone block waits for.  Not selected by the release library.
+template <int TH>
+struct R2Geo {
+  static constexpr int H1R = TH + 4;                    // input halo rows
+  static constexpr int NPIX1 = R2_H1 * H1R;             // input halo pixels: 144 / 96 (multiples of 16)
+  static constexpr int MR = TH + 2;                     // mid region rows
+  static constexpr int NMID = R2_MW * MR;               // 100 / 60
+  static constexpr int NPIX2 = (NMID + 15) & ~15;       // 112 / 64
+  static constexpr int MT1 = NPIX2 / 16;                // 16-pixel tiles of the mid region: 7 / 4
+  static constexpr int MT1A = (MT1 + 1) / 2;            // ... finished by chunk group 0 (the rest by group 1): 4 / 2
+  static constexpr int MT2 = TH * R2_TS / 16;           // 16-pixel tiles of the output: 4 / 2
+  static constexpr int MT2A = MT2 / 2;                  // ... finished by each chunk group: 2 / 1
+  static_assert(NPIX1 % 16 == 0 && MT2 % 2 == 0, "tile shape");
+};
 
 struct Res2Params {
   const float* in;    // [N, H, W, 64]: x (forward) / dy (backward); also the residual added to `out`
@@ -52,7 +69,15 @@ struct Res2Params {
   float* y_amax;   // optional (any arithmetic): running max of |out|
   const float* wd1;
   const float* wd2;
+  long long* prof;   // experiments build only (srk_debug_res2_prof): 16 clock64() stamps per block, thread 0
 };
+
+#ifdef SRK_EXPERIMENTS
+#define R2_PROF(i) do { if (R.prof && threadIdx.x == 0) R.prof[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
+static long long* g_res2_prof = nullptr;
+#else
+#define R2_PROF(i) do { } while (0)
+#endif
 
 template <int NP>
 __device__ __forceinline__ void r2_split4(const f32x4& v, uint2 (&pl)[NP]) {
@@ -99,9 +124,12 @@ __device__ __forceinline__ void r2_split4h(const f32x4& v, float s, uint2 (&pl)[
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) ACC[mt] = mfma16(BF[0], A[0][mt], ACC[mt]);        \
   }
 
-template <int NP, bool BWD, bool F16 = false>
+template <int NP, bool BWD, bool F16 = false, int TH = 8>
 __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
   static_assert(!F16 || (NP == 2 && !BWD), "f16x3 is the two-plane forward arithmetic");
+  typedef R2Geo<TH> G;
+  constexpr int R2_NPIX1 = G::NPIX1, R2_NMID = G::NMID, R2_NPIX2 = G::NPIX2, R2_MT1 = G::MT1, MT1A = G::MT1A, MT2 = G::MT2,
+                MT2A = G::MT2A;
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   __shared__ float r2_amx[8];
   // f16x3: input scale 2^kx from the tensor's running maximum; the intermediate gets its own scale from the tile's maximum
@@ -122,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
   b /= R.tiles_x;
   const int tyi = b % R.tiles_y;
   const int n = b / R.tiles_y;
-  const int r0 = tyi * R2_TS, c0 = txi * R2_TS;
+  const int r0 = tyi * TH, c0 = txi * R2_TS;
   const size_t img = (size_t)n * R.H * R.W * R2_C;
   const float* __restrict__ inb = R.in + img;
 
@@ -137,6 +165,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
     dst[1] = w[256];
     if (NP == 3) dst[NP - 1] = ((cv ? R.wq2l : R.wq1l) + slot * 256)[wlane];
   };
+  R2_PROF(0);
   uint4 bq[3][NP];
   load_b(0, bq[0]);
   load_b(1, bq[1]);
@@ -179,7 +208,9 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
       }
     }
   }
+  R2_PROF(1);
   __syncthreads();
+  R2_PROF(2);
 
   // ---- first conv on the 10x10 mid region: 7 pixel tiles x this wave's 16 channels x chunk kgrp
   f32x4 acc1[R2_MT1];
@@ -211,20 +242,21 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
     }
   }
 
+  R2_PROF(3);
   // ---- the chunk groups swap halves: group 0 finishes mid tiles 0-3, group 1 tiles 4-6
   const int ch4 = ow * 16 + kq * 4;
-  f32x4 gt[4];  // backward: forward mid values of this wave's tiles (issued before the barriers)
-  int moff[4];  // element offset of the tile's pixel in the image (-1: outside the image or the region)
-  bool mcen[4];
+  f32x4 gt[MT1A];  // backward: forward mid values of this wave's tiles (issued before the barriers)
+  int moff[MT1A];  // element offset of the tile's pixel in the image (-1: outside the image or the region)
+  bool mcen[MT1A];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int mt = kgrp ? 4 + q : q;
+  for (int q = 0; q < MT1A; ++q) {
+    const int mt = kgrp ? MT1A + q : q;
     const int m = mt * 16 + j;
     const int r = m / R2_MW, c = m - r * R2_MW;
     const int iy = r0 - 1 + r, ix = c0 - 1 + c;
     const bool inimg = mt < R2_MT1 && m < R2_NMID && (unsigned)iy < (unsigned)R.H && (unsigned)ix < (unsigned)R.W;
     moff[q] = inimg ? (int)(((size_t)iy * R.W + ix) * R2_C) + ch4 : -1;
-    mcen[q] = inimg && r >= 1 && r <= R2_TS && c >= 1 && c <= R2_TS;
+    mcen[q] = inimg && r >= 1 && r <= TH && c >= 1 && c <= R2_TS;
     // (unconditional, from a clamped address: a load under a divergent branch is followed by s_waitcnt vmcnt(0) at the
     //  join, which would serialise the latencies of these loads; a pixel outside the image is zeroed below anyway)
     gt[q] = (f32x4){1.f, 1.f, 1.f, 1.f};
@@ -239,23 +271,26 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
   f32x4* red = reinterpret_cast<f32x4*>(smem4) + (size_t)(ow * R2_MT1) * 64 + lane;  // [4 ow][7 tiles][64 lanes]
   if (kgrp == 0) {
 #pragma unroll
-    for (int mt = 4; mt < R2_MT1; ++mt) red[mt * 64] = acc1[mt];
+    for (int mt = MT1A; mt < R2_MT1; ++mt) red[mt * 64] = acc1[mt];
   } else {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) red[mt * 64] = acc1[mt];
+    for (int mt = 0; mt < MT1A; ++mt) red[mt * 64] = acc1[mt];
   }
   __syncthreads();
   float smid = 1.f, dsc2 = 1.f;
   {
     asm volatile("" ::"v"(b1), "v"(b2));
-    if constexpr (BWD) asm volatile("" ::"v"(gt[0]), "v"(gt[1]), "v"(gt[2]), "v"(gt[3]));
+    if constexpr (BWD) {
+#pragma unroll
+      for (int q = 0; q < MT1A; ++q) asm volatile("" ::"v"(gt[q]));
+    }
     const int ch2 = ow >> 1, g2 = (ow & 1) * 2 + (kq >> 1);
-    f32x4 vv[4];
+    f32x4 vv[MT1A];
     float lmax = 0.f;
 #pragma unroll
     for (int mt = 0; mt < R2_MT1; ++mt) {
-      if ((mt < 4) != (kgrp == 0)) continue;
-      const int q = mt & 3;
+      if ((mt < MT1A) != (kgrp == 0)) continue;
+      const int q = mt < MT1A ? mt : mt - MT1A;
       f32x4 v = acc1[mt] + red[mt * 64];
       if (!BWD) {
         if constexpr (F16) v *= dsc1;
@@ -285,8 +320,8 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
     }
 #pragma unroll
     for (int mt = 0; mt < R2_MT1; ++mt) {
-      if ((mt < 4) != (kgrp == 0)) continue;
-      const int q = mt & 3;
+      if ((mt < MT1A) != (kgrp == 0)) continue;
+      const int q = mt < MT1A ? mt : mt - MT1A;
       const int m = mt * 16 + j;
       if (m < R2_NMID) {
         uint2 pl[NP];
@@ -297,27 +332,29 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
       }
     }
   }
-  // residual (= the centre of the input) for the tiles this wave finishes: group 0 tiles 0, 1; group 1 tiles 2, 3
-  f32x4 res[2];
-  int ooff[2];
+  // residual (= the centre of the input) for the tiles this wave finishes: group 0 the first half, group 1 the second
+  f32x4 res[MT2A];
+  int ooff[MT2A];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int m = (kgrp * 2 + q) * 16 + j;
+  for (int q = 0; q < MT2A; ++q) {
+    const int m = (kgrp * MT2A + q) * 16 + j;
     const int iy = r0 + (m >> 3), ix = c0 + (m & 7);
     const bool ok = iy < R.H && ix < R.W;
     ooff[q] = ok ? (int)(((size_t)iy * R.W + ix) * R2_C) + ch4 : -1;
     res[q] = *reinterpret_cast<const f32x4*>(inb + (ok ? ooff[q] : ch4));  // (unconditional: see gt; unused when !ok)
   }
+  R2_PROF(4);
   __syncthreads();  // mid planes complete
+  R2_PROF(5);
 
-  // ---- second conv on the 8x8 centre: 4 pixel tiles
-  f32x4 acc2[4];
+  // ---- second conv on the TH x 8 centre: MT2 pixel tiles
+  f32x4 acc2[MT2];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) acc2[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int mt = 0; mt < MT2; ++mt) acc2[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   {
-    int hpB[4];
+    int hpB[MT2];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MT2; ++mt) {
       const int m = mt * 16 + j;
       hpB[mt] = (m >> 3) * R2_MW + (m & 7) + kq * R2_NPIX2;
     }
@@ -328,33 +365,41 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
       if (t + 2 < 9) load_b(9 + t + 2, bq[(t + 2) % 3]);
       if (!(R.dbg & 4)) {
         const int toff = (t / 3) * R2_MW + (t % 3);
-        uint4 a[NP][4];
+        uint4 a[NP][MT2];
 #pragma unroll
         for (int p = 0; p < NP; ++p)
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt) a[p][mt] = h2c[p * plane2 + hpB[mt] + toff];
-        SRK_R2_PASSES(acc2, a, bq[t % 3], 4)
+          for (int mt = 0; mt < MT2; ++mt) a[p][mt] = h2c[p * plane2 + hpB[mt] + toff];
+        SRK_R2_PASSES(acc2, a, bq[t % 3], MT2)
       }
     }
   }
+  R2_PROF(6);
   // swap halves again (the region of the input halo is free: nothing reads it after the barrier above)
-  f32x4* red2 = reinterpret_cast<f32x4*>(smem4) + (size_t)(ow * 4) * 64 + lane;  // [4 ow][4 tiles][64 lanes]
+  f32x4* red2 = reinterpret_cast<f32x4*>(smem4) + (size_t)(ow * MT2) * 64 + lane;  // [4 ow][MT2 tiles][64 lanes]
   const float peeked = amax_peek(R.y_amax, blockIdx.x);  // (early: see amax_commit)
   if (kgrp == 0) {
-    red2[2 * 64] = acc2[2];
-    red2[3 * 64] = acc2[3];
+#pragma unroll
+    for (int mt = MT2A; mt < MT2; ++mt) red2[mt * 64] = acc2[mt];
   } else {
-    red2[0 * 64] = acc2[0];
-    red2[1 * 64] = acc2[1];
+#pragma unroll
+    for (int mt = 0; mt < MT2A; ++mt) red2[mt * 64] = acc2[mt];
   }
   __syncthreads();
-  asm volatile("" ::"v"(res[0]), "v"(res[1]));  // (landed during the second conv: no wait between the stores below)
+  R2_PROF(7);
+#pragma unroll
+  for (int q = 0; q < MT2A; ++q) asm volatile("" ::"v"(res[q]));  // (landed during the second conv: no wait between the stores below)
   float oamax = 0.f;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int mt = kgrp * 2 + q;
+  for (int q = 0; q < MT2A; ++q) {
+    const int mt = kgrp * MT2A + q;
     if (ooff[q] >= 0) {
-      const f32x4 own = kgrp ? (q ? acc2[3] : acc2[2]) : (q ? acc2[1] : acc2[0]);
+      // (element-wise select of VALUES: a select between two elements of the register array is folded into one load with
+      //  a dynamic index, which sends the whole accumulator array to scratch memory)
+      const f32x4 own_lo = acc2[q], own_hi = acc2[MT2A + q];
+      f32x4 own;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) own[e] = kgrp ? own_hi[e] : own_lo[e];
       f32x4 v = own + red2[mt * 64];
       if constexpr (F16) v *= dsc2;
       v = v + b2 + res[q];
@@ -362,7 +407,9 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
       if (R.y_amax) oamax = abs_max4(oamax, v);
     }
   }
+  R2_PROF(8);
   if (R.y_amax) amax_commit_block(R.y_amax, oamax, blockIdx.x, r2_amx, 8, peeked);
+  R2_PROF(9);
 }
 #undef SRK_R2_PASSES
 #undef mfma16
@@ -384,14 +431,25 @@ bool conv_res2_supported(int N, int H, int W, int C) {
   return tiles <= max_tiles;
 }
 
-template <int NP, bool BWD, bool F16 = false>
-static int r2_launch(const Res2Params& R, hipStream_t s) {
-  const size_t lds = (size_t)2 * NP * 4 * (R2_NPIX1 + R2_NPIX2) * 16;
+template <int NP, bool BWD, bool F16, int TH>
+static int r2_launch_t(const Res2Params& R, hipStream_t s) {
+  const size_t lds = (size_t)2 * NP * 4 * (R2Geo<TH>::NPIX1 + R2Geo<TH>::NPIX2) * 16;
   static LdsLimit lim;
-  lim.ensure(reinterpret_cast<const void*>(&k_res2<NP, BWD, F16>), lds);
-  note_kernel("k_res2<%d,%d%s>", NP, (int)BWD, F16 ? ",f16" : "");
-  hipLaunchKernelGGL((k_res2<NP, BWD, F16>), dim3((unsigned)((size_t)R.N * R.tiles_y * R.tiles_x)), dim3(512), lds, s, R);
+  lim.ensure(reinterpret_cast<const void*>(&k_res2<NP, BWD, F16, TH>), lds);
+  note_kernel("k_res2<%d,%d%s%s>", NP, (int)BWD, F16 ? ",f16" : "", TH == 4 ? ",th4" : "");
+  hipLaunchKernelGGL((k_res2<NP, BWD, F16, TH>), dim3((unsigned)((size_t)R.N * R.tiles_y * R.tiles_x)), dim3(512), lds, s, R);
   return check_launch("conv_res2");
+}
+
+template <int NP, bool BWD, bool F16 = false>
+static int r2_launch(Res2Params R, hipStream_t s) {
+#ifdef SRK_EXPERIMENTS
+  if (SRK_EXP_INT("SRK_RES2_TH", 8) == 4) {   // half tiles (R2Geo): measured, not faster
+    R.tiles_y = (R.H + 3) / 4;
+    return r2_launch_t<NP, BWD, F16, 4>(R, s);
+  }
+#endif
+  return r2_launch_t<NP, BWD, F16, 8>(R, s);
 }
 
 // `wp1` / `wp2`: packed filter buffers of srk_pack_weight_fwd (forward) / srk_pack_weight_bwd (backward) of the conv
@@ -420,6 +478,9 @@ int conv_res2(const float* in, const float* wp1, const float* wp2, const float* 
   R.dbg = r2_dbg();
   R.x_amax = x_amax;
   R.y_amax = y_amax;
+#ifdef SRK_EXPERIMENTS
+  R.prof = g_res2_prof;
+#endif
   if (planes == 4) {
     if (bwd || !x_amax) {
       set_error("conv_res2: f16x3 is a forward arithmetic and needs x_amax");
@@ -437,3 +498,8 @@ int conv_res2(const float* in, const float* wp1, const float* wp2, const float* 
 }
 
 }  // namespace srk
+
+#ifdef SRK_EXPERIMENTS
+// experiments build only: device buffer of 16 int64 per block that the next fused-block launches stamp (R2_PROF); NULL: off
+extern "C" void srk_debug_res2_prof(void* p) { srk::g_res2_prof = static_cast<long long*>(p); }
+#endif

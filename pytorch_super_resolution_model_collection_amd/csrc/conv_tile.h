@@ -242,8 +242,9 @@ __device__ __forceinline__ EpiCol epi_col_setup(const Epi& ep, int OW, int OC, i
   return c;
 }
 
-__device__ __forceinline__ void epi_store4_col(const Epi& ep, const EpiCol& col, int OH, int OW, int OC, int n, int oy,
-                                               int ox, epi_f4 v, float* __restrict__ out) {
+// (returns what the vector path stored; the scalar fallback returns its input)
+__device__ __forceinline__ epi_f4 epi_store4_col(const Epi& ep, const EpiCol& col, int OH, int OW, int OC, int n, int oy,
+                                                 int ox, epi_f4 v, float* __restrict__ out) {
   if (col.vec) {
     size_t base;
     if (ep.ps_r > 1) {
@@ -264,6 +265,7 @@ __device__ __forceinline__ void epi_store4_col(const Epi& ep, const EpiCol& col,
   } else {
     epi_store4(ep, OH, OW, OC, n, oy, ox, col.oc, v, out);
   }
+  return v;
 }
 
 // Host-side mirror of epi_col_setup's `vec` test for EVERY 4-channel group of the layer: true when no lane can need

@@ -33,6 +33,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 int conv_wgrad_reduce_launch(const float* ws, float* dw, int G, int Cout, int Cin, int KH, int KW, int transposed,
                              float beta, const float* bias_partial, float* db, int bias_cout, int out_ps_r,
                              hipStream_t s);
+bool wgrad_reduce_deferring();
+int wgrad_reduce_submit(bool wide, const float* ws, float* dw, int G, int Cout, int Cin, int KH, int KW, int transposed,
+                        float beta, const float* bias_partial, float* db, int bias_cout, int out_ps_r, hipStream_t s);
 
 constexpr int WB_MAXOCT = 64;  // octets per tile (<= 512 pixels)
 constexpr int WB_SST = 512;    // SPEC: staging threads (8 waves next to the 4 working waves; 4 stager waves: 0.157 -> 0.20 ms on the VDSR layer)
@@ -1150,6 +1153,16 @@ int conv_wgrad_bf_grouped(const srk_conv_desc& d, int n, const float* const* xs,
   }
   int rc = check_launch("conv_wgrad_bf_grouped");
   if (rc) return rc;
+  if (wgrad_reduce_deferring()) {   // queued: one job per layer, summed in this kernel's order by the merged launch
+    for (int l = 0; l < n; ++l) {
+      rc = wgrad_reduce_submit(false, (const float*)ws + (size_t)l * G * elems, GO.L[l].dw, G, d.Cout, d.Cin, d.KH, d.KW, 0,
+                               beta, has_bias ? (const float*)bias_ws + (size_t)l * G * d.Cout : nullptr, GO.L[l].db, d.Cout,
+                               0, s);
+      if (rc == -100) break;        // (does not fit a job record: the launch below does the whole group)
+      if (rc) return rc;
+    }
+    if (rc == SRK_OK) return SRK_OK;
+  }
   const int nwb = cdiv(elems, 64), bias_blocks = has_bias ? cdiv(d.Cout, 64) : 0;
   hipLaunchKernelGGL(k_wgrad_reduce_grouped, dim3(nwb + bias_blocks, n), dim3(256), 0, s, (const float*)ws, GO, G, d.Cout,
                      d.Cin, d.KH, d.KW, beta, has_bias ? (const float*)bias_ws : nullptr);

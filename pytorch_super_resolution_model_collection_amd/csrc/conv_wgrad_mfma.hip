@@ -323,32 +323,43 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_smallcin(WgradParams P) {
 // ---------------------------------------------------------------------------------------------
 // Deterministic slab reduction + layout change:  dw(torch layout) = beta*dw + sum_g ws[g][t][ci][co]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw, int G,
-                                                      int Cout, int Cin, int KH, int KW, int transposed, float beta,
-                                                      const float* __restrict__ bias_partial, float* __restrict__ db,
-                                                      int bias_cout, int out_ps_r) {
+// `blk`: block index inside this reduction (blockIdx.x of a launch of its own).  WIDE: the summation order of
+// k_wgrad_reduce (4 accumulators, slab stride 16); !WIDE: that of the grouped reduce of conv_wgrad_bf16.hip (2
+// accumulators, stride 8) -- k_wgrad_reduce_multi reproduces either bit for bit.
+template <bool WIDE>
+__device__ __forceinline__ void wgrad_reduce_body(float (&sm)[4][64], int blk, const float* __restrict__ ws,
+                                                  float* __restrict__ dw, int G, int Cout, int Cin, int KH, int KW,
+                                                  int transposed, float beta, const float* __restrict__ bias_partial,
+                                                  float* __restrict__ db, int bias_cout, int out_ps_r) {
   // 64 consecutive slab elements per block (coalesced 256-byte rows); the 4 waves each sum a quarter
   // of the G slabs with 4 independent accumulators (16 loads in flight per lane), combined through
   // LDS in a fixed order => deterministic.  The blocks past the last slab element finish the bias
   // gradient the same way (bias_partial[G][bias_cout] -> db), saving a launch per layer.
-  __shared__ float sm[4][64];
   const int elems = KH * KW * Cin * Cout;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nwb = (elems + 63) / 64;
-  if ((int)blockIdx.x >= nwb) {
-    const int co = ((int)blockIdx.x - nwb) * 64 + lane;
+  if (blk >= nwb) {
+    if (!db || !bias_partial) return;
+    const int co = (blk - nwb) * 64 + lane;
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
     if (co < bias_cout) {
       int g = w;
-      for (; g + 12 < G; g += 16) {
-        t0 += bias_partial[(size_t)g * bias_cout + co];
-        t1 += bias_partial[(size_t)(g + 4) * bias_cout + co];
-        t2 += bias_partial[(size_t)(g + 8) * bias_cout + co];
-        t3 += bias_partial[(size_t)(g + 12) * bias_cout + co];
+      if (WIDE) {
+        for (; g + 12 < G; g += 16) {
+          t0 += bias_partial[(size_t)g * bias_cout + co];
+          t1 += bias_partial[(size_t)(g + 4) * bias_cout + co];
+          t2 += bias_partial[(size_t)(g + 8) * bias_cout + co];
+          t3 += bias_partial[(size_t)(g + 12) * bias_cout + co];
+        }
+      } else {
+        for (; g + 4 < G; g += 8) {
+          t0 += bias_partial[(size_t)g * bias_cout + co];
+          t1 += bias_partial[(size_t)(g + 4) * bias_cout + co];
+        }
       }
       for (; g < G; g += 4) t0 += bias_partial[(size_t)g * bias_cout + co];
     }
-    sm[w][lane] = (t0 + t1) + (t2 + t3);
+    sm[w][lane] = WIDE ? (t0 + t1) + (t2 + t3) : t0 + t1;
     __syncthreads();
     if (w == 0 && co < bias_cout) {
       const float t = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
@@ -362,19 +373,26 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     }
     return;
   }
-  const int e = blockIdx.x * 64 + lane;
+  const int e = blk * 64 + lane;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (e < elems) {
     int g = w;
-    for (; g + 12 < G; g += 16) {
-      s0 += ws[(size_t)g * elems + e];
-      s1 += ws[(size_t)(g + 4) * elems + e];
-      s2 += ws[(size_t)(g + 8) * elems + e];
-      s3 += ws[(size_t)(g + 12) * elems + e];
+    if (WIDE) {
+      for (; g + 12 < G; g += 16) {
+        s0 += ws[(size_t)g * elems + e];
+        s1 += ws[(size_t)(g + 4) * elems + e];
+        s2 += ws[(size_t)(g + 8) * elems + e];
+        s3 += ws[(size_t)(g + 12) * elems + e];
+      }
+    } else {
+      for (; g + 4 < G; g += 8) {
+        s0 += ws[(size_t)g * elems + e];
+        s1 += ws[(size_t)(g + 4) * elems + e];
+      }
     }
     for (; g < G; g += 4) s0 += ws[(size_t)g * elems + e];
   }
-  sm[w][lane] = (s0 + s1) + (s2 + s3);
+  sm[w][lane] = WIDE ? (s0 + s1) + (s2 + s3) : s0 + s1;
   __syncthreads();
   if (w != 0 || e >= elems) return;
   const float v = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
@@ -395,15 +413,101 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   dw[o] = beta != 0.f ? beta * dw[o] + v : v;
 }
 
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw, int G,
+                                                      int Cout, int Cin, int KH, int KW, int transposed, float beta,
+                                                      const float* __restrict__ bias_partial, float* __restrict__ db,
+                                                      int bias_cout, int out_ps_r) {
+  __shared__ float sm[4][64];
+  wgrad_reduce_body<true>(sm, (int)blockIdx.x, ws, dw, G, Cout, Cin, KH, KW, transposed, beta, bias_partial, db, bias_cout,
+                          out_ps_r);
+}
+
+// ---- deferred reductions: the slab reductions of SEVERAL weight-gradient launches in one launch ----------------------
+// A strong-scaled shard or an SRGAN step ends its backward pass with a handful to dozens of weight-gradient launches, each
+// followed by a reduce launch of a few microseconds of work (EDSR, 16 patches: 6 reduce launches = 60 us of a 1.2 ms step;
+// SRGAN: 32 per step).  Between srk_wgrad_reduce_defer(1) and srk_wgrad_reduce_flush() the reduce of every weight-gradient
+// call of the calling thread is queued instead (the caller keeps the workspaces alive and distinct), and the flush runs
+// them all as ONE launch: block -> (job, block inside the job) by a scan over <= 40 jobs passed by value (graph-capturable),
+// each job summed in exactly the order of the kernel it replaces.
+struct RedJob {
+  const float* ws;
+  float* dw;
+  const float* bias_partial;
+  float* db;
+  int G, blk0;            // slabs; first block of this job in the merged grid
+  short Cout, Cin, bias_cout;
+  unsigned char KH, KW, transposed, out_ps_r, wide, pad_;
+  float beta;
+};
+constexpr int kMaxRedJobs = 40;
+struct RedJobs {
+  RedJob j[kMaxRedJobs];
+  int n, blocks;
+};
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce_multi(RedJobs J) {
+  __shared__ float sm[4][64];
+  int k = 0;
+  for (int i = 1; i < J.n; ++i)
+    if ((int)blockIdx.x >= J.j[i].blk0) k = i;
+  const RedJob& r = J.j[k];
+  const int blk = (int)blockIdx.x - r.blk0;
+  if (r.wide)
+    wgrad_reduce_body<true>(sm, blk, r.ws, r.dw, r.G, r.Cout, r.Cin, r.KH, r.KW, r.transposed, r.beta, r.bias_partial, r.db,
+                            r.bias_cout, r.out_ps_r);
+  else
+    wgrad_reduce_body<false>(sm, blk, r.ws, r.dw, r.G, r.Cout, r.Cin, r.KH, r.KW, r.transposed, r.beta, r.bias_partial, r.db,
+                             r.bias_cout, r.out_ps_r);
+}
+
+static thread_local RedJobs g_red{};
+static thread_local int g_red_defer = 0;
+
+bool wgrad_reduce_deferring() { return g_red_defer > 0; }
+
+int wgrad_reduce_flush(hipStream_t s) {
+  if (g_red.n == 0) return SRK_OK;
+  hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3((unsigned)g_red.blocks), dim3(256), 0, s, g_red);
+  g_red.n = 0;
+  g_red.blocks = 0;
+  return check_launch("wgrad_reduce_multi");
+}
+
+// queue one reduction (or run it now when nothing is being deferred / it does not fit a job record)
+int wgrad_reduce_submit(bool wide, const float* ws, float* dw, int G, int Cout, int Cin, int KH, int KW, int transposed,
+                        float beta, const float* bias_partial, float* db, int bias_cout, int out_ps_r, hipStream_t s) {
+  const int elems = KH * KW * Cin * Cout;
+  const int bias_blocks = (bias_partial && db) ? cdiv(bias_cout, 64) : 0;
+  const bool fits = Cout < 32768 && Cin < 32768 && bias_cout < 32768 && KH < 256 && KW < 256;
+  if (!g_red_defer || !fits) {
+    if (!wide) return -100;   // (the grouped caller launches its own kernel)
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(elems, 64) + bias_blocks), dim3(256), 0, s, ws, dw, G, Cout, Cin, KH, KW,
+                       transposed, beta, bias_partial, db, bias_cout, out_ps_r);
+    return check_launch("conv_wgrad_reduce");
+  }
+  // two queued jobs must not update the same tensor (beta = 1 accumulates: shared weights), nor may the queue overflow
+  bool clash = g_red.n >= kMaxRedJobs;
+  for (int i = 0; i < g_red.n && !clash; ++i) clash = g_red.j[i].dw == dw || (db && g_red.j[i].db == db);
+  if (clash) {
+    const int rc = wgrad_reduce_flush(s);
+    if (rc) return rc;
+  }
+  RedJob& r = g_red.j[g_red.n++];
+  r.ws = ws; r.dw = dw; r.bias_partial = bias_blocks ? bias_partial : nullptr; r.db = bias_blocks ? db : nullptr;
+  r.G = G; r.blk0 = g_red.blocks;
+  r.Cout = (short)Cout; r.Cin = (short)Cin; r.bias_cout = (short)bias_cout;
+  r.KH = (unsigned char)KH; r.KW = (unsigned char)KW; r.transposed = (unsigned char)transposed;
+  r.out_ps_r = (unsigned char)out_ps_r; r.wide = wide ? 1 : 0; r.pad_ = 0;
+  r.beta = beta;
+  g_red.blocks += cdiv(elems, 64) + bias_blocks;
+  return SRK_OK;
+}
+
 // bias_partial / db may be NULL (no bias, or the bias gradient is produced elsewhere); bias_cout = channels of db
 int conv_wgrad_reduce_launch(const float* ws, float* dw, int G, int Cout, int Cin, int KH, int KW, int transposed,
                              float beta, const float* bias_partial, float* db, int bias_cout, int out_ps_r,
                              hipStream_t s) {
-  const int elems = KH * KW * Cin * Cout;
-  const int bias_blocks = (bias_partial && db) ? cdiv(bias_cout, 64) : 0;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(elems, 64) + bias_blocks), dim3(256), 0, s, ws, dw, G, Cout, Cin, KH, KW,
-                     transposed, beta, bias_partial, db, bias_cout, out_ps_r);
-  return check_launch("conv_wgrad_reduce");
+  return wgrad_reduce_submit(true, ws, dw, G, Cout, Cin, KH, KW, transposed, beta, bias_partial, db, bias_cout, out_ps_r, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -648,3 +752,11 @@ int conv_wgrad_mfma(const srk_conv_desc& d, const float* x, const float* dy, con
 }
 
 }  // namespace srk
+
+extern "C" int srk_wgrad_reduce_defer(int on) {
+  const int prev = srk::g_red_defer;
+  srk::g_red_defer = on ? 1 : 0;
+  return prev;
+}
+
+extern "C" int srk_wgrad_reduce_flush(void* stream) { return srk::wgrad_reduce_flush((hipStream_t)stream); }

@@ -149,16 +149,19 @@ __global__ __launch_bounds__(256) void k_sgd4(float* __restrict__ p, const float
   }
 }
 
-__global__ void k_inc_step(int32_t* step) { *step += 1; }
-
+// The step counter is advanced by the kernel itself (it used to be a one-thread launch of its own in front, ~5 us of a
+// 1.2 ms train step): every block reads the count of the PREVIOUS steps before anything else and works with count + 1;
+// the block that finishes last -- a ticket in step_dev[1]: it has seen every other block's arrival, so every block has
+// read the old count -- stores count + 1 and clears the ticket.  The count is consumed by the next launch only.
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g,
                                               float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
                                               float b1, float b2, float eps, float wd,
-                                              const int32_t* __restrict__ step_dev, const float* __restrict__ lr_dev,
+                                              int32_t* __restrict__ step_dev, const float* __restrict__ lr_dev,
                                               const float* __restrict__ gs_dev) {
   if (lr_dev) lr = *lr_dev;
   const float gs = gs_dev ? *gs_dev : 1.f;
-  const float t = (float)(*step_dev);
+  const int32_t t_i = __hip_atomic_load(step_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  const float t = (float)t_i;
   // torch/optim/adam.py (_single_tensor_adam): bias corrections, step_size, denom
   const float bc1 = 1.f - powf(b1, t);
   const float bc2 = 1.f - powf(b2, t);
@@ -175,6 +178,14 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] = pi - step_size * (mi / denom);
+  }
+  __syncthreads();   // (the whole block has read the old count)
+  if (threadIdx.x == 0) {
+    const int32_t arrived = atomicAdd(step_dev + 1, 1);
+    if (arrived == (int32_t)gridDim.x - 1) {
+      __hip_atomic_store(step_dev, t_i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(step_dev + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -273,9 +284,8 @@ extern "C" int srk_adam_step(float* p, const float* g, float* exp_avg, float* ex
                              const float* lr_dev, const float* grad_scale_dev, void* stream) {
   SRK_REQUIRE(p && g && exp_avg && exp_avg_sq && step_dev && n > 0, "adam_step: null pointer or empty");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_inc_step, dim3(1), dim3(1), 0, s, step_dev);
   hipLaunchKernelGGL(k_adam, dim3(red_grid(n)), dim3(256), 0, s, p, g, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
-                     weight_decay, (const int32_t*)step_dev, lr_dev, grad_scale_dev);
+                     weight_decay, step_dev, lr_dev, grad_scale_dev);
   return check_launch("adam_step");
 }
 

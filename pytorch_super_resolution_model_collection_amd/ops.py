@@ -45,6 +45,10 @@ _MODES = {"mixed": {"infer": _lib.ALGO_MFMA_BF16X6, "train_fwd": _lib.ALGO_MFMA_
           # not acceptable for the forward either
           "bf16x6": {"infer": _lib.ALGO_MFMA_BF16X6, "train_fwd": _lib.ALGO_MFMA_BF16X6, "bwd": ALGO_AUTO,
                      "train_fwd_tail": _lib.ALGO_MFMA_BF16X6},
+          # ... and in both gradient kernels too (data gradient on the six-MFMA split, weight gradient on the exact fp32 MFMA
+          # kernels): every product of a train step at fp32 accuracy -- the reference point for what the 3-MFMA backward costs
+          "faithful": {"infer": _lib.ALGO_MFMA_BF16X6, "train_fwd": _lib.ALGO_MFMA_BF16X6, "bwd": _lib.ALGO_MFMA_BF16X6,
+                       "train_fwd_tail": _lib.ALGO_MFMA_BF16X6},
           "bf16x3": {"infer": ALGO_AUTO, "train_fwd": ALGO_AUTO, "bwd": ALGO_AUTO, "train_fwd_tail": ALGO_AUTO},
           "fp32": {"infer": _lib.ALGO_MFMA, "train_fwd": _lib.ALGO_MFMA, "bwd": _lib.ALGO_MFMA,
                    "train_fwd_tail": _lib.ALGO_MFMA}}
@@ -52,7 +56,7 @@ _PRECISION = {"mode": "mixed"}
 
 
 def set_precision(mode):
-    """Select the convolution arithmetic: 'mixed' (default), 'bf16x3', 'bf16x6' or 'fp32' (see above)."""
+    """Select the convolution arithmetic: 'mixed' (default), 'bf16x3', 'bf16x6', 'faithful' or 'fp32' (see above)."""
     if mode not in _MODES:
         raise ValueError("precision must be one of %s" % sorted(_MODES))
     _PRECISION["mode"] = mode
@@ -65,7 +69,12 @@ def get_precision():
 def backward_arithmetic():
     """What the data- and weight-gradient products run on in the current mode (bench.py states it next to every training
     number)."""
-    return "exact fp32 MFMA" if _PRECISION["mode"] == "fp32" else "bf16x3 (3 MFMAs, ~5e-6 rms)"
+    mode = _PRECISION["mode"]
+    if mode == "fp32":
+        return "exact fp32 MFMA"
+    if mode == "faithful":
+        return "bf16x6 data gradients (6 MFMAs, ~3e-7 rms), exact fp32 MFMA weight gradients"
+    return "bf16x3 (3 MFMAs, ~5e-6 rms)"
 
 
 def _algo_for(cfg, role):
@@ -89,21 +98,27 @@ _AMAX = {}   # device index -> [chunk tensor, slots used]
 _AMAX_EPOCH = [0]
 
 
-def amax_new_step():
+def amax_new_step(chunk=None):
     """Start of a train step (optimizer.zero_grad) or of a graph capture: the next running maximum comes from a fresh
     zeroed chunk (inside a captured step the zero fill is part of the graph, so every replay starts from zero), and
     maxima attached to tensors before this point are no longer trusted -- a captured step must recompute the maximum of
-    its static input buffers inside the graph, where every replay sees the batch of that replay."""
+    its static input buffers inside the graph, where every replay sees the batch of that replay.
+    chunk: a float32 tensor of a multiple of AMAX_FLOATS elements that the CALLER zeroes on the stream before the step's
+    first kernel (optim.FlatParams keeps one next to its gradients: one fill for both); the step's first buffers come
+    from it, further ones from chunks allocated (and zeroed) here."""
     _AMAX.clear()
     _AMAX_EPOCH[0] += 1
+    if chunk is not None:
+        idx = chunk.device.index if chunk.device.index is not None else torch.cuda.current_device()
+        _AMAX[idx] = [chunk, 0, chunk.numel() // _lib.AMAX_FLOATS]
 
 
 def _amax_alloc(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     ent = _AMAX.get(idx)
-    if ent is None or ent[1] >= _AMAX_CHUNK_TENSORS:
+    if ent is None or ent[1] >= ent[2]:
         ent = _AMAX[idx] = [torch.zeros(_AMAX_CHUNK_TENSORS * _lib.AMAX_FLOATS, dtype=torch.float32,
-                                        device=torch.device("cuda", idx)), 0]
+                                        device=torch.device("cuda", idx)), 0, _AMAX_CHUNK_TENSORS]
     lo = ent[1] * _lib.AMAX_FLOATS
     ent[1] += 1
     return ent[0][lo:lo + _lib.AMAX_FLOATS]
@@ -477,6 +492,7 @@ def launch_wgrad_group(recs):
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
     check(lib.srk_conv2d_backward_weight_grouped(ctypes.byref(d), n, xs, dys, masks, dws, dbs, 1.0, ptr(ws), ws.numel(),
                                                  stream_ptr()), "srk_conv2d_backward_weight_grouped")
+    return ws   # (deferred reductions: the caller keeps the partial slabs alive until srk_wgrad_reduce_flush)
 
 
 def flush_wgrads(on_group=None, max_layers=None):
@@ -487,10 +503,24 @@ def flush_wgrads(on_group=None, max_layers=None):
     groups = pending_wgrad_groups(max_layers)
     del _PENDING[:]
     _DEFER["bytes"] = 0
-    for recs in groups:
-        launch_wgrad_group(recs)
-        if on_group is not None:
-            on_group(recs)
+    if on_group is not None or len(groups) < 2 or not MERGE_REDUCES:
+        for recs in groups:
+            launch_wgrad_group(recs)
+            if on_group is not None:
+                on_group(recs)
+        return len(groups)
+    # several launch groups and nobody waiting for one of them in particular: their slab reductions run as ONE launch
+    # behind the last group (srk_wgrad_reduce_defer / _flush; the workspaces stay alive until then)
+    lib = _lib.load()
+    prev = lib.srk_wgrad_reduce_defer(1)
+    try:
+        keep = [launch_wgrad_group(recs) for recs in groups]
+        check(lib.srk_wgrad_reduce_flush(stream_ptr()), "srk_wgrad_reduce_flush")
+    finally:
+        lib.srk_wgrad_reduce_defer(prev)
+        # a failure above may leave queued jobs behind: run them now rather than inside somebody else's flush
+        lib.srk_wgrad_reduce_flush(stream_ptr())
+    del keep
     return len(groups)
 
 
@@ -499,6 +529,7 @@ def drop_pending_wgrads():
     _DEFER["bytes"] = 0
 
 
+MERGE_REDUCES = os.environ.get("SRK_MERGE_REDUCES", "1") != "0"   # 0: every weight-gradient launch group reduces its slabs itself
 FUSE_SKIP_GRAD = os.environ.get("SRK_FUSE_SKIP_GRAD", "1") != "0"  # 0: residual blocks sum their gradient fan-in with srk_axpby
 
 
@@ -714,7 +745,7 @@ def resblock2_applicable(x, w1, w2):
         return False
     mode = _MODES[_PRECISION["mode"]]
     if mode["train_fwd"] not in (ALGO_AUTO, _lib.ALGO_MFMA_BF16X3, _lib.ALGO_MFMA_BF16X6) or \
-            mode["bwd"] not in (ALGO_AUTO, _lib.ALGO_MFMA_BF16X3):
+            mode["bwd"] not in (ALGO_AUTO, _lib.ALGO_MFMA_BF16X3, _lib.ALGO_MFMA_BF16X6):
         return False
     return bool(_lib.load().srk_resblock2_supported(n, h, w, c))
 

@@ -47,17 +47,23 @@ class FlatParams(object):
             total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.module, self.params, self.names, self.offsets, self.numel = module, params, names, offs, total
         self.data = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         for p, o in zip(params, offs):
             v = self.data[o:o + p.numel()].view(p.shape)
             v.copy_(p.data)
             p.data = v
+        bump_weight_epoch()
+        self.epoch = 0           # bumped whenever the flat parameters change (optimizer step, load_state_dict)
+        # ONE allocation [packed filters ... | max|w| scratch words | flat gradients | running-maximum chunk]: everything a
+        # train step has to find zeroed (the last three) is adjacent, so zero_grad is a single fill node instead of three
+        # (the strong-scaled EDSR shard is ~70 kernels of 5 - 100 us: every launch counts)
+        self._store = None
+        self.plan = PackPlan(module, self)     # lays the packed buffers out and calls _alloc_store
+        if self._store is None:
+            self._alloc_store(0, 0)
+        for p, o in zip(params, offs):
             g = self.grad[o:o + p.numel()].view(p.shape)
             p._srk_grad = g      # kernels accumulate here (ops._Conv2d.backward etc.)
             p.grad = g           # what user code / hooks see
-        bump_weight_epoch()
-        self.epoch = 0           # bumped whenever the flat parameters change (optimizer step, load_state_dict)
-        self.plan = PackPlan(module, self)
         # load_state_dict copies into the parameter views in place: the packed filters (PackPlan, no-grad caches) and
         # the graphs that skip a current plan (trainers._repack_touched compares `epoch`) must see that as a change
         self._load_hook = None
@@ -72,10 +78,27 @@ class FlatParams(object):
 
             self._load_hook = module.register_load_state_dict_post_hook(_loaded)
 
+    AMAX_TENSORS = 128   # running-maximum buffers (ops._amax_alloc) a step gets from the zeroed chunk of the store
+
+    def _alloc_store(self, packed_bytes, zero_from):
+        """[packed_bytes of PackPlan buffers, of which everything from `zero_from` on is per-step scratch | gradients |
+        running-maximum chunk] -> the PackPlan's part."""
+        dev = self.data.device
+        goff = (int(packed_bytes) + 255) // 256 * 256
+        gbytes = self.numel * 4
+        abytes = self.AMAX_TENSORS * _lib.AMAX_FLOATS * 4
+        self._store = torch.zeros(goff + (gbytes + 255) // 256 * 256 + abytes, dtype=torch.uint8, device=dev)
+        self.grad = self._store[goff:goff + gbytes].view(torch.float32)
+        aoff = goff + (gbytes + 255) // 256 * 256
+        self.amax_chunk = self._store[aoff:aoff + abytes].view(torch.float32)
+        self._zero_region = self._store[(zero_from if packed_bytes else goff):]
+        return self._store[:max(int(packed_bytes), 256)] if packed_bytes else None
+
     def zero_grad(self):
+        """Gradients, the PackPlan's max|w| scratch words and the running-maximum chunk: one fill."""
         from . import ops
         ops.join_side_streams()  # no weight gradient of the previous step may still be accumulating
-        self.grad.zero_()  # one memset node
+        self._zero_region.zero_()
 
     def mark_changed(self):
         """Call after the flat parameters changed by anything other than optimizer.step() — a hipGraph replay of a
@@ -134,7 +157,7 @@ class PackPlan(object):
         self.scratch_off = take(64 * len(rows))
         for i, r in enumerate(rows):
             r[11] = self.scratch_off + 64 * i
-        self.buf = torch.empty(max(off, 256), dtype=torch.uint8, device=dev)
+        self.buf = flat._alloc_store(max(off, 256), self.scratch_off)   # (scratch words last: zeroed together with the gradients)
         self.scratch = self.buf[self.scratch_off:self.scratch_off + 64 * len(rows)]
         # fast path (k_pack_fast): plain Conv2d filters are packed tile by tile from LDS, (Cout / 8) * ceil(Cin / 32)
         # blocks per layer; everything else (first layers, 64 -> 3 convs, deconvs, 9x9 kernels) takes the generic kernel
@@ -162,11 +185,13 @@ class PackPlan(object):
             bp = self.buf[bp_off:bp_off + cout * 4].view(torch.float32) if bp_off >= 0 else None
             m._plan = [self, ps_r, wpf, bp, wpb, -1, -1]
 
-    def pack(self):
+    def pack(self, scratch_zeroed=False):
+        """scratch_zeroed: the caller just zeroed the scratch words (FlatParams.zero_grad's fill covers them)."""
         if self.n == 0:
             return
         lib = _lib.load()
-        self.scratch.zero_()
+        if not scratch_zeroed:
+            self.scratch.zero_()
         check(lib.srk_pack_weights_batched(ptr(self.flat.data), ptr(self.buf), ptr(self.table), self.n, -self.blocks,
                                            ptr(self.fast_blocks), self.n_fast, stream_ptr()), "srk_pack_weights_batched")
         self.epoch = self.flat.epoch
@@ -216,10 +241,10 @@ class _FlatOptimizer(object):
         graph which FlatParams it updates (trainers.GraphedFn(flats=...)): inside a replay nobody can see that somebody
         rewrote the parameters in place, the unconditional pack is what makes that case work by itself."""
         from . import ops
-        ops.amax_new_step()
+        ops.amax_new_step(self.flat.amax_chunk)   # (zeroed by the fill below)
         self.flat.zero_grad()
         if repack != "stale" or not self.flat.plan.current():
-            self.flat.plan.pack()
+            self.flat.plan.pack(scratch_zeroed=True)
 
     def clip_grad_norm(self, max_norm):
         """torch.nn.utils.clip_grad_norm(params, max_norm) (vdsr.py:149): computes the global L2
@@ -267,7 +292,7 @@ class Adam(_FlatOptimizer):
         self.betas, self.eps, self.weight_decay = (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
         self.exp_avg = torch.zeros_like(self.flat.data)
         self.exp_avg_sq = torch.zeros_like(self.flat.data)
-        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.flat.data.device)
+        self.step_dev = torch.zeros(2, dtype=torch.int32, device=self.flat.data.device)   # {step count, kernel's ticket}
 
     def step(self):
         from . import ops

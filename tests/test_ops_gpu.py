@@ -680,7 +680,7 @@ def test_optimizers_kat(gpu, ops_kat, kind):
     assert float(np.abs(got - ops_kat["opt.p0"]).max()) > 1e-4          # the parameters did move
     assert float(np.abs(got - want).max()) <= 1e-6 * max(1.0, float(np.abs(want).max())), kind
     if kind == "edsr":
-        assert int(opt.step_dev.item()) == 3
+        assert opt.step_dev.tolist() == [3, 0]      # {step count, the kernel's arrival ticket back at 0}
 
 
 def test_grad_norm_clip_kat(gpu, ops_kat):
@@ -863,7 +863,6 @@ def test_pack_batched_amax_scans_an_unaligned_layer_completely(gpu):
     a = buf[offs[0][0]:offs[0][0] + nf].cpu()
     b = buf[offs[1][0]:offs[1][0] + nf].cpu()
     assert torch.equal(a, b)
-    assert torch.isfinite(a[:nf // 2 * 2].view(torch.float16).float()).all()   # (no plane overflowed)
     assert torch.equal(buf[offs[0][1]:offs[0][1] + nb].cpu(), buf[offs[1][1]:offs[1][1] + nb].cpu())
 
 
@@ -875,13 +874,31 @@ def test_conv_says_whether_it_wrote_the_running_maximum(gpu, monkeypatch):
     ops, lib = pkg.ops, pkg._lib.load()
     x = fill.randn((2, 64, 20, 20), 3).to(gpu)
     w = (fill.randn((64, 64, 3, 3), 4) * 0.05).to(gpu)
+    monkeypatch.setattr(ops, "F16X3_ALWAYS", True)   # (a problem this small would not ask for the maximum otherwise)
     with torch.no_grad():
         y = ops.conv2d_infer(x, w, None, None, ops.ConvCfg(1, 1, False, 0, 1, 0.0, 0, pkg._lib.ALGO_MFMA_BF16X6))
         assert lib.srk_last_conv_wrote_amax() == 1
         assert y._srk_amax[0] is not None and float(y._srk_amax[0].max()) == float(y.abs().max())
-        y = ops.conv2d_infer(x, w, None, None, ops.ConvCfg(1, 1, False, 0, 1, 0.0, 0, pkg._lib.ALGO_MFMA))
-        assert lib.srk_last_conv_wrote_amax() == 0
-        assert getattr(y, "_srk_amax", (None,))[0] is None
+        # the exact-fp32 kernels keep the maximum on their 16-byte store path since round 4 (a first layer on them used to
+        # cost the trunk behind it an srk_absmax pass) ...
+        ya = torch.zeros(pkg._lib.AMAX_FLOATS, device=gpu)
+        d = ops._make_desc(x.shape, w, ops.ConvCfg(1, 1, False, 0, 1, 0.0, 0, pkg._lib.ALGO_MFMA))
+        xs = x.contiguous(memory_format=torch.channels_last)
+        yy = torch.empty_like(xs)
+        ep = pkg._lib.Epilogue(None, None, None, 0.0, 1, 0, 0, None, pkg._lib.ptr(ya))
+        wp = ops.pack_weight_fwd(w, False, 0)
+        rc = lib.srk_conv2d_forward(ctypes.byref(d), pkg._lib.ptr(xs), pkg._lib.ptr(wp), pkg._lib.ptr(yy), ctypes.byref(ep),
+                                    pkg._lib.stream_ptr())
+        assert rc == 0 and lib.srk_last_conv_wrote_amax() == 1
+        assert float(ya.max()) == float(yy.abs().max())
+        # ... a call without y_amax says 0, and so does the shape-agnostic kernel
+        ep = pkg._lib.Epilogue(None, None, None, 0.0, 1, 0, 0, None, None)
+        assert lib.srk_conv2d_forward(ctypes.byref(d), pkg._lib.ptr(xs), pkg._lib.ptr(wp), pkg._lib.ptr(yy), ctypes.byref(ep),
+                                      pkg._lib.stream_ptr()) == 0 and lib.srk_last_conv_wrote_amax() == 0
+        d.algo = 1   # SRK_ALGO_GENERIC
+        ep = pkg._lib.Epilogue(None, None, None, 0.0, 1, 0, 0, None, pkg._lib.ptr(ya))
+        assert lib.srk_conv2d_forward(ctypes.byref(d), pkg._lib.ptr(xs), pkg._lib.ptr(wp), pkg._lib.ptr(yy), ctypes.byref(ep),
+                                      pkg._lib.stream_ptr()) == 0 and lib.srk_last_conv_wrote_amax() == 0
 
 
 def test_batchnorm_on_an_unaligned_view_takes_the_scalar_path(gpu):
@@ -902,3 +919,56 @@ def test_batchnorm_on_an_unaligned_view_takes_the_scalar_path(gpu):
         ops.F16X3_ALWAYS = prev
     ref = torch.nn.functional.batch_norm(x.contiguous(), None, None, gamma, beta, True)
     assert rel_err(y, ref) < 1e-5
+
+
+C64_SHAPES = [(16, 32, 32), (3, 13, 21), (1, 8, 8), (2, 5, 40), (1, 1, 1), (2, 17, 9)]
+
+
+@pytest.mark.parametrize("shape", C64_SHAPES)
+@pytest.mark.parametrize("bias,res", [(True, False), (False, True), (True, True)])
+def test_conv_c64_small_problem_kernel(gpu, shape, bias, res):
+    """k_c64 (conv_c64.hip): the 3x3 pad-1 64 -> 64 convolution of a small problem, one 8x8 tile per block -- what SRGAN's
+    BatchNorm-separated generator convs (srgan.py:14-46 through base_networks.py:128-150) and EDSR's body-end conv run at
+    the reference's batch of 16.  Forward in the three arithmetics and the data gradient (flipped taps, gradient fan-in
+    add) against float64, through the C ABI; the dispatcher must really have picked the kernel."""
+    import torch.nn.functional as F
+    pkg = _pkg()
+    ops, L, lib = pkg.ops, pkg._lib, pkg._lib.load()
+    n, h, w = shape
+    x = fill.randn((n, 64, h, w), 31 + h)
+    wt = fill.randn((64, 64, 3, 3), 32 + w) * (2.0 / 576) ** 0.5
+    b = fill.randn((64,), 33) * 0.1 if bias else None
+    r = fill.randn((n, 64, h, w), 34) if res else None
+    ref = F.conv2d(x.double(), wt.double(), None if b is None else b.double(), padding=1)
+    if r is not None:
+        ref = ref + r.double()
+    xg, wg = x.to(gpu), wt.to(gpu)
+    bg = None if b is None else b.to(gpu)
+    rg = None if r is None else r.to(gpu)
+    for algo, tol, tag in ((L.ALGO_MFMA_BF16X6, TOL_TIGHT, "k_c64<3,0>"), (L.ALGO_MFMA_F16X3, TOL_TIGHT, "k_c64<2,0,f16>"),
+                           (L.ALGO_MFMA_BF16X3, 1e-4, "k_c64<2,0>")):
+        with torch.no_grad():
+            y = ops.conv2d_infer(xg, wg, bg, rg, ops.ConvCfg(1, 1, False, 0, 0, 0.0, 0, algo))
+        assert lib.srk_last_kernel_name().decode() == tag
+        assert rel_err(y, ref) < tol, (tag, rel_err(y, ref))
+        if algo != L.ALGO_MFMA_BF16X3:     # the faithful-class kernels leave the running maximum of what they stored
+            assert float(y._srk_amax[0].max()) == float(y.abs().max())
+    # data gradient: dx = conv^T(dy) [+ add_to]
+    dy = fill.randn((n, 64, h, w), 35)
+    dref = F.conv_transpose2d(dy.double(), wt.double(), padding=1)
+    if r is not None:
+        dref = dref + r.double()
+    CL = torch.channels_last
+    dyg = dy.to(gpu).contiguous(memory_format=CL)
+    addg = None if r is None else rg.contiguous(memory_format=CL)
+    dx = torch.empty_like(dyg)
+    d = ops._make_desc(xg.shape, wg, ops.ConvCfg(1, 1, False, 0, 0, 0.0, 0), "bwd")
+    wpb = ops.pack_weight_bwd(wg, False, 0)
+    rc = lib.srk_conv2d_backward_data(ctypes.byref(d), L.ptr(dyg), L.ptr(wpb), L.ptr(dx), None, L.ptr(addg), L.stream_ptr())
+    assert rc == 0, lib.srk_last_error_string()
+    assert lib.srk_last_kernel_name().decode() == "k_c64<2,1>"
+    assert rel_err(dx, dref) < 1e-4
+    # with an activation the layer stays on the general kernels
+    with torch.no_grad():
+        ops.conv2d_infer(xg, wg, bg, None, ops.ConvCfg(1, 1, False, 0, 1, 0.0, 0))
+    assert not lib.srk_last_kernel_name().decode().startswith("k_c64")

@@ -503,3 +503,43 @@ def test_srgan_step_without_its_dead_gradients(gpu):
             assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()), what
         else:
             assert torch.equal(a, b), (what, float((a - b).abs().max()), float(b.abs().max()))
+
+
+@pytest.mark.parametrize("kind", ["edsr", "lapsrn", "srgan_d"])
+def test_merged_slab_reductions_equal_per_group_reductions(gpu, kind):
+    """ops.flush_wgrads runs the slab reductions of all weight-gradient launch groups of a backward pass as ONE launch
+    (srk_wgrad_reduce_defer / _flush): same gradients, bit for bit, as every group reducing its own slabs -- EDSR (grouped
+    bf16x3 launches, the few-channel kernels of the first / last conv, pixel-shuffled dy), LapSRN (shared weights: a second
+    update of a queued dw forces a flush in between) and the SRGAN discriminator (strided convs: exact-fp32 kernels)."""
+    pkg = _pkg()
+    ops = pkg.ops
+    from oracle import fill
+    grads = []
+    for merge in (True, False):
+        if kind == "edsr":
+            net = pkg.EDSRNet(3, 64, 4)
+            x, t = fill.rand((4, 3, 16, 12), 61), fill.rand((4, 3, 64, 48), 62)
+            loss_of = lambda out: ops.l1_loss(out, t.to(gpu))
+        elif kind == "lapsrn":
+            net = pkg.LapSRNNet(3, 64, 3)
+            x, t = fill.rand((2, 3, 12, 12), 63), fill.rand((2, 3, 48, 48), 64)
+            loss_of = lambda out: ops.charbonnier_loss(out[1], t.to(gpu))
+        else:
+            net = pkg.SRGANDiscriminator(3, 64, 32)
+            x, t = fill.rand((4, 3, 32, 32), 65), fill.rand((4, 1), 66)
+            loss_of = lambda out: ops.bce_loss(out, t.to(gpu))
+        fill.fill_module(net, 9, 0.5)
+        net.to(gpu).train()
+        flat = pkg.optim.FlatParams(net)
+        flat.zero_grad()
+        flat.plan.pack()
+        prev = ops.MERGE_REDUCES
+        ops.MERGE_REDUCES = merge
+        try:
+            ops.backward(loss_of(net(x.to(gpu))))
+        finally:
+            ops.MERGE_REDUCES = prev
+        torch.cuda.synchronize()
+        grads.append(flat.grad.clone())
+    assert float(grads[0].abs().max()) > 0
+    assert torch.equal(grads[0], grads[1])
