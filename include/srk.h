@@ -331,6 +331,12 @@ int srk_bn_apply(const float* x, float* y, const float* mean, const float* rstd,
                  const float* beta, size_t rows, int C, int act, float slope, float* y_amax, void* stream);
 int srk_bn_eval_params(const float* running_mean, const float* running_var, float eps, float* mean, float* rstd,
                        int C, void* stream);
+/* nn.InstanceNorm1d on the [B, F] output of a Linear (DenseBlock(norm='instance'), base_networks.py:12-13): torch reads the
+ * 2-D tensor as one unbatched sample of B channels x F positions, i.e. every ROW is normalised with its own biased
+ * statistics (no affine parameters, no running statistics).  mean / rstd: [rows] outputs the backward needs. */
+int srk_rownorm_forward(const float* x, float* y, float* mean, float* rstd, int rows, int cols, float eps, void* stream);
+int srk_rownorm_backward(const float* dy, const float* x, const float* mean, const float* rstd, float* dx, int rows,
+                         int cols, void* stream);
 /* Backward: `dstats` [2*C] doubles = (sum dy, sum dy*xhat) (all-reducible for SyncBN);
  * srk_bn_backward_apply writes dx = gamma*rstd*(dy - dstats[c]/count - xhat*dstats[C+c]/count)
  * (pass zeros for eval-mode BN); srk_bn_param_grads accumulates dbeta += dstats[c],

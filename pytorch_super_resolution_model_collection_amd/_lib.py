@@ -108,6 +108,8 @@ _PROTOTYPES = {
     "srk_bn_backward_apply_act": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_vp, ctypes.c_double, c_f, c_size, c_int, c_int,
                                            c_float, c_f, c_int, c_vp]),
     "srk_bn_eval_params": (c_int, [c_f, c_f, c_float, c_f, c_f, c_int, c_vp]),
+    "srk_rownorm_forward": (c_int, [c_f, c_f, c_f, c_f, c_int, c_int, c_float, c_vp]),
+    "srk_rownorm_backward": (c_int, [c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_vp]),
     "srk_bn_backward_stats": (c_int, [c_f, c_f, c_f, c_f, c_vp, c_size, c_int, c_vp, c_vp]),
     "srk_bn_backward_apply": (c_int, [c_f, c_f, c_f, c_f, c_f, c_vp, ctypes.c_double, c_f, c_size, c_int, c_vp]),
     "srk_bn_param_grads": (c_int, [c_vp, c_f, c_f, c_int, c_vp]),

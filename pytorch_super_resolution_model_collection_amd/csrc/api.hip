@@ -101,12 +101,17 @@ int conv_generic_wgrad(const srk_conv_desc& d, const float* x, const float* dy, 
 // conv_wgrad_mfma.hip
 bool wgrad_reduce_deferring();
 int wgrad_reduce_flush(hipStream_t s);
+int wgrad_reduce_before_update(const float* dw, const float* db, hipStream_t s);
 bool conv_wgrad_mfma_supported(const srk_conv_desc& d);
 size_t conv_wgrad_mfma_ws(const srk_conv_desc& d);
 int conv_wgrad_mfma(const srk_conv_desc& d, const float* x, const float* dy, const srk_bwd_mask* mask, float* dw,
                     float* db, float beta, void* ws, size_t ws_bytes, hipStream_t s);
 
 // conv_wgrad_bf16.hip
+bool conv_wgrad_s2_supported(const srk_conv_desc& d, const float* x, const float* dy, const srk_bwd_mask* mask);
+size_t conv_wgrad_s2_ws(const srk_conv_desc& d);
+int conv_wgrad_s2(const srk_conv_desc& d, const float* x, const float* dy, float* dw, float* db, float beta, void* ws,
+                  size_t ws_bytes, hipStream_t s);
 bool conv_wgrad_bf_supported(const srk_conv_desc& d);
 size_t conv_wgrad_bf_ws(const srk_conv_desc& d);
 int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const srk_bwd_mask* mask, float* dw,
@@ -425,6 +430,8 @@ extern "C" size_t srk_conv2d_backward_weight_workspace_bytes(const srk_conv_desc
   if (b > a) a = b;
   if (c > a) a = c;
   const size_t t = conv_wgrad_tapn_supported(*d, nullptr, nullptr) ? conv_wgrad_tapn_ws(*d) : 0;
+  const size_t s2 = conv_wgrad_s2_ws(*d);   // (0 when the stride-2 bf16x3 kernel does not cover the layer)
+  if (s2 > a) a = s2;
   return a > t ? a : t;
 }
 
@@ -435,6 +442,7 @@ extern "C" int srk_conv2d_backward_weight(const srk_conv_desc* d, const float* x
   if (rc) return rc;
   SRK_REQUIRE(x && dy && dw, "conv2d_backward_weight: null tensor pointer");
   SRK_REQUIRE(beta == 0.f || beta == 1.f, "conv2d_backward_weight: beta must be 0 or 1");
+  if ((rc = wgrad_reduce_before_update(dw, db, (hipStream_t)stream))) return rc;   // (deferred reductions: srk_wgrad_reduce_defer)
   // AUTO / BF16X3: bf16x3 MFMA kernel where it applies (stride-1 convs up to 3x3); MFMA / BF16X6 / DIRECT: the
   // exact fp32 MFMA kernel; GENERIC: the plain kernel
   const int algo = forced_algo(d->algo);
@@ -444,6 +452,9 @@ extern "C" int srk_conv2d_backward_weight(const srk_conv_desc* d, const float* x
     return conv_wgrad_tapn(*d, x, dy, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);
   if ((algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3) && !(wb && atoi(wb) == 0) && conv_wgrad_bf_supported(*d))
     return conv_wgrad_bf(*d, x, dy, mask, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);
+  // stride-2 3x3 convs (SRGAN's discriminator): bf16x3 on de-interleaved halo columns
+  if ((algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3) && !(wb && atoi(wb) == 0) && conv_wgrad_s2_supported(*d, x, dy, mask))
+    return conv_wgrad_s2(*d, x, dy, dw, db, beta, workspace, workspace_bytes, (hipStream_t)stream);
   if (d->dy_ps_r > 1) {
     set_error("conv2d_backward_weight: pixel-shuffled dy is only supported by the bf16x3 kernel (un-shuffle with "
               "srk_pixel_shuffle_backward)");
@@ -493,6 +504,7 @@ extern "C" int srk_conv2d_backward_weight_grouped(const srk_conv_desc* d, int n,
     for (int k = 0; k < l; ++k)
       SRK_REQUIRE(dw[k] != dw[l], "conv2d_backward_weight_grouped: layers %d and %d write the same dw (shared weights must "
                   "go into separate calls)", k, l);
+    if ((rc = wgrad_reduce_before_update(dw[l], db ? db[l] : nullptr, (hipStream_t)stream))) return rc;
   }
   if (n >= 2 && wgrad_group_uses_bf(*d)) {
     for (int l0 = 0; l0 < n; l0 += kMaxWgradGroup) {

@@ -888,6 +888,76 @@ extern "C" int srk_bn_eval_params(const float* running_mean, const float* runnin
   return check_launch("bn_eval_params");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row normalisation: nn.InstanceNorm1d(F) applied to a [B, F] activation (DenseBlock(norm='instance'),
+// base_networks.py:12-13).  torch reads the 2-D input as ONE unbatched sample of B channels x F positions, so every ROW
+// is normalised with its own biased statistics over the F features (no affine parameters, no running statistics).
+// One 256-thread block per row; sums in double.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rownorm_fwd(const float* __restrict__ x, float* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int cols,
+                                                     float eps) {
+  __shared__ double sm[4];
+  __shared__ float stat[2];
+  const float* xr = x + (size_t)blockIdx.x * cols;
+  float* yr = y + (size_t)blockIdx.x * cols;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < cols; i += 256) s += (double)xr[i];
+  const double m = block_sum_256_d(s, sm) / cols;
+  double q = 0.0;
+  for (int i = threadIdx.x; i < cols; i += 256) {
+    const double d = (double)xr[i] - m;
+    q += d * d;
+  }
+  const double var = block_sum_256_d(q, sm) / cols;
+  if (threadIdx.x == 0) {
+    stat[0] = (float)m;
+    stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+    mean[blockIdx.x] = stat[0];
+    rstd[blockIdx.x] = stat[1];
+  }
+  __syncthreads();
+  const float mf = stat[0], rf = stat[1];
+  for (int i = threadIdx.x; i < cols; i += 256) yr[i] = (xr[i] - mf) * rf;
+}
+
+// dx = rstd * (dy - mean(dy) - xhat * mean(dy * xhat)) per row
+__global__ __launch_bounds__(256) void k_rownorm_bwd(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     float* __restrict__ dx, int cols) {
+  __shared__ double sm[4];
+  const size_t base = (size_t)blockIdx.x * cols;
+  const float mf = mean[blockIdx.x], rf = rstd[blockIdx.x];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < cols; i += 256) {
+    const float g = dy[base + i], xh = (x[base + i] - mf) * rf;
+    a += (double)g;
+    b += (double)g * (double)xh;
+  }
+  const double sa = block_sum_256_d(a, sm) / cols;
+  __syncthreads();
+  const double sb = block_sum_256_d(b, sm) / cols;
+  const float fa = (float)sa, fb = (float)sb;
+  for (int i = threadIdx.x; i < cols; i += 256) {
+    const float xh = (x[base + i] - mf) * rf;
+    dx[base + i] = rf * (dy[base + i] - fa - xh * fb);
+  }
+}
+
+extern "C" int srk_rownorm_forward(const float* x, float* y, float* mean, float* rstd, int rows, int cols, float eps,
+                                   void* stream) {
+  SRK_REQUIRE(x && y && mean && rstd && rows > 0 && cols > 0, "rownorm_forward: bad args");
+  hipLaunchKernelGGL(k_rownorm_fwd, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, y, mean, rstd, cols, eps);
+  return check_launch("rownorm_forward");
+}
+
+extern "C" int srk_rownorm_backward(const float* dy, const float* x, const float* mean, const float* rstd, float* dx,
+                                    int rows, int cols, void* stream) {
+  SRK_REQUIRE(dy && x && mean && rstd && dx && rows > 0 && cols > 0, "rownorm_backward: bad args");
+  hipLaunchKernelGGL(k_rownorm_bwd, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, dx, cols);
+  return check_launch("rownorm_backward");
+}
+
 extern "C" int srk_bn_apply(const float* x, float* y, const float* mean, const float* rstd, const float* gamma,
                             const float* beta, size_t rows, int C, int act, float slope, float* y_amax, void* stream) {
   SRK_REQUIRE(x && y && mean && rstd && rows > 0 && C > 0, "bn_apply: bad args");

@@ -69,7 +69,7 @@ static long long* g_bfw_prof = nullptr;
 template <int NTW, int TT, int MTW, bool F16 = false, bool MASK = false, bool OMASK = false, int NPW = 4>
 __global__ __launch_bounds__(64 * (16 / MTW + NPW), (16 / MTW + NPW) / 4) void k_conv_bfw(BfwParams B) {
   constexpr int NCW = 16 / MTW;          // consumer waves: MTW 16-pixel groups each, 256 pixels per block
-  constexpr int NTHR = 64 * (NCW + NPW);   // + NPW producer waves (4; 8: round-4 experiment, SRK_BFW_NPW)
+  constexpr int NTHR = 64 * (NCW + NPW);   // + NPW producer waves (4; 8 measured in round 4: 481 -> 489 us on the c2 64->32 layer)
   constexpr int PSTEP = 16 * NPW;        // halo pixels the producers cover per register batch
   constexpr int PIT = BFW_IT * 4 / NPW;  // register batches per producer thread
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
@@ -169,37 +169,67 @@ __global__ __launch_bounds__(64 * (16 / MTW + NPW), (16 / MTW + NPW) / 4) void k
     const int g = ptid & 3, hp0 = ptid >> 2;
     const int hy0 = hp0 / P.HW, hx0 = hp0 - hy0 * P.HW;
     const int dyp = PSTEP / P.HW, dxp = PSTEP - dyp * P.HW;
+    // (Two register sets -- the loads of stage s+2 issued BEFORE stage s+1 is committed, a whole stage to land instead of
+    // issue time + barrier wait -- were measured again in round 4 on top of the counted waits: 473 vs 474 us and 356 vs 356
+    // us on the two c2 layers.  The producers are not what a stage waits for: after the rewrite of issue() below their wave
+    // spends 35 % of a stage at the barrier, tools/bfw_prof.py.)
     f32x4 pv0[PIT], pv1[PIT];
     f32x4 mk0[MASK ? PIT : 1], mk1[MASK ? PIT : 1];  // MASK: y of the forward layer (dx = conv^T(dy * act'(y)))
-    auto issue = [&]() {
-      int n, r0, c0, cc;
-      decode(n, r0, c0, cc);
-      if (B.dbg & 1) return;
-      const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
-      const int ch = cc * 32 + g * 8;
-      const bool ch_on = ch + 7 < P.IC;
-      const size_t ibase = (size_t)n * P.IH * P.IW * P.IC + ch;
+    // Round 4: everything about the thread's items that does not depend on the stage is computed ONCE -- byte offset
+    // relative to the halo origin (-1: no item), halo column -- and the loads go, unconditionally, through a buffer
+    // descriptor of the image: a row above / below the image is an offset outside the descriptor (reads zero), a column
+    // left / right of it, a missing item or a channel group beyond IC gets one by a select.  Per stage and item that
+    // leaves one add, one compare and one select in front of two loads.  (Before: a 64-bit multiply chain and a
+    // divergent branch around every pair of loads -- ~35 VALU instructions per item, 1450 of the producer wave's 6300
+    // clocks per stage by the clock64 stamps of tools/bfw_prof.py, and an s_waitcnt vmcnt(0) in front of the first
+    // conversion of the commit because loads under a branch cannot be counted.)
+    int it_rel[PIT], it_hx[PIT];
+    {
       int hy = hy0, hx = hx0;
 #pragma unroll
       for (int k = 0; k < PIT; ++k) {
-        pv0[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        pv1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if constexpr (MASK) mk0[k] = mk1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int iy = iyb + hy, ix = ixb + hx;
-        if (hp0 + PSTEP * k < npix && ch_on && (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW) {
-          const size_t off = ibase + ((size_t)iy * P.IW + ix) * P.IC;
-          pv0[k] = *reinterpret_cast<const f32x4*>(P.in + off);
-          pv1[k] = *reinterpret_cast<const f32x4*>(P.in + off + 4);
-          if constexpr (MASK) {
-            mk0[k] = *reinterpret_cast<const f32x4*>(P.mask_y + off);
-            mk1[k] = *reinterpret_cast<const f32x4*>(P.mask_y + off + 4);
-          }
-        }
+        it_rel[k] = hp0 + PSTEP * k < npix ? ((hy * P.IW + hx) * P.IC + g * 8) * 4 : -1;
+        it_hx[k] = hx;
         hy += dyp;
         hx += dxp;
         if (hx >= P.HW) {
           hx -= P.HW;
           ++hy;
+        }
+      }
+    }
+    const unsigned img_bytes = (unsigned)((size_t)P.IH * P.IW * P.IC * 4);   // (host: below 2 GiB)
+    auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+      typedef unsigned bfw_u32x4 __attribute__((ext_vector_type(4)));
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+    };
+    auto rsrc_of = [](const float* base, unsigned bytes) {
+      const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+      void* p = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+      return __builtin_amdgcn_make_buffer_rsrc(p, (short)0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+    };
+    auto issue = [&]() {
+      int n, r0, c0, cc;
+      decode(n, r0, c0, cc);
+      if (B.dbg & 1) return;
+      constexpr unsigned OOB = 0x80000000u;
+      const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
+      const bool ch_on = cc * 32 + g * 8 + 7 < P.IC;
+      const size_t img = (size_t)n * P.IH * P.IW * P.IC;
+      const __amdgpu_buffer_rsrc_t rin = rsrc_of(P.in + img, img_bytes);
+      const __amdgpu_buffer_rsrc_t rmk = rsrc_of(MASK ? P.mask_y + img : P.in, MASK ? img_bytes : 0u);
+      (void)rmk;
+      const int obase = ((iyb * P.IW + ixb) * P.IC + cc * 32) * 4;   // may be negative: rows above the image wrap out of range
+#pragma unroll
+      for (int k = 0; k < PIT; ++k) {
+        const bool ok = it_rel[k] >= 0 && ch_on && (unsigned)(ixb + it_hx[k]) < (unsigned)P.IW;
+        const unsigned o = ok ? (unsigned)(obase + it_rel[k]) : OOB;
+        pv0[k] = bload(rin, o);
+        pv1[k] = bload(rin, o + 16u);
+        if constexpr (MASK) {
+          mk0[k] = bload(rmk, o);
+          mk1[k] = bload(rmk, o + 16u);
         }
       }
     };
@@ -226,13 +256,13 @@ __global__ __launch_bounds__(64 * (16 / MTW + NPW), (16 / MTW + NPW) / 4) void k
         }
       }
     };
+    long long pt_commit = 0, pt_issue = 0, pt_wait = 0;
     if (S > 0 && T > 0) {
       issue();
       commit(hal0);
       if (S > 1) issue();
     }
     __syncthreads();  // filter, tap table and stage 0 visible
-    long long pt_commit = 0, pt_issue = 0, pt_wait = 0;
     const long long pt_begin = BFW_CLK();
     for (int s = 0; s < S; ++s) {
       const long long c0 = BFW_CLK();
@@ -336,7 +366,12 @@ __global__ __launch_bounds__(64 * (16 / MTW + NPW), (16 / MTW + NPW) / 4) void k
   auto store_slot = [&](auto qc) {
     constexpr int q = decltype(qc)::value;
     constexpr int mt = q / NTW, nt = q - mt * NTW;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, pend[nt][mt]), orsrc, (int)(pend_voff[mt] + 4u * (unsigned)coff[nt]), 0, 0);
+    // (Round 4 measured the epilogue arithmetic moved here -- raw accumulators parked, descale / bias / activation / running
+    //  maximum right in front of each store, between the taps of the next stage: same-box A/B 469 -> 504 us and 340 -> 348 us
+    //  on the c2 layers, VDSR step 6.64 -> 6.84 ms.  The VALU work delays the wave's own next MFMAs more than the idle
+    //  parking phase costs; not kept.)
+    const f32x4 v = pend[nt][mt];
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), orsrc, (int)(pend_voff[mt] + 4u * (unsigned)coff[nt]), 0, 0);
   };
   auto flush_from = [&](auto q0c) {  // slots q0 .. NST-1
     constexpr int q0 = decltype(q0c)::value;
@@ -554,6 +589,7 @@ bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, co
   if (mode == 0 || g.stride != 1 || g.in_nchw || g.in_ps_r > 1) return false;
   if (g.IC < 8 || g.IC % 8 != 0 || (uintptr_t)in % 16 != 0) return false;
   if (g.OC % 16 != 0 || g.OC < 16) return false;
+  if ((long)g.IH * g.IW * g.IC * 4 >= (1L << 31)) return false;   // the producers' per-image buffer descriptor (32-bit byte offsets)
   const int T = g.KH * g.KW;
   const int nsl = bfw_slices(g);
   if (nsl == 0) return false;
@@ -602,17 +638,6 @@ static int bfw_launch_t(const BfwParams& B, size_t lds, int grid, hipStream_t s)
     }
   }
   if (B.P.mask_y || B.P.ep.out_relu) return -1;
-#ifdef SRK_EXPERIMENTS
-  if constexpr (NTW == 2 && TT == 9 && MTW == 2) {
-    if (B.w_descale && SRK_EXP_INT("SRK_BFW_NPW", 4) == 8) {   // experiment: 8 producer waves (16-wave blocks)
-      static LdsLimit lim8;
-      lim8.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, MTW, true, false, false, 8>), lds);
-      note_kernel("k_conv_bfw<%d,%d,%d,f16,npw8>", NTW, TT, MTW);
-      hipLaunchKernelGGL((k_conv_bfw<NTW, TT, MTW, true, false, false, 8>), dim3(grid), dim3(64 * (16 / MTW + 8)), lds, s, B);
-      return check_launch("conv_bfw");
-    }
-  }
-#endif
   if (B.w_descale) {  // f16x3 arithmetic
     static LdsLimit limh;
     limh.ensure(reinterpret_cast<const void*>(&k_conv_bfw<NTW, TT, MTW, true>), lds);

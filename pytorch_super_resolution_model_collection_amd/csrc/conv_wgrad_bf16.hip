@@ -760,6 +760,237 @@ __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stride-2 3x3 pad-1 weight gradient (SRGAN's discriminator, srgan.py:57,59,61,63: conv -> BatchNorm, no fused
+// activation) on the bf16 matrix cores.  Until round 4 these four layers ran the exact-fp32 kernel of conv_wgrad_mfma.hip:
+// 12 launches x 100 us = 8 % of the adversarial step, for 4.8 GFLOP each.
+//
+//   dW[u][v][ci][co] = sum over output pixels (r, c) of  X[2r + u - 1][2c + v - 1][ci] * dY[r][c][co]
+//
+// Same GEMM view as k_wgrad_bf (M = ci, N = co, K = output pixels, 8 consecutive pixels of a tile row per fragment), but
+// the 8 input pixels a fragment needs are two columns apart.  The X halo of a tile is therefore staged DE-INTERLEAVED:
+// each halo row holds its even halo columns (E) followed by its odd ones (O), halo column hx = 2 (c - c0) + v:
+//   v = 0 -> E[c - c0 ..], v = 1 -> O[c - c0 ..], v = 2 -> E[c - c0 + 1 ..] (the v_alignbit shift of k_wgrad_bf, by one element);
+// a staging thread loads four adjacent halo pixels x 4 channels and stores the E pair and the O pair as packed dwords.
+// Per-tile kernel (stage, barrier, K loop), two blocks of 4 waves (cit, cow) = 32 ci x 64 co per CU; slabs and the bias
+// partials go to the shared deterministic reduce.  Requires Cin % 32 == 0, Cout % 64 == 0, no gradient mask.
+// ---------------------------------------------------------------------------------------------
+struct WgS2Params {
+  const float* x;
+  const float* dy;
+  float* ws;
+  float* bias_partial;
+  int N, Cin, Cout, XH, XW, YH, YW;
+  int TH, TW, TWo, tiles_y, tiles_x, HH, TWp, CS, DS, ntiles, G, nks, nq;
+};
+constexpr int WS2_XB = 3;  // register batches of the X staging (4 pixels x 4 channels each) per thread and tile
+constexpr int WS2_YB = 2;  // ... of the dY staging (pixel pairs)
+
+__global__ __launch_bounds__(256, 2) void k_wgrad_s2(WgS2Params P) {
+  constexpr int CIB = 32, COB = 64, NTW = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+  __shared__ int oct_x[WB_MAXOCT], oct_y[WB_MAXOCT];
+  __shared__ float bred[256][4];
+  unsigned short* xs = smem16;                              // [2 planes][CIB][CS]: rows of E | O halves
+  unsigned short* ys = smem16 + (size_t)2 * CIB * P.CS;     // [2 planes][COB][DS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int cit = wave & 1, cow = wave >> 1;
+  const int cib = blockIdx.y * CIB, cob = blockIdx.z * COB;
+  const int ROW = 2 * P.TWp;
+  const int noct = P.TH * P.TWo;
+  for (int o = tid; o < P.nks * 4; o += 256) {
+    if (o < noct) {
+      const int orow = o / P.TWo, oc = o - orow * P.TWo;
+      oct_x[o] = (2 * orow) * ROW + oc * 8;
+      oct_y[o] = o * 8;
+    } else {  // K padding: multiply by the zero octet appended to every dY plane
+      oct_x[o] = 0;
+      oct_y[o] = P.TH * P.TW;
+    }
+  }
+  for (int e = tid; e < 2 * COB * 4; e += 256) {  // zero octets (never overwritten by the staging)
+    const int pc = e >> 2, w = e & 3;
+    reinterpret_cast<unsigned*>(ys + (size_t)pc * P.DS + P.TH * P.TW)[w] = 0u;
+  }
+  f32x4 acc[3][3][NTW];
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) acc[u][v][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = P.bias_partial != nullptr && blockIdx.y == 0;
+  const int tw2 = P.TW >> 1;
+  constexpr unsigned OOB = 0x80000000u;
+  const size_t ximg = (size_t)P.XH * P.XW * P.Cin, yimg = (size_t)P.YH * P.YW * P.Cout;
+
+  for (int tile = blockIdx.x; tile < P.ntiles; tile += P.G) {
+    int b = tile;
+    const int txi = b % P.tiles_x;
+    b /= P.tiles_x;
+    const int tyi = b % P.tiles_y;
+    const int n = b / P.tiles_y;
+    const int r0 = tyi * P.TH, c0 = txi * P.TW;
+    __syncthreads();  // previous tile fully consumed (tables / zero octets visible on the first pass)
+    {  // ---- X halo: rows 2 r0 - 1 + hy, columns 2 c0 - 1 + hx; item = (4 adjacent halo pixels, 4 channels)
+      const __amdgpu_buffer_rsrc_t rx = wb_rsrc(P.x + (size_t)n * ximg, (unsigned)(ximg * 4));
+      const int q = tid & 7, ch = cib + q * 4;
+      const int nitems = P.HH * P.nq;
+      const int by0 = 2 * r0 - 1, bx0 = 2 * c0 - 1;
+      f32x4 px[WS2_XB][4];
+#pragma unroll
+      for (int k = 0; k < WS2_XB; ++k) {
+        const int ip = (tid >> 3) + k * 32;
+        const int hy = ip / P.nq, j = ip - hy * P.nq;
+        const int iy = by0 + hy, ix = bx0 + 4 * j;
+        const int rowoff = ((iy * P.XW + ix) * P.Cin + ch) * 4;   // (rows above / below the image fall outside the descriptor)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = ip < nitems && (unsigned)iy < (unsigned)P.XH && (unsigned)(ix + e) < (unsigned)P.XW;
+          px[k][e] = wb_bload(rx, ok ? (unsigned)(rowoff + e * P.Cin * 4) : OOB);
+        }
+      }
+      unsigned short* xq = xs + (size_t)(q * 4) * P.CS;
+#pragma unroll
+      for (int k = 0; k < WS2_XB; ++k) {
+        const int ip = (tid >> 3) + k * 32;
+        if (ip < nitems) {
+          const int hy = ip / P.nq, j = ip - hy * P.nq;
+          unsigned hi[4], lo[4];
+          unsigned short* dst = xq + hy * ROW + 2 * j;
+          wb_split_pair(px[k][0], px[k][2], hi, lo);   // even halo columns 4 j, 4 j + 2 -> E[2 j], E[2 j + 1]
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            *reinterpret_cast<unsigned*>(dst + (size_t)c * P.CS) = hi[c];
+            *reinterpret_cast<unsigned*>(dst + (size_t)(CIB + c) * P.CS) = lo[c];
+          }
+          wb_split_pair(px[k][1], px[k][3], hi, lo);   // odd halo columns -> O[2 j], O[2 j + 1]
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            *reinterpret_cast<unsigned*>(dst + P.TWp + (size_t)c * P.CS) = hi[c];
+            *reinterpret_cast<unsigned*>(dst + P.TWp + (size_t)(CIB + c) * P.CS) = lo[c];
+          }
+        }
+      }
+    }
+    {  // ---- dY tile: rows [r0, +TH), cols [c0, +TW), channels [cob, +64) -> planes [co][r][c]
+      const __amdgpu_buffer_rsrc_t ry = wb_rsrc(P.dy + (size_t)n * yimg, (unsigned)(yimg * 4));
+      const int q = tid & 15, ch = cob + q * 4;
+      const int npairs = P.TH * tw2;
+      f32x4 p0[WS2_YB], p1[WS2_YB];
+#pragma unroll
+      for (int k = 0; k < WS2_YB; ++k) {
+        const int pp = (tid >> 4) + k * 16;
+        const int r = pp / tw2, c = (pp - r * tw2) * 2;
+        const int iy = r0 + r, ix = c0 + c;
+        const unsigned off = (unsigned)(((iy * P.YW + ix) * P.Cout + ch) * 4);
+        const bool rowok = pp < npairs && iy < P.YH;
+        p0[k] = wb_bload(ry, rowok && ix < P.YW ? off : OOB);
+        p1[k] = wb_bload(ry, rowok && ix + 1 < P.YW ? off + (unsigned)P.Cout * 4u : OOB);
+      }
+      unsigned short* yq = ys + (size_t)(q * 4) * P.DS;
+#pragma unroll
+      for (int k = 0; k < WS2_YB; ++k) {
+        const int pp = (tid >> 4) + k * 16;
+        if (pp < npairs) {
+          const int r = pp / tw2, c = (pp - r * tw2) * 2;
+          bsum += p0[k] + p1[k];
+          unsigned hi[4], lo[4];
+          wb_split_pair(p0[k], p1[k], hi, lo);
+          unsigned short* dst = yq + r * P.TW + c;
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            *reinterpret_cast<unsigned*>(dst + (size_t)cc * P.DS) = hi[cc];
+            *reinterpret_cast<unsigned*>(dst + (size_t)(COB + cc) * P.DS) = lo[cc];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- K loop: per K step the fragments of the three row shifts (E octet + next pair, O octet; both planes), then the
+    // MFMAs pass-major over the 3 * NTW accumulators of a row shift
+    const unsigned short* xa_h = xs + (size_t)(cit * 16 + i) * P.CS;
+    const unsigned short* xa_l = xa_h + (size_t)CIB * P.CS;
+    const unsigned short* yb_h = ys + (size_t)(cow * NTW * 16 + i) * P.DS;
+    const unsigned short* yb_l = yb_h + (size_t)COB * P.DS;
+    for (int ks = 0; ks < P.nks; ++ks) {
+      const int ox = oct_x[ks * 4 + kq], oy = oct_y[ks * 4 + kq];
+      uint4 bh[NTW], bl[NTW], eh4[3], el4[3], oh4[3], ol4[3];
+      unsigned eh[3], el[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int xo = ox + u * ROW;
+        eh4[u] = *reinterpret_cast<const uint4*>(xa_h + xo);
+        el4[u] = *reinterpret_cast<const uint4*>(xa_l + xo);
+        eh[u] = *reinterpret_cast<const unsigned*>(xa_h + xo + 8);
+        el[u] = *reinterpret_cast<const unsigned*>(xa_l + xo + 8);
+        oh4[u] = *reinterpret_cast<const uint4*>(xa_h + xo + P.TWp);
+        ol4[u] = *reinterpret_cast<const uint4*>(xa_l + xo + P.TWp);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        bh[nt] = *reinterpret_cast<const uint4*>(yb_h + (size_t)nt * 16 * P.DS + oy);
+        bl[nt] = *reinterpret_cast<const uint4*>(yb_l + (size_t)nt * 16 * P.DS + oy);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        uint4 ah[3], al[3];
+        ah[0] = eh4[u];
+        al[0] = el4[u];
+        ah[1] = oh4[u];
+        al[1] = ol4[u];
+        ah[2] = make_uint4(__builtin_amdgcn_alignbit(eh4[u].y, eh4[u].x, 16), __builtin_amdgcn_alignbit(eh4[u].z, eh4[u].y, 16),
+                           __builtin_amdgcn_alignbit(eh4[u].w, eh4[u].z, 16), __builtin_amdgcn_alignbit(eh[u], eh4[u].w, 16));
+        al[2] = make_uint4(__builtin_amdgcn_alignbit(el4[u].y, el4[u].x, 16), __builtin_amdgcn_alignbit(el4[u].z, el4[u].y, 16),
+                           __builtin_amdgcn_alignbit(el4[u].w, el4[u].z, 16), __builtin_amdgcn_alignbit(el[u], el4[u].w, 16));
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) acc[u][v][nt] = wb_mfma(al[v], bh[nt], acc[u][v][nt]);
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) acc[u][v][nt] = wb_mfma(ah[v], bl[nt], acc[u][v][nt]);
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) acc[u][v][nt] = wb_mfma(ah[v], bh[nt], acc[u][v][nt]);
+      }
+    }
+  }
+  if (want_bias) {  // column sums of dY: combine the threads that staged the same channel group
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bred[tid][e] = bsum[e];
+    __syncthreads();
+    if (tid < COB) {
+      const int q = tid >> 2, e = tid & 3;
+      float sacc = 0.f;
+      for (int t = q; t < 256; t += 16) sacc += bred[t][e];
+      P.bias_partial[(size_t)blockIdx.x * P.Cout + cob + tid] = sacc;
+    }
+  }
+  // partial slab ws[g][t][ci][co]; C/D layout: col = lane&15 (co), row = (lane>>4)*4 + reg (ci)
+  float* slab = P.ws + (size_t)blockIdx.x * 9 * P.Cin * P.Cout;
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const int t = u * 3 + v;
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int co = cob + (cow * NTW + nt) * 16 + i;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int ci = cib + cit * 16 + kq * 4 + reg;
+          slab[((size_t)t * P.Cin + ci) * P.Cout + co] = acc[u][v][nt][reg];
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Host
 // ---------------------------------------------------------------------------------------------
 static constexpr int kWbLdsBudget = 74 * 1024;  // + ~4.6 KB static (tables, bias reduction): 2 blocks per CU
@@ -862,6 +1093,98 @@ static size_t wb_ring_setup(const WbPlan& pl, bool spec, int prefetch, int& cs_r
   cs_ring = round_8odd(2 * pl.HH * pl.HWp);
   const size_t bytes = ((size_t)2 * pl.CIB * cs_ring + (size_t)2 * 2 * pl.COB * pl.DS) * 2;
   return bytes + 8 * 1024 <= 160 * 1024 ? bytes : 0;
+}
+
+// ---- stride-2 plan (k_wgrad_s2) ----
+struct Ws2Plan {
+  bool ok;
+  int TH, TW, TWo, tiles_y, tiles_x, HH, TWp, CS, DS, nks, nq, ntiles, G, gy, gz;
+  size_t lds;
+};
+
+static Ws2Plan ws2_plan(const srk_conv_desc& d) {
+  Ws2Plan pl{};
+  pl.ok = false;
+  if (env_int("SRK_WGRAD_S2", 1) == 0) return pl;
+  if (d.transposed || d.stride != 2 || d.KH != 3 || d.KW != 3 || d.pad != 1 || d.dy_ps_r > 1) return pl;
+  if (d.Cin % 32 != 0 || d.Cout % 64 != 0) return pl;
+  if ((long)d.H * d.W * d.Cin * 4 >= (1L << 31) || (long)d.OH * d.OW * d.Cout * 4 >= (1L << 31)) return pl;  // buffer descriptors
+  int best_px = 0;
+  for (int TWo = 1; TWo <= 4 && (TWo - 1) * 8 < d.OW; TWo *= 2) {
+    const int TW = TWo * 8;
+    int TH = 16 / TWo;
+    if (TH > d.OH) TH = d.OH;
+    for (; TH >= 1; --TH) {
+      const int HH = 2 * TH + 1, TWp = TW + 8;
+      const int CS = round_8odd(HH * 2 * TWp), DS = round_8odd(TH * TW + 8);
+      const size_t lds = ((size_t)2 * 32 * CS + (size_t)2 * 64 * DS) * 2;
+      const int nq = (2 * TW + 1 + 3) / 4;
+      if (lds > (size_t)kWbLdsBudget || HH * nq > 32 * WS2_XB || TH * (TW / 2) > 16 * WS2_YB || TH * TWo > WB_MAXOCT) continue;
+      // useful pixels per padded tile, then the larger tile
+      const double eff = (double)d.OH * d.OW / ((double)cdiv(d.OH, TH) * cdiv(d.OW, TW) * cdiv(TH * TWo, 4) * 32);
+      const int score = (int)(eff * 1000.0) * 1000 + TH * TW;
+      if (score > best_px) {
+        best_px = score;
+        pl.TH = TH; pl.TW = TW; pl.TWo = TWo; pl.HH = HH; pl.TWp = TWp; pl.CS = CS; pl.DS = DS; pl.lds = lds; pl.nq = nq;
+      }
+      break;
+    }
+  }
+  if (!best_px) return pl;
+  pl.tiles_x = cdiv(d.OW, pl.TW);
+  pl.tiles_y = cdiv(d.OH, pl.TH);
+  pl.nks = cdiv(pl.TH * pl.TWo, 4);
+  const long nt = (long)d.N * pl.tiles_y * pl.tiles_x;
+  if (nt > (1L << 30)) return pl;
+  pl.ntiles = (int)nt;
+  pl.gy = d.Cin / 32;
+  pl.gz = d.Cout / 64;
+  int g = (2 * kNumCU) / (pl.gy * pl.gz);
+  if (g < 1) g = 1;
+  pl.G = pl.ntiles < g ? pl.ntiles : g;
+  pl.ok = true;
+  return pl;
+}
+
+bool conv_wgrad_s2_supported(const srk_conv_desc& d, const float* x, const float* dy, const srk_bwd_mask* mask) {
+  if (mask && mask->y) return false;
+  if ((((uintptr_t)x | (uintptr_t)dy) & 15) != 0) return false;
+  return ws2_plan(d).ok;
+}
+
+size_t conv_wgrad_s2_ws(const srk_conv_desc& d) {
+  const Ws2Plan pl = ws2_plan(d);
+  if (!pl.ok) return 0;
+  return (size_t)pl.G * 9 * d.Cin * d.Cout * sizeof(float) + (size_t)pl.G * d.Cout * sizeof(float) + 256;
+}
+
+int conv_wgrad_s2(const srk_conv_desc& d, const float* x, const float* dy, float* dw, float* db, float beta, void* ws,
+                  size_t ws_bytes, hipStream_t s) {
+  const Ws2Plan pl = ws2_plan(d);
+  if (!pl.ok) {
+    set_error("conv_wgrad_s2: shape not covered");
+    return SRK_ERR_UNSUPPORTED;
+  }
+  if (ws_bytes < conv_wgrad_s2_ws(d)) {
+    set_error("conv_wgrad_s2: workspace too small (%zu < %zu)", ws_bytes, conv_wgrad_s2_ws(d));
+    return SRK_ERR_WORKSPACE;
+  }
+  const size_t slab_bytes = ((size_t)pl.G * 9 * d.Cin * d.Cout * sizeof(float) + 255) & ~(size_t)255;
+  WgS2Params P{};
+  P.x = x; P.dy = dy;
+  P.ws = static_cast<float*>(ws);
+  float* bias_ws = reinterpret_cast<float*>(static_cast<char*>(ws) + slab_bytes);
+  P.bias_partial = db ? bias_ws : nullptr;
+  P.N = d.N; P.Cin = d.Cin; P.Cout = d.Cout; P.XH = d.H; P.XW = d.W; P.YH = d.OH; P.YW = d.OW;
+  P.TH = pl.TH; P.TW = pl.TW; P.TWo = pl.TWo; P.tiles_y = pl.tiles_y; P.tiles_x = pl.tiles_x; P.HH = pl.HH; P.TWp = pl.TWp;
+  P.CS = pl.CS; P.DS = pl.DS; P.ntiles = pl.ntiles; P.G = pl.G; P.nks = pl.nks; P.nq = pl.nq;
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&k_wgrad_s2), pl.lds);
+  hipLaunchKernelGGL(k_wgrad_s2, dim3(pl.G, pl.gy, pl.gz), dim3(256), pl.lds, s, P);
+  const int rc = check_launch("conv_wgrad_s2");
+  if (rc) return rc;
+  return conv_wgrad_reduce_launch((const float*)ws, dw, pl.G, d.Cout, d.Cin, 3, 3, 0, beta, db ? bias_ws : nullptr, db, d.Cout,
+                                  0, s);
 }
 
 bool conv_wgrad_bf_supported(const srk_conv_desc& d) { return wb_plan(d).ok; }

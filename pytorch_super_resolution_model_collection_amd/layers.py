@@ -19,9 +19,10 @@ def bump_weight_epoch():
 
 
 def _single(v):
+    """Stride / padding / output_padding: one value for both axes (the C ABI's srk_conv_desc carries one of each)."""
     if isinstance(v, (tuple, list)):
         if len(set(v)) != 1:
-            raise NotImplementedError("only square kernels / isotropic stride & padding are supported, got %r" % (v,))
+            raise NotImplementedError("only isotropic stride / padding / output_padding are supported, got %r" % (v,))
         return int(v[0])
     return int(v)
 
@@ -72,7 +73,7 @@ class Conv2d(torch.nn.Conv2d):
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
         super(Conv2d, self).__init__(in_channels, out_channels, kernel_size, stride, padding, bias=bias)
-        self._k, self._s, self._p = _single(self.kernel_size), _single(self.stride), _single(self.padding)
+        self._s, self._p = _single(self.stride), _single(self.padding)   # (kernel_size may be (kh, kw): taken from the weight)
         self._cache = _PackCache()
 
     def run(self, x, act=ACT_NONE, slope=0.0, prelu_w=None, residual=None, ps_r=0, res_box=None, add_box=None):
@@ -95,7 +96,7 @@ class ConvTranspose2d(torch.nn.ConvTranspose2d):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, bias=True):
         super(ConvTranspose2d, self).__init__(in_channels, out_channels, kernel_size, stride, padding,
                                               output_padding, bias=bias)
-        self._k, self._s, self._p = _single(self.kernel_size), _single(self.stride), _single(self.padding)
+        self._s, self._p = _single(self.stride), _single(self.padding)   # (kernel_size may be (kh, kw): taken from the weight)
         self._op = _single(self.output_padding)
         self._cache = _PackCache()
 
@@ -167,6 +168,20 @@ class InstanceNorm2d(torch.nn.InstanceNorm2d):
         if x.dim() != 4 or x.shape[1] != self.num_features:
             raise RuntimeError("InstanceNorm2d(%d): bad input shape %s" % (self.num_features, tuple(x.shape)))
         return ops.instance_norm(x, self.eps)
+
+
+class InstanceNorm1d(torch.nn.InstanceNorm1d):
+    """torch.nn.InstanceNorm1d(F) with its defaults on the [B, F] output of a Linear (DenseBlock(norm='instance'),
+    base_networks.py:12-13).  torch reads a 2-D input as ONE unbatched sample of B channels x F positions: every row is
+    normalised with its own biased statistics; no parameters, no state_dict entries."""
+
+    def __init__(self, num_features):
+        super(InstanceNorm1d, self).__init__(num_features)
+
+    def forward(self, x):
+        if x.dim() != 2:
+            raise NotImplementedError("InstanceNorm1d is implemented for [B, F] inputs (DenseBlock); got %s" % (tuple(x.shape),))
+        return ops.row_norm(x, self.eps)
 
 
 class Linear(torch.nn.Linear):
@@ -246,7 +261,5 @@ def make_norm1d(norm, features):
     if norm == "batch":
         return BatchNorm1d(features)
     if norm == "instance":
-        # nn.InstanceNorm1d on a [B, F] tensor is ill-defined (modern torch reads it as one unbatched (C, L) sample)
-        raise NotImplementedError("DenseBlock(norm='instance'): InstanceNorm1d over a [B, F] activation is ill-defined "
-                                  "and unused by every reference net")
+        return InstanceNorm1d(features)
     return None

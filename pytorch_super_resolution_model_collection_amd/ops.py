@@ -1339,6 +1339,42 @@ def instance_norm(x, eps=1e-5):
     return _InstanceNorm.apply(x, float(eps))
 
 
+class _RowNorm(torch.autograd.Function):
+    """nn.InstanceNorm1d on a [B, F] activation (DenseBlock(norm='instance'), base_networks.py:12-13): every row normalised
+    with its own biased statistics (srk_rownorm_*)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        lib = _lib.load()
+        require_cuda(x)
+        x = x.contiguous()
+        rows, cols = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        check(lib.srk_rownorm_forward(ptr(x), ptr(y), ptr(mean), ptr(rstd), rows, cols, eps, stream_ptr()),
+              "srk_rownorm_forward")
+        ctx.save_for_backward(x, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        check(lib.srk_rownorm_backward(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(dx), x.shape[0], x.shape[1], stream_ptr()),
+              "srk_rownorm_backward")
+        return dx, None
+
+
+def row_norm(x, eps=1e-5):
+    """nn.InstanceNorm1d(F) with its defaults on a [B, F] tensor."""
+    if x.dim() != 2:
+        raise RuntimeError("row_norm expects a [B, F] tensor, got shape %s" % (tuple(x.shape),))
+    return _RowNorm.apply(x, float(eps))
+
+
 class _UpsampleNearest(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, r):

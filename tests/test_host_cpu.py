@@ -91,7 +91,8 @@ def test_block_variants_construct_like_the_reference(pkg):
              (B.ResnetBlock, R.ResnetBlock, (16,), dict(norm='instance')),
              (B.PSBlock, R.PSBlock, (8, 8, 2), dict(norm='instance')),
              (B.DenseBlock, R.DenseBlock, (24, 10), dict()),                       # default norm='batch' -> BatchNorm1d
-             (B.DenseBlock, R.DenseBlock, (24, 10), dict(activation='prelu', norm='batch'))]
+             (B.DenseBlock, R.DenseBlock, (24, 10), dict(activation='prelu', norm='batch')),
+             (B.DenseBlock, R.DenseBlock, (24, 10), dict(norm='instance'))]     # InstanceNorm1d on the [B, F] activation
     for ours, theirs, args, kw in cases:
         a, b = ours(*args, **kw), theirs(*args, **kw)
         sa, sb = a.state_dict(), b.state_dict()
@@ -102,8 +103,6 @@ def test_block_variants_construct_like_the_reference(pkg):
         a.load_state_dict(sb)
         for m in a.modules():          # the reference's initialiser walks every module by class name
             pkg.utils.weights_init_normal(m)
-    with pytest.raises(NotImplementedError):
-        B.DenseBlock(24, 10, norm='instance')   # InstanceNorm1d on [B, F] is ill-defined (see layers.make_norm1d)
     with pytest.raises(ValueError):
         B.Upsample2xBlock(8, 8, upsample='bogus')
 

@@ -540,6 +540,10 @@ def test_merged_slab_reductions_equal_per_group_reductions(gpu, kind):
         finally:
             ops.MERGE_REDUCES = prev
         torch.cuda.synchronize()
-        grads.append(flat.grad.clone())
-    assert float(grads[0].abs().max()) > 0
-    assert torch.equal(grads[0], grads[1])
+        grads.append({n: g.clone() for n, g in flat.named_grads().items()})
+    assert max(float(g.abs().max()) for g in grads[0].values()) > 0
+    for name, g in grads[0].items():
+        if "convt_I" in name:   # LapSRN's 3 -> 3 image deconvs run the shape-agnostic kernel, which sums with float atomics
+            assert rel_err(g, grads[1][name]) < 1e-5, name
+        else:
+            assert torch.equal(g, grads[1][name]), name
