@@ -232,7 +232,7 @@ def training_roofline(tag, px, layer_px_note, layers_per_step=1, steps=5):
              # residual blocks fused per tile (conv -> ReLU -> conv -> + skip in one launch): useful work of two layers
              ("fused_block_forward", ("k_res2<2, false", "k_res2<3, false"), 3 * t, "x, intermediate, y", 2.0),
              ("fused_block_data_gradient", ("k_res2<2, true",), 4 * t, "dy, saved intermediate, its gradient, dx", 2.0)]
-    if any("k_conv_bfw<2, 9, 2, false, false, true>" in r["Name"] for r in rows):
+    if any("k_conv_bfw<2, 9, 2, false, false, true" in r["Name"] for r in rows):
         # pre-masked gradients (ops.PREMASK): dy arrives already multiplied by this layer's ReLU gradient
         roles[2] = ("weight_gradient", ("k_wgrad_bf<2, 2, 2, true",), 2 * t, "x, dy (pre-masked by the data gradient above)", None)
     if any("k_res2<" in r["Name"] for r in rows):   # body layers run fused per block: no stand-alone forward / data gradient

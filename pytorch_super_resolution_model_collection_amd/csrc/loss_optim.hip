@@ -189,6 +189,50 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
   }
 }
 
+// 16-byte form of k_adam (n % 4 == 0, aligned buffers): the same operations per element, four elements per thread and
+// pass, and at most two blocks per CU -- the arrival ticket is one atomic per block on one word, and ~740 of them in the
+// scalar kernel's grid made the folded step counter cost what the separate launch had (EDSR: 19.4 vs 14.5 + 2.8 us).
+typedef float adam_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_adam4(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                               float* __restrict__ v, size_t n4, float lr, float b1, float b2, float eps,
+                                               float wd, int32_t* __restrict__ step_dev, const float* __restrict__ lr_dev,
+                                               const float* __restrict__ gs_dev) {
+  if (lr_dev) lr = *lr_dev;
+  const float gs = gs_dev ? *gs_dev : 1.f;
+  const int32_t t_i = __hip_atomic_load(step_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  const float t = (float)t_i;
+  const float bc1 = 1.f - powf(b1, t);
+  const float bc2 = 1.f - powf(b2, t);
+  const float step_size = lr / bc1;
+  const float bc2_sqrt = sqrtf(bc2);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    adam_f4 pi = reinterpret_cast<const adam_f4*>(p)[i];
+    const adam_f4 gi4 = reinterpret_cast<const adam_f4*>(g)[i];
+    adam_f4 mi = reinterpret_cast<const adam_f4*>(m)[i];
+    adam_f4 vi = reinterpret_cast<const adam_f4*>(v)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gi = gi4[e] * gs;
+      if (wd != 0.f) gi += wd * pi[e];
+      mi[e] = mi[e] + (1.f - b1) * (gi - mi[e]);
+      vi[e] = vi[e] * b2 + (1.f - b2) * gi * gi;
+      const float denom = sqrtf(vi[e]) / bc2_sqrt + eps;
+      pi[e] = pi[e] - step_size * (mi[e] / denom);
+    }
+    reinterpret_cast<adam_f4*>(m)[i] = mi;
+    reinterpret_cast<adam_f4*>(v)[i] = vi;
+    reinterpret_cast<adam_f4*>(p)[i] = pi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int32_t arrived = atomicAdd(step_dev + 1, 1);
+    if (arrived == (int32_t)gridDim.x - 1) {
+      __hip_atomic_store(step_dev, t_i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(step_dev + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_sqsum_partial(const float* __restrict__ g, size_t n,
                                                        double* __restrict__ partials) {
   __shared__ double sm[4];
@@ -284,6 +328,14 @@ extern "C" int srk_adam_step(float* p, const float* g, float* exp_avg, float* ex
                              const float* lr_dev, const float* grad_scale_dev, void* stream) {
   SRK_REQUIRE(p && g && exp_avg && exp_avg_sq && step_dev && n > 0, "adam_step: null pointer or empty");
   hipStream_t s = (hipStream_t)stream;
+  if (n % 4 == 0 && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0) {
+    size_t nb = (n / 4 + 256 * 2 - 1) / (256 * 2);
+    const size_t cap = (size_t)2 * kNumCU;
+    if (nb > cap) nb = cap;
+    hipLaunchKernelGGL(k_adam4, dim3((unsigned)nb), dim3(256), 0, s, p, g, exp_avg, exp_avg_sq, n / 4, lr, beta1, beta2, eps,
+                       weight_decay, step_dev, lr_dev, grad_scale_dev);
+    return check_launch("adam_step");
+  }
   hipLaunchKernelGGL(k_adam, dim3(red_grid(n)), dim3(256), 0, s, p, g, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
                      weight_decay, step_dev, lr_dev, grad_scale_dev);
   return check_launch("adam_step");

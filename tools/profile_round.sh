@@ -5,7 +5,7 @@
 #   3. the same for one EDSR x4 training step (c4) so the train-path kernels are on record as well
 # Output: gpurun_out/prof_<tag>/...; tools/summarize_prof.py turns it into profiles/<tag>_*.{csv,json}.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -18,6 +18,9 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/c2_fetch -o c2 -- $C2 > $
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/c2_write -o c2 -- $C2 > $OUT/c2_write.log 2>&1
 # matrix-core and LDS activity of the same command (SQ counters share a pass: 8 SQ slots)
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/c2_sq -o c2 -- $C2 > $OUT/c2_sq.log 2>&1
+# round 4: wave states and LDS issue of the same command (two passes: 8 SQ counter slots each)
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/c2_stall1 -o c2 -- $C2 > $OUT/c2_stall1.log 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_MFMA_MOPS_F16 --output-format csv -d $OUT/c2_stall2 -o c2 -- $C2 > $OUT/c2_stall2.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_kt -o c4 -- $C4 > $OUT/c4_kt.log 2>&1
 # the other training configs: c3 (VDSR, batch 256), c5 (SRGAN adversarial step), and the 16-patch EDSR shard that bounds
 # 8-GPU strong scaling (kernel traces only)
@@ -34,6 +37,8 @@ for WL in c3 c4 c4s16; do
   timeout 600 rocprofv3 --pmc $SQ --output-format csv -d $OUT/${WL}_sq -o $WL -- $CMD > $OUT/${WL}_sq.log 2>&1
 done
 timeout 600 rocprofv3 --pmc $SQ --output-format csv -d $OUT/c5_sq -o c5 -- python $ROOT/tools/srgan_step.py 16 > $OUT/c5_sq.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/c5_fetch -o c5 -- python $ROOT/tools/srgan_step.py 16 > $OUT/c5_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/c5_write -o c5 -- python $ROOT/tools/srgan_step.py 16 > $OUT/c5_write.log 2>&1
 # raw counter CSVs are large: keep only the reduced files
 cd $ROOT
 python tools/summarize_prof.py $TAG > $OUT/summary.log 2>&1

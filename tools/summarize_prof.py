@@ -80,7 +80,7 @@ def traffic_and_mfma(wl):
                       "v_mfma_f32_16x16x32_bf16 summed over all SIMDs (checked against the instruction count of the layer)",
               "kernels": {}}
     for k in sorted(set().union(*[set(v) for v in sq.values()])):
-        if "srk::k_conv" not in k and "srk::k_wgrad" not in k and "srk::k_res2" not in k:
+        if "srk::k_conv" not in k and "srk::k_wgrad" not in k and "srk::k_res2" not in k and "srk::k_c64" not in k:
             continue
         rec = {n: round(sq[n].get(k, (0.0, 0))[0], 1) for n in SQ_NAMES}
         rec["launches"] = max(sq[n].get(k, (0.0, 0))[1] for n in SQ_NAMES)
@@ -95,3 +95,34 @@ def traffic_and_mfma(wl):
 
 for wl in ("c2", "c3", "c4", "c4s16", "c5"):
     traffic_and_mfma(wl)
+
+
+# round 4: wave-state / LDS-issue counters of the c2 kernels (what holds k_conv_bfw at 3.2 - 3.7 TB/s of mixed traffic)
+STALL_NAMES = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS",
+               "SQ_WAIT_INST_LDS", "SQ_INST_CYCLES_VMEM", "SQ_INSTS_VALU", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_VALU_MFMA_MOPS_F16",
+               "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"]
+st = {}
+for sub in ("c2_stall1", "c2_stall2"):
+    for n in STALL_NAMES:
+        m = counter_means(sub, n)
+        if m:
+            st[n] = m
+if st:
+    out = {"source": "rocprofv3 --pmc <counters below, two passes> over `%s`" % COMMANDS["c2"],
+           "note": "per-launch means summed over all waves / SIMDs; SQ_WAVE_CYCLES = wave-resident cycles, SQ_WAIT_ANY = cycles a "
+                   "wave waits on any s_waitcnt, SQ_ACTIVE_INST_LDS / SQ_WAIT_INST_LDS = cycles LDS instructions execute / wait "
+                   "to issue; fractions are relative to SQ_WAVE_CYCLES", "kernels": {}}
+    for k in sorted(set().union(*[set(v) for v in st.values()])):
+        if "srk::k_conv" not in k:
+            continue
+        rec = {n: round(st[n].get(k, (0.0, 0))[0], 1) for n in STALL_NAMES if n in st}
+        wc = rec.get("SQ_WAVE_CYCLES", 0.0)
+        if wc > 0:
+            for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VALU"):
+                if n in rec:
+                    rec[n + "_frac"] = round(rec[n] / wc, 4)
+        out["kernels"][k] = rec
+    with open(os.path.join(dst, "%s_c2_pmc_stalls.json" % tag), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("wrote %s_c2_pmc_stalls.json (%d kernels)" % (tag, len(out["kernels"])))
+
