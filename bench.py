@@ -362,7 +362,7 @@ ARITHMETIC = {
           "(body-end, up-sampler, reconstruction convs); data and weight gradients %s; Adam in fp32",
     "c4_shard16": "as c4; at 16 patches the small-problem forward convs outside the fused blocks run bf16x6 (6 MFMAs)",
     "c5": "fp32 storage / accumulation; forward bf16x6 (small 3x3 problems) / f16x3 (large discriminator layers), data and "
-          "weight gradients %s (stride-2 weight gradients: see c5_notes), BatchNorm statistics in double"}
+          "weight gradients %s (incl. the stride-2 convs: k_wgrad_s2), BatchNorm statistics in double"}
 
 
 PROGRESS = {"section": "start", "since": 0.0}   # which side metric is running (read by the watchdog)

@@ -59,6 +59,8 @@ struct WgBfParams {
   int dbg;  // ablation (SRK_DBG): 2 skip the staging, 4 skip the K loop
   int dy_ps_r, dy_ps_C;  // dY handed over pixel-shuffled [N, YH*r, YW*r, Cout/r^2]: un-shuffled while staging
   int prefetch;          // SPEC: a tile's loads fit the stagers' register batch (WB_PIT x 512 items): load one tile ahead
+  long long* prof;       // experiments build only (srk_debug_wgrad_prof): per block 16 int64 -- clock64() sums of the first stager
+                         // wave {commit, issue, barrier wait, tiles} and of worker wave 0 {K loop, barrier wait, tiles, K steps}
   int ring;              // SPEC + prefetch: X halo rows live in a ring of 2 * HH rows shared by vertically adjacent tiles
                          // (a block walks a CONTIGUOUS range of tiles, rows fastest): a tile below its predecessor loads
                          // only its TH new rows instead of all TH + KH - 1 (2-row tiles: the X read halves).  CS is then
@@ -98,6 +100,13 @@ struct WgOut {
 struct WgGroupOut {
   WgOut L[WB_MAXGROUP];
 };
+
+#ifdef SRK_EXPERIMENTS
+#define WB_CLK() clock64()
+static long long* g_wb_prof = nullptr;
+#else
+#define WB_CLK() 0ll
+#endif
 
 __device__ __forceinline__ f32x4 wb_mfma(const uint4& a, const uint4& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
@@ -177,11 +186,19 @@ __device__ __forceinline__ f32x4 wb_load4(const float* __restrict__ src, const f
 // issued together and the 27 * NTW MFMAs follow without control flow in between (the generic loop reads each row shift's
 // fragments right in front of its MFMAs, behind a branch: two exposed LDS round trips per 18 MFMAs).
 template <int CIT, int COW, int NTW, bool SPEC, bool GRP, bool K33 = false>
-__global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 256 : 2) void k_wgrad_bf(WgBfParams P,
+__global__ __launch_bounds__(SPEC ? 64 * CIT * COW + WB_SST : 64 * CIT * COW,
+                                 SPEC ? (64 * CIT * COW + WB_SST) / 256 : (CIT * COW == 4 ? 2 : 1)) void k_wgrad_bf(WgBfParams P,
                                                                              typename WgGroupArg<GRP>::type GR) {
   constexpr int CIB = CIT * 16, COB = COW * NTW * 16;
-  constexpr int NTHR = SPEC ? 256 + WB_SST : 256;
-  constexpr int NST = SPEC ? WB_SST : 256;  // staging threads (SPEC: 8 stager waves keep the staging rate of two 256-thread blocks)
+  // NWV working waves: 4.  (Round 4, tools/wgrad_prof.py: the worker wave's K loop is 97 % of its time and ~2080 clocks per K
+  // step for ~920 clocks of MFMA issue, while the stagers wait 30 - 49 % of a tile at the barrier -- the workers pace the kernel.
+  // EIGHT working waves (<2, 4, 1>: two per SIMD taking turns at the matrix pipe, 104 VGPRs, -DSRK_EXPERIMENTS + SRK_WG_W8=1)
+  // were measured SLOWER: VDSR layer 0.154 -> 0.184 ms, step 6.00 -> 6.62 ms, EDSR 6.07 -> 6.42 ms.  They read 1.75x the LDS
+  // bytes per K step (every X fragment once per output-channel column): the shared LDS pipe -- fragment reads against the
+  // stagers' 4-byte transposing writes -- is what the K loop waits for, not latency a second wave could hide.)
+  constexpr int NWV = CIT * COW, WTHR = 64 * NWV;
+  constexpr int NTHR = SPEC ? WTHR + WB_SST : WTHR;
+  constexpr int NST = SPEC ? WB_SST : WTHR;  // staging threads (SPEC: 8 stager waves keep the staging rate of two 256-thread blocks)
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
   __shared__ int oct_x[WB_MAXOCT], oct_y[WB_MAXOCT], oct_r[WB_MAXOCT], oct_c[WB_MAXOCT];
   __shared__ float bred[NST][4];
@@ -201,11 +218,11 @@ __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 
     return b >= R2 ? b - R2 : b;
   };
   const int tid0 = threadIdx.x, lane = tid0 & 63, wave = tid0 >> 6;
-  const bool stager = !SPEC || wave >= 4;    // stages tiles
-  const bool worker = !SPEC || wave < 4;     // runs the K loop, owns accumulators
-  const int tid = SPEC ? (wave >= 4 ? tid0 - 256 : tid0) : tid0;  // index among the staging threads (stagers) / working threads
+  const bool stager = !SPEC || wave >= NWV;    // stages tiles
+  const bool worker = !SPEC || wave < NWV;     // runs the K loop, owns accumulators
+  const int tid = SPEC ? (wave >= NWV ? tid0 - WTHR : tid0) : tid0;  // index among the staging threads (stagers) / working threads
   const int i = lane & 15, kq = lane >> 4;
-  const int cit = (wave & 3) % CIT, cow = (wave & 3) / CIT;
+  const int cit = (wave % NWV) % CIT, cow = (wave % NWV) / CIT;
   // (slab index, input-channel chunk) of this block.  The gy = 2 blocks that share a slab index read the SAME dY / mask
   // tiles in the same order: place them on one XCD (workgroups are dealt round-robin over the 8 XCDs in dispatch order)
   // so that the second reader hits that XCD's L2 instead of HBM — the weight gradient moves ~3.5 TB/s, it is bound by
@@ -566,9 +583,22 @@ __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 
     const unsigned short* yb_h = ys + (size_t)(cow * NTW * 16 + i) * P.DS;
     const unsigned short* yb_l = yb_h + (size_t)COB * P.DS;
     if constexpr (K33) {
-      for (int ks = 0; ks < ((P.dbg & 4) ? 0 : P.nks); ++ks) {
-        const int ox = oct_x[ks * 4 + kq], oy = oct_y[ks * 4 + kq];
-        const int orw = ring ? rbase + oct_r[ks * 4 + kq] : 0, ocl = ring ? oct_c[ks * 4 + kq] : 0;
+      // (round 4: the octet tables of K step ks + 1 are read while step ks multiplies -- the lookups were a dependent LDS
+      //  round trip in front of every K step's fragment reads, with one working wave per SIMD and nothing to hide it)
+      const int nks_run = (P.dbg & 4) ? 0 : P.nks;
+      int ox_n = oct_x[kq], oy_n = oct_y[kq], or_n = ring ? oct_r[kq] : 0, oc_n = ring ? oct_c[kq] : 0;
+      for (int ks = 0; ks < nks_run; ++ks) {
+        const int ox = ox_n, oy = oy_n;
+        const int orw = ring ? rbase + or_n : 0, ocl = oc_n;
+        {
+          const int nx = (ks + 1 < nks_run ? ks + 1 : ks) * 4 + kq;
+          ox_n = oct_x[nx];
+          oy_n = oct_y[nx];
+          if (ring) {
+            or_n = oct_r[nx];
+            oc_n = oct_c[nx];
+          }
+        }
         uint4 bh[NTW], bl[NTW], qh[3], ql[3];
         unsigned eh[3], el[3];
 #pragma unroll
@@ -593,6 +623,11 @@ __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 
         for (int u = 0; u < 3; ++u) {
           // the three column shifts of this row, then pass-major over its 3 * NTW accumulators: two MFMAs on one
           // accumulator are 3 * NTW issues apart (back to back they wait for each other's result)
+          // (Round 4, tools/wgrad_prof.py: the WORKER wave, not the stagers, paces this kernel -- K loop 97 % of its time,
+          //  ~2080 clocks per K step for 54 MFMAs, while the first stager wave waits 30 - 49 % of a tile at the barrier.  The
+          //  compiler sinks two fragment reads into the MFMA stream and threads the 24 v_perm of the column shifts between the
+          //  matrix instructions; scheduling fences that force "all reads, 8 v_perm, 18 MFMAs" per row shift (168 VGPRs) were
+          //  measured SLOWER: VDSR layer 0.157 -> 0.172 ms, step 6.30 -> 6.93 ms.  Not kept.)
           uint4 ah[3], al[3];
           ah[0] = qh[u];
           al[0] = ql[u];
@@ -698,11 +733,25 @@ __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 
           if (ntb > 1) issue(first_tile + tstep, 1);
         }
         __syncthreads();
+        long long st_commit = 0, st_issue = 0, st_wait = 0;
         for (int it = 0; it < ntb; ++it) {
+          const long long c0 = WB_CLK();
           if (it + 1 < ntb) commit((it + 1) & 1);        // tile it+1: its loads were issued an iteration ago
+          const long long c1 = WB_CLK();
           if (it + 2 < ntb) issue(first_tile + (it + 2) * tstep, it + 2);  // tile it+2: lands under the K loop of tile it+1
+          const long long c2 = WB_CLK();
           __syncthreads();
+          st_commit += c1 - c0;
+          st_issue += c2 - c1;
+          st_wait += WB_CLK() - c2;
         }
+#ifdef SRK_EXPERIMENTS
+        if (P.prof && tid0 == WTHR) {
+          long long* pr = P.prof + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16;
+          pr[0] = st_commit; pr[1] = st_issue; pr[2] = st_wait; pr[3] = ntb;
+        }
+#endif
+        (void)st_commit; (void)st_issue; (void)st_wait;
       } else {
         if (ntb > 0) stage(bx, 0);     // (no ring without the prefetch path: the host never sets both)
         __syncthreads();
@@ -714,11 +763,23 @@ __global__ __launch_bounds__(SPEC ? 256 + WB_SST : 256, SPEC ? (256 + WB_SST) / 
     } else {
       __syncthreads();
       int wprev = P.HH;
+      long long wk_loop = 0, wk_wait = 0;
       for (int it = 0; it < ntb; ++it) {
+        const long long k0 = WB_CLK();
         if (ring) wprev = ring_next(wprev, it == 0 || ((first_tile + it) % P.tiles_y) == 0);
         kloop(it & 1, wprev);
+        const long long k1 = WB_CLK();
         __syncthreads();
+        wk_loop += k1 - k0;
+        wk_wait += WB_CLK() - k1;
       }
+#ifdef SRK_EXPERIMENTS
+      if (P.prof && tid0 == 0) {
+        long long* pr = P.prof + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + 8;
+        pr[0] = wk_loop; pr[1] = wk_wait; pr[2] = ntb; pr[3] = (long long)ntb * P.nks;
+      }
+#endif
+      (void)wk_loop; (void)wk_wait;
     }
   }
 
@@ -1205,18 +1266,18 @@ static void wb_launch(const WgBfParams& P, dim3 grid, size_t lds, bool spec, hip
   if (spec && wb_k33(P)) {
     static LdsLimit lim3;
     lim3.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, true, false, true>), 2 * lds);
-    hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, true, false, true>), grid, dim3(256 + WB_SST), 2 * lds, s, P, WgNoGroup{0});
+    hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, true, false, true>), grid, dim3(64 * CIT * COW + WB_SST), 2 * lds, s, P, WgNoGroup{0});
     return;
   }
   if (spec) {
     static LdsLimit lim2;
     lim2.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, true, false>), 2 * lds);
-    hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, true, false>), grid, dim3(256 + WB_SST), 2 * lds, s, P, WgNoGroup{0});
+    hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, true, false>), grid, dim3(64 * CIT * COW + WB_SST), 2 * lds, s, P, WgNoGroup{0});
     return;
   }
   static LdsLimit lim;
   lim.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, false, false>), lds);
-  hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, false, false>), grid, dim3(256), lds, s, P, WgNoGroup{0});
+  hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, false, false>), grid, dim3(64 * CIT * COW), lds, s, P, WgNoGroup{0});
 }
 
 template <int CIT, int COW, int NTW>
@@ -1224,18 +1285,18 @@ static void wb_launch_grouped(const WgBfParams& P, const WgGroup& GR, dim3 grid,
   if (spec && wb_k33(P)) {
     static LdsLimit lim3;
     lim3.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, true, true, true>), 2 * lds);
-    hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, true, true, true>), grid, dim3(256 + WB_SST), 2 * lds, s, P, GR);
+    hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, true, true, true>), grid, dim3(64 * CIT * COW + WB_SST), 2 * lds, s, P, GR);
     return;
   }
   if (spec) {
     static LdsLimit lim2;
     lim2.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, true, true>), 2 * lds);
-    hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, true, true>), grid, dim3(256 + WB_SST), 2 * lds, s, P, GR);
+    hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, true, true>), grid, dim3(64 * CIT * COW + WB_SST), 2 * lds, s, P, GR);
     return;
   }
   static LdsLimit lim;
   lim.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, false, true>), lds);
-  hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, false, true>), grid, dim3(256), lds, s, P, GR);
+  hipLaunchKernelGGL((k_wgrad_bf<CIT, COW, NTW, false, true>), grid, dim3(64 * CIT * COW), lds, s, P, GR);
 }
 
 // dw_l (torch layout [co][ci][kh][kw]) = beta*dw_l + sum_g ws[l][g][t][ci][co] and db_l likewise, for every layer of
@@ -1351,13 +1412,22 @@ int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const
   {
     const int dbg = SRK_EXP_INT("SRK_DBG", 0);
     P.dbg = dbg;
+#ifdef SRK_EXPERIMENTS
+    P.prof = g_wb_prof;
+#endif
     if (dbg & 32)
       fprintf(stderr, "[srk] k_wgrad_bf cfg %d%s%s: tile %d x %d (%d K steps), %d tiles over %d x %d x %d blocks, lds %zu B\n",
               pl.cfg, spec ? " (wave-specialised)" : "", P.ring ? " (X ring)" : "", pl.TH, pl.TW, pl.nks, pl.ntiles, G, pl.gy,
               pl.gz, spec ? 2 * lds_half : pl.lds);
   }
   switch (pl.cfg) {
-    case 0: wb_launch<2, 2, 2>(P, grid, lds_half, spec, s); break;
+    case 0:
+#ifdef SRK_EXPERIMENTS
+      // experiment (SRK_WG_W8=1): eight working waves (2 ci tiles x 4 single-tile co columns) -- measured SLOWER: see k_wgrad_bf
+      if (spec && wb_k33(P) && SRK_EXP_INT("SRK_WG_W8", 0)) { wb_launch<2, 4, 1>(P, grid, lds_half, spec, s); break; }
+#endif
+      wb_launch<2, 2, 2>(P, grid, lds_half, spec, s);
+      break;
     case 1: wb_launch<4, 1, 2>(P, grid, lds_half, spec, s); break;
     default: wb_launch<4, 1, 1>(P, grid, lds_half, spec, s); break;
   }
@@ -1454,6 +1524,9 @@ int conv_wgrad_bf_grouped(const srk_conv_desc& d, int n, const float* const* xs,
   {
     const int dbg = SRK_EXP_INT("SRK_DBG", 0);
     P.dbg = dbg;
+#ifdef SRK_EXPERIMENTS
+    P.prof = g_wb_prof;
+#endif
     if (dbg & 32)
       fprintf(stderr, "[srk] k_wgrad_bf grouped cfg %d%s: %d layers x %d slabs, tile %d x %d, %d tiles per layer, grid %d x %d x %d\n",
               pl.cfg, spec ? " (wave-specialised)" : "", n, G, pl.TH, pl.TW, pl.ntiles, n * G, pl.gy, pl.gz);
@@ -1470,7 +1543,12 @@ int conv_wgrad_bf_grouped(const srk_conv_desc& d, int n, const float* const* xs,
     }
   }
   switch (pl.cfg) {
-    case 0: wb_launch_grouped<2, 2, 2>(P, GR, grid, lds_half, spec, s); break;
+    case 0:
+#ifdef SRK_EXPERIMENTS
+      if (spec && wb_k33(P) && SRK_EXP_INT("SRK_WG_W8", 0)) { wb_launch_grouped<2, 4, 1>(P, GR, grid, lds_half, spec, s); break; }
+#endif
+      wb_launch_grouped<2, 2, 2>(P, GR, grid, lds_half, spec, s);
+      break;
     case 1: wb_launch_grouped<4, 1, 2>(P, GR, grid, lds_half, spec, s); break;
     default: wb_launch_grouped<4, 1, 1>(P, GR, grid, lds_half, spec, s); break;
   }
@@ -1493,3 +1571,9 @@ int conv_wgrad_bf_grouped(const srk_conv_desc& d, int n, const float* const* xs,
 }
 
 }  // namespace srk
+
+#ifdef SRK_EXPERIMENTS
+// experiments build only: device buffer of 16 int64 per block for the role-time sums of the next k_wgrad_bf launches
+extern "C" void srk_debug_wgrad_prof(void* p) { srk::g_wb_prof = static_cast<long long*>(p); }
+#endif
+
