@@ -40,6 +40,25 @@ int wgrad_reduce_submit(bool wide, const float* ws, float* dw, int G, int Cout, 
 constexpr int WB_MAXOCT = 64;  // octets per tile (<= 512 pixels)
 constexpr int WB_SST = 512;    // SPEC: staging threads (8 waves next to the 4 working waves; 4 stager waves: 0.157 -> 0.20 ms on the VDSR layer)
 constexpr int WB_PIT = 1024 / WB_SST;  // SPEC stagers: register batches per tensor and tile when prefetching one tile ahead
+// Staging-thread -> (channel group q, first pixel pair) map.  A wave covers 4 channel groups x 16 consecutive pixel pairs:
+// its transposing 4-byte LDS stores then fall on 4 x 16 distinct banks (channel-group stride = 16 * odd dwords, pixel pairs =
+// consecutive dwords).  The round-1 map (q fastest: 16 groups x 4 pairs per wave for a 64-channel tensor) put 4 lanes on
+// every bank it touched.  QN = channel groups of the staged tensor, NSTT = staging threads (a multiple of 16 * QN).
+#ifndef WB_CF_MAP
+#define WB_CF_MAP 1
+#endif
+template <int QN, int NSTT>
+__device__ __forceinline__ void wb_item(int tid, int& q, int& pp0) {
+  if (WB_CF_MAP) {
+    constexpr int QB = QN / 4;  // 4-group blocks
+    const int w = tid >> 6, l = tid & 63;
+    q = (w % QB) * 4 + (l >> 4);
+    pp0 = (w / QB) * 16 + (l & 15);
+  } else {
+    q = tid % QN;
+    pp0 = tid / QN;
+  }
+}
 constexpr int WB_IT = 1;       // pixel pairs per thread loaded together while staging (4 measured: no gain plain, spills in the specialised variant)
 
 struct WgBfParams {
@@ -302,13 +321,15 @@ __global__ __launch_bounds__(SPEC ? 64 * CIT * COW + WB_SST : 64 * CIT * COW,
       const unsigned need2_magic = wb_magic20(need2);
       const int npairs = P.HH * need2;
       const int by0 = r0 - P.pad, bx0 = c0 - P.pad;
-      const int q = tid % QN, ch = cib + q * 4;
+      int q, ppb;
+      wb_item<QN, NST>(tid, q, ppb);
+      const int ch = cib + q * 4;
       const int nch = P.Cin - ch;  // channels of this group that exist (<= 0: none)
       const float* __restrict__ xb = Lx + (size_t)n * P.XH * P.XW * P.Cin;  // wave-uniform image base
       unsigned short* xq = xs + (size_t)(q * 4) * P.CS;
       // batches of WB_IT pixel pairs per thread: every global load of a batch is issued before the first conversion
       // (one exposed load latency per batch instead of one per pair)
-      for (int pp0 = tid / QN; pp0 < npairs; pp0 += PSTEP * WB_IT) {
+      for (int pp0 = ppb; pp0 < npairs; pp0 += PSTEP * WB_IT) {
         f32x4 p0[WB_IT], p1[WB_IT];
 #pragma unroll
         for (int k = 0; k < WB_IT; ++k) {
@@ -342,7 +363,9 @@ __global__ __launch_bounds__(SPEC ? 64 * CIT * COW + WB_SST : 64 * CIT * COW,
       constexpr int QN = COB / 4, PSTEP = NST / QN;
       const unsigned tw2_magic = wb_magic20(tw2);
       const int npairs = P.TH * tw2;
-      const int q = tid % QN, ch = cob + q * 4;
+      int q, ppb;
+      wb_item<QN, NST>(tid, q, ppb);
+      const int ch = cob + q * 4;
       const int nch = P.Cout - ch;
       // element strides of (row, col) and the channel-group offset inside a pixel; pixel-shuffled dY: packed channel
       // (i, j, c) of pixel (y, x) lives at (y*r + i, x*r + j, c) of the [N, YH*r, YW*r, C] tensor
@@ -364,7 +387,7 @@ __global__ __launch_bounds__(SPEC ? 64 * CIT * COW + WB_SST : 64 * CIT * COW,
       const float* __restrict__ yb = Ldy + img;
       const float* __restrict__ mb = Lmask ? Lmask + img : nullptr;
       unsigned short* yq = ys + (size_t)(q * 4) * P.DS;
-      for (int pp0 = tid / QN; pp0 < npairs; pp0 += PSTEP * WB_IT) {
+      for (int pp0 = ppb; pp0 < npairs; pp0 += PSTEP * WB_IT) {
         f32x4 p0[WB_IT], p1[WB_IT];
 #pragma unroll
         for (int k = 0; k < WB_IT; ++k) {
@@ -449,10 +472,12 @@ __global__ __launch_bounds__(SPEC ? 64 * CIT * COW + WB_SST : 64 * CIT * COW,
         constexpr int QN = CIB / 4, PSTEP = NST / QN;
         const int need2 = (P.TW + P.KW) >> 1;
         const int npairs = P.HH * need2;
-        const int q = tid % QN, ch = cib + q * 4;
+        int q, ppb;
+        wb_item<QN, NST>(tid, q, ppb);
+        const int ch = cib + q * 4;
 #pragma unroll
         for (int k = 0; k < WB_PIT; ++k) {
-          const int pp = tid / QN + k * PSTEP;
+          const int pp = ppb + k * PSTEP;
           const int hy = pp / need2, hx = (pp - hy * need2) * 2;
           const bool act = pp < npairs && ch < P.Cin;
           x_rel[k] = ((hy * P.XW + hx) * P.Cin + ch) * 4;
@@ -465,12 +490,14 @@ __global__ __launch_bounds__(SPEC ? 64 * CIT * COW + WB_SST : 64 * CIT * COW,
       {
         constexpr int QN = COB / 4, PSTEP = NST / QN;
         const int npairs = P.TH * tw2;
-        const int q = tid % QN, ch = cob + q * 4;
+        int q, ppb;
+        wb_item<QN, NST>(tid, q, ppb);
+        const int ch = cob + q * 4;
         unsigned koff;
         dy_strides(ch, y_srow, y_scol, koff);
 #pragma unroll
         for (int k = 0; k < WB_PIT; ++k) {
-          const int pp = tid / QN + k * PSTEP;
+          const int pp = ppb + k * PSTEP;
           const int r = pp / tw2, c = (pp - r * tw2) * 2;
           const bool act = pp < npairs && ch < P.Cout;
           y_rel[k] = (int)(((unsigned)r * y_srow + (unsigned)c * y_scol + koff) * 4u);
@@ -794,7 +821,12 @@ __global__ __launch_bounds__(SPEC ? 64 * CIT * COW + WB_SST : 64 * CIT * COW,
     if (stager && tid < COB && cob + tid < P.Cout) {
       const int q = tid >> 2, e = tid & 3;
       float s = 0.f;
-      for (int t = q; t < NST; t += QN) s += bred[t][e];
+      if (WB_CF_MAP) {   // the staging threads of channel group q: lanes 16 (q % 4) .. + 15 of waves q / 4, q / 4 + QN / 4, ...
+        for (int w = q >> 2; w < NST / 64; w += QN / 4)
+          for (int jj = 0; jj < 16; ++jj) s += bred[w * 64 + (q & 3) * 16 + jj][e];
+      } else {
+        for (int t = q; t < NST; t += QN) s += bred[t][e];
+      }
       P.bias_partial[(size_t)bxl * P.Cout + cob + tid] = s;
     }
   }
