@@ -29,27 +29,62 @@ constexpr int R2_C = 64;       // channels in = mid = out
 constexpr int R2_TS = 8;       // output tile width (and the height of the standard tile)
 constexpr int R2_H1 = 12;      // input halo width (tile + 2 + 2)
 constexpr int R2_MW = 10;      // mid region width (tile + 1 + 1)
-// Tile = TH rows x 8 columns.  TH = 8: the standard tile (12 x 12 input halo, 10 x 10 intermediate in 7 MFMA row tiles).
-// TH = 4 (round 4 experiment, compiled with -DSRK_EXPERIMENTS only): a problem that leaves a CU with ONE 8 x 8 tile (the
-// 16-patch EDSR shard of 8-GPU strong scaling: 256 tiles) as twice as many half tiles -- 8 x 12 halo, 6 x 10 intermediate
-// in 4 row tiles, 12 instead of 11 MFMA row tiles per 64 output pixels -- so that every CU holds TWO resident blocks
-// whose phases could overlap.  Measured (tools/res2_prof.py, clock64 stamps; EDSR shard step): forward 16.2 -> 16.5 us,
-// backward 15.2 -> 14.8 us, step 1.199 -> 1.212 ms: the two co-resident blocks stretch each other's tap phases by what
-// they hide of each other's barriers (conv1 taps 9.5 k ticks alone, 8.9 k for HALF the pixels with a neighbour): the CU's
-// LDS / MFMA issue, not exposed latency, is what a lone block waits for.  Not selected by the release library.
-template <int TH>
-struct R2Geo {
-  static constexpr int H1R = TH + 4;                    // input halo rows
-  static constexpr int NPIX1 = R2_H1 * H1R;             // input halo pixels: 144 / 96 (multiples of 16)
-  static constexpr int MR = TH + 2;                     // mid region rows
-  static constexpr int NMID = R2_MW * MR;               // 100 / 60
-  static constexpr int NPIX2 = (NMID + 15) & ~15;       // 112 / 64
-  static constexpr int MT1 = NPIX2 / 16;                // 16-pixel tiles of the mid region: 7 / 4
-  static constexpr int MT1A = (MT1 + 1) / 2;            // ... finished by chunk group 0 (the rest by group 1): 4 / 2
-  static constexpr int MT2 = TH * R2_TS / 16;           // 16-pixel tiles of the output: 4 / 2
-  static constexpr int MT2A = MT2 / 2;                  // ... finished by each chunk group: 2 / 1
-  static_assert(NPIX1 % 16 == 0 && MT2 % 2 == 0, "tile shape");
-};
+// Tile = 8 x 8 outputs: 12 x 12 input halo, 10 x 10 intermediate in 7 MFMA pixel tiles, 4 output pixel tiles.
+// (Round 4 experiment, removed: 4-row half tiles so that the 16-patch EDSR shard -- one 8 x 8 tile per CU -- has two
+// resident blocks per CU.  tools/res2_prof.py: forward 16.2 -> 16.5 us, backward 15.2 -> 14.8 us, step 1.199 -> 1.212 ms:
+// the two blocks stretch each other's tap phases by what they hide of each other's barriers.)
+constexpr int R2_NPIX1 = R2_H1 * R2_H1;   // 144 input halo pixels
+constexpr int R2_MT1 = 7;                 // 16-pixel tiles of the intermediate (r2_mid_rc)
+constexpr int R2_MT1A = 4;                // ... finished by chunk group 0 (the rest by group 1)
+constexpr int R2_MT2 = 4;                 // 16-pixel tiles of the output: rows 2 mt, 2 mt + 1
+constexpr int R2_MT2A = 2;                // ... finished by each chunk group
+
+// ---- LDS layout of the operand planes, in 16-byte slots (8 channels of one pixel): [chunk][plane][group g][pixel slot]
+// with the group offset r2_goff(g) = g * S + (g >> 1) * 4 and S = 8 (mod 16).
+//  * ds_read_b128 serves the lane sets {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (and + 32) in one clock each when
+//    their 16 slots differ mod 16; a set mixes 8 lanes of group kq with 8 lanes of group kq + 1.  Round 3 read 16
+//    row-major pixels of a 10-wide region from rows of pitch 12 (conv1) / 10 (conv2) with S = 0 (mod 16): the pixels of
+//    the tile's second row alias the first row's (16 == 0, 17 == 1), EVERY operand read took two clocks per set
+//    (SQ_LDS_BANK_CONFLICT = 35 % of the kernel's cycles at batch 128), and the LDS, not the matrix pipe, paced the taps.
+//    Now a pixel tile is 2 rows x 8 columns, the lane -> pixel maps r2_pix1 / r2_pix2 put slots on the lanes {0-3, 12-15}
+//    whose residues, shifted by S = 8, are the complement of the other 8 lanes' residues, for every tap (a tap shifts all
+//    16 alike): one clock per set.  The 10 x 10 intermediate is five 2 x 8 tiles (columns 0-7), the 8 x 2 strip of columns
+//    8-9 above row 8 (rows of pitch 12 give a column strip only 8 residues: this one tile reads in two clocks), and the
+//    2 x 2 corner evaluated as the 2 x 8 tile at columns 2-9 of rows 8-9 (columns 2-7 recomputed and dropped).
+//  * ds_write_b128 serves 8 adjacent lanes per clock when their slots differ mod 8: the halo staging puts 4 adjacent
+//    pixels x the groups {g, g + 2} on 8 lanes (r2_goff(g + 2) - r2_goff(g) = 4 mod 8); 16 lanes still read 4 x 128
+//    contiguous bytes of global memory.
+constexpr int R2_S1 = 152, R2_S2 = 104;           // >= 144 / >= 100, 8 mod 16
+constexpr int R2_PL1 = 4 * R2_S1 + 4, R2_PL2 = 4 * R2_S2 + 4;   // one [4 groups] plane
+__device__ __forceinline__ constexpr int r2_goff(int g, int S) { return g * S + (g >> 1) * 4; }
+
+// lane column (lane & 15) -> pixel index within a 2 x 8 tile.  conv1 (row pitch 12): lanes {0-3, 12-15} hold the pixels
+// {0-5, 8, 9}; conv2 (row pitch 10): {0-4, 8-10}.
+__device__ __forceinline__ int r2_pix1(int col) {
+  return col < 4 ? col : col < 6 ? col + 2 : col < 12 ? col + 4 : col < 14 ? col - 8 : col - 6;
+}
+__device__ __forceinline__ int r2_pix2(int col) {
+  return col < 4 ? col : col < 7 ? col + 1 : col < 12 ? col + 4 : col == 12 ? 4 : col - 5;
+}
+// pixel (r, c) of the 10 x 10 intermediate that lane column `col` holds in tile mt (0..6); false: a dropped duplicate
+__device__ __forceinline__ bool r2_mid_rc(int mt, int col, int& r, int& c) {
+  const int i = r2_pix1(col);
+  if (mt == 5) {   // strip: rows 0-3 on the lanes {0-3, 12-15}, rows 4-7 on {4-11}
+    const bool a = col < 4 || col >= 12;
+    const int k = a ? (col < 4 ? col : col - 8) : col - 4;
+    r = (a ? 0 : 4) + (k >> 1);
+    c = 8 + (k & 1);
+    return true;
+  }
+  if (mt >= 6) {
+    r = 8 + (i >> 3);
+    c = 2 + (i & 7);
+    return mt == 6 && (i & 7) >= 6;
+  }
+  r = 2 * mt + (i >> 3);
+  c = i & 7;
+  return true;
+}
 
 struct Res2Params {
   const float* in;    // [N, H, W, 64]: x (forward) / dy (backward); also the residual added to `out`
@@ -124,12 +159,11 @@ __device__ __forceinline__ void r2_split4h(const f32x4& v, float s, uint2 (&pl)[
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) ACC[mt] = mfma16(BF[0], A[0][mt], ACC[mt]);        \
   }
 
-template <int NP, bool BWD, bool F16 = false, int TH = 8>
+template <int NP, bool BWD, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
   static_assert(!F16 || (NP == 2 && !BWD), "f16x3 is the two-plane forward arithmetic");
-  typedef R2Geo<TH> G;
-  constexpr int R2_NPIX1 = G::NPIX1, R2_NMID = G::NMID, R2_NPIX2 = G::NPIX2, R2_MT1 = G::MT1, MT1A = G::MT1A, MT2 = G::MT2,
-                MT2A = G::MT2A;
+  constexpr int TH = R2_TS, MT1A = R2_MT1A, MT2 = R2_MT2, MT2A = R2_MT2A;
+  constexpr int S1 = R2_S1, S2 = R2_S2, PL1 = R2_PL1, PL2 = R2_PL2;
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   __shared__ float r2_amx[8];
   // f16x3: input scale 2^kx from the tensor's running maximum; the intermediate gets its own scale from the tile's maximum
@@ -140,11 +174,11 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
     sx = exp2i(kx);
     dsc1 = exp2i(-kx) * R.wd1[0];
   }
-  uint4* hal1 = smem4;                          // [2 chunks][NP][4 groups][144 pixels]
-  uint4* hal2 = smem4 + 2 * NP * 4 * R2_NPIX1;  // [2][NP][4][112]
+  uint4* hal1 = smem4;                 // [2 chunks][NP][PL1]: 12 x 12 input halo
+  uint4* hal2 = smem4 + 2 * NP * PL1;  // [2][NP][PL2]: 10 x 10 intermediate
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ow = wave & 3, kgrp = wave >> 2;
-  const int j = lane & 15, kq = lane >> 4;
+  const int col = lane & 15, kq = lane >> 4;
   int b = blockIdx.x;
   const int txi = b % R.tiles_x;
   b /= R.tiles_x;
@@ -155,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
   const float* __restrict__ inb = R.in + img;
 
   // ---- filter fragments: position seq = conv * 9 + tap of the 18-tap sequence (the prefetch runs across the two convs)
-  const int wlane = kq * 64 + j + ow * 16;
+  const int wlane = kq * 64 + col + ow * 16;
   auto load_b = [&](int seq, uint4(&dst)[NP]) {
     const int cv = seq >= 9 ? 1 : 0, t = seq - 9 * cv;
     const int wt = BWD ? 8 - t : t;  // data gradient: the taps run flipped (conv_tile.h, TRANS gather with stride 1)
@@ -170,15 +204,15 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
   load_b(0, bq[0]);
   load_b(1, bq[1]);
 
-  // ---- input halo -> planes in LDS.  item = (pixel, 8-channel group of the 64): 8 adjacent lanes read one pixel's
-  // 256 bytes; every global load is issued before the first conversion
+  // ---- input halo -> planes in LDS.  item = (pixel, 8-channel group of the 64); lane bits: [pixel & 3][g >> 1][g & 1]
+  // [chunk][pixel >> 2] (see r2_goff); every global load is issued before the first conversion
   if (!(R.dbg & 1)) {
     constexpr int NIT = (R2_NPIX1 * 8 + 511) / 512;
     f32x4 v0[NIT], v1[NIT];
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       const int item = tid + k * 512;
-      const int g8 = item & 7, hp = item >> 3;
+      const int g8 = ((item >> 1) & 2) | ((item >> 3) & 1) | ((item >> 2) & 4), hp = ((item >> 5) << 2) | (item & 3);
       const int hy = hp / R2_H1, hx = hp - hy * R2_H1;
       const int iy = r0 - 2 + hy, ix = c0 - 2 + hx;
       v0[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -192,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       const int item = tid + k * 512;
-      const int g8 = item & 7, hp = item >> 3;
+      const int g8 = ((item >> 1) & 2) | ((item >> 3) & 1) | ((item >> 2) & 4), hp = ((item >> 5) << 2) | (item & 3);
       if (hp < R2_NPIX1) {
         float f[8];
 #pragma unroll
@@ -204,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
         if constexpr (F16) split8h(f, sx, pl); else split8n<NP>(f, pl);
         const int chunk = g8 >> 2, g = g8 & 3;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) hal1[((chunk * NP + p) * 4 + g) * R2_NPIX1 + hp] = pl[p];
+        for (int p = 0; p < NP; ++p) hal1[(chunk * NP + p) * PL1 + r2_goff(g, S1) + hp] = pl[p];
       }
     }
   }
@@ -220,12 +254,11 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
     int hpA[R2_MT1];
 #pragma unroll
     for (int mt = 0; mt < R2_MT1; ++mt) {
-      int m = mt * 16 + j;
-      if (m >= R2_NMID) m = 0;
-      const int r = m / R2_MW, c = m - r * R2_MW;
-      hpA[mt] = r * R2_H1 + c + kq * R2_NPIX1;
+      int r, c;
+      r2_mid_rc(mt, col, r, c);
+      hpA[mt] = r * R2_H1 + c + r2_goff(kq, S1);
     }
-    constexpr int plane1 = 4 * R2_NPIX1;
+    constexpr int plane1 = PL1;
     const uint4* h1c = hal1 + kgrp * NP * plane1;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -247,14 +280,16 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
   const int ch4 = ow * 16 + kq * 4;
   f32x4 gt[MT1A];  // backward: forward mid values of this wave's tiles (issued before the barriers)
   int moff[MT1A];  // element offset of the tile's pixel in the image (-1: outside the image or the region)
+  int mpos[MT1A];  // its slot in the 10 x 10 intermediate (-1: a dropped duplicate)
   bool mcen[MT1A];
 #pragma unroll
   for (int q = 0; q < MT1A; ++q) {
     const int mt = kgrp ? MT1A + q : q;
-    const int m = mt * 16 + j;
-    const int r = m / R2_MW, c = m - r * R2_MW;
+    int r, c;
+    const bool valid = r2_mid_rc(mt, col, r, c);
+    mpos[q] = valid ? r * R2_MW + c : -1;
     const int iy = r0 - 1 + r, ix = c0 - 1 + c;
-    const bool inimg = mt < R2_MT1 && m < R2_NMID && (unsigned)iy < (unsigned)R.H && (unsigned)ix < (unsigned)R.W;
+    const bool inimg = valid && (unsigned)iy < (unsigned)R.H && (unsigned)ix < (unsigned)R.W;
     moff[q] = inimg ? (int)(((size_t)iy * R.W + ix) * R2_C) + ch4 : -1;
     mcen[q] = inimg && r >= 1 && r <= TH && c >= 1 && c <= R2_TS;
     // (unconditional, from a clamped address: a load under a divergent branch is followed by s_waitcnt vmcnt(0) at the
@@ -322,13 +357,12 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
     for (int mt = 0; mt < R2_MT1; ++mt) {
       if ((mt < MT1A) != (kgrp == 0)) continue;
       const int q = mt < MT1A ? mt : mt - MT1A;
-      const int m = mt * 16 + j;
-      if (m < R2_NMID) {
+      if (mpos[q] >= 0) {
         uint2 pl[NP];
         if constexpr (F16) r2_split4h(vv[q], smid, pl); else r2_split4<NP>(vv[q], pl);
 #pragma unroll
         for (int p = 0; p < NP; ++p)
-          reinterpret_cast<uint2*>(hal2 + ((ch2 * NP + p) * 4 + g2) * R2_NPIX2 + m)[kq & 1] = pl[p];
+          reinterpret_cast<uint2*>(hal2 + (ch2 * NP + p) * PL2 + r2_goff(g2, S2) + mpos[q])[kq & 1] = pl[p];
       }
     }
   }
@@ -337,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
   int ooff[MT2A];
 #pragma unroll
   for (int q = 0; q < MT2A; ++q) {
-    const int m = (kgrp * MT2A + q) * 16 + j;
+    const int m = (kgrp * MT2A + q) * 16 + r2_pix2(col);
     const int iy = r0 + (m >> 3), ix = c0 + (m & 7);
     const bool ok = iy < R.H && ix < R.W;
     ooff[q] = ok ? (int)(((size_t)iy * R.W + ix) * R2_C) + ch4 : -1;
@@ -355,10 +389,10 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
     int hpB[MT2];
 #pragma unroll
     for (int mt = 0; mt < MT2; ++mt) {
-      const int m = mt * 16 + j;
-      hpB[mt] = (m >> 3) * R2_MW + (m & 7) + kq * R2_NPIX2;
+      const int m = mt * 16 + r2_pix2(col);
+      hpB[mt] = (m >> 3) * R2_MW + (m & 7) + r2_goff(kq, S2);
     }
-    constexpr int plane2 = 4 * R2_NPIX2;
+    constexpr int plane2 = PL2;
     const uint4* h2c = hal2 + kgrp * NP * plane2;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -431,25 +465,14 @@ bool conv_res2_supported(int N, int H, int W, int C) {
   return tiles <= max_tiles;
 }
 
-template <int NP, bool BWD, bool F16, int TH>
-static int r2_launch_t(const Res2Params& R, hipStream_t s) {
-  const size_t lds = (size_t)2 * NP * 4 * (R2Geo<TH>::NPIX1 + R2Geo<TH>::NPIX2) * 16;
-  static LdsLimit lim;
-  lim.ensure(reinterpret_cast<const void*>(&k_res2<NP, BWD, F16, TH>), lds);
-  note_kernel("k_res2<%d,%d%s%s>", NP, (int)BWD, F16 ? ",f16" : "", TH == 4 ? ",th4" : "");
-  hipLaunchKernelGGL((k_res2<NP, BWD, F16, TH>), dim3((unsigned)((size_t)R.N * R.tiles_y * R.tiles_x)), dim3(512), lds, s, R);
-  return check_launch("conv_res2");
-}
-
 template <int NP, bool BWD, bool F16 = false>
-static int r2_launch(Res2Params R, hipStream_t s) {
-#ifdef SRK_EXPERIMENTS
-  if (SRK_EXP_INT("SRK_RES2_TH", 8) == 4) {   // half tiles (R2Geo): measured, not faster
-    R.tiles_y = (R.H + 3) / 4;
-    return r2_launch_t<NP, BWD, F16, 4>(R, s);
-  }
-#endif
-  return r2_launch_t<NP, BWD, F16, 8>(R, s);
+static int r2_launch(const Res2Params& R, hipStream_t s) {
+  const size_t lds = (size_t)2 * NP * (R2_PL1 + R2_PL2) * 16;
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&k_res2<NP, BWD, F16>), lds);
+  note_kernel("k_res2<%d,%d%s>", NP, (int)BWD, F16 ? ",f16" : "");
+  hipLaunchKernelGGL((k_res2<NP, BWD, F16>), dim3((unsigned)((size_t)R.N * R.tiles_y * R.tiles_x)), dim3(512), lds, s, R);
+  return check_launch("conv_res2");
 }
 
 // `wp1` / `wp2`: packed filter buffers of srk_pack_weight_fwd (forward) / srk_pack_weight_bwd (backward) of the conv

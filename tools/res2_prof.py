@@ -5,7 +5,7 @@ import ctypes, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 if len(sys.argv) > 2:
-    os.environ["SRK_RES2_TH"] = sys.argv[2]
+    os.environ["SRK_RES2_TH"] = sys.argv[2]  # (the half-tile variant was removed with the round-4 LDS layout)
 import pytorch_super_resolution_model_collection_amd as pkg
 from pytorch_super_resolution_model_collection_amd import _lib
 ops = pkg.ops
