@@ -110,4 +110,18 @@ __device__ __forceinline__ float abs_max4(float cur, const f32x4& v) {
   return fmaxf(fmaxf(cur, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }
 
+// ---- LDS layout helpers of the 2 x 8 pixel-tile kernels (conv_res2.hip, conv_c64.hip; the scheme is explained at the top
+// of conv_res2.hip): offset of 8-channel group g in a [4 groups] plane whose group stride S is 8 (mod 16), and the lane
+// column -> tile pixel maps for rows of pitch 12 / 10 slots.
+__device__ __forceinline__ constexpr int lds_goff(int g, int S) { return g * S + (g >> 1) * 4; }
+
+// lane column (lane & 15) -> pixel index within a 2 x 8 tile.  conv1 (row pitch 12): lanes {0-3, 12-15} hold the pixels
+// {0-5, 8, 9}; conv2 (row pitch 10): {0-4, 8-10}.
+__device__ __forceinline__ int lds_pix_p12(int col) {
+  return col < 4 ? col : col < 6 ? col + 2 : col < 12 ? col + 4 : col < 14 ? col - 8 : col - 6;
+}
+__device__ __forceinline__ int lds_pix_p10(int col) {
+  return col < 4 ? col : col < 7 ? col + 1 : col < 12 ? col + 4 : col == 12 ? 4 : col - 5;
+}
+
 }  // namespace srk

@@ -26,7 +26,8 @@ namespace srk {
 constexpr int C64_C = 64;
 constexpr int C64_TS = 8;       // output tile side
 constexpr int C64_HS = 10;      // halo side
-constexpr int C64_NPIX = 112;   // 100 halo pixels rounded up to a multiple of 16
+constexpr int C64_S = 104;      // LDS stride of an 8-channel group: >= 100 halo pixels, 8 (mod 16) -- conflict-free reads and
+constexpr int C64_PL = 4 * C64_S + 4;   // writes as in conv_res2.hip (lds_goff, lds_pix_p10); one [4 groups] plane
 
 struct C64Params {
   const float* in;     // [N, H, W, 64]
@@ -53,11 +54,12 @@ __global__ __launch_bounds__(512, 2) void k_c64(C64Params R) {
     sx = exp2i(kx);
     dsc = exp2i(-kx) * R.wd[0];
   }
-  uint4* hal = smem4;                                                         // [2 chunks][NP][4 groups][112 pixels]
-  f32x4* redb = reinterpret_cast<f32x4*>(smem4 + 2 * NP * 4 * C64_NPIX);      // [4 ow][4 tiles][64 lanes]
+  uint4* hal = smem4;                                               // [2 chunks][NP][C64_PL]
+  f32x4* redb = reinterpret_cast<f32x4*>(smem4 + 2 * NP * C64_PL);  // [4 ow][4 tiles][64 lanes]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ow = wave & 3, kgrp = wave >> 2;
-  const int j = lane & 15, kq = lane >> 4;
+  const int col = lane & 15, kq = lane >> 4;
+  const int j = lds_pix_p10(col);  // this lane's pixel within a 2 x 8 pixel tile
   int b = blockIdx.x;
   const int txi = b % R.tiles_x;
   b /= R.tiles_x;
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(512, 2) void k_c64(C64Params R) {
   const size_t img = (size_t)n * R.H * R.W * C64_C;
   const float* __restrict__ inb = R.in + img;
 
-  const int wlane = kq * 64 + j + ow * 16;
+  const int wlane = kq * 64 + col + ow * 16;
   auto load_b = [&](int t, uint4(&dst)[NP]) {
     const int wt = BWD ? 8 - t : t;  // data gradient: flipped taps (TRANS gather with stride 1)
     const size_t slot = (size_t)(wt * 2 + kgrp);
@@ -80,7 +82,8 @@ __global__ __launch_bounds__(512, 2) void k_c64(C64Params R) {
   load_b(0, bq[0]);
   load_b(1, bq[1]);
 
-  // ---- input halo -> planes in LDS: item = (pixel, 8-channel group); unconditional loads from clamped addresses (a
+  // ---- input halo -> planes in LDS: item = (pixel, 8-channel group), lane bits [pixel & 3][g >> 1][g & 1][chunk]
+  // [pixel >> 2] (conflict-free ds_write_b128, conv_res2.hip); unconditional loads from clamped addresses (a
   // load under a divergent branch is followed by s_waitcnt vmcnt(0) at the join), zeroed by a select for the padding
   {
     constexpr int NIT = (100 * 8 + 511) / 512;
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(512, 2) void k_c64(C64Params R) {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       const int item = tid + k * 512;
-      const int g8 = item & 7, hp = item >> 3;
+      const int g8 = ((item >> 1) & 2) | ((item >> 3) & 1) | ((item >> 2) & 4), hp = ((item >> 5) << 2) | (item & 3);
       const int hy = hp / C64_HS, hx = hp - hy * C64_HS;
       const int iy = r0 - 1 + hy, ix = c0 - 1 + hx;
       ok[k] = hp < 100 && (unsigned)iy < (unsigned)R.H && (unsigned)ix < (unsigned)R.W;
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void k_c64(C64Params R) {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       const int item = tid + k * 512;
-      const int g8 = item & 7, hp = item >> 3;
+      const int g8 = ((item >> 1) & 2) | ((item >> 3) & 1) | ((item >> 2) & 4), hp = ((item >> 5) << 2) | (item & 3);
       if (hp < 100) {
         float f[8];
 #pragma unroll
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void k_c64(C64Params R) {
         if constexpr (F16) split8h(f, sx, pl); else split8n<NP>(f, pl);
         const int chunk = g8 >> 2, g = g8 & 3;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) hal[((chunk * NP + p) * 4 + g) * C64_NPIX + hp] = pl[p];
+        for (int p = 0; p < NP; ++p) hal[(chunk * NP + p) * C64_PL + lds_goff(g, C64_S) + hp] = pl[p];
       }
     }
   }
@@ -142,9 +145,9 @@ __global__ __launch_bounds__(512, 2) void k_c64(C64Params R) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const int m = mt * 16 + j;
-      hp[mt] = (m >> 3) * C64_HS + (m & 7) + kq * C64_NPIX;
+      hp[mt] = (m >> 3) * C64_HS + (m & 7) + lds_goff(kq, C64_S);
     }
-    constexpr int plane = 4 * C64_NPIX;
+    constexpr int plane = C64_PL;
     const uint4* hc = hal + kgrp * NP * plane;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -219,7 +222,7 @@ bool conv_c64_applicable(const GatherConv& g, const Epi& ep, const float* in, co
 
 template <int NP, bool BWD, bool F16>
 static int c64_launch(const C64Params& R, hipStream_t s) {
-  const size_t lds = (size_t)2 * NP * 4 * C64_NPIX * 16 + (size_t)4 * 4 * 64 * 16;
+  const size_t lds = (size_t)2 * NP * C64_PL * 16 + (size_t)4 * 4 * 64 * 16;
   static LdsLimit lim;
   lim.ensure(reinterpret_cast<const void*>(&k_c64<NP, BWD, F16>), lds);
   note_kernel("k_c64<%d,%d%s>", NP, (int)BWD, F16 ? ",f16" : "");

@@ -40,35 +40,25 @@ constexpr int R2_MT2 = 4;                 // 16-pixel tiles of the output: rows 
 constexpr int R2_MT2A = 2;                // ... finished by each chunk group
 
 // ---- LDS layout of the operand planes, in 16-byte slots (8 channels of one pixel): [chunk][plane][group g][pixel slot]
-// with the group offset r2_goff(g) = g * S + (g >> 1) * 4 and S = 8 (mod 16).
+// with the group offset lds_goff(g) = g * S + (g >> 1) * 4 and S = 8 (mod 16).
 //  * ds_read_b128 serves the lane sets {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (and + 32) in one clock each when
 //    their 16 slots differ mod 16; a set mixes 8 lanes of group kq with 8 lanes of group kq + 1.  Round 3 read 16
 //    row-major pixels of a 10-wide region from rows of pitch 12 (conv1) / 10 (conv2) with S = 0 (mod 16): the pixels of
 //    the tile's second row alias the first row's (16 == 0, 17 == 1), EVERY operand read took two clocks per set
 //    (SQ_LDS_BANK_CONFLICT = 35 % of the kernel's cycles at batch 128), and the LDS, not the matrix pipe, paced the taps.
-//    Now a pixel tile is 2 rows x 8 columns, the lane -> pixel maps r2_pix1 / r2_pix2 put slots on the lanes {0-3, 12-15}
+//    Now a pixel tile is 2 rows x 8 columns, the lane -> pixel maps lds_pix_p12 / lds_pix_p10 put slots on the lanes {0-3, 12-15}
 //    whose residues, shifted by S = 8, are the complement of the other 8 lanes' residues, for every tap (a tap shifts all
 //    16 alike): one clock per set.  The 10 x 10 intermediate is five 2 x 8 tiles (columns 0-7), the 8 x 2 strip of columns
 //    8-9 above row 8 (rows of pitch 12 give a column strip only 8 residues: this one tile reads in two clocks), and the
 //    2 x 2 corner evaluated as the 2 x 8 tile at columns 2-9 of rows 8-9 (columns 2-7 recomputed and dropped).
 //  * ds_write_b128 serves 8 adjacent lanes per clock when their slots differ mod 8: the halo staging puts 4 adjacent
-//    pixels x the groups {g, g + 2} on 8 lanes (r2_goff(g + 2) - r2_goff(g) = 4 mod 8); 16 lanes still read 4 x 128
+//    pixels x the groups {g, g + 2} on 8 lanes (lds_goff(g + 2) - lds_goff(g) = 4 mod 8); 16 lanes still read 4 x 128
 //    contiguous bytes of global memory.
 constexpr int R2_S1 = 152, R2_S2 = 104;           // >= 144 / >= 100, 8 mod 16
 constexpr int R2_PL1 = 4 * R2_S1 + 4, R2_PL2 = 4 * R2_S2 + 4;   // one [4 groups] plane
-__device__ __forceinline__ constexpr int r2_goff(int g, int S) { return g * S + (g >> 1) * 4; }
-
-// lane column (lane & 15) -> pixel index within a 2 x 8 tile.  conv1 (row pitch 12): lanes {0-3, 12-15} hold the pixels
-// {0-5, 8, 9}; conv2 (row pitch 10): {0-4, 8-10}.
-__device__ __forceinline__ int r2_pix1(int col) {
-  return col < 4 ? col : col < 6 ? col + 2 : col < 12 ? col + 4 : col < 14 ? col - 8 : col - 6;
-}
-__device__ __forceinline__ int r2_pix2(int col) {
-  return col < 4 ? col : col < 7 ? col + 1 : col < 12 ? col + 4 : col == 12 ? 4 : col - 5;
-}
 // pixel (r, c) of the 10 x 10 intermediate that lane column `col` holds in tile mt (0..6); false: a dropped duplicate
 __device__ __forceinline__ bool r2_mid_rc(int mt, int col, int& r, int& c) {
-  const int i = r2_pix1(col);
+  const int i = lds_pix_p12(col);
   if (mt == 5) {   // strip: rows 0-3 on the lanes {0-3, 12-15}, rows 4-7 on {4-11}
     const bool a = col < 4 || col >= 12;
     const int k = a ? (col < 4 ? col : col - 8) : col - 4;
@@ -205,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
   load_b(1, bq[1]);
 
   // ---- input halo -> planes in LDS.  item = (pixel, 8-channel group of the 64); lane bits: [pixel & 3][g >> 1][g & 1]
-  // [chunk][pixel >> 2] (see r2_goff); every global load is issued before the first conversion
+  // [chunk][pixel >> 2] (see lds_goff); every global load is issued before the first conversion
   if (!(R.dbg & 1)) {
     constexpr int NIT = (R2_NPIX1 * 8 + 511) / 512;
     f32x4 v0[NIT], v1[NIT];
@@ -238,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
         if constexpr (F16) split8h(f, sx, pl); else split8n<NP>(f, pl);
         const int chunk = g8 >> 2, g = g8 & 3;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) hal1[(chunk * NP + p) * PL1 + r2_goff(g, S1) + hp] = pl[p];
+        for (int p = 0; p < NP; ++p) hal1[(chunk * NP + p) * PL1 + lds_goff(g, S1) + hp] = pl[p];
       }
     }
   }
@@ -256,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
     for (int mt = 0; mt < R2_MT1; ++mt) {
       int r, c;
       r2_mid_rc(mt, col, r, c);
-      hpA[mt] = r * R2_H1 + c + r2_goff(kq, S1);
+      hpA[mt] = r * R2_H1 + c + lds_goff(kq, S1);
     }
     constexpr int plane1 = PL1;
     const uint4* h1c = hal1 + kgrp * NP * plane1;
@@ -362,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
         if constexpr (F16) r2_split4h(vv[q], smid, pl); else r2_split4<NP>(vv[q], pl);
 #pragma unroll
         for (int p = 0; p < NP; ++p)
-          reinterpret_cast<uint2*>(hal2 + (ch2 * NP + p) * PL2 + r2_goff(g2, S2) + mpos[q])[kq & 1] = pl[p];
+          reinterpret_cast<uint2*>(hal2 + (ch2 * NP + p) * PL2 + lds_goff(g2, S2) + mpos[q])[kq & 1] = pl[p];
       }
     }
   }
@@ -371,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
   int ooff[MT2A];
 #pragma unroll
   for (int q = 0; q < MT2A; ++q) {
-    const int m = (kgrp * MT2A + q) * 16 + r2_pix2(col);
+    const int m = (kgrp * MT2A + q) * 16 + lds_pix_p10(col);
     const int iy = r0 + (m >> 3), ix = c0 + (m & 7);
     const bool ok = iy < R.H && ix < R.W;
     ooff[q] = ok ? (int)(((size_t)iy * R.W + ix) * R2_C) + ch4 : -1;
@@ -389,8 +379,8 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
     int hpB[MT2];
 #pragma unroll
     for (int mt = 0; mt < MT2; ++mt) {
-      const int m = mt * 16 + r2_pix2(col);
-      hpB[mt] = (m >> 3) * R2_MW + (m & 7) + r2_goff(kq, S2);
+      const int m = mt * 16 + lds_pix_p10(col);
+      hpB[mt] = (m >> 3) * R2_MW + (m & 7) + lds_goff(kq, S2);
     }
     constexpr int plane2 = PL2;
     const uint4* h2c = hal2 + kgrp * NP * plane2;
