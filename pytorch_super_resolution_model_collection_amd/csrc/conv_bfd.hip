@@ -28,6 +28,11 @@
 #include "conv_tile.h"
 #include "bf16_frag.h"
 #include <stdlib.h>
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
 
 namespace srk {
 
@@ -38,7 +43,8 @@ struct BfdParams {
   int ICc;           // 32-channel chunks
   int OCb;           // 64-channel output blocks
   int NB;            // output channels per block in the prepared layout
-  int NPIXp;         // halo pixels rounded up to 16
+  int NPIXp;         // LDS stride of an 8-channel group in 16-byte slots: >= the halo pixels, chosen with `perm` (bfd_lds_plan)
+  unsigned long long perm;  // lane column (lane & 15) -> pixel of a 16-pixel M tile, 4 bits each
   int dbg;
   int allc;          // small problems: every channel chunk of the halo staged up front (one load latency, one barrier)
   int cpr;           // chunks staged per barrier round: ICc (allc), 2 (K-split without allc) or 1
@@ -128,7 +134,7 @@ __device__ __forceinline__ void bfd_stage_halo_t(const BfdParams& B, uint4* hal,
         uint4 pl[NP];
         if constexpr (F16) split8h(f, sx, pl); else split8n<NP>(f, pl);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) hal[(p * 4 + g) * B.NPIXp + hp] = pl[p];
+        for (int p = 0; p < NP; ++p) hal[p * (4 * B.NPIXp + 4) + lds_goff(g, B.NPIXp) + hp] = pl[p];
       }
     }
   }
@@ -146,8 +152,9 @@ constexpr int BFD_EPI_STRIDE = 68;  // floats per staged output row (64 + 4: con
 // accumulators -> LDS slab of the pixel group (32 pixels x block channels, two halves) -> 16-byte
 // stores by all NOW waves of the group.  C/D layout: col = lane&15 (channel), row = (lane>>4)*4+reg.
 template <int NTW, int NPW, int NOW>
-__device__ __forceinline__ void bfd_epilogue(const MfmaConvParams& P, float* smem_f, const f32x4 (&acc)[4][NTW], int n,
-                                             int r0, int c0, int ocb, int pw, int ow, int lane, bool active = true) {
+__device__ __forceinline__ void bfd_epilogue(const MfmaConvParams& P, unsigned long long perm, float* smem_f,
+                                             const f32x4 (&acc)[4][NTW], int n, int r0, int c0, int ocb, int pw, int ow,
+                                             int lane, bool active = true) {
   float amax = 0.f;
   const float peeked = amax_peek(P.ep.y_amax, blockIdx.x + (threadIdx.x >> 6));
   const int j = lane & 15, kq = lane >> 4;
@@ -173,7 +180,8 @@ __device__ __forceinline__ void bfd_epilogue(const MfmaConvParams& P, float* sme
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg)
-            st[(mh * 16 + kq * 4 + reg) * BFD_EPI_STRIDE + (ow * NTW + nt) * 16 + j] = acc[2 * h + mh][nt][reg];
+            st[(mh * 16 + (int)((perm >> (4 * (kq * 4 + reg))) & 15)) * BFD_EPI_STRIDE + (ow * NTW + nt) * 16 + j] =
+                acc[2 * h + mh][nt][reg];   // (accumulator row i = the pixel lane column i read: perm)
     }
     __syncthreads();
     if (lane_on) {
@@ -204,10 +212,11 @@ __device__ __forceinline__ void bfd_epilogue(const MfmaConvParams& P, float* sme
 // kernel a latency chain) the LDS-staged epilogue was 2.2 of the 12.4 us; its better store coalescing only pays
 // when the epilogue is bandwidth-bound (large problems keep it).
 template <int NTW>
-__device__ __forceinline__ void bfd_epilogue_direct(const MfmaConvParams& P, const f32x4 (&acc)[4][NTW], int n, int r0,
-                                                    int c0, int ocb, int pw, int ow, int lane, bool active) {
+__device__ __forceinline__ void bfd_epilogue_direct(const MfmaConvParams& P, unsigned long long perm,
+                                                    const f32x4 (&acc)[4][NTW], int n, int r0, int c0, int ocb, int pw,
+                                                    int ow, int lane, bool active) {
   if (!active) return;
-  const int j = lane & 15, kq = lane >> 4;
+  const int j = (int)((perm >> (4 * (lane & 15))) & 15), kq = lane >> 4;
   const int npx = P.TH * P.TW;
   const int tw_magic = div_small_magic(P.TW);
   const EpiTile et = epi_tile_setup(P, n, r0, c0);
@@ -267,7 +276,8 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, OCCX ? OCCX : (bfd_occ<NTW, NP
   const int tid = threadIdx.x, lane = tid & 63, wave0 = tid >> 6;
   const int kgrp = wave0 / (NPW * NOW), wave = wave0 - kgrp * (NPW * NOW);  // K-split group, wave inside it
   const int pw = wave % NPW, ow = wave / NPW;
-  const int j = lane & 15, kq = lane >> 4;
+  const int col = lane & 15, kq = lane >> 4;
+  const int j = (int)((B.perm >> (4 * col)) & 15);   // this lane's pixel within a 16-pixel M tile
   int b = blockIdx.x;
   const int txi = b % P.tiles_x;
   b /= P.tiles_x;
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, OCCX ? OCCX : (bfd_occ<NTW, NP
       int m = pw * 64 + mt * 16 + j;
       if (m >= npx) m = 0;
       const int r = div_small(m, tw_magic), c = m - r * P.TW;
-      hp[mt] = (r * P.is) * P.HW + c * P.is + kq * B.NPIXp;
+      hp[mt] = (r * P.is) * P.HW + c * P.is + lds_goff(kq, B.NPIXp);
     }
   }
   f32x4 acc[4][NTW];
@@ -298,8 +308,8 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, OCCX ? OCCX : (bfd_occ<NTW, NP
     for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const bool wave_live = pw * 64 < npx;
-  const int plane = 4 * B.NPIXp;
-  const int wlane = kq * NB + j + ow * NTW * 16;
+  const int plane = 4 * B.NPIXp + 4;
+  const int wlane = kq * NB + col + ow * NTW * 16;
   // f16x3: activation scale 2^kx from the running maximum of the input tensor, descale 2^-(kx + kw)
   float sx = 1.f, dsc = 1.f;
   if constexpr (F16) {
@@ -383,7 +393,7 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, OCCX ? OCCX : (bfd_occ<NTW, NP
       load_b(head, bq[d]);
       walk_next(head);
     }
-    const int cstride = NP * 4 * B.NPIXp;  // uint4 per staged chunk
+    const int cstride = NP * plane;  // uint4 per staged chunk
     // Rounds of `cpr` chunks between barriers: 1 chunk, 2 chunks (K-split: one per wave group), or all of them (allc,
     // a single round so that the rotation below runs across chunk boundaries).  Group kgrp computes the chunks
     // kgrp, kgrp + KS, ... of its round.
@@ -476,14 +486,101 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, OCCX ? OCCX : (bfd_occ<NTW, NP
       for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] *= dsc;
   }
   if constexpr (TEPI)
-    bfd_epilogue_direct<NTW>(P, acc, n, r0, c0, ocb, pw, ow, lane, kgrp == 0);
+    bfd_epilogue_direct<NTW>(P, B.perm, acc, n, r0, c0, ocb, pw, ow, lane, kgrp == 0);
   else
-    bfd_epilogue<NTW, NPW, NOW>(P, reinterpret_cast<float*>(smem4), acc, n, r0, c0, ocb, pw, ow, lane, kgrp == 0);
+    bfd_epilogue<NTW, NPW, NOW>(P, B.perm, reinterpret_cast<float*>(smem4), acc, n, r0, c0, ocb, pw, ow, lane, kgrp == 0);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Host
 // ---------------------------------------------------------------------------------------------
+// LDS plan of the operand reads (round 4).  ds_read_b128 serves the lane sets {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}
+// (+ 32) in one clock each when their 16 slots differ mod 16; a set mixes 8 lanes of channel group kq with 8 lanes of
+// group kq + 1, whose slots lie D = stride mod 16 further (lds_goff).  Pixel i of an M tile sits at slot
+// (m / TW) * is * HW + (m % TW) * is: 16 consecutive slots when a tile row is >= 16 pixels wide (D = 0, identity), but the
+// 8 x 8 tiles of the small-problem blocks put pixels 8-15 one halo row further, where they alias pixels 0-7 -- every
+// operand read took two clocks per set (SQ_LDS_BANK_CONFLICT: 19-22 % of the cycles of k_conv_bfd<1,1,4,*>).  This
+// searches D and the split of the 16 pixels over the two lane classes for the fewest clocks over the block's M tiles
+// (12870 splits x 16 strides, cached per geometry); conv_res2.hip documents the two hand-derived instances.
+static void bfd_lds_plan(int TW, int is, int HW, int npx, int npix, int NPW, int& stride, unsigned long long& perm) {
+  struct Key {
+    int TW, is, HW, npx, NPW;
+    bool operator<(const Key& o) const {
+      return std::tie(TW, is, HW, npx, NPW) < std::tie(o.TW, o.is, o.HW, o.npx, o.NPW);
+    }
+  };
+  struct Val {
+    int D;
+    unsigned long long perm;
+  };
+  static std::mutex mu;
+  static std::map<Key, Val> cache;
+  const Key key{TW, is, HW, npx, NPW};
+  Val v{};
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) {
+      v = it->second;
+    } else {
+      const int ntile = NPW * 4;
+      std::vector<int> pos((size_t)ntile * 16, -1);
+      int live = 0;
+      for (int t = 0; t < ntile; ++t)
+        for (int i = 0; i < 16; ++i) {
+          const int m = t * 16 + i;
+          if (m < npx) pos[(size_t)t * 16 + i] = (m / TW) * is * HW + (m % TW) * is;
+          if (i == 0 && m < npx) live = t + 1;
+        }
+      static const int colA[8] = {0, 1, 2, 3, 12, 13, 14, 15}, colB[8] = {4, 5, 6, 7, 8, 9, 10, 11};
+      long best_cost = -1;
+      int best_D = 0;
+      unsigned best_mask = 0;
+      const bool off = env_int("SRK_BFD_LDS_PLAN", 1) == 0;
+      // candidate order: the round-3 layout first (ties keep it), then the rest
+      for (int di = 0; di < (off ? 1 : 16); ++di) {
+        const int D = di == 0 ? 0 : (di == 1 ? 8 : (di <= 8 ? di - 1 : di));   // 0, 8, 1 .. 7, 9 .. 15
+        for (unsigned mask = 0; mask < (off ? 1u : 65536u); ++mask) {
+          // mask: pixels on the lane class A; the first candidate is the identity (pixels {0-3, 12-15})
+          const unsigned mk = mask == 0 ? 0xF00Fu : mask;
+          if (mask != 0 && (__builtin_popcount(mk) != 8 || mk == 0xF00Fu)) continue;
+          long cost = 0;
+          for (int t = 0; t < live; ++t) {
+            int cnt0[16] = {0}, cnt1[16] = {0};
+            int m0 = 0, m1 = 0;
+            for (int i = 0; i < 16; ++i) {
+              const int ps = pos[(size_t)t * 16 + i];
+              if (ps < 0) continue;   // dead pixels all read slot 0 of their group: one address, no conflict of their own
+              const bool a = (mk >> i) & 1;
+              const int r0 = (a ? ps : ps + D) & 15, r1 = (a ? ps + D : ps) & 15;
+              m0 = std::max(m0, ++cnt0[r0]);
+              m1 = std::max(m1, ++cnt1[r1]);
+            }
+            cost += m0 + m1;
+          }
+          if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best_D = D;
+            best_mask = mk;
+            if (best_cost == 2L * live) break;
+          }
+        }
+        if (best_cost == 2L * live) break;   // one clock per set everywhere
+      }
+      v.D = best_D;
+      v.perm = 0;
+      int na = 0, nb = 0;
+      for (int i = 0; i < 16; ++i) {
+        const int colx = ((best_mask >> i) & 1) ? colA[na++] : colB[nb++];
+        v.perm |= (unsigned long long)i << (4 * colx);
+      }
+      cache[key] = v;
+    }
+  }
+  stride = ((npix - v.D + 15) & ~15) + v.D;   // smallest value >= npix that is D (mod 16)
+  perm = v.perm;
+}
+
 template <int NTW, int NPW, int NOW, int NP, int PF, bool F16 = false, int OCCX = 0>
 static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
   note_amax_written(B.P.ep.y_amax != nullptr);   // both epilogues keep the running maximum of what they store
@@ -505,8 +602,8 @@ static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
     return SRK_ERR_UNSUPPORTED;
   }
   P.TH = best.TH; P.TW = best.TW; P.tiles_y = best.tiles_y; P.tiles_x = best.tiles_x; P.HH = best.HH; P.HW = best.HW;
-  B.NPIXp = (best.HH * best.HW + 15) & ~15;  // multiple of 16: the kq lane groups of a ds_read_b128 interleave conflict-free
-  size_t lds = (size_t)NP * 4 * B.NPIXp * 16;
+  bfd_lds_plan(P.TW, P.is, P.HW, P.TH * P.TW, P.HH * P.HW, NPW, B.NPIXp, B.perm);
+  size_t lds = (size_t)NP * (4 * B.NPIXp + 4) * 16;
   B.allc = 0;
   B.cpr = 1;
   const size_t lds_chunk = lds;
