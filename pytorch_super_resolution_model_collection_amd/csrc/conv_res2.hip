@@ -196,9 +196,9 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
 
   // ---- input halo -> planes in LDS.  item = (pixel, 8-channel group of the 64); lane bits: [pixel & 3][g >> 1][g & 1]
   // [chunk][pixel >> 2] (see lds_goff); every global load is issued before the first conversion
+  constexpr int NIT = (R2_NPIX1 * 8 + 511) / 512;
+  f32x4 v0[NIT], v1[NIT];
   if (!(R.dbg & 1)) {
-    constexpr int NIT = (R2_NPIX1 * 8 + 511) / 512;
-    f32x4 v0[NIT], v1[NIT];
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       const int item = tid + k * 512;
@@ -213,6 +213,28 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
         v1[k] = *reinterpret_cast<const f32x4*>(p + 4);
       }
     }
+  }
+  // ---- per-lane geometry of the exchange after the first conv (group 0 finishes mid tiles 0-3, group 1 tiles 4-6),
+  // computed HERE, behind the halo loads and in front of their first use: after the first conv's taps this index
+  // arithmetic was part of the ~2.3 k clocks the block's first wave then waits at the barrier (tools/res2_prof.py).
+  // (The gate / bias loads stay behind the taps: 16 + 8 more live registers across them are 132 - 138 VGPRs, one
+  //  block per CU.)
+  const int ch4 = ow * 16 + kq * 4;
+  int moff[MT1A];  // element offset of the tile's pixel in the image (-1: outside the image or the region)
+  int mpos[MT1A];  // its slot in the 10 x 10 intermediate (-1: a dropped duplicate)
+  bool mcen[MT1A];
+#pragma unroll
+  for (int q = 0; q < MT1A; ++q) {
+    const int mt = kgrp ? MT1A + q : q;
+    int r, c;
+    const bool valid = r2_mid_rc(mt, col, r, c);
+    mpos[q] = valid ? r * R2_MW + c : -1;
+    const int iy = r0 - 1 + r, ix = c0 - 1 + c;
+    const bool inimg = valid && (unsigned)iy < (unsigned)R.H && (unsigned)ix < (unsigned)R.W;
+    moff[q] = inimg ? (int)(((size_t)iy * R.W + ix) * R2_C) + ch4 : -1;
+    mcen[q] = inimg && r >= 1 && r <= TH && c >= 1 && c <= R2_TS;
+  }
+  if (!(R.dbg & 1)) {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       const int item = tid + k * 512;
@@ -266,26 +288,14 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
   }
 
   R2_PROF(3);
-  // ---- the chunk groups swap halves: group 0 finishes mid tiles 0-3, group 1 tiles 4-6
-  const int ch4 = ow * 16 + kq * 4;
+  // ---- the chunk groups swap halves
   f32x4 gt[MT1A];  // backward: forward mid values of this wave's tiles (issued before the barriers)
-  int moff[MT1A];  // element offset of the tile's pixel in the image (-1: outside the image or the region)
-  int mpos[MT1A];  // its slot in the 10 x 10 intermediate (-1: a dropped duplicate)
-  bool mcen[MT1A];
 #pragma unroll
   for (int q = 0; q < MT1A; ++q) {
-    const int mt = kgrp ? MT1A + q : q;
-    int r, c;
-    const bool valid = r2_mid_rc(mt, col, r, c);
-    mpos[q] = valid ? r * R2_MW + c : -1;
-    const int iy = r0 - 1 + r, ix = c0 - 1 + c;
-    const bool inimg = valid && (unsigned)iy < (unsigned)R.H && (unsigned)ix < (unsigned)R.W;
-    moff[q] = inimg ? (int)(((size_t)iy * R.W + ix) * R2_C) + ch4 : -1;
-    mcen[q] = inimg && r >= 1 && r <= TH && c >= 1 && c <= R2_TS;
     // (unconditional, from a clamped address: a load under a divergent branch is followed by s_waitcnt vmcnt(0) at the
     //  join, which would serialise the latencies of these loads; a pixel outside the image is zeroed below anyway)
     gt[q] = (f32x4){1.f, 1.f, 1.f, 1.f};
-    if constexpr (BWD) gt[q] = *reinterpret_cast<const f32x4*>(R.gate + img + (inimg ? moff[q] : ch4));
+    if constexpr (BWD) gt[q] = *reinterpret_cast<const f32x4*>(R.gate + img + (moff[q] >= 0 ? moff[q] : ch4));
   }
   // biases: requested here, complete before the epilogues that use them (a first use inside those conditional store
   // sequences put an s_waitcnt vmcnt(0) -- a wait for the previous store's acknowledgement -- in front of every store)
@@ -293,6 +303,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
   if (!BWD && R.bias1) b1 = *reinterpret_cast<const f32x4*>(R.bias1 + ch4);
   if (!BWD && R.bias2) b2 = *reinterpret_cast<const f32x4*>(R.bias2 + ch4);
   __syncthreads();  // every wave is done with the input halo
+  R2_PROF(10);
   f32x4* red = reinterpret_cast<f32x4*>(smem4) + (size_t)(ow * R2_MT1) * 64 + lane;  // [4 ow][7 tiles][64 lanes]
   if (kgrp == 0) {
 #pragma unroll
@@ -302,6 +313,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
     for (int mt = 0; mt < MT1A; ++mt) red[mt * 64] = acc1[mt];
   }
   __syncthreads();
+  R2_PROF(11);
   float smid = 1.f, dsc2 = 1.f;
   {
     asm volatile("" ::"v"(b1), "v"(b2));
@@ -331,6 +343,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
       vv[q] = v;
       if constexpr (F16) lmax = abs_max4(lmax, v);
     }
+    R2_PROF(12);
     if constexpr (F16) {
       // the intermediate's scale: maximum over the whole 10 x 10 x 64 tile (the second conv mixes all of it)
       lmax = wave_max(lmax);
@@ -343,6 +356,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
       smid = exp2i(km);
       dsc2 = exp2i(-km) * R.wd2[0];
     }
+    R2_PROF(13);
 #pragma unroll
     for (int mt = 0; mt < R2_MT1; ++mt) {
       if ((mt < MT1A) != (kgrp == 0)) continue;

@@ -65,3 +65,9 @@ for name, fn in (("forward f16x3", fwd), ("backward bf16x3", bwd)):
     for i, nm in enumerate(NAMES):
         d = t[:, i + 1] - t[:, i]
         print("   %-70s mean %7.0f  min %7.0f  max %7.0f ticks" % (nm, float(d.mean()), float(d.min()), float(d.max())))
+    sub = [("conv1 done -> barrier 1 passed", 3, 10), ("red written + barrier 2", 10, 11), ("red read, bias/gate, ReLU, mid stored", 11, 12),
+           ("tile maximum (f16x3: wave max, barrier 3)", 12, 13), ("split + mid planes written, residual loads issued", 13, 4)]
+    for nm, a, b in sub:
+        d = t[:, b] - t[:, a]
+        print("      . %-66s mean %7.0f  min %7.0f  max %7.0f ticks" % (nm, float(d.mean()), float(d.min()), float(d.max())))
+
