@@ -697,16 +697,31 @@ __global__ __launch_bounds__(512) void k_linear_fwd_wide(const float* __restrict
   // the same few HBM channels at any moment (0.8 TB/s for a plain weight stream).
   const int nsteps = (In + 512 * 4 - 1) / (512 * 4);
   int step = blockIdx.x % nsteps;
-  for (int it = 0; it < nsteps; ++it, step = step + 1 == nsteps ? 0 : step + 1) {
+  // (round 4: the weights of step it + 1 are requested before step it multiplies -- one block per CU with 64 bytes per
+  //  thread in flight and the load latency of every step exposed streamed the 134 MB weight of SRGAN's 32768 -> 1024
+  //  layer at 1.8 TB/s.  Unconditional loads from a clamped column + a select: a load under a branch is followed by
+  //  s_waitcnt vmcnt(0).)
+  lf4 wn[4];
+  auto wload = [&](int st) {
+    const int i = st * 512 * 4 + tid * 4;
+    const int ic = i < In ? i : 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wn[k] = *reinterpret_cast<const lf4*>(wr[k] + ic);
+  };
+  wload(step);
+  for (int it = 0; it < nsteps; ++it) {
     const int i = step * 512 * 4 + tid * 4;
-    if (i >= In) continue;
+    const bool live = i < In;
     lf4 wv[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) wv[k] = *reinterpret_cast<const lf4*>(wr[k] + i);
+    for (int k = 0; k < 4; ++k) wv[k] = live ? wn[k] : (lf4){0.f, 0.f, 0.f, 0.f};
+    step = step + 1 == nsteps ? 0 : step + 1;
+    if (it + 1 < nsteps) wload(step);
+    const int ix = live ? i : 0;
 #pragma unroll
     for (int r = 0; r < LW_BT; ++r) {
       const int br = b0 + r < B ? b0 + r : B - 1;
-      const lf4 xv = *reinterpret_cast<const lf4*>(x + (size_t)br * In + i);
+      const lf4 xv = *reinterpret_cast<const lf4*>(x + (size_t)br * In + ix);
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         acc[k][r] = fmaf(wv[k][0], xv[0], fmaf(wv[k][1], xv[1], fmaf(wv[k][2], xv[2], fmaf(wv[k][3], xv[3], acc[k][r]))));
