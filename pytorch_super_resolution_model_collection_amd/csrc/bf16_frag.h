@@ -74,10 +74,25 @@ __device__ __forceinline__ float exp2i(int k) {  // 2^k for -126 <= k <= 127 (cl
   k = k < -126 ? -126 : (k > 127 ? 127 : k);
   return __uint_as_float((unsigned)(k + 127) << 23);
 }
+// Maximum over the 64 lanes, the same value in every lane.  Rotations inside the rows of 16 lanes as DPP operands of
+// v_max (no LDS traffic), then the four row results through v_readlane.  (Until round 4 this was six dependent
+// __shfl_xor = ds_bpermute_b32 round trips, ~400 clocks in front of every running-maximum commit and inside the fused
+// residual block's intermediate scale, tools/res2_prof.py.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_rot(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_rot<0x121>(v));   // row_ror:1
+  v = fmaxf(v, dpp_rot<0x122>(v));   // row_ror:2
+  v = fmaxf(v, dpp_rot<0x124>(v));   // row_ror:4
+  v = fmaxf(v, dpp_rot<0x128>(v));   // row_ror:8 -> every lane holds its row's maximum
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 // Committing a maximum: the slot is read EARLY (amax_peek, before the stores of the epilogue, so that the tail of a
 // short-lived block does not wait for a memory round trip that nothing overlaps) and the atomic is issued only when the
