@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, OCCX ? OCCX : (bfd_occ<NTW, NP
   // filter fragments of the head position -> registers (past the end the walk re-reads the last chunk: valid
   // memory, never used)
   auto load_b = [&](const Walk& h, uint4 (&dst)[NP][NTW]) {
-    if (B.dbg & 8) return;
+    if (SRK_KDBG(B.dbg) & 8) return;
     const int hc = h.cc < B.ICc ? h.cc : B.ICc - 1;
     const size_t slot = (size_t)(h.wt * B.ICc + hc) * B.OCb + ocbi;
     const uint4* w = B.wq + slot * (size_t)(8 * NB) + wlane;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, OCCX ? OCCX : (bfd_occ<NTW, NP
   };
   // one tap: A fragments from LDS, 3 or 6 MFMA passes against the given filter fragments
   auto tap_mfma = [&](const uint4* halc, int toff, const uint4 (&bf)[NP][NTW]) {
-    if (wave_live && !(B.dbg & 4)) {
+    if (wave_live && !(SRK_KDBG(B.dbg) & 4)) {
       const uint4* hb = halc + toff;
       uint4 a[NP][4];
 #pragma unroll
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, OCCX ? OCCX : (bfd_occ<NTW, NP
       const int cfirst = seg * cpr;
       const int cend = cfirst + cpr < B.ICc ? cfirst + cpr : B.ICc;
       if (seg) __syncthreads();  // previous round's halo fully consumed
-      for (int c2 = cfirst; c2 < cend && !(B.dbg & 1); ++c2) {
+      for (int c2 = cfirst; c2 < cend && !(SRK_KDBG(B.dbg) & 1); ++c2) {
         if (P.mask_y)
           bfd_stage_halo_t<true, NTHR, NP, SIT, F16>(B, hal + (c2 - cfirst) * cstride, n, r0, c0, c2 * 32, sx);
         else
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, OCCX ? OCCX : (bfd_occ<NTW, NP
       }
     }
   }
-  if (B.dbg & 2) {
+  if (SRK_KDBG(B.dbg) & 2) {
     if (acc[0][0][0] == 123.456f) P.out[0] = 1.f;  // keep the accumulators live
     return;
   }
@@ -631,7 +631,7 @@ static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
       if (lds < red_bytes) lds = red_bytes;
       static LdsLimit lim2;
       lim2.ensure(reinterpret_cast<const void*>(&k_conv_bfd<NTW, NPW, NOW, NP, PF, 2, F16, OCCX>), lds);
-      if (B.dbg & 32)
+      if (SRK_KDBG(B.dbg) & 32)
         fprintf(stderr, "[srk] k_conv_bfd<%d,%d,%d,%d,%d> K-split 2: lds %zu B, grid %u x %u, tile %dx%d halo %dx%d\n", NTW, NPW,
                 NOW, NP, PF, lds, grid.x, grid.y, P.TH, P.TW, P.HH, P.HW);
       note_kernel("k_conv_bfd<%d,%d,%d,%d,%d,2%s>", NTW, NPW, NOW, NP, PF, F16 ? ",f16" : "");
@@ -642,7 +642,7 @@ static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
   static LdsLimit lim;
   const void* fn = reinterpret_cast<const void*>(&k_conv_bfd<NTW, NPW, NOW, NP, PF, 1, F16, OCCX>);
   lim.ensure(fn, lds);
-  if (B.dbg & 32) {
+  if (SRK_KDBG(B.dbg) & 32) {
     int nb = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * NPW * NOW, lds);
     fprintf(stderr, "[srk] k_conv_bfd<%d,%d,%d,%d,%d>: lds %zu B, grid %u x %u, occupancy %d blocks/CU, tile %dx%d halo %dx%d\n",

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64 * (16 / MTW + NPW), (16 / MTW + NPW) / 4) void k
     // the halo buffer is free (64->32 layer of c2: 0.471 -> 0.437 ms; the 48-channel pixel-shuffle layer LOSES 9 % with
     // it -- its consumers also carry the 756 MB store stream -- and priority on the consumers changes nothing).
     // s_setprio ignores EXEC, so the branch must be provably wave-uniform (readfirstlane).  SRK_DBG & 2048: off.
-    if (NTW <= 2 && __builtin_amdgcn_readfirstlane(tid) >= 64 * NCW && !(B.dbg & 2048)) __builtin_amdgcn_s_setprio(1);
+    if (NTW <= 2 && __builtin_amdgcn_readfirstlane(tid) >= 64 * NCW && !(SRK_KDBG(B.dbg) & 2048)) __builtin_amdgcn_s_setprio(1);
     const int ptid = tid - 64 * NCW;
     const int g = ptid & 3, hp0 = ptid >> 2;
     const int hy0 = hp0 / P.HW, hx0 = hp0 - hy0 * P.HW;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64 * (16 / MTW + NPW), (16 / MTW + NPW) / 4) void k
     auto issue = [&]() {
       int n, r0, c0, cc;
       decode(n, r0, c0, cc);
-      if (B.dbg & 1) return;
+      if (SRK_KDBG(B.dbg) & 1) return;
       constexpr unsigned OOB = 0x80000000u;
       const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
       const bool ch_on = cc * 32 + g * 8 + 7 < P.IC;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64 * (16 / MTW + NPW), (16 / MTW + NPW) / 4) void k
       }
     };
     auto commit = [&](uint4* hal) {
-      if (B.dbg & 16) return;
+      if (SRK_KDBG(B.dbg) & 16) return;
 #pragma unroll
       for (int k = 0; k < PIT; ++k) {
         const int hq = hp0 + PSTEP * k;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64 * (16 / MTW + NPW), (16 / MTW + NPW) / 4) void k
         }
       }
     }
-    if (wave_live && T > 0 && !(B.dbg & 4)) {
+    if (wave_live && T > 0 && !(SRK_KDBG(B.dbg) & 4)) {
       const uint4* hal = hal0 + (size_t)(s & 1) * hbuf;
       const uint4* wb = wl + (size_t)cc * wslot;
       const size_t wstep = (size_t)B.ICc * wslot;
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(64 * (16 / MTW + NPW), (16 / MTW + NPW) / 4) void k
       }
     }
     const long long k1 = BFW_CLK();
-    if (cc == B.ICc - 1 && wave_live && !(B.dbg & 2)) {
+    if (cc == B.ICc - 1 && wave_live && !(SRK_KDBG(B.dbg) & 2)) {
       // tile finished (C/D col = lane & 15 = pixel, rows kq*4 + reg = 4 consecutive channels per M tile): park it
       if (pend_live) flush_from(std::integral_constant<int, 0>{});  // (cannot happen with TT > 0)
       const unsigned tile_off = 4u * (unsigned)epi_tile_setup(P, n, r0, c0).off0;
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(64 * (16 / MTW + NPW), (16 / MTW + NPW) / 4) void k
         }
       }
       pend_live = true;
-      if (TT == 0 || s == S - 1 || (B.dbg & 1024)) {  // no unrolled tap loop to ride under / last tile of this block
+      if (TT == 0 || s == S - 1 || (SRK_KDBG(B.dbg) & 1024)) {  // no unrolled tap loop to ride under / last tile of this block
         flush_from(std::integral_constant<int, 0>{});
         pend_live = false;
       }

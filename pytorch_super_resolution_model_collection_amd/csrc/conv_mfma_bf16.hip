@@ -354,7 +354,7 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 && NW == 4) ? 3 : 2) void k_conv_
       __syncthreads();  // previous chunk fully consumed
       const uint4* wbase = B.wq + ((size_t)cc * B.OCb + ocbi) * (size_t)wslot;
       int wtap = P.wh0 * P.KW_full + P.ww0;  // weight tap of (u, v) = (0, 0)
-      if (!(B.dbg & 1)) bf3_stage_halo<NTHR>(B, hal, n, r0, c0, cc * 32);
+      if (!(SRK_KDBG(B.dbg) & 1)) bf3_stage_halo<NTHR>(B, hal, n, r0, c0, cc * 32);
       {
         // (loads unconditional from a clamped index, only the LDS writes conditional: load + write under one branch
         //  compiled to load, s_waitcnt vmcnt(0), write -- per copy, one after the other)
@@ -375,13 +375,13 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 && NW == 4) ? 3 : 2) void k_conv_
         uint4 wr[WCP];
 #pragma unroll
         for (int c = 0; c < WCP; ++c) wr[c] = make_uint4(0, 0, 0, 0);
-        if (t + 1 < T && !(B.dbg & 8)) {  // prefetch the next tap's slice; lands while the MFMAs below run
+        if (t + 1 < T && !(SRK_KDBG(B.dbg) & 8)) {  // prefetch the next tap's slice; lands while the MFMAs below run
           const uint4* src = wbase + (size_t)wnext * wtap_stride;
 #pragma unroll
           for (int c = 0; c < WCP; ++c)
             if (tid + c * NTHR < wslot) wr[c] = src[tid + c * NTHR];
         }
-        if (wave_live && !(B.dbg & 4)) {
+        if (wave_live && !(SRK_KDBG(B.dbg) & 4)) {
           const uint4* wb = wl + (t & 1) * wslot + wlane;
           const uint4* hb = hal + toff;
           uint4 ah[4], al[4];
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 && NW == 4) ? 3 : 2) void k_conv_
       }
     }
   }
-  if (B.dbg & 2) {
+  if (SRK_KDBG(B.dbg) & 2) {
     if (acc[0][0][0] == 123.456f) P.out[0] = 1.f;  // keep the accumulators live
     return;
   }
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3_rows(Bf3Params B) {
       if (hp < npix) {
         const int hy = hp / P.HW, hx = hp - hy * P.HW;
         const int iy = iyb + hy, ix = ixb + hx;
-        if (iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW && !(B.dbg & 1)) {
+        if (iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW && !(SRK_KDBG(B.dbg) & 1)) {
           const size_t off = (((size_t)n * P.IH + iy) * P.IW + ix) * P.IC;
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3_rows(Bf3Params B) {
         if (w0_ok) wr0 = src[tid];
         if (w1_ok) wr1 = src[tid + 256];
       }
-      if (wave_live && !(B.dbg & 4)) {
+      if (wave_live && !(SRK_KDBG(B.dbg) & 4)) {
         const int toff = u * P.HW + ks * 8;
         const uint4* wb = wl + (q & 1) * wslot + wlane;
         uint4 ah[4], al[4];
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_bf3_rows(Bf3Params B) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] *= dsc;
   }
-  bf3_epilogue<NT, VEC_ONLY>(P, reinterpret_cast<float*>(smem4), acc, n, r0, c0, ocb, wave, lane, B.dbg);
+  bf3_epilogue<NT, VEC_ONLY>(P, reinterpret_cast<float*>(smem4), acc, n, r0, c0, ocb, wave, lane, SRK_KDBG(B.dbg));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -893,7 +893,7 @@ template <int NT>
 static void bf3_launch_vec(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s) {
   static LdsLimit lim;
   lim.ensure(reinterpret_cast<const void*>(&k_conv_bf3<NT, 4, true>), lds);
-  if (B.dbg & 32) {
+  if (SRK_KDBG(B.dbg) & 32) {
     int nb = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_conv_bf3<NT, 4, true>), 256,
                                                        lds);
@@ -908,7 +908,7 @@ template <int NT, int NW>
 static void bf3_launch(const Bf3Params& B, dim3 grid, size_t lds, hipStream_t s) {
   static LdsLimit lim;
   lim.ensure(reinterpret_cast<const void*>(&k_conv_bf3<NT, NW>), lds);
-  if (B.dbg & 32) {
+  if (SRK_KDBG(B.dbg) & 32) {
     int nb = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_conv_bf3<NT, NW>), 64 * NW,
                                                        lds);

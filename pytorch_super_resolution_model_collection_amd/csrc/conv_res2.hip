@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
   // [chunk][pixel >> 2] (see lds_goff); every global load is issued before the first conversion
   constexpr int NIT = (R2_NPIX1 * 8 + 511) / 512;
   f32x4 v0[NIT], v1[NIT];
-  if (!(R.dbg & 1)) {
+  if (!(SRK_KDBG(R.dbg) & 1)) {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       const int item = tid + k * 512;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
     moff[q] = inimg ? (int)(((size_t)iy * R.W + ix) * R2_C) + ch4 : -1;
     mcen[q] = inimg && r >= 1 && r <= TH && c >= 1 && c <= R2_TS;
   }
-  if (!(R.dbg & 1)) {
+  if (!(SRK_KDBG(R.dbg) & 1)) {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       const int item = tid + k * 512;
@@ -275,7 +275,10 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       load_b(t + 2, bq[(t + 2) % 3]);
-      if (!(R.dbg & 4)) {
+      // (a scheduling fence per tap: without one the unrolled taps' fragment reads are hoisted over each other -- 248 VGPRs,
+      //  one block per CU; until round 4 a run-time ablation branch around the tap body had that effect by accident)
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(SRK_KDBG(R.dbg) & 4)) {
         const int toff = (t / 3) * R2_H1 + (t % 3);
         uint4 a[NP][R2_MT1];
 #pragma unroll
@@ -401,7 +404,8 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       if (t + 2 < 9) load_b(9 + t + 2, bq[(t + 2) % 3]);
-      if (!(R.dbg & 4)) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(SRK_KDBG(R.dbg) & 4)) {
         const int toff = (t / 3) * R2_MW + (t % 3);
         uint4 a[NP][MT2];
 #pragma unroll

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_rowsw(RowswParams B) {
   auto issue = [&]() {
     const int n = wi.n, iyb = wi.y * P.TH + P.iy0, ixb = wi.x * P.TW + P.ix0;
     wi.advance(st_n, st_y, st_x, P.tiles_x, P.tiles_y);
-    if (B.dbg & 1) return;
+    if (SRK_KDBG(B.dbg) & 1) return;
     vmask = 0;
     const float* img = P.in + (size_t)n * P.IC * plane;
 #pragma unroll
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_rowsw(RowswParams B) {
     }
   };
   auto commit = [&](uint4* hal) {
-    if (B.dbg & 16) return;
+    if (SRK_KDBG(B.dbg) & 16) return;
 #pragma unroll
     for (int k = 0; k < RW_IT; ++k) {
       const int hq = tid + NTHR * k;
@@ -321,8 +321,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_rowsw(RowswParams B) {
 #pragma unroll
           for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = mfma16x<F16>(a[0][nt], b[0][mt], acc[nt][mt]);  // w_h * x_h
       };
-      if (!(B.dbg & 4)) load_frags(fa[0], fb[0]);
-      if (!(B.dbg & 4)) rw_static_for<0, QT>([&](auto tc) {
+      if (!(SRK_KDBG(B.dbg) & 4)) load_frags(fa[0], fb[0]);
+      if (!(SRK_KDBG(B.dbg) & 4)) rw_static_for<0, QT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         if (t + 1 < QT) load_frags(fa[WREG ? 0 : ((t + 1) & 1)], fb[(t + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_rowsw(RowswParams B) {
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt) {
         const int r = pix_ok[mt] >> 16, c = pix_ok[mt] & 0xffff;
-        const bool ok = pix_ok[mt] >= 0 && r0 + r < P.PH && c0 + c < P.PW && !(B.dbg & 2);
+        const bool ok = pix_ok[mt] >= 0 && r0 + r < P.PH && c0 + c < P.PW && !(SRK_KDBG(B.dbg) & 2);
         if (ok) pend_mask |= 1 << mt;
         pend_voff[mt] = ok ? tile_off + 4u * (unsigned)poff[mt] : kDrop;
 #pragma unroll
@@ -351,6 +351,263 @@ __global__ __launch_bounds__(512, 2) void k_conv_rowsw(RowswParams B) {
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : act_slope * v[e];
           pend[nt][mt] = v;
           if (P.ep.y_amax && ((pend_mask >> mt) & 1)) amax = abs_max4(amax, v);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  rw_static_for<0, NST>([&](auto qc) { store_slot(qc); });  // the last tile (S = 0: nothing parked, dropped)
+  if (P.ep.y_amax) amax_commit(P.ep.y_amax, amax, blockIdx.x + wave, amax_peek(P.ep.y_amax, blockIdx.x + wave));
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_conv_rowsr: the same layer with ROW-REUSED pixel fragments and the filter in registers (round 4).
+//
+// What paced k_conv_rowsw on the c2 first layer (3 -> 64, 5x5, 64 x 256x256; SRK_ROWSW_DBG ablations, 318 us): skeleton
+// (staging, parking, barriers) alone 105 us, + the MFMA loop 244 us, + the stores 318 us, where the layer's 7.9 M MFMAs are
+// 102 us of matrix issue.  Two things: (1) per 32 pixels a wave read the whole filter (40 x ds_read_b128) and 20 pixel
+// fragments for 120 MFMAs -- 3840 clocks of LDS reads per 256-pixel stage and CU beside 3840 clocks of matrix issue per SIMD;
+// (2) all eight waves of the one block per CU ran their matrix phase and their VALU phases (staging conversion, parking
+// arithmetic) in lockstep behind one barrier per stage, so the matrix pipe idled through every VALU phase.
+// Here:
+//   * a wave owns 4 consecutive tile rows x 16 columns x 32 output channels.  The K slots of a step are 8 taps of ONE
+//     kernel row, so the fragment of halo row R serves (tile row mt, kernel row ky) for every mt + ky = R: the 4 rows x KH
+//     kernel rows need KH + 3 row fragments (2 x ds_read_b128 each) instead of 4 KH -- 16 reads per 64 pixels for the 5x5
+//     layer instead of 40 -- and each is consumed as soon as it lands (walk over R; per accumulator the kernel rows still
+//     arrive in ascending order with the passes w_h x_l, w_l x_h, w_h x_h: the summation order of k_conv_bf3_rows);
+//   * the wave's filter fragments (KH x 2 planes x 2 channel tiles = 80 registers for 5x5) are loaded once from global
+//     memory and stay in registers: no filter in LDS at all, LDS reads per 256 pixels 480 -> 64 + 64;
+//   * blocks are 4 waves (2 row groups x 2 channel halves: an 8 x 16 tile x 64 channels), TWO persistent blocks per CU, one
+//     wave of each per SIMD: the two blocks of a CU drift apart and one's matrix phase covers the other's VALU phases and
+//     barrier.  Register budget per wave is the same 256 as with one 8-wave block.
+// Applies when the kernel row fits one K step (KW <= 8) and the 8 x 16 tile's halo fits one pixel per thread; anything
+// else stays with k_conv_rowsw.
+template <int KH, bool F16, bool RELU>
+__global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
+  constexpr int NTW = 2, MTW = 4, NTHR = 256, NR = KH + MTW - 1, TH = 8, TW = 16;
+  extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+  const MfmaConvParams& P = B.P;
+  uint4* hal0 = smem4;  // 2 buffers x NPIXp pixels x {h: 4 x 16 bit, l: 4 x 16 bit}
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int chh = wave & 1, rg = wave >> 1;
+  const int npix = P.HH * P.HW;
+  float sx = 1.f, dsc = 1.f;
+  if constexpr (F16) {
+    const int kx = amax_scale_exp(amax_read(P.ep.x_amax));
+    sx = exp2i(kx);
+    dsc = exp2i(-kx) * B.w_descale[0];
+  }
+  const int nsl = B.nsl;
+  const int xcd = blockIdx.x & 7;
+  const int sl = (blockIdx.x >> 3) % nsl, bi = (blockIdx.x >> 3) / nsl;
+  // filter fragments of this wave: [kernel row][plane][channel tile], lane (j, kq) = channel j of the tile, K slots 8 kq ..
+  uint4 wreg[KH][2][NTW];
+#pragma unroll
+  for (int q = 0; q < KH; ++q)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int oc = sl * 64 + chh * 32 + nt * 16 + j, ocb = oc / B.NBfull;
+      const uint4* w = B.wq + ((size_t)q * B.OCb + ocb) * (size_t)(8 * B.NBfull) + (oc - ocb * B.NBfull);
+      wreg[q][0][nt] = w[kq * B.NBfull];
+      wreg[q][1][nt] = w[(4 + kq) * B.NBfull];
+    }
+  // pixels past the halo (the padded tap slots of the last row read them; they meet zero filter taps and must be finite)
+  for (int e = tid; e < 2 * (B.NPIXp - npix); e += NTHR) {
+    const int b = e / (B.NPIXp - npix), i = e - b * (B.NPIXp - npix);
+    hal0[(size_t)b * B.NPIXp + npix + i] = make_uint4(0, 0, 0, 0);
+  }
+  // tiles of this block: XCD-aware contiguous ranges (see k_conv_bfw)
+  const int nblk = gridDim.x;
+  int first, count;
+  const int nb_x = ((nblk + 7 - xcd) >> 3) / nsl;
+  {
+    const int per_x = B.ntiles >> 3, rem_x = B.ntiles & 7;
+    const int tiles_x = per_x + (xcd < rem_x ? 1 : 0);
+    const int start_x = xcd * per_x + (xcd < rem_x ? xcd : rem_x);
+    first = start_x + bi;
+    count = bi < tiles_x ? (tiles_x - bi + nb_x - 1) / nb_x : 0;
+  }
+  const int S = count;
+  const int img_tiles = P.tiles_x * P.tiles_y;
+  const int st_n = nb_x / img_tiles, st_y = (nb_x - st_n * img_tiles) / P.tiles_x, st_x = nb_x - st_n * img_tiles - st_y * P.tiles_x;
+  RowswWalk wi, wc;
+  wi.init(first, P.tiles_x, img_tiles);
+  wc = wi;
+
+  // ---- staging: thread tid owns halo pixel tid (npix <= 256); loads one stage ahead of the LDS commit, unconditional and
+  // branch-free as in k_conv_rowsw
+  float pv[4];
+  const int hy0 = tid / P.HW, hx0 = tid - hy0 * P.HW;
+  const size_t plane = (size_t)P.IH * P.IW;
+  const size_t est = P.in_nchw ? plane : 1;
+  const size_t e1 = P.IC > 1 ? est : 0, e2 = P.IC > 2 ? 2 * est : 0, e3 = P.IC > 3 ? 3 * est : 0;
+  bool vok = false;
+  auto issue = [&]() {
+    const int n = wi.n, iy = wi.y * TH + P.iy0 + hy0, ix = wi.x * TW + P.ix0 + hx0;
+    wi.advance(st_n, st_y, st_x, P.tiles_x, P.tiles_y);
+    if (SRK_KDBG(B.dbg) & 1) return;
+    vok = tid < npix && (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW;
+    const int cy = min(max(iy, 0), P.IH - 1), cx = min(max(ix, 0), P.IW - 1);
+    const size_t pix = (size_t)cy * P.IW + cx;
+    const float* src = P.in + (size_t)n * P.IC * plane + (P.in_nchw ? pix : pix * P.IC);
+    pv[0] = src[0];
+    pv[1] = src[e1];
+    pv[2] = src[e2];
+    pv[3] = src[e3];
+  };
+  auto commit = [&](uint4* hal) {
+    if (SRK_KDBG(B.dbg) & 16) return;
+    if (tid < npix) {
+      uint2 hu, lu;
+      if constexpr (F16) {
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        f16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xs = (vok && e < P.IC) ? pv[e] * sx : 0.f;
+          const _Float16 hh = (_Float16)xs;
+          h[e] = hh;
+          l[e] = (_Float16)(xs - (float)hh);
+        }
+        hu = __builtin_bit_cast(uint2, h);
+        lu = __builtin_bit_cast(uint2, l);
+      } else {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xv = (vok && e < P.IC) ? pv[e] : 0.f;
+          const __bf16 hh = (__bf16)xv;
+          h[e] = hh;
+          l[e] = (__bf16)(xv - (float)hh);
+        }
+        hu = __builtin_bit_cast(uint2, h);
+        lu = __builtin_bit_cast(uint2, l);
+      }
+      hal[tid] = make_uint4(hu.x, hu.y, lu.x, lu.y);
+    }
+  };
+
+  // ---- MFMA side: halo slot of (row rg * 4 + R, column j, taps 2 kq, 2 kq + 1) = hp0 + R * HW
+  const int hp0 = (rg * MTW) * P.HW + j + 2 * kq;
+  f32x4 bias4[NTW];
+  int coff[NTW];
+  const EpiTile e0 = epi_tile_setup(P, 0, 0, 0);
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const EpiCol cl = epi_col_setup(P.ep, P.OW, P.OC, sl * 64 + chh * 32 + nt * 16 + kq * 4);
+    coff[nt] = (int)cl.off_oc;
+    bias4[nt] = cl.bias;
+  }
+  const float act_slope = P.ep.act == SRK_ACT_NONE ? 1.f
+                          : P.ep.act == SRK_ACT_RELU ? 0.f
+                          : P.ep.act == SRK_ACT_PRELU ? P.ep.prelu_w[0] : P.ep.slope;
+  f32x4 acc[NTW][MTW], pend[NTW][MTW];
+  float amax = 0.f;
+  constexpr unsigned kDrop = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(P.out, 0, B.out_bytes, 0x00020000);
+  unsigned pend_voff[MTW];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) pend_voff[mt] = kDrop;
+  constexpr int NST = NTW * MTW;
+  constexpr int SPREAD = NR - 2;
+  constexpr int PER_STEP = (NST + SPREAD - 1) / SPREAD;
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  auto store_slot = [&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int mt = q / NTW, nt = q - mt * NTW;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, pend[nt][mt]), orsrc, (int)(pend_voff[mt] + 4u * (unsigned)coff[nt]), 0, 0);
+  };
+  if (S > 0) {
+    issue();
+    commit(hal0);
+    if (S > 1) issue();
+  }
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) asm volatile("" ::"v"(bias4[nt]));
+#pragma unroll
+  for (int q = 0; q < KH; ++q)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      typedef unsigned u4v __attribute__((ext_vector_type(4)));
+      asm volatile("" ::"v"(__builtin_bit_cast(u4v, wreg[q][0][nt])), "v"(__builtin_bit_cast(u4v, wreg[q][1][nt])));
+    }
+  asm volatile("" ::"v"(act_slope));
+  __syncthreads();  // tile 0 visible
+  for (int s = 0; s < S; ++s) {
+    const int n = wc.n, r0 = wc.y * TH, c0 = wc.x * TW;
+    wc.advance(st_n, st_y, st_x, P.tiles_x, P.tiles_y);
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      const uint4* hal = hal0 + (size_t)(s & 1) * B.NPIXp + hp0;
+      uint4 fb[2][2];  // [buffer][plane]
+      int roff = 0;
+      auto load_row = [&](uint4 (&b)[2]) {
+        const uint4 p0 = hal[roff], p1 = hal[roff + 1];
+        b[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
+        b[1] = make_uint4(p0.z, p0.w, p1.z, p1.w);
+        roff += P.HW;
+      };
+      if (!(SRK_KDBG(B.dbg) & 4)) load_row(fb[0]);
+      if (!(SRK_KDBG(B.dbg) & 4)) rw_static_for<0, NR>([&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        if (R + 1 < NR) load_row(fb[(R + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const uint4(&b)[2] = fb[R & 1];
+        // (tile row mt, kernel row ky = R - mt) for every valid pair; pass-major like k_conv_rowsw's K step
+        rw_static_for<0, MTW>([&](auto mc) {
+          constexpr int mt = decltype(mc)::value, ky = R - mt;
+          if constexpr (ky >= 0 && ky < KH) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[nt][mt] = mfma16x<F16>(wreg[ky][0][nt], b[1], acc[nt][mt]);  // w_h * x_l
+          }
+        });
+        rw_static_for<0, MTW>([&](auto mc) {
+          constexpr int mt = decltype(mc)::value, ky = R - mt;
+          if constexpr (ky >= 0 && ky < KH) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[nt][mt] = mfma16x<F16>(wreg[ky][1][nt], b[0], acc[nt][mt]);  // w_l * x_h
+          }
+        });
+        rw_static_for<0, MTW>([&](auto mc) {
+          constexpr int mt = decltype(mc)::value, ky = R - mt;
+          if constexpr (ky >= 0 && ky < KH) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[nt][mt] = mfma16x<F16>(wreg[ky][0][nt], b[0], acc[nt][mt]);  // w_h * x_h
+          }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        rw_static_for<(R * PER_STEP < NST ? R * PER_STEP : NST), ((R + 1) * PER_STEP < NST ? (R + 1) * PER_STEP : NST)>(
+            [&](auto qc) { store_slot(qc); });
+      });
+      if (s + 1 < S) commit(hal0 + (size_t)((s + 1) & 1) * B.NPIXp);  // (that buffer was last read in stage s - 1)
+      if (s + 2 < S) issue();
+      // tile finished: park it (C/D col = lane & 15 = pixel column, rows kq*4 + reg = 4 consecutive channels)
+      const unsigned tile_off = 4u * (unsigned)epi_tile_setup(P, n, r0, c0).off0;
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) {
+        const int r = rg * MTW + mt;
+        const bool ok = r0 + r < P.PH && c0 + j < P.PW && !(SRK_KDBG(B.dbg) & 2);
+        pend_voff[mt] = ok ? tile_off + 4u * (unsigned)(r * e0.RS + j * e0.CS) : kDrop;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          f32x4 v = acc[nt][mt];
+          if constexpr (F16) v *= dsc;
+          v += bias4[nt];
+          if constexpr (RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : act_slope * v[e];
+          }
+          pend[nt][mt] = v;
+          if (P.ep.y_amax && ok) amax = abs_max4(amax, v);
         }
       }
     }
@@ -424,6 +681,19 @@ static int rowsw_launch(const RowswParams& B, size_t lds, int grid, hipStream_t 
   return check_launch("conv_rowsw");
 }
 
+template <int KH>
+static int rowsr_launch(const RowswParams& B, size_t lds, int grid, hipStream_t s) {
+  note_amax_written(B.P.ep.y_amax != nullptr);
+  const bool relu = B.P.ep.act == SRK_ACT_RELU;
+  const bool f16 = B.w_descale != nullptr;
+  note_kernel("k_conv_rowsr<%d%s%s>", KH, f16 ? ",f16" : "", relu ? ",relu" : "");
+  if (f16 && relu) hipLaunchKernelGGL((k_conv_rowsr<KH, true, true>), dim3(grid), dim3(256), lds, s, B);
+  else if (f16) hipLaunchKernelGGL((k_conv_rowsr<KH, true, false>), dim3(grid), dim3(256), lds, s, B);
+  else if (relu) hipLaunchKernelGGL((k_conv_rowsr<KH, false, true>), dim3(grid), dim3(256), lds, s, B);
+  else hipLaunchKernelGGL((k_conv_rowsr<KH, false, false>), dim3(grid), dim3(256), lds, s, B);
+  return check_launch("conv_rowsr");
+}
+
 // returns -1 when no tile fits (the caller falls back to k_conv_bf3_rows).  f16: the f16x3 arithmetic (ep.x_amax set)
 int conv_rowsw_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s,
                       bool f16) {
@@ -448,6 +718,25 @@ int conv_rowsw_gather(const GatherConv& g, const float* in, const float* wp, flo
     B.nsl = P.OC / (16 * ntw);
     const int dbg = SRK_EXP_INT("SRK_ROWSW_DBG", 0);
     B.dbg = dbg;
+    // row-reused fragments, filter in registers, two 4-wave blocks per CU (k_conv_rowsr): one K step per kernel row and the
+    // fixed 8 x 16 tile's halo on one pixel per thread.  SRK_ROWSR=0: the 8-wave kernel below.
+    if (P.is == 1 && B.KS == 1 && (Q == 3 || Q == 5) && (7 + P.KHv) * (15 + P.KWv) <= 256 && env_int("SRK_ROWSR", 1) != 0) {
+      P.TH = 8; P.TW = 16;
+      P.tiles_y = (P.PH + 7) / 8; P.tiles_x = (P.PW + 15) / 16;
+      P.HH = 7 + P.KHv; P.HW = 15 + P.KWv;
+      B.NPIXp = P.HH * P.HW + 16;
+      B.nsl = P.OC / 64;
+      const long ntiles = (long)P.tiles_x * P.tiles_y * P.N;
+      if (ntiles < (1L << 30)) {
+        B.ntiles = (int)ntiles;
+        B.out_bytes = (unsigned)((size_t)P.N * P.OH * P.OW * P.OC * sizeof(float));
+        const size_t lds = (size_t)2 * B.NPIXp * 16;
+        int grid = 2 * kNumCU - (2 * kNumCU) % (8 * B.nsl);
+        const long want = ((ntiles + 7) / 8) * 8 * B.nsl;
+        if (want < grid) grid = (int)want;
+        if (grid > 0) return Q == 3 ? rowsr_launch<3>(B, lds, grid, s) : rowsr_launch<5>(B, lds, grid, s);
+      }
+    }
     TilePick best{};
     if (P.is != 1 || !rowsw_pick_tile(P.PH, P.PW, P.KHv, P.KWv, 768, best)) return -1;
     P.TH = best.TH; P.TW = best.TW; P.tiles_y = best.tiles_y; P.tiles_x = best.tiles_x; P.HH = best.HH; P.HW = best.HW;

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(SPEC ? 64 * CIT * COW + WB_SST : 64 * CIT * COW,
     const int tyi = b % P.tiles_y;
     const int n = b / P.tiles_y;
     const int r0 = tyi * P.TH, c0 = txi * P.TW;
-    if (!(P.dbg & 2)) {  // X halo: rows [r0-pad, +HH), cols [c0-pad, +TW+KW-1), channels [cib, cib+CIB) -> planes [ci][hy][hx]
+    if (!(SRK_KDBG(P.dbg) & 2)) {  // X halo: rows [r0-pad, +HH), cols [c0-pad, +TW+KW-1), channels [cib, cib+CIB) -> planes [ci][hy][hx]
       // A thread's channel group q is fixed (256 % QN == 0): it walks pixel pairs pp, pp + 256/QN, ...
       constexpr int QN = CIB / 4, PSTEP = NST / QN;
       // only the TW + KW - 1 columns the fragments can touch are loaded (the plane row stride HWp = TW + 8 is for
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(SPEC ? 64 * CIT * COW + WB_SST : 64 * CIT * COW,
         }
       }
     }
-    if (!(P.dbg & 2)) {  // dY tile: rows [r0, +TH), cols [c0, +TW), channels [cob, cob+COB) -> planes [co][r][c] (masked)
+    if (!(SRK_KDBG(P.dbg) & 2)) {  // dY tile: rows [r0, +TH), cols [c0, +TW), channels [cob, cob+COB) -> planes [co][r][c] (masked)
       constexpr int QN = COB / 4, PSTEP = NST / QN;
       const unsigned tw2_magic = wb_magic20(tw2);
       const int npairs = P.TH * tw2;
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(SPEC ? 64 * CIT * COW + WB_SST : 64 * CIT * COW,
     if constexpr (K33) {
       // (round 4: the octet tables of K step ks + 1 are read while step ks multiplies -- the lookups were a dependent LDS
       //  round trip in front of every K step's fragment reads, with one working wave per SIMD and nothing to hide it)
-      const int nks_run = (P.dbg & 4) ? 0 : P.nks;
+      const int nks_run = (SRK_KDBG(P.dbg) & 4) ? 0 : P.nks;
       int ox_n = oct_x[kq], oy_n = oct_y[kq], or_n = ring ? oct_r[kq] : 0, oc_n = ring ? oct_c[kq] : 0;
       for (int ks = 0; ks < nks_run; ++ks) {
         const int ox = ox_n, oy = oy_n;
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(SPEC ? 64 * CIT * COW + WB_SST : 64 * CIT * COW,
       }
       return;
     }
-    for (int ks = 0; ks < ((P.dbg & 4) ? 0 : P.nks); ++ks) {
+    for (int ks = 0; ks < ((SRK_KDBG(P.dbg) & 4) ? 0 : P.nks); ++ks) {
       const int ox = oct_x[ks * 4 + kq], oy = oct_y[ks * 4 + kq];
       const int orw = ring ? rbase + oct_r[ks * 4 + kq] : 0, ocl = ring ? oct_c[ks * 4 + kq] : 0;
       uint4 bh[NTW], bl[NTW];
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(SPEC ? 64 * CIT * COW + WB_SST : 64 * CIT * COW,
     // Two loops, one per role, with the same barriers (1 + ntb): the stagers' prefetch registers and the workers'
     // accumulators are never live in the same wave.
     if (stager) {
-      if (P.prefetch && !(P.dbg & 2)) {
+      if (P.prefetch && !(SRK_KDBG(P.dbg) & 2)) {
         if (ntb > 0) {
           issue(first_tile, 0);
           commit(0);

@@ -25,12 +25,23 @@ int env_int(const char* name, int dflt);
 // Experiment switches (ablation bits, alternative block shapes, forced tiles): compiled into the library only with
 // -DSRK_EXPERIMENTS (SRK_BUILD_EXPERIMENTS=1 python -m ..._build --force, which tools/ab.sh and the ablation tools need);
 // the release library carries the defaults as constants.
+// SRK_KDBG(x): a kernel's ablation word (a launch parameter) -- a COMPILE-TIME 0 in the release library.  Not only dead
+// code: a run-time `if (dbg & 4)` around a kernel's MFMA loop and its stores gives the compiler's s_waitcnt pass a path on
+// which the stores were never issued, and the waits for loads issued before them then assume the worst (k_conv_rowsw:
+// s_waitcnt vmcnt(7..0) instead of vmcnt(15..8) in front of the staging commit = every stage waited for the write
+// acknowledgements of its own eight stores).
 #ifdef SRK_EXPERIMENTS
 #define SRK_EXP_INT(name, dflt) (::srk::env_int(name, dflt))
 #define SRK_EXP_STR(name) (::srk::env_str(name))
+#define SRK_KDBG(x) (x)
+#elif defined(SRK_KDBG_CONST)   // ablation builds that keep the release code shape: tools/build_variant.sh ... -DSRK_KDBG_CONST=4
+#define SRK_EXP_INT(name, dflt) (dflt)
+#define SRK_EXP_STR(name) (static_cast<const char*>(nullptr))
+#define SRK_KDBG(x) (SRK_KDBG_CONST)
 #else
 #define SRK_EXP_INT(name, dflt) (dflt)
 #define SRK_EXP_STR(name) (static_cast<const char*>(nullptr))
+#define SRK_KDBG(x) 0
 #endif
 
 inline int check_launch(const char* what) {

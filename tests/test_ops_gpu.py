@@ -209,16 +209,19 @@ def test_conv_first_layer_wave_specialized(gpu, monkeypatch, cin, cout, k, p, H,
     monkeypatch.setattr(ops, "F16X3_ALWAYS", True)   # (small problems: the size policy would keep the fp32 MFMA kernel)
     ops.set_precision(mode)
     try:
-        for sw in ("0", "1"):
-            monkeypatch.setenv("SRK_ROWSW", sw)
+        # "0": per-tile kernel; "1": 8-wave persistent kernel; "r": its row-reuse form (4-wave blocks, filter in registers)
+        for sw in ("0", "1", "r"):
+            monkeypatch.setenv("SRK_ROWSW", "0" if sw == "0" else "1")
+            monkeypatch.setenv("SRK_ROWSR", "1" if sw == "r" else "0")
             with torch.no_grad():
                 outs[sw] = ops.conv2d_infer(x.to(gpu), w.to(gpu), b.to(gpu), None, cfg)
             name = pkg._lib.load().srk_last_kernel_name().decode()
-            assert name.startswith("k_conv_rowsw<" if sw == "1" else "k_conv_bf3_rows<"), name
+            assert name.startswith({"0": "k_conv_bf3_rows<", "1": "k_conv_rowsw<", "r": "k_conv_rowsr<"}[sw]), name
             assert ("f16" in name) == (mode == "mixed"), name
     finally:
         ops.set_precision("mixed")
     assert torch.equal(outs["0"], outs["1"])
+    assert torch.equal(outs["0"], outs["r"])
     assert rel_err(outs["1"], ref.float()) < (2e-6 if mode == "mixed" else 1e-4)
 
 
