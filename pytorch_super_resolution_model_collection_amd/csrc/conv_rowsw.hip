@@ -40,7 +40,18 @@ struct RowswParams {
   int KS, NBfull, OCb, NPIXp, ntiles, nsl;
   unsigned out_bytes;
   int dbg;  // ablation (SRK_ROWSW_DBG): 1 no global loads, 2 no stores, 4 no MFMA loop, 16 no LDS commit
+#ifdef SRK_ROWSR_PROF
+  unsigned* prof;  // phase-clock build (tools/rowsr_prof.py): 8 counters per wave
+#endif
 };
+#ifdef SRK_ROWSR_PROF
+static unsigned* g_rowsr_prof = nullptr;
+#define RS_T() ((unsigned)clock64())  /* s_memtime (gfx950 has no SHADER_CYCLES register) */
+#define RS_ACC(i, a, b) pacc[i] += (b) - (a)
+#else
+#define RS_T() 0u
+#define RS_ACC(i, a, b) do { } while (0)
+#endif
 
 // add-and-carry walk over the tiles first, first + step, ... of a block (wave-uniform, scalar registers): a 32-bit
 // division is ~40 VALU instructions = 160 SIMD cycles per wave, and the per-stage decode had three of them
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_rowsw(RowswParams B) {
 //     barrier.  Register budget per wave is the same 256 as with one 8-wave block.
 // Applies when the kernel row fits one K step (KW <= 8) and the 8 x 16 tile's halo fits one pixel per thread; anything
 // else stays with k_conv_rowsw.
-template <int KH, bool F16, bool RELU>
+template <int KH, bool F16, bool RELU, int ICN>
 __global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
   constexpr int NTW = 2, MTW = 4, NTHR = 256, NR = KH + MTW - 1, TH = 8, TW = 16;
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
@@ -436,58 +447,77 @@ __global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
   wi.init(first, P.tiles_x, img_tiles);
   wc = wi;
 
-  // ---- staging: thread tid owns halo pixel tid (npix <= 256); loads one stage ahead of the LDS commit, unconditional and
-  // branch-free as in k_conv_rowsw
-  float pv[4];
+  // ---- staging: thread tid owns halo pixel tid (npix <= 256).  Loads are unconditional and branch-free as in
+  // k_conv_rowsw, and run TWO stages ahead of the LDS commit in two register sets (tile t in set t & 1): vmcnt retires in
+  // order, so the wait for a tile's pixels is also a wait for every store issued before those loads -- with the loads one
+  // stage ahead that was the previous stage's eight stores, one stage old, and the write acknowledgements of a chip that
+  // writes 3.5 TB/s take longer than that (constant-ablation builds, tools/build_variant.sh -DSRK_KDBG_CONST: the layer in
+  // 199 us without the loads, 176 us without the stores, 302 us with both).  Now the wait covers stores two stages old.
+  // Everything is issued unconditionally -- tiles past the end of the block's range are dummies (clamped loads, a commit
+  // nobody reads, stores dropped) and the stage loop runs in pairs -- so that the compiler can count: a path on which an
+  // operation was not issued makes its s_waitcnt pass assume the smaller distance everywhere.
+  float pv[2][4];
+  bool vok[2] = {false, false};
   const int hy0 = tid / P.HW, hx0 = tid - hy0 * P.HW;
   const size_t plane = (size_t)P.IH * P.IW;
   const size_t est = P.in_nchw ? plane : 1;
   const size_t e1 = P.IC > 1 ? est : 0, e2 = P.IC > 2 ? 2 * est : 0, e3 = P.IC > 3 ? 3 * est : 0;
-  bool vok = false;
-  auto issue = [&]() {
-    const int n = wi.n, iy = wi.y * TH + P.iy0 + hy0, ix = wi.x * TW + P.ix0 + hx0;
+  int issued = 0;  // tiles issued so far (wave-uniform)
+  auto issue = [&](auto setc) {
+    constexpr int st = decltype(setc)::value;
+    const bool live = issued < S;
+    ++issued;
+#if defined(SRK_ROWSR_T0)
+    const int n = 0, ty = 0, tx = 0;
+#elif defined(SRK_ROWSR_N0)
+    const int n = 0, ty = live ? wi.y : 0, tx = live ? wi.x : 0;
+#else
+    const int n = live ? wi.n : 0, ty = live ? wi.y : 0, tx = live ? wi.x : 0;
+#endif
+    const int iy = ty * TH + P.iy0 + hy0, ix = tx * TW + P.ix0 + hx0;
     wi.advance(st_n, st_y, st_x, P.tiles_x, P.tiles_y);
     if (SRK_KDBG(B.dbg) & 1) return;
-    vok = tid < npix && (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW;
+    vok[st] = tid < npix && (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW;
     const int cy = min(max(iy, 0), P.IH - 1), cx = min(max(ix, 0), P.IW - 1);
     const size_t pix = (size_t)cy * P.IW + cx;
     const float* src = P.in + (size_t)n * P.IC * plane + (P.in_nchw ? pix : pix * P.IC);
-    pv[0] = src[0];
-    pv[1] = src[e1];
-    pv[2] = src[e2];
-    pv[3] = src[e3];
+    // (one load instruction per channel the input HAS: every VMEM instruction in the consumers' store stream costs issue
+    //  time of the stores -- the layer ran in 199 us without the loads, 252 us with all of them hitting L1, 300 us as it is)
+    pv[st][0] = src[0];
+    pv[st][1] = ICN > 1 ? src[e1] : 0.f;
+    pv[st][2] = ICN > 2 ? src[e2] : 0.f;
+    pv[st][3] = ICN > 3 ? src[e3] : 0.f;
   };
-  auto commit = [&](uint4* hal) {
+  auto commit = [&](uint4* hal, auto setc) {
+    constexpr int st = decltype(setc)::value;
     if (SRK_KDBG(B.dbg) & 16) return;
-    if (tid < npix) {
-      uint2 hu, lu;
-      if constexpr (F16) {
-        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-        f16x4 h, l;
+    uint2 hu, lu;
+    if constexpr (F16) {
+      typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+      f16x4 h, l;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float xs = (vok && e < P.IC) ? pv[e] * sx : 0.f;
-          const _Float16 hh = (_Float16)xs;
-          h[e] = hh;
-          l[e] = (_Float16)(xs - (float)hh);
-        }
-        hu = __builtin_bit_cast(uint2, h);
-        lu = __builtin_bit_cast(uint2, l);
-      } else {
-        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-        bf16x4 h, l;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float xv = (vok && e < P.IC) ? pv[e] : 0.f;
-          const __bf16 hh = (__bf16)xv;
-          h[e] = hh;
-          l[e] = (__bf16)(xv - (float)hh);
-        }
-        hu = __builtin_bit_cast(uint2, h);
-        lu = __builtin_bit_cast(uint2, l);
+      for (int e = 0; e < 4; ++e) {
+        const float xs = (vok[st] && e < P.IC) ? pv[st][e] * sx : 0.f;
+        const _Float16 hh = (_Float16)xs;
+        h[e] = hh;
+        l[e] = (_Float16)(xs - (float)hh);
       }
-      hal[tid] = make_uint4(hu.x, hu.y, lu.x, lu.y);
+      hu = __builtin_bit_cast(uint2, h);
+      lu = __builtin_bit_cast(uint2, l);
+    } else {
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xv = (vok[st] && e < P.IC) ? pv[st][e] : 0.f;
+        const __bf16 hh = (__bf16)xv;
+        h[e] = hh;
+        l[e] = (__bf16)(xv - (float)hh);
+      }
+      hu = __builtin_bit_cast(uint2, h);
+      lu = __builtin_bit_cast(uint2, l);
     }
+    if (tid < npix) hal[tid] = make_uint4(hu.x, hu.y, lu.x, lu.y);  // (the wait for pv sits in front of the conversions)
   };
 
   // ---- MFMA side: halo slot of (row rg * 4 + R, column j, taps 2 kq, 2 kq + 1) = hp0 + R * HW
@@ -520,10 +550,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
     constexpr int mt = q / NTW, nt = q - mt * NTW;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, pend[nt][mt]), orsrc, (int)(pend_voff[mt] + 4u * (unsigned)coff[nt]), 0, 0);
   };
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
   if (S > 0) {
-    issue();
-    commit(hal0);
-    if (S > 1) issue();
+    issue(Set0{});                  // tile 0
+    commit(hal0, Set0{});
+    issue(Set1{});                  // tile 1
+    // eight dropped stores (nothing is parked yet): the steady state has a stage's eight stores between the two sets'
+    // loads, and the first wait inside the loop is counted for the smaller of the two distances
+    rw_static_for<0, NST>([&](auto qc) { store_slot(qc); });
+    issue(Set0{});                  // tile 2
   }
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) asm volatile("" ::"v"(bias4[nt]));
@@ -536,7 +572,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
     }
   asm volatile("" ::"v"(act_slope));
   __syncthreads();  // tile 0 visible
-  for (int s = 0; s < S; ++s) {
+#ifdef SRK_ROWSR_PROF
+  unsigned pacc[5] = {0, 0, 0, 0, 0};
+  unsigned pgrp[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // clocks per row group R of the matrix loop (SRK_ROWSR_PROF=2)
+  unsigned pprev = 0;
+#endif
+  auto stage = [&](const int s, auto nset) {  // nset: register set of tile s + 1 (= of tile s + 3)
+    const unsigned pt0 = RS_T();
+    unsigned pt1 = 0, pt2 = 0, pt3 = 0;
     const int n = wc.n, r0 = wc.y * TH, c0 = wc.x * TW;
     wc.advance(st_n, st_y, st_x, P.tiles_x, P.tiles_y);
 #pragma unroll
@@ -582,17 +625,33 @@ __global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
           }
         });
         __builtin_amdgcn_sched_barrier(0);
-        rw_static_for<(R * PER_STEP < NST ? R * PER_STEP : NST), ((R + 1) * PER_STEP < NST ? (R + 1) * PER_STEP : NST)>(
-            [&](auto qc) { store_slot(qc); });
+#ifdef SRK_ROWSR_LATE
+        constexpr int RS = R - (NR - SPREAD);  // stores ride under the LAST row groups
+#else
+        constexpr int RS = R;
+#endif
+        if constexpr (RS >= 0)
+          rw_static_for<(RS * PER_STEP < NST ? RS * PER_STEP : NST), ((RS + 1) * PER_STEP < NST ? (RS + 1) * PER_STEP : NST)>(
+              [&](auto qc) { store_slot(qc); });
+#if defined(SRK_ROWSR_PROF) && SRK_ROWSR_PROF == 2
+        {
+          const unsigned tn = RS_T();
+          pgrp[R & 7] += tn - (R == 0 ? pt0 : pprev);
+          pprev = tn;
+        }
+#endif
       });
-      if (s + 1 < S) commit(hal0 + (size_t)((s + 1) & 1) * B.NPIXp);  // (that buffer was last read in stage s - 1)
-      if (s + 2 < S) issue();
+      pt1 = RS_T();
+      commit(hal0 + (size_t)((s + 1) & 1) * B.NPIXp, nset);  // tile s + 1 (that buffer was last read in stage s - 1)
+      pt2 = RS_T();
+      issue(nset);                                            // tile s + 3
+      pt3 = RS_T();
       // tile finished: park it (C/D col = lane & 15 = pixel column, rows kq*4 + reg = 4 consecutive channels)
       const unsigned tile_off = 4u * (unsigned)epi_tile_setup(P, n, r0, c0).off0;
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt) {
         const int r = rg * MTW + mt;
-        const bool ok = r0 + r < P.PH && c0 + j < P.PW && !(SRK_KDBG(B.dbg) & 2);
+        const bool ok = s < S && r0 + r < P.PH && c0 + j < P.PW && !(SRK_KDBG(B.dbg) & 2);
         pend_voff[mt] = ok ? tile_off + 4u * (unsigned)(r * e0.RS + j * e0.CS) : kDrop;
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
@@ -611,10 +670,29 @@ __global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
         }
       }
     }
+    const unsigned pt4 = RS_T();
     __syncthreads();
+    const unsigned pt5 = RS_T();
+    (void)pt0; (void)pt1; (void)pt2; (void)pt3; (void)pt4; (void)pt5;
+    RS_ACC(0, pt0, pt1); RS_ACC(1, pt1, pt2); RS_ACC(2, pt2, pt3); RS_ACC(3, pt3, pt4); RS_ACC(4, pt4, pt5);
+  };
+  for (int s0 = 0; s0 < S; s0 += 2) {  // (an odd S ends with one dummy stage)
+    stage(s0, Set1{});
+    stage(s0 + 1, Set0{});
   }
   rw_static_for<0, NST>([&](auto qc) { store_slot(qc); });  // the last tile (S = 0: nothing parked, dropped)
   if (P.ep.y_amax) amax_commit(P.ep.y_amax, amax, blockIdx.x + wave, amax_peek(P.ep.y_amax, blockIdx.x + wave));
+#ifdef SRK_ROWSR_PROF
+  if (B.prof && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) B.prof[((size_t)blockIdx.x * 4 + wave) * 8 + i] = pacc[i];
+    B.prof[((size_t)blockIdx.x * 4 + wave) * 8 + 5] = (unsigned)S;
+#if SRK_ROWSR_PROF == 2
+#pragma unroll
+    for (int i = 0; i < 8; ++i) B.prof[(size_t)gridDim.x * 32 + ((size_t)blockIdx.x * 4 + wave) * 8 + i] = pgrp[i];
+#endif
+  }
+#endif
 }
 
 // the tile (<= 256 pixels) that covers PH x PW with the fewest tiles and a halo of at most cap_px pixels
@@ -687,10 +765,19 @@ static int rowsr_launch(const RowswParams& B, size_t lds, int grid, hipStream_t 
   const bool relu = B.P.ep.act == SRK_ACT_RELU;
   const bool f16 = B.w_descale != nullptr;
   note_kernel("k_conv_rowsr<%d%s%s>", KH, f16 ? ",f16" : "", relu ? ",relu" : "");
-  if (f16 && relu) hipLaunchKernelGGL((k_conv_rowsr<KH, true, true>), dim3(grid), dim3(256), lds, s, B);
-  else if (f16) hipLaunchKernelGGL((k_conv_rowsr<KH, true, false>), dim3(grid), dim3(256), lds, s, B);
-  else if (relu) hipLaunchKernelGGL((k_conv_rowsr<KH, false, true>), dim3(grid), dim3(256), lds, s, B);
-  else hipLaunchKernelGGL((k_conv_rowsr<KH, false, false>), dim3(grid), dim3(256), lds, s, B);
+  auto go = [&](auto f16c, auto reluc) {
+    constexpr bool F = decltype(f16c)::value, R = decltype(reluc)::value;
+    switch (B.P.IC) {
+      case 1: hipLaunchKernelGGL((k_conv_rowsr<KH, F, R, 1>), dim3(grid), dim3(256), lds, s, B); break;
+      case 2: hipLaunchKernelGGL((k_conv_rowsr<KH, F, R, 2>), dim3(grid), dim3(256), lds, s, B); break;
+      case 3: hipLaunchKernelGGL((k_conv_rowsr<KH, F, R, 3>), dim3(grid), dim3(256), lds, s, B); break;
+      default: hipLaunchKernelGGL((k_conv_rowsr<KH, F, R, 4>), dim3(grid), dim3(256), lds, s, B); break;
+    }
+  };
+  if (f16 && relu) go(std::true_type{}, std::true_type{});
+  else if (f16) go(std::true_type{}, std::false_type{});
+  else if (relu) go(std::false_type{}, std::true_type{});
+  else go(std::false_type{}, std::false_type{});
   return check_launch("conv_rowsr");
 }
 
@@ -731,6 +818,9 @@ int conv_rowsw_gather(const GatherConv& g, const float* in, const float* wp, flo
         B.ntiles = (int)ntiles;
         B.out_bytes = (unsigned)((size_t)P.N * P.OH * P.OW * P.OC * sizeof(float));
         const size_t lds = (size_t)2 * B.NPIXp * 16;
+#ifdef SRK_ROWSR_PROF
+        B.prof = g_rowsr_prof;
+#endif
         int grid = 2 * kNumCU - (2 * kNumCU) % (8 * B.nsl);
         const long want = ((ntiles + 7) / 8) * 8 * B.nsl;
         if (want < grid) grid = (int)want;
@@ -757,3 +847,8 @@ int conv_rowsw_gather(const GatherConv& g, const float* in, const float* wp, flo
 }
 
 }  // namespace srk
+
+#ifdef SRK_ROWSR_PROF
+// phase-clock build only: device buffer of 8 x uint32 per wave (4 waves per block) that the next k_conv_rowsr launches fill
+extern "C" void srk_debug_rowsr_prof(void* p) { srk::g_rowsr_prof = static_cast<unsigned*>(p); }
+#endif
