@@ -377,6 +377,13 @@ __global__ __launch_bounds__(64 * (16 / MTW + NPW), (16 / MTW + NPW) / 4) void k
     constexpr int q0 = decltype(q0c)::value;
     srk_static_for<q0, NST>([&](auto qc) { store_slot(qc); });
   };
+  // everything this wave loaded so far (biases, activation slope) has landed BEFORE the loop: a first use inside it is
+  // an s_waitcnt vmcnt(0) in every iteration -- the parking phase of every stage then waited for the write
+  // acknowledgements of the stores issued under that stage's taps (found in the compiled code in round 4; k_conv_rowsw had
+  // the fix, this kernel did not)
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) asm volatile("" ::"v"(bias4[nt]));
+  asm volatile("" ::"v"(act_slope));
   __syncthreads();  // filter and stage 0 visible
   long long ct_taps = 0, ct_park = 0, ct_wait = 0;
   const long long ct_begin = BFW_CLK();
