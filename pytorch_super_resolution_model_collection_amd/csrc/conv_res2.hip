@@ -149,7 +149,10 @@ __device__ __forceinline__ void r2_split4h(const f32x4& v, float s, uint2 (&pl)[
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) ACC[mt] = mfma16(BF[0], A[0][mt], ACC[mt]);        \
   }
 
-template <int NP, bool BWD, bool F16 = false>
+// PF: the NEXT tap's operand reads are issued in front of the current tap's MFMAs (two fragment sets: ~180 VGPRs, one
+// block per CU) -- for grids of at most one block per CU (the 16-patch EDSR shard), where nothing else hides the LDS
+// latency at the start of every tap.
+template <int NP, bool BWD, bool F16 = false, bool PF = false>
 __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
   static_assert(!F16 || (NP == 2 && !BWD), "f16x3 is the two-plane forward arithmetic");
   constexpr int TH = R2_TS, MT1A = R2_MT1A, MT2 = R2_MT2, MT2A = R2_MT2A;
@@ -272,6 +275,25 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
     }
     constexpr int plane1 = PL1;
     const uint4* h1c = hal1 + kgrp * NP * plane1;
+    if constexpr (PF) {
+      uint4 a2[2][NP][R2_MT1];
+      auto lda = [&](int t, uint4 (&a)[NP][R2_MT1]) {
+        const int toff = (t / 3) * R2_H1 + (t % 3);
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int mt = 0; mt < R2_MT1; ++mt) a[p][mt] = h1c[p * plane1 + hpA[mt] + toff];
+      };
+      lda(0, a2[0]);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        load_b(t + 2, bq[(t + 2) % 3]);
+        if (t + 1 < 9) lda(t + 1, a2[(t + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        SRK_R2_PASSES(acc1, a2[t & 1], bq[t % 3], R2_MT1)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       load_b(t + 2, bq[(t + 2) % 3]);
@@ -287,6 +309,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
           for (int mt = 0; mt < R2_MT1; ++mt) a[p][mt] = h1c[p * plane1 + hpA[mt] + toff];
         SRK_R2_PASSES(acc1, a, bq[t % 3], R2_MT1)
       }
+    }
     }
   }
 
@@ -401,6 +424,25 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
     }
     constexpr int plane2 = PL2;
     const uint4* h2c = hal2 + kgrp * NP * plane2;
+    if constexpr (PF) {
+      uint4 a2[2][NP][MT2];
+      auto lda = [&](int t, uint4 (&a)[NP][MT2]) {
+        const int toff = (t / 3) * R2_MW + (t % 3);
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int mt = 0; mt < MT2; ++mt) a[p][mt] = h2c[p * plane2 + hpB[mt] + toff];
+      };
+      lda(0, a2[0]);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (t + 2 < 9) load_b(9 + t + 2, bq[(t + 2) % 3]);
+        if (t + 1 < 9) lda(t + 1, a2[(t + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        SRK_R2_PASSES(acc2, a2[t & 1], bq[t % 3], MT2)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       if (t + 2 < 9) load_b(9 + t + 2, bq[(t + 2) % 3]);
@@ -414,6 +456,7 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
           for (int mt = 0; mt < MT2; ++mt) a[p][mt] = h2c[p * plane2 + hpB[mt] + toff];
         SRK_R2_PASSES(acc2, a, bq[t % 3], MT2)
       }
+    }
     }
   }
   R2_PROF(6);
@@ -476,10 +519,21 @@ bool conv_res2_supported(int N, int H, int W, int C) {
 template <int NP, bool BWD, bool F16 = false>
 static int r2_launch(const Res2Params& R, hipStream_t s) {
   const size_t lds = (size_t)2 * NP * (R2_PL1 + R2_PL2) * 16;
+  const size_t grid = (size_t)R.N * R.tiles_y * R.tiles_x;
+  if constexpr (NP == 2) {
+    // at most one block per CU: the variant that reads the next tap's operands ahead (SRK_RES2_PF=0: off)
+    if (grid <= (size_t)kNumCU && env_int("SRK_RES2_PF", 1) != 0) {
+      static LdsLimit limp;
+      limp.ensure(reinterpret_cast<const void*>(&k_res2<NP, BWD, F16, true>), lds);
+      note_kernel("k_res2<%d,%d%s,pf>", NP, (int)BWD, F16 ? ",f16" : "");
+      hipLaunchKernelGGL((k_res2<NP, BWD, F16, true>), dim3((unsigned)grid), dim3(512), lds, s, R);
+      return check_launch("conv_res2");
+    }
+  }
   static LdsLimit lim;
   lim.ensure(reinterpret_cast<const void*>(&k_res2<NP, BWD, F16>), lds);
   note_kernel("k_res2<%d,%d%s>", NP, (int)BWD, F16 ? ",f16" : "");
-  hipLaunchKernelGGL((k_res2<NP, BWD, F16>), dim3((unsigned)((size_t)R.N * R.tiles_y * R.tiles_x)), dim3(512), lds, s, R);
+  hipLaunchKernelGGL((k_res2<NP, BWD, F16>), dim3((unsigned)grid), dim3(512), lds, s, R);
   return check_launch("conv_res2");
 }
 

@@ -10,6 +10,7 @@ lib = pkg._lib.load()
 torch.manual_seed(1234)
 net = pkg.ESPCNNet(3, 64, 4); net.weight_init(); net.to(dev).eval()
 x = torch.rand(64, 3, 256, 256, device=dev)
+if os.environ.get("NHWC"): x = x.contiguous(memory_format=torch.channels_last)   # first layer reads NHWC in place
 pkg.ops.set_precision(os.environ.get("PRECISION", "mixed"))
 which = [int(a) for a in sys.argv[1:]] or [0, 1, 2]
 with torch.no_grad():
