@@ -53,6 +53,7 @@ struct BfwParams {
   // channels; slice sl of tile range i is block 8 * (nsl * i + sl) + xcd -- the nsl blocks that walk the same tiles are
   // neighbours on one XCD and start together, so the halo the first one pulls into that XCD's L2 serves the others.
   int nsl, NBfull, OCb;
+  int late;  // consumer waves 4 - 7 park a finished tile at the START of the next stage (see the consumer loop)
   unsigned out_bytes;  // size of the output tensor (buffer descriptor of the consumers' stores)
   int dbg;  // ablation (SRK_DBG): 1 no global loads, 2 no epilogue, 4 no MFMA loop, 16 no LDS commit, 1024 no deferred stores
   long long* prof;  // experiments build only (srk_debug_bfw_prof): per block 16 int64 -- clock64() sums of the first producer
@@ -377,6 +378,42 @@ __global__ __launch_bounds__(64 * (16 / MTW + NPW), (16 / MTW + NPW) / 4) void k
     constexpr int q0 = decltype(q0c)::value;
     srk_static_for<q0, NST>([&](auto qc) { store_slot(qc); });
   };
+  // Parking (descale, bias, activation, output mask, running maximum: accumulators -> `pend`) takes ~1 k clocks in which
+  // the wave issues no MFMA, and every consumer wave of the block did it at the same moment, at the end of a tile's last
+  // stage: the matrix pipe idled through it (13 - 15 % of a consumer's stage).  With B.late the waves 4 - 7
+  // -- each shares its SIMD with one of the waves 0 - 3 -- park a finished tile at the START of the next stage instead, from
+  // the accumulators they are about to clear: one wave's parking runs under the other wave's taps at both ends of a
+  // stage.  (Pays for single-chunk layers, where every stage ends a tile; the host sets it for those.)
+  const bool late_wave = B.late && TT > 0 && NCW == 8 && (__builtin_amdgcn_readfirstlane(wave) & 4);
+  bool park_due = false;
+  int pk_n = 0, pk_r0 = 0, pk_c0 = 0;
+  auto park = [&](int n, int r0, int c0) {
+    // tile finished (C/D col = lane & 15 = pixel, rows kq*4 + reg = 4 consecutive channels per M tile): park it
+    const unsigned tile_off = 4u * (unsigned)epi_tile_setup(P, n, r0, c0).off0;
+    pend_mask = 0;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+      const int r = pix_ok[mt] >> 16, c = pix_ok[mt] & 0xffff;
+      const bool pok = pix_ok[mt] >= 0 && r0 + r < P.PH && c0 + c < P.PW;
+      if (pok) pend_mask |= 1 << mt;
+      pend_voff[mt] = pok ? tile_off + 4u * (unsigned)poff[mt] : kDrop;
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        f32x4 v = acc[nt][mt];
+        if constexpr (F16) v *= dsc;
+        v += bias4[nt];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : act_slope * v[e];
+        if constexpr (OMASK) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = om[nt][mt][e] > 0.f ? v[e] : 0.f;
+        }
+        pend[nt][mt] = v;
+        if (P.ep.y_amax && ((pend_mask >> mt) & 1)) amax = abs_max4(amax, v);
+      }
+    }
+    pend_live = true;
+  };
   // everything this wave loaded so far (biases, activation slope) has landed BEFORE the loop: a first use inside it is
   // an s_waitcnt vmcnt(0) in every iteration -- the parking phase of every stage then waited for the write
   // acknowledgements of the stores issued under that stage's taps (found in the compiled code in round 4; k_conv_rowsw had
@@ -391,6 +428,10 @@ __global__ __launch_bounds__(64 * (16 / MTW + NPW), (16 / MTW + NPW) / 4) void k
     const long long k0 = BFW_CLK();
     int n, r0, c0, cc;
     decode(n, r0, c0, cc);
+    if (park_due) {  // (late waves: the previous stage ended a tile; cc == 0 here)
+      park(pk_n, pk_r0, pk_c0);
+      park_due = false;
+    }
     if (cc == 0) {
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt)
@@ -484,35 +525,15 @@ __global__ __launch_bounds__(64 * (16 / MTW + NPW), (16 / MTW + NPW) / 4) void k
     }
     const long long k1 = BFW_CLK();
     if (cc == B.ICc - 1 && wave_live && !(SRK_KDBG(B.dbg) & 2)) {
-      // tile finished (C/D col = lane & 15 = pixel, rows kq*4 + reg = 4 consecutive channels per M tile): park it
-      if (pend_live) flush_from(std::integral_constant<int, 0>{});  // (cannot happen with TT > 0)
-      const unsigned tile_off = 4u * (unsigned)epi_tile_setup(P, n, r0, c0).off0;
-      pend_mask = 0;
-#pragma unroll
-      for (int mt = 0; mt < MTW; ++mt) {
-        const int r = pix_ok[mt] >> 16, c = pix_ok[mt] & 0xffff;
-        const bool pok = pix_ok[mt] >= 0 && r0 + r < P.PH && c0 + c < P.PW;
-        if (pok) pend_mask |= 1 << mt;
-        pend_voff[mt] = pok ? tile_off + 4u * (unsigned)poff[mt] : kDrop;
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-          f32x4 v = acc[nt][mt];
-          if constexpr (F16) v *= dsc;
-          v += bias4[nt];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : act_slope * v[e];
-          if constexpr (OMASK) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = om[nt][mt][e] > 0.f ? v[e] : 0.f;
-          }
-          pend[nt][mt] = v;
-          if (P.ep.y_amax && ((pend_mask >> mt) & 1)) amax = abs_max4(amax, v);
+      if (late_wave && s != S - 1) {  // parked at the top of the next stage, while the SIMD's other consumer wave runs its taps
+        park_due = true;
+        pk_n = n; pk_r0 = r0; pk_c0 = c0;
+      } else {
+        park(n, r0, c0);
+        if (TT == 0 || s == S - 1 || (SRK_KDBG(B.dbg) & 1024)) {  // no unrolled tap loop to ride under / last tile of this block
+          flush_from(std::integral_constant<int, 0>{});
+          pend_live = false;
         }
-      }
-      pend_live = true;
-      if (TT == 0 || s == S - 1 || (SRK_KDBG(B.dbg) & 1024)) {  // no unrolled tap loop to ride under / last tile of this block
-        flush_from(std::integral_constant<int, 0>{});
-        pend_live = false;
       }
     }
     const long long k2 = BFW_CLK();
@@ -709,6 +730,7 @@ int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float
     const int perm = SRK_EXP_INT("SRK_BFW_PERM", 1);
     const int w16 = SRK_EXP_INT("SRK_BFW_W16", 0);
     B.perm = perm;
+    B.late = B.ICc == 1 && env_int("SRK_BFW_LATE", 1) != 0;   // (B.ICc is set above)
     TilePick best{};
     if (px_cap < 64 || P.is != 1) return -1;
     if (!bfw_pick_tile(256, P.PH, P.PW, P.KHv, P.KWv, px_cap, perm, w16 ? 16 : 1, best)) return -1;
