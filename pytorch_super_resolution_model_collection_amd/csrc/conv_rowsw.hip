@@ -375,11 +375,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_rowsw(RowswParams B) {
 // ---------------------------------------------------------------------------------------------------------------------
 // k_conv_rowsr: the same layer with ROW-REUSED pixel fragments and the filter in registers (round 4).
 //
-// What paced k_conv_rowsw on the c2 first layer (3 -> 64, 5x5, 64 x 256x256; SRK_ROWSW_DBG ablations, 318 us): skeleton
-// (staging, parking, barriers) alone 105 us, + the MFMA loop 244 us, + the stores 318 us, where the layer's 7.9 M MFMAs are
-// 102 us of matrix issue.  Two things: (1) per 32 pixels a wave read the whole filter (40 x ds_read_b128) and 20 pixel
-// fragments for 120 MFMAs -- 3840 clocks of LDS reads per 256-pixel stage and CU beside 3840 clocks of matrix issue per SIMD;
-// (2) all eight waves of the one block per CU ran their matrix phase and their VALU phases (staging conversion, parking
+// k_conv_rowsw on the c2 first layer (3 -> 64, 5x5, 64 x 256x256; builds with the ablation word as a compile-time
+// constant, -DSRK_KDBG_CONST, 310 us): skeleton (staging, parking, barriers) alone 66 us, + the MFMA loop 219 us, + the
+// stores 310 us, where the layer's 7.9 M MFMAs are 102 us of matrix issue.  Two things: (1) per 32 pixels a wave read the
+// whole filter (40 x ds_read_b128) and 20 pixel fragments for 120 MFMAs -- 480 reads = 1920 LDS cycles per 256-pixel
+// stage and CU beside 3840 clocks of matrix issue per SIMD, every first read of a K step in front of its MFMAs; (2) all
+// eight waves of the one block per CU ran their matrix phase and their VALU phases (staging conversion, parking
 // arithmetic) in lockstep behind one barrier per stage, so the matrix pipe idled through every VALU phase.
 // Here:
 //   * a wave owns 4 consecutive tile rows x 16 columns x 32 output channels.  The K slots of a step are 8 taps of ONE
@@ -467,13 +468,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
     constexpr int st = decltype(setc)::value;
     const bool live = issued < S;
     ++issued;
-#if defined(SRK_ROWSR_T0)
-    const int n = 0, ty = 0, tx = 0;
-#elif defined(SRK_ROWSR_N0)
-    const int n = 0, ty = live ? wi.y : 0, tx = live ? wi.x : 0;
-#else
     const int n = live ? wi.n : 0, ty = live ? wi.y : 0, tx = live ? wi.x : 0;
-#endif
     const int iy = ty * TH + P.iy0 + hy0, ix = tx * TW + P.ix0 + hx0;
     wi.advance(st_n, st_y, st_x, P.tiles_x, P.tiles_y);
     if (SRK_KDBG(B.dbg) & 1) return;
@@ -625,14 +620,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
           }
         });
         __builtin_amdgcn_sched_barrier(0);
-#ifdef SRK_ROWSR_LATE
-        constexpr int RS = R - (NR - SPREAD);  // stores ride under the LAST row groups
-#else
-        constexpr int RS = R;
-#endif
-        if constexpr (RS >= 0)
-          rw_static_for<(RS * PER_STEP < NST ? RS * PER_STEP : NST), ((RS + 1) * PER_STEP < NST ? (RS + 1) * PER_STEP : NST)>(
-              [&](auto qc) { store_slot(qc); });
+        rw_static_for<(R * PER_STEP < NST ? R * PER_STEP : NST), ((R + 1) * PER_STEP < NST ? (R + 1) * PER_STEP : NST)>(
+            [&](auto qc) { store_slot(qc); });
 #if defined(SRK_ROWSR_PROF) && SRK_ROWSR_PROF == 2
         {
           const unsigned tn = RS_T();
