@@ -117,6 +117,12 @@ typedef struct srk_epilogue {
   float* y_amax;             /* optional: SRK_AMAX_FLOATS floats that receive (atomic max) max|y| of this call's output
                                 -- the next layer's x_amax.  Honoured by the kernels listed at srk_conv2d_f16x3_supported;
                                 ask srk_last_conv_wrote_amax() after the call */
+  double* bn_partial;        /* optional (forward): the conv leaves the per-channel column sums of its OUTPUT for the
+                                BatchNorm behind it (base_networks.py:46,117: conv -> bn) -- row t of
+                                [tiles][2 * Cout] doubles = {sum y, sum y*y} over the pixels of tile t, summed in a fixed
+                                order; room for N * ceil(OH / 8) * ceil(OW / 8) rows.  Honoured by the per-tile 64 -> 64
+                                3x3 kernel (k_c64) only: srk_last_conv_bn_partial_rows() says how many rows the call wrote
+                                (0: none -- run srk_bn_stats_finalize as usual), srk_bn_finalize_partials() consumes them */
 } srk_epilogue;
 
 /* Activation-gradient prologue of the backward kernels: the incoming gradient dy is
@@ -139,6 +145,9 @@ const char* srk_last_kernel_name(void);
  * srk_epilogue.y_amax (and y_amax was given), else 0: the caller may hand the slots to the next layer as x_amax only
  * then (base_networks.py:101-104: a ConvBlock's output is the next block's input). */
 int srk_last_conv_wrote_amax(void);
+/* Rows of srk_epilogue.bn_partial the calling thread's last srk_conv2d_forward filled (0: the kernel it dispatched to
+ * does not keep them, or none were asked for). */
+int srk_last_conv_bn_partial_rows(void);
 /* Output spatial size of a conv / transposed conv along one axis (torch semantics). */
 int srk_conv_out_dim(int in, int k, int stride, int pad, int transposed, int out_pad);
 
@@ -325,6 +334,12 @@ int srk_bn_finalize(const double* stats, double count, float* save_mean, float* 
 int srk_bn_stats_finalize(const float* x, double* stats, size_t rows, int C, float* save_mean, float* save_rstd,
                           float* running_mean, float* running_var, float momentum, float eps,
                           int64_t* num_batches_tracked, void* workspace, void* stream);
+/* The second launch of srk_bn_stats_finalize alone, on column sums a convolution's epilogue left
+ * (srk_epilogue.bn_partial: `splits` rows of [2*C] doubles): mean / rstd / running statistics of base_networks.py:46,117's
+ * BatchNorm without the pass over the activation.  `rows` = N*H*W of the activation. */
+int srk_bn_finalize_partials(const double* partials, int splits, double* stats, size_t rows, int C, float* save_mean,
+                             float* save_rstd, float* running_mean, float* running_var, float momentum, float eps,
+                             int64_t* num_batches_tracked, void* stream);
 /* y_amax (optional, here and in srk_bn_apply_act): SRK_AMAX_FLOATS floats that receive max|y| -- the x_amax of a
  * following SRK_ALGO_MFMA_F16X3 convolution (16-byte path only: C % 4 == 0, aligned tensors). */
 int srk_bn_apply(const float* x, float* y, const float* mean, const float* rstd, const float* gamma,

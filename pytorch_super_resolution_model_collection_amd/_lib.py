@@ -40,7 +40,7 @@ class Epilogue(ctypes.Structure):
     """struct srk_epilogue"""
     _fields_ = [("bias", c_vp), ("prelu_weight", c_vp), ("residual", c_vp), ("slope", c_float),
                 ("act", ctypes.c_int32), ("prelu_n", ctypes.c_int32), ("ps_r", ctypes.c_int32),
-                ("x_amax", c_vp), ("y_amax", c_vp)]
+                ("x_amax", c_vp), ("y_amax", c_vp), ("bn_partial", c_vp)]
 
 
 class BwdMask(ctypes.Structure):
@@ -54,6 +54,7 @@ _PROTOTYPES = {
     "srk_last_error_string": (ctypes.c_char_p, []),
     "srk_last_kernel_name": (ctypes.c_char_p, []),
     "srk_last_conv_wrote_amax": (c_int, []),
+    "srk_last_conv_bn_partial_rows": (c_int, []),
     "srk_conv_out_dim": (c_int, [c_int] * 6),
     "srk_nchw_to_nhwc": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_vp]),
     "srk_nhwc_to_nchw": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_vp]),
@@ -100,6 +101,7 @@ _PROTOTYPES = {
     "srk_bn_workspace_bytes": (c_size, [c_int]),
     "srk_bn_finalize": (c_int, [c_vp, ctypes.c_double, c_f, c_f, c_f, c_f, c_float, c_float, c_int, c_vp, c_vp]),
     "srk_bn_stats_finalize": (c_int, [c_f, c_vp, c_size, c_int, c_f, c_f, c_f, c_f, c_float, c_float, c_vp, c_vp, c_vp]),
+    "srk_bn_finalize_partials": (c_int, [c_vp, c_int, c_vp, c_size, c_int, c_f, c_f, c_f, c_f, c_float, c_float, c_vp, c_vp]),
     "srk_bn_backward_stats_grads": (c_int, [c_f, c_f, c_f, c_f, c_vp, c_size, c_int, c_f, c_f, c_vp, c_vp]),
     "srk_bn_apply": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_size, c_int, c_int, c_float, c_f, c_vp]),
     "srk_bn_apply_act": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_size, c_int, c_int, c_float, c_f, c_int, c_f, c_f, c_vp]),

@@ -155,16 +155,24 @@ class ResnetBlock(_Block):
             # as in the no-norm block: the skip gradient (= the block output gradient, handed over by the second
             # BatchNorm's backward) is added by conv1's data-gradient kernel -- no fan-in pass of its own
             box = ops.GradBox()
-            out = self.bn.run(self.conv1.run(x, add_box=box), kind, slope, pw)
-            return self.bn.run(self.conv2.run(out), residual=x, res_box=box)
+            with ops.bn_partial_request():   # the convs leave the BatchNorm's column sums where their kernel can
+                c1 = self.conv1.run(x, add_box=box)
+            out = self.bn.run(c1, kind, slope, pw)
+            with ops.bn_partial_request():
+                c2 = self.conv2.run(out)
+            return self.bn.run(c2, residual=x, res_box=box)
         if training:
             x, residual = ops.fork(x)  # gradient fan-in summed by srk_axpby
         else:
             residual = x
         if fused_bn:
             # act(bn(conv1)) and bn(conv2) + x each in the BatchNorm's own launches (ONE shared bn: base_networks.py:117)
-            out = self.bn.run(self.conv1.run(x), kind, slope, pw)
-            return self.bn.run(self.conv2.run(out), residual=residual)
+            with ops.bn_partial_request(training):
+                c1 = self.conv1.run(x)
+            out = self.bn.run(c1, kind, slope, pw)
+            with ops.bn_partial_request(training):
+                c2 = self.conv2.run(out)
+            return self.bn.run(c2, residual=residual)
         out = self.bn(self.conv1.run(x))
         if self.activation is not None:
             out = self.act(out)

@@ -67,6 +67,8 @@ int env_int(const char* name, int dflt) {
 static thread_local int g_amax_written = 0;
 
 void note_amax_written(bool written) { g_amax_written = written ? 1 : 0; }
+static thread_local int g_bn_partial_rows = 0;
+void note_bn_partial_rows(int rows) { g_bn_partial_rows = rows; }
 
 // conv_tapn.hip
 bool conv_tapn_gather_supported(const GatherConv& g, const float* in, const float* mask_y);
@@ -275,6 +277,7 @@ extern "C" const char* srk_last_error_string(void) { return g_err; }
 extern "C" const char* srk_last_kernel_name(void) { return g_kernel; }
 
 extern "C" int srk_last_conv_wrote_amax(void) { return g_amax_written; }
+extern "C" int srk_last_conv_bn_partial_rows(void) { return g_bn_partial_rows; }
 
 extern "C" int srk_conv_out_dim(int in, int k, int stride, int pad, int transposed, int out_pad) {
   if (in <= 0 || k <= 0 || stride <= 0 || pad < 0) return -1;
@@ -285,6 +288,7 @@ extern "C" int srk_conv_out_dim(int in, int k, int stride, int pad, int transpos
 extern "C" int srk_conv2d_forward(const srk_conv_desc* d, const float* x, const float* w_packed_fwd, float* y,
                                   const srk_epilogue* ep_in, void* stream) {
   note_amax_written(false);
+  note_bn_partial_rows(0);
   int rc = validate_desc(d, "conv2d_forward");
   if (rc) return rc;
   SRK_REQUIRE(x && w_packed_fwd && y, "conv2d_forward: null tensor pointer");

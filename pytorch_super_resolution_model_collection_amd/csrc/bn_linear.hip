@@ -877,6 +877,22 @@ extern "C" int srk_bn_stats_finalize(const float* x, double* stats, size_t rows,
   return bn_colsum(0, x, nullptr, nullptr, nullptr, stats, rows, C, workspace, (hipStream_t)stream, fu);
 }
 
+extern "C" int srk_bn_finalize_partials(const double* partials, int splits, double* stats, size_t rows, int C,
+                                        float* save_mean, float* save_rstd, float* running_mean, float* running_var,
+                                        float momentum, float eps, int64_t* num_batches_tracked, void* stream) {
+  SRK_REQUIRE(partials && stats && save_mean && save_rstd && splits > 0 && rows > 0 && C > 0, "bn_finalize_partials: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  if (splits > 64)
+    hipLaunchKernelGGL((k_bn_reduce_fused<0, 16>), dim3(cdiv(C, 64)), dim3(1024), 0, s, partials, stats, splits, C,
+                       (double)rows, save_mean, save_rstd, running_mean, running_var, momentum, eps,
+                       (long long*)num_batches_tracked);
+  else
+    hipLaunchKernelGGL((k_bn_reduce_fused<0, 4>), dim3(cdiv(C, 64)), dim3(256), 0, s, partials, stats, splits, C,
+                       (double)rows, save_mean, save_rstd, running_mean, running_var, momentum, eps,
+                       (long long*)num_batches_tracked);
+  return check_launch("bn_finalize_partials");
+}
+
 extern "C" int srk_bn_backward_stats_grads(const float* dy, const float* x, const float* mean, const float* rstd,
                                            double* dstats, size_t rows, int C, float* dgamma, float* dbeta, void* workspace,
                                            void* stream) {

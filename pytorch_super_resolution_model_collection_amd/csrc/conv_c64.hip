@@ -40,7 +40,25 @@ struct C64Params {
   const float* x_amax;  // F16
   float* y_amax;        // optional
   const float* wd;      // F16: trailer {2^-kw, 2^kw}
+  double* bn_partial;   // optional (forward): row blockIdx.x of [tiles][2 * 64] = {sum, sum of squares} of this tile's output
 };
+
+// sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15) of a double, by four row rotations on its two halves; every
+// lane gets a total (lane 0 of the row is the one that is used: a fixed order of additions)
+template <int CTRL>
+__device__ __forceinline__ double c64_rot_d(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double c64_row_sum_d(double v) {
+  v += c64_rot_d<0x121>(v);   // row_ror:1
+  v += c64_rot_d<0x122>(v);   // row_ror:2
+  v += c64_rot_d<0x124>(v);   // row_ror:4
+  v += c64_rot_d<0x128>(v);   // row_ror:8
+  return v;
+}
 
 #define c64_mfma mfma16x<F16>
 template <int NP, bool BWD, bool F16 = false>
@@ -48,6 +66,7 @@ __global__ __launch_bounds__(512, 2) void k_c64(C64Params R) {
   static_assert(!F16 || NP == 2, "f16x3 is a two-plane arithmetic");
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   __shared__ float c64_amx[8];
+  __shared__ double c64_bn[2][2][C64_C];   // [chunk group][sum | sum of squares][channel] (bn_partial)
   float sx = 1.f, dsc = 1.f;
   if constexpr (F16) {
     const int kx = amax_scale_exp(amax_read(R.x_amax));
@@ -187,6 +206,7 @@ __global__ __launch_bounds__(512, 2) void k_c64(C64Params R) {
   }
   __syncthreads();
   float oamax = 0.f;
+  double bs[4] = {0.0, 0.0, 0.0, 0.0}, bq2[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int mt = kgrp * 2 + q;
@@ -201,6 +221,36 @@ __global__ __launch_bounds__(512, 2) void k_c64(C64Params R) {
     if (ooff[q] >= 0) {
       *reinterpret_cast<f32x4*>(R.out + img + ooff[q]) = v;
       if (R.y_amax) oamax = abs_max4(oamax, v);
+      if (!BWD && R.bn_partial) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const double d = (double)v[e];
+          bs[e] += d;
+          bq2[e] += d * d;   // (exact products, as in k_bn_colsum's forward mode)
+        }
+      }
+    }
+  }
+  // Column sums of the stored tile for the BatchNorm behind this conv (srk_epilogue.bn_partial): the lane's two pixels,
+  // the 16 pixel columns of its DPP row, then the two chunk groups (which finish different pixel tiles) through LDS --
+  // a fixed order, one row of the partial slab per block, no atomics.
+  if (!BWD && R.bn_partial) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bs[e] = c64_row_sum_d(bs[e]);
+      bq2[e] = c64_row_sum_d(bq2[e]);
+    }
+    if (col == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        c64_bn[kgrp][0][ow * 16 + kq * 4 + e] = bs[e];
+        c64_bn[kgrp][1][ow * 16 + kq * 4 + e] = bq2[e];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * C64_C) {
+      const int which = tid >> 6, c = tid & 63;
+      R.bn_partial[(size_t)blockIdx.x * (2 * C64_C) + which * C64_C + c] = c64_bn[0][which][c] + c64_bn[1][which][c];
     }
   }
   if (R.y_amax) amax_commit_block(R.y_amax, oamax, blockIdx.x, c64_amx, 8, peeked);
@@ -250,6 +300,8 @@ int conv_c64_gather(const GatherConv& g, const float* in, const float* wp, float
   R.x_amax = ep.x_amax;
   R.y_amax = ep.y_amax;
   const bool bwd = g.trans != 0;
+  R.bn_partial = bwd ? nullptr : ep.bn_partial;
+  if (R.bn_partial) note_bn_partial_rows(R.N * R.tiles_y * R.tiles_x);
   if (planes == 4) {
     if (bwd || !ep.x_amax) {
       set_error("conv_c64: f16x3 is a forward arithmetic and needs x_amax");

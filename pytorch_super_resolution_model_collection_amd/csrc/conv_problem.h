@@ -26,6 +26,7 @@ struct Epi {
   const float* x_amax;  // SRK_AMAX_SLOTS floats (f16x3 kernels)
   float* y_amax;        // optional running max of |out| (kernels that support it)
   const float* out_relu;  // optional: out <- out * (out_relu > 0), a tensor of out's shape (k_conv_bfw<2,9,2> only)
+  double* bn_partial;     // optional: per-tile column sums of the output (srk_epilogue.bn_partial; k_c64 forward only)
 };
 
 inline Epi make_epi(const srk_epilogue* e) {
@@ -40,6 +41,7 @@ inline Epi make_epi(const srk_epilogue* e) {
     r.ps_r = e->ps_r > 1 ? e->ps_r : 0;
     r.x_amax = e->x_amax;
     r.y_amax = e->y_amax;
+    r.bn_partial = e->bn_partial;
   }
   return r;
 }

@@ -16,6 +16,8 @@ void note_kernel(const char* fmt, ...);
 // A conv launcher whose kernel keeps the running maximum of what it stores (srk_epilogue.y_amax) says so here; read back
 // through srk_last_conv_wrote_amax().  Reset by every srk_conv2d_forward call.
 void note_amax_written(bool written);
+// ... and a launcher that filled srk_epilogue.bn_partial says how many rows (srk_last_conv_bn_partial_rows()).
+void note_bn_partial_rows(int rows);
 
 // Environment switches.  env_int / env_str read a variable ONCE per process and answer from a table
 // afterwards -- a dispatch must not pay getenv's environment scan -- unless SRK_ENV_LIVE is set when the library is first

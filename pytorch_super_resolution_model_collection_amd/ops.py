@@ -340,6 +340,30 @@ def pack_bias_ps(bias, ps_r):
     return bp
 
 
+# BatchNorm column sums from the producing conv's epilogue (srk_epilogue.bn_partial): a block that runs conv -> BatchNorm
+# in training asks for them around the conv call; a kernel that keeps them (k_c64: the per-tile 64 -> 64 3x3 kernel of
+# SRGAN's generator) tags its output, and _BatchNorm.forward then skips its own pass over the activation.
+BN_PARTIAL = os.environ.get("SRK_BN_PARTIAL", "1") != "0"
+_BN_REQ = [0]
+
+
+class bn_partial_request(object):
+    """with ops.bn_partial_request(on): y = conv.run(x)   -- y may carry `_srk_bn_partial` afterwards"""
+
+    def __init__(self, on=True):
+        self.on = bool(on) and BN_PARTIAL
+
+    def __enter__(self):
+        if self.on:
+            _BN_REQ[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            _BN_REQ[0] -= 1
+        return False
+
+
 def conv_forward_raw(x, wp, bias_p, weight_shape_src, cfg, prelu_w=None, residual=None, role="infer", x_nchw=False):
     """Launch srk_conv2d_forward on already-packed weights. x must be NHWC-dense (or NCHW with x_nchw)."""
     lib = _lib.load()
@@ -350,7 +374,13 @@ def conv_forward_raw(x, wp, bias_p, weight_shape_src, cfg, prelu_w=None, residua
     if residual is not None and tuple(residual.shape) != tuple(y.shape):
         raise RuntimeError("conv: residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
     ep = Epilogue(ptr(bias_p), ptr(prelu_w), ptr(residual), cfg.slope, cfg.act,
-                  0 if prelu_w is None else prelu_w.numel(), cfg.ps_r, None, None)
+                  0 if prelu_w is None else prelu_w.numel(), cfg.ps_r, None, None, None)
+    bnp = None
+    if (_BN_REQ[0] > 0 and role != "infer" and d.Cin == 64 and d.Cout == 64 and d.KH == 3 and d.KW == 3 and r == 1
+            and cfg.act == ACT_NONE):
+        # (the shape k_c64 covers; whether THAT kernel runs is the library's decision -- asked after the call)
+        bnp = torch.empty((d.N * ((d.OH + 7) // 8) * ((d.OW + 7) // 8), 2 * d.Cout), dtype=torch.float64, device=x.device)
+        ep.bn_partial = ptr(bnp)
     ya = None
     if d.algo == _lib.ALGO_MFMA_F16X3:      # asked for by name (ConvCfg.algo): the maximum is computed if nobody left one
         ep.x_amax = ptr(amax_of(x))
@@ -373,6 +403,10 @@ def conv_forward_raw(x, wp, bias_p, weight_shape_src, cfg, prelu_w=None, residua
         d.x_nchw = 0
     check(lib.srk_conv2d_forward(ctypes.byref(d), ptr(x), ptr(wp), ptr(y), ctypes.byref(ep), stream_ptr()),
           "srk_conv2d_forward")
+    if bnp is not None:
+        rows_p = int(lib.srk_last_conv_bn_partial_rows())
+        if rows_p > 0:
+            y._srk_bn_partial = (bnp, rows_p, _ver(y))
     if ya is not None and lib.srk_last_conv_wrote_amax():
         _tag_amax(y, ya)
     elif F16X3 and d.algo in (_lib.ALGO_MFMA, _lib.ALGO_MFMA_BF16X6):
@@ -1169,7 +1203,15 @@ class _BatchNorm(torch.autograd.Function):
             if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
                 raise RuntimeError("batch_norm: num_batches_tracked must be a CUDA int64 tensor")
             nbt_p = None if nbt is None else ctypes.c_void_p(nbt.data_ptr())
-            if sync_group is None:   # statistics + finalize: column sums, then reduce + mean / rstd / running stats
+            part = getattr(x, "_srk_bn_partial", None)
+            if part is not None and (part[2] != _ver(x) or part[0].shape[1] != 2 * c):
+                part = None
+            if sync_group is None and part is not None:
+                # the conv that produced x left its column sums (k_c64's epilogue): reduce + finalize only
+                check(lib.srk_bn_finalize_partials(ptr(part[0]), part[1], ptr(stats), rows, c, ptr(mean), ptr(rstd),
+                                                   ptr(running_mean), ptr(running_var), momentum, eps, nbt_p,
+                                                   stream_ptr()), "srk_bn_finalize_partials")
+            elif sync_group is None:   # statistics + finalize: column sums, then reduce + mean / rstd / running stats
                 check(lib.srk_bn_stats_finalize(ptr(x), ptr(stats), rows, c, ptr(mean), ptr(rstd), ptr(running_mean),
                                                 ptr(running_var), momentum, eps, nbt_p, ptr(ws), stream_ptr()),
                       "srk_bn_stats_finalize")

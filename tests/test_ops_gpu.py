@@ -1079,3 +1079,60 @@ def test_wgrad_stride2_bf16x3(gpu, monkeypatch, cin, cout, H, W, N, bias):
     assert not torch.equal(out["s2"][0], out["fp32"][0])      # (the bf16x3 kernel did run)
     if bias:
         assert rel_err(out["s2"][1], ref_b) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(16, 32, 32), (3, 13, 21), (2, 17, 9)])
+def test_conv_c64_leaves_batchnorm_column_sums(gpu, shape):
+    """srk_epilogue.bn_partial (base_networks.py:46,117: conv -> bn): k_c64's forward leaves {sum y, sum y^2} per tile and
+    channel of what it stored, srk_bn_finalize_partials turns them into the statistics srk_bn_stats_finalize computes
+    from the activation itself -- through the C ABI against float64, then through ResnetBlock(norm='batch') with the
+    protocol on and off (ragged tiles included)."""
+    pkg = _pkg()
+    ops, L, lib = pkg.ops, pkg._lib, pkg._lib.load()
+    n, h, w = shape
+    x = fill.randn((n, 64, h, w), 41 + h).to(gpu).contiguous(memory_format=torch.channels_last)
+    wt = (fill.randn((64, 64, 3, 3), 42 + w) * (2.0 / 576) ** 0.5).to(gpu)
+    b = (fill.randn((64,), 43) * 0.1).to(gpu)
+    cfg = ops.ConvCfg(1, 1, False, 0, 0, 0.0, 0, L.ALGO_MFMA_BF16X6)
+    d = ops._make_desc(x.shape, wt, cfg, "train_fwd")
+    wp, bp = ops.pack_weight_fwd(wt, False, 0), ops.pack_bias_ps(b, 0)
+    y = torch.empty_like(x)
+    tiles = n * ((h + 7) // 8) * ((w + 7) // 8)
+    part = torch.full((tiles, 128), float("nan"), dtype=torch.float64, device=gpu)
+    ep = L.Epilogue(L.ptr(bp), None, None, 0.0, 0, 0, 0, None, None, L.ptr(part))
+    assert lib.srk_conv2d_forward(ctypes.byref(d), L.ptr(x), L.ptr(wp), L.ptr(y), ctypes.byref(ep), L.stream_ptr()) == 0
+    assert lib.srk_last_kernel_name().decode().startswith("k_c64<")
+    assert lib.srk_last_conv_bn_partial_rows() == tiles
+    yd = y.double()
+    s_ref = torch.cat([yd.sum((0, 2, 3)), (yd * yd).sum((0, 2, 3))])
+    assert rel_err(part.sum(0), s_ref) < 1e-12
+    rows = n * h * w
+    stats = torch.empty(128, dtype=torch.float64, device=gpu)
+    mean, rstd = torch.empty(64, device=gpu), torch.empty(64, device=gpu)
+    rm, rv = torch.zeros(64, device=gpu), torch.ones(64, device=gpu)
+    assert lib.srk_bn_finalize_partials(L.ptr(part), tiles, L.ptr(stats), rows, 64, L.ptr(mean), L.ptr(rstd), L.ptr(rm),
+                                        L.ptr(rv), 0.1, 1e-5, None, L.stream_ptr()) == 0
+    m_ref = yd.mean((0, 2, 3))
+    v_ref = yd.var((0, 2, 3), unbiased=False)
+    assert rel_err(mean, m_ref.float()) < 1e-6 and rel_err(rstd, (v_ref + 1e-5).rsqrt().float()) < 1e-6
+    assert rel_err(rm, (0.1 * m_ref).float()) < 1e-6
+    # a kernel that does not keep them says so
+    ep2 = L.Epilogue(L.ptr(bp), None, None, 0.0, 1, 0, 0, None, None, L.ptr(part))   # with ReLU: not k_c64
+    assert lib.srk_conv2d_forward(ctypes.byref(d), L.ptr(x), L.ptr(wp), L.ptr(y), ctypes.byref(ep2), L.stream_ptr()) == 0
+    assert lib.srk_last_conv_bn_partial_rows() == 0
+    # the block: same outputs, gradients and running statistics with the protocol on and off
+    outs = {}
+    for on in (True, False):
+        torch.manual_seed(5)
+        blk = pkg.base_networks.ResnetBlock(64, norm="batch").to(gpu).train()
+        xin = x.clone().requires_grad_(True)
+        old = ops.BN_PARTIAL
+        ops.BN_PARTIAL = on
+        try:
+            out = blk(xin)
+            out.square().mean().backward()
+        finally:
+            ops.BN_PARTIAL = old
+        outs[on] = (out.detach(), xin.grad, blk.bn.running_mean.clone(), blk.bn.running_var.clone(), blk.conv1.weight.grad)
+    for a, bb in zip(outs[True], outs[False]):
+        assert rel_err(a, bb) < 1e-5
