@@ -475,9 +475,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
     vok[st] = tid < npix && (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW;
     const int cy = min(max(iy, 0), P.IH - 1), cx = min(max(ix, 0), P.IW - 1);
     const size_t pix = (size_t)cy * P.IW + cx;
-    const float* src = P.in + (size_t)n * P.IC * plane + (P.in_nchw ? pix : pix * P.IC);
     // (one load instruction per channel the input HAS: every VMEM instruction in the consumers' store stream costs issue
     //  time of the stores -- the layer ran in 199 us without the loads, 252 us with all of them hitting L1, 300 us as it is)
+    const float* src = P.in + (size_t)n * P.IC * plane + (P.in_nchw ? pix : pix * P.IC);
     pv[st][0] = src[0];
     pv[st][1] = ICN > 1 ? src[e1] : 0.f;
     pv[st][2] = ICN > 2 ? src[e2] : 0.f;
