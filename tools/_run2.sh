@@ -1,10 +1,8 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-{
-for r in 1 2 3; do
-echo "keep:  $(python tools/time_c2_layers.py 0 2>&1 | grep layer)"
-echo "head~: $(SRK_LIB_PATH=/root/repo/variants/rowsw_bufload.so python tools/time_c2_layers.py 0 2>&1 | grep layer)"
-done
-timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "first_layer" 2>&1 | tail -2
-} > gpurun_out/run23.log 2>&1
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --list-avail > /root/repo/gpurun_out/counters.txt 2>&1
+grep -o "Name:[[:space:]]*[A-Za-z0-9_]*" /root/repo/gpurun_out/counters.txt | sort -u | grep -E "TA_|TCP_|TCC_|TD_|SQ_INST.*VMEM|SQ_WAIT_INST|SQ_INSTS_V" > /root/repo/gpurun_out/counters_mem.txt
+wc -l /root/repo/gpurun_out/counters_mem.txt
