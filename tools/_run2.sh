@@ -1,10 +1,10 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-export TMPDIR=/tmp
-cd /tmp
-s=$(date +%s)
-timeout 150 rocprofv3 --pmc TCP_PENDING_STALL_CYCLES TA_BUSY --output-format csv -d /tmp/pq -o p -- python /root/repo/tools/time_c2_layers.py 0 > /tmp/pq.log 2>&1
-echo "rc=$? secs=$(( $(date +%s) - s ))" > /root/repo/gpurun_out/pq.txt
-tail -5 /tmp/pq.log >> /root/repo/gpurun_out/pq.txt
-find /tmp/pq -name "*.csv" | head >> /root/repo/gpurun_out/pq.txt
+{
+for r in 1 2 3; do
+echo "walk1: $(python tools/time_c2_layers.py 0 2>&1 | grep layer)"
+echo "walk0: $(SRK_ROWSR_WALK=0 python tools/time_c2_layers.py 0 2>&1 | grep layer)"
+done
+timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "first_layer" 2>&1 | tail -2
+} > gpurun_out/run28.log 2>&1
