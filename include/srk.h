@@ -148,6 +148,10 @@ int srk_last_conv_wrote_amax(void);
 /* Rows of srk_epilogue.bn_partial the calling thread's last srk_conv2d_forward filled (0: the kernel it dispatched to
  * does not keep them, or none were asked for). */
 int srk_last_conv_bn_partial_rows(void);
+/* Diagnostic of the ring kernels (k_conv_bfr: producer and consumer waves of a persistent block hand halo buffers over
+ * through counters in LDS, every poll has an iteration cap): number of polls that ran into the cap since the last
+ * reset -- 0 in a correct library.  Synchronises the device; tests and fuzzers call it, the product never does. */
+int srk_ring_timeouts(int reset);
 /* Output spatial size of a conv / transposed conv along one axis (torch semantics). */
 int srk_conv_out_dim(int in, int k, int stride, int pad, int transposed, int out_pad);
 

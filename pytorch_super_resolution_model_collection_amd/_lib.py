@@ -55,6 +55,7 @@ _PROTOTYPES = {
     "srk_last_kernel_name": (ctypes.c_char_p, []),
     "srk_last_conv_wrote_amax": (c_int, []),
     "srk_last_conv_bn_partial_rows": (c_int, []),
+    "srk_ring_timeouts": (c_int, [c_int]),
     "srk_conv_out_dim": (c_int, [c_int] * 6),
     "srk_nchw_to_nhwc": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_vp]),
     "srk_nhwc_to_nchw": (c_int, [c_f, c_f, c_int, c_int, c_int, c_int, c_vp]),
