@@ -49,10 +49,12 @@ const char* env_str(const char* name) {
     if (!strcmp(g_env[i].name, name)) { v = g_env[i].val; found = true; }
   if (!found) {
     const char* e = getenv(name);
-    v = e ? strdup(e) : nullptr;
-    if (m < kEnvSlots) {
-      g_env[m] = EnvSlot{name, v};
+    if (m < kEnvSlots) {  // (both strings are copied: the caller's `name` need not be a literal)
+      v = e ? strdup(e) : nullptr;
+      g_env[m] = EnvSlot{strdup(name), v};
       g_env_n.store(m + 1, std::memory_order_release);
+    } else {
+      v = e;  // table full: answer from the environment itself, nothing is allocated
     }
   }
   g_env_lock.store(0, std::memory_order_release);

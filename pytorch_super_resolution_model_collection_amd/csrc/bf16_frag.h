@@ -78,6 +78,9 @@ __device__ __forceinline__ float exp2i(int k) {  // 2^k for -126 <= k <= 127 (cl
 // v_max (no LDS traffic), then the four row results through v_readlane.  (Until round 4 this was six dependent
 // __shfl_xor = ds_bpermute_b32 round trips, ~400 clocks in front of every running-maximum commit and inside the fused
 // residual block's intermediate scale, tools/res2_prof.py.)
+// PRECONDITION: all 64 lanes active (full EXEC) -- v_readlane of an inactive lane returns whatever its register holds.
+// Every caller (amax_commit, amax_commit_block, the fused residual block's intermediate scale) runs convergent; a call under
+// lane divergence or behind a per-lane early return would feed garbage into the running maximum.
 template <int CTRL>
 __device__ __forceinline__ float dpp_rot(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
@@ -103,13 +106,13 @@ __device__ __forceinline__ float amax_peek(const float* __restrict__ slots, int 
   // of the CU's vector L1 for the whole kernel, and then every wave issues its atomic)
   return slots ? __hip_atomic_load(slots + (slot_hint & 15) * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
 }
-// one atomic per wave
+// one atomic per wave (all 64 lanes must be active: wave_max)
 __device__ __forceinline__ void amax_commit(float* __restrict__ slots, float lane_max, int slot_hint, float peeked) {
   const float m = wave_max(lane_max);
   if ((threadIdx.x & 63) == 0 && m > peeked)
     atomicMax(reinterpret_cast<unsigned*>(slots + (slot_hint & 15) * 16), __float_as_uint(m));
 }
-// one atomic per BLOCK (kernels whose epilogue may use a barrier): `sm` = one float per wave
+// one atomic per BLOCK (kernels whose epilogue may use a barrier; all lanes of every wave active): `sm` = one float per wave
 __device__ __forceinline__ void amax_commit_block(float* __restrict__ slots, float lane_max, int slot_hint, float* sm,
                                                   int nwaves, float peeked) {
   const float m = wave_max(lane_max);

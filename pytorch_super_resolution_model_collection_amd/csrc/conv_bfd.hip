@@ -517,65 +517,83 @@ static void bfd_lds_plan(int TW, int is, int HW, int npx, int npix, int NPW, int
   static std::map<Key, Val> cache;
   const Key key{TW, is, HW, npx, NPW};
   Val v{};
+  bool hit = false;
   {
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) {
       v = it->second;
-    } else {
-      const int ntile = NPW * 4;
-      std::vector<int> pos((size_t)ntile * 16, -1);
-      int live = 0;
-      for (int t = 0; t < ntile; ++t)
+      hit = true;
+    }
+  }
+  if (!hit) {
+    // the search runs OUTSIDE the lock (other threads -- DP ranks of one process, the autograd thread -- keep dispatching;
+    // two threads that miss on the same geometry compute the same plan twice)
+    const int ntile = NPW * 4;
+    std::vector<int> pos((size_t)ntile * 16, -1);
+    int live = 0;
+    for (int t = 0; t < ntile; ++t)
+      for (int i = 0; i < 16; ++i) {
+        const int m = t * 16 + i;
+        if (m < npx) pos[(size_t)t * 16 + i] = (m / TW) * is * HW + (m % TW) * is;
+        if (i == 0 && m < npx) live = t + 1;
+      }
+    static const int colA[8] = {0, 1, 2, 3, 12, 13, 14, 15}, colB[8] = {4, 5, 6, 7, 8, 9, 10, 11};
+    long best_cost = -1;
+    int best_D = 0;
+    unsigned best_mask = 0;
+    const bool off = env_int("SRK_BFD_LDS_PLAN", 1) == 0;
+    auto cost_of = [&](int D, unsigned mk) {
+      long cost = 0;
+      for (int t = 0; t < live; ++t) {
+        int cnt0[16] = {0}, cnt1[16] = {0};
+        int m0 = 0, m1 = 0;
         for (int i = 0; i < 16; ++i) {
-          const int m = t * 16 + i;
-          if (m < npx) pos[(size_t)t * 16 + i] = (m / TW) * is * HW + (m % TW) * is;
-          if (i == 0 && m < npx) live = t + 1;
+          const int ps = pos[(size_t)t * 16 + i];
+          if (ps < 0) continue;   // dead pixels all read slot 0 of their group: one address, no conflict of their own
+          const bool a = (mk >> i) & 1;
+          const int r0 = (a ? ps : ps + D) & 15, r1 = (a ? ps + D : ps) & 15;
+          m0 = std::max(m0, ++cnt0[r0]);
+          m1 = std::max(m1, ++cnt1[r1]);
         }
-      static const int colA[8] = {0, 1, 2, 3, 12, 13, 14, 15}, colB[8] = {4, 5, 6, 7, 8, 9, 10, 11};
-      long best_cost = -1;
-      int best_D = 0;
-      unsigned best_mask = 0;
-      const bool off = env_int("SRK_BFD_LDS_PLAN", 1) == 0;
-      // candidate order: the round-3 layout first (ties keep it), then the rest
-      for (int di = 0; di < (off ? 1 : 16); ++di) {
-        const int D = di == 0 ? 0 : (di == 1 ? 8 : (di <= 8 ? di - 1 : di));   // 0, 8, 1 .. 7, 9 .. 15
-        for (unsigned mask = 0; mask < (off ? 1u : 65536u); ++mask) {
-          // mask: pixels on the lane class A; the first candidate is the identity (pixels {0-3, 12-15})
-          const unsigned mk = mask == 0 ? 0xF00Fu : mask;
-          if (mask != 0 && (__builtin_popcount(mk) != 8 || mk == 0xF00Fu)) continue;
-          long cost = 0;
-          for (int t = 0; t < live; ++t) {
-            int cnt0[16] = {0}, cnt1[16] = {0};
-            int m0 = 0, m1 = 0;
-            for (int i = 0; i < 16; ++i) {
-              const int ps = pos[(size_t)t * 16 + i];
-              if (ps < 0) continue;   // dead pixels all read slot 0 of their group: one address, no conflict of their own
-              const bool a = (mk >> i) & 1;
-              const int r0 = (a ? ps : ps + D) & 15, r1 = (a ? ps + D : ps) & 15;
-              m0 = std::max(m0, ++cnt0[r0]);
-              m1 = std::max(m1, ++cnt1[r1]);
-            }
-            cost += m0 + m1;
-          }
+        cost += m0 + m1;
+      }
+      return cost;
+    };
+    // candidate order: the round-3 layout first (ties keep it), then the rest
+    for (int di = 0; di < (off ? 1 : 16) && best_cost != 2L * live; ++di) {
+      const int D = di == 0 ? 0 : (di == 1 ? 8 : (di <= 8 ? di - 1 : di));   // 0, 8, 1 .. 7, 9 .. 15
+      // mask: pixels on the lane class A; the first candidate is the identity (pixels {0-3, 12-15}), then every other
+      // 8-of-16 subset in increasing order (Gosper's hack: 12870 masks, not 65536 popcount tests)
+      for (unsigned mk = 0xF00Fu, first = 1; mk < 65536u;) {
+        if (first || mk != 0xF00Fu) {
+          const long cost = cost_of(D, mk);
           if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
             best_D = D;
             best_mask = mk;
-            if (best_cost == 2L * live) break;
+            if (best_cost == 2L * live) break;   // one clock per set everywhere
           }
         }
-        if (best_cost == 2L * live) break;   // one clock per set everywhere
+        if (off) break;
+        if (first) {
+          first = 0;
+          mk = 0x00FFu;
+          continue;
+        }
+        const unsigned c = mk & (0u - mk), r = mk + c;
+        mk = (((r ^ mk) >> 2) / c) | r;
       }
-      v.D = best_D;
-      v.perm = 0;
-      int na = 0, nb = 0;
-      for (int i = 0; i < 16; ++i) {
-        const int colx = ((best_mask >> i) & 1) ? colA[na++] : colB[nb++];
-        v.perm |= (unsigned long long)i << (4 * colx);
-      }
-      cache[key] = v;
     }
+    v.D = best_D;
+    v.perm = 0;
+    int na = 0, nb = 0;
+    for (int i = 0; i < 16; ++i) {
+      const int colx = ((best_mask >> i) & 1) ? colA[na++] : colB[nb++];
+      v.perm |= (unsigned long long)i << (4 * colx);
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    cache[key] = v;
   }
   stride = ((npix - v.D + 15) & ~15) + v.D;   // smallest value >= npix that is D (mod 16)
   perm = v.perm;

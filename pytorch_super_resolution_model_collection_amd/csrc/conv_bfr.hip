@@ -1,26 +1,31 @@
-// Ring form of the wave-specialised persistent 3x3 convolution (k_conv_bfw, conv_bfw.hip): the same roles, arithmetic and
-// accumulation order (bit-equal outputs), but producers and consumers no longer meet at a workgroup barrier every stage.
+// Ring form of the wave-specialised persistent 3x3 convolution (k_conv_bfw, conv_bfw.hip) for the large layers whose
+// filter stays in LDS (c2: ESPCN 64 -> 32 and 32 -> 48 + pixel shuffle).  Same roles and products (f16x3 / bf16x3:
+// x = h + m, w_h x_m + w_m x_h + w_h x_h, fp32 accumulate, chunks in order), two structural changes:
 //
-// Why (DESIGN 10.3 / 10.9 #1, round-4 profile): with two halo buffers and one s_barrier per (tile, chunk) stage every wave
-// of the block runs in lockstep -- all consumer waves park a finished tile at the same moment (the matrix pipe idles), a
-// stage lasts as long as its slowest wave, and the producers spend a third of it waiting.  Neither pipe was saturated
-// (MFMA ~50 % busy, LDS ~30 %, HBM 3.4 TB/s).  Here:
+// 1. Half the LDS bytes per MFMA.  Round 5's constant-ablation builds of the barrier kernel's tap loop (tools/
+//    ring_ablate.sh) on the 64 -> 32 layer: its fragment reads alone run 207 us, its MFMAs alone 261 us, both
+//    together 303 - 326 us with no global memory traffic at all -- a 32-pixel x 32-channel wave tile reads 8 fragments
+//    per 12 MFMAs (0.67 KB per MFMA: 2/3 of the LDS's peak at full matrix rate, and the LDS reaches ~2/3 of its peak), so
+//    the consumers were LDS-bound before the first byte left HBM.  Here a consumer wave owns 4 ROWS x 16 columns of an
+//    8 x 16 tile and walks (kernel column v, halo row R): the pixel fragment of halo row R, columns v .. v + 15 serves
+//    every (output row r, kernel row u) with r + u = R -- up to three MFMA groups per fragment -- and the filter
+//    fragments of one kernel column (u = 0 .. 2) stay in registers while the six halo rows pass, each reloaded for the
+//    next column right behind its last use: 72 fragment reads per 216 MFMAs (0.33 KB per MFMA).  The tile is fixed, so
+//    every LDS address is lane base + immediate.  Accumulation order per output: chunk, then kernel column, then kernel
+//    row (k_conv_bfw: row, then column) -- equal to the barrier kernel up to fp32 summation order, not bit-equal.
 //
-//   * tiles are 128 pixels; the 8 consumer waves form TWO groups of 4 (waves 0-3 / 4-7; wave w and w + 4 share a SIMD)
-//     that take alternate tiles of the block's list, so the two waves of a SIMD are in different phases of different
-//     tiles: one wave's parking (descale / bias / activation, no MFMA) runs under the other's taps;
-//   * the halo buffers form a ring of NBUF >= 3 slots in LDS, filled in the fixed global stage order
-//     (pair p of tiles, chunk cc, group g): stage s lives in slot s % NBUF;
-//   * per slot two monotonic counters in LDS: full[slot] += 1 per producer wave once its ds_writes have landed,
-//     free[slot] += 1 per consumer wave once its fragment reads of the slot have returned.  Use k of a slot may be
-//     filled when free >= 4 k and read when full >= 4 (k + 1).  A wave waits for exactly the data it needs
-//     (ds_read_b32 + s_sleep polling); nobody waits for the block;
-//   * producers keep TWO register sets of loads in flight (stages s + 1 and s + 2) and run ahead as far as the ring
-//     allows; every load is issued unconditionally (stages past the end read through an out-of-range offset), so the
-//     compiler counts the waits of a commit exactly (vmcnt = the other set's loads).
-//
-// Every poll is bounded (BFR_SPIN_CAP): a protocol error ends as wrong numbers and a non-zero srk_ring_timeouts(), not as
-// a hung GPU.
+// 2. No workgroup barrier per stage.  4 consumer waves (one per SIMD, beside one producer wave each: matrix beside
+//    memory) form two groups of two that take alternate tiles of the block's list; the halo buffers are a ring of
+//    NBUF >= 3 slots filled in the fixed global stage order (pair of tiles, chunk, group): stage s lives in slot s % NBUF.
+//    Per slot two monotonic counters in LDS: full[slot] += 1 per producer wave once its ds_writes have landed,
+//    free[slot] += 1 per consumer wave once its fragment reads of the slot have returned; use k of a slot may be filled
+//    when free >= 2 k and read when full >= 4 (k + 1).  A wave waits for exactly the data it needs (ds_read_b32 +
+//    s_sleep polling, every poll capped: a protocol error ends as wrong numbers and a non-zero srk_ring_timeouts(), not as
+//    a hung GPU).  Producers keep NSET register sets of loads in flight and run ahead as far as the ring allows; every
+//    load is issued unconditionally (stages past the end read through an out-of-range offset), so the compiler counts a
+//    commit's wait exactly (vmcnt = the loads of the other sets).
+//    (The ring alone, on the barrier kernel's 32-pixel consumers, changed nothing: 472 vs 465 us and 332 vs 330 us on the
+//    two c2 layers -- the lockstep was not what that kernel waited for)
 #include "conv_bfw.h"
 
 namespace srk {
@@ -30,11 +35,27 @@ namespace srk {
 #ifndef BFR_ABL
 #define BFR_ABL 0
 #endif
+#ifndef BFR_NSET
+#define BFR_NSET 3
+#endif
 constexpr int BFR_MAXBUF = 6;
-constexpr int BFR_PIT = 3;  // producer register batches per set: halos of <= 64 * 3 = 192 pixels
+constexpr int BFR_PIT = 3;  // producer register batches per set: the 180-pixel halo in 64-pixel batches
+constexpr int BFR_NSET_C = BFR_NSET;  // register sets = stages of loads in flight per producer wave
 constexpr unsigned BFR_SPIN_CAP = 1u << 18;
+constexpr int BFR_TH = 8, BFR_TW = 16, BFR_HH = 10, BFR_HW = 18, BFR_NPIX = 180;
+constexpr int BFR_NPIXP = 190;  // = bfw_group_stride(180, perm): +-2 (mod 16), conflict-free fragment reads and halo writes
 
 __device__ unsigned g_bfr_timeouts = 0;
+
+// Profiling builds (-DBFR_PROF, tools/ring_prof.py): s_memtime sums per role -- 16 int64 per block:
+// [0..5] first producer wave {wait free, wait loads, split + commit, signal, issue, total}, [8..13] consumer wave 0
+// {wait full, steps, signal, park, total, stages}
+#ifdef BFR_PROF
+static long long* g_bfr_prof = nullptr;
+#define BFR_CLK() clock64()
+#else
+#define BFR_CLK() 0ll
+#endif
 
 typedef __attribute__((address_space(3))) unsigned bfr_cnt_t;
 
@@ -50,7 +71,7 @@ __device__ __forceinline__ void bfr_wait(bfr_cnt_t* p, unsigned target, bool& de
   if (!dead) {
     unsigned spins = 0;
     while ((int)(bfr_peek(p) - target) < 0) {
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(1);
       if (++spins > BFR_SPIN_CAP) {
         dead = true;
         break;
@@ -66,24 +87,26 @@ __device__ __forceinline__ void bfr_signal(bfr_cnt_t* p) {
   asm volatile("" ::: "memory");
 }
 
-template <int NTW, bool F16 = false, bool MASK = false, bool OMASK = false>
-__global__ __launch_bounds__(768, 3) void k_conv_bfr(BfwParams B) {
-  constexpr int TT = 9, MTW = 2;
-  constexpr int NCW = 8, NGW = 4, NPW = 4;  // consumer waves (two groups of NGW), producer waves
+template <int NTW, int ICC, bool F16>
+__global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
+  constexpr int NB = 16 * NTW;
+  constexpr int NCW = 4, NGW = 2, NPW = 4;  // consumer waves (two groups of NGW), producer waves
   constexpr int NTHR = 64 * (NCW + NPW);
-  constexpr int PSTEP = 16 * NPW, PIT = BFR_PIT;
+  constexpr int PSTEP = 16 * NPW, PIT = BFR_PIT, NSET = BFR_NSET_C;
+  constexpr int TH = BFR_TH, TW = BFR_TW, HW = BFR_HW, NPIX = BFR_NPIX, NPIXP = BFR_NPIXP;
+  constexpr int MR = TH / NGW;          // output rows per consumer wave (4)
+  constexpr int WSLOT = 8 * NB;         // uint4 per (tap, chunk): [plane 2][group 4][NB]
+  constexpr int HBUF = 8 * NPIXP;       // uint4 per halo slot: [plane 2][group 4][NPIXP]
+  constexpr int PLANE_B = 4 * NPIXP, PLANE_A = 4 * NB;
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   const MfmaConvParams& P = B.P;
-  const int NB = B.NB;
-  const int wslot = 8 * NB;  // uint4 per (tap, chunk): [plane 2][group 4][NB]
-  const int hbuf = 8 * B.NPIXp;  // uint4 per halo buffer: [plane 2][group 4][NPIXp]
   uint4* wl = smem4;
-  uint4* hal0 = smem4 + (size_t)TT * B.ICc * wslot;
-  bfr_cnt_t* cnt = (bfr_cnt_t*)(hal0 + (size_t)B.nbuf * hbuf);  // full[BFR_MAXBUF], free[BFR_MAXBUF]
+  uint4* hal0 = smem4 + 9 * ICC * WSLOT;
+  const int nbuf = __builtin_amdgcn_readfirstlane(B.nbuf);
+  bfr_cnt_t* cnt = (bfr_cnt_t*)(hal0 + (size_t)nbuf * HBUF);  // full[BFR_MAXBUF], free[BFR_MAXBUF]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool producer = wave >= NCW;
   const int j = lane & 15, kq = lane >> 4;
-  const int npx = P.TH * P.TW, npix = P.HH * P.HW;
   float sx = 1.f, dsc = 1.f;
   if constexpr (F16) {
     const int kx = amax_scale_exp(amax_read(P.ep.x_amax));
@@ -91,17 +114,14 @@ __global__ __launch_bounds__(768, 3) void k_conv_bfr(BfwParams B) {
     dsc = exp2i(-kx) * B.w_descale[0];
   }
 
-  const int nsl = B.nsl;
-  const int xcd = blockIdx.x & 7;
-  const int sl = (blockIdx.x >> 3) % nsl, bi = (blockIdx.x >> 3) / nsl;  // slice, block index inside the XCD
-  for (int e = tid; e < TT * B.ICc * wslot; e += NTHR) {
-    const int slot = e / wslot, w = e - slot * wslot;
-    const int t = slot / B.ICc, cc = slot - t * B.ICc;
-    const int u = t / P.KWv, v = t - u * P.KWv;
+  const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;  // (one slice: the whole filter is resident)
+  for (int e = tid; e < 9 * ICC * WSLOT; e += NTHR) {
+    const int slot = e / WSLOT, w = e - slot * WSLOT;
+    const int t = slot / ICC, cc = slot - t * ICC;
+    const int u = t / 3, v = t - u * 3;
     const int tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
-    const int pg = w / NB, o = w - pg * NB;
-    const int oc = sl * NB + o, ocb = oc / B.NBfull;
-    wl[e] = B.wq[((size_t)(tapw * B.ICc + cc) * B.OCb + ocb) * (size_t)(8 * B.NBfull) + pg * B.NBfull + (oc - ocb * B.NBfull)];
+    // packed layout [tap][chunk][64-channel block][plane][group][NBfull channels] with NBfull = NB here (OC <= 48)
+    wl[e] = B.wq[(size_t)(tapw * ICC + cc) * WSLOT + w];
   }
   if (tid < 2 * BFR_MAXBUF) cnt[tid] = 0u;
   // tiles of this block (XCD-aware contiguous ranges, as in k_conv_bfw): first, first + tstride, ... (count of them)
@@ -109,16 +129,14 @@ __global__ __launch_bounds__(768, 3) void k_conv_bfr(BfwParams B) {
   int first, count;
   {
     const int per_x = B.ntiles >> 3, rem_x = B.ntiles & 7;
-    const int nb_x = ((nblk + 7 - xcd) >> 3) / nsl;
+    const int nb_x = (nblk + 7 - xcd) >> 3;
     const int tiles_x = per_x + (xcd < rem_x ? 1 : 0);
     const int start_x = xcd * per_x + (xcd < rem_x ? xcd : rem_x);
     first = start_x + bi;
     count = bi < tiles_x ? (tiles_x - bi + nb_x - 1) / nb_x : 0;
   }
-  const int tstride = ((nblk + 7 - xcd) >> 3) / nsl;
+  const int tstride = (nblk + 7 - xcd) >> 3;
   count = __builtin_amdgcn_readfirstlane(count);
-  const int ICc = __builtin_amdgcn_readfirstlane(B.ICc);
-  const int nbuf = __builtin_amdgcn_readfirstlane(B.nbuf);
 
   // Tile coordinates (image, tile row, tile column) of the two tiles of a pair, advanced by TWO list steps per pair:
   // add + carry on wave-uniform values, no divisions in the loops.
@@ -153,30 +171,21 @@ __global__ __launch_bounds__(768, 3) void k_conv_bfr(BfwParams B) {
     }
   };
   bool dead = false;
+  const int prio = __builtin_amdgcn_readfirstlane(B.late);  // 1: producers, 2: consumers issue first on their SIMD
 
   if (producer) {
     // ------------------------------------------------------------------ producers
-    if (NTW <= 2 && __builtin_amdgcn_readfirstlane(tid) >= 64 * NCW) __builtin_amdgcn_s_setprio(1);  // (see k_conv_bfw)
+    if (prio == 1) __builtin_amdgcn_s_setprio(1);
     const int ptid = tid - 64 * NCW;
     const int g = ptid & 3, hp0 = ptid >> 2;
-    const int hy0 = hp0 / P.HW, hx0 = hp0 - hy0 * P.HW;
-    const int dyp = PSTEP / P.HW, dxp = PSTEP - dyp * P.HW;
-    f32x4 pvA[PIT][2], pvB[PIT][2];
-    f32x4 mkA[MASK ? PIT : 1][2], mkB[MASK ? PIT : 1][2];
+    f32x4 pv[NSET][PIT][2];
     int it_rel[PIT], it_hx[PIT];
-    {
-      int hy = hy0, hx = hx0;
 #pragma unroll
-      for (int k = 0; k < PIT; ++k) {
-        it_rel[k] = hp0 + PSTEP * k < npix ? ((hy * P.IW + hx) * P.IC + g * 8) * 4 : -1;
-        it_hx[k] = hx;
-        hy += dyp;
-        hx += dxp;
-        if (hx >= P.HW) {
-          hx -= P.HW;
-          ++hy;
-        }
-      }
+    for (int k = 0; k < PIT; ++k) {
+      const int hq = hp0 + PSTEP * k;
+      const int hy = hq / HW, hx = hq - hy * HW;
+      it_rel[k] = hq < NPIX ? ((hy * P.IW + hx) * P.IC + g * 8) * 4 : -1;
+      it_hx[k] = hx;
     }
     const unsigned img_bytes = (unsigned)((size_t)P.IH * P.IW * P.IC * 4);
     auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
@@ -190,17 +199,17 @@ __global__ __launch_bounds__(768, 3) void k_conv_bfr(BfwParams B) {
     };
     // global stage order: for every pair of tiles, for every chunk, group 0 then group 1 (a last single tile: group 0 only)
     int left = count, wcc = 0, wg = 0;
-    auto issue = [&](f32x4 (&pv)[PIT][2], f32x4 (&mk)[MASK ? PIT : 1][2]) {
+    auto issue = [&](f32x4 (&v)[PIT][2]) {
       const bool valid = left > 0;
       const bool second = wg == 1;
       const int n = valid ? (second ? b_n : a_n) : 0;
-      const int r0 = (second ? b_y : a_y) * P.TH, c0 = (second ? b_x : a_x) * P.TW;
+      const int r0 = (second ? b_y : a_y) * TH, c0 = (second ? b_x : a_x) * TW;
       const int cc = wcc;
       if (valid) {
         const int ng = left >= 2 ? 2 : 1;
         if (++wg == ng) {
           wg = 0;
-          if (++wcc == ICc) {
+          if (++wcc == ICC) {
             wcc = 0;
             left -= ng;
             adv2(a_n, a_y, a_x);
@@ -209,118 +218,108 @@ __global__ __launch_bounds__(768, 3) void k_conv_bfr(BfwParams B) {
         }
       }
       constexpr unsigned OOB = 0x80000000u;
-      const int iyb = r0 * P.is + P.iy0, ixb = c0 * P.is + P.ix0;
+      const int iyb = r0 + P.iy0, ixb = c0 + P.ix0;
       const bool ch_on = valid && cc * 32 + g * 8 + 7 < P.IC;
       const size_t img = (size_t)n * P.IH * P.IW * P.IC;
       const __amdgpu_buffer_rsrc_t rin = rsrc_of(P.in + img, img_bytes);
-      const __amdgpu_buffer_rsrc_t rmk = rsrc_of(MASK ? P.mask_y + img : P.in, MASK ? img_bytes : 0u);
-      (void)rmk;
       const int obase = ((iyb * P.IW + ixb) * P.IC + cc * 32) * 4;  // may be negative: rows above the image wrap out of range
 #pragma unroll
       for (int k = 0; k < PIT; ++k) {
         const bool ok = it_rel[k] >= 0 && ch_on && (unsigned)(ixb + it_hx[k]) < (unsigned)P.IW;
         const unsigned o = ok ? (unsigned)(obase + it_rel[k]) : OOB;
         if constexpr (BFR_ABL & 1) {
-          pv[k][0] = pv[k][1] = (f32x4){(float)o, 1.f, 2.f, 3.f};
-          if constexpr (MASK) mk[k][0] = mk[k][1] = pv[k][0];
+          v[k][0] = v[k][1] = (f32x4){(float)o, 1.f, 2.f, 3.f};
         } else {
-          pv[k][0] = bload(rin, o);
-          pv[k][1] = bload(rin, o + 16u);
-          if constexpr (MASK) {
-            mk[k][0] = bload(rmk, o);
-            mk[k][1] = bload(rmk, o + 16u);
-          }
+          v[k][0] = bload(rin, o);
+          v[k][1] = bload(rin, o + 16u);
         }
       }
     };
-    auto commit = [&](const f32x4 (&pv)[PIT][2], const f32x4 (&mk)[MASK ? PIT : 1][2], uint4* hal) {
+    auto commit = [&](const f32x4 (&v)[PIT][2], uint4* hal) {
       if constexpr (BFR_ABL & 16) {
 #pragma unroll
-        for (int k = 0; k < PIT; ++k) asm volatile("" ::"v"(pv[k][0]), "v"(pv[k][1]));
+        for (int k = 0; k < PIT; ++k) asm volatile("" ::"v"(v[k][0]), "v"(v[k][1]));
         return;
       }
 #pragma unroll
       for (int k = 0; k < PIT; ++k) {
         const int hq = hp0 + PSTEP * k;
-        if (hq < npix) {
+        if (hq < NPIX) {
           float f[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            f[e] = pv[k][0][e];
-            f[4 + e] = pv[k][1][e];
-            if constexpr (MASK) {
-              f[e] = mk[k][0][e] > 0.f ? f[e] : f[e] * P.mask_slope;
-              f[4 + e] = mk[k][1][e] > 0.f ? f[4 + e] : f[4 + e] * P.mask_slope;
-            }
+            f[e] = v[k][0][e];
+            f[4 + e] = v[k][1][e];
           }
           uint4 pl[2];
           if constexpr (F16) split8h(f, sx, pl); else split8n<2>(f, pl);
-          hal[(0 * 4 + g) * B.NPIXp + hq] = pl[0];
-          hal[(1 * 4 + g) * B.NPIXp + hq] = pl[1];
+          hal[(0 * 4 + g) * NPIXP + hq] = pl[0];
+          hal[(1 * 4 + g) * NPIXP + hq] = pl[1];
         }
       }
     };
-    const int S = count * ICc;
-    issue(pvA, mkA);
-    issue(pvB, mkB);
+    const int S = count * ICC;
+    srk_static_for<0, NSET>([&](auto ic) { issue(pv[decltype(ic)::value]); });
     __syncthreads();  // filter and counters visible
     int b = 0;
     unsigned k = 0;  // slot and use count of the stage about to be committed
-    for (int s = 0; s < S; s += 2) {
-      bfr_wait(cnt + BFR_MAXBUF + b, NGW * k, dead);
-      commit(pvA, mkA, hal0 + (size_t)b * hbuf);
-      bfr_signal(cnt + b);
-      if (++b == nbuf) {
-        b = 0;
-        ++k;
-      }
-      issue(pvA, mkA);  // stage s + 2
-      if (s + 1 < S) {
-        bfr_wait(cnt + BFR_MAXBUF + b, NGW * k, dead);
-        commit(pvB, mkB, hal0 + (size_t)b * hbuf);
-        bfr_signal(cnt + b);
-        if (++b == nbuf) {
-          b = 0;
-          ++k;
+    long long pt[5] = {0, 0, 0, 0, 0};
+    const long long pt_begin = BFR_CLK();
+    for (int s = 0; s < S; s += NSET) {
+      srk_static_for<0, NSET>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const long long c0 = BFR_CLK();
+        if (s + i < S) {
+          bfr_wait(cnt + BFR_MAXBUF + b, NGW * k, dead);
+          const long long c1 = BFR_CLK();
+#ifdef BFR_PROF
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIT * (NSET - 1)) : "memory");
+#endif
+          const long long c2 = BFR_CLK();
+          commit(pv[i], hal0 + (size_t)b * HBUF);
+          const long long c3 = BFR_CLK();
+          bfr_signal(cnt + b);
+          const long long c4 = BFR_CLK();
+          pt[0] += c1 - c0; pt[1] += c2 - c1; pt[2] += c3 - c2; pt[3] += c4 - c3;
+          if (++b == nbuf) {
+            b = 0;
+            ++k;
+          }
         }
-      }
-      issue(pvB, mkB);  // stage s + 3
+        const long long c5 = BFR_CLK();
+        issue(pv[i]);  // stage s + i + NSET (unconditional: the waits of the next commits stay countable)
+        pt[4] += BFR_CLK() - c5;
+      });
     }
+#ifdef BFR_PROF
+    if (B.prof && tid == 64 * NCW) {
+      long long* pr = B.prof + (size_t)blockIdx.x * 16;
+      for (int i = 0; i < 5; ++i) pr[i] = pt[i];
+      pr[5] = BFR_CLK() - pt_begin;
+    }
+#endif
+    (void)pt; (void)pt_begin;
     if (dead && lane == 0) atomicAdd(&g_bfr_timeouts, 1u);
     return;
   }
 
   // -------------------------------------------------------------------- consumers
-  const int grp = __builtin_amdgcn_readfirstlane(wave >> 2), gw = wave & 3;
-  const int pj = !B.perm ? j : (j < 4 ? 2 * j : (j < 12 ? 2 * j - 7 : 2 * j - 16));
-  int hp[MTW];
-#pragma unroll
-  for (int mt = 0; mt < MTW; ++mt) {
-    int m = gw * (16 * MTW) + mt * 16 + pj;
-    if (m >= npx) m = 0;
-    const int r = m / P.TW, c = m - r * P.TW;
-    hp[mt] = (r * P.is) * P.HW + c * P.is + kq * B.NPIXp;
-  }
-  const bool wave_live = gw * (16 * MTW) < npx;
-  const int plane = 4 * B.NPIXp;
-  int wrow[NTW];
-#pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) wrow[nt] = kq * NB + nt * 16 + j;
+  if (prio == 2) __builtin_amdgcn_s_setprio(1);
+  const int grp = __builtin_amdgcn_readfirstlane(wave >> 1), gw = wave & 1;
+  // lane column -> pixel column of the 16-pixel M tile: lanes {0-3, 12-15} hold the even columns, {4-11} the odd ones
+  // (bfw_group_stride: with a group stride of +-2 (mod 16) every ds_read_b128 lane set covers 16 distinct slots)
+  const int pj = j < 4 ? 2 * j : (j < 12 ? 2 * j - 7 : 2 * j - 16);
+  const int lane_b = (MR * gw) * HW + pj + kq * NPIXP;  // pixel fragment (halo row R, column shift v): + R * HW + v
+  const int lane_a = kq * NB + j;                        // filter fragment of tap t, tile nt: + t * ICC * WSLOT + nt * 16
   f32x4 bias4[NTW];
-  int coff[NTW], poff[MTW];
-  int pix_ok[MTW];
+  int coff[NTW], poff[MR];
   {
     const EpiTile e0 = epi_tile_setup(P, 0, 0, 0);
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt) {
-      const int m = gw * (16 * MTW) + mt * 16 + pj;
-      const int r = m / P.TW, c = m - r * P.TW;
-      pix_ok[mt] = m < npx ? ((r << 16) | c) : -1;
-      poff[mt] = r * e0.RS + c * e0.CS;
-    }
+    for (int r = 0; r < MR; ++r) poff[r] = (MR * gw + r) * e0.RS + pj * e0.CS;
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-      const EpiCol cl = epi_col_setup(P.ep, P.OW, P.OC, sl * NB + nt * 16 + kq * 4);
+      const EpiCol cl = epi_col_setup(P.ep, P.OW, P.OC, nt * 16 + kq * 4);
       coff[nt] = (int)cl.off_oc;
       bias4[nt] = cl.bias;
     }
@@ -328,56 +327,48 @@ __global__ __launch_bounds__(768, 3) void k_conv_bfr(BfwParams B) {
   const float act_slope = P.ep.act == SRK_ACT_NONE ? 1.f
                           : P.ep.act == SRK_ACT_RELU ? 0.f
                           : P.ep.act == SRK_ACT_PRELU ? P.ep.prelu_w[0] : P.ep.slope;
-  f32x4 acc[NTW][MTW];
-  f32x4 pend[NTW][MTW];  // the finished tile, stored one slot per tap under the next stage's MFMAs (see k_conv_bfw)
-  f32x4 om[OMASK ? NTW : 1][OMASK ? MTW : 1];
+  f32x4 acc[NTW][MR];
+  f32x4 pend[NTW][MR];  // the finished tile, stored one slot per step under the next stage's MFMAs (see k_conv_bfw)
   float amax = 0.f;
   constexpr unsigned kDrop = 0x80000000u;
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(P.out, 0, B.out_bytes, 0x00020000);
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
-  unsigned pend_voff[MTW];
+  unsigned pend_voff[MR];
 #pragma unroll
-  for (int mt = 0; mt < MTW; ++mt) pend_voff[mt] = kDrop;
-  int pend_mask = 0;
+  for (int r = 0; r < MR; ++r) pend_voff[r] = kDrop;
   bool pend_live = false;
-  constexpr int NST = NTW * MTW;  // stores per tile and lane, slot q = mt * NTW + nt
-  static_assert(NST <= TT, "every pending store must find a tap");
+  constexpr int NST = NTW * MR;  // stores per tile and lane, slot q = r * NTW + nt
+  static_assert(NST <= 18, "every pending store must find a step");
   auto store_slot = [&](auto qc) {
     constexpr int q = decltype(qc)::value;
-    constexpr int mt = q / NTW, nt = q - mt * NTW;
-    const f32x4 v = pend[nt][mt];
+    constexpr int r = q / NTW, nt = q - r * NTW;
+    const f32x4 v = pend[nt][r];
     if constexpr (BFR_ABL & 2) {
       asm volatile("" ::"v"(v));
       return;
     }
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), orsrc, (int)(pend_voff[mt] + 4u * (unsigned)coff[nt]), 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), orsrc, (int)(pend_voff[r] + 4u * (unsigned)coff[nt]), 0, 0);
   };
   auto park = [&](int n, int r0, int c0) {
     const unsigned tile_off = 4u * (unsigned)epi_tile_setup(P, n, r0, c0).off0;
-    pend_mask = 0;
+    const bool col_ok = c0 + pj < P.PW;
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt) {
-      const int r = pix_ok[mt] >> 16, c = pix_ok[mt] & 0xffff;
-      const bool pok = pix_ok[mt] >= 0 && r0 + r < P.PH && c0 + c < P.PW;
-      if (pok) pend_mask |= 1 << mt;
-      pend_voff[mt] = pok ? tile_off + 4u * (unsigned)poff[mt] : kDrop;
+    for (int r = 0; r < MR; ++r) {
+      const bool pok = col_ok && r0 + MR * gw + r < P.PH;
+      pend_voff[r] = pok ? tile_off + 4u * (unsigned)poff[r] : kDrop;
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
-        f32x4 v = acc[nt][mt];
+        f32x4 v = acc[nt][r];
         if constexpr (BFR_ABL & 32) {
-          pend[nt][mt] = v;
+          pend[nt][r] = v;
           continue;
         }
         if constexpr (F16) v *= dsc;
         v += bias4[nt];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : act_slope * v[e];
-        if constexpr (OMASK) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = om[nt][mt][e] > 0.f ? v[e] : 0.f;
-        }
-        pend[nt][mt] = v;
-        if (P.ep.y_amax && ((pend_mask >> mt) & 1)) amax = abs_max4(amax, v);
+        pend[nt][r] = v;
+        if (P.ep.y_amax && pok) amax = abs_max4(amax, v);
       }
     }
     pend_live = true;
@@ -388,205 +379,209 @@ __global__ __launch_bounds__(768, 3) void k_conv_bfr(BfwParams B) {
   asm volatile("" ::"v"(act_slope));
   __syncthreads();  // filter and counters visible
 
-  // own tiles: list entries grp, grp + 2, ...; stage (entry i, chunk cc) is number (i >> 1) * 2 ICc + cc * ng + (i & 1) of
+  // own tiles: list entries grp, grp + 2, ...; stage (entry i, chunk cc) is number (i >> 1) * 2 ICC + cc * ng + (i & 1) of
   // the global order, ng = tiles of the pair
   int o_n = grp ? b_n : a_n, o_y = grp ? b_y : a_y, o_x = grp ? b_x : a_x;
-  int b = grp;       // ring slot of the next own stage (nbuf >= 3 > grp)
-  unsigned k = 0;    // ... and how often that slot was used before
+  long long ct[6] = {0, 0, 0, 0, 0, 0};
+  const long long ct_begin = BFR_CLK();
+  int b = grp;     // ring slot of the next own stage (nbuf >= 3 > grp)
+  unsigned k = 0;  // ... and how often that slot was used before
   for (int ti = grp; ti < count; ti += 2) {
     const int ng = (ti | 1) < count ? 2 : 1;
-    const int n = o_n, r0 = o_y * P.TH, c0 = o_x * P.TW;
+    const int n = o_n, r0 = o_y * TH, c0 = o_x * TW;
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-      for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int cc = 0; cc < ICc; ++cc) {
-      if constexpr (OMASK) {
-        if (cc == ICc - 1 && wave_live) {
-          const float* ob = P.ep.out_relu + epi_tile_setup(P, n, r0, c0).off0;
-#pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) {
-            const int r = pix_ok[mt] >> 16, c = pix_ok[mt] & 0xffff;
-            const bool ok = pix_ok[mt] >= 0 && r0 + r < P.PH && c0 + c < P.PW;
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-              om[nt][mt] = *reinterpret_cast<const f32x4*>(ok ? ob + (coff[nt] + poff[mt]) : P.ep.out_relu);
-          }
-        }
-      }
+      for (int r = 0; r < MR; ++r) acc[nt][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int cc = 0; cc < ICC; ++cc) {
+      const long long k0 = BFR_CLK();
       bfr_wait(cnt + b, NPW * (k + 1), dead);
-      if (wave_live) {
-        const uint4* hal = hal0 + (size_t)b * hbuf;
-        const uint4* wb = wl + (size_t)cc * wslot;
-        const size_t wstep = (size_t)ICc * wslot;
-        uint4 fa[2][2][NTW], fb[2][2][MTW];  // [buffer][plane][tile]
-        int wt_toff = 0, wt_tv = 0, wt_t = 0;
-        auto load_frags = [&](uint4 (&a)[2][NTW], uint4 (&bb)[2][MTW]) {
-          if constexpr (BFR_ABL & 8) {
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) { bfr_touch(bb[0][mt]); bfr_touch(bb[1][mt]); }
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) { bfr_touch(a[0][nt]); bfr_touch(a[1][nt]); }
-            return;
-          }
-          const uint4* hb = hal + wt_toff;
-          const uint4* wt = wb + (size_t)wt_t * wstep;
-#pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) {
-            bb[0][mt] = hb[hp[mt]];
-            bb[1][mt] = hb[hp[mt] + plane];
-          }
+      const long long k1 = BFR_CLK();
+      {
+        const uint4* hb = hal0 + (size_t)b * HBUF + lane_b;
+        const uint4* wb = wl + (size_t)cc * WSLOT + lane_a;
+        uint4 fa[3][2][NTW];  // filter fragments of the current kernel column: [kernel row u][plane][tile]
+        uint4 fb[3][2];       // pixel fragments of three consecutive steps: [step % 3][plane]
+        auto ldA = [&](auto uc, auto vc) {
+          constexpr int u = decltype(uc)::value, v = decltype(vc)::value;
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt) {
-            a[0][nt] = wt[wrow[nt]];
-            a[1][nt] = wt[4 * NB + wrow[nt]];
-          }
-          ++wt_t;
-          ++wt_toff;
-          if (++wt_tv == P.KWv) {
-            wt_tv = 0;
-            wt_toff += P.HW - P.KWv;
+            if constexpr (BFR_ABL & 8) {
+              bfr_touch(fa[u][0][nt]);
+              bfr_touch(fa[u][1][nt]);
+            } else {
+              fa[u][0][nt] = wb[(u * 3 + v) * ICC * WSLOT + nt * 16];
+              fa[u][1][nt] = wb[(u * 3 + v) * ICC * WSLOT + PLANE_A + nt * 16];
+            }
           }
         };
-        auto mfmas = [&](const uint4 (&a)[2][NTW], const uint4 (&bb)[2][MTW]) {
+        auto ldB = [&](auto sc) {  // step s = v * 6 + R
+          constexpr int s = decltype(sc)::value, v = s / 6, R = s - 6 * v;
+          if constexpr (BFR_ABL & 8) {
+            bfr_touch(fb[s % 3][0]);
+            bfr_touch(fb[s % 3][1]);
+          } else {
+            fb[s % 3][0] = hb[R * HW + v];
+            fb[s % 3][1] = hb[R * HW + v + PLANE_B];
+          }
+        };
+        auto mfma3 = [&](auto uc, auto sc) {  // kernel row u against the pixel fragment of step s: output row R - u
+          constexpr int u = decltype(uc)::value, s = decltype(sc)::value, R = s % 6, r = R - u;
+          const uint4(&a)[2][NTW] = fa[u];
+          const uint4(&bb)[2] = fb[s % 3];
           if constexpr (BFR_ABL & 4) {
+            bfr_use(bb[0]);
+            bfr_use(bb[1]);
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) { bfr_use(bb[0][mt]); bfr_use(bb[1][mt]); }
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) { bfr_use(a[0][nt]); bfr_use(a[1][nt]); }
+            for (int nt = 0; nt < NTW; ++nt) {
+              bfr_use(a[0][nt]);
+              bfr_use(a[1][nt]);
+            }
             return;
           }
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt)
+          for (int nt = 0; nt < NTW; ++nt) acc[nt][r] = mfma16x<F16>(a[0][nt], bb[1], acc[nt][r]);  // w_h * x_m
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = mfma16x<F16>(a[0][nt], bb[1][mt], acc[nt][mt]);  // w_h * x_m
+          for (int nt = 0; nt < NTW; ++nt) acc[nt][r] = mfma16x<F16>(a[1][nt], bb[0], acc[nt][r]);  // w_m * x_h
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = mfma16x<F16>(a[1][nt], bb[0][mt], acc[nt][mt]);  // w_m * x_h
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = mfma16x<F16>(a[0][nt], bb[0][mt], acc[nt][mt]);  // w_h * x_h
+          for (int nt = 0; nt < NTW; ++nt) acc[nt][r] = mfma16x<F16>(a[0][nt], bb[0], acc[nt][r]);  // w_h * x_h
         };
-        load_frags(fa[0], fb[0]);
-        srk_static_for<0, TT>([&](auto tc) {
-          constexpr int t = decltype(tc)::value;
-          if (t + 1 < TT) load_frags(fa[(t + 1) & 1], fb[(t + 1) & 1]);
-          __builtin_amdgcn_sched_barrier(0);
-          mfmas(fa[t & 1], fb[t & 1]);
-          __builtin_amdgcn_sched_barrier(0);
-          if (pend_live) {
-            srk_static_for<t, (t + 1 < NST ? t + 1 : NST)>([&](auto qc) { store_slot(qc); });
-          }
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        ldA(I0{}, I0{});
+        ldB(I0{});
+        ldA(I1{}, I0{});
+        ldB(I1{});
+        ldA(I2{}, I0{});
+        // 18 steps (kernel column v, halo row R); a step's groups in ascending kernel row, the pixel fragment of step
+        // s + 2 requested behind the first group, the filter fragments of the NEXT kernel column behind the last use of
+        // the current ones (u = 0 after R = 3, u = 1 after R = 4, u = 2 after R = 5)
+        srk_static_for<0, 18>([&](auto sc) {
+          constexpr int s = decltype(sc)::value, v = s / 6, R = s - 6 * v;
+          constexpr int u_lo = R - (MR - 1) > 0 ? R - (MR - 1) : 0, u_hi = R < 2 ? R : 2;
+          srk_static_for<u_lo, u_hi + 1>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            mfma3(uc, sc);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (u == u_lo) {
+              if constexpr (s + 2 < 18) ldB(std::integral_constant<int, s + 2>{});
+              if (pend_live) {
+                if constexpr (s < NST) store_slot(sc);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (v < 2 && u == R - (MR - 1)) {  // last use of kernel row u in this column
+              ldA(uc, std::integral_constant<int, v + 1>{});
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          });
         });
         pend_live = false;
       }
-      bfr_signal(cnt + BFR_MAXBUF + b);  // (the last tap's fragments were operands of MFMAs issued above: the reads have returned)
-      b += cc + 1 < ICc ? ng : 2 * ICc - (ICc - 1) * ng;
+      const long long k2 = BFR_CLK();
+      bfr_signal(cnt + BFR_MAXBUF + b);  // (the last fragments were operands of MFMAs issued above: the reads have returned)
+      ct[0] += k1 - k0; ct[1] += k2 - k1; ct[2] += BFR_CLK() - k2; ct[5] += 1;
+      b += cc + 1 < ICC ? ng : 2 * ICC - (ICC - 1) * ng;
       while (b >= nbuf) {
         b -= nbuf;
         ++k;
       }
     }
-    if (wave_live) park(n, r0, c0);
+    const long long k3 = BFR_CLK();
+    park(n, r0, c0);
+    ct[3] += BFR_CLK() - k3;
     adv2(o_n, o_y, o_x);
   }
+#ifdef BFR_PROF
+  if (B.prof && (tid & 127) == 0) {   // the first wave of either group
+    long long* pr = B.prof + (size_t)blockIdx.x * 16 + 8 + 0 * grp;
+    if (grp == 0) {
+      for (int i = 0; i < 4; ++i) pr[i] = ct[i];
+      pr[4] = BFR_CLK() - ct_begin;
+      pr[5] = ct[5];
+    }
+  }
+#endif
+  (void)ct; (void)ct_begin;
   if (pend_live) srk_static_for<0, NST>([&](auto qc) { store_slot(qc); });
   if (P.ep.y_amax) amax_commit(P.ep.y_amax, amax, blockIdx.x + wave, amax_peek(P.ep.y_amax, blockIdx.x + wave));
   if (dead && lane == 0) atomicAdd(&g_bfr_timeouts, 1u);
 }
 
-template <int NTW>
+template <int NTW, int ICC>
 static int bfr_launch_t(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
   note_amax_written(B.P.ep.y_amax != nullptr);
-  const dim3 blk(768);
-  if constexpr (NTW == 2) {  // data gradients (bf16x3): mask on dy and / or ReLU gradient on dx
-    if (B.P.mask_y && B.P.ep.out_relu) {
-      static LdsLimit limb;
-      limb.ensure(reinterpret_cast<const void*>(&k_conv_bfr<NTW, false, true, true>), lds);
-      note_kernel("k_conv_bfr<%d,mask,relu>", NTW);
-      hipLaunchKernelGGL((k_conv_bfr<NTW, false, true, true>), dim3(grid), blk, lds, s, B);
-      return check_launch("conv_bfr");
-    }
-    if (B.P.mask_y) {
-      static LdsLimit limm;
-      limm.ensure(reinterpret_cast<const void*>(&k_conv_bfr<NTW, false, true, false>), lds);
-      note_kernel("k_conv_bfr<%d,mask>", NTW);
-      hipLaunchKernelGGL((k_conv_bfr<NTW, false, true, false>), dim3(grid), blk, lds, s, B);
-      return check_launch("conv_bfr");
-    }
-    if (B.P.ep.out_relu) {
-      static LdsLimit limo;
-      limo.ensure(reinterpret_cast<const void*>(&k_conv_bfr<NTW, false, false, true>), lds);
-      note_kernel("k_conv_bfr<%d,relu>", NTW);
-      hipLaunchKernelGGL((k_conv_bfr<NTW, false, false, true>), dim3(grid), blk, lds, s, B);
-      return check_launch("conv_bfr");
-    }
-  }
-  if (B.P.mask_y || B.P.ep.out_relu) return -1;
+  const dim3 blk(512);
   if (B.w_descale) {  // f16x3 arithmetic
     static LdsLimit limh;
-    limh.ensure(reinterpret_cast<const void*>(&k_conv_bfr<NTW, true>), lds);
-    note_kernel("k_conv_bfr<%d,f16>", NTW);
-    hipLaunchKernelGGL((k_conv_bfr<NTW, true>), dim3(grid), blk, lds, s, B);
+    limh.ensure(reinterpret_cast<const void*>(&k_conv_bfr<NTW, ICC, true>), lds);
+    note_kernel("k_conv_bfr<%d,%d,f16>", NTW, ICC);
+    hipLaunchKernelGGL((k_conv_bfr<NTW, ICC, true>), dim3(grid), blk, lds, s, B);
     return check_launch("conv_bfr");
   }
   static LdsLimit lim;
-  lim.ensure(reinterpret_cast<const void*>(&k_conv_bfr<NTW>), lds);
-  note_kernel("k_conv_bfr<%d>", NTW);
-  hipLaunchKernelGGL((k_conv_bfr<NTW>), dim3(grid), blk, lds, s, B);
+  lim.ensure(reinterpret_cast<const void*>(&k_conv_bfr<NTW, ICC, false>), lds);
+  note_kernel("k_conv_bfr<%d,%d>", NTW, ICC);
+  hipLaunchKernelGGL((k_conv_bfr<NTW, ICC, false>), dim3(grid), blk, lds, s, B);
   return check_launch("conv_bfr");
 }
 
-// B: the launch as conv_bfw_gather prepared it up to the tile choice (P, wq, ICc, NB, nsl, ...).  Picks the 128-pixel
-// tile and the ring depth; -1 when the layer is not one of the ring kernel's (3x3, 32 or 48 channels per slice, a ring of
-// at least three slots beside the filter).  SRK_BFR=0: never.
+// B: the launch as conv_bfw_gather prepared it up to the tile choice (P, wq, ICc, NB, nsl, ...).  -1 when the layer is not
+// one of the ring kernel's: a stride-1 3x3 gather with 32 or 48 output channels in one slice and 32 or 64 input
+// channels, no gradient masks, an output whose 8 x 16 tiles are mostly full, a ring of at least three slots beside the
+// filter.  SRK_BFR: 0 never, 1 whenever applicable, unset = the efficiency rule.
 int conv_bfr_launch(const BfwParams& B0, hipStream_t s) {
-  if (env_int("SRK_BFR", 1) == 0) return -1;
+  const int mode = env_int("SRK_BFR", 2);
+  if (mode == 0) return -1;
   BfwParams B = B0;
   MfmaConvParams& P = B.P;
   const int ntw = B.NB / 16;
-  if (P.KHv != 3 || P.KWv != 3 || P.is != 1 || (ntw != 2 && ntw != 3) || B.NB % 16 != 0) return -1;
-  if ((P.mask_y || P.ep.out_relu) && ntw != 2) return -1;
+  if (P.KHv != 3 || P.KWv != 3 || P.is != 1 || B.nsl != 1 || (ntw != 2 && ntw != 3) || B.NB != P.OC) return -1;
+  if ((B.ICc != 1 && B.ICc != 2) || P.IC % 8 != 0) return -1;
+  if (ntw == 3 && B.ICc != 1) return -1;  // (48 channels from 64: the instantiation spills; no net has that layer)
+  if (P.mask_y || P.ep.out_relu) return -1;
+  P.TH = BFR_TH; P.TW = BFR_TW; P.HH = BFR_HH; P.HW = BFR_HW;
+  P.tiles_y = (P.PH + BFR_TH - 1) / BFR_TH;
+  P.tiles_x = (P.PW + BFR_TW - 1) / BFR_TW;
+  const long ntiles = (long)P.tiles_x * P.tiles_y * P.N;
+  if (ntiles >= (1L << 29)) return -1;
+  if (mode != 1) {  // worth it from ~90 % full tiles and four tiles per CU upwards (else k_conv_bfw's free tile shapes)
+    if ((double)P.PH * P.PW < 0.9 * (double)P.tiles_y * P.tiles_x * (BFR_TH * BFR_TW)) return -1;
+    if (ntiles < 4L * kNumCU) return -1;
+  }
   const size_t wbytes = (size_t)9 * B.ICc * 8 * B.NB * 16;
+  const size_t slot_bytes = (size_t)8 * BFR_NPIXP * 16;
   const long lds_cap = 160L * 1024 - 512 - 2 * BFR_MAXBUF * 4;
-  long px_cap = (lds_cap - (long)wbytes) / (3 * 128);  // three slots at least
-  if (px_cap > 64 * BFR_PIT) px_cap = 64 * BFR_PIT;
-  if (px_cap < 64) return -1;
-  TilePick best{};
-  if (!bfw_pick_tile(128, P.PH, P.PW, 3, 3, px_cap, B.perm, 1, best)) return -1;
-  P.TH = best.TH; P.TW = best.TW; P.tiles_y = best.tiles_y; P.tiles_x = best.tiles_x; P.HH = best.HH; P.HW = best.HW;
-  B.NPIXp = bfw_group_stride(best.HH * best.HW, B.perm);
-  const size_t slot_bytes = (size_t)8 * B.NPIXp * 16;
   long nbuf = (lds_cap - (long)wbytes) / (long)slot_bytes;
   const int want = env_int("SRK_BFR_NBUF", 0);
   if (want >= 3 && want < nbuf) nbuf = want;
   if (nbuf > BFR_MAXBUF) nbuf = BFR_MAXBUF;
   if (nbuf < 3) return -1;
   B.nbuf = (int)nbuf;
+  B.perm = 1;
+  B.NPIXp = BFR_NPIXP;
+  B.late = env_int("SRK_BFR_PRIO", 2);  // which role issues first on its SIMD (k_conv_bfr: prio)
   const size_t lds = wbytes + (size_t)nbuf * slot_bytes + 2 * BFR_MAXBUF * 4;
-  const long ntiles = (long)P.tiles_x * P.tiles_y * P.N;
-  if (ntiles >= (1L << 29)) return -1;
   B.ntiles = (int)ntiles;
+#ifdef BFR_PROF
+  B.prof = g_bfr_prof;
+#endif
   B.out_bytes = (unsigned)((size_t)P.N * P.OH * P.OW * P.OC * sizeof(float));
-  const int nsl = B.nsl;
   int grid = kNumCU;
-  if (nsl > 1) {
-    grid -= grid % (8 * nsl);
-    const long want_g = ((ntiles + 7) / 8) * 8 * nsl;
-    if (grid == 0) return -1;
-    if (want_g < grid) grid = (int)want_g;
-  } else if (grid > ntiles) {
-    grid = (int)ntiles;
-  }
+  if (grid > ntiles) grid = (int)ntiles;
   if (B.dbg & 32)
-    fprintf(stderr, "[srk] k_conv_bfr<%d>: lds %zu B (filter %zu), ring %d x %zu B, grid %d of %ld tiles x %d slices, tile %dx%d halo %dx%d\n",
-            ntw, lds, wbytes, B.nbuf, slot_bytes, grid, ntiles, nsl, P.TH, P.TW, P.HH, P.HW);
-  return ntw == 2 ? bfr_launch_t<2>(B, lds, grid, s) : bfr_launch_t<3>(B, lds, grid, s);
+    fprintf(stderr, "[srk] k_conv_bfr<%d,%d>: lds %zu B (filter %zu), ring %d x %zu B, grid %d of %ld tiles\n", ntw, B.ICc, lds,
+            wbytes, B.nbuf, slot_bytes, grid, ntiles);
+  if (ntw == 2) return B.ICc == 1 ? bfr_launch_t<2, 1>(B, lds, grid, s) : bfr_launch_t<2, 2>(B, lds, grid, s);
+  return bfr_launch_t<3, 1>(B, lds, grid, s);
 }
 
 }  // namespace srk
+
+#ifdef BFR_PROF
+extern "C" void srk_debug_ring_prof(void* p) { srk::g_bfr_prof = static_cast<long long*>(p); }
+#endif
 
 // Polls of k_conv_bfr that ran into their iteration cap since the last reset (0 in a correct library; a diagnostic for
 // tests and fuzzers -- synchronises the device).

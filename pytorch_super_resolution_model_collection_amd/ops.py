@@ -547,14 +547,17 @@ def flush_wgrads(on_group=None, max_layers=None):
     # behind the last group (srk_wgrad_reduce_defer / _flush; the workspaces stay alive until then)
     lib = _lib.load()
     prev = lib.srk_wgrad_reduce_defer(1)
+    keep = []   # the workspaces of the queued jobs: alive until the queue has run, on the error path as well
     try:
-        keep = [launch_wgrad_group(recs) for recs in groups]
+        for recs in groups:
+            keep.append(launch_wgrad_group(recs))
         check(lib.srk_wgrad_reduce_flush(stream_ptr()), "srk_wgrad_reduce_flush")
     finally:
         lib.srk_wgrad_reduce_defer(prev)
-        # a failure above may leave queued jobs behind: run them now rather than inside somebody else's flush
+        # a failure above may leave queued jobs behind: run them now (their slabs are still held by `keep`) rather than
+        # inside somebody else's flush
         lib.srk_wgrad_reduce_flush(stream_ptr())
-    del keep
+        del keep[:]
     return len(groups)
 
 

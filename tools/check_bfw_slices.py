@@ -2,6 +2,7 @@
 """Output-channel slices of k_conv_bfw (64 -> 64 / 128 / 256, plain and pixel-shuffled stores) against the per-tile
 bf16x3 kernels (SRK_BFW=0): same arithmetic and accumulation order, so the outputs must be equal."""
 import os, sys, torch
+os.environ["SRK_ENV_LIVE"] = "1"   # this tool flips SRK_* switches in-process: the library must re-read them (csrc/api.hip env_str)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import pytorch_super_resolution_model_collection_amd as pkg

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Role-time sums inside k_conv_bfr (first producer wave: wait for a free slot / wait for its loads / split + commit / signal /
+issue; consumer wave 0: wait for a full slot / the 18 steps / signal / parking) on the two 3x3 layers of c2.
+Needs a -DBFR_PROF build:  EXTRA=-DBFR_PROF TAG=prof tools/ring_ablate.sh 0;  SRK_LIB_PATH=variants/ring_0prof.so python tools/ring_prof.py"""
+import ctypes, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import pytorch_super_resolution_model_collection_amd as pkg
+from pytorch_super_resolution_model_collection_amd import _lib
+ops = pkg.ops
+lib = _lib.load()
+P = _lib.ptr
+dev = torch.device("cuda:0")
+lib.srk_debug_ring_prof.argtypes = [ctypes.c_void_p]
+lib.srk_debug_ring_prof.restype = None
+prof = torch.zeros(4096 * 16, dtype=torch.int64, device=dev)
+net = pkg.ESPCNNet(3, 64, 4); net.weight_init(); net.to(dev).eval()
+x = torch.rand(64, 3, 256, 256, device=dev)
+with torch.no_grad():
+    hs, h = [], x
+    for l in net.layers:
+        hs.append(h); h = l(h)
+    for i in (1, 2):
+        l = net.layers[i]
+        for _ in range(3): l(hs[i])
+        torch.cuda.synchronize()
+        prof.zero_()
+        lib.srk_debug_ring_prof(P(prof))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); l(hs[i]); e1.record(); torch.cuda.synchronize()
+        lib.srk_debug_ring_prof(None)
+        t = prof.view(-1, 16).cpu().double()
+        t = t[t[:, 13] > 0]
+        st = t[:, 13].mean()      # own stages of consumer wave 0 (half of the block's)
+        print("layer %d %s: %.1f us with stamps, %d blocks, %.0f stages per group" % (i, lib.srk_last_kernel_name().decode(), e0.elapsed_time(e1) * 1e3, t.shape[0], st))
+        tp, tc = t[:, 5].mean(), t[:, 12].mean()
+        names = ["wait free", "wait loads", "split+commit", "signal", "issue"]
+        print("   producer (ticks per stage, %% of its loop): " + "  ".join("%s %.0f (%.0f %%)" % (n, t[:, j].mean() / (2 * st), 100 * t[:, j].mean() / tp) for j, n in enumerate(names)) + "   loop %.0f" % tp)
+        names = ["wait full", "steps", "signal", "park"]
+        print("   consumer (ticks per own stage, %% of its loop): " + "  ".join("%s %.0f (%.0f %%)" % (n, t[:, 8 + j].mean() / st, 100 * t[:, 8 + j].mean() / tc) for j, n in enumerate(names)) + "   loop %.0f" % tc)

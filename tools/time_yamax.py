@@ -3,6 +3,7 @@
 each layer timed alone on a fixed, tagged input with and without SRK_NO_YAMAX=1; then the first layer on the per-tile
 (SRK_ROWSW=0) and the persistent (SRK_ROWSW=1) row-packed kernel.   python tools/time_yamax.py"""
 import os, sys, torch
+os.environ["SRK_ENV_LIVE"] = "1"   # this tool flips SRK_* switches in-process: the library must re-read them (csrc/api.hip env_str)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import pytorch_super_resolution_model_collection_amd as pkg
