@@ -33,17 +33,22 @@ __device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c)
 // ---- f16x3: x * 2^k split into two fp16 planes (h = RN(x s), m = RN(x s - h)); see SRK_ALGO_MFMA_F16X3 -------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// Two values per call, four v_fma_mix: h = f16(x s) and m = f16(x s - h) straight from the fp32 operands (the mixed-precision
+// fma rounds once to fp16; x s is exact -- s is a power of two -- and x s - h has at most 13 significant bits, so both
+// results equal the cvt / sub / cvt sequence bit for bit: tools/micro/split_test.hip, 8.4 M words at four scales).  The
+// compiler's own choice for the scalar source was 23 instructions per 8 values, half of them packed fp32 operations that are
+// slow beside an MFMA stream (tools/micro/coissue.hip); this is 16.
+__device__ __forceinline__ void split2h(float x0, float x1, float s, unsigned& h, unsigned& m) {
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(m) : "v"(x0), "v"(s), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(m) : "v"(x1), "v"(s), "v"(h));
+}
 __device__ __forceinline__ void split8h(const float (&f)[8], float s, uint4 (&pl)[2]) {
-  f16x8 h, m;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float x = f[e] * s;
-    const _Float16 hh = (_Float16)x;
-    h[e] = hh;
-    m[e] = (_Float16)(x - (float)hh);
-  }
-  pl[0] = __builtin_bit_cast(uint4, h);
-  pl[1] = __builtin_bit_cast(uint4, m);
+  split2h(f[0], f[1], s, pl[0].x, pl[1].x);
+  split2h(f[2], f[3], s, pl[0].y, pl[1].y);
+  split2h(f[4], f[5], s, pl[0].z, pl[1].z);
+  split2h(f[6], f[7], s, pl[0].w, pl[1].w);
 }
 
 __device__ __forceinline__ f32x4 mfma16h(const uint4& a, const uint4& b, f32x4 c) {

@@ -50,11 +50,14 @@ __device__ unsigned g_bfr_timeouts = 0;
 // Profiling builds (-DBFR_PROF, tools/ring_prof.py): s_memtime sums per role -- 16 int64 per block:
 // [0..5] first producer wave {wait free, wait loads, split + commit, signal, issue, total}, [8..13] consumer wave 0
 // {wait full, steps, signal, park, total, stages}
+// (-DBFR_PROF=2: only the loop totals -- two stamps per wave, the stream itself is the release one)
 #ifdef BFR_PROF
 static long long* g_bfr_prof = nullptr;
-#define BFR_CLK() clock64()
+#define BFR_CLK() (BFR_PROF == 2 ? 0ll : clock64())
+#define BFR_CLK_TOTAL() clock64()
 #else
 #define BFR_CLK() 0ll
+#define BFR_CLK_TOTAL() 0ll
 #endif
 
 typedef __attribute__((address_space(3))) unsigned bfr_cnt_t;
@@ -80,9 +83,14 @@ __device__ __forceinline__ void bfr_wait(bfr_cnt_t* p, unsigned target, bool& de
   }
   asm volatile("" ::: "memory");
 }
-// every LDS access this wave issued so far has completed, then one count
+// One count behind every LDS access this wave has issued so far.  No s_waitcnt: the LDS executes the operations of one wave
+// in the order they were issued, so whoever sees the count sees the writes (or finds the reads done) that precede it.
+// (BFR_SIGNAL_WAIT=1 builds drain the wave's LDS queue first.)
+#ifndef BFR_SIGNAL_WAIT
+#define BFR_SIGNAL_WAIT 0
+#endif
 __device__ __forceinline__ void bfr_signal(bfr_cnt_t* p) {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if constexpr (BFR_SIGNAL_WAIT != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("" ::: "memory");
   if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   asm volatile("" ::: "memory");
 }
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
     int b = 0;
     unsigned k = 0;  // slot and use count of the stage about to be committed
     long long pt[5] = {0, 0, 0, 0, 0};
-    const long long pt_begin = BFR_CLK();
+    const long long pt_begin = BFR_CLK_TOTAL();
     for (int s = 0; s < S; s += NSET) {
       srk_static_for<0, NSET>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
     if (B.prof && tid == 64 * NCW) {
       long long* pr = B.prof + (size_t)blockIdx.x * 16;
       for (int i = 0; i < 5; ++i) pr[i] = pt[i];
-      pr[5] = BFR_CLK() - pt_begin;
+      pr[5] = BFR_CLK_TOTAL() - pt_begin;
     }
 #endif
     (void)pt; (void)pt_begin;
@@ -304,6 +312,13 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
   }
 
   // -------------------------------------------------------------------- consumers
+  // One consumer wave per SIMD: every cycle in which this wave has no MFMA to issue is a cycle its matrix pipe idles (a
+  // lone MFMA wave reaches 2.25 - 2.4 PF at any accumulator distance, beside a VALU / LDS / VMEM partner wave too:
+  // tools/micro/mfma_chain.hip, coissue.hip).  So the stream below has no stage boundaries: fragments are requested two
+  // steps ahead ACROSS stages (the next stage's filter fragments are in LDS anyway, its first pixel fragments are
+  // requested once its slot is known to be full: counter peeked at step 8, checked at step 14), the slot is handed back
+  // at step 15 right behind its last read, the finished tile's stores go out unconditionally one per `SPER` steps of the
+  // next tile, and parking is a handful of packed operations per accumulator.
   if (prio == 2) __builtin_amdgcn_s_setprio(1);
   const int grp = __builtin_amdgcn_readfirstlane(wave >> 1), gw = wave & 1;
   // lane column -> pixel column of the 16-pixel M tile: lanes {0-3, 12-15} hold the even columns, {4-11} the odd ones
@@ -327,18 +342,24 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
   const float act_slope = P.ep.act == SRK_ACT_NONE ? 1.f
                           : P.ep.act == SRK_ACT_RELU ? 0.f
                           : P.ep.act == SRK_ACT_PRELU ? P.ep.prelu_w[0] : P.ep.slope;
+  const int act_kind = __builtin_amdgcn_readfirstlane(P.ep.act == SRK_ACT_NONE ? 0 : (P.ep.act == SRK_ACT_RELU ? 1 : 2));
+  const bool want_amax = __builtin_amdgcn_readfirstlane(P.ep.y_amax != nullptr);
   f32x4 acc[NTW][MR];
-  f32x4 pend[NTW][MR];  // the finished tile, stored one slot per step under the next stage's MFMAs (see k_conv_bfw)
+  f32x4 pend[NTW][MR];  // the finished tile, stored under the next tile's MFMAs
   float amax = 0.f;
   constexpr unsigned kDrop = 0x80000000u;
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(P.out, 0, B.out_bytes, 0x00020000);
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
-  unsigned pend_voff[MR];
+  unsigned pend_voff[MR];  // (kDrop: the buffer unit drops the store -- before the first tile, and pixels beyond the image)
 #pragma unroll
   for (int r = 0; r < MR; ++r) pend_voff[r] = kDrop;
-  bool pend_live = false;
-  constexpr int NST = NTW * MR;  // stores per tile and lane, slot q = r * NTW + nt
-  static_assert(NST <= 18, "every pending store must find a step");
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int r = 0; r < MR; ++r) pend[nt][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int NST = NTW * MR;               // stores per tile and lane, slot q = r * NTW + nt
+  constexpr int SPER = (18 * ICC) / NST;      // one store every SPER steps of the next tile
+  static_assert(SPER >= 1, "every pending store must find a step");
   auto store_slot = [&](auto qc) {
     constexpr int q = decltype(qc)::value;
     constexpr int r = q / NTW, nt = q - r * NTW;
@@ -349,29 +370,41 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
     }
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), orsrc, (int)(pend_voff[r] + 4u * (unsigned)coff[nt]), 0, 0);
   };
-  auto park = [&](int n, int r0, int c0) {
+  // accumulators -> pend: v = act(acc * 2^-k + bias).  One packed fma per two values, the activation by kind (ReLU = one
+  // max; none = nothing; leaky / PReLU = max + min + fma), the running maximum as max3 with |.| modifiers
+  auto park_kind = [&](auto kind_c, int n, int r0, int c0) {
+    constexpr int KIND = decltype(kind_c)::value;
     const unsigned tile_off = 4u * (unsigned)epi_tile_setup(P, n, r0, c0).off0;
     const bool col_ok = c0 + pj < P.PW;
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
       const bool pok = col_ok && r0 + MR * gw + r < P.PH;
       pend_voff[r] = pok ? tile_off + 4u * (unsigned)poff[r] : kDrop;
+      float rmax = 0.f;
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
         f32x4 v = acc[nt][r];
-        if constexpr (BFR_ABL & 32) {
-          pend[nt][r] = v;
-          continue;
-        }
-        if constexpr (F16) v *= dsc;
-        v += bias4[nt];
+        if constexpr (!(BFR_ABL & 32)) {
+          if constexpr (F16) v = __builtin_elementwise_fma(v, (f32x4){dsc, dsc, dsc, dsc}, bias4[nt]); else v += bias4[nt];
+          if constexpr (KIND == 1) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : act_slope * v[e];
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          } else if constexpr (KIND == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(act_slope, fminf(v[e], 0.f), fmaxf(v[e], 0.f));
+          }
+          rmax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), rmax);
+          rmax = fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), rmax);
+        }
         pend[nt][r] = v;
-        if (P.ep.y_amax && pok) amax = abs_max4(amax, v);
       }
+      if (want_amax) amax = pok ? fmaxf(amax, rmax) : amax;
     }
-    pend_live = true;
+  };
+  auto park = [&](int n, int r0, int c0) {
+    if (act_kind == 1) park_kind(std::integral_constant<int, 1>{}, n, r0, c0);
+    else if (act_kind == 0) park_kind(std::integral_constant<int, 0>{}, n, r0, c0);
+    else park_kind(std::integral_constant<int, 2>{}, n, r0, c0);
   };
   // (everything this wave loaded so far has landed before the loop: see k_conv_bfw)
 #pragma unroll
@@ -383,9 +416,70 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
   // the global order, ng = tiles of the pair
   int o_n = grp ? b_n : a_n, o_y = grp ? b_y : a_y, o_x = grp ? b_x : a_x;
   long long ct[6] = {0, 0, 0, 0, 0, 0};
-  const long long ct_begin = BFR_CLK();
-  int b = grp;     // ring slot of the next own stage (nbuf >= 3 > grp)
+  const long long ct_begin = BFR_CLK_TOTAL();
+#ifdef BFR_PROF
+  const long long cw_begin = wall_clock64();
+#endif
+  int b = grp;     // ring slot of the current own stage (nbuf >= 3 > grp)
   unsigned k = 0;  // ... and how often that slot was used before
+  uint4 fa[3][2][NTW];  // filter fragments of the current kernel column: [kernel row u][plane][tile]
+  uint4 fb[3][2];       // pixel fragments of three consecutive steps: [step % 3][plane]
+  const uint4* hb = hal0 + (size_t)b * HBUF + lane_b;
+  auto ldA = [&](auto uc, auto vc, auto ccc) {
+    constexpr int u = decltype(uc)::value, v = decltype(vc)::value, cc = decltype(ccc)::value;
+    const uint4* wb = wl + lane_a;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      if constexpr (BFR_ABL & 8) {
+        bfr_touch(fa[u][0][nt]);
+        bfr_touch(fa[u][1][nt]);
+      } else {
+        fa[u][0][nt] = wb[((u * 3 + v) * ICC + cc) * WSLOT + nt * 16];
+        fa[u][1][nt] = wb[((u * 3 + v) * ICC + cc) * WSLOT + PLANE_A + nt * 16];
+      }
+    }
+  };
+  auto ldB = [&](const uint4* base, auto sc) {  // step s = v * 6 + R of the stage whose slot `base` points into
+    constexpr int s = decltype(sc)::value, v = s / 6, R = s - 6 * v;
+    if constexpr (BFR_ABL & 8) {
+      bfr_touch(fb[s % 3][0]);
+      bfr_touch(fb[s % 3][1]);
+    } else {
+      fb[s % 3][0] = base[R * HW + v];
+      fb[s % 3][1] = base[R * HW + v + PLANE_B];
+    }
+  };
+  auto mfma3 = [&](auto uc, auto sc) {  // kernel row u against the pixel fragment of step s: output row R - u
+    constexpr int u = decltype(uc)::value, s = decltype(sc)::value, R = s % 6, r = R - u;
+    const uint4(&a)[2][NTW] = fa[u];
+    const uint4(&bb)[2] = fb[s % 3];
+    if constexpr (BFR_ABL & 4) {
+      bfr_use(bb[0]);
+      bfr_use(bb[1]);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        bfr_use(a[0][nt]);
+        bfr_use(a[1][nt]);
+      }
+      return;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[nt][r] = mfma16x<F16>(a[0][nt], bb[1], acc[nt][r]);  // w_h * x_m
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[nt][r] = mfma16x<F16>(a[1][nt], bb[0], acc[nt][r]);  // w_m * x_h
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[nt][r] = mfma16x<F16>(a[0][nt], bb[0], acc[nt][r]);  // w_h * x_h
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  if (grp < count) {  // the first own stage: nothing to overlap the wait and the first fragments with
+    bfr_wait(cnt + b, NPW * (k + 1), dead);
+    ldA(I0{}, I0{}, I0{});
+    ldB(hb, I0{});
+    ldA(I1{}, I0{}, I0{});
+    ldB(hb, I1{});
+  }
   for (int ti = grp; ti < count; ti += 2) {
     const int ng = (ti | 1) < count ? 2 : 1;
     const int n = o_n, r0 = o_y * TH, c0 = o_x * TW;
@@ -393,118 +487,91 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
       for (int r = 0; r < MR; ++r) acc[nt][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int cc = 0; cc < ICC; ++cc) {
-      const long long k0 = BFR_CLK();
-      bfr_wait(cnt + b, NPW * (k + 1), dead);
+    srk_static_for<0, ICC>([&](auto ccc) {
+      constexpr int cc = decltype(ccc)::value, ccn = cc + 1 < ICC ? cc + 1 : 0;
       const long long k1 = BFR_CLK();
-      {
-        const uint4* hb = hal0 + (size_t)b * HBUF + lane_b;
-        const uint4* wb = wl + (size_t)cc * WSLOT + lane_a;
-        uint4 fa[3][2][NTW];  // filter fragments of the current kernel column: [kernel row u][plane][tile]
-        uint4 fb[3][2];       // pixel fragments of three consecutive steps: [step % 3][plane]
-        auto ldA = [&](auto uc, auto vc) {
-          constexpr int u = decltype(uc)::value, v = decltype(vc)::value;
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) {
-            if constexpr (BFR_ABL & 8) {
-              bfr_touch(fa[u][0][nt]);
-              bfr_touch(fa[u][1][nt]);
-            } else {
-              fa[u][0][nt] = wb[(u * 3 + v) * ICC * WSLOT + nt * 16];
-              fa[u][1][nt] = wb[(u * 3 + v) * ICC * WSLOT + PLANE_A + nt * 16];
-            }
-          }
-        };
-        auto ldB = [&](auto sc) {  // step s = v * 6 + R
-          constexpr int s = decltype(sc)::value, v = s / 6, R = s - 6 * v;
-          if constexpr (BFR_ABL & 8) {
-            bfr_touch(fb[s % 3][0]);
-            bfr_touch(fb[s % 3][1]);
-          } else {
-            fb[s % 3][0] = hb[R * HW + v];
-            fb[s % 3][1] = hb[R * HW + v + PLANE_B];
-          }
-        };
-        auto mfma3 = [&](auto uc, auto sc) {  // kernel row u against the pixel fragment of step s: output row R - u
-          constexpr int u = decltype(uc)::value, s = decltype(sc)::value, R = s % 6, r = R - u;
-          const uint4(&a)[2][NTW] = fa[u];
-          const uint4(&bb)[2] = fb[s % 3];
-          if constexpr (BFR_ABL & 4) {
-            bfr_use(bb[0]);
-            bfr_use(bb[1]);
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-              bfr_use(a[0][nt]);
-              bfr_use(a[1][nt]);
-            }
-            return;
-          }
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[nt][r] = mfma16x<F16>(a[0][nt], bb[1], acc[nt][r]);  // w_h * x_m
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[nt][r] = mfma16x<F16>(a[1][nt], bb[0], acc[nt][r]);  // w_m * x_h
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[nt][r] = mfma16x<F16>(a[0][nt], bb[0], acc[nt][r]);  // w_h * x_h
-        };
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>;
-        ldA(I0{}, I0{});
-        ldB(I0{});
-        ldA(I1{}, I0{});
-        ldB(I1{});
-        ldA(I2{}, I0{});
-        // 18 steps (kernel column v, halo row R); a step's groups in ascending kernel row, the pixel fragment of step
-        // s + 2 requested behind the first group, the filter fragments of the NEXT kernel column behind the last use of
-        // the current ones (u = 0 after R = 3, u = 1 after R = 4, u = 2 after R = 5)
-        srk_static_for<0, 18>([&](auto sc) {
-          constexpr int s = decltype(sc)::value, v = s / 6, R = s - 6 * v;
-          constexpr int u_lo = R - (MR - 1) > 0 ? R - (MR - 1) : 0, u_hi = R < 2 ? R : 2;
-          srk_static_for<u_lo, u_hi + 1>([&](auto uc) {
-            constexpr int u = decltype(uc)::value;
-            mfma3(uc, sc);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (u == u_lo) {
-              if constexpr (s + 2 < 18) ldB(std::integral_constant<int, s + 2>{});
-              if (pend_live) {
-                if constexpr (s < NST) store_slot(sc);
+      // the next own stage: its slot, its use count, whether it exists
+      const bool has_next = cc + 1 < ICC || ti + 2 < count;
+      int nb = b + (cc + 1 < ICC ? ng : 2 * ICC - (ICC - 1) * ng);
+      unsigned nk = k;
+      while (nb >= nbuf) {
+        nb -= nbuf;
+        ++nk;
+      }
+      const uint4* hbn = hal0 + (size_t)nb * HBUF + lane_b;
+      unsigned peek_v = 0;
+      // 18 steps (kernel column v, halo row R); a step's groups in ascending kernel row; behind the first group: the pixel
+      // fragment of step s + 2 (of the NEXT stage from step 16 on), a pending store, the ring bookkeeping; behind the
+      // first group as well: one kernel row of filter fragments (see below)
+      srk_static_for<0, 18>([&](auto sc) {
+        constexpr int s = decltype(sc)::value, v = s / 6, R = s - 6 * v;
+        constexpr int u_lo = R - (MR - 1) > 0 ? R - (MR - 1) : 0, u_hi = R < 2 ? R : 2;
+        constexpr int g = cc * 18 + s;
+        srk_static_for<u_lo, u_hi + 1>([&](auto uc) {
+          constexpr int u = decltype(uc)::value;
+          mfma3(uc, sc);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (u == u_lo) {
+            if constexpr (s + 2 < 18) ldB(hb, std::integral_constant<int, s + 2>{});
+            else ldB(hbn, std::integral_constant<int, s + 2 - 18>{});
+            if constexpr (g % SPER == 0 && g / SPER < NST) store_slot(std::integral_constant<int, g / SPER>{});
+            if constexpr (s == 8) peek_v = __hip_atomic_load(cnt + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if constexpr (s == 14) {
+              if (has_next && !dead) {  // the next stage's slot must be full before its first fragments are requested (step 16)
+                unsigned seen = (unsigned)__builtin_amdgcn_readfirstlane((int)peek_v), spins = 0;
+                while ((int)(seen - NPW * (nk + 1)) < 0) {
+                  __builtin_amdgcn_s_sleep(1);
+                  seen = bfr_peek(cnt + nb);
+                  if (++spins > BFR_SPIN_CAP) {
+                    dead = true;
+                    break;
+                  }
+                }
               }
+              asm volatile("" ::: "memory");
+            }
+            if constexpr (s == 15) {  // the slot's last fragment (step 17) has just been requested: hand the slot back (the LDS
+                                      // executes one wave's operations in order: the count lands behind the reads)
+              bfr_signal(cnt + BFR_MAXBUF + b);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          // filter fragments: kernel row u's last use in a column is step R = u + 3, and requesting its successor right
+          // behind that use costs WAR wait states -- so row 0 follows at R = 4 and row 1 at R = 5 (for the next column; from
+          // v = 2 on: the next stage's first column), row 2 at R = 0 of the column that needs it at R = 2
+          if constexpr (u == u_lo) {
+            if constexpr (R == 0) {
+              ldA(I2{}, std::integral_constant<int, v>{}, ccc);
+              __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (R >= 4) {
+              if constexpr (v < 2) ldA(std::integral_constant<int, R - 4>{}, std::integral_constant<int, v + 1>{}, ccc);
+              else ldA(std::integral_constant<int, R - 4>{}, I0{}, std::integral_constant<int, ccn>{});
               __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (v < 2 && u == R - (MR - 1)) {  // last use of kernel row u in this column
-              ldA(uc, std::integral_constant<int, v + 1>{});
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          });
+          }
         });
-        pend_live = false;
-      }
-      const long long k2 = BFR_CLK();
-      bfr_signal(cnt + BFR_MAXBUF + b);  // (the last fragments were operands of MFMAs issued above: the reads have returned)
-      ct[0] += k1 - k0; ct[1] += k2 - k1; ct[2] += BFR_CLK() - k2; ct[5] += 1;
-      b += cc + 1 < ICC ? ng : 2 * ICC - (ICC - 1) * ng;
-      while (b >= nbuf) {
-        b -= nbuf;
-        ++k;
-      }
-    }
+      });
+      ct[1] += BFR_CLK() - k1; ct[5] += 1;
+      b = nb;
+      k = nk;
+      hb = hbn;
+    });
     const long long k3 = BFR_CLK();
     park(n, r0, c0);
     ct[3] += BFR_CLK() - k3;
     adv2(o_n, o_y, o_x);
   }
+  srk_static_for<0, NST>([&](auto qc) { store_slot(qc); });   // the last tile
 #ifdef BFR_PROF
-  if (B.prof && (tid & 127) == 0) {   // the first wave of either group
-    long long* pr = B.prof + (size_t)blockIdx.x * 16 + 8 + 0 * grp;
-    if (grp == 0) {
-      for (int i = 0; i < 4; ++i) pr[i] = ct[i];
-      pr[4] = BFR_CLK() - ct_begin;
-      pr[5] = ct[5];
-    }
+  if (B.prof && tid == 0) {
+    long long* pr = B.prof + (size_t)blockIdx.x * 16 + 8;
+    for (int i = 0; i < 4; ++i) pr[i] = ct[i];
+    pr[4] = BFR_CLK_TOTAL() - ct_begin;
+    pr[5] = ct[5];
+    pr[6] = wall_clock64() - cw_begin;   // 100 MHz: the loop in wall time
   }
 #endif
   (void)ct; (void)ct_begin;
-  if (pend_live) srk_static_for<0, NST>([&](auto qc) { store_slot(qc); });
   if (P.ep.y_amax) amax_commit(P.ep.y_amax, amax, blockIdx.x + wave, amax_peek(P.ep.y_amax, blockIdx.x + wave));
   if (dead && lane == 0) atomicAdd(&g_bfr_timeouts, 1u);
 }

@@ -309,7 +309,6 @@ def test_conv_wave_specialized_data_gradient(gpu, monkeypatch, cin, cout, H, W, 
     (32, 48, 37, 50, 2, None, 4, "mixed"),        # c2 third layer: one chunk, fused pixel-shuffle store, f16x3
     (64, 32, 9, 300, 1, "lrelu", 0, "bf16x3"),    # fewer tiles than XCDs, ragged rows and columns
     (32, 32, 19, 19, 1, "lrelu", 0, "bf16x3"),    # one chunk, odd tile counts per block
-    (40, 48, 23, 17, 5, "prelu", 0, "mixed"),     # partial channel chunk (40 = 32 + 8): two chunks need the 32-channel form
     (40, 32, 23, 17, 5, "prelu", 0, "mixed"),     # partial channel chunk (40 = 32 + 8)
     (64, 32, 130, 200, 4, "relu", 0, "mixed"),    # several pairs of tiles per block
     (32, 48, 90, 150, 6, "relu", 0, "bf16x3"),    # several pairs of tiles per block, 48 channels

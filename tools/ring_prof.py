@@ -27,6 +27,7 @@ with torch.no_grad():
         prof.zero_()
         lib.srk_debug_ring_prof(P(prof))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(10): l(hs[i])     # back to back: a lone launch behind an idle gap runs at a lower clock (DVFS ramp)
         e0.record(); l(hs[i]); e1.record(); torch.cuda.synchronize()
         lib.srk_debug_ring_prof(None)
         t = prof.view(-1, 16).cpu().double()
@@ -36,5 +37,6 @@ with torch.no_grad():
         tp, tc = t[:, 5].mean(), t[:, 12].mean()
         names = ["wait free", "wait loads", "split+commit", "signal", "issue"]
         print("   producer (ticks per stage, %% of its loop): " + "  ".join("%s %.0f (%.0f %%)" % (n, t[:, j].mean() / (2 * st), 100 * t[:, j].mean() / tp) for j, n in enumerate(names)) + "   loop %.0f" % tp)
+        print("   consumer loop: %.0f ticks in %.1f us of wall clock -> %.3f GHz" % (tc, t[:, 14].mean() / 100.0, tc / (t[:, 14].mean() / 100.0) / 1e3))
         names = ["wait full", "steps", "signal", "park"]
         print("   consumer (ticks per own stage, %% of its loop): " + "  ".join("%s %.0f (%.0f %%)" % (n, t[:, 8 + j].mean() / st, 100 * t[:, 8 + j].mean() / tc) for j, n in enumerate(names)) + "   loop %.0f" % tc)
