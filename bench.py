@@ -167,10 +167,10 @@ def pmc_traffic(kernel_label, batch, lr_size):
     inside this process).  Only valid for the default c2 shape the passes were taken on."""
     import glob
     if batch != 64 or lr_size != 256:
-        return None
+        return None, None
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_c2_pmc_traffic.json")))
     if not files:
-        return None
+        return None, None
     with open(files[-1]) as fh:
         kernels = json.load(fh).get("kernels", {})
     def targs(name):
@@ -200,8 +200,8 @@ def pmc_traffic(kernel_label, batch, lr_size):
     want = targs(kernel_label.split(" ")[0])
     for name, rec in kernels.items():
         if rec.get("hbm_bytes") and targs(name) == want:
-            return int(rec["hbm_bytes"])
-    return None
+            return int(rec["hbm_bytes"]), os.path.join("profiles", os.path.basename(files[-1]))
+    return None, None
 
 
 def training_roofline(tag, px, layer_px_note, layers_per_step=1, steps=5):
@@ -331,8 +331,10 @@ def cpu_baseline(batch_cap=8, lr_size=256):
     # host has is listed as host_* beside it
     return {"value": round(batch_cap / best, 2), "unit": "images/s", "cores": best_threads,
             "host_physical_cores": physical, "host_threads": ncpu, "kind": "port",
-            "sample": "oracle ESPCN x4 forward (stock torch.nn CPU fp32), batch %d of %dx%d LR, best of 3 at the best of "
-                      "%s threads" % (batch_cap, lr_size, lr_size, sorted({ncpu, ncpu // 2, ncpu // 4, 32, 16, 8}))}
+            "sample": "oracle ESPCN x4 forward (stock torch.nn CPU fp32), batch %d of %dx%d LR, best of 3; `cores` = the torch "
+                      "thread count of the best run (%d) out of the tried %s on a host with %d hardware threads -- more threads "
+                      "were slower, not unavailable" % (batch_cap, lr_size, lr_size, best_threads,
+                                                        sorted(t for t in {ncpu, ncpu // 2, ncpu // 4, 32, 16, 8} if 0 < t <= ncpu), ncpu)}
 
 
 # Per-sample algorithmic conv FLOPs of the training configs and the bf16 MFMA work the default
@@ -640,6 +642,73 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None, cpu_baselines=True):
     return out
 
 
+def c2_graph_replay_ms(net, x, steps, dev):
+    """ms per c2 forward replayed from a hipGraph (the three launches back to back, no host work between them)."""
+    side = torch.cuda.Stream(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.stream(side):
+        net(x)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            y = net(x)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    del y
+    return e0.elapsed_time(e1) / steps
+
+
+def board_power_probe(fn, seconds=2.5):
+    """Board power and shader clock (rocm-smi, median of the samples) while `fn` loops for `seconds`: the c2 layers run at
+    the board's power cap, where the clock -- not a pipe -- is what a faster kernel buys back.  None when
+    rocm-smi is not there."""
+    import re
+    import shutil
+    import statistics
+    import subprocess
+    import threading
+    if not shutil.which("rocm-smi"):
+        return None
+    stop = threading.Event()
+    samples = []
+
+    def sample():
+        while not stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+            except Exception:  # noqa: BLE001
+                return
+            pw = re.findall(r"Power \(W\): ([0-9.]+)", out)
+            ck = re.findall(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+            if pw and ck:
+                samples.append((float(pw[0]), float(ck[0])))
+
+    th = threading.Thread(target=sample, daemon=True)
+    t0 = time.time()
+    n = 0
+    th.start()
+    while time.time() - t0 < seconds:
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        n += 20
+    dt = (time.time() - t0) / max(n, 1)
+    stop.set()
+    th.join(timeout=6)
+    samples = samples[1:] if len(samples) > 2 else samples   # (the first sample may predate the load)
+    if not samples:
+        return None
+    return {"board_power_w": round(statistics.median(p for p, _ in samples), 1),
+            "sclk_mhz": round(statistics.median(c for _, c in samples), 1), "samples": len(samples),
+            "ms_per_step_while_sampling": round(dt * 1e3, 4)}
+
+
 def c2_other_precisions(pkg, net, x, steps, warmup, dev):
     """The same c2 forward in the other arithmetics, next to the headline's fp32-faithful f16x3 products: bf16x3 (3-term
     bf16 split, ~5e-6 rel: the fast option, the headline of rounds 1 and 2), bf16x6 (exact 3-way bf16 split, 6 MFMAs: the
@@ -735,6 +804,7 @@ def main():
         flops = [2.0 * args.batch * (H - 4) ** 2 * 64 * 3 * 25, flop_l2, 2.0 * args.batch * (H - 8) ** 2 * 48 * 32 * 9]
         achieved = flops[dom] / (layer_ms[dom] * 1e-3) / 1e12
         scale = (H / 256.0) ** 2
+        traffic, traffic_source = pmc_traffic(names[dom], args.batch, H)   # (a committed rocprofv3 pass, not this run)
         result = {
             "metric": "ESPCN x4 LR->HR images/sec (infer)", "value": round(imgs_per_s, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -748,7 +818,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": names[dom], "achieved": round(achieved, 2),
                          "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
-                         "traffic": pmc_traffic(names[dom], args.batch, H),
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "note": "achieved = algorithmic conv FLOPs / live HIP-event kernel time; peak = dense 16-bit "
                                  "MFMA peak / 3 (three fp16 / bf16 MFMAs per fp32-equivalent product)" if bf3 else
                                  "achieved = algorithmic conv FLOPs / live HIP-event kernel time; peak = fp32 MFMA",
@@ -758,9 +828,7 @@ def main():
                              "achieved_GBps": round(ESPCN_BYTES_PER_IMG * scale * imgs_per_s / world / 1e9, 1),
                              "peak_GBps": HBM_PEAK_GBS, "measured_copy_GBps": copy_gbps,
                              "frac": round(ESPCN_BYTES_PER_IMG * scale * imgs_per_s / world / 1e9 / HBM_PEAK_GBS, 4),
-                             "note": "61.11 MB/img per-layer compulsory traffic (SURVEY.md 8d); north-star target 0.30"},
-                         "whole_net_fp32_flop_frac": round(
-                             ESPCN_FLOP_PER_IMG * scale * imgs_per_s / world / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
+                             "note": "61.11 MB/img per-layer compulsory traffic (SURVEY.md 8d); north-star target 0.30"}},
         }
     extra = {}
     if torch.distributed.is_initialized():
@@ -776,6 +844,20 @@ def main():
         if torch.distributed.is_initialized():
             torch.distributed.barrier()
             dog = extras_watchdog(result, extra, rank, int(os.environ.get("SRK_BENCH_EXTRA_TIMEOUT", "420")))
+        if world == 1 and rank == 0:
+            # what is outside the three kernels of a step, and what a hipGraph of the forward does about it
+            extra["c2_step_minus_kernels_ms"] = round(1e3 * sec / args.steps - sum(layer_ms), 4)
+            try:
+                extra["c2_graph_ms_per_step"] = round(c2_graph_replay_ms(net, x, max(10, args.steps), dev), 4)
+                extra["c2_graph_images_per_s"] = round(args.batch / (extra["c2_graph_ms_per_step"] * 1e-3), 1)
+            except Exception as e:  # noqa: BLE001
+                extra["c2_graph_error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
+            try:
+                probe = board_power_probe(step)
+                if probe:
+                    extra["c2_power_probe"] = probe
+            except Exception as e:  # noqa: BLE001
+                extra["c2_power_probe_error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
         if world == 1 and pkg.ops.get_precision() == "mixed":
             extra.update(c2_other_precisions(pkg, net, x, max(5, args.steps // 2), 2, dev))
         if world == 1:

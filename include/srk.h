@@ -10,15 +10,23 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer to fp32 data owned by the caller; the library never
- *     allocates, frees or retains a pointer past the call;
+ *     allocates or frees, and does not retain a pointer past the call
  *   - activations are dense NHWC ("channels_last"): x[n][h][w][c];
  *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*) of the CURRENT
  *     device (hipSetDevice is the caller's job); no call synchronises the device;
+ *     -- with ONE sanctioned exception: between srk_wgrad_reduce_defer(1) and the next
+ *     srk_wgrad_reduce_flush() the calling thread's weight-gradient calls queue their slab
+ *     reductions, and the queue holds their workspace / dw / db pointers until that flush (the
+ *     contract is spelled out at srk_wgrad_reduce_defer);
  *   - calls may be made concurrently from several host threads and for several devices of one
- *     process.  The library's only mutable state is: the thread-local last-error string; one
- *     atomic "dynamic-LDS limit raised" flag per (kernel, device) — hipFuncSetAttribute is a
- *     per-device property, set on a kernel's first large-LDS launch on that device; and the
- *     SRK_* debugging environment switches, each read once (C++11 thread-safe statics);
+ *     process.  The library's mutable state is: thread-local -- the last-error string, the name
+ *     of the last dispatched kernel (srk_last_kernel_name, a diagnostic), the deferred-reduction
+ *     queue above, and the two deprecated srk_last_conv_* values (results now come back through
+ *     the out-fields of srk_epilogue); process-wide -- one atomic "dynamic-LDS limit raised"
+ *     flag per (kernel, device) (hipFuncSetAttribute is a per-device property, set on a kernel's
+ *     first large-LDS launch on that device), a mutex-guarded cache of LDS layouts per tile
+ *     geometry (conv_bfd), the SRK_* debugging environment switches, each read once, and the
+ *     device-side timeout counter behind srk_ring_timeouts();
  *   - return value: SRK_OK (0) or a negative srk_status; no exception crosses the ABI.
  */
 #ifndef SRK_H_
@@ -123,6 +131,11 @@ typedef struct srk_epilogue {
                                 order; room for N * ceil(OH / 8) * ceil(OW / 8) rows.  Honoured by the per-tile 64 -> 64
                                 3x3 kernel (k_c64) only: srk_last_conv_bn_partial_rows() says how many rows the call wrote
                                 (0: none -- run srk_bn_stats_finalize as usual), srk_bn_finalize_partials() consumes them */
+  int32_t* wrote_amax;       /* optional HOST out-field: srk_conv2d_forward stores 1 here when the kernel it dispatched to
+                                keeps the running maximum in y_amax (and y_amax was given), else 0 -- only then may the
+                                caller hand the slots to the next layer as x_amax (base_networks.py:101-104) */
+  int32_t* bn_partial_rows;  /* optional HOST out-field: rows of bn_partial the call filled (0: the dispatched kernel keeps
+                                none -- run srk_bn_stats_finalize as usual) */
 } srk_epilogue;
 
 /* Activation-gradient prologue of the backward kernels: the incoming gradient dy is
@@ -141,12 +154,9 @@ const char* srk_last_error_string(void); /* thread-local, valid until the next f
 /* Name (with template arguments) of the kernel the calling thread's last srk_conv2d_forward / _backward_data call
  * dispatched to, e.g. "k_conv_bfw<2,9,2>" — what a measurement should quote (thread-local, never NULL). */
 const char* srk_last_kernel_name(void);
-/* 1 when the calling thread's last srk_conv2d_forward launched a kernel that keeps the running maximum of its output in
- * srk_epilogue.y_amax (and y_amax was given), else 0: the caller may hand the slots to the next layer as x_amax only
- * then (base_networks.py:101-104: a ConvBlock's output is the next block's input). */
+/* DEPRECATED aliases of the out-fields srk_epilogue.wrote_amax / .bn_partial_rows (thread-local side channels that had to be
+ * queried before the thread's next conv call; kept for callers written against the round-4 header). */
 int srk_last_conv_wrote_amax(void);
-/* Rows of srk_epilogue.bn_partial the calling thread's last srk_conv2d_forward filled (0: the kernel it dispatched to
- * does not keep them, or none were asked for). */
 int srk_last_conv_bn_partial_rows(void);
 /* Diagnostic of the ring kernels (k_conv_bfr: producer and consumer waves of a persistent block hand halo buffers over
  * through counters in LDS, every poll has an iteration cap): number of polls that ran into the cap since the last

@@ -40,7 +40,8 @@ class Epilogue(ctypes.Structure):
     """struct srk_epilogue"""
     _fields_ = [("bias", c_vp), ("prelu_weight", c_vp), ("residual", c_vp), ("slope", c_float),
                 ("act", ctypes.c_int32), ("prelu_n", ctypes.c_int32), ("ps_r", ctypes.c_int32),
-                ("x_amax", c_vp), ("y_amax", c_vp), ("bn_partial", c_vp)]
+                ("x_amax", c_vp), ("y_amax", c_vp), ("bn_partial", c_vp),
+                ("wrote_amax", ctypes.POINTER(ctypes.c_int32)), ("bn_partial_rows", ctypes.POINTER(ctypes.c_int32))]
 
 
 class BwdMask(ctypes.Structure):

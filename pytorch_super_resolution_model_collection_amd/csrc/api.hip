@@ -318,7 +318,11 @@ extern "C" int srk_conv2d_forward(const srk_conv_desc* d, const float* x, const 
     }
     g.in_nchw = 1;
   }
-  return run_gather(g, d->algo, x, w_packed_fwd, y, ep, nullptr, 0.f, (hipStream_t)stream, "conv2d_forward");
+  rc = run_gather(g, d->algo, x, w_packed_fwd, y, ep, nullptr, 0.f, (hipStream_t)stream, "conv2d_forward");
+  // results of the dispatch: out-fields of the epilogue (the srk_last_conv_* queries are deprecated aliases)
+  if (ep_in && ep_in->wrote_amax) *ep_in->wrote_amax = rc == SRK_OK ? g_amax_written : 0;
+  if (ep_in && ep_in->bn_partial_rows) *ep_in->bn_partial_rows = rc == SRK_OK ? g_bn_partial_rows : 0;
+  return rc;
 }
 
 extern "C" int srk_conv2d_f16x3_supported(const srk_conv_desc* d, const srk_epilogue* ep_in, const float* y) {

@@ -401,13 +401,17 @@ def conv_forward_raw(x, wp, bias_p, weight_shape_src, cfg, prelu_w=None, residua
     if d.x_nchw and d.algo not in (ALGO_AUTO, _lib.ALGO_MFMA_BF16X3, _lib.ALGO_MFMA_F16X3):
         x = to_nhwc(x)      # only the bf16x3 / f16x3 first-layer kernels read an NCHW input in place
         d.x_nchw = 0
+    # what the dispatched kernel did comes back through the epilogue's out-fields (two host ints)
+    outs = (ctypes.c_int32 * 2)(0, 0)
+    ep.wrote_amax = ctypes.cast(ctypes.byref(outs, 0), ctypes.POINTER(ctypes.c_int32))
+    ep.bn_partial_rows = ctypes.cast(ctypes.byref(outs, 4), ctypes.POINTER(ctypes.c_int32))
     check(lib.srk_conv2d_forward(ctypes.byref(d), ptr(x), ptr(wp), ptr(y), ctypes.byref(ep), stream_ptr()),
           "srk_conv2d_forward")
     if bnp is not None:
-        rows_p = int(lib.srk_last_conv_bn_partial_rows())
+        rows_p = int(outs[1])
         if rows_p > 0:
             y._srk_bn_partial = (bnp, rows_p, _ver(y))
-    if ya is not None and lib.srk_last_conv_wrote_amax():
+    if ya is not None and outs[0]:
         _tag_amax(y, ya)
     elif F16X3 and d.algo in (_lib.ALGO_MFMA, _lib.ALGO_MFMA_BF16X6):
         _tag_amax(y, None)   # a faithful-class conv whose kernel leaves no maximum: worth one srk_absmax pass downstream

@@ -235,7 +235,13 @@ def test_c5_srgan_full_size_adversarial_step(gpu):
             den = max(float(g64[n].norm()), 1e-3 * gmax * g64[n].numel() ** 0.5)
             worst_p = max(worst_p, float((p.grad.detach().cpu().double() - g64[n]).norm()) / den)
             worst_o = max(worst_o, float((g32[n] - g64[n]).norm()) / den, float((g32n[n] - g64[n]).norm()) / den)
-        record[tag] = {"product_vs_fp64": worst_p, "torch_fp32_vs_fp64_worse_of_onednn_and_native": worst_o}
+        # FIXED regression bars a little above what rounds 2 - 5 measured (G 2.31e-3, D 2.60e-3 vs float64; DESIGN 10.4
+        # explains why no fp32 evaluation of these modules gets below ~1.4e-3): a change that moves a gradient error from
+        # 2.6e-3 to 3.5e-3 fails here, whatever torch's own spread is on that day ...
+        bar = {"G": 3.0e-3, "D": 3.2e-3}[tag]
+        record[tag] = {"product_vs_fp64": worst_p, "torch_fp32_vs_fp64_worse_of_onednn_and_native": worst_o, "fixed_bar": bar}
+        assert worst_p <= bar, (tag, worst_p, bar)
+        # ... and, as before, never worse than 1.5x (G: 1.0x) the spread of the reference's own two fp32 evaluations
         assert worst_p <= max(1e-3, 1.5 * worst_o), (worst_p, worst_o)
         if tag == "G":   # the better-conditioned net: no slack over the reference's own fp32 spread
             assert worst_p <= max(1e-3, 1.0 * worst_o), (worst_p, worst_o)

@@ -952,6 +952,14 @@ def test_conv_says_whether_it_wrote_the_running_maximum(gpu, monkeypatch):
                                     pkg._lib.stream_ptr())
         assert rc == 0 and lib.srk_last_conv_wrote_amax() == 1
         assert float(ya.max()) == float(yy.abs().max())
+        # the same answers through the epilogue's out-fields (srk_epilogue.wrote_amax / .bn_partial_rows: host ints the call
+        # fills; the srk_last_conv_* queries above are deprecated aliases of them)
+        outs = (ctypes.c_int32 * 2)(7, 7)
+        ep.wrote_amax = ctypes.cast(ctypes.byref(outs, 0), ctypes.POINTER(ctypes.c_int32))
+        ep.bn_partial_rows = ctypes.cast(ctypes.byref(outs, 4), ctypes.POINTER(ctypes.c_int32))
+        assert lib.srk_conv2d_forward(ctypes.byref(d), pkg._lib.ptr(xs), pkg._lib.ptr(wp), pkg._lib.ptr(yy), ctypes.byref(ep),
+                                      pkg._lib.stream_ptr()) == 0
+        assert (outs[0], outs[1]) == (1, 0)
         # ... a call without y_amax says 0, and so does the shape-agnostic kernel
         ep = pkg._lib.Epilogue(None, None, None, 0.0, 1, 0, 0, None, None)
         assert lib.srk_conv2d_forward(ctypes.byref(d), pkg._lib.ptr(xs), pkg._lib.ptr(wp), pkg._lib.ptr(yy), ctypes.byref(ep),
@@ -1161,6 +1169,10 @@ def test_conv_c64_leaves_batchnorm_column_sums(gpu, shape):
     assert lib.srk_conv2d_forward(ctypes.byref(d), L.ptr(x), L.ptr(wp), L.ptr(y), ctypes.byref(ep), L.stream_ptr()) == 0
     assert lib.srk_last_kernel_name().decode().startswith("k_c64<")
     assert lib.srk_last_conv_bn_partial_rows() == tiles
+    rows_out = ctypes.c_int32(-1)       # ... and through the out-field
+    ep.bn_partial_rows = ctypes.pointer(rows_out)
+    assert lib.srk_conv2d_forward(ctypes.byref(d), L.ptr(x), L.ptr(wp), L.ptr(y), ctypes.byref(ep), L.stream_ptr()) == 0
+    assert rows_out.value == tiles
     yd = y.double()
     s_ref = torch.cat([yd.sum((0, 2, 3)), (yd * yd).sum((0, 2, 3))])
     assert rel_err(part.sum(0), s_ref) < 1e-12
@@ -1186,11 +1198,17 @@ def test_conv_c64_leaves_batchnorm_column_sums(gpu, shape):
         xin = x.clone().requires_grad_(True)
         old = ops.BN_PARTIAL
         ops.BN_PARTIAL = on
+        # (the fused path must actually RUN in the `on` arm -- if the conv output lost its tag on the way to the BatchNorm,
+        #  both arms would take the classic path and agree trivially: count the finalize calls)
+        real, calls = lib.srk_bn_finalize_partials, []
+        lib.srk_bn_finalize_partials = lambda *a: (calls.append(1), real(*a))[1]
         try:
             out = blk(xin)
             out.square().mean().backward()
         finally:
             ops.BN_PARTIAL = old
+            lib.srk_bn_finalize_partials = real
+        assert len(calls) == (2 if on else 0), (on, len(calls))    # conv1 -> bn and conv2 -> bn (one shared BatchNorm)
         outs[on] = (out.detach(), xin.grad, blk.bn.running_mean.clone(), blk.bn.running_var.clone(), blk.conv1.weight.grad)
     for a, bb in zip(outs[True], outs[False]):
         assert rel_err(a, bb) < 1e-5
