@@ -218,6 +218,21 @@ int srk_conv2d_f16x3_supported(const srk_conv_desc* d, const srk_epilogue* ep, c
 /* ---- convolution (Conv2d / ConvTranspose2d: base_networks.py:42,77,112-113,156; fsrcnn.py:33) */
 int srk_conv2d_forward(const srk_conv_desc* d, const float* x, const float* w_packed_fwd, float* y,
                        const srk_epilogue* ep, void* stream);
+/* Two stacked convolutions as ONE launch (espcn.py:17-19: conv 3 -> 64 5x5 + ReLU, then conv 64 -> 32 3x3 + ReLU):
+ *   y = act2(conv2(act1(conv1(x) + b1)) + b2)
+ * The first layer is recomputed by the producer waves of the second layer's persistent kernel on the halo of every output
+ * tile and handed over through LDS: its Cout1-channel output -- more than half of the HBM bytes of an ESPCN forward --
+ * is never written or read.  Arithmetic: SRK_ALGO_MFMA_F16X3 in both layers (ep1->x_amax = running maximum of |x|, the
+ * network input); the intermediate is split with the exact maximum of each tile's own halo, a tighter scale than the
+ * global one of the two-call form, so the two forms agree to fp32 rounding, not bit for bit.  ep2->y_amax as in
+ * srk_conv2d_forward.  d1: stride 1, Cin <= 4 (x_nchw honoured), 5x5, Cout 64, no / ReLU / leaky activation;
+ * d2: stride 1, 3x3, 64 -> 32, any activation srk_conv2d_forward fuses on that layer; d2's input size = d1's output size.
+ * srk_conv2d_pair_supported() says 1 when the pair is covered (else: two srk_conv2d_forward calls). */
+int srk_conv2d_pair_supported(const srk_conv_desc* d1, const srk_epilogue* ep1, const srk_conv_desc* d2,
+                              const srk_epilogue* ep2, const float* y);
+int srk_conv2d_pair_forward(const srk_conv_desc* d1, const float* x, const float* w1_packed_fwd, const srk_epilogue* ep1,
+                            const srk_conv_desc* d2, const float* w2_packed_fwd, float* y, const srk_epilogue* ep2,
+                            void* stream);
 /* dx = d(loss)/dx given dy; optional act-grad prologue on dy; optional fused "+ add_to"
  * (gradient fan-in of a residual connection).  Replaces aten::convolution_backward (input
  * gradient) as dispatched from loss.backward() — edsr.py:154, vdsr.py:146, srgan.py:286,309. */

@@ -68,6 +68,10 @@ _PROTOTYPES = {
     "srk_pack_weights_batched": (c_int, [c_f, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     "srk_packed_weight_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
     "srk_conv2d_forward": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, c_f, ctypes.POINTER(Epilogue), c_vp]),
+    "srk_conv2d_pair_supported": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(Epilogue), ctypes.POINTER(ConvDesc),
+                                          ctypes.POINTER(Epilogue), c_f]),
+    "srk_conv2d_pair_forward": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, ctypes.POINTER(Epilogue), ctypes.POINTER(ConvDesc),
+                                        c_f, c_f, ctypes.POINTER(Epilogue), c_vp]),
     "srk_conv2d_backward_data": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, c_f, ctypes.POINTER(BwdMask), c_f,
                                          c_vp]),
     "srk_conv2d_backward_data_relu_supported": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, ctypes.POINTER(BwdMask)]),

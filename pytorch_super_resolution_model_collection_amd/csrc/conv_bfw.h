@@ -95,5 +95,8 @@ static inline int bfw_slices(const GatherConv& g) {
 
 // conv_bfr.hip: the ring form of the 3x3 kernels with 32 / 48 output channels (per slice); -1 = not applicable
 int conv_bfr_launch(const BfwParams& B, hipStream_t s);
+// ... and the pair (first layer, 3x3 64 -> 32) as one launch: the first layer computed by the producers (conv_bfr.hip, FUSE)
+int conv_bfr_fused(const GatherConv& g1, const float* x, const float* wp1, const Epi& ep1, const GatherConv& g2, const float* wp2,
+                   float* out, const Epi& ep2, hipStream_t s);
 
 }  // namespace srk

@@ -362,6 +362,59 @@ def test_conv_wave_specialized_ring(gpu, monkeypatch, cin, cout, H, W, N, act, p
     assert rel_err(outs["1"], ref.float()) < (2e-6 if mode == "mixed" else 1e-4)
 
 
+@pytest.mark.parametrize("N,H,W,act1,act2,nchw", [
+    (2, 40, 52, "relu", "relu", True),       # ESPCN's first two layers on an NCHW batch read in place, one tile per block
+    (3, 100, 130, "relu", "relu", True),     # ragged tiles on both edges, pairs of tiles per block
+    (2, 61, 47, "lrelu", None, False),       # leaky first layer, no activation behind the second, NHWC input
+    (5, 70, 150, None, "prelu", True),       # no activation in front, scalar PReLU behind; several tiles per block
+])
+def test_conv_pair_fused(gpu, monkeypatch, N, H, W, act1, act2, nchw):
+    """srk_conv2d_pair_forward (espcn.py:17-19): conv 3 -> 64 5x5 + act and conv 64 -> 32 3x3 + act as ONE launch -- the first
+    layer recomputed by the producer waves of the ring kernel on every tile's halo, the intermediate split with the tile's own
+    maximum.  Against torch fp64, against the two-launch form, through the module (ESPCNNet under SRK_PAIR=1), and no poll of
+    the ring may run into its cap."""
+    pkg = _pkg()
+    ops = pkg.ops
+    lib = pkg._lib.load()
+    x = fill.rand((N, 3, H, W), 601)
+    w1 = fill.randn((64, 3, 5, 5), 602, (2.0 / 75) ** 0.5)
+    b1 = fill.randn((64,), 603, 0.1)
+    w2 = fill.randn((32, 64, 3, 3), 604, (2.0 / 576) ** 0.5)
+    b2 = fill.randn((32,), 605, 0.1)
+    slope = torch.tensor([0.3])
+
+    def act(t, a):
+        if a == "relu":
+            return torch.relu(t)
+        if a == "lrelu":
+            return torch.nn.functional.leaky_relu(t, 0.2)
+        if a == "prelu":
+            return torch.nn.functional.prelu(t, slope.double())
+        return t
+    ref = act(torch.nn.functional.conv2d(act(torch.nn.functional.conv2d(x.double(), w1.double(), b1.double()), act1),
+                                         w2.double(), b2.double()), act2)
+    code = {None: 0, "relu": 1, "lrelu": 3, "prelu": pkg._lib.ACT_PRELU}
+    cfg1 = ops.ConvCfg(1, 0, False, 0, code[act1], 0.2 if act1 == "lrelu" else 0.0, 0)
+    cfg2 = ops.ConvCfg(1, 0, False, 0, code[act2], 0.2 if act2 == "lrelu" else 0.0, 0)
+    xg = x.to(gpu)
+    if not nchw:
+        xg = xg.contiguous(memory_format=torch.channels_last)
+    monkeypatch.setattr(ops, "PAIR", "1")
+    monkeypatch.setattr(ops, "F16X3_ALWAYS", True)
+    ops.set_precision("mixed")
+    lib.srk_ring_timeouts(1)
+    pw = slope.to(gpu) if act2 == "prelu" else None
+    with torch.no_grad():
+        y = ops.conv_pair_infer(xg, w1.to(gpu), b1.to(gpu), cfg1, None, w2.to(gpu), b2.to(gpu), cfg2, pw, None)
+        assert y is not None and lib.srk_last_kernel_name().decode().startswith("k_conv_bfr<2,2,f16,fused")
+        y2 = ops.conv2d_infer(ops.conv2d_infer(xg, w1.to(gpu), b1.to(gpu), None, cfg1), w2.to(gpu), b2.to(gpu), None, cfg2, pw)
+    assert lib.srk_ring_timeouts(1) == 0
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert rel_err(y, ref.float()) < 2e-6
+    assert rel_err(y, y2) < 3e-6
+    assert float(y._srk_amax[0].max()) == float(y.abs().max())      # the running maximum for the layer behind the pair
+
+
 @pytest.mark.parametrize("fan_out", [False, True])
 def test_premasked_gradients(gpu, monkeypatch, fan_out):
     """Chain of conv + ReLU layers whose data gradients run on k_conv_bfw: each dx leaves multiplied by the ReLU gradient
