@@ -59,6 +59,13 @@ __device__ __forceinline__ void wb_item(int tid, int& q, int& pp0) {
     pp0 = tid / QN;
   }
 }
+// WB_PIPE: software-pipelined K loop of the 3x3 kernels (see kloop); 0 = the round-4 loop (tools/build_variant.sh A/B)
+#ifndef WB_PIPE
+#define WB_PIPE 0
+#endif
+#ifndef WB_PRIO
+#define WB_PRIO 0
+#endif
 constexpr int WB_IT = 1;       // pixel pairs per thread loaded together while staging (4 measured: no gain plain, spills in the specialised variant)
 
 struct WgBfParams {
@@ -84,6 +91,7 @@ struct WgBfParams {
                          // (a block walks a CONTIGUOUS range of tiles, rows fastest): a tile below its predecessor loads
                          // only its TH new rows instead of all TH + KH - 1 (2-row tiles: the X read halves).  CS is then
                          // the plane stride of the ring, and the dY tiles keep their two buffer sets behind it.
+  int XP, XPL, YPL;      // k_wgrad_tr: pixels per ring row, bytes per X plane / dY plane of its pixel-major LDS image
 };
 
 // Grouped launch: the weight gradients of up to WB_MAXGROUP convolutions that share ONE geometry (the 33 body convs
@@ -130,6 +138,12 @@ static long long* g_wb_prof = nullptr;
 __device__ __forceinline__ f32x4 wb_mfma(const uint4& a, const uint4& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
                                                  0);
+}
+
+// ablation helpers: a value the compiler must materialise / may not assume anything about
+__device__ __forceinline__ void wb_keep(const uint4& a) { asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w)); }
+__device__ __forceinline__ void wb_touch(uint4& a, int dep) {
+  asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w) : "v"(dep));
 }
 
 __device__ __forceinline__ unsigned short wb_bits(__bf16 v) { return __builtin_bit_cast(unsigned short, v); }
@@ -219,7 +233,7 @@ __global__ __launch_bounds__(SPEC ? 64 * CIT * COW + WB_SST : 64 * CIT * COW,
   constexpr int NTHR = SPEC ? WTHR + WB_SST : WTHR;
   constexpr int NST = SPEC ? WB_SST : WTHR;  // staging threads (SPEC: 8 stager waves keep the staging rate of two 256-thread blocks)
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
-  __shared__ int oct_x[WB_MAXOCT], oct_y[WB_MAXOCT], oct_r[WB_MAXOCT], oct_c[WB_MAXOCT];
+  __shared__ int oct_x[WB_MAXOCT], oct_y[WB_MAXOCT], oct_r[WB_MAXOCT], oct_c[WB_MAXOCT], oct_pk[WB_MAXOCT];
   __shared__ float bred[NST][4];
   const size_t buf_shorts = (size_t)2 * CIB * P.CS + (size_t)2 * COB * P.DS;  // one buffer set: [2][CIB][CS] + [2][COB][DS]
   // ring mode: [2][CIB][CS] (the ring, once) followed by two dY sets [2][COB][DS]
@@ -278,11 +292,13 @@ __global__ __launch_bounds__(SPEC ? 64 * CIT * COW + WB_SST : 64 * CIT * COW,
       oct_y[o] = o * 8;
       oct_r[o] = orow;
       oct_c[o] = oc * 8;
+      oct_pk[o] = (o * 8) | ((oc * 8) << 12) | (orow << 20);
     } else {  // K padding: multiply by the zero octet appended to every dY plane
       oct_x[o] = 0;
       oct_y[o] = P.TH * P.TW;
       oct_r[o] = 0;
       oct_c[o] = 0;
+      oct_pk[o] = P.TH * P.TW;
     }
   }
   for (int e = tid0; e < (SPEC ? 2 : 1) * 2 * COB * 4; e += NTHR) {  // zero octets (never overwritten by the staging)
@@ -609,6 +625,144 @@ __global__ __launch_bounds__(SPEC ? 64 * CIT * COW + WB_SST : 64 * CIT * COW,
     const unsigned short* xa_l = xa_h + (size_t)CIB * P.CS;
     const unsigned short* yb_h = ys + (size_t)(cow * NTW * 16 + i) * P.DS;
     const unsigned short* yb_l = yb_h + (size_t)COB * P.DS;
+    if constexpr (K33 && WB_PIPE) {
+      // Round 5: the K loop as a software pipeline over (K step, kernel row) phases.  The loop below this one reads a K
+      // step's fragments at the top of that step: its ISA has three exposed LDS round trips per K step (the first
+      // row's reads, and two ds_read_b128 the compiler sinks into the MFMA stream with an s_waitcnt lgkmcnt(0) right
+      // behind each) -- with ONE working wave per SIMD nothing else can use the matrix pipe meanwhile (~2080 clocks per K
+      // step for 864 clocks of MFMA issue, tools/wgrad_prof.py).  Here the X fragments of phase p + 1 (the next kernel
+      // row; at a step's last row the next step's first row and its dY fragments) are requested BEFORE the 9 * NTW MFMAs
+      // of phase p, into a second register set; sched_barriers keep the requests where they are written, the waits the
+      // compiler inserts are then counted ones (lgkmcnt(4..8)) behind a phase's worth of MFMAs.  Two K steps per loop
+      // trip so that the two register sets alternate without copies.  Same products, same order per accumulator:
+      // bit-equal to the loop below.
+      struct XF {
+        uint4 h, l;
+        unsigned eh, el;
+      };
+      // one packed table word per octet (oct_pk: dY offset | halo column << 12 | tile row << 20); ring and plain tiles share
+      // the address form  halo row slot = (base + tile row + u) mod ring rows  (plain: base 0, no wrap)
+      struct TB {
+        int oy, orr, oc;
+      };
+      const int nks_run = (SRK_KDBG(P.dbg) & 4) ? 0 : P.nks;
+      if (nks_run <= 0) return;
+      const int last = nks_run - 1;
+      const int rb = ring ? rbase : 0, rwrap = ring ? R2 : (1 << 20);
+      auto tab = [&](int ks) -> TB {
+        const unsigned w = (unsigned)oct_pk[(ks < last ? ks : last) * 4 + kq];
+        TB t;
+        t.oy = (int)(w & 0xfffu);
+        t.oc = (int)((w >> 12) & 0xffu);
+        t.orr = (int)(w >> 20) + rb;
+        return t;
+      };
+      auto xload = [&](XF& f, const TB& t, int u) {
+        int slot = t.orr + u;
+        slot = slot >= rwrap ? slot - rwrap : slot;
+        const int xo = slot * P.HWp + t.oc;
+        if (SRK_KDBG(P.dbg) & 16) {  // ablation: no fragment reads (the MFMAs run on whatever the registers hold)
+          wb_touch(f.h, xo);
+          wb_touch(f.l, xo);
+          asm volatile("" : "+v"(f.eh), "+v"(f.el) : "v"(xo));
+          return;
+        }
+        f.h = *reinterpret_cast<const uint4*>(xa_h + xo);
+        f.l = *reinterpret_cast<const uint4*>(xa_l + xo);
+        if (SRK_KDBG(P.dbg) & 32) return;   // ablation: no 4-byte tail reads
+        f.eh = *reinterpret_cast<const unsigned*>(xa_h + xo + 8);
+        f.el = *reinterpret_cast<const unsigned*>(xa_l + xo + 8);
+      };
+      auto yload = [&](uint4 (&bh)[NTW], uint4 (&bl)[NTW], int oy) {
+        if (SRK_KDBG(P.dbg) & (16 | 128)) {
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) {
+            wb_touch(bh[nt], oy);
+            wb_touch(bl[nt], oy);
+          }
+          return;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          bh[nt] = *reinterpret_cast<const uint4*>(yb_h + (size_t)nt * 16 * P.DS + oy);
+          bl[nt] = *reinterpret_cast<const uint4*>(yb_l + (size_t)nt * 16 * P.DS + oy);
+        }
+      };
+      auto rowmm = [&](const XF& f, const uint4 (&bh)[NTW], const uint4 (&bl)[NTW], f32x4 (&a)[3][NTW]) {
+        uint4 ah[3], al[3];
+        ah[0] = f.h;
+        al[0] = f.l;
+        ah[1] = make_uint4(__builtin_amdgcn_alignbit(f.h.y, f.h.x, 16), __builtin_amdgcn_alignbit(f.h.z, f.h.y, 16),
+                           __builtin_amdgcn_alignbit(f.h.w, f.h.z, 16), __builtin_amdgcn_alignbit(f.eh, f.h.w, 16));
+        al[1] = make_uint4(__builtin_amdgcn_alignbit(f.l.y, f.l.x, 16), __builtin_amdgcn_alignbit(f.l.z, f.l.y, 16),
+                           __builtin_amdgcn_alignbit(f.l.w, f.l.z, 16), __builtin_amdgcn_alignbit(f.el, f.l.w, 16));
+        ah[2] = make_uint4(f.h.y, f.h.z, f.h.w, f.eh);
+        al[2] = make_uint4(f.l.y, f.l.z, f.l.w, f.el);
+        if (SRK_KDBG(P.dbg) & 64) {  // ablation: no column shifts (every tap column multiplies the unshifted fragment)
+          ah[1] = ah[2] = ah[0];
+          al[1] = al[2] = al[0];
+        }
+        if (SRK_KDBG(P.dbg) & 8) {  // ablation: fragment reads and shifts, no MFMAs
+#pragma unroll
+          for (int v = 0; v < 3; ++v) {
+            wb_keep(ah[v]);
+            wb_keep(al[v]);
+          }
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) {
+            wb_keep(bh[nt]);
+            wb_keep(bl[nt]);
+          }
+          return;
+        }
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) a[v][nt] = wb_mfma(al[v], bh[nt], a[v][nt]);
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) a[v][nt] = wb_mfma(ah[v], bl[nt], a[v][nt]);
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) a[v][nt] = wb_mfma(ah[v], bh[nt], a[v][nt]);
+      };
+      // one K step: rows 0..2 of step `tc` from (x0, yh, yl); leaves row 0 and the dY fragments of step `tn` in (xn, nh, nl)
+      auto step = [&](const XF& x0, const uint4 (&yh)[NTW], const uint4 (&yl)[NTW], XF& xn, uint4 (&nh)[NTW],
+                      uint4 (&nl)[NTW], const TB& tc, const TB& tn) {
+        XF x1 = {}, x2 = {};
+        xload(x1, tc, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        rowmm(x0, yh, yl, acc[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        xload(x2, tc, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        rowmm(x1, yh, yl, acc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        xload(xn, tn, 0);
+        yload(nh, nl, tn.oy);
+        __builtin_amdgcn_sched_barrier(0);
+        rowmm(x2, yh, yl, acc[2]);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      TB t0 = tab(0), t1 = tab(1);
+      XF xa = {}, xb = {};
+      uint4 yah[NTW] = {}, yal[NTW] = {}, ybh[NTW] = {}, ybl[NTW] = {};
+      xload(xa, t0, 0);
+      yload(yah, yal, t0.oy);
+      int ks = 0;
+      for (; ks + 1 < nks_run; ks += 2) {
+        const TB t2 = tab(ks + 2);
+        step(xa, yah, yal, xb, ybh, ybl, t0, t1);
+        const TB t3 = tab(ks + 3);
+        step(xb, ybh, ybl, xa, yah, yal, t1, t2);
+        t0 = t2;
+        t1 = t3;
+      }
+      if (ks < nks_run) step(xa, yah, yal, xb, ybh, ybl, t0, t1);
+      return;
+    }
     if constexpr (K33) {
       // (round 4: the octet tables of K step ks + 1 are read while step ks multiplies -- the lookups were a dependent LDS
       //  round trip in front of every K step's fragment reads, with one working wave per SIMD and nothing to hide it)
@@ -789,6 +943,7 @@ __global__ __launch_bounds__(SPEC ? 64 * CIT * COW + WB_SST : 64 * CIT * COW,
       }
     } else {
       __syncthreads();
+      if (WB_PRIO) __builtin_amdgcn_s_setprio(WB_PRIO);  // (this branch is taken by whole waves: wave >= NWV is wave-uniform)
       int wprev = P.HH;
       long long wk_loop = 0, wk_wait = 0;
       for (int it = 0; it < ntb; ++it) {
@@ -847,6 +1002,421 @@ __global__ __launch_bounds__(SPEC ? 64 * CIT * COW + WB_SST : 64 * CIT * COW,
             const int ci = cib + cit * 16 + kq * 4 + reg;
             if (ci < P.Cin && co < P.Cout) slab[((size_t)t * P.Cin + ci) * P.Cout + co] = acc[u][v][nt][reg];
           }
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_wgrad_tr: the wave-specialised 3x3 weight gradient on a PIXEL-MAJOR LDS image read with the LDS transpose read
+// (ds_read_b64_tr_b16, gfx950).  Same roles, tiles, ring of X halo rows, split-K slabs and summation order as
+// k_wgrad_bf<2, 2, 2, SPEC, ., K33> -- results are bit-equal -- but the staged tensors stay in their NHWC order:
+//
+//   X ring  [hi | lo][ring row][halo column][32 ci] bf16      (64 B per pixel and plane)
+//   dY set  [hi | lo][tile pixel (+ 8 zero pixels)][64 co]     (128 B per pixel and plane), two sets
+//
+// * a staging item is ONE pixel x 8 channels (two 16-byte loads): the bf16 split packs CHANNEL pairs and leaves as one
+//   ds_write_b128 per plane -- 2 LDS stores per item instead of the 8 transposing ds_write_b32 of k_wgrad_bf (the eight
+//   stager waves were bound by their instruction issue: tools/wgrad_variant.sh ablations, stagers alone 133 us of the
+//   170 us VDSR layer);
+// * a working wave's MFMA fragment (lane = channel, 8 consecutive pixels of a tile row) comes out of two transpose reads:
+//   in a 16-lane group lane r addresses pixel (r >> 2), channels 4 (r & 3) .. + 3 and receives channel r of the
+//   group's four pixels.  The three column shifts of a kernel row are derived in registers from pixels 0 .. 9 as before
+//   (a third read fetches pixels 8 .. 11);
+// * bank conflicts: a transpose read serves 32 lanes (two octets) per clock over 64 banks.  X: the two 16-channel
+//   halves of a pixel swap places in odd halo octets (column >> 3 odd); dY: the four 16-channel tiles of a pixel are
+//   XORed with  (pixel >> 1 & 1) | (pixel >> 3 & 1) << 1.  Both are lane constants on the reading side.
+// Requirements (wt_eligible): 3x3, stride 1, Cin % 32 == 0, Cout % 64 == 0, 16-byte aligned tensors, pixel-shuffled dY
+// only with >= 64 channels per sub-pixel; everything else stays on k_wgrad_bf.
+// ---------------------------------------------------------------------------------------------
+typedef short wt_s16x4 __attribute__((ext_vector_type(4)));
+typedef short wt_s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) wt_s16x4* wt_ldsp;
+
+// (a, b, c, d) x (e, f, g, h) fp32 -> 4 dwords of packed bf16 channel pairs, hi and lo parts
+__device__ __forceinline__ void wt_split8(const f32x4& v0, const f32x4& v1, uint4& hi, uint4& lo) {
+  const f32x4 ev = {v0[0], v0[2], v1[0], v1[2]}, od = {v0[1], v0[3], v1[1], v1[3]};
+  unsigned h[4], l[4];
+  wb_split_pair(ev, od, h, l);
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+template <bool GRP>
+__global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGroupArg<GRP>::type GR) {
+  constexpr int CIB = 32, COB = 64, NWV = 4, WTHR = 64 * NWV, NST = WB_SST, NTHR = WTHR + NST, NTW = 2, PIT = 1024 / NST;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+  __shared__ unsigned oct_tw[WB_MAXOCT];
+  const int tid0 = threadIdx.x, lane = tid0 & 63, wave = tid0 >> 6;
+  const bool worker = wave < NWV;
+  const int tid = worker ? tid0 : tid0 - WTHR;
+  const int R2 = 2 * P.HH;
+  const unsigned XPL = (unsigned)P.XPL, YPL = (unsigned)P.YPL;   // plane sizes in bytes
+  const unsigned XROW = (unsigned)P.XP * 64u;                   // bytes per ring row
+  const unsigned YSET0 = 2u * XPL, YSET = 2u * YPL;
+  const int noct = P.TH * P.TWo;
+  int bxl = blockIdx.x, byl = blockIdx.y;
+  if (gridDim.y == 2 && (gridDim.x & 7) == 0) {   // the two ci halves of a slab index on one XCD (see k_wgrad_bf)
+    const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    bxl = (lin >> 4) * 8 + (lin & 7);
+    byl = (lin >> 3) & 1;
+  }
+  const int cib = byl * CIB, cob = blockIdx.z * COB;
+  const bool want_bias = P.bias_partial != nullptr && byl == 0;
+  int bx = bxl;
+  const float* __restrict__ Lx = P.x;
+  const float* __restrict__ Ldy = P.dy;
+  const float* __restrict__ Lmask = P.mask_y;
+  float Lslope = P.mask_slope;
+  if constexpr (GRP) {
+    const int layer = bxl / P.G;
+    bx = bxl - layer * P.G;
+    Lx = GR.L[layer].x;
+    Ldy = GR.L[layer].dy;
+    Lmask = GR.L[layer].mask_y;
+    Lslope = GR.L[layer].mask_slope;
+  }
+  // octet table: tile row << 16 | octet column; K padding: bit 31 (multiplied by the zero pixels behind every dY plane)
+  for (int o = tid0; o < P.nks * 4; o += NTHR) {
+    if (o < noct) {
+      const int orow = o / P.TWo;
+      oct_tw[o] = (unsigned)(orow << 16) | (unsigned)(o - orow * P.TWo);
+    } else {
+      oct_tw[o] = 0x80000000u;
+    }
+  }
+  for (int e = tid0; e < 2 * 2 * 64; e += NTHR) {   // 8 zero pixels x 128 B behind each of the four dY planes
+    const int pl = e >> 6, w = e & 63;
+    *reinterpret_cast<uint4*>(smem8 + YSET0 + (unsigned)pl * YPL + (unsigned)(P.TH * P.TW) * 128u + (unsigned)w * 16u) =
+        make_uint4(0u, 0u, 0u, 0u);
+  }
+  // tiles of this block: a contiguous range in rows-fastest order (ring of halo rows)
+  const int per = (P.ntiles + P.G - 1) / P.G;
+  const int first_tile = bx * per;
+  int ntb = P.ntiles - first_tile;
+  ntb = ntb < 0 ? 0 : (ntb > per ? per : ntb);
+  auto ring_next = [&](int prev, bool first) {
+    const int b = prev + (first ? P.HH : P.TH);
+    return b >= R2 ? b - R2 : b;
+  };
+  auto tile_origin = [&](int tile, int& n, int& r0, int& c0) {
+    int b = tile;
+    const int tyi = b % P.tiles_y;
+    b /= P.tiles_y;
+    const int txi = b % P.tiles_x;
+    n = b / P.tiles_x;
+    r0 = tyi * P.TH;
+    c0 = txi * P.TW;
+  };
+  __syncthreads();  // table / zero pixels visible
+
+  if (!worker) {
+    // ------------------------------------------------------------------ stagers (8 waves)
+    f32x4 bsum0 = {0.f, 0.f, 0.f, 0.f}, bsum1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 pxa[PIT], pxb[PIT], pya[PIT], pyb[PIT], pma[PIT], pmb[PIT];
+    int x_rel[PIT], x_lds[PIT], x_hx[PIT], x_hy[PIT];
+    int y_rel[PIT], y_lds[PIT], y_c[PIT];
+    unsigned y_srow = 0, y_scol = 0;
+    {
+      const int XN = P.TW + 2, npix = P.HH * XN;
+      const int g = tid & 3;
+#pragma unroll
+      for (int k = 0; k < PIT; ++k) {
+        const int pi = (tid + k * NST) >> 2;
+        const int hy = pi / XN, hx = pi - hy * XN;
+        x_rel[k] = ((hy * P.XW + hx) * P.Cin + cib + g * 8) * 4;
+        x_lds[k] = pi < npix ? hx * 64 + ((((g >> 1) ^ (hx >> 3)) & 1) << 5) + ((g & 1) << 4) : -1;
+        x_hx[k] = hx;
+        x_hy[k] = hy;
+      }
+    }
+    {
+      const int npix = P.TH * P.TW;
+      const int g = tid & 7;
+      unsigned koff;
+      if (P.dy_ps_r > 1) {   // packed channel (i, j, c) of pixel (y, x) lives at (y r + i, x r + j, c): this block = one (i, j)
+        const int r = P.dy_ps_r, C = P.dy_ps_C;
+        const int qq = cob / C, c = cob - qq * C;
+        const int i = qq / r, j = qq - i * r;
+        y_scol = (unsigned)(r * C);
+        y_srow = (unsigned)(r * P.YW) * y_scol;
+        koff = (unsigned)(i * P.YW) * y_scol + (unsigned)(j * C + c);
+      } else {
+        y_scol = (unsigned)P.Cout;
+        y_srow = (unsigned)P.YW * y_scol;
+        koff = (unsigned)cob;
+      }
+#pragma unroll
+      for (int k = 0; k < PIT; ++k) {
+        const int px = (tid + k * NST) >> 3;
+        const int r = px / P.TW, c = px - r * P.TW;
+        const int f = ((px >> 1) & 1) | (((px >> 3) & 1) << 1);
+        y_rel[k] = (int)(((unsigned)r * y_srow + (unsigned)c * y_scol + koff + (unsigned)(g * 8)) * 4u);
+        y_lds[k] = px < npix ? px * 128 + (((g >> 1) ^ f) << 5) + ((g & 1) << 4) : -1;
+        y_c[k] = c;
+      }
+    }
+    int st_base[2] = {0, 0}, st_skip[2] = {0, 0}, st_prev = P.HH;
+    auto issue = [&](int tile, int j) {
+      int n, r0, c0;
+      tile_origin(tile, n, r0, c0);
+      constexpr unsigned OOB = 0x80000000u;
+      const bool first = j == 0 || (tile % P.tiles_y) == 0;
+      st_prev = ring_next(st_prev, first);
+      st_base[j & 1] = st_prev;
+      const int skip_rows = first ? 0 : P.HH - P.TH;   // halo rows [0, skip) are the predecessor's last rows
+      st_skip[j & 1] = skip_rows;
+      {
+        const size_t img = (size_t)P.XH * P.XW * P.Cin;
+        const __amdgpu_buffer_rsrc_t rx = wb_rsrc(Lx + (size_t)n * img, (unsigned)(img * 4));
+        const int by0 = r0 - P.pad, bx0 = c0 - P.pad;
+        const int obase = (by0 * P.XW + bx0) * P.Cin * 4;  // may be negative: rows above the image wrap out of range
+#pragma unroll
+        for (int k = 0; k < PIT; ++k) {
+          const unsigned o = (unsigned)(obase + x_rel[k]);
+          const int ix = bx0 + x_hx[k];
+          const bool act = x_lds[k] >= 0 && x_hy[k] >= skip_rows && (unsigned)ix < (unsigned)P.XW;
+          pxa[k] = wb_bload(rx, act ? o : OOB);
+          pxb[k] = wb_bload(rx, act ? o + 16u : OOB);
+        }
+      }
+      {
+        const size_t img = (size_t)P.YH * y_srow;
+        const __amdgpu_buffer_rsrc_t ry = wb_rsrc(Ldy + (size_t)n * img, (unsigned)(img * 4));
+        const __amdgpu_buffer_rsrc_t rm = wb_rsrc(Lmask ? Lmask + (size_t)n * img : Ldy, Lmask ? (unsigned)(img * 4) : 0u);
+        const unsigned obase = ((unsigned)r0 * y_srow + (unsigned)c0 * y_scol) * 4u;
+#pragma unroll
+        for (int k = 0; k < PIT; ++k) {
+          const unsigned o = obase + (unsigned)y_rel[k];
+          const bool act = y_lds[k] >= 0 && c0 + y_c[k] < P.YW;
+          const unsigned o0 = act ? o : OOB, o1 = act ? o + 16u : OOB;
+          pya[k] = wb_bload(ry, o0);
+          pyb[k] = wb_bload(ry, o1);
+          if (Lmask) {  // raw mask values: applied at commit time, so that nothing here waits for a load
+            pma[k] = wb_bload(rm, o0);
+            pmb[k] = wb_bload(rm, o1);
+          }
+        }
+      }
+    };
+    auto commit = [&](int bsel) {
+      const int rbase = st_base[bsel], skip_rows = st_skip[bsel];
+#pragma unroll
+      for (int k = 0; k < PIT; ++k) {
+        if (x_lds[k] >= 0 && x_hy[k] >= skip_rows) {
+          uint4 hi, lo;
+          wt_split8(pxa[k], pxb[k], hi, lo);
+          int slot = rbase + x_hy[k];
+          slot = slot >= R2 ? slot - R2 : slot;
+          unsigned char* dst = smem8 + (unsigned)slot * XROW + (unsigned)x_lds[k];
+          *reinterpret_cast<uint4*>(dst) = hi;
+          *reinterpret_cast<uint4*>(dst + XPL) = lo;
+        }
+      }
+      unsigned char* ys = smem8 + YSET0 + (unsigned)bsel * YSET;
+#pragma unroll
+      for (int k = 0; k < PIT; ++k) {
+        if (y_lds[k] >= 0) {
+          f32x4 v0 = pya[k], v1 = pyb[k];
+          if (Lmask) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v0[e] = pma[k][e] > 0.f ? v0[e] : v0[e] * Lslope;
+              v1[e] = pmb[k][e] > 0.f ? v1[e] : v1[e] * Lslope;
+            }
+          }
+          bsum0 += v0;
+          bsum1 += v1;
+          uint4 hi, lo;
+          wt_split8(v0, v1, hi, lo);
+          unsigned char* dst = ys + (unsigned)y_lds[k];
+          *reinterpret_cast<uint4*>(dst) = hi;
+          *reinterpret_cast<uint4*>(dst + YPL) = lo;
+        }
+      }
+    };
+    if (!(SRK_KDBG(P.dbg) & 2)) {
+      if (ntb > 0) {
+        issue(first_tile, 0);
+        commit(0);
+        if (ntb > 1) issue(first_tile + 1, 1);
+      }
+      __syncthreads();
+      for (int it = 0; it < ntb; ++it) {
+        if (it + 1 < ntb) commit((it + 1) & 1);              // tile it + 1: its loads were issued an iteration ago
+        if (it + 2 < ntb) issue(first_tile + it + 2, it + 2);  // tile it + 2: lands under the K loop of tile it + 1
+        __syncthreads();
+      }
+    } else {
+      __syncthreads();
+      for (int it = 0; it < ntb; ++it) __syncthreads();
+    }
+    if (want_bias) {   // column sums of dY: the 64 staging threads of one 8-channel group (tid & 7) add up in LDS
+      float* bred = reinterpret_cast<float*>(smem8);   // [NST][8], the X ring is no longer read (barrier above)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bred[tid * 8 + e] = bsum0[e];
+        bred[tid * 8 + 4 + e] = bsum1[e];
+      }
+    }
+    __syncthreads();
+    if (want_bias && tid < COB) {
+      const float* bred = reinterpret_cast<const float*>(smem8);
+      const int g = tid >> 3, e = tid & 7;
+      float s = 0.f;
+      for (int t = g; t < NST; t += 8) s += bred[t * 8 + e];
+      P.bias_partial[(size_t)bxl * P.Cout + cob + tid] = s;
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- workers (4 waves: cit x cow)
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int cit = wave & 1, cow = wave >> 1;
+  f32x4 acc[3][3][NTW];
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) acc[u][v][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  struct XF {
+    uint4 h, l;
+    unsigned eh, el;
+  };
+  struct TB {
+    int orr;         // tile row of the octet
+    unsigned xc;     // byte offset of the lane's first transpose read inside a ring row
+    unsigned yo;     // byte offset of the octet inside a dY plane
+  };
+  const unsigned lane_x = (unsigned)((r16 >> 2) * 64 + (r16 & 3) * 8);
+  const int fl = ((r16 >> 3) & 1) | ((kq & 1) << 1);
+  const unsigned lane_y0 = (unsigned)((r16 >> 2) * 128 + (r16 & 3) * 8 + (((cow * 2 + 0) ^ fl) << 5));
+  const unsigned lane_y1 = (unsigned)((r16 >> 2) * 128 + (r16 & 3) * 8 + (((cow * 2 + 1) ^ fl) << 5));
+  const int nks_run = (SRK_KDBG(P.dbg) & 4) ? 0 : P.nks;
+  const int last = nks_run - 1;
+  auto tab = [&](int ks) -> TB {
+    const unsigned w = oct_tw[(ks < last ? ks : last) * 4 + kq];
+    const unsigned oc = w & 0xffu;
+    TB t;
+    t.orr = (int)((w >> 16) & 0xffu);
+    t.xc = oc * 512u + ((((oc & 1u) ^ (unsigned)cit)) << 5) + lane_x;
+    t.yo = (w >> 31) ? (unsigned)(P.TH * P.TW) * 128u : (unsigned)((ks < last ? ks : last) * 4 + kq) * 1024u;
+    return t;
+  };
+  auto tr = [&](unsigned off) -> uint2 {
+    const wt_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wt_ldsp)(smem8 + off));
+    return __builtin_bit_cast(uint2, v);
+  };
+  int rb = 0;   // ring row of the current tile's halo row 0
+  auto xload = [&](XF& f, const TB& t, int u) {
+    int slot = rb + t.orr + u;
+    slot = slot >= R2 ? slot - R2 : slot;
+    const unsigned a = (unsigned)slot * XROW + t.xc;
+    const unsigned b = (a + 512u) ^ 32u;   // pixels 8 .. 11: the next halo octet (its channel halves are swapped)
+    const uint2 h0 = tr(a), h1 = tr(a + 256u), l0 = tr(a + XPL), l1 = tr(a + XPL + 256u);
+    const uint2 h2 = tr(b), l2 = tr(b + XPL);
+    f.h = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    f.l = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    f.eh = h2.x;
+    f.el = l2.x;
+  };
+  unsigned ysel = YSET0;   // dY buffer set of the current tile
+  auto yload = [&](uint4 (&bh)[NTW], uint4 (&bl)[NTW], const TB& t) {
+    const unsigned a0 = ysel + t.yo + lane_y0, a1 = ysel + t.yo + lane_y1;
+    const uint2 p0 = tr(a0), p1 = tr(a0 + 512u), q0 = tr(a0 + YPL), q1 = tr(a0 + YPL + 512u);
+    const uint2 p2 = tr(a1), p3 = tr(a1 + 512u), q2 = tr(a1 + YPL), q3 = tr(a1 + YPL + 512u);
+    bh[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
+    bl[0] = make_uint4(q0.x, q0.y, q1.x, q1.y);
+    bh[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
+    bl[1] = make_uint4(q2.x, q2.y, q3.x, q3.y);
+  };
+  auto rowmm = [&](const XF& f, const uint4 (&bh)[NTW], const uint4 (&bl)[NTW], f32x4 (&a)[3][NTW]) {
+    uint4 ah[3], al[3];
+    ah[0] = f.h;
+    al[0] = f.l;
+    ah[1] = make_uint4(__builtin_amdgcn_alignbit(f.h.y, f.h.x, 16), __builtin_amdgcn_alignbit(f.h.z, f.h.y, 16),
+                       __builtin_amdgcn_alignbit(f.h.w, f.h.z, 16), __builtin_amdgcn_alignbit(f.eh, f.h.w, 16));
+    al[1] = make_uint4(__builtin_amdgcn_alignbit(f.l.y, f.l.x, 16), __builtin_amdgcn_alignbit(f.l.z, f.l.y, 16),
+                       __builtin_amdgcn_alignbit(f.l.w, f.l.z, 16), __builtin_amdgcn_alignbit(f.el, f.l.w, 16));
+    ah[2] = make_uint4(f.h.y, f.h.z, f.h.w, f.eh);
+    al[2] = make_uint4(f.l.y, f.l.z, f.l.w, f.el);
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) a[v][nt] = wb_mfma(al[v], bh[nt], a[v][nt]);
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) a[v][nt] = wb_mfma(ah[v], bl[nt], a[v][nt]);
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) a[v][nt] = wb_mfma(ah[v], bh[nt], a[v][nt]);
+  };
+  // one K step (see the pipelined loop of k_wgrad_bf): rows 0 .. 2 of step `tc` from (x0, yh, yl); row 0 and the dY
+  // fragments of step `tn` are requested under the last row's MFMAs
+  auto step = [&](const XF& x0, const uint4 (&yh)[NTW], const uint4 (&yl)[NTW], XF& xn, uint4 (&nh)[NTW], uint4 (&nl)[NTW],
+                  const TB& tc, const TB& tn) {
+    XF x1, x2;
+    xload(x1, tc, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    rowmm(x0, yh, yl, acc[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    xload(x2, tc, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    rowmm(x1, yh, yl, acc[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    xload(xn, tn, 0);
+    yload(nh, nl, tn);
+    __builtin_amdgcn_sched_barrier(0);
+    rowmm(x2, yh, yl, acc[2]);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  if (WB_PRIO) __builtin_amdgcn_s_setprio(WB_PRIO);
+  __syncthreads();   // tile 0 staged
+  if (nks_run > 0) {
+    const TB tb0 = tab(0), tb1 = tab(1);   // the first two K steps' table words do not depend on the tile
+    int wprev = P.HH;
+    for (int it = 0; it < ntb; ++it) {
+      wprev = ring_next(wprev, it == 0 || ((first_tile + it) % P.tiles_y) == 0);
+      rb = wprev;
+      ysel = YSET0 + (unsigned)(it & 1) * YSET;
+      TB t0 = tb0, t1 = tb1;
+      XF xa, xb;
+      uint4 yah[NTW], yal[NTW], ybh[NTW], ybl[NTW];
+      xload(xa, t0, 0);
+      yload(yah, yal, t0);
+      int ks = 0;
+      for (; ks + 1 < nks_run; ks += 2) {
+        const TB t2 = tab(ks + 2);
+        step(xa, yah, yal, xb, ybh, ybl, t0, t1);
+        const TB t3 = tab(ks + 3);
+        step(xb, ybh, ybl, xa, yah, yal, t1, t2);
+        t0 = t2;
+        t1 = t3;
+      }
+      if (ks < nks_run) step(xa, yah, yal, xb, ybh, ybl, t0, t1);
+      __syncthreads();
+    }
+  } else {
+    for (int it = 0; it < ntb; ++it) __syncthreads();
+  }
+  __syncthreads();   // (the stagers' bias reduction)
+  // partial slab ws[g][t][ci][co]; C/D layout: col = lane & 15 (co), row = (lane >> 4) * 4 + reg (ci)
+  float* slab = P.ws + (size_t)bxl * 9 * P.Cin * P.Cout;
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const int t = u * 3 + v;
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int co = cob + (cow * NTW + nt) * 16 + r16;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int ci = cib + cit * 16 + kq * 4 + reg;
+          slab[((size_t)t * P.Cin + ci) * P.Cout + co] = acc[u][v][nt][reg];
         }
       }
     }
@@ -1280,6 +1850,31 @@ int conv_wgrad_s2(const srk_conv_desc& d, const float* x, const float* dy, float
                                   0, s);
 }
 
+// ---- k_wgrad_tr (pixel-major LDS image + transpose reads): eligibility, LDS layout, launch.  SRK_WGRAD_TR=0: never.
+static bool wt_setup(WgBfParams& P, const srk_conv_desc& d, const WbPlan& pl, bool spec, size_t& lds_bytes) {
+  if (!spec || pl.cfg != 0 || !env_int("SRK_WGRAD_TR", 1)) return false;
+  if (d.KH != 3 || d.KW != 3 || d.Cin % 32 != 0 || d.Cout % 64 != 0 || !P.vec_x || !P.vec_y) return false;
+  if (d.dy_ps_r > 1 && (d.Cout / (d.dy_ps_r * d.dy_ps_r)) % 64 != 0) return false;
+  const long ximg = (long)d.H * d.W * d.Cin * 4, yimg = (long)d.OH * d.OW * d.Cout * 4;
+  if (ximg >= (1L << 31) || yimg >= (1L << 31)) return false;   // per-image buffer descriptors, 32-bit byte offsets
+  if ((long)pl.HH * (pl.TW + 2) * 4 > 1024 || (long)pl.TH * pl.TW * 8 > 1024) return false;  // two items per stager and tensor
+  const int XP = pl.TW + 4;   // halo columns 0 .. TW + 1 are staged; the third transpose read of a row touches TW + 3
+  const size_t XPL = (size_t)2 * pl.HH * XP * 64, YPL = (size_t)(pl.TH * pl.TW + 8) * 128;
+  const size_t bytes = 2 * XPL + 4 * YPL;
+  if (bytes + 1024 > 160 * 1024 || 2 * XPL < (size_t)WB_SST * 8 * 4 || XPL + 512 >= 65536 || YPL + 1024 >= 65536) return false;
+  P.XP = XP;
+  P.XPL = (int)XPL;
+  P.YPL = (int)YPL;
+  lds_bytes = bytes;
+  return true;
+}
+template <bool GRP>
+static void wt_launch(const WgBfParams& P, const typename WgGroupArg<GRP>::type& GR, dim3 grid, size_t lds, hipStream_t s) {
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&k_wgrad_tr<GRP>), lds);
+  hipLaunchKernelGGL((k_wgrad_tr<GRP>), grid, dim3(768), lds, s, P, GR);
+}
+
 bool conv_wgrad_bf_supported(const srk_conv_desc& d) { return wb_plan(d).ok; }
 
 size_t conv_wgrad_bf_ws(const srk_conv_desc& d) {
@@ -1452,12 +2047,14 @@ int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const
               pl.cfg, spec ? " (wave-specialised)" : "", P.ring ? " (X ring)" : "", pl.TH, pl.TW, pl.nks, pl.ntiles, G, pl.gy,
               pl.gz, spec ? 2 * lds_half : pl.lds);
   }
+  size_t tr_lds = 0;
   switch (pl.cfg) {
     case 0:
 #ifdef SRK_EXPERIMENTS
       // experiment (SRK_WG_W8=1): eight working waves (2 ci tiles x 4 single-tile co columns) -- measured SLOWER: see k_wgrad_bf
       if (spec && wb_k33(P) && SRK_EXP_INT("SRK_WG_W8", 0)) { wb_launch<2, 4, 1>(P, grid, lds_half, spec, s); break; }
 #endif
+      if (wt_setup(P, d, pl, spec, tr_lds)) { wt_launch<false>(P, WgNoGroup{0}, grid, tr_lds, s); break; }
       wb_launch<2, 2, 2>(P, grid, lds_half, spec, s);
       break;
     case 1: wb_launch<4, 1, 2>(P, grid, lds_half, spec, s); break;
@@ -1574,11 +2171,13 @@ int conv_wgrad_bf_grouped(const srk_conv_desc& d, int n, const float* const* xs,
       lds_half = (ring_bytes + 1) / 2;
     }
   }
+  size_t tr_lds = 0;
   switch (pl.cfg) {
     case 0:
 #ifdef SRK_EXPERIMENTS
       if (spec && wb_k33(P) && SRK_EXP_INT("SRK_WG_W8", 0)) { wb_launch_grouped<2, 4, 1>(P, GR, grid, lds_half, spec, s); break; }
 #endif
+      if (wt_setup(P, d, pl, spec, tr_lds)) { wt_launch<true>(P, GR, grid, tr_lds, s); break; }
       wb_launch_grouped<2, 2, 2>(P, GR, grid, lds_half, spec, s);
       break;
     case 1: wb_launch_grouped<4, 1, 2>(P, GR, grid, lds_half, spec, s); break;
