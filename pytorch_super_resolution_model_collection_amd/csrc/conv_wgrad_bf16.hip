@@ -66,6 +66,9 @@ __device__ __forceinline__ void wb_item(int tid, int& q, int& pp0) {
 #ifndef WB_PRIO
 #define WB_PRIO 0
 #endif
+#ifndef WT_SGB
+#define WT_SGB 1
+#endif
 constexpr int WB_IT = 1;       // pixel pairs per thread loaded together while staging (4 measured: no gain plain, spills in the specialised variant)
 
 struct WgBfParams {
@@ -1076,13 +1079,13 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
     Lmask = GR.L[layer].mask_y;
     Lslope = GR.L[layer].mask_slope;
   }
-  // octet table: tile row << 16 | octet column; K padding: bit 31 (multiplied by the zero pixels behind every dY plane)
+  // octet table: tile row << 16 | dY octet << 8 | octet column; K padding: X octet (0, 0) times the zero octet behind a dY plane
   for (int o = tid0; o < P.nks * 4; o += NTHR) {
     if (o < noct) {
       const int orow = o / P.TWo;
-      oct_tw[o] = (unsigned)(orow << 16) | (unsigned)(o - orow * P.TWo);
+      oct_tw[o] = (unsigned)(orow << 16) | (unsigned)(o << 8) | (unsigned)(o - orow * P.TWo);
     } else {
-      oct_tw[o] = 0x80000000u;
+      oct_tw[o] = (unsigned)(noct << 8);
     }
   }
   for (int e = tid0; e < 2 * 2 * 64; e += NTHR) {   // 8 zero pixels x 128 B behind each of the four dY planes
@@ -1242,11 +1245,25 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
         if (ntb > 1) issue(first_tile + 1, 1);
       }
       __syncthreads();
+      long long st_commit = 0, st_issue = 0, st_wait = 0;
       for (int it = 0; it < ntb; ++it) {
+        const long long c0 = WB_CLK();
         if (it + 1 < ntb) commit((it + 1) & 1);              // tile it + 1: its loads were issued an iteration ago
+        const long long c1 = WB_CLK();
         if (it + 2 < ntb) issue(first_tile + it + 2, it + 2);  // tile it + 2: lands under the K loop of tile it + 1
+        const long long c2 = WB_CLK();
         __syncthreads();
+        st_commit += c1 - c0;
+        st_issue += c2 - c1;
+        st_wait += WB_CLK() - c2;
       }
+#ifdef SRK_EXPERIMENTS
+      if (P.prof && tid0 == WTHR) {
+        long long* pr = P.prof + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16;
+        pr[0] = st_commit; pr[1] = st_issue; pr[2] = st_wait; pr[3] = ntb;
+      }
+#endif
+      (void)st_commit; (void)st_issue; (void)st_wait;
     } else {
       __syncthreads();
       for (int it = 0; it < ntb; ++it) __syncthreads();
@@ -1283,36 +1300,31 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
   struct XF {
     uint4 h, l;
     unsigned eh, el;
+    unsigned xh, xl;   // pixels 10, 11 of the third reads: never multiplied, kept live until the row has been (a register the
+                       // allocator hands out again while its read is in flight puts an s_waitcnt into the MFMA stream)
   };
-  struct TB {
-    int orr;         // tile row of the octet
-    unsigned xc;     // byte offset of the lane's first transpose read inside a ring row
-    unsigned yo;     // byte offset of the octet inside a dY plane
-  };
+  typedef unsigned TB;   // an octet's table word
   const unsigned lane_x = (unsigned)((r16 >> 2) * 64 + (r16 & 3) * 8);
   const int fl = ((r16 >> 3) & 1) | ((kq & 1) << 1);
   const unsigned lane_y0 = (unsigned)((r16 >> 2) * 128 + (r16 & 3) * 8 + (((cow * 2 + 0) ^ fl) << 5));
-  const unsigned lane_y1 = (unsigned)((r16 >> 2) * 128 + (r16 & 3) * 8 + (((cow * 2 + 1) ^ fl) << 5));
   const int nks_run = (SRK_KDBG(P.dbg) & 4) ? 0 : P.nks;
   const int last = nks_run - 1;
-  auto tab = [&](int ks) -> TB {
-    const unsigned w = oct_tw[(ks < last ? ks : last) * 4 + kq];
-    const unsigned oc = w & 0xffu;
-    TB t;
-    t.orr = (int)((w >> 16) & 0xffu);
-    t.xc = oc * 512u + ((((oc & 1u) ^ (unsigned)cit)) << 5) + lane_x;
-    t.yo = (w >> 31) ? (unsigned)(P.TH * P.TW) * 128u : (unsigned)((ks < last ? ks : last) * 4 + kq) * 1024u;
-    return t;
-  };
+  auto tab = [&](int ks) -> TB { return oct_tw[(ks < last ? ks : last) * 4 + kq]; };
   auto tr = [&](unsigned off) -> uint2 {
     const wt_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wt_ldsp)(smem8 + off));
     return __builtin_bit_cast(uint2, v);
   };
   int rb = 0;   // ring row of the current tile's halo row 0
-  auto xload = [&](XF& f, const TB& t, int u) {
-    int slot = rb + t.orr + u;
+  unsigned ysel = YSET0;   // dY buffer set of the current tile
+  // byte address of a lane's first transpose read of halo row (octet row + u)
+  auto xaddr = [&](const TB& t, int u) -> unsigned {
+    const unsigned oc = t & 0xffu;
+    int slot = rb + (int)(t >> 16) + u;
     slot = slot >= R2 ? slot - R2 : slot;
-    const unsigned a = (unsigned)slot * XROW + t.xc;
+    return __umul24((unsigned)slot, XROW) + (oc << 9) + (((oc ^ (unsigned)cit) & 1u) << 5) + lane_x;
+  };
+  auto yaddr = [&](const TB& t) -> unsigned { return ysel + ((t & 0xff00u) << 2) + lane_y0; };
+  auto xissue = [&](XF& f, unsigned a) {
     const unsigned b = (a + 512u) ^ 32u;   // pixels 8 .. 11: the next halo octet (its channel halves are swapped)
     const uint2 h0 = tr(a), h1 = tr(a + 256u), l0 = tr(a + XPL), l1 = tr(a + XPL + 256u);
     const uint2 h2 = tr(b), l2 = tr(b + XPL);
@@ -1320,10 +1332,11 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
     f.l = make_uint4(l0.x, l0.y, l1.x, l1.y);
     f.eh = h2.x;
     f.el = l2.x;
+    f.xh = h2.y;
+    f.xl = l2.y;
   };
-  unsigned ysel = YSET0;   // dY buffer set of the current tile
-  auto yload = [&](uint4 (&bh)[NTW], uint4 (&bl)[NTW], const TB& t) {
-    const unsigned a0 = ysel + t.yo + lane_y0, a1 = ysel + t.yo + lane_y1;
+  auto yissue = [&](uint4 (&bh)[NTW], uint4 (&bl)[NTW], unsigned a0) {
+    const unsigned a1 = a0 ^ 32u;   // the wave's second 16-channel tile: lane_y1 = lane_y0 ^ 32
     const uint2 p0 = tr(a0), p1 = tr(a0 + 512u), q0 = tr(a0 + YPL), q1 = tr(a0 + YPL + 512u);
     const uint2 p2 = tr(a1), p3 = tr(a1 + 512u), q2 = tr(a1 + YPL), q3 = tr(a1 + YPL + 512u);
     bh[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
@@ -1353,40 +1366,64 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
     for (int v = 0; v < 3; ++v)
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) a[v][nt] = wb_mfma(ah[v], bh[nt], a[v][nt]);
+    asm volatile("" ::"v"(f.xh), "v"(f.xl));
   };
-  // one K step (see the pipelined loop of k_wgrad_bf): rows 0 .. 2 of step `tc` from (x0, yh, yl); row 0 and the dY
-  // fragments of step `tn` are requested under the last row's MFMAs
+  // A phase = the 18 MFMAs of one (K step, kernel row).  Its region starts with the transpose reads of the NEXT phase
+  // (addresses computed one phase earlier) and then holds ONLY matrix instructions with the VALU work -- this row's column
+  // shifts, the address of the phase after next -- threaded between them: the matrix pipe takes an MFMA every 16 clocks and
+  // stands still while its wave issues anything else in front of one.
+  auto mm_region = [&]() {
+    if (WT_SGB) {
+#pragma unroll
+      for (int q = 0; q < 18; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  unsigned nxa = 0;   // address of the next phase's X reads
+  // one K step: rows 0 .. 2 of step `tc` from (x0, yh, yl); row 0 and the dY fragments of step `tn` are requested in front of
+  // the last row's MFMAs; on entry nxa = xaddr(tc, 1), on exit nxa = xaddr(tn, 1)
   auto step = [&](const XF& x0, const uint4 (&yh)[NTW], const uint4 (&yl)[NTW], XF& xn, uint4 (&nh)[NTW], uint4 (&nl)[NTW],
                   const TB& tc, const TB& tn) {
     XF x1, x2;
-    xload(x1, tc, 1);
+    xissue(x1, nxa);
     __builtin_amdgcn_sched_barrier(0);
     rowmm(x0, yh, yl, acc[0]);
-    __builtin_amdgcn_sched_barrier(0);
-    xload(x2, tc, 2);
+    nxa = xaddr(tc, 2);
+    mm_region();
+    xissue(x2, nxa);
     __builtin_amdgcn_sched_barrier(0);
     rowmm(x1, yh, yl, acc[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    xload(xn, tn, 0);
-    yload(nh, nl, tn);
+    nxa = xaddr(tn, 0);
+    const unsigned nya = yaddr(tn);
+    mm_region();
+    xissue(xn, nxa);
+    yissue(nh, nl, nya);
     __builtin_amdgcn_sched_barrier(0);
     rowmm(x2, yh, yl, acc[2]);
-    __builtin_amdgcn_sched_barrier(0);
+    nxa = xaddr(tn, 1);
+    mm_region();
   };
   if (WB_PRIO) __builtin_amdgcn_s_setprio(WB_PRIO);
   __syncthreads();   // tile 0 staged
   if (nks_run > 0) {
     const TB tb0 = tab(0), tb1 = tab(1);   // the first two K steps' table words do not depend on the tile
     int wprev = P.HH;
+    long long wk_loop = 0, wk_wait = 0, wk_pro = 0;
     for (int it = 0; it < ntb; ++it) {
+      const long long k0 = WB_CLK();
       wprev = ring_next(wprev, it == 0 || ((first_tile + it) % P.tiles_y) == 0);
       rb = wprev;
       ysel = YSET0 + (unsigned)(it & 1) * YSET;
       TB t0 = tb0, t1 = tb1;
       XF xa, xb;
       uint4 yah[NTW], yal[NTW], ybh[NTW], ybl[NTW];
-      xload(xa, t0, 0);
-      yload(yah, yal, t0);
+      xissue(xa, xaddr(t0, 0));
+      yissue(yah, yal, yaddr(t0));
+      nxa = xaddr(t0, 1);
+      const long long k1 = WB_CLK();
       int ks = 0;
       for (; ks + 1 < nks_run; ks += 2) {
         const TB t2 = tab(ks + 2);
@@ -1397,8 +1434,19 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
         t1 = t3;
       }
       if (ks < nks_run) step(xa, yah, yal, xb, ybh, ybl, t0, t1);
+      const long long k2 = WB_CLK();
       __syncthreads();
+      wk_pro += k1 - k0;
+      wk_loop += k2 - k0;
+      wk_wait += WB_CLK() - k2;
     }
+#ifdef SRK_EXPERIMENTS
+    if (P.prof && tid0 == 0) {
+      long long* pr = P.prof + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + 8;
+      pr[0] = wk_loop; pr[1] = wk_wait; pr[2] = ntb; pr[3] = (long long)ntb * P.nks; pr[4] = wk_pro;
+    }
+#endif
+    (void)wk_loop; (void)wk_wait; (void)wk_pro;
   } else {
     for (int it = 0; it < ntb; ++it) __syncthreads();
   }

@@ -34,5 +34,12 @@ for name in (sys.argv[1:] or list(SHAPES)):
     for _ in range(5): g.replay()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 100
+    if os.environ.get("LOOP_SECS"):   # keep the layer looping for the power / clock probe (tools/power_probe.sh)
+        import time
+        t0 = time.time(); n = 0
+        while time.time() - t0 < float(os.environ["LOOP_SECS"]):
+            for _ in range(20): g.replay()
+            torch.cuda.synchronize(); n += 400
+        ms = (time.time() - t0) / n * 1e3
     print("%-8s wgrad+reduce %.4f ms  %.1f TF  checksum %.6e" % (name, ms, 2.0 * N * H * W * cin * cout * k * k / ms / 1e9,
                                                              float(dw.double().abs().sum())))

@@ -50,3 +50,6 @@ for name, n, h in (("VDSR body layer 256 x 41 x 41", 256, 41), ("EDSR body layer
     print("   worker wave: K loop %4.1f %%  barrier wait %4.1f %%   (per tile: %.0f / %.0f clocks; per K step %.0f clocks for 864 of MFMA)" % (
         100 * float((t[:, 8] / tot_w).mean()), 100 * float((t[:, 9] / tot_w).mean()), float((t[:, 8] / t[:, 10]).mean()),
         float((t[:, 9] / t[:, 10]).mean()), float((t[:, 8] / t[:, 11]).mean())))
+    if float(t[:, 12].sum()) > 0:   # k_wgrad_tr: the part of the K loop in front of a tile's first K step (ring bookkeeping, addresses, first reads issued)
+        print("   worker wave: per tile %.0f clocks in front of the first K step; (K loop - that) per K step %.0f" % (
+            float((t[:, 12] / t[:, 10]).mean()), float(((t[:, 8] - t[:, 12]) / t[:, 11]).mean())))
