@@ -1325,6 +1325,7 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
   };
   auto yaddr = [&](const TB& t) -> unsigned { return ysel + ((t & 0xff00u) << 2) + lane_y0; };
   auto xissue = [&](XF& f, unsigned a) {
+    if (SRK_KDBG(P.dbg) & 16) return;   // ablation: no fragment reads (the MFMAs run on whatever the registers hold)
     const unsigned b = (a + 512u) ^ 32u;   // pixels 8 .. 11: the next halo octet (its channel halves are swapped)
     const uint2 h0 = tr(a), h1 = tr(a + 256u), l0 = tr(a + XPL), l1 = tr(a + XPL + 256u);
     const uint2 h2 = tr(b), l2 = tr(b + XPL);
@@ -1336,6 +1337,7 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
     f.xl = l2.y;
   };
   auto yissue = [&](uint4 (&bh)[NTW], uint4 (&bl)[NTW], unsigned a0) {
+    if (SRK_KDBG(P.dbg) & 16) return;
     const unsigned a1 = a0 ^ 32u;   // the wave's second 16-channel tile: lane_y1 = lane_y0 ^ 32
     const uint2 p0 = tr(a0), p1 = tr(a0 + 512u), q0 = tr(a0 + YPL), q1 = tr(a0 + YPL + 512u);
     const uint2 p2 = tr(a1), p3 = tr(a1 + 512u), q2 = tr(a1 + YPL), q3 = tr(a1 + YPL + 512u);
@@ -1354,26 +1356,89 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
                        __builtin_amdgcn_alignbit(f.l.w, f.l.z, 16), __builtin_amdgcn_alignbit(f.el, f.l.w, 16));
     ah[2] = make_uint4(f.h.y, f.h.z, f.h.w, f.eh);
     al[2] = make_uint4(f.l.y, f.l.z, f.l.w, f.el);
+    if (SRK_KDBG(P.dbg) & 64) {   // ablation: no column shifts
+      ah[1] = ah[2] = ah[0];
+      al[1] = al[2] = al[0];
+    }
+    // (dY is the A operand: the accumulator rows are output channels, a lane's four registers four consecutive co of
+    //  one ci -- one 16-byte store per tile into the [tap][ci][co] slab; same products, same order as X-first)
 #pragma unroll
     for (int v = 0; v < 3; ++v)
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) a[v][nt] = wb_mfma(al[v], bh[nt], a[v][nt]);
+      for (int nt = 0; nt < NTW; ++nt) a[v][nt] = wb_mfma(bh[nt], al[v], a[v][nt]);
 #pragma unroll
     for (int v = 0; v < 3; ++v)
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) a[v][nt] = wb_mfma(ah[v], bl[nt], a[v][nt]);
+      for (int nt = 0; nt < NTW; ++nt) a[v][nt] = wb_mfma(bl[nt], ah[v], a[v][nt]);
 #pragma unroll
     for (int v = 0; v < 3; ++v)
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) a[v][nt] = wb_mfma(ah[v], bh[nt], a[v][nt]);
+      for (int nt = 0; nt < NTW; ++nt) a[v][nt] = wb_mfma(bh[nt], ah[v], a[v][nt]);
     asm volatile("" ::"v"(f.xh), "v"(f.xl));
   };
   // A phase = the 18 MFMAs of one (K step, kernel row).  Its region starts with the transpose reads of the NEXT phase
   // (addresses computed one phase earlier) and then holds ONLY matrix instructions with the VALU work -- this row's column
   // shifts, the address of the phase after next -- threaded between them: the matrix pipe takes an MFMA every 16 clocks and
   // stands still while its wave issues anything else in front of one.
-  auto mm_region = [&]() {
-    if (WT_SGB) {
+  // WT_SGB == 3: the same phase with the order of its matrix instructions and LDS reads written down -- MFMA q, then read q of
+  // the next phase's fragments (sched_barrier(0x6): only VALU / SALU instructions may move across, so the column shifts and
+  // the address arithmetic settle into the gaps the compiler finds for them).  The first reads are the ones the next phase's
+  // first MFMAs need (lo halves, then dY).
+  auto xread1 = [&](XF& f, unsigned a, int k) {
+    if (SRK_KDBG(P.dbg) & 16) return;
+    const unsigned b = (a + 512u) ^ 32u;
+    if (k == 0) { const uint2 t = tr(a + XPL); f.l.x = t.x; f.l.y = t.y; }
+    if (k == 1) { const uint2 t = tr(a + XPL + 256u); f.l.z = t.x; f.l.w = t.y; }
+    if (k == 2) { const uint2 t = tr(a); f.h.x = t.x; f.h.y = t.y; }
+    if (k == 3) { const uint2 t = tr(a + 256u); f.h.z = t.x; f.h.w = t.y; }
+    if (k == 4) { const uint2 t = tr(b + XPL); f.el = t.x; f.xl = t.y; }
+    if (k == 5) { const uint2 t = tr(b); f.eh = t.x; f.xh = t.y; }
+  };
+  auto yread1 = [&](uint4 (&bh)[NTW], uint4 (&bl)[NTW], unsigned a0, int k) {
+    if (SRK_KDBG(P.dbg) & 16) return;
+    const unsigned a = (k & 4) ? (a0 ^ 32u) : a0;
+    const int nt = k >> 2;
+    if ((k & 3) == 0) { const uint2 t = tr(a); bh[nt].x = t.x; bh[nt].y = t.y; }
+    if ((k & 3) == 1) { const uint2 t = tr(a + 512u); bh[nt].z = t.x; bh[nt].w = t.y; }
+    if ((k & 3) == 2) { const uint2 t = tr(a + YPL); bl[nt].x = t.x; bl[nt].y = t.y; }
+    if ((k & 3) == 3) { const uint2 t = tr(a + YPL + 512u); bl[nt].z = t.x; bl[nt].w = t.y; }
+  };
+  // MFMA q of a row's 18 (pass-major: lo x hi, hi x lo, hi x hi; tap column, then output tile)
+  auto mm1 = [&](const uint4 (&ah)[3], const uint4 (&al)[3], const uint4 (&bh)[NTW], const uint4 (&bl)[NTW], f32x4 (&a)[3][NTW],
+                 int q) {
+    const int pass = q / 6, v = (q % 6) / NTW, nt = q % NTW;
+    a[v][nt] = wb_mfma(pass == 1 ? bl[nt] : bh[nt], pass == 0 ? al[v] : ah[v], a[v][nt]);
+  };
+  auto shifts = [&](const XF& f, uint4 (&ah)[3], uint4 (&al)[3]) {
+    ah[0] = f.h;
+    al[0] = f.l;
+    ah[1] = make_uint4(__builtin_amdgcn_alignbit(f.h.y, f.h.x, 16), __builtin_amdgcn_alignbit(f.h.z, f.h.y, 16),
+                       __builtin_amdgcn_alignbit(f.h.w, f.h.z, 16), __builtin_amdgcn_alignbit(f.eh, f.h.w, 16));
+    al[1] = make_uint4(__builtin_amdgcn_alignbit(f.l.y, f.l.x, 16), __builtin_amdgcn_alignbit(f.l.z, f.l.y, 16),
+                       __builtin_amdgcn_alignbit(f.l.w, f.l.z, 16), __builtin_amdgcn_alignbit(f.el, f.l.w, 16));
+    ah[2] = make_uint4(f.h.y, f.h.z, f.h.w, f.eh);
+    al[2] = make_uint4(f.l.y, f.l.z, f.l.w, f.el);
+    if (SRK_KDBG(P.dbg) & 64) {
+      ah[1] = ah[2] = ah[0];
+      al[1] = al[2] = al[0];
+    }
+  };
+  // (tools/wgrad_variant.sh ablations, workers alone on the VDSR layer: all 92.6 us, no column shifts 87.6, no fragment reads
+  //  65.4 -- a transpose read issued in front of the MFMAs costs the matrix pipe ~16 clocks: with WT_SGB = 2 the NR reads of a
+  //  region are threaded one per MFMA gap as well, oldest first.)
+  auto mm_region = [&](int nreads) {
+    if (WT_SGB == 2) {
+#pragma unroll
+      for (int q = 0; q < 18; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (q < nreads) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+      }
+    } else if (WT_SGB) {
 #pragma unroll
       for (int q = 0; q < 18; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1383,28 +1448,73 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
     __builtin_amdgcn_sched_barrier(0);
   };
   unsigned nxa = 0;   // address of the next phase's X reads
-  // one K step: rows 0 .. 2 of step `tc` from (x0, yh, yl); row 0 and the dY fragments of step `tn` are requested in front of
+  // one K step: rows 0 .. 2 of step `tc` from (x0, yh, yl); row 0 and the dY fragments of step `tn` are requested with
   // the last row's MFMAs; on entry nxa = xaddr(tc, 1), on exit nxa = xaddr(tn, 1)
   auto step = [&](const XF& x0, const uint4 (&yh)[NTW], const uint4 (&yl)[NTW], XF& xn, uint4 (&nh)[NTW], uint4 (&nl)[NTW],
                   const TB& tc, const TB& tn) {
-    XF x1, x2;
+    XF x1 = {}, x2 = {};
+    if (WT_SGB == 3) {
+      uint4 ah[3], al[3];
+      {
+        const unsigned a = nxa;
+        shifts(x0, ah, al);
+#pragma unroll
+        for (int q = 0; q < 18; ++q) {
+          mm1(ah, al, yh, yl, acc[0], q);
+          if (q < 6) xread1(x1, a, q);
+          __builtin_amdgcn_sched_barrier(0x6);
+        }
+        asm volatile("" ::"v"(x0.xh), "v"(x0.xl));
+        nxa = xaddr(tc, 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      {
+        const unsigned a = nxa;
+        shifts(x1, ah, al);
+#pragma unroll
+        for (int q = 0; q < 18; ++q) {
+          mm1(ah, al, yh, yl, acc[1], q);
+          if (q < 6) xread1(x2, a, q);
+          __builtin_amdgcn_sched_barrier(0x6);
+        }
+        asm volatile("" ::"v"(x1.xh), "v"(x1.xl));
+        nxa = xaddr(tn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      {
+        const unsigned a = nxa, ya = yaddr(tn);
+        shifts(x2, ah, al);
+#pragma unroll
+        for (int q = 0; q < 18; ++q) {
+          mm1(ah, al, yh, yl, acc[2], q);
+          if (q < 2) xread1(xn, a, q);            // lo halves of the next step's first row,
+          else if (q < 10) yread1(nh, nl, ya, q - 2);   // its dY fragments,
+          else if (q < 14) xread1(xn, a, q - 8);  // the rest of the row
+          __builtin_amdgcn_sched_barrier(0x6);
+        }
+        asm volatile("" ::"v"(x2.xh), "v"(x2.xl));
+        nxa = xaddr(tn, 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
     xissue(x1, nxa);
-    __builtin_amdgcn_sched_barrier(0);
+    if (WT_SGB != 2) __builtin_amdgcn_sched_barrier(0);
     rowmm(x0, yh, yl, acc[0]);
     nxa = xaddr(tc, 2);
-    mm_region();
+    mm_region(6);
     xissue(x2, nxa);
-    __builtin_amdgcn_sched_barrier(0);
+    if (WT_SGB != 2) __builtin_amdgcn_sched_barrier(0);
     rowmm(x1, yh, yl, acc[1]);
     nxa = xaddr(tn, 0);
     const unsigned nya = yaddr(tn);
-    mm_region();
+    mm_region(6);
     xissue(xn, nxa);
     yissue(nh, nl, nya);
-    __builtin_amdgcn_sched_barrier(0);
+    if (WT_SGB != 2) __builtin_amdgcn_sched_barrier(0);
     rowmm(x2, yh, yl, acc[2]);
     nxa = xaddr(tn, 1);
-    mm_region();
+    mm_region(14);
   };
   if (WB_PRIO) __builtin_amdgcn_s_setprio(WB_PRIO);
   __syncthreads();   // tile 0 staged
@@ -1418,8 +1528,8 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
       rb = wprev;
       ysel = YSET0 + (unsigned)(it & 1) * YSET;
       TB t0 = tb0, t1 = tb1;
-      XF xa, xb;
-      uint4 yah[NTW], yal[NTW], ybh[NTW], ybl[NTW];
+      XF xa = {}, xb = {};
+      uint4 yah[NTW] = {}, yal[NTW] = {}, ybh[NTW] = {}, ybl[NTW] = {};
       xissue(xa, xaddr(t0, 0));
       yissue(yah, yal, yaddr(t0));
       nxa = xaddr(t0, 1);
@@ -1451,22 +1561,16 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
     for (int it = 0; it < ntb; ++it) __syncthreads();
   }
   __syncthreads();   // (the stagers' bias reduction)
-  // partial slab ws[g][t][ci][co]; C/D layout: col = lane & 15 (co), row = (lane >> 4) * 4 + reg (ci)
-  float* slab = P.ws + (size_t)bxl * 9 * P.Cin * P.Cout;
+  // partial slab ws[g][t][ci][co]; C/D layout: col = lane & 15 (ci), row = (lane >> 4) * 4 + reg (co)
+  float* slab = P.ws + (size_t)bxl * 9 * P.Cin * P.Cout + (size_t)(cib + cit * 16 + r16) * P.Cout + cob + cow * 32 + kq * 4;
 #pragma unroll
   for (int u = 0; u < 3; ++u)
 #pragma unroll
     for (int v = 0; v < 3; ++v) {
       const int t = u * 3 + v;
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) {
-        const int co = cob + (cow * NTW + nt) * 16 + r16;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int ci = cib + cit * 16 + kq * 4 + reg;
-          slab[((size_t)t * P.Cin + ci) * P.Cout + co] = acc[u][v][nt][reg];
-        }
-      }
+      for (int nt = 0; nt < NTW; ++nt)
+        *reinterpret_cast<f32x4*>(slab + (size_t)t * P.Cin * P.Cout + nt * 16) = acc[u][v][nt];
     }
 }
 
@@ -1979,10 +2083,13 @@ static void wb_launch_grouped(const WgBfParams& P, const WgGroup& GR, dim3 grid,
 __global__ __launch_bounds__(256) void k_wgrad_reduce_grouped(const float* __restrict__ ws, WgGroupOut O, int G, int Cout,
                                                               int Cin, int KH, int KW, float beta,
                                                               const float* __restrict__ bias_partial) {
-  __shared__ float sm[4][64];
+  // (256 slab elements per block, four per lane as 16-byte loads; per element the summation order of the 64-element form)
+  typedef float r4 __attribute__((ext_vector_type(4)));
+  constexpr int EPB = 256;
+  __shared__ __attribute__((aligned(16))) float sm[4][EPB];
   const int elems = KH * KW * Cin * Cout;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int nwb = (elems + 63) / 64;
+  const int nwb = (elems + EPB - 1) / EPB;
   const int layer = blockIdx.y;
   float* __restrict__ dw = O.L[layer].dw;
   float* __restrict__ db = O.L[layer].db;
@@ -2008,20 +2115,31 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_grouped(const float* __res
     return;
   }
   const float* wl = ws + (size_t)layer * G * elems;
-  const int e = blockIdx.x * 64 + lane;
-  float s0 = 0.f, s1 = 0.f;
-  if (e < elems) {
+  const int e0 = blockIdx.x * EPB + lane * 4;
+  const bool vec = (elems & 3) == 0 && (reinterpret_cast<uintptr_t>(wl) & 15) == 0;
+  auto load4 = [&](int g) -> r4 {
+    const float* p = wl + (size_t)g * elems + e0;
+    if (vec) return *reinterpret_cast<const r4*>(p);
+    r4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (e0 + k < elems) v[k] = p[k];
+    return v;
+  };
+  r4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  if (e0 < elems) {
     int g = w;
     for (; g + 4 < G; g += 8) {
-      s0 += wl[(size_t)g * elems + e];
-      s1 += wl[(size_t)(g + 4) * elems + e];
+      s0 += load4(g);
+      s1 += load4(g + 4);
     }
-    for (; g < G; g += 4) s0 += wl[(size_t)g * elems + e];
+    for (; g < G; g += 4) s0 += load4(g);
   }
-  sm[w][lane] = s0 + s1;
+  *reinterpret_cast<r4*>(&sm[w][lane * 4]) = s0 + s1;
   __syncthreads();
-  if (w != 0 || e >= elems) return;
-  const float v = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+  const int t = threadIdx.x, e = blockIdx.x * EPB + t;
+  if (e >= elems) return;
+  const float v = (sm[0][t] + sm[1][t]) + (sm[2][t] + sm[3][t]);
   const int co = e % Cout;
   const int ci = (e / Cout) % Cin;
   const int tap = e / (Cout * Cin);
@@ -2243,7 +2361,7 @@ int conv_wgrad_bf_grouped(const srk_conv_desc& d, int n, const float* const* xs,
     }
     if (rc == SRK_OK) return SRK_OK;
   }
-  const int nwb = cdiv(elems, 64), bias_blocks = has_bias ? cdiv(d.Cout, 64) : 0;
+  const int nwb = cdiv(elems, 256), bias_blocks = has_bias ? cdiv(d.Cout, 64) : 0;
   hipLaunchKernelGGL(k_wgrad_reduce_grouped, dim3(nwb + bias_blocks, n), dim3(256), 0, s, (const float*)ws, GO, G, d.Cout,
                      d.Cin, d.KH, d.KW, beta, has_bias ? (const float*)bias_ws : nullptr);
   return check_launch("conv_wgrad_reduce_grouped");
