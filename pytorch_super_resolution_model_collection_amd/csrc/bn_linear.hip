@@ -175,6 +175,85 @@ __global__ __launch_bounds__(64 * NW) void k_bn_reduce_fused(const double* __res
   }
 }
 
+// The same reduction with 16 channels per block and 64 split phases of 16 lanes each (1024 threads): a 64-channel BatchNorm
+// of the SRGAN generator is FOUR blocks reading 128 KB of partial sums each -- every split of a thread in flight at once for
+// up to 512 splits -- instead of ONE block reading 512 KB (k_bn_reduce_fused<., 16>: 7.3 us average, ~110 launches per
+// adversarial step; the kernel is the L2 read time of a single CU).  Double sums: the order of the adds is immaterial at
+// the fp32 precision of everything downstream.
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_bn_reduce16(const double* __restrict__ partial, double* __restrict__ stats, int nsplit,
+                                                      int C, double count, float* __restrict__ o0, float* __restrict__ o1,
+                                                      float* __restrict__ rm, float* __restrict__ rv, float momentum, float eps,
+                                                      long long* __restrict__ nbt) {
+  __shared__ double sm[2][64][16];
+  const int t = threadIdx.x, cl = t & 15, ph = t >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const int cc = c < C ? c : C - 1;
+  double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+  constexpr int U = 8;
+  for (int kb = ph; kb < nsplit; kb += 64 * U) {
+    double va[U], vb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = kb + 64 * u, kc = k < nsplit ? k : nsplit - 1;   // (clamped unconditional loads + select: see k_bn_colsum)
+      va[u] = partial[(size_t)kc * 2 * C + cc];
+      vb[u] = partial[(size_t)kc * 2 * C + C + cc];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (kb + 64 * u >= nsplit) va[u] = vb[u] = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; u += 2) {
+      a0 += va[u];
+      b0 += vb[u];
+      a1 += va[u + 1];
+      b1 += vb[u + 1];
+    }
+  }
+  sm[0][ph][cl] = a0 + a1;
+  sm[1][ph][cl] = b0 + b1;
+  __syncthreads();
+  double s0 = 0.0, s1 = 0.0;
+  if (ph < 8) {   // phases 8 ph .. 8 ph + 7
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s0 += sm[0][ph * 8 + j][cl];
+      s1 += sm[1][ph * 8 + j][cl];
+    }
+  }
+  __syncthreads();
+  if (ph < 8) {
+    sm[0][ph][cl] = s0;
+    sm[1][ph][cl] = s1;
+  }
+  __syncthreads();
+  if (ph != 0 || c >= C) return;
+  s0 = s1 = 0.0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s0 += sm[0][j][cl];
+    s1 += sm[1][j][cl];
+  }
+  stats[c] = s0;
+  stats[C + c] = s1;
+  if (MODE == 0) {
+    if (c == 0 && nbt) *nbt += 1;
+    const double mean = s0 / count;
+    double var = s1 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    o0[c] = (float)mean;
+    o1[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rm) rm[c] = (1.f - momentum) * rm[c] + momentum * (float)mean;
+    if (rv) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unbiased;
+    }
+  } else {
+    if (o1) o1[c] += (float)s0;  // dbeta
+    if (o0) o0[c] += (float)s1;  // dgamma
+  }
+}
+
 __global__ __launch_bounds__(256) void k_bn_finalize(const double* __restrict__ stats, double count,
                                                      float* __restrict__ save_mean, float* __restrict__ save_rstd,
                                                      float* __restrict__ rm, float* __restrict__ rv, float momentum,
@@ -537,7 +616,14 @@ static int bn_colsum(int mode, const float* a, const float* x, const float* mean
   else
     hipLaunchKernelGGL((k_bn_colsum<1, true>), grid, dim3(256), 0, s, a, x, mean, rstd, (double*)ws, rows, C, rps);
   const bool wide = splits > 64;
-  if (fu.mode == 0 && wide)
+  const bool r16 = wide && env_int("SRK_BN_RED16", 1) != 0;
+  if (fu.mode == 0 && r16)
+    hipLaunchKernelGGL((k_bn_reduce16<0>), dim3(cdiv(C, 16)), dim3(1024), 0, s, (const double*)ws, out, splits, C, fu.count,
+                       fu.o0, fu.o1, fu.rm, fu.rv, fu.momentum, fu.eps, fu.nbt);
+  else if (fu.mode == 1 && r16)
+    hipLaunchKernelGGL((k_bn_reduce16<1>), dim3(cdiv(C, 16)), dim3(1024), 0, s, (const double*)ws, out, splits, C, 0.0, fu.o0,
+                       fu.o1, nullptr, nullptr, 0.f, 0.f, nullptr);
+  else if (fu.mode == 0 && wide)
     hipLaunchKernelGGL((k_bn_reduce_fused<0, 16>), dim3(cdiv(C, 64)), dim3(1024), 0, s, (const double*)ws, out, splits, C,
                        fu.count, fu.o0, fu.o1, fu.rm, fu.rv, fu.momentum, fu.eps, fu.nbt);
   else if (fu.mode == 0)
@@ -882,7 +968,10 @@ extern "C" int srk_bn_finalize_partials(const double* partials, int splits, doub
                                         float momentum, float eps, int64_t* num_batches_tracked, void* stream) {
   SRK_REQUIRE(partials && stats && save_mean && save_rstd && splits > 0 && rows > 0 && C > 0, "bn_finalize_partials: bad args");
   hipStream_t s = (hipStream_t)stream;
-  if (splits > 64)
+  if (splits > 64 && env_int("SRK_BN_RED16", 1) != 0)
+    hipLaunchKernelGGL((k_bn_reduce16<0>), dim3(cdiv(C, 16)), dim3(1024), 0, s, partials, stats, splits, C, (double)rows,
+                       save_mean, save_rstd, running_mean, running_var, momentum, eps, (long long*)num_batches_tracked);
+  else if (splits > 64)
     hipLaunchKernelGGL((k_bn_reduce_fused<0, 16>), dim3(cdiv(C, 64)), dim3(1024), 0, s, partials, stats, splits, C,
                        (double)rows, save_mean, save_rstd, running_mean, running_var, momentum, eps,
                        (long long*)num_batches_tracked);

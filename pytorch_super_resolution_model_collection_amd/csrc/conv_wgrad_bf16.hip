@@ -2024,6 +2024,7 @@ template <bool GRP>
 static void wt_launch(const WgBfParams& P, const typename WgGroupArg<GRP>::type& GR, dim3 grid, size_t lds, hipStream_t s) {
   static LdsLimit lim;
   lim.ensure(reinterpret_cast<const void*>(&k_wgrad_tr<GRP>), lds);
+  note_kernel("k_wgrad_tr<%s>", GRP ? "grouped" : "single");
   hipLaunchKernelGGL((k_wgrad_tr<GRP>), grid, dim3(768), lds, s, P, GR);
 }
 
@@ -2042,6 +2043,7 @@ static bool wb_k33(const WgBfParams& P) {
 
 template <int CIT, int COW, int NTW>
 static void wb_launch(const WgBfParams& P, dim3 grid, size_t lds, bool spec, hipStream_t s) {
+  note_kernel("k_wgrad_bf<%d,%d,%d,%s>", CIT, COW, NTW, spec ? "spec" : "tile");
   if (spec && wb_k33(P)) {
     static LdsLimit lim3;
     lim3.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, true, false, true>), 2 * lds);
@@ -2061,6 +2063,7 @@ static void wb_launch(const WgBfParams& P, dim3 grid, size_t lds, bool spec, hip
 
 template <int CIT, int COW, int NTW>
 static void wb_launch_grouped(const WgBfParams& P, const WgGroup& GR, dim3 grid, size_t lds, bool spec, hipStream_t s) {
+  note_kernel("k_wgrad_bf<%d,%d,%d,%s,grouped>", CIT, COW, NTW, spec ? "spec" : "tile");
   if (spec && wb_k33(P)) {
     static LdsLimit lim3;
     lim3.ensure(reinterpret_cast<const void*>(&k_wgrad_bf<CIT, COW, NTW, true, true, true>), 2 * lds);

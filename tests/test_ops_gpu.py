@@ -892,6 +892,73 @@ def test_wgrad_grouped(gpu, n, N, cin, cout, k, p, H, W, act, bias):
         assert rc == -1 and b"same dw" in lib.srk_last_error_string()
 
 
+@pytest.mark.parametrize("N,cin,cout,H,W,p,act,bias,ps_r,n", [
+    (32, 64, 64, 32, 32, 1, "relu", True, 0, 1),     # EDSR body layer: 4 x 32 tiles, ring of halo rows, ReLU mask
+    (16, 64, 64, 41, 41, 1, None, False, 0, 1),      # VDSR body layer: 2 x 48 tiles, ragged right / bottom edges, K steps across rows
+    (8, 64, 256, 40, 36, 1, None, True, 2, 1),       # EDSR up-sampler: dY handed over pixel-shuffled, four 64-channel blocks
+    (64, 32, 128, 23, 29, 0, "lrelu", True, 0, 1),   # one input-channel chunk, no padding, LeakyReLU mask, ragged everything
+    (4, 128, 64, 64, 64, 1, None, True, 0, 1),       # four input-channel chunks
+    (16, 64, 64, 32, 32, 1, "relu", True, 0, 3),     # grouped launch (three layers, the middle one unmasked)
+])
+def test_wgrad_transpose_read_kernel(gpu, monkeypatch, N, cin, cout, H, W, p, act, bias, ps_r, n):
+    """k_wgrad_tr (pixel-major LDS image, ds_read_b64_tr_b16 fragments) against k_wgrad_bf (SRK_WGRAD_TR=0) and float64:
+    the weight gradients of the two kernels are BIT-EQUAL (same products, same summation order per accumulator and slab),
+    the bias gradients agree to fp32 summation noise; beta = 1 accumulates onto what the tensors held."""
+    pkg = _pkg()
+    lib, L = pkg._lib.load(), pkg._lib
+    k = 3
+    OH = lib.srk_conv_out_dim(H, k, 1, p, 0, 0)
+    OW = lib.srk_conv_out_dim(W, k, 1, p, 0, 0)
+    d = L.ConvDesc(N, H, W, cin, OH, OW, cout, k, k, 1, p, 0, 0, 0, 0, ps_r)
+    st = L.stream_ptr()
+    slope = 0.2 if act == "lrelu" else 0.0
+    cl = lambda t: t.to(gpu).contiguous(memory_format=torch.channels_last)
+    xs, dys, ys, refs = [], [], [], []
+    for l in range(n):
+        x = fill.randn((N, cin, H, W), 1300 + l)
+        dy = fill.randn((N, cout, OH, OW), 1350 + l)
+        y = fill.randn((N, cout, OH, OW), 1390 + l) if (act and l != 1) else None
+        dym = dy.double()
+        if y is not None:
+            dym = torch.where(y > 0, dym, dym * slope)
+        wr = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+        br = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+        torch.nn.functional.conv2d(x.double(), wr, br, 1, p).backward(dym)
+        refs.append((wr.grad, br.grad))
+        if ps_r > 1:   # the gradient as the pixel-shuffle's input gradient would arrive: [N, C / r^2, OH r, OW r]
+            dy = torch.nn.functional.pixel_shuffle(dy, ps_r)
+        xs.append(cl(x)); dys.append(cl(dy)); ys.append(None if y is None else cl(y))
+    vp = ctypes.c_void_p
+    arr = lambda ts: (vp * n)(*[None if t is None else t.data_ptr() for t in ts])
+    out = {}
+    for tag in ("1", "0"):
+        monkeypatch.setenv("SRK_WGRAD_TR", tag)
+        dws = [torch.full((cout, cin, k, k), 0.5, device=gpu) for _ in range(n)]
+        dbs = [torch.full((cout,), -0.25, device=gpu) if bias else None for _ in range(n)]
+        if n == 1:
+            ws = torch.empty(int(lib.srk_conv2d_backward_weight_workspace_bytes(ctypes.byref(d))) + 16, dtype=torch.uint8, device=gpu)
+            m = L.BwdMask(None if ys[0] is None else ys[0].data_ptr(), slope)
+            L.check(lib.srk_conv2d_backward_weight(ctypes.byref(d), L.ptr(xs[0]), L.ptr(dys[0]),
+                                                   ctypes.byref(m) if ys[0] is not None else None, L.ptr(dws[0]), L.ptr(dbs[0]), 1.0,
+                                                   L.ptr(ws), ws.numel(), st), "wgrad")
+        else:
+            masks = (L.BwdMask * n)(*[L.BwdMask(None if y is None else y.data_ptr(), slope) for y in ys])
+            ws = torch.empty(int(lib.srk_conv2d_backward_weight_grouped_workspace_bytes(ctypes.byref(d), n)) + 16, dtype=torch.uint8,
+                             device=gpu)
+            L.check(lib.srk_conv2d_backward_weight_grouped(ctypes.byref(d), n, arr(xs), arr(dys), masks, arr(dws),
+                                                           arr(dbs) if bias else None, 1.0, L.ptr(ws), ws.numel(), st), "grouped")
+        name = lib.srk_last_kernel_name().decode()
+        assert name.startswith("k_wgrad_tr<" if tag == "1" else "k_wgrad_bf<2,2,2,spec"), name
+        torch.cuda.synchronize()
+        out[tag] = (dws, dbs)
+    for l in range(n):
+        assert torch.equal(out["1"][0][l], out["0"][0][l]), l
+        assert rel_err(out["1"][0][l] - 0.5, refs[l][0].float()) < 1e-4, l
+        if bias:
+            assert rel_err(out["1"][1][l], out["0"][1][l]) < 2e-6, l
+            assert rel_err(out["1"][1][l] + 0.25, refs[l][1].float()) < 2e-5, l
+
+
 @pytest.mark.parametrize("scale_x,scale_w", [(1.0, 0.05), (1e-5, 40.0), (3e4, 1e-6), (1e-30, 1e20)])
 def test_f16x3_is_fp32_faithful_at_any_operand_scale(gpu, scale_x, scale_w):
     """SRK_ALGO_MFMA_F16X3 (two fp16 planes of the operands scaled by exact powers of two from their running maxima):
