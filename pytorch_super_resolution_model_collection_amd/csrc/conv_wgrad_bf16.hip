@@ -66,6 +66,13 @@ __device__ __forceinline__ void wb_item(int tid, int& q, int& pp0) {
 #ifndef WB_PRIO
 #define WB_PRIO 0
 #endif
+// ablation bits of k_wgrad_tr's inner loop (16 no fragment reads, 64 no column shifts): compile-time only (-DSRK_KDBG_CONST=..),
+// also in the experiments build -- a run-time test inside the phases changes their schedule (K step 1450 -> 3200 clocks)
+#ifdef SRK_KDBG_CONST
+#define WT_ABL (SRK_KDBG_CONST)
+#else
+#define WT_ABL 0
+#endif
 #ifndef WT_SGB
 #define WT_SGB 1
 #endif
@@ -1045,11 +1052,16 @@ __device__ __forceinline__ void wt_split8(const f32x4& v0, const f32x4& v1, uint
   lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-template <bool GRP>
-__global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGroupArg<GRP>::type GR) {
-  constexpr int CIB = 32, COB = 64, NWV = 4, WTHR = 64 * NWV, NST = WB_SST, NTHR = WTHR + NST, NTW = 2, PIT = 1024 / NST;
+// NTW = 2: four working waves (2 ci tiles x 2 pairs of co tiles, one per SIMD beside two stager waves; 168 VGPRs).
+// NTW = 1: EIGHT working waves (2 x 4 single co tiles, two per SIMD: one wave's transpose reads are issued while the other's
+// MFMAs run -- a lone working wave pays ~16 clocks of matrix pipe per read, section 12.3 of DESIGN.md; 128 VGPRs).
+template <bool GRP, int NTW>
+__global__ __launch_bounds__(NTW == 2 ? 768 : 1024, NTW == 2 ? 3 : 4) void k_wgrad_tr(WgBfParams P,
+                                                                                       typename WgGroupArg<GRP>::type GR) {
+  constexpr int CIB = 32, COB = 64, NWV = 8 / NTW, WTHR = 64 * NWV, NST = WB_SST, NTHR = WTHR + NST, PIT = 1024 / NST;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
   __shared__ unsigned oct_tw[WB_MAXOCT];
+  const long long clk_begin = WB_CLK();
   const int tid0 = threadIdx.x, lane = tid0 & 63, wave = tid0 >> 6;
   const bool worker = wave < NWV;
   const int tid = worker ? tid0 : tid0 - WTHR;
@@ -1269,11 +1281,11 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
       for (int it = 0; it < ntb; ++it) __syncthreads();
     }
     if (want_bias) {   // column sums of dY: the 64 staging threads of one 8-channel group (tid & 7) add up in LDS
-      float* bred = reinterpret_cast<float*>(smem8);   // [NST][8], the X ring is no longer read (barrier above)
+      float* bred = reinterpret_cast<float*>(smem8);   // [NST][8 + 1 pad], the X ring is no longer read (barrier above)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        bred[tid * 8 + e] = bsum0[e];
-        bred[tid * 8 + 4 + e] = bsum1[e];
+        bred[tid * 9 + e] = bsum0[e];
+        bred[tid * 9 + 4 + e] = bsum1[e];
       }
     }
     __syncthreads();
@@ -1281,13 +1293,13 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
       const float* bred = reinterpret_cast<const float*>(smem8);
       const int g = tid >> 3, e = tid & 7;
       float s = 0.f;
-      for (int t = g; t < NST; t += 8) s += bred[t * 8 + e];
+      for (int t = g; t < NST; t += 8) s += bred[t * 9 + e];
       P.bias_partial[(size_t)bxl * P.Cout + cob + tid] = s;
     }
     return;
   }
 
-  // -------------------------------------------------------------------- workers (4 waves: cit x cow)
+  // -------------------------------------------------------------------- workers (cit x cow)
   const int r16 = lane & 15, kq = lane >> 4;
   const int cit = wave & 1, cow = wave >> 1;
   f32x4 acc[3][3][NTW];
@@ -1306,7 +1318,7 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
   typedef unsigned TB;   // an octet's table word
   const unsigned lane_x = (unsigned)((r16 >> 2) * 64 + (r16 & 3) * 8);
   const int fl = ((r16 >> 3) & 1) | ((kq & 1) << 1);
-  const unsigned lane_y0 = (unsigned)((r16 >> 2) * 128 + (r16 & 3) * 8 + (((cow * 2 + 0) ^ fl) << 5));
+  const unsigned lane_y0 = (unsigned)((r16 >> 2) * 128 + (r16 & 3) * 8 + (((cow * NTW) ^ fl) << 5));
   const int nks_run = (SRK_KDBG(P.dbg) & 4) ? 0 : P.nks;
   const int last = nks_run - 1;
   auto tab = [&](int ks) -> TB { return oct_tw[(ks < last ? ks : last) * 4 + kq]; };
@@ -1325,7 +1337,7 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
   };
   auto yaddr = [&](const TB& t) -> unsigned { return ysel + ((t & 0xff00u) << 2) + lane_y0; };
   auto xissue = [&](XF& f, unsigned a) {
-    if (SRK_KDBG(P.dbg) & 16) return;   // ablation: no fragment reads (the MFMAs run on whatever the registers hold)
+    if (WT_ABL & 16) return;   // ablation: no fragment reads (the MFMAs run on whatever the registers hold)
     const unsigned b = (a + 512u) ^ 32u;   // pixels 8 .. 11: the next halo octet (its channel halves are swapped)
     const uint2 h0 = tr(a), h1 = tr(a + 256u), l0 = tr(a + XPL), l1 = tr(a + XPL + 256u);
     const uint2 h2 = tr(b), l2 = tr(b + XPL);
@@ -1337,14 +1349,16 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
     f.xl = l2.y;
   };
   auto yissue = [&](uint4 (&bh)[NTW], uint4 (&bl)[NTW], unsigned a0) {
-    if (SRK_KDBG(P.dbg) & 16) return;
-    const unsigned a1 = a0 ^ 32u;   // the wave's second 16-channel tile: lane_y1 = lane_y0 ^ 32
+    if (WT_ABL & 16) return;
     const uint2 p0 = tr(a0), p1 = tr(a0 + 512u), q0 = tr(a0 + YPL), q1 = tr(a0 + YPL + 512u);
-    const uint2 p2 = tr(a1), p3 = tr(a1 + 512u), q2 = tr(a1 + YPL), q3 = tr(a1 + YPL + 512u);
     bh[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
     bl[0] = make_uint4(q0.x, q0.y, q1.x, q1.y);
-    bh[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
-    bl[1] = make_uint4(q2.x, q2.y, q3.x, q3.y);
+    if constexpr (NTW == 2) {
+      const unsigned a1 = a0 ^ 32u;   // the wave's second 16-channel tile: lane_y1 = lane_y0 ^ 32
+      const uint2 p2 = tr(a1), p3 = tr(a1 + 512u), q2 = tr(a1 + YPL), q3 = tr(a1 + YPL + 512u);
+      bh[NTW - 1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
+      bl[NTW - 1] = make_uint4(q2.x, q2.y, q3.x, q3.y);
+    }
   };
   auto rowmm = [&](const XF& f, const uint4 (&bh)[NTW], const uint4 (&bl)[NTW], f32x4 (&a)[3][NTW]) {
     uint4 ah[3], al[3];
@@ -1356,7 +1370,7 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
                        __builtin_amdgcn_alignbit(f.l.w, f.l.z, 16), __builtin_amdgcn_alignbit(f.el, f.l.w, 16));
     ah[2] = make_uint4(f.h.y, f.h.z, f.h.w, f.eh);
     al[2] = make_uint4(f.l.y, f.l.z, f.l.w, f.el);
-    if (SRK_KDBG(P.dbg) & 64) {   // ablation: no column shifts
+    if (WT_ABL & 64) {   // ablation: no column shifts
       ah[1] = ah[2] = ah[0];
       al[1] = al[2] = al[0];
     }
@@ -1385,7 +1399,7 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
   // the address arithmetic settle into the gaps the compiler finds for them).  The first reads are the ones the next phase's
   // first MFMAs need (lo halves, then dY).
   auto xread1 = [&](XF& f, unsigned a, int k) {
-    if (SRK_KDBG(P.dbg) & 16) return;
+    if (WT_ABL & 16) return;
     const unsigned b = (a + 512u) ^ 32u;
     if (k == 0) { const uint2 t = tr(a + XPL); f.l.x = t.x; f.l.y = t.y; }
     if (k == 1) { const uint2 t = tr(a + XPL + 256u); f.l.z = t.x; f.l.w = t.y; }
@@ -1395,9 +1409,9 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
     if (k == 5) { const uint2 t = tr(b); f.eh = t.x; f.xh = t.y; }
   };
   auto yread1 = [&](uint4 (&bh)[NTW], uint4 (&bl)[NTW], unsigned a0, int k) {
-    if (SRK_KDBG(P.dbg) & 16) return;
+    if (WT_ABL & 16) return;
     const unsigned a = (k & 4) ? (a0 ^ 32u) : a0;
-    const int nt = k >> 2;
+    const int nt = (k >> 2) < NTW ? (k >> 2) : NTW - 1;
     if ((k & 3) == 0) { const uint2 t = tr(a); bh[nt].x = t.x; bh[nt].y = t.y; }
     if ((k & 3) == 1) { const uint2 t = tr(a + 512u); bh[nt].z = t.x; bh[nt].w = t.y; }
     if ((k & 3) == 2) { const uint2 t = tr(a + YPL); bl[nt].x = t.x; bl[nt].y = t.y; }
@@ -1418,7 +1432,7 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
                        __builtin_amdgcn_alignbit(f.l.w, f.l.z, 16), __builtin_amdgcn_alignbit(f.el, f.l.w, 16));
     ah[2] = make_uint4(f.h.y, f.h.z, f.h.w, f.eh);
     al[2] = make_uint4(f.l.y, f.l.z, f.l.w, f.el);
-    if (SRK_KDBG(P.dbg) & 64) {
+    if (WT_ABL & 64) {
       ah[1] = ah[2] = ah[0];
       al[1] = al[2] = al[0];
     }
@@ -1429,7 +1443,7 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
   auto mm_region = [&](int nreads) {
     if (WT_SGB == 2) {
 #pragma unroll
-      for (int q = 0; q < 18; ++q) {
+      for (int q = 0; q < 9 * NTW; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         if (q < nreads) {
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -1440,7 +1454,7 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
       }
     } else if (WT_SGB) {
 #pragma unroll
-      for (int q = 0; q < 18; ++q) {
+      for (int q = 0; q < 9 * NTW; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
       }
@@ -1453,7 +1467,7 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
   auto step = [&](const XF& x0, const uint4 (&yh)[NTW], const uint4 (&yl)[NTW], XF& xn, uint4 (&nh)[NTW], uint4 (&nl)[NTW],
                   const TB& tc, const TB& tn) {
     XF x1 = {}, x2 = {};
-    if (WT_SGB == 3) {
+    if (WT_SGB == 3 && NTW == 2) {
       uint4 ah[3], al[3];
       {
         const unsigned a = nxa;
@@ -1518,6 +1532,8 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
   };
   if (WB_PRIO) __builtin_amdgcn_s_setprio(WB_PRIO);
   __syncthreads();   // tile 0 staged
+  const long long clk_first = WB_CLK();   // tile 0 staged: everything before is launch + first-tile latency
+  long long clk_loops = clk_first;
   if (nks_run > 0) {
     const TB tb0 = tab(0), tb1 = tab(1);   // the first two K steps' table words do not depend on the tile
     int wprev = P.HH;
@@ -1550,10 +1566,12 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
       wk_loop += k2 - k0;
       wk_wait += WB_CLK() - k2;
     }
+    clk_loops = WB_CLK();
 #ifdef SRK_EXPERIMENTS
     if (P.prof && tid0 == 0) {
       long long* pr = P.prof + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + 8;
       pr[0] = wk_loop; pr[1] = wk_wait; pr[2] = ntb; pr[3] = (long long)ntb * P.nks; pr[4] = wk_pro;
+      pr[5] = clk_first - clk_begin;   // launch of the block .. its first tile is staged
     }
 #endif
     (void)wk_loop; (void)wk_wait; (void)wk_pro;
@@ -1562,7 +1580,7 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
   }
   __syncthreads();   // (the stagers' bias reduction)
   // partial slab ws[g][t][ci][co]; C/D layout: col = lane & 15 (ci), row = (lane >> 4) * 4 + reg (co)
-  float* slab = P.ws + (size_t)bxl * 9 * P.Cin * P.Cout + (size_t)(cib + cit * 16 + r16) * P.Cout + cob + cow * 32 + kq * 4;
+  float* slab = P.ws + (size_t)bxl * 9 * P.Cin * P.Cout + (size_t)(cib + cit * 16 + r16) * P.Cout + cob + cow * (NTW * 16) + kq * 4;
 #pragma unroll
   for (int u = 0; u < 3; ++u)
 #pragma unroll
@@ -1572,6 +1590,15 @@ __global__ __launch_bounds__(768, 3) void k_wgrad_tr(WgBfParams P, typename WgGr
       for (int nt = 0; nt < NTW; ++nt)
         *reinterpret_cast<f32x4*>(slab + (size_t)t * P.Cin * P.Cout + nt * 16) = acc[u][v][nt];
     }
+#ifdef SRK_EXPERIMENTS
+  if (P.prof && tid0 == 0) {
+    __builtin_amdgcn_s_waitcnt(0);   // (vmcnt(0): the slab stores have left)
+    long long* pr = P.prof + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + 8;
+    pr[6] = WB_CLK() - clk_loops;   // last tile done .. slab stored
+    pr[7] = WB_CLK() - clk_begin;   // the block's life
+  }
+#endif
+  (void)clk_begin; (void)clk_loops;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2013,7 +2040,7 @@ static bool wt_setup(WgBfParams& P, const srk_conv_desc& d, const WbPlan& pl, bo
   const int XP = pl.TW + 4;   // halo columns 0 .. TW + 1 are staged; the third transpose read of a row touches TW + 3
   const size_t XPL = (size_t)2 * pl.HH * XP * 64, YPL = (size_t)(pl.TH * pl.TW + 8) * 128;
   const size_t bytes = 2 * XPL + 4 * YPL;
-  if (bytes + 1024 > 160 * 1024 || 2 * XPL < (size_t)WB_SST * 8 * 4 || XPL + 512 >= 65536 || YPL + 1024 >= 65536) return false;
+  if (bytes + 1024 > 160 * 1024 || 2 * XPL < (size_t)WB_SST * 9 * 4 || XPL + 512 >= 65536 || YPL + 1024 >= 65536) return false;
   P.XP = XP;
   P.XPL = (int)XPL;
   P.YPL = (int)YPL;
@@ -2022,10 +2049,17 @@ static bool wt_setup(WgBfParams& P, const srk_conv_desc& d, const WbPlan& pl, bo
 }
 template <bool GRP>
 static void wt_launch(const WgBfParams& P, const typename WgGroupArg<GRP>::type& GR, dim3 grid, size_t lds, hipStream_t s) {
+  if (env_int("SRK_WGRAD_TR_W8", 0)) {   // eight working waves (two per SIMD)
+    static LdsLimit lim8;
+    lim8.ensure(reinterpret_cast<const void*>(&k_wgrad_tr<GRP, 1>), lds);
+    note_kernel("k_wgrad_tr<%s,w8>", GRP ? "grouped" : "single");
+    hipLaunchKernelGGL((k_wgrad_tr<GRP, 1>), grid, dim3(1024), lds, s, P, GR);
+    return;
+  }
   static LdsLimit lim;
-  lim.ensure(reinterpret_cast<const void*>(&k_wgrad_tr<GRP>), lds);
+  lim.ensure(reinterpret_cast<const void*>(&k_wgrad_tr<GRP, 2>), lds);
   note_kernel("k_wgrad_tr<%s>", GRP ? "grouped" : "single");
-  hipLaunchKernelGGL((k_wgrad_tr<GRP>), grid, dim3(768), lds, s, P, GR);
+  hipLaunchKernelGGL((k_wgrad_tr<GRP, 2>), grid, dim3(768), lds, s, P, GR);
 }
 
 bool conv_wgrad_bf_supported(const srk_conv_desc& d) { return wb_plan(d).ok; }

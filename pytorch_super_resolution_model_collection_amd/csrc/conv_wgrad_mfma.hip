@@ -326,21 +326,21 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_smallcin(WgradParams P) {
 // `blk`: block index inside this reduction (blockIdx.x of a launch of its own).  WIDE: the summation order of
 // k_wgrad_reduce (4 accumulators, slab stride 16); !WIDE: that of the grouped reduce of conv_wgrad_bf16.hip (2
 // accumulators, stride 8) -- k_wgrad_reduce_multi reproduces either bit for bit.
-constexpr int kRedEPB = 256;   // slab elements per block: four consecutive ones (16 bytes) per lane
 template <bool WIDE>
-__device__ __forceinline__ void wgrad_reduce_body(float (&sm)[4][kRedEPB], int blk, const float* __restrict__ ws,
+__device__ __forceinline__ void wgrad_reduce_body(float (&sm)[4][64], int blk, const float* __restrict__ ws,
                                                   float* __restrict__ dw, int G, int Cout, int Cin, int KH, int KW,
                                                   int transposed, float beta, const float* __restrict__ bias_partial,
                                                   float* __restrict__ db, int bias_cout, int out_ps_r) {
-  // 256 consecutive slab elements per block, four per lane as one 16-byte load (round 5: 4-byte loads of 64 elements moved
-  // 1.3 - 2.3 TB/s out of the Infinity Cache -- 62 us of reduce launches in a 1.05 ms shard step); the 4 waves each sum a
-  // quarter of the G slabs with 4 (WIDE) / 2 independent accumulators per element, combined through LDS in a fixed order:
-  // every element is summed in exactly the order of the 64-element kernel this replaces.  The blocks past the last slab
-  // element finish the bias gradient the same way (bias_partial[G][bias_cout] -> db), saving a launch per layer.
-  typedef float r4 __attribute__((ext_vector_type(4)));
+  // (round 5: 256 elements per block with one 16-byte load per lane -- what the grouped reduce of conv_wgrad_bf16.hip now does:
+  //  14.2 -> 11.3 us over 21 layers -- was measured SLOWER here: a single layer's reduce is a few hundred blocks at most, and
+  //  four times fewer of them leave CUs idle: VDSR layer 7.0 -> 9.1 us, SRGAN-D 512 -> 512 layer 47 -> 56 us per call.)
+  // 64 consecutive slab elements per block (coalesced 256-byte rows); the 4 waves each sum a quarter
+  // of the G slabs with 4 independent accumulators (16 loads in flight per lane), combined through
+  // LDS in a fixed order => deterministic.  The blocks past the last slab element finish the bias
+  // gradient the same way (bias_partial[G][bias_cout] -> db), saving a launch per layer.
   const int elems = KH * KW * Cin * Cout;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int nwb = (elems + kRedEPB - 1) / kRedEPB;
+  const int nwb = (elems + 63) / 64;
   if (blk >= nwb) {
     if (!db || !bias_partial) return;
     const int co = (blk - nwb) * 64 + lane;
@@ -376,41 +376,29 @@ __device__ __forceinline__ void wgrad_reduce_body(float (&sm)[4][kRedEPB], int b
     }
     return;
   }
-  const int e0 = blk * kRedEPB + lane * 4;
-  const bool vec = (elems & 3) == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0;
-  auto load4 = [&](int g) -> r4 {
-    const float* p = ws + (size_t)g * elems + e0;
-    if (vec) return *reinterpret_cast<const r4*>(p);
-    r4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (e0 + k < elems) v[k] = p[k];
-    return v;
-  };
-  r4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-  if (e0 < elems) {
+  const int e = blk * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < elems) {
     int g = w;
     if (WIDE) {
       for (; g + 12 < G; g += 16) {
-        s0 += load4(g);
-        s1 += load4(g + 4);
-        s2 += load4(g + 8);
-        s3 += load4(g + 12);
+        s0 += ws[(size_t)g * elems + e];
+        s1 += ws[(size_t)(g + 4) * elems + e];
+        s2 += ws[(size_t)(g + 8) * elems + e];
+        s3 += ws[(size_t)(g + 12) * elems + e];
       }
     } else {
       for (; g + 4 < G; g += 8) {
-        s0 += load4(g);
-        s1 += load4(g + 4);
+        s0 += ws[(size_t)g * elems + e];
+        s1 += ws[(size_t)(g + 4) * elems + e];
       }
     }
-    for (; g < G; g += 4) s0 += load4(g);
+    for (; g < G; g += 4) s0 += ws[(size_t)g * elems + e];
   }
-  const r4 sw = WIDE ? (s0 + s1) + (s2 + s3) : s0 + s1;
-  *reinterpret_cast<r4*>(&sm[w][lane * 4]) = sw;
+  sm[w][lane] = WIDE ? (s0 + s1) + (s2 + s3) : s0 + s1;
   __syncthreads();
-  const int t = threadIdx.x, e = blk * kRedEPB + t;
-  if (e >= elems) return;
-  const float v = (sm[0][t] + sm[1][t]) + (sm[2][t] + sm[3][t]);
+  if (w != 0 || e >= elems) return;
+  const float v = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
   int co = e % Cout;
   if (out_ps_r > 1) {
     const int C = Cout / (out_ps_r * out_ps_r);
@@ -432,7 +420,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
                                                       int Cout, int Cin, int KH, int KW, int transposed, float beta,
                                                       const float* __restrict__ bias_partial, float* __restrict__ db,
                                                       int bias_cout, int out_ps_r) {
-  __shared__ __attribute__((aligned(16))) float sm[4][kRedEPB];
+  __shared__ float sm[4][64];
   wgrad_reduce_body<true>(sm, (int)blockIdx.x, ws, dw, G, Cout, Cin, KH, KW, transposed, beta, bias_partial, db, bias_cout,
                           out_ps_r);
 }
@@ -461,7 +449,7 @@ struct RedJobs {
 };
 
 __global__ __launch_bounds__(256) void k_wgrad_reduce_multi(RedJobs J) {
-  __shared__ __attribute__((aligned(16))) float sm[4][kRedEPB];
+  __shared__ float sm[4][64];
   int k = 0;
   for (int i = 1; i < J.n; ++i)
     if ((int)blockIdx.x >= J.j[i].blk0) k = i;
@@ -514,7 +502,7 @@ int wgrad_reduce_submit(bool wide, const float* ws, float* dw, int G, int Cout, 
                     (size_t)G * elems * sizeof(float) <= ((size_t)6 << 20);
   if (!g_red_defer || !fits) {
     if (!wide) return -100;   // (the grouped caller launches its own kernel)
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(elems, kRedEPB) + bias_blocks), dim3(256), 0, s, ws, dw, G, Cout, Cin, KH, KW,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(elems, 64) + bias_blocks), dim3(256), 0, s, ws, dw, G, Cout, Cin, KH, KW,
                        transposed, beta, bias_partial, db, bias_cout, out_ps_r);
     return check_launch("conv_wgrad_reduce");
   }
@@ -532,7 +520,7 @@ int wgrad_reduce_submit(bool wide, const float* ws, float* dw, int G, int Cout, 
   r.KH = (unsigned char)KH; r.KW = (unsigned char)KW; r.transposed = (unsigned char)transposed;
   r.out_ps_r = (unsigned char)out_ps_r; r.wide = wide ? 1 : 0; r.pad_ = 0;
   r.beta = beta;
-  g_red.blocks += cdiv(elems, kRedEPB) + bias_blocks;
+  g_red.blocks += cdiv(elems, 64) + bias_blocks;
   g_red_bytes += (size_t)G * elems * sizeof(float);
   return SRK_OK;
 }

@@ -7,7 +7,9 @@ import pytorch_super_resolution_model_collection_amd as pkg
 from pytorch_super_resolution_model_collection_amd._lib import ConvDesc, check, load, ptr, stream_ptr
 lib = load()
 SHAPES = {"edsr128": (128, 64, 32, 32, 64, 3, 1), "vdsr": (256, 64, 41, 41, 64, 3, 1), "edsr16": (16, 64, 32, 32, 64, 3, 1),
-          "edsrtail128": (128, 64, 128, 128, 3, 3, 1), "edsrtail16": (16, 64, 128, 128, 3, 3, 1), "vdsrtail": (256, 64, 41, 41, 3, 3, 1)}
+          "edsrtail128": (128, 64, 128, 128, 3, 3, 1), "edsrtail16": (16, 64, 128, 128, 3, 3, 1), "vdsrtail": (256, 64, 41, 41, 3, 3, 1),
+          # SRGAN discriminator class: few pixels, many channels (the slab reduce and its scattered dw stores dominate)
+          "d256": (16, 128, 32, 32, 256, 3, 1), "d512": (16, 256, 16, 16, 512, 3, 1), "d512b": (16, 512, 8, 8, 512, 3, 1)}
 dev = torch.device("cuda:0")
 for name in (sys.argv[1:] or list(SHAPES)):
     N, cin, H, W, cout, k, pad = SHAPES[name]

@@ -53,3 +53,6 @@ for name, n, h in (("VDSR body layer 256 x 41 x 41", 256, 41), ("EDSR body layer
     if float(t[:, 12].sum()) > 0:   # k_wgrad_tr: the part of the K loop in front of a tile's first K step (ring bookkeeping, addresses, first reads issued)
         print("   worker wave: per tile %.0f clocks in front of the first K step; (K loop - that) per K step %.0f" % (
             float((t[:, 12] / t[:, 10]).mean()), float(((t[:, 8] - t[:, 12]) / t[:, 11]).mean())))
+        print("   worker wave: block start -> first tile staged %.0f clocks, tile loops %.0f, last tile -> slab stored %.0f, block life %.0f "
+              "(longest block %.0f)" % (float(t[:, 13].mean()), float((t[:, 8] + t[:, 9]).mean()), float(t[:, 14].mean()),
+                                        float(t[:, 15].mean()), float(t[:, 15].max())))
