@@ -626,6 +626,41 @@ def test_batchnorm_shared_double_call(gpu, ops_kat):
         assert rel_err(bn(x), ops_kat["bn.eval_y"]) < TOL_TIGHT
 
 
+@pytest.mark.parametrize("n,c,h,w", [(16, 64, 32, 32), (3, 72, 40, 37), (8, 512, 8, 8)])
+def test_batchnorm_split_reduction_blocks(gpu, monkeypatch, n, c, h, w):
+    """k_bn_reduce16 (16 channels per block, SRK_BN_RED16 = 1, default) against the 64-channel blocks it replaces and
+    torch's float64 BatchNorm: outputs, input / parameter gradients, running statistics -- more than 64 row splits, channel
+    counts that are not a multiple of 16 included."""
+    pkg = _pkg()
+    x0 = fill.randn((n, c, h, w), 61 + c) * 1.7 + 0.3
+    g0 = fill.randn((n, c, h, w), 62 + c)
+    ref = torch.nn.BatchNorm2d(c).double()
+    ref.weight.data.copy_(fill.randn((c,), 63).double() * 0.2 + 1.0)
+    ref.bias.data.copy_(fill.randn((c,), 64).double() * 0.1)
+    xr = x0.double().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(g0.double())
+    res = {}
+    for tag in ("1", "0"):
+        monkeypatch.setenv("SRK_BN_RED16", tag)
+        bn = pkg.layers.BatchNorm2d(c)
+        bn.weight.data.copy_(ref.weight.data.float())
+        bn.bias.data.copy_(ref.bias.data.float())
+        bn.to(gpu).train()
+        x = x0.to(gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = bn(x)
+        y.backward(g0.to(gpu).contiguous(memory_format=torch.channels_last))
+        res[tag] = (y.detach(), x.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone())
+        assert rel_err(y, yr.detach().float()) < 2e-5
+        assert rel_err(x.grad, xr.grad.float()) < 1e-4
+        assert rel_err(bn.weight.grad, ref.weight.grad.float()) < 1e-4
+        assert rel_err(bn.bias.grad, ref.bias.grad.float()) < 1e-4
+        assert rel_err(bn.running_mean, ref.running_mean.float()) < 1e-5
+        assert rel_err(bn.running_var, ref.running_var.float()) < 1e-5
+    for a, b in zip(res["1"], res["0"]):    # double sums in another order: equal to fp32 rounding of the results
+        assert rel_err(a, b) < 1e-6
+
+
 class _Affine(torch.autograd.Function):
     """y = 0.5*x + 0.1 built from srk_axpby (test helper; keeps the graph on our kernels)."""
 
