@@ -1240,8 +1240,10 @@ __global__ __launch_bounds__(NTW == 2 ? 768 : 1024, NTW == 2 ? 3 : 4) void k_wgr
               v1[e] = pmb[k][e] > 0.f ? v1[e] : v1[e] * Lslope;
             }
           }
-          bsum0 += v0;
-          bsum1 += v1;
+          if (want_bias) {   // (block-uniform: bias-free stacks -- VDSR -- and the second ci half skip the column sums)
+            bsum0 += v0;
+            bsum1 += v1;
+          }
           uint4 hi, lo;
           wt_split8(v0, v1, hi, lo);
           unsigned char* dst = ys + (unsigned)y_lds[k];
