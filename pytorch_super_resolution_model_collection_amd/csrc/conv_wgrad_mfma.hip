@@ -26,6 +26,7 @@ namespace srk {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WG_TP = 64;       // anchor pixels per tile
+constexpr int WG_TP_SC = 192;   // ... of k_wgrad_mfma_smallcin (round 5: a 64-pixel tile was 7 us of barriers and LDS round trips for 16 MFMA quads)
 constexpr int WG_TAPS = 9;      // taps per register pass
 constexpr int WG_MAXBLOCKS = 512;
 
@@ -230,12 +231,57 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WgradParams P) {
 // Wave w owns output-channel tile w of a 64-channel chunk and all MT row tiles.
 // LDS: x halo [pixel][4], dy tile [pixel][PSY].
 // ---------------------------------------------------------------------------------------------
+// stage_region in two halves for a register prefetch: item `it` of the region (what stage_region's thread loop loads in
+// iteration it / 256) as a value, and its LDS store
+__device__ __forceinline__ f32x4 stage_item_load(const float* __restrict__ src, const float* __restrict__ mask, float mslope,
+                                                 int n, int TH_, int TW_, int C, int y0, int x0, int ny, int nx,
+                                                 int rows_total, int cb, int cc, int ccp, int vec, int it) {
+  const int nvec = ccp >> 2;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (it >= rows_total * nvec) return v;
+  const int hp = it / nvec, q = it - hp * nvec;
+  const int hy = hp / nx, hx = hp - hy * nx;
+  const int iy = y0 + hy, ix = x0 + hx;
+  const int ch = q * 4;
+  if (hy < ny && iy >= 0 && iy < TH_ && ix >= 0 && ix < TW_ && ch < cc) {
+    const size_t off = (((size_t)n * TH_ + iy) * TW_ + ix) * C + cb + ch;
+    if (vec && ch + 3 < cc) {
+      v = *reinterpret_cast<const f32x4*>(src + off);
+      if (mask) {
+        const f32x4 m = *reinterpret_cast<const f32x4*>(mask + off);
+        v.x = m.x > 0.f ? v.x : v.x * mslope;
+        v.y = m.y > 0.f ? v.y : v.y * mslope;
+        v.z = m.z > 0.f ? v.z : v.z * mslope;
+        v.w = m.w > 0.f ? v.w : v.w * mslope;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (ch + e < cc) {
+          float t = src[off + e];
+          if (mask) t = mask[off + e] > 0.f ? t : t * mslope;
+          v[e] = t;
+        }
+    }
+  }
+  return v;
+}
+__device__ __forceinline__ void stage_item_store(float* lds, int ps, int rows_total, int ccp, int it, const f32x4& v) {
+  const int nvec = ccp >> 2;
+  if (it >= rows_total * nvec) return;
+  const int hp = it / nvec, q = it - hp * nvec;
+  *reinterpret_cast<f32x4*>(lds + (size_t)hp * ps + q * 4) = v;
+}
+
+#ifndef SCIN_UNROLL
+#define SCIN_UNROLL 1
+#endif
 template <int MT>
 __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_smallcin(WgradParams P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;
   float* ys = smem + P.xs_floats;
-  __shared__ int hoff[WG_TP];
+  __shared__ int hoff[WG_TP_SC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int cob = blockIdx.z * 64;
@@ -246,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_smallcin(WgradParams P) {
   const int npx4 = (npx + 3) & ~3;
   const bool wave_live = wave * 16 < coc;
 
-  for (int p = tid; p < WG_TP; p += 256) {
+  for (int p = tid; p < WG_TP_SC; p += 256) {
     int h = 0;
     if (p < npx) {
       const int r = p / P.TW, c = p - r * P.TW;
@@ -271,28 +317,67 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_smallcin(WgradParams P) {
   for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
 
-  for (int tile = blockIdx.x; tile < P.ntiles; tile += P.G) {
+  // Register prefetch of the next tile (round 5): a tile is 64 anchor pixels -- 16 KB of dY and a few hundred halo values --
+  // and the block used to load it, wait, multiply 16 quads and start over: a latency chain per tile with two blocks per CU
+  // to hide it (VDSR's first layer: 6724 tiles, 103 us for 115 MB).  Now tile t + 1's loads are issued in front of tile t's
+  // MFMA loop and stored to LDS behind it.  Regions whose items exceed the register batches (XIT / YIT per thread) keep
+  // the staged form.
+  constexpr bool PFOK = MT <= 4;   // (the 9x9 problems hold 64 accumulator registers: no room for a 48-register batch at two blocks per CU)
+  constexpr int XIT = PFOK ? 2 : 1, YIT = PFOK ? WG_TP_SC * 16 / 256 : 1;
+  const bool pf = PFOK && P.HH * P.HW <= XIT * 256 && npx4 * 16 <= YIT * 256;
+  f32x4 xr[XIT], yr[YIT];
+  auto tile_rc = [&](int tile, int& n, int& r0, int& c0) {
     int b = tile;
     const int txi = b % P.tiles_x;
     b /= P.tiles_x;
     const int tyi = b % P.tiles_y;
-    const int n = b / P.tiles_y;
-    const int r0 = tyi * P.TH, c0 = txi * P.TW;
+    n = b / P.tiles_y;
+    r0 = tyi * P.TH;
+    c0 = txi * P.TW;
+  };
+  auto prefetch = [&](int tile) {
+    int n, r0, c0;
+    tile_rc(tile, n, r0, c0);
+#pragma unroll
+    for (int k = 0; k < XIT; ++k)
+      xr[k] = stage_item_load(P.x, nullptr, 0.f, n, P.XH, P.XW, P.Cin, r0 * P.stride - P.pad, c0 * P.stride - P.pad, P.HH, P.HW,
+                              P.HH * P.HW, 0, P.Cin, 4, P.vec_x, tid + 256 * k);
+#pragma unroll
+    for (int k = 0; k < YIT; ++k)
+      yr[k] = stage_item_load(P.dy, P.mask_y, P.mask_slope, n, P.YH, P.YW, P.Cout, r0, c0, P.TH, P.TW, npx4, cob, coc, 64,
+                              P.vec_y, tid + 256 * k);
+  };
+  if (pf && (int)blockIdx.x < P.ntiles) prefetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < P.ntiles; tile += P.G) {
+    int n, r0, c0;
+    tile_rc(tile, n, r0, c0);
     __syncthreads();
-    stage_region(P.x, nullptr, 0.f, xs, 4, n, P.XH, P.XW, P.Cin, r0 * P.stride - P.pad, c0 * P.stride - P.pad, P.HH,
-                 P.HW, P.HH * P.HW, 0, P.Cin, 4, P.vec_x);
-    stage_region(P.dy, P.mask_y, P.mask_slope, ys, P.PSY, n, P.YH, P.YW, P.Cout, r0, c0, P.TH, P.TW, npx4, cob, coc,
-                 64, P.vec_y);
+    if (pf) {
+#pragma unroll
+      for (int k = 0; k < XIT; ++k) stage_item_store(xs, 4, P.HH * P.HW, 4, tid + 256 * k, xr[k]);
+#pragma unroll
+      for (int k = 0; k < YIT; ++k) stage_item_store(ys, P.PSY, npx4, 64, tid + 256 * k, yr[k]);
+    } else {
+      stage_region(P.x, nullptr, 0.f, xs, 4, n, P.XH, P.XW, P.Cin, r0 * P.stride - P.pad, c0 * P.stride - P.pad, P.HH,
+                   P.HW, P.HH * P.HW, 0, P.Cin, 4, P.vec_x);
+      stage_region(P.dy, P.mask_y, P.mask_slope, ys, P.PSY, n, P.YH, P.YW, P.Cout, r0, c0, P.TH, P.TW, npx4, cob, coc,
+                   64, P.vec_y);
+    }
     __syncthreads();
-    if (P.bias_partial && tid < 64) {
+    if (pf && tile + P.G < P.ntiles) prefetch(tile + P.G);
+    if (P.bias_partial) {   // column sums of dY: wave w takes the pixels w, w + 4, ... (combined once, behind the last tile)
       float bs0 = 0.f, bs1 = 0.f;
-      for (int p = 0; p + 1 < npx4; p += 2) {
-        bs0 += ys[p * P.PSY + tid];
-        bs1 += ys[(p + 1) * P.PSY + tid];
+      for (int p = wave; p + 4 < npx4; p += 8) {
+        bs0 += ys[p * P.PSY + lane];
+        bs1 += ys[(p + 4) * P.PSY + lane];
       }
+      if (((npx4 - 1 - wave) >> 2) % 2 == 0 && wave < npx4) bs0 += ys[(wave + ((npx4 - 1 - wave) >> 2) * 4) * P.PSY + lane];
       bsum += bs0 + bs1;
     }
     if (wave_live) {
+      // (SCIN_UNROLL pixel quads per trip: their LDS reads -- 1 + MT per quad, each behind a table lookup -- are independent and
+      //  issue together; one quad per trip left every MFMA behind a full LDS round trip)
+#pragma unroll SCIN_UNROLL
       for (int k4 = 0; k4 < npx4; k4 += 4) {
         const int p = k4 + kq;
         const float bv = ys[p * P.PSY + wave * 16 + i];
@@ -305,7 +390,14 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma_smallcin(WgradParams P) {
       }
     }
   }
-  if (P.bias_partial && tid < 64 && cob + tid < P.Cout) P.bias_partial[(size_t)blockIdx.x * P.Cout + cob + tid] = bsum;
+  if (P.bias_partial) {
+    __syncthreads();
+    float* bred = smem;   // [4 waves][64]
+    bred[wave * 64 + lane] = bsum;
+    __syncthreads();
+    if (tid < 64 && cob + tid < P.Cout)
+      P.bias_partial[(size_t)blockIdx.x * P.Cout + cob + tid] = (bred[tid] + bred[64 + tid]) + (bred[128 + tid] + bred[192 + tid]);
+  }
   if (wave_live) {
     float* slab = P.ws + (size_t)blockIdx.x * T * P.Cin * P.Cout;
     const int co = cob + wave * 16 + i;
@@ -568,8 +660,12 @@ static WgPlan plan(const srk_conv_desc& d) {
   const int ps_tile = d.transposed ? psx_full : psy_full;
   bool found = false;
   long best_tiles = 0, best_halo = 0;
-  for (int TW = 1; TW <= (AW < WG_TP ? AW : WG_TP); ++TW) {
-    int TH = WG_TP / TW;
+  // smallcin: 192-pixel tiles when the problem still has >= 2 of them per block slot (VDSR's first layer, SRGAN-D's at
+  // 128x128), 64-pixel tiles otherwise (SRGAN-G's 9x9 first layer at 32x32: 86 large tiles would leave two thirds of the CUs idle)
+  int tp = WG_TP;
+  if (pl.smallcin && (long)d.N * cdiv(AH * AW, WG_TP_SC) >= 2L * WG_MAXBLOCKS && T * d.Cin <= 64) tp = WG_TP_SC;
+  for (int TW = 1; TW <= (AW < tp ? AW : tp); ++TW) {
+    int TH = tp / TW;
     if (TH > AH) TH = AH;
     for (; TH >= 1; --TH) {
       const int HH = (TH - 1) * d.stride + d.KH, HW = (TW - 1) * d.stride + d.KW;

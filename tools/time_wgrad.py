@@ -9,6 +9,8 @@ lib = load()
 SHAPES = {"edsr128": (128, 64, 32, 32, 64, 3, 1), "vdsr": (256, 64, 41, 41, 64, 3, 1), "edsr16": (16, 64, 32, 32, 64, 3, 1),
           "edsrtail128": (128, 64, 128, 128, 3, 3, 1), "edsrtail16": (16, 64, 128, 128, 3, 3, 1), "vdsrtail": (256, 64, 41, 41, 3, 3, 1),
           # SRGAN discriminator class: few pixels, many channels (the slab reduce and its scattered dw stores dominate)
+          # first layers (Cin = 3: k_wgrad_mfma_smallcin): VDSR 3x3, SRGAN-G 9x9 at 32x32, SRGAN-D 3x3 at 128x128
+          "vdsrhead": (256, 3, 41, 41, 64, 3, 1), "ghead9": (16, 3, 32, 32, 64, 9, 4), "dhead": (16, 3, 128, 128, 64, 3, 1),
           "d256": (16, 128, 32, 32, 256, 3, 1), "d512": (16, 256, 16, 16, 512, 3, 1), "d512b": (16, 512, 8, 8, 512, 3, 1)}
 dev = torch.device("cuda:0")
 for name in (sys.argv[1:] or list(SHAPES)):
