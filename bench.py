@@ -251,7 +251,7 @@ def training_roofline(tag, px, layer_px_note, layers_per_step=1, steps=5):
         counter = next((v.get("hbm_bytes") for k, v in hbm.items() if k == name), None)
         us = float(best["AverageNs"]) / 1e3
         if nlay is None:   # weight gradients are launched per layer or grouped over several layers of one geometry
-            nlay = max(1.0, round(layers_per_step * steps / float(best["Calls"]))) if ("true, true" in name or "k_wgrad_tr<true>" in name) else 1.0
+            nlay = max(1.0, round(layers_per_step * steps / float(best["Calls"]))) if ("true, true" in name or "k_wgrad_tr<true" in name) else 1.0
         lay_alg, lay_flop = alg * (nlay if role == "weight_gradient" else 1.0), flop * nlay
         six = "k_conv_bfd<2, 2, 2, 3" in name      # the bf16x6 forward of earlier rounds: six MFMAs per product
         peak = BF16_MFMA_PEAK_TFLOPS / (6.0 if six else 3.0)
