@@ -22,6 +22,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Run order for `-x`: kernel parity first (ops -> blocks -> nets -> train trajectories -> BASELINE full sizes -> pre/post),
+# then the input pipeline, and the multi-process / subprocess plumbing tests LAST, so that nothing fragile (ports, spawned
+# ranks, a bench subprocess) can ever stop the run before the hot-path parity tests have been reached.
+_FILE_ORDER = ("test_oracle_golden", "test_host_cpu", "test_ops_gpu", "test_resblock2_gpu", "test_nets_gpu",
+               "test_train_gpu", "test_fullsize_gpu", "test_prepost_gpu", "test_interp", "test_data_pipeline",
+               "test_dp_gpu")
+
+
+def pytest_collection_modifyitems(config, items):
+    def rank(item):
+        name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return _FILE_ORDER.index(name) if name in _FILE_ORDER else len(_FILE_ORDER) - 1.5
+    items.sort(key=rank)      # stable: the order inside a file is kept
+
+
 def _load(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
