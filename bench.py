@@ -146,12 +146,13 @@ def espcn_layer_events(net, x, steps, discard=0):
     `discard + steps` forwards (the first ones run while the clock governor ramps up from idle)."""
     import pytorch_super_resolution_model_collection_amd as pkg
     lib = pkg._lib.load()
-    xs = x   # the first layer reads the NCHW batch in place, exactly as net(x) does
+    batches = x if isinstance(x, (list, tuple)) else [x]   # the first layer reads the NCHW batch in place, exactly as net(x) does
     evs, names = [], ["", "", ""]
     with torch.no_grad():
-        for _ in range(discard + steps):
+        for k in range(discard + steps):
             e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            h = xs
+            h = batches[k % len(batches)]
+            h = h.view(h.shape)   # (a new tensor object, as in the timed loop: the first bracket holds the |x| maximum pass too)
             e[0].record()
             for i, layer in enumerate(net.layers):
                 h = layer(h)
@@ -239,7 +240,8 @@ def training_roofline(tag, px, layer_px_note, layers_per_step=1, steps=5):
         roles[2] = ("weight_gradient", ("k_wgrad_tr<", "k_wgrad_bf<2, 2, 2, true"), 2 * t, "x, dy (pre-masked by the data gradient above)", None)
     if any("k_res2<" in r["Name"] for r in rows):   # body layers run fused per block: no stand-alone forward / data gradient
         roles = [r for r in roles if r[0] not in ("forward", "data_gradient")]
-    out = {"source": [os.path.basename(stats[-1]), os.path.basename(traffic[-1])], "layer": layer_px_note, "kernels": {}}
+    out = {"from_profiles": True, "live": False,
+           "source": [os.path.basename(stats[-1]), os.path.basename(traffic[-1])], "layer": layer_px_note, "kernels": {}}
     for role, keys, alg, what, nlay in roles:
         best = None
         for r in rows:
@@ -402,6 +404,7 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None, cpu_baselines=True):
     out = {} if out is None else out
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     WARM = 5
+    out["train_untimed_warmup_steps"] = WARM   # (per section; the shard step states its own)
     # the N > 1 code path: more than one rank, or a one-rank process group forced by SRK_DP_FORCE_COMM=1 (dry run of the
     # data-parallel sections with real RCCL collectives on a single GPU; the numbers then mean nothing)
     multi = world > 1 or torch.distributed.is_initialized()
@@ -419,8 +422,13 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None, cpu_baselines=True):
         # copies land: data.py writes a batch to any device tensor); a call with other tensors would copy them in first
         for sbuf, b in zip(step.static, (inp, tgt)):
             sbuf.copy_(b)
+        inp0, tgt0 = inp, tgt
         inp, tgt = step.static[0], step.static[1]
         sec = time_steps(lambda: step(inp, tgt), steps, warmup, world if use_dp else 1, dev)
+        # ... and the rounds-1..4 protocol beside it: the batch arrives in OTHER resident tensors, every step copies it into
+        # the static buffers first (two device-to-device copies inside the timed region)
+        run.sec_with_copy = time_steps(lambda: step(inp0, tgt0), steps, 2, world if use_dp else 1, dev)
+        run.warmup = warmup
         sec_nocomm = None
         run.rank_span = None
         if dp is not None:   # the same step with the all-reduces skipped: the difference is the exposed communication
@@ -483,6 +491,7 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None, cpu_baselines=True):
         sec, k, _ = run("vdsr", net, x, t, pkg.ops.mse_loss, 0.4, False)
         out["c3_vdsr_x4_train_patches_per_s"] = round(256 * k / sec, 1)
         out["c3_vdsr_ms_per_step"] = round(1e3 * sec / k, 3)
+        out["c3_vdsr_ms_per_step_with_input_copy"] = round(1e3 * run.sec_with_copy / k, 3)
         out["c3_vdsr_mfma3_peak_frac"] = round(mfma3_peak_frac(3 * C3_FWD, sec / k / 256), 4)
         out["c3_arithmetic"] = ARITHMETIC["c3"] % pkg.ops.backward_arithmetic()
         rl = training_roofline("c3", 256 * 41 * 41, "VDSR body layer: conv3x3 64 -> 64 on 256 x 41 x 41 pixels, 31.7 GFLOP", 18)
@@ -504,6 +513,7 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None, cpu_baselines=True):
         sec, k, nocomm = run("edsr", edsr(), x, t, pkg.ops.l1_loss, None, True)
         out["c4_edsr_x4_train_patches_per_s_global_batch_128"] = round(gb * k / sec, 1)
         out["c4_edsr_ms_per_step"] = round(1e3 * sec / k, 3)
+        out["c4_edsr_ms_per_step_with_input_copy"] = round(1e3 * run.sec_with_copy / k, 3)
         out["c4_edsr_mfma3_peak_frac"] = round(mfma3_peak_frac(3 * C4_FWD, sec / k / gb) / world, 4)
         out["c4_arithmetic"] = ARITHMETIC["c4"] % pkg.ops.backward_arithmetic()
         if not multi:
@@ -537,6 +547,8 @@ def train_extra(pkg, dev, rank, world, nsteps=20, out=None, cpu_baselines=True):
         #  11.2: ~50 launches -- and reads 3 - 5 % slow; the step draws 730 W, nothing about it is power-limited)
         sec, k, _ = run("edsr", edsr(), x, t, pkg.ops.l1_loss, None, False, steps=50, warmup=60)
         out["c4_shard16_ms_per_step"] = round(1e3 * sec / k, 3)
+        out["c4_shard16_ms_per_step_with_input_copy"] = round(1e3 * run.sec_with_copy / k, 3)
+        out["c4_shard16_untimed_warmup_steps"] = run.warmup
         out["c4_shard16_mfma3_peak_frac"] = round(mfma3_peak_frac(3 * C4_FWD, sec / k / 16), 4)
         out["c4_shard16_arithmetic"] = ARITHMETIC["c4_shard16"]
         if "c4_edsr_ms_per_step" in out and world == 1:
@@ -766,12 +778,19 @@ def main():
     net = pkg.ESPCNNet(3, 64, 4)
     net.weight_init()
     net.to(dev).eval()
-    x = torch.rand(args.batch, 3, args.lr_size, args.lr_size, generator=torch.Generator().manual_seed(1234 + rank))
-    x = x.to(dev)
+    # Three resident LR batches taken in turn, each handed over as a NEW tensor object (what a loader delivers): the
+    # absolute-maximum pass of the first layer (ops.amax_of caches it on the tensor object) therefore runs in EVERY timed
+    # forward, as it would on a stream of new batches -- profiles/r06_c2_kernel_stats.csv: k_absmax calls == forwards.
+    gen = torch.Generator().manual_seed(1234 + rank)
+    xs = [torch.rand(args.batch, 3, args.lr_size, args.lr_size, generator=gen).to(dev) for _ in range(3)]
+    x = xs[0]
+    turn = [0]
 
     def step():
+        turn[0] += 1
+        xb = xs[turn[0] % 3]
         with torch.no_grad():
-            return net(x)
+            return net(xb.view(xb.shape))
 
     y = step()
     assert tuple(y.shape) == (args.batch, 3, 4 * (args.lr_size - 8), 4 * (args.lr_size - 8))
@@ -780,7 +799,7 @@ def main():
     # 50+ 1.01 ms), so W = 5 warm-up steps alone would leave the whole timed window -- and the layer times -- inside that ramp.
     # Disclosed in the line: extra.c2_cold_window_ms_per_step is the same W + K window behind 2 s of idle,
     # extra.c2_power_probe.ms_per_step_while_sampling the rate sustained over seconds.
-    layer_ms, layer_kernels = espcn_layer_events(net, x, max(3, min(args.steps, 10)), discard=30)
+    layer_ms, layer_kernels = espcn_layer_events(net, xs, max(3, min(args.steps, 10)), discard=30)
     sec = time_steps(step, args.steps, args.warmup, world, dev)
     imgs_per_s = world * args.batch * args.steps / sec
     ranks_seen = rccl_ranks_seen(dev)
@@ -830,6 +849,9 @@ def main():
                        "timing": "W warm-up + K timed forwards, barrier + synchronize on both sides; 40 forwards of per-layer "
                                  "event timing run in front of the window (the clock governor needs ~50 forwards from idle: "
                                  "extra.c2_cold_window_* is the same window behind 2 s of idle)",
+                       "untimed_forwards_before_window": 1 + 40 + args.warmup,
+                       "input": "3 resident batches in rotation, a new tensor object per forward: the first layer's |x| "
+                                "maximum pass runs inside every timed forward",
                        "parallelism": "replicas x%d (no collective)" % world},
             "roofline": {"bound": "mfma", "kernel": names[dom], "achieved": round(achieved, 2),
                          "peak": round(peak, 1), "unit": "TFLOP/s",
