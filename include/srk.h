@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SRK_VERSION 100 /* major*10000 + minor*100 + patch */
+#define SRK_VERSION 600 /* major*10000 + minor*100 + patch; 0.6.0: srk_conv2d_forward_ex + srk_conv_result, the pair entry points retired */
 
 typedef enum srk_status {
   SRK_OK = 0,
@@ -124,19 +124,24 @@ typedef struct srk_epilogue {
   const float* x_amax;       /* SRK_ALGO_MFMA_F16X3: SRK_AMAX_FLOATS floats, max over the slots >= max|x| (NULL otherwise) */
   float* y_amax;             /* optional: SRK_AMAX_FLOATS floats that receive (atomic max) max|y| of this call's output
                                 -- the next layer's x_amax.  Honoured by the kernels listed at srk_conv2d_f16x3_supported;
-                                ask srk_last_conv_wrote_amax() after the call */
+                                srk_conv2d_forward_ex reports whether the dispatched kernel did (srk_conv_result) */
   double* bn_partial;        /* optional (forward): the conv leaves the per-channel column sums of its OUTPUT for the
                                 BatchNorm behind it (base_networks.py:46,117: conv -> bn) -- row t of
                                 [tiles][2 * Cout] doubles = {sum y, sum y*y} over the pixels of tile t, summed in a fixed
                                 order; room for N * ceil(OH / 8) * ceil(OW / 8) rows.  Honoured by the per-tile 64 -> 64
-                                3x3 kernel (k_c64) only: srk_last_conv_bn_partial_rows() says how many rows the call wrote
+                                3x3 kernel (k_c64) only: srk_conv_result.bn_partial_rows says how many rows the call wrote
                                 (0: none -- run srk_bn_stats_finalize as usual), srk_bn_finalize_partials() consumes them */
-  int32_t* wrote_amax;       /* optional HOST out-field: srk_conv2d_forward stores 1 here when the kernel it dispatched to
-                                keeps the running maximum in y_amax (and y_amax was given), else 0 -- only then may the
-                                caller hand the slots to the next layer as x_amax (base_networks.py:101-104) */
-  int32_t* bn_partial_rows;  /* optional HOST out-field: rows of bn_partial the call filled (0: the dispatched kernel keeps
-                                none -- run srk_bn_stats_finalize as usual) */
-} srk_epilogue;
+} srk_epilogue;  /* (layout frozen at library version 600 = the round-4 layout: results of a call travel in srk_conv_result, never here) */
+
+/* What the kernel a forward call dispatched to did -- a HOST struct the caller owns, filled by srk_conv2d_forward_ex.
+ * `struct_size` is set by the CALLER to sizeof(srk_conv_result) of the header it was compiled against: the library writes
+ * only the fields that fit, so the struct can grow without breaking older callers. */
+typedef struct srk_conv_result {
+  uint32_t struct_size;
+  int32_t wrote_amax;       /* 1: the kernel keeps the running maximum of |y| in ep->y_amax (and y_amax was given) -- only
+                               then may the slots be handed to the next layer as x_amax (base_networks.py:101-104) */
+  int32_t bn_partial_rows;  /* rows of ep->bn_partial the call filled (0: none -- run srk_bn_stats_finalize as usual) */
+} srk_conv_result;
 
 /* Activation-gradient prologue of the backward kernels: the incoming gradient dy is
  * multiplied by act'(.) while it is loaded, using the SAVED FORWARD OUTPUT `y`
@@ -154,8 +159,8 @@ const char* srk_last_error_string(void); /* thread-local, valid until the next f
 /* Name (with template arguments) of the kernel the calling thread's last srk_conv2d_forward / _backward_data call
  * dispatched to, e.g. "k_conv_bfw<2,9,2>" — what a measurement should quote (thread-local, never NULL). */
 const char* srk_last_kernel_name(void);
-/* DEPRECATED aliases of the out-fields srk_epilogue.wrote_amax / .bn_partial_rows (thread-local side channels that had to be
- * queried before the thread's next conv call; kept for callers written against the round-4 header). */
+/* DEPRECATED aliases of srk_conv_result.wrote_amax / .bn_partial_rows (thread-local side channels that have to be queried
+ * before the thread's next conv call; kept for callers written against the round-4 header). */
 int srk_last_conv_wrote_amax(void);
 int srk_last_conv_bn_partial_rows(void);
 /* Diagnostic of the ring kernels (k_conv_bfr: producer and consumer waves of a persistent block hand halo buffers over
@@ -218,21 +223,10 @@ int srk_conv2d_f16x3_supported(const srk_conv_desc* d, const srk_epilogue* ep, c
 /* ---- convolution (Conv2d / ConvTranspose2d: base_networks.py:42,77,112-113,156; fsrcnn.py:33) */
 int srk_conv2d_forward(const srk_conv_desc* d, const float* x, const float* w_packed_fwd, float* y,
                        const srk_epilogue* ep, void* stream);
-/* Two stacked convolutions as ONE launch (espcn.py:17-19: conv 3 -> 64 5x5 + ReLU, then conv 64 -> 32 3x3 + ReLU):
- *   y = act2(conv2(act1(conv1(x) + b1)) + b2)
- * The first layer is recomputed by the producer waves of the second layer's persistent kernel on the halo of every output
- * tile and handed over through LDS: its Cout1-channel output -- more than half of the HBM bytes of an ESPCN forward --
- * is never written or read.  Arithmetic: SRK_ALGO_MFMA_F16X3 in both layers (ep1->x_amax = running maximum of |x|, the
- * network input); the intermediate is split with the exact maximum of each tile's own halo, a tighter scale than the
- * global one of the two-call form, so the two forms agree to fp32 rounding, not bit for bit.  ep2->y_amax as in
- * srk_conv2d_forward.  d1: stride 1, Cin <= 4 (x_nchw honoured), 5x5, Cout 64, no / ReLU / leaky activation;
- * d2: stride 1, 3x3, 64 -> 32, any activation srk_conv2d_forward fuses on that layer; d2's input size = d1's output size.
- * srk_conv2d_pair_supported() says 1 when the pair is covered (else: two srk_conv2d_forward calls). */
-int srk_conv2d_pair_supported(const srk_conv_desc* d1, const srk_epilogue* ep1, const srk_conv_desc* d2,
-                              const srk_epilogue* ep2, const float* y);
-int srk_conv2d_pair_forward(const srk_conv_desc* d1, const float* x, const float* w1_packed_fwd, const srk_epilogue* ep1,
-                            const srk_conv_desc* d2, const float* w2_packed_fwd, float* y, const srk_epilogue* ep2,
-                            void* stream);
+/* The same call, reporting what the dispatched kernel did in *res (may be NULL = srk_conv2d_forward).  Replaces the
+ * thread-local srk_last_conv_* side channels below. */
+int srk_conv2d_forward_ex(const srk_conv_desc* d, const float* x, const float* w_packed_fwd, float* y,
+                          const srk_epilogue* ep, srk_conv_result* res, void* stream);
 /* dx = d(loss)/dx given dy; optional act-grad prologue on dy; optional fused "+ add_to"
  * (gradient fan-in of a residual connection).  Replaces aten::convolution_backward (input
  * gradient) as dispatched from loss.backward() — edsr.py:154, vdsr.py:146, srgan.py:286,309. */

@@ -40,8 +40,15 @@ class Epilogue(ctypes.Structure):
     """struct srk_epilogue"""
     _fields_ = [("bias", c_vp), ("prelu_weight", c_vp), ("residual", c_vp), ("slope", c_float),
                 ("act", ctypes.c_int32), ("prelu_n", ctypes.c_int32), ("ps_r", ctypes.c_int32),
-                ("x_amax", c_vp), ("y_amax", c_vp), ("bn_partial", c_vp),
-                ("wrote_amax", ctypes.POINTER(ctypes.c_int32)), ("bn_partial_rows", ctypes.POINTER(ctypes.c_int32))]
+                ("x_amax", c_vp), ("y_amax", c_vp), ("bn_partial", c_vp)]
+
+
+class ConvResult(ctypes.Structure):
+    """struct srk_conv_result (host out-struct of srk_conv2d_forward_ex; struct_size is the caller's sizeof)"""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("wrote_amax", ctypes.c_int32), ("bn_partial_rows", ctypes.c_int32)]
+
+    def __init__(self):
+        super().__init__(ctypes.sizeof(ConvResult), 0, 0)
 
 
 class BwdMask(ctypes.Structure):
@@ -68,10 +75,8 @@ _PROTOTYPES = {
     "srk_pack_weights_batched": (c_int, [c_f, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     "srk_packed_weight_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int]),
     "srk_conv2d_forward": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, c_f, ctypes.POINTER(Epilogue), c_vp]),
-    "srk_conv2d_pair_supported": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(Epilogue), ctypes.POINTER(ConvDesc),
-                                          ctypes.POINTER(Epilogue), c_f]),
-    "srk_conv2d_pair_forward": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, ctypes.POINTER(Epilogue), ctypes.POINTER(ConvDesc),
-                                        c_f, c_f, ctypes.POINTER(Epilogue), c_vp]),
+    "srk_conv2d_forward_ex": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, c_f, ctypes.POINTER(Epilogue),
+                                      ctypes.POINTER(ConvResult), c_vp]),
     "srk_conv2d_backward_data": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, c_f, ctypes.POINTER(BwdMask), c_f,
                                          c_vp]),
     "srk_conv2d_backward_data_relu_supported": (c_int, [ctypes.POINTER(ConvDesc), c_f, c_f, ctypes.POINTER(BwdMask)]),

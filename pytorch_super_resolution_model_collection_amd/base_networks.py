@@ -104,22 +104,6 @@ class ConvBlock(_Block):
         return out
 
 
-def fused_conv_pair(blk1, blk2, x):
-    """blk2(blk1(x)) for two norm-free ConvBlocks as ONE launch where the library has a kernel for the pair (the first two
-    layers of ESPCN in inference: ops.conv_pair_infer), else None."""
-    if blk1.norm is not None or blk2.norm is not None:
-        return None
-    c1, c2 = blk1.conv, blk2.conv
-    k1, s1, pw1 = blk1._act_args()
-    k2, s2, pw2 = blk2._act_args()
-    if pw1 is not None or grad_mode(x, c1.weight, c1.bias, c2.weight, c2.bias, pw2):
-        return None
-    cfg1 = ops.ConvCfg(c1._s, c1._p, False, 0, k1, s1, 0)
-    cfg2 = ops.ConvCfg(c2._s, c2._p, False, 0, k2, s2, 0)
-    return ops.conv_pair_infer(x, c1.weight, c1.bias, cfg1, c1._cache.get(c1.weight, c1.bias, False, 0),
-                               c2.weight, c2.bias, cfg2, pw2, c2._cache.get(c2.weight, c2.bias, False, 0))
-
-
 class DeconvBlock(_Block):
     """base_networks.py:74-106"""
 

@@ -3,6 +3,7 @@
 // the MFMA, direct or generic kernels.
 #include "srk_common.h"
 #include "conv_problem.h"
+#include <stddef.h>
 #include <string.h>
 #include <stdlib.h>
 
@@ -319,67 +320,18 @@ extern "C" int srk_conv2d_forward(const srk_conv_desc* d, const float* x, const 
     g.in_nchw = 1;
   }
   rc = run_gather(g, d->algo, x, w_packed_fwd, y, ep, nullptr, 0.f, (hipStream_t)stream, "conv2d_forward");
-  // results of the dispatch: out-fields of the epilogue (the srk_last_conv_* queries are deprecated aliases)
-  if (ep_in && ep_in->wrote_amax) *ep_in->wrote_amax = rc == SRK_OK ? g_amax_written : 0;
-  if (ep_in && ep_in->bn_partial_rows) *ep_in->bn_partial_rows = rc == SRK_OK ? g_bn_partial_rows : 0;
   return rc;
 }
 
-namespace srk {
-// conv_bfr.hip
-int conv_bfr_fused(const GatherConv& g1, const float* x, const float* wp1, const Epi& ep1, const GatherConv& g2, const float* wp2,
-                   float* out, const Epi& ep2, hipStream_t s);
-}  // namespace srk
-static bool pair_shape_ok(const srk_conv_desc* d1, const Epi& ep1, const srk_conv_desc* d2, const Epi& ep2, const float* y) {
-  if (d1->transposed || d2->transposed || d1->stride != 1 || d2->stride != 1 || d1->dy_ps_r || d2->dy_ps_r || d2->x_nchw) return false;
-  if (d1->Cin < 1 || d1->Cin > 4 || d1->Cout != 64 || d1->KH != 5 || d1->KW != 5) return false;
-  if (d2->Cin != 64 || d2->Cout != 32 || d2->KH != 3 || d2->KW != 3 || d2->N != d1->N || d2->H != d1->OH || d2->W != d1->OW) return false;
-  if (!ep1.x_amax || ep1.residual || ep1.ps_r > 1) return false;
-  if (ep1.act != SRK_ACT_NONE && ep1.act != SRK_ACT_RELU && ep1.act != SRK_ACT_LRELU) return false;
-  if (ep2.residual || ep2.ps_r > 1 || (ep2.act == SRK_ACT_PRELU && ep2.prelu_n > 1)) return false;
-  if (ep2.act != SRK_ACT_NONE && ep2.act != SRK_ACT_RELU && ep2.act != SRK_ACT_LRELU && ep2.act != SRK_ACT_PRELU) return false;
-  if (!conv_epi_all_vector(d2->Cout, ep2, y) || (ep1.bias && (uintptr_t)ep1.bias % 16 != 0)) return false;
-  if ((long)d2->N * d2->OH * d2->OW * d2->Cout >= (1L << 29)) return false;
-  return env_int("SRK_PAIR", 1) != 0;
-}
-
-extern "C" int srk_conv2d_pair_supported(const srk_conv_desc* d1, const srk_epilogue* ep1_in, const srk_conv_desc* d2,
-                                         const srk_epilogue* ep2_in, const float* y) {
-  if (!d1 || !d2 || validate_desc(d1, "conv2d_pair_supported") || validate_desc(d2, "conv2d_pair_supported")) return 0;
-  Epi ep1 = make_epi(ep1_in), ep2 = make_epi(ep2_in);
-  static const float dummy = 0.f;
-  if (!ep1.x_amax) ep1.x_amax = &dummy;   // (the question is about the shapes; the call itself needs the real slots)
-  return pair_shape_ok(d1, ep1, d2, ep2, y ? y : reinterpret_cast<const float*>(16)) ? 1 : 0;
-}
-
-extern "C" int srk_conv2d_pair_forward(const srk_conv_desc* d1, const float* x, const float* w1_packed_fwd,
-                                       const srk_epilogue* ep1_in, const srk_conv_desc* d2, const float* w2_packed_fwd, float* y,
-                                       const srk_epilogue* ep2_in, void* stream) {
-  note_amax_written(false);
-  note_bn_partial_rows(0);
-  SRK_REQUIRE(d1 && d2, "conv2d_pair_forward: null descriptor");
-  int rc = validate_desc(d1, "conv2d_pair_forward");
-  if (rc) return rc;
-  rc = validate_desc(d2, "conv2d_pair_forward");
-  if (rc) return rc;
-  SRK_REQUIRE(x && w1_packed_fwd && w2_packed_fwd && y, "conv2d_pair_forward: null tensor pointer");
-  Epi ep1 = make_epi(ep1_in), ep2 = make_epi(ep2_in);
-  SRK_REQUIRE(ep1.x_amax, "conv2d_pair_forward: ep1.x_amax (running maximum of the input) is required");
-  SRK_REQUIRE(ep2.act != SRK_ACT_PRELU || (ep2.prelu_w && ep2.prelu_n >= 1), "conv2d_pair_forward: PReLU needs its weight");
-  if (!pair_shape_ok(d1, ep1, d2, ep2, y)) {
-    set_error("conv2d_pair_forward: the pair is not one the fused kernel covers (srk_conv2d_pair_supported)");
-    return SRK_ERR_UNSUPPORTED;
+extern "C" int srk_conv2d_forward_ex(const srk_conv_desc* d, const float* x, const float* w_packed_fwd, float* y,
+                                     const srk_epilogue* ep_in, srk_conv_result* res, void* stream) {
+  const int rc = srk_conv2d_forward(d, x, w_packed_fwd, y, ep_in, stream);
+  if (res) {
+    // (the caller says how much of the struct it knows: only those fields are written)
+    if (res->struct_size >= offsetof(srk_conv_result, wrote_amax) + sizeof(int32_t)) res->wrote_amax = rc == SRK_OK ? g_amax_written : 0;
+    if (res->struct_size >= offsetof(srk_conv_result, bn_partial_rows) + sizeof(int32_t))
+      res->bn_partial_rows = rc == SRK_OK ? g_bn_partial_rows : 0;
   }
-  GatherConv g1{d1->N, d1->H, d1->W, d1->Cin, d1->OH, d1->OW, d1->Cout, d1->KH, d1->KW, d1->stride, d1->pad, 0, 0};
-  g1.in_nchw = d1->x_nchw;
-  GatherConv g2{d2->N, d2->H, d2->W, d2->Cin, d2->OH, d2->OW, d2->Cout, d2->KH, d2->KW, d2->stride, d2->pad, 0, 0};
-  rc = conv_bfr_fused(g1, x, w1_packed_fwd, ep1, g2, w2_packed_fwd, y, ep2, (hipStream_t)stream);
-  if (rc == -1) {
-    set_error("conv2d_pair_forward: no launch configuration for this size");
-    return SRK_ERR_UNSUPPORTED;
-  }
-  if (ep2_in && ep2_in->wrote_amax) *ep2_in->wrote_amax = rc == SRK_OK ? g_amax_written : 0;
-  if (ep2_in && ep2_in->bn_partial_rows) *ep2_in->bn_partial_rows = 0;
   return rc;
 }
 

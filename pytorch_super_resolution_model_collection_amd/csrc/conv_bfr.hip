@@ -63,6 +63,17 @@ static long long* g_bfr_prof = nullptr;
 
 typedef __attribute__((address_space(3))) unsigned bfr_cnt_t;
 
+// A poll that ran into its cap means the ring protocol slipped (or the wave was starved beyond anything a profiler does):
+// whatever this tile holds is wrong.  Count it (srk_ring_timeouts, diagnostics) and ABORT the dispatch: the stream then
+// reports hipErrorLaunchFailure at its next synchronisation / srk_* call instead of SRK_OK with corrupt output.
+__device__ __noinline__ void bfr_fail(int lane) {
+  if (lane == 0) {
+    atomicAdd(&g_bfr_timeouts, 1u);
+    __threadfence_system();
+  }
+  __builtin_trap();
+}
+
 // (ablation builds) a fragment the compiler must treat as written / as read
 __device__ __forceinline__ void bfr_touch(uint4& u) { asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w)); }
 __device__ __forceinline__ void bfr_use(const uint4& u) { asm volatile("" ::"v"(u.x), "v"(u.y), "v"(u.z), "v"(u.w)); }
@@ -96,34 +107,14 @@ __device__ __forceinline__ void bfr_signal(bfr_cnt_t* p) {
   asm volatile("" ::: "memory");
 }
 
-// FUSE: the layer in front (a Cin <= 4 conv + activation, the row-packed first layer of conv_rowsw.hip: ESPCN's 3 -> 64 5x5)
-// is computed by the PRODUCERS, tile by tile, straight into the ring -- its 64-channel output never exists in memory.
-// Why: the c2 layers run at the 1400 W board cap, where a layer's time is its energy, and 53 % of the whole
-// net's HBM bytes are that one tensor written and read back (2 x 1.04 GB of 3.9 GB).  Recomputing the first layer on the
-// 10 x 18 halo of every 8 x 16 tile costs 1.41x its MFMAs (a few per cent of the net's) and removes both passes.
-// The f16x3 scale of the intermediate is the tile's OWN maximum (the producers hold the whole halo in registers, so no
-// pass over the tensor is needed for it): uniform over everything one accumulator sums, exact, and tighter than a global one.
-struct BfrFuse {
-  const float* x;           // the first layer's input, NCHW or NHWC (x_nchw), IC1 <= 4 channels
-  const uint4* w1q;         // its row-packed fp16 planes [kernel row][plane][group][64 channels] (conv_rowsw.hip's layout)
-  const float* w1_descale;  // trailer {2^-kw1, 2^kw1}
-  const float* bias1;       // 64 floats or NULL
-  const float* x_amax;      // running maximum of |x| (global: the network input)
-  float slope1;             // activation of the first layer: v > 0 ? v : slope1 * v   (1: none, 0: ReLU)
-  int IC1, IH1, IW1, OH1, OW1, pad1, x_nchw;
-};
-struct BfrParams {
-  BfwParams B;
-  BfrFuse Z;
-};
-
-template <int NTW, int ICC, bool F16, bool FUSE = false, int KH1 = 5>
-__global__ __launch_bounds__(512, 2) void k_conv_bfr(BfrParams BP) {
-  const BfwParams& B = BP.B;
+// (Round 5 carried a FUSE variant here -- the Cin <= 4 first layer computed by the producers straight into the ring,
+//  srk_conv2d_pair_forward.  Correct but slower than the two launches (0.93 vs 0.70 ms on the c2 pair: its producers carried
+//  ~930 instructions per tile against the consumers' ~365); retired in round 6, DESIGN 13.  The last tree with it: b92a5aa.)
+template <int NTW, int ICC, bool F16>
+__global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
   constexpr int NB = 16 * NTW;
   constexpr int NCW = 4, NGW = 2, NPW = 4;  // consumer waves (two groups of NGW), producer waves
-  constexpr int NPS = FUSE ? 2 : NPW;       // producer waves that fill one slot (fused: one pair per channel chunk)
-  constexpr int XH = BFR_HH + KH1 - 1, XW = 26, XPIX = XH * XW;   // fused: the first layer's input tile (8 tap slots per row)
+  constexpr int NPS = NPW;                  // producer waves that fill one slot
   constexpr int NTHR = 64 * (NCW + NPW);
   constexpr int PSTEP = 16 * NPW, PIT = BFR_PIT, NSET = BFR_NSET_C;
   constexpr int TH = BFR_TH, TW = BFR_TW, HW = BFR_HW, NPIX = BFR_NPIX, NPIXP = BFR_NPIXP;
@@ -136,17 +127,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfrParams BP) {
   uint4* wl = smem4;
   uint4* hal0 = smem4 + 9 * ICC * WSLOT;
   const int nbuf = __builtin_amdgcn_readfirstlane(B.nbuf);
-  bfr_cnt_t* cnt = (bfr_cnt_t*)(hal0 + (size_t)nbuf * HBUF);  // full[BFR_MAXBUF], free[BFR_MAXBUF]; fused: + 20 words
-  // fused: cnt[12 .. 17] scale exponent of the tile in a slot, cnt[18] tiles staged, cnt[19] tiles computed, cnt[20 .. 23]
-  // tile maxima (ring of four), then two input tiles of XPIX pixels {h: 4 x fp16, l: 4 x fp16}
-  // (two planes per buffer, 8 bytes per pixel each: a fragment -- taps 2 kq, 2 kq + 1 x 4 channels -- is 16 contiguous bytes
-  //  of ONE plane, 8-byte aligned: ds_read2_b64 straight into the MFMA operand, no register shuffles)
-  uint2* xin0 = reinterpret_cast<uint2*>(reinterpret_cast<uint4*>(hal0 + (size_t)nbuf * HBUF) + 8);
+  bfr_cnt_t* cnt = (bfr_cnt_t*)(hal0 + (size_t)nbuf * HBUF);  // full[BFR_MAXBUF], free[BFR_MAXBUF]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool producer = wave >= NCW;
   const int j = lane & 15, kq = lane >> 4;
   float sx = 1.f, dsc = 1.f;
-  if constexpr (F16 && !FUSE) {
+  if constexpr (F16) {
     const int kx = amax_scale_exp(amax_read(P.ep.x_amax));
     sx = exp2i(kx);
     dsc = exp2i(-kx) * B.w_descale[0];
@@ -162,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfrParams BP) {
     // packed layout [tap][chunk][64-channel block][plane][group][NBfull channels] with NBfull = NB here (OC <= 48)
     wl[e] = B.wq[(size_t)(tapw * ICC + cc) * WSLOT + w];
   }
-  if (tid < 2 * BFR_MAXBUF + 12) cnt[tid] = 0u;
+  if (tid < 2 * BFR_MAXBUF) cnt[tid] = 0u;
   // tiles of this block (XCD-aware contiguous ranges, as in k_conv_bfw): first, first + tstride, ... (count of them)
   const int nblk = gridDim.x;
   int first, count;
@@ -212,263 +198,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfrParams BP) {
   bool dead = false;
   const int prio = __builtin_amdgcn_readfirstlane(B.late);  // 1: producers, 2: consumers issue first on their SIMD
 
-  if constexpr (FUSE) {
-    if (producer) {
-      // ------------------------------------------------------------ producers, fused first layer
-      // Wave pw = (pixel half mh, channel half nh): 6 of the halo's 12 sixteen-pixel M tiles x the 32 channels of chunk nh,
-      // as the row-packed MFMA of conv_rowsw.hip (K slots of a step = 8 taps x 4 channels of ONE kernel row; filter
-      // fragments of the wave's channels in registers: KH1 x 2 planes x 2 tiles).  Per tile t of the block's list:
-      //   1. request the input pixels of tile t + 1 (364 pixels over 256 threads, unconditional clamped loads)
-      //   2. wait until every producer wave has staged tile t                              (cnt[18] >= 4 (t + 1))
-      //   3. KH1 x 6 K steps from the input tile in LDS; bias, activation, zero outside the first layer's output;
-      //      the wave's maximum into the tile's word (ring of four, wave 0 clears the word two tiles ahead)
-      //   4. stage tile t + 1 (split with the network input's GLOBAL scale) into the other input buffer -- every wave is
-      //      past its step 3 of tile t - 1, the last reader of that buffer, because all of them passed step 2 of tile t
-      //   5. wait until every wave has computed tile t                                     (cnt[19] >= 4 (t + 1))
-      //      -> the tile's maximum, its scale 2^k with max 2^k in [2^14, 2^15)
-      //   6. wait for the ring slot of its stage (tile t, chunk nh), split, write [plane][group][pixel] as 8-byte halves,
-      //      leave k for the consumers, count the slot full
-      const BfrFuse& Z = BP.Z;
-      const int pw = wave - NCW, mh = pw >> 1, nh = pw & 1;
-      const int ptid = tid - 64 * NCW;
-      uint4 w1[KH1][2][2];
-#pragma unroll
-      for (int q = 0; q < KH1; ++q)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const uint4* w = Z.w1q + (size_t)q * (8 * 64) + (nh * 32 + nt * 16 + j);
-          w1[q][0][nt] = w[kq * 64];
-          w1[q][1][nt] = w[(4 + kq) * 64];
-        }
-      f32x4 bias1v[2];
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-        bias1v[nt] = Z.bias1 ? *reinterpret_cast<const f32x4*>(Z.bias1 + nh * 32 + nt * 16 + kq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int kx0 = amax_scale_exp(amax_read(Z.x_amax));
-      const float sx0 = exp2i(kx0), dsc1 = exp2i(-kx0) * Z.w1_descale[0];
-      const float slope1 = Z.slope1;
-      constexpr int MT = 6;
-      int xo[MT], mhy[MT], mhx[MT];
-      unsigned so[MT];
-      bool mv[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int m = (mh * MT + mt) * 16 + j;
-        mv[mt] = m < NPIX;
-        const int mm = mv[mt] ? m : 0;
-        mhy[mt] = mm / HW;
-        mhx[mt] = mm - mhy[mt] * HW;
-        xo[mt] = mhy[mt] * XW + mhx[mt] + 2 * kq;                              // + ky * XW: taps 2 kq, 2 kq + 1 of kernel row ky
-        so[mt] = (unsigned)(((kq >> 1) * NPIXP + mm) * 16 + (kq & 1) * 8);      // + (plane * 4 + 2 nt) * NPIXP * 16
-      }
-      // staging: pixels ptid and ptid + 256 of the XH x XW input tile
-      int sp_y[2], sp_x[2];
-      bool sp_on[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int pidx = ptid + 256 * i;
-        sp_on[i] = pidx < XPIX;
-        sp_y[i] = (sp_on[i] ? pidx : 0) / XW;
-        sp_x[i] = (sp_on[i] ? pidx : 0) - sp_y[i] * XW;
-      }
-      const size_t plane1 = (size_t)Z.IH1 * Z.IW1;
-      const size_t est = Z.x_nchw ? plane1 : 1;
-      float sv[2][4];
-      bool svok[2] = {false, false};
-      // tile walks: tw_* = the tile being computed, ts_* = the tile being staged (one ahead)
-      int ta_n = a_n, ta_y = a_y, ta_x = a_x, tb_n = b_n, tb_y = b_y, tb_x = b_x;   // compute walk (pair of list entries)
-      int sa_n = a_n, sa_y = a_y, sa_x = a_x, sb_n = b_n, sb_y = b_y, sb_x = b_x;   // staging walk
-      int ts = 0;
-      auto stage_issue = [&]() {
-        const bool live = ts < count;
-        const bool odd = ts & 1;
-        const int n = live ? (odd ? sb_n : sa_n) : 0, ty = live ? (odd ? sb_y : sa_y) : 0, tx = live ? (odd ? sb_x : sa_x) : 0;
-        if (odd) {
-          adv2(sa_n, sa_y, sa_x);
-          adv2(sb_n, sb_y, sb_x);
-        }
-        ++ts;
-        const int iy0 = ty * TH + P.iy0 - Z.pad1, ix0 = tx * TW + P.ix0 - Z.pad1;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int iy = iy0 + sp_y[i], ix = ix0 + sp_x[i];
-          svok[i] = live && sp_on[i] && (unsigned)iy < (unsigned)Z.IH1 && (unsigned)ix < (unsigned)Z.IW1;
-          const int cy = min(max(iy, 0), Z.IH1 - 1), cx = min(max(ix, 0), Z.IW1 - 1);
-          const size_t pix = (size_t)cy * Z.IW1 + cx;
-          const float* src = Z.x + (size_t)n * Z.IC1 * plane1 + (Z.x_nchw ? pix : pix * Z.IC1);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) sv[i][c] = src[(size_t)(c < Z.IC1 ? c : Z.IC1 - 1) * est];
-        }
-      };
-      auto stage_commit = [&](uint2* xb) {   // xb: [plane h | plane l][XPIX]
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          float v[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = (svok[i] && c < Z.IC1) ? sv[i][c] : 0.f;
-          uint2 ph, pl;
-          split2h(v[0], v[1], sx0, ph.x, pl.x);
-          split2h(v[2], v[3], sx0, ph.y, pl.y);
-          if (sp_on[i]) {
-            xb[ptid + 256 * i] = ph;
-            xb[XPIX + ptid + 256 * i] = pl;
-          }
-        }
-      };
-      stage_issue();
-      stage_commit(xin0);
-      __syncthreads();  // filter, counters and input tile 0 visible (the consumers arrive here as well)
-      if (count > 0) stage_issue();   // tile 1
-      long long fpt[5] = {0, 0, 0, 0, 0};
-      const long long fpt_begin = BFR_CLK_TOTAL();
-      for (int t = 0; t < count; ++t) {
-        const bool odd = t & 1;
-        // this wave's stage of tile t in the global order (pair, chunk, group) -- the consumers' order: a group's consecutive
-        // stages must never share a slot (it waits for the next one before it hands the current one back), which the
-        // tile-major order (t * ICC + chunk) does with three slots
-        const int ngp = (t | 1) < count ? 2 : 1;
-        const int sidx = (t >> 1) * 2 * ICC + nh * ngp + (t & 1);
-        const unsigned k = (unsigned)(sidx / nbuf);
-        const int b = sidx - (int)k * nbuf;
-        const int ty = odd ? tb_y : ta_y, tx = odd ? tb_x : ta_x;
-        if (odd) {
-          adv2(ta_n, ta_y, ta_x);
-          adv2(tb_n, tb_y, tb_x);
-        }
-        const int oy0 = ty * TH + P.iy0, ox0 = tx * TW + P.ix0;   // first-layer output position of halo pixel (0, 0)
-        const long long f0 = BFR_CLK();
-        if (t > 0) bfr_wait(cnt + 18, 4u * (unsigned)t, dead);   // (tile 0: the barrier above)
-        const long long f1 = BFR_CLK();
-        const uint2* xb = xin0 + (size_t)(t & 1) * (2 * XPIX);
-        f32x4 acc1[MT][2];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // pixel fragments three steps ahead (a step is 6 MFMAs = 96 cycles of the matrix pipe: one step of cover is less
-        // than the LDS latency beside the consumers' reads); sched_barriers keep the requests where they are written
-        constexpr int PF = 3, NS1 = MT * KH1;
-        uint4 xh[PF + 1], xl[PF + 1];  // [step % (PF + 1)]: planes h, l
-        auto ldX = [&](auto ic) {
-          constexpr int i = decltype(ic)::value, mtn = i / KH1, kyn = i - mtn * KH1;
-          const uint2* ph = xb + xo[mtn] + kyn * XW;
-          const uint2 h0 = ph[0], h1 = ph[1], l0 = ph[XPIX], l1 = ph[XPIX + 1];
-          xh[i % (PF + 1)] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-          xl[i % (PF + 1)] = make_uint4(l0.x, l0.y, l1.x, l1.y);
-        };
-        srk_static_for<0, PF>([&](auto ic) { ldX(ic); });
-        srk_static_for<0, NS1>([&](auto ic) {
-          constexpr int i = decltype(ic)::value, mt = i / KH1, ky = i - mt * KH1;
-          if constexpr (i + PF < NS1) ldX(std::integral_constant<int, i + PF>{});
-          __builtin_amdgcn_sched_barrier(0);
-          const uint4 bh = xh[i % (PF + 1)], bl = xl[i % (PF + 1)];
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = mfma16x<true>(w1[ky][0][nt], bl, acc1[mt][nt]);  // w_h * x_l
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = mfma16x<true>(w1[ky][1][nt], bh, acc1[mt][nt]);  // w_l * x_h
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) acc1[mt][nt] = mfma16x<true>(w1[ky][0][nt], bh, acc1[mt][nt]);  // w_h * x_h
-          __builtin_amdgcn_sched_barrier(0);
-        });
-        const long long f2 = BFR_CLK();
-        // bias, activation, zero outside the first layer's output (tiles on the image border only: wave-uniform test) and for
-        // the 12 lanes past the halo; the wave's maximum.  One packed fma per two values, ReLU as one med3, |.| in the max3.
-        const bool inner = oy0 >= 0 && ox0 >= 0 && oy0 + BFR_HH <= Z.OH1 && ox0 + HW <= Z.OW1;
-        float wmax = 0.f;
-        auto epilogue = [&](auto kindc, auto edgec) {
-          constexpr int KIND = decltype(kindc)::value;
-          constexpr bool EDGE = decltype(edgec)::value;
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            bool in1 = mv[mt];
-            if constexpr (EDGE) in1 = in1 && (unsigned)(oy0 + mhy[mt]) < (unsigned)Z.OH1 && (unsigned)(ox0 + mhx[mt]) < (unsigned)Z.OW1;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-              f32x4 v = __builtin_elementwise_fma(acc1[mt][nt], (f32x4){dsc1, dsc1, dsc1, dsc1}, bias1v[nt]);
-              if constexpr (KIND == 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.f, __builtin_inff());
-              } else if constexpr (KIND == 2) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : slope1 * v[e];
-              }
-              if constexpr (EDGE) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = in1 ? v[e] : 0.f;
-              } else if (mt == MT - 1) {   // (the 12 lanes past the halo live in the last M tile of the second half)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = in1 ? v[e] : 0.f;
-              }
-              acc1[mt][nt] = v;
-              wmax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), wmax);
-              wmax = fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), wmax);
-            }
-          }
-        };
-        {
-          using K0 = std::integral_constant<int, 0>;
-          using K1 = std::integral_constant<int, 1>;
-          using K2 = std::integral_constant<int, 2>;
-          const int kind = slope1 == 0.f ? 1 : (slope1 == 1.f ? 0 : 2);
-          if (inner) {
-            if (kind == 1) epilogue(K1{}, std::false_type{}); else if (kind == 0) epilogue(K0{}, std::false_type{}); else epilogue(K2{}, std::false_type{});
-          } else {
-            if (kind == 1) epilogue(K1{}, std::true_type{}); else if (kind == 0) epilogue(K0{}, std::true_type{}); else epilogue(K2{}, std::true_type{});
-          }
-        }
-        wmax = wave_max(wmax);
-        asm volatile("" ::: "memory");
-        if (lane == 0) {
-          __hip_atomic_fetch_max(cnt + 20 + (t & 3), __float_as_uint(wmax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (pw == 0) __hip_atomic_store(cnt + 20 + ((t + 2) & 3), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        bfr_signal(cnt + 19);
-        const long long f3 = BFR_CLK();
-        // input tile t + 1 into the other buffer, the loads of tile t + 2 behind it
-        stage_commit(xin0 + (size_t)((t + 1) & 1) * (2 * XPIX));
-        bfr_signal(cnt + 18);
-        stage_issue();
-        const long long f4 = BFR_CLK();
-        bfr_wait(cnt + 19, 4u * (unsigned)(t + 1), dead);
-        const long long f5 = BFR_CLK();
-        const float tmax = __uint_as_float(bfr_peek(cnt + 20 + (t & 3)));
-        const int kt = tmax > 0.f ? amax_scale_exp(tmax) + 1 : 0;
-        const float st = exp2i(kt);
-        bfr_wait(cnt + BFR_MAXBUF + b, NGW * k, dead);
-        const long long f6 = BFR_CLK();
-        char* slot = reinterpret_cast<char*>(hal0 + (size_t)b * HBUF);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          if (mv[mt]) {
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-              const f32x4 v = acc1[mt][nt];
-              uint2 h, m;
-              split2h(v[0], v[1], st, h.x, m.x);
-              split2h(v[2], v[3], st, h.y, m.y);
-              *reinterpret_cast<uint2*>(slot + so[mt] + (unsigned)((2 * nt) * NPIXP * 16)) = h;
-              *reinterpret_cast<uint2*>(slot + so[mt] + (unsigned)((4 + 2 * nt) * NPIXP * 16)) = m;
-            }
-          }
-        }
-        if (lane == 0) __hip_atomic_store(cnt + 12 + b, (unsigned)(kt + 1024), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        bfr_signal(cnt + b);
-        // (profile: [0] wait free, [1] rendezvous waits, [2] K steps, [3] epilogue + split + write, [4] staging)
-        fpt[0] += f6 - f5; fpt[1] += (f1 - f0) + (f5 - f4); fpt[2] += f2 - f1; fpt[3] += (f3 - f2) + (BFR_CLK() - f6); fpt[4] += f4 - f3;
-      }
-#ifdef BFR_PROF
-      if (B.prof && tid == 64 * NCW) {
-        long long* pr = B.prof + (size_t)blockIdx.x * 16;
-        for (int i = 0; i < 5; ++i) pr[i] = fpt[i];
-        pr[5] = BFR_CLK_TOTAL() - fpt_begin;
-      }
-#endif
-      (void)fpt; (void)fpt_begin;
-      if (dead && lane == 0) atomicAdd(&g_bfr_timeouts, 1u);
-      return;
-    }
-  }
-  if (!FUSE && producer) {
+  if (producer) {
     // ------------------------------------------------------------------ producers
     if (prio == 1) __builtin_amdgcn_s_setprio(1);
     const int ptid = tid - 64 * NCW;
@@ -594,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfrParams BP) {
     }
 #endif
     (void)pt; (void)pt_begin;
-    if (dead && lane == 0) atomicAdd(&g_bfr_timeouts, 1u);
+    if (dead) bfr_fail(lane);
     return;
   }
 
@@ -634,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfrParams BP) {
   f32x4 acc[NTW][MR];
   f32x4 pend[NTW][MR];  // the finished tile, stored under the next tile's MFMAs
   float amax = 0.f;
-  float dsc_t = dsc;    // descale of the tile at hand (fused: from the tile's own scale exponent, left beside the slot)
+  const float dsc_t = dsc;
   constexpr unsigned kDrop = 0x80000000u;
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(P.out, 0, B.out_bytes, 0x00020000);
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -781,10 +511,6 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfrParams BP) {
       // the next own stage: its slot, its use count, whether it exists
       const bool has_next = cc + 1 < ICC || ti + 2 < count;
       int nb = b + (cc + 1 < ICC ? ng : 2 * ICC - (ICC - 1) * ng);
-      if constexpr (FUSE && cc == 0) {  // (the slot is known to be full: the tile's scale exponent is there)
-        const int kt = (int)bfr_peek(cnt + 12 + b) - 1024;
-        dsc_t = exp2i(-kt) * B.w_descale[0];
-      }
       unsigned nk = k;
       while (nb >= nbuf) {
         nb -= nbuf;
@@ -870,7 +596,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfrParams BP) {
 #endif
   (void)ct; (void)ct_begin;
   if (P.ep.y_amax) amax_commit(P.ep.y_amax, amax, blockIdx.x + wave, amax_peek(P.ep.y_amax, blockIdx.x + wave));
-  if (dead && lane == 0) atomicAdd(&g_bfr_timeouts, 1u);
+  if (dead) bfr_fail(lane);
 }
 
 template <int NTW, int ICC>
@@ -881,13 +607,13 @@ static int bfr_launch_t(const BfwParams& B, size_t lds, int grid, hipStream_t s)
     static LdsLimit limh;
     limh.ensure(reinterpret_cast<const void*>(&k_conv_bfr<NTW, ICC, true>), lds);
     note_kernel("k_conv_bfr<%d,%d,f16>", NTW, ICC);
-    hipLaunchKernelGGL((k_conv_bfr<NTW, ICC, true>), dim3(grid), blk, lds, s, BfrParams{B, BfrFuse{}});
+    hipLaunchKernelGGL((k_conv_bfr<NTW, ICC, true>), dim3(grid), blk, lds, s, B);
     return check_launch("conv_bfr");
   }
   static LdsLimit lim;
   lim.ensure(reinterpret_cast<const void*>(&k_conv_bfr<NTW, ICC, false>), lds);
   note_kernel("k_conv_bfr<%d,%d>", NTW, ICC);
-  hipLaunchKernelGGL((k_conv_bfr<NTW, ICC, false>), dim3(grid), blk, lds, s, BfrParams{B, BfrFuse{}});
+  hipLaunchKernelGGL((k_conv_bfr<NTW, ICC, false>), dim3(grid), blk, lds, s, B);
   return check_launch("conv_bfr");
 }
 
@@ -939,73 +665,6 @@ int conv_bfr_launch(const BfwParams& B0, hipStream_t s) {
             wbytes, B.nbuf, slot_bytes, grid, ntiles);
   if (ntw == 2) return B.ICc == 1 ? bfr_launch_t<2, 1>(B, lds, grid, s) : bfr_launch_t<2, 2>(B, lds, grid, s);
   return bfr_launch_t<3, 1>(B, lds, grid, s);
-}
-
-// The fused pair (FUSE above): conv1 = a stride-1 Cin <= 4 KH x KW conv with 64 output channels and a branch-free scalar
-// activation (ESPCN's 3 -> 64 5x5 + ReLU), conv2 = a stride-1 3x3 conv 64 -> 32 (f16x3).  Both in the arithmetic of
-// SRK_ALGO_MFMA_F16X3; ep1.x_amax = running maximum of the network input, ep2.y_amax as usual.  -1: not this shape.
-int conv_bfr_fused(const GatherConv& g1, const float* x, const float* wp1, const Epi& ep1, const GatherConv& g2, const float* wp2,
-                   float* out, const Epi& ep2, hipStream_t s) {
-  if (g1.trans || g2.trans || g1.stride != 1 || g2.stride != 1 || g1.IC > 4 || g1.IC < 1 || g1.OC != 64 || g1.KH != 5 || g1.KW != 5)
-    return -1;
-  if (g2.IC != 64 || g2.OC != 32 || g2.KH != 3 || g2.KW != 3 || g2.in_nchw || g2.in_ps_r > 1 || g1.in_ps_r > 1) return -1;
-  if (g2.IH != g1.OH || g2.IW != g1.OW || g2.N != g1.N || !ep1.x_amax) return -1;
-  if (ep1.residual || ep1.ps_r > 1 || (ep1.act == SRK_ACT_PRELU && ep1.prelu_n > 1)) return -1;
-  if (ep1.act != SRK_ACT_NONE && ep1.act != SRK_ACT_RELU && ep1.act != SRK_ACT_LRELU) return -1;   // (PReLU: its slope lives on the device)
-  if (ep2.residual || ep2.ps_r > 1 || (ep2.act == SRK_ACT_PRELU && ep2.prelu_n > 1) || !conv_epi_all_vector(g2.OC, ep2, out)) return -1;
-  if (ep2.act != SRK_ACT_NONE && ep2.act != SRK_ACT_RELU && ep2.act != SRK_ACT_LRELU && ep2.act != SRK_ACT_PRELU) return -1;
-  if ((ep1.bias && (uintptr_t)ep1.bias % 16 != 0) || (long)g2.N * g2.OH * g2.OW * g2.OC >= (1L << 29)) return -1;
-  if ((long)g1.IH * g1.IW >= (1L << 30)) return -1;
-  BfrParams BP{};
-  BfwParams& B = BP.B;
-  const size_t e2 = (size_t)9 * g2.IC * g2.OC;
-  const char* prep2 = reinterpret_cast<const char*>(wp2) + bf3_prepared_offset(e2);
-  const char* fsec2 = prep2 + f16_section_offset(g2.IC, g2.OC, 9);
-  B.wq = reinterpret_cast<const uint4*>(fsec2);
-  B.w_descale = reinterpret_cast<const float*>(fsec2 + bf3_main_bytes(g2.IC, g2.OC, 9));
-  const size_t e1 = (size_t)g1.KH * g1.KW * g1.IC * g1.OC;
-  const char* prep1 = reinterpret_cast<const char*>(wp1) + bf3_prepared_offset(e1);
-  const char* fsec1 = prep1 + f16_section_offset(g1.IC, g1.OC, g1.KH * g1.KW);
-  BfrFuse& Z = BP.Z;
-  Z.x = x;
-  Z.w1q = reinterpret_cast<const uint4*>(fsec1);
-  Z.w1_descale = reinterpret_cast<const float*>(fsec1 + bf3_main_bytes(g1.IC, g1.OC, g1.KH * g1.KW));
-  Z.bias1 = ep1.bias;
-  Z.x_amax = ep1.x_amax;
-  Z.slope1 = ep1.act == SRK_ACT_NONE ? 1.f : (ep1.act == SRK_ACT_RELU ? 0.f : ep1.slope);
-  Z.IC1 = g1.IC; Z.IH1 = g1.IH; Z.IW1 = g1.IW; Z.OH1 = g1.OH; Z.OW1 = g1.OW; Z.pad1 = g1.pad; Z.x_nchw = g1.in_nchw;
-  return for_each_phase(g2, nullptr, wp2, out, ep2, nullptr, 0.f, [&](const MfmaConvParams& P0) {
-    B.P = P0;
-    MfmaConvParams& P = B.P;
-    B.nsl = 1; B.NBfull = 32; B.OCb = 1; B.NB = 32; B.ICc = 2; B.perm = 1; B.NPIXp = BFR_NPIXP;
-    B.late = env_int("SRK_BFR_PRIO", 2);
-    P.TH = BFR_TH; P.TW = BFR_TW; P.HH = BFR_HH; P.HW = BFR_HW;
-    P.tiles_y = (P.PH + BFR_TH - 1) / BFR_TH;
-    P.tiles_x = (P.PW + BFR_TW - 1) / BFR_TW;
-    const long ntiles = (long)P.tiles_x * P.tiles_y * P.N;
-    if (ntiles >= (1L << 29)) return -1;
-    constexpr int XPIX = (BFR_HH + 4) * 26;
-    const size_t wbytes = (size_t)9 * 2 * 8 * 32 * 16, slot_bytes = (size_t)8 * BFR_NPIXP * 16, xin_bytes = (size_t)2 * XPIX * 16;
-    const long lds_cap = 160L * 1024 - 512 - BFR_CNT_BYTES - (long)xin_bytes;
-    long nbuf = (lds_cap - (long)wbytes) / (long)slot_bytes;
-    if (nbuf > BFR_MAXBUF) nbuf = BFR_MAXBUF;
-    if (nbuf < 3) return -1;
-    B.nbuf = (int)nbuf;
-    const size_t lds = wbytes + (size_t)nbuf * slot_bytes + BFR_CNT_BYTES + xin_bytes;
-    B.ntiles = (int)ntiles;
-#ifdef BFR_PROF
-    B.prof = g_bfr_prof;
-#endif
-    B.out_bytes = (unsigned)((size_t)P.N * P.OH * P.OW * P.OC * sizeof(float));
-    int grid = kNumCU;
-    if (grid > ntiles) grid = (int)ntiles;
-    note_amax_written(P.ep.y_amax != nullptr);
-    static LdsLimit lim;
-    lim.ensure(reinterpret_cast<const void*>(&k_conv_bfr<2, 2, true, true, 5>), lds);
-    note_kernel("k_conv_bfr<2,2,f16,fused5>");
-    hipLaunchKernelGGL((k_conv_bfr<2, 2, true, true, 5>), dim3(grid), dim3(512), lds, s, BP);
-    return check_launch("conv_bfr_fused");
-  });
 }
 
 }  // namespace srk

@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import ops, utils
 from ._lib import ACT_RELU
-from .base_networks import ConvBlock, DeconvBlock, DenseBlock, PSBlock, ResnetBlock, Upsample2xBlock, fused_conv_pair
+from .base_networks import ConvBlock, DeconvBlock, DenseBlock, PSBlock, ResnetBlock, Upsample2xBlock
 from .layers import Conv2d, ConvTranspose2d, PReLU, grad_mode
 
 
@@ -51,11 +51,6 @@ class ESPCNNet(nn.Module):
             PSBlock(base_filter // 2, num_channels, scale_factor, 3, 1, 0, activation=None, norm=None))
 
     def forward(self, x):
-        # inference at benchmark size: the 5x5 layer is recomputed inside the 3x3 layer's kernel (its 64-channel output --
-        # half of the HBM bytes of the forward -- never exists); None: the pair is not covered, run the layers one by one
-        h = fused_conv_pair(self.layers[0], self.layers[1], x)
-        if h is not None:
-            return self.layers[2](h)
         return self.layers(x)
 
     def weight_init(self):

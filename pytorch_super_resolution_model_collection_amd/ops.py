@@ -401,17 +401,15 @@ def conv_forward_raw(x, wp, bias_p, weight_shape_src, cfg, prelu_w=None, residua
     if d.x_nchw and d.algo not in (ALGO_AUTO, _lib.ALGO_MFMA_BF16X3, _lib.ALGO_MFMA_F16X3):
         x = to_nhwc(x)      # only the bf16x3 / f16x3 first-layer kernels read an NCHW input in place
         d.x_nchw = 0
-    # what the dispatched kernel did comes back through the epilogue's out-fields (two host ints)
-    outs = (ctypes.c_int32 * 2)(0, 0)
-    ep.wrote_amax = ctypes.cast(ctypes.byref(outs, 0), ctypes.POINTER(ctypes.c_int32))
-    ep.bn_partial_rows = ctypes.cast(ctypes.byref(outs, 4), ctypes.POINTER(ctypes.c_int32))
-    check(lib.srk_conv2d_forward(ctypes.byref(d), ptr(x), ptr(wp), ptr(y), ctypes.byref(ep), stream_ptr()),
+    # what the dispatched kernel did comes back in a host struct of the caller's (srk_conv_result)
+    res = _lib.ConvResult()
+    check(lib.srk_conv2d_forward_ex(ctypes.byref(d), ptr(x), ptr(wp), ptr(y), ctypes.byref(ep), ctypes.byref(res), stream_ptr()),
           "srk_conv2d_forward")
     if bnp is not None:
-        rows_p = int(outs[1])
+        rows_p = int(res.bn_partial_rows)
         if rows_p > 0:
             y._srk_bn_partial = (bnp, rows_p, _ver(y))
-    if ya is not None and outs[0]:
+    if ya is not None and res.wrote_amax:
         _tag_amax(y, ya)
     elif F16X3 and d.algo in (_lib.ALGO_MFMA, _lib.ALGO_MFMA_BF16X6):
         _tag_amax(y, None)   # a faithful-class conv whose kernel leaves no maximum: worth one srk_absmax pass downstream
@@ -872,47 +870,6 @@ def conv2d_infer(x, weight, bias=None, residual=None, cfg=None, prelu_w=None, pa
         wp = pack_weight_fwd(weight, cfg.transposed, cfg.ps_r)
         bp = pack_bias_ps(bias, cfg.ps_r)
     return conv_forward_raw(x, wp, bp, weight, cfg, prelu_w, residual, "infer", x_nchw)
-
-
-# Fused conv pairs (srk_conv2d_pair_forward).  "1": whenever the kernel covers the pair; anything else: never.  OFF by
-# default: the round-5 kernel is correct (tests/test_ops_gpu.py::test_conv_pair_fused) but its four producer waves carry ~930
-# instructions per tile against the consumers' ~365 and pace the launch at 0.93 ms for the c2 pair, against 0.70 ms for the two
-# launches it replaces (measured, with what a balanced split of the roles would need).
-PAIR = os.environ.get("SRK_PAIR")
-
-
-def conv_pair_infer(x, w1, b1, cfg1, packed1, w2, b2, cfg2, prelu2, packed2):
-    """No-grad fused pair: act2(conv2(act1(conv1(x)))) as ONE launch (srk_conv2d_pair_forward: espcn.py:17-19), or None when
-    the pair is not one the kernel covers / the problem is too small to pay -- the caller then runs the two layers."""
-    if PAIR != "1" or not F16X3 or get_precision() != "mixed" or x.dim() != 4 or not x.is_cuda:
-        return None
-    if cfg1.transposed or cfg2.transposed or cfg1.ps_r > 1 or cfg2.ps_r > 1:
-        return None
-    lib = _lib.load()
-    cout1, cin1, _, _ = _weight_dims(w1, False)
-    if cin1 > 4 or not (_is_nchw_dense(x) or _is_nhwc_dense(x)):
-        return None
-    x_nchw = not _is_nhwc_dense(x)
-    d1 = _make_desc(x.shape, w1, cfg1, "infer")
-    d1.x_nchw = int(x_nchw)
-    d2 = _make_desc((d1.N, d1.Cout, d1.OH, d1.OW), w2, cfg2, "infer")
-    wp1, bp1 = packed1 if packed1 is not None else (pack_weight_fwd(w1, False, 0), pack_bias_ps(b1, 0))
-    wp2, bp2 = packed2 if packed2 is not None else (pack_weight_fwd(w2, False, 0), pack_bias_ps(b2, 0))
-    y = _empty_cl(d2.N, d2.Cout, d2.OH, d2.OW, x)
-    ep1 = Epilogue(ptr(bp1), None, None, cfg1.slope, cfg1.act, 0, 0, None, None, None)
-    ep2 = Epilogue(ptr(bp2), ptr(prelu2), None, cfg2.slope, cfg2.act, 0 if prelu2 is None else prelu2.numel(), 0, None, None, None)
-    if not lib.srk_conv2d_pair_supported(ctypes.byref(d1), ctypes.byref(ep1), ctypes.byref(d2), ctypes.byref(ep2), ptr(y)):
-        return None
-    ep1.x_amax = ptr(amax_of(x, compute=True))     # the network input: one pass over a <= 4-channel tensor
-    ya = _amax_alloc(y.device)
-    ep2.y_amax = ptr(ya)
-    wrote = ctypes.c_int32(0)
-    ep2.wrote_amax = ctypes.pointer(wrote)
-    check(lib.srk_conv2d_pair_forward(ctypes.byref(d1), ptr(x), ptr(wp1), ctypes.byref(ep1), ctypes.byref(d2), ptr(wp2), ptr(y),
-                                      ctypes.byref(ep2), stream_ptr()), "srk_conv2d_pair_forward")
-    if wrote.value:
-        _tag_amax(y, ya)
-    return y
 
 
 # ------------------------------------------------------------------------------------------------

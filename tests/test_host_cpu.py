@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for s in syms:
         assert hasattr(lib, s), s
     assert set(syms) == set(pkg._lib._PROTOTYPES), "ctypes prototypes out of sync with include/srk.h"
-    assert lib.srk_version() == 100
+    assert lib.srk_version() == 600
     assert lib.srk_status_string(-2) == b"unsupported configuration"
     # geometry helper is pure host code
     assert lib.srk_conv_out_dim(256, 5, 1, 0, 0, 0) == 252

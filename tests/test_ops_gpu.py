@@ -366,59 +366,6 @@ def test_conv_wave_specialized_ring(gpu, monkeypatch, cin, cout, H, W, N, act, p
     assert rel_err(outs["1"], ref.float()) < (2e-6 if mode == "mixed" else 1e-4)
 
 
-@pytest.mark.parametrize("N,H,W,act1,act2,nchw", [
-    (2, 40, 52, "relu", "relu", True),       # ESPCN's first two layers on an NCHW batch read in place, one tile per block
-    (3, 100, 130, "relu", "relu", True),     # ragged tiles on both edges, pairs of tiles per block
-    (2, 61, 47, "lrelu", None, False),       # leaky first layer, no activation behind the second, NHWC input
-    (5, 70, 150, None, "prelu", True),       # no activation in front, scalar PReLU behind; several tiles per block
-])
-def test_conv_pair_fused(gpu, monkeypatch, N, H, W, act1, act2, nchw):
-    """srk_conv2d_pair_forward (espcn.py:17-19): conv 3 -> 64 5x5 + act and conv 64 -> 32 3x3 + act as ONE launch -- the first
-    layer recomputed by the producer waves of the ring kernel on every tile's halo, the intermediate split with the tile's own
-    maximum.  Against torch fp64, against the two-launch form, through the module (ESPCNNet under SRK_PAIR=1), and no poll of
-    the ring may run into its cap."""
-    pkg = _pkg()
-    ops = pkg.ops
-    lib = pkg._lib.load()
-    x = fill.rand((N, 3, H, W), 601)
-    w1 = fill.randn((64, 3, 5, 5), 602, (2.0 / 75) ** 0.5)
-    b1 = fill.randn((64,), 603, 0.1)
-    w2 = fill.randn((32, 64, 3, 3), 604, (2.0 / 576) ** 0.5)
-    b2 = fill.randn((32,), 605, 0.1)
-    slope = torch.tensor([0.3])
-
-    def act(t, a):
-        if a == "relu":
-            return torch.relu(t)
-        if a == "lrelu":
-            return torch.nn.functional.leaky_relu(t, 0.2)
-        if a == "prelu":
-            return torch.nn.functional.prelu(t, slope.double())
-        return t
-    ref = act(torch.nn.functional.conv2d(act(torch.nn.functional.conv2d(x.double(), w1.double(), b1.double()), act1),
-                                         w2.double(), b2.double()), act2)
-    code = {None: 0, "relu": 1, "lrelu": 3, "prelu": pkg._lib.ACT_PRELU}
-    cfg1 = ops.ConvCfg(1, 0, False, 0, code[act1], 0.2 if act1 == "lrelu" else 0.0, 0)
-    cfg2 = ops.ConvCfg(1, 0, False, 0, code[act2], 0.2 if act2 == "lrelu" else 0.0, 0)
-    xg = x.to(gpu)
-    if not nchw:
-        xg = xg.contiguous(memory_format=torch.channels_last)
-    monkeypatch.setattr(ops, "PAIR", "1")
-    monkeypatch.setattr(ops, "F16X3_ALWAYS", True)
-    ops.set_precision("mixed")
-    lib.srk_ring_timeouts(1)
-    pw = slope.to(gpu) if act2 == "prelu" else None
-    with torch.no_grad():
-        y = ops.conv_pair_infer(xg, w1.to(gpu), b1.to(gpu), cfg1, None, w2.to(gpu), b2.to(gpu), cfg2, pw, None)
-        assert y is not None and lib.srk_last_kernel_name().decode().startswith("k_conv_bfr<2,2,f16,fused")
-        y2 = ops.conv2d_infer(ops.conv2d_infer(xg, w1.to(gpu), b1.to(gpu), None, cfg1), w2.to(gpu), b2.to(gpu), None, cfg2, pw)
-    assert lib.srk_ring_timeouts(1) == 0
-    assert tuple(y.shape) == tuple(ref.shape)
-    assert rel_err(y, ref.float()) < 2e-6
-    assert rel_err(y, y2) < 3e-6
-    assert float(y._srk_amax[0].max()) == float(y.abs().max())      # the running maximum for the layer behind the pair
-
-
 @pytest.mark.parametrize("fan_out", [False, True])
 def test_premasked_gradients(gpu, monkeypatch, fan_out):
     """Chain of conv + ReLU layers whose data gradients run on k_conv_bfw: each dx leaves multiplied by the ReLU gradient
@@ -1111,14 +1058,20 @@ def test_conv_says_whether_it_wrote_the_running_maximum(gpu, monkeypatch):
                                     pkg._lib.stream_ptr())
         assert rc == 0 and lib.srk_last_conv_wrote_amax() == 1
         assert float(ya.max()) == float(yy.abs().max())
-        # the same answers through the epilogue's out-fields (srk_epilogue.wrote_amax / .bn_partial_rows: host ints the call
-        # fills; the srk_last_conv_* queries above are deprecated aliases of them)
-        outs = (ctypes.c_int32 * 2)(7, 7)
-        ep.wrote_amax = ctypes.cast(ctypes.byref(outs, 0), ctypes.POINTER(ctypes.c_int32))
-        ep.bn_partial_rows = ctypes.cast(ctypes.byref(outs, 4), ctypes.POINTER(ctypes.c_int32))
-        assert lib.srk_conv2d_forward(ctypes.byref(d), pkg._lib.ptr(xs), pkg._lib.ptr(wp), pkg._lib.ptr(yy), ctypes.byref(ep),
-                                      pkg._lib.stream_ptr()) == 0
-        assert (outs[0], outs[1]) == (1, 0)
+        # the same answers in the caller's srk_conv_result (srk_conv2d_forward_ex; the srk_last_conv_* queries above are
+        # deprecated aliases of its fields)
+        res = pkg._lib.ConvResult()
+        res.wrote_amax, res.bn_partial_rows = 7, 7
+        assert lib.srk_conv2d_forward_ex(ctypes.byref(d), pkg._lib.ptr(xs), pkg._lib.ptr(wp), pkg._lib.ptr(yy), ctypes.byref(ep),
+                                         ctypes.byref(res), pkg._lib.stream_ptr()) == 0
+        assert (res.wrote_amax, res.bn_partial_rows) == (1, 0)
+        # a caller compiled against a SHORTER struct (here: one that ends behind wrote_amax) gets only the fields it knows
+        res.struct_size, res.wrote_amax, res.bn_partial_rows = 8, 7, 7
+        assert lib.srk_conv2d_forward_ex(ctypes.byref(d), pkg._lib.ptr(xs), pkg._lib.ptr(wp), pkg._lib.ptr(yy), ctypes.byref(ep),
+                                         ctypes.byref(res), pkg._lib.stream_ptr()) == 0
+        assert (res.wrote_amax, res.bn_partial_rows) == (1, 7)
+        assert lib.srk_conv2d_forward_ex(ctypes.byref(d), pkg._lib.ptr(xs), pkg._lib.ptr(wp), pkg._lib.ptr(yy), ctypes.byref(ep),
+                                         None, pkg._lib.stream_ptr()) == 0
         # ... a call without y_amax says 0, and so does the shape-agnostic kernel
         ep = pkg._lib.Epilogue(None, None, None, 0.0, 1, 0, 0, None, None)
         assert lib.srk_conv2d_forward(ctypes.byref(d), pkg._lib.ptr(xs), pkg._lib.ptr(wp), pkg._lib.ptr(yy), ctypes.byref(ep),
@@ -1328,10 +1281,10 @@ def test_conv_c64_leaves_batchnorm_column_sums(gpu, shape):
     assert lib.srk_conv2d_forward(ctypes.byref(d), L.ptr(x), L.ptr(wp), L.ptr(y), ctypes.byref(ep), L.stream_ptr()) == 0
     assert lib.srk_last_kernel_name().decode().startswith("k_c64<")
     assert lib.srk_last_conv_bn_partial_rows() == tiles
-    rows_out = ctypes.c_int32(-1)       # ... and through the out-field
-    ep.bn_partial_rows = ctypes.pointer(rows_out)
-    assert lib.srk_conv2d_forward(ctypes.byref(d), L.ptr(x), L.ptr(wp), L.ptr(y), ctypes.byref(ep), L.stream_ptr()) == 0
-    assert rows_out.value == tiles
+    res = L.ConvResult()                # ... and in the caller's srk_conv_result
+    assert lib.srk_conv2d_forward_ex(ctypes.byref(d), L.ptr(x), L.ptr(wp), L.ptr(y), ctypes.byref(ep), ctypes.byref(res),
+                                     L.stream_ptr()) == 0
+    assert res.bn_partial_rows == tiles
     yd = y.double()
     s_ref = torch.cat([yd.sum((0, 2, 3)), (yd * yd).sum((0, 2, 3))])
     assert rel_err(part.sum(0), s_ref) < 1e-12
