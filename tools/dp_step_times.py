@@ -83,3 +83,16 @@ for name, use_dp, graphed in (("plain", False, False), ("dp_eager", True, False)
         step.close()
 dist.barrier()
 dist.destroy_process_group()
+
+# hypothesis check: what ONE full (generation-2) collection of this process's heap costs -- an automatic one lands inside
+# whichever step crosses the threshold
+t0 = time.perf_counter()
+n = gc.collect()
+print("full gc.collect(): %.1f ms, %d unreachable, %d tracked objects" % (1e3 * (time.perf_counter() - t0), n, len(gc.get_objects())))
+t0 = time.perf_counter()
+gc.collect()
+print("second full gc.collect(): %.1f ms" % (1e3 * (time.perf_counter() - t0)))
+gc.freeze()
+t0 = time.perf_counter()
+gc.collect()
+print("after gc.freeze(): %.1f ms" % (1e3 * (time.perf_counter() - t0)))
