@@ -799,6 +799,7 @@ def main():
     # 50+ 1.01 ms), so W = 5 warm-up steps alone would leave the whole timed window -- and the layer times -- inside that ramp.
     # Disclosed in the line: extra.c2_cold_window_ms_per_step is the same W + K window behind 2 s of idle,
     # extra.c2_power_probe.ms_per_step_while_sampling the rate sustained over seconds.
+    pkg.trainers.quiesce_gc()   # set-up is done: no full cyclic collection (~80 ms with torch loaded) inside a timed window
     layer_ms, layer_kernels = espcn_layer_events(net, xs, max(3, min(args.steps, 10)), discard=30)
     sec = time_steps(step, args.steps, args.warmup, world, dev)
     imgs_per_s = world * args.batch * args.steps / sec

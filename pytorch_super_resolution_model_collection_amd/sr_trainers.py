@@ -155,6 +155,7 @@ class _Trainer(object):
             loader = self.load_dataset(self.train_dataset, is_train=True)
             self.data_source = "folder" if loader is not None else "synthetic"
         self._announce_data()
+        trainers.quiesce_gc()    # no full cyclic collection (~80 ms) inside a step from here on
         for epoch in range(self.num_epochs):
             self.lr_decay(epoch, self.optimizer)
             batches = loader if loader is not None else synthetic_loader(self.kind, self.args, self.steps_per_epoch,
@@ -371,6 +372,7 @@ class SRGAN(_Trainer):
             loader = self.load_dataset(self.train_dataset, is_train=True)
             self.data_source = "folder" if loader is not None else "synthetic"
         self._announce_data()
+        trainers.quiesce_gc()    # no full cyclic collection (~80 ms) inside a step from here on
 
         def batches(seed):   # loaders yield (lr, hr) or the reference's (lr, hr, bicubic) tuples (dataset.py:101)
             for batch in (loader or synthetic_loader("srgan", self.args, self.steps_per_epoch, self.device, seed)):
