@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsrk.so")
-SOURCES = ["api.hip", "elementwise.hip", "loss_optim.hip", "conv_generic.hip", "conv_mfma.hip", "conv_mfma_bf16.hip", "conv_bfd.hip", "conv_tapn.hip", "conv_bfw.hip", "conv_bfr.hip", "conv_rowsw.hip", "conv_res2.hip", "conv_c64.hip",
+SOURCES = ["api.hip", "elementwise.hip", "loss_optim.hip", "conv_generic.hip", "conv_mfma.hip", "conv_mfma_bf16.hip", "conv_bfd.hip", "conv_tapn.hip", "conv_rown.hip", "conv_bfw.hip", "conv_bfr.hip", "conv_rowsw.hip", "conv_res2.hip", "conv_c64.hip",
            "conv_wgrad_mfma.hip", "conv_wgrad_bf16.hip", "bn_linear.hip", "resize_pil.hip", "prepost.hip"]
 HEADERS = ["srk_common.h", "conv_problem.h", "conv_tile.h", "pack_items.h", "conv_bfw.h", "bf16_frag.h", os.path.join("..", "..", "include", "srk.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5",

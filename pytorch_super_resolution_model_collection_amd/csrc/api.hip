@@ -73,6 +73,10 @@ void note_amax_written(bool written) { g_amax_written = written ? 1 : 0; }
 static thread_local int g_bn_partial_rows = 0;
 void note_bn_partial_rows(int rows) { g_bn_partial_rows = rows; }
 
+// conv_rown.hip
+bool conv_rown_gather_supported(const GatherConv& g, const float* in, const float* mask_y);
+int conv_rown_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, bool x6,
+                     hipStream_t s);
 // conv_tapn.hip
 bool conv_tapn_gather_supported(const GatherConv& g, const float* in, const float* mask_y);
 int conv_tapn_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, bool x6,
@@ -214,6 +218,11 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
     set_error("%s: MFMA kernel does not cover this shape", who);
     return SRK_ERR_UNSUPPORTED;
   }
+  // few-output-channel convs with more taps than one 32-column group holds (9x9 / 5x5 x 3 channels): kernel rows on N,
+  // kernel columns in K, one GEMM per input row
+  if ((algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3 || algo == SRK_ALGO_MFMA_BF16X6) &&
+      conv_rown_gather_supported(g, in, mask_y))
+    return conv_rown_gather(g, in, wp, out, ep, algo == SRK_ALGO_MFMA_BF16X6, s);
   // few-output-channel 3x3 convs (the 64 -> 3 reconstruction layers): taps-as-N bf16x6 kernel for every bf16 class
   if ((algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3 || algo == SRK_ALGO_MFMA_BF16X6) &&
       conv_tapn_gather_supported(g, in, mask_y))

@@ -17,7 +17,7 @@ from oracle.kat_table import CONV_KATS, conv_case_inputs
 
 pytestmark = pytest.mark.gpu
 
-ALGOS = {"auto": 0, "generic": 1, "mfma_fp32": 2, "bf16x6": 5}
+ALGOS = {"auto": 0, "generic": 1, "mfma_fp32": 2, "bf16x3": 4, "bf16x6": 5}
 # AUTO runs the bf16x3 split-MFMA kernels where they apply (~1e-5 rel); generic / fp32 MFMA are exact-order fp32
 # and bf16x6 (exact 3-way operand split, 6 bf16 MFMAs) is held to the same tolerance as them.
 # variant -> (algo, env): the env switches pick the kernel family / block configuration that a problem of
@@ -104,7 +104,9 @@ def test_conv_infer_fused_epilogue(gpu, idx):
 def test_conv_few_output_channels(gpu, cin, cout, k, p, H, W, N, algo):
     """The taps-as-N kernel (KH*KW*Cout <= 32 columns, conv_tapn.hip) against torch fp64 on CPU, held to the
     exact-fp32 tolerance in every precision class (it always runs the exact 3-way split); bias + LeakyReLU +
-    residual go through its scalar epilogue."""
+    residual go through its scalar epilogue.  Kernels with more taps than one 32-column group (9x9, 5x5, 7x7) run
+    k_conv_rown (conv_rown.hip: kernel rows on N, one GEMM per input row) -- bf16x6 here in both classes too ("auto" in the
+    fp32-faithful mode of the suite resolves to the exact split)."""
     pkg = _pkg()
     ops = pkg.ops
     x = fill.randn((N, cin, H, W), 71)
@@ -116,7 +118,45 @@ def test_conv_few_output_channels(gpu, cin, cout, k, p, H, W, N, algo):
     cfg = ops.ConvCfg(1, p, False, 0, ACTS["lrelu"], 0.2, 0, ALGOS[algo])
     with torch.no_grad():
         y = ops.conv2d_infer(x.to(gpu), w.to(gpu), b.to(gpu), res.to(gpu), cfg)
+    name = pkg._lib.load().srk_last_kernel_name().decode()
+    assert name.startswith("k_conv_rown<" if k * k * cout > 32 else "k_conv_tapn<"), name
     assert rel_err(y, ref.float()) < TOL_TIGHT
+
+
+@pytest.mark.parametrize("cin,cout,k,p,H,W,N,th", [
+    (64, 3, 9, 4, 70, 150, 2, 0),    # SRGAN-G output conv: three 64-column tiles (the last ragged), several row tiles
+    (64, 3, 9, 4, 70, 150, 2, 8),    # ... 8-row tiles: 16 input rows per tile, the ring wraps inside a tile
+    (64, 3, 9, 4, 33, 64, 1, 32),    # ... 32-row tiles, the second one a single row; exactly one column tile
+    (64, 3, 9, 0, 40, 90, 2, 16),    # no padding (output 32 x 82)
+    (32, 3, 5, 0, 52, 52, 3, 0),     # SRCNN output conv (c1 size): one 32-channel step, one 16-column N tile
+    (32, 1, 5, 2, 20, 100, 2, 16),   # single output channel
+    (64, 2, 7, 3, 31, 65, 2, 0),     # 7x7, two output channels; one column past the first tile
+    (64, 3, 9, 4, 128, 128, 2, 0),   # c5 size per image
+])
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x6"])
+def test_conv_rows_on_n_kernel(gpu, monkeypatch, cin, cout, k, p, H, W, N, th, mode):
+    """k_conv_rown (conv_rown.hip): few output channels, more taps than one 32-column group.  Both arithmetics (bf16x3: 1e-4,
+    the exact split: fp32 tolerance), every tile height the host may pick (SRK_ROWN_TH), ragged row / column tiles, rows of
+    the halo outside the image (skipped matrix phases), bias + LeakyReLU + residual through the epilogue; vs torch fp64."""
+    pkg = _pkg()
+    ops = pkg.ops
+    if th:
+        monkeypatch.setenv("SRK_ROWN_TH", str(th))
+    x = fill.randn((N, cin, H, W), 171)
+    w = fill.randn((cout, cin, k, k), 172, (2.0 / (cin * k * k)) ** 0.5)
+    b = fill.randn((cout,), 173, 0.1)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 1, p)
+    res = fill.randn(tuple(ref.shape), 174)
+    ref = torch.nn.functional.leaky_relu(ref, 0.2) + res.double()
+    cfg = ops.ConvCfg(1, p, False, 0, ACTS["lrelu"], 0.2, 0, ALGOS[mode])
+    with torch.no_grad():
+        y = ops.conv2d_infer(x.to(gpu), w.to(gpu), b.to(gpu), res.to(gpu), cfg)
+        y2 = ops.conv2d_infer(x.to(gpu), w.to(gpu), b.to(gpu), res.to(gpu), cfg)
+    name = pkg._lib.load().srk_last_kernel_name().decode()
+    assert name.startswith("k_conv_rown<%d,%d,%d,%d," % (cin // 32, cout, k, 3 if mode == "bf16x6" else 2)), name
+    assert torch.equal(y, y2)                                   # fixed summation order: run-to-run identical
+    assert rel_err(y, ref.float()) < (TOL_TIGHT if mode == "bf16x6" else 1e-4)
+    assert_close_elementwise(y, ref.float(), 1e-4 if mode == "bf16x6" else 1e-3, what="k_conv_rown")
 
 
 @pytest.mark.parametrize("cin,cout,k,p,H,W,N", [
