@@ -78,7 +78,19 @@ __global__ __launch_bounds__(256, 2) void k_conv_rown(MfmaConvParams P) {
   const int nrows = th + KH - 1;                         // input rows it walks
 
   // ---- this wave's filter fragments: pairs q = wave, wave + 4, ...; column nn = nt*16 + j = (u, oc); K slot e of lane
-  // (j, kq) = channel ks*32 + kq*8 + e (the order of the staged A operand)
+  // (j, kq) = channel ks*32 + kq*8 + e (the order of the staged A operand).  The fp32 filter [tap][IC][OC] (62 KB for
+  // 9 x 9 x 64 x 3) goes through LDS first, read from global memory ONCE per block in whole lines: gathered straight from
+  // global memory a lane's 80 values are 80 wave-loads of 64 different lines each -- ~20 k L2 requests per block.
+  {
+    float* wsm = reinterpret_cast<float*>(smem4);
+    const int nflt = P.KHv * P.KW_full * P.IC * OCT;   // (stride-1 gathers: every tap of the filter is a valid one)
+    if ((nflt & 3) == 0 && (reinterpret_cast<uintptr_t>(P.wp) & 15) == 0) {
+      for (int i = tid; i < (nflt >> 2); i += 256) reinterpret_cast<f32x4*>(wsm)[i] = reinterpret_cast<const f32x4*>(P.wp)[i];
+    } else {
+      for (int i = tid; i < nflt; i += 256) wsm[i] = P.wp[i];
+    }
+    __syncthreads();
+  }
   uint4 bw[QW][NT][NP];
 #pragma unroll
   for (int qi = 0; qi < QW; ++qi) {
@@ -92,15 +104,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_rown(MfmaConvParams P) {
       const bool on = qon && nn < NN;
       const int u = on ? nn / OCT : 0, oc = on ? nn - u * OCT : 0;
       const int tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
-      const float* __restrict__ w = P.wp + ((size_t)tapw * P.IC + ks * 32 + kq * 8) * OCT + oc;
+      const float* w = reinterpret_cast<const float*>(smem4) + ((size_t)tapw * P.IC + ks * 32 + kq * 8) * OCT + oc;
       float f[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = w[e * OCT];   // (unconditional, in-bounds loads; padding columns zeroed below)
+      for (int e = 0; e < 8; ++e) f[e] = w[e * OCT];   // (unconditional, in-bounds reads; padding columns zeroed below)
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = on ? f[e] : 0.f;
       split8n<NP>(f, bw[qi][nt]);
     }
   }
+  __syncthreads();   // the filter image is dead: xs / zs / ring take its place
 
   // ---- staging items of this thread: 8 consecutive pixels x the groups of a pixel per 8 * NG consecutive items (a wave
   // reads whole pixels: 256-byte rows; 8 adjacent lanes store 8 adjacent slots of one group: conflict-free)
@@ -246,7 +259,9 @@ bool conv_rown_gather_supported(const GatherConv& g, const float* in, const floa
 template <int KS, int OCT, int KW, int NP, int NT>
 static int rown_launch_t(MfmaConvParams P, hipStream_t s) {
   constexpr int NG = KS * 4, XP = ((RN_TW + KW - 1) + 15) & ~15;
-  const size_t lds = (size_t)NP * NG * XP * 16 + (size_t)4 * RN_TW * RN_ZS * 4 + (size_t)P.KHv * RN_RS * 4;
+  size_t lds = (size_t)NP * NG * XP * 16 + (size_t)4 * RN_TW * RN_ZS * 4 + (size_t)P.KHv * RN_RS * 4;
+  const size_t flt = (size_t)P.KHv * P.KW_full * P.IC * OCT * 4;   // the fp32 filter passes through the same memory first
+  if (lds < flt) lds = flt;
   static LdsLimit lim;
   lim.ensure(reinterpret_cast<const void*>(&k_conv_rown<KS, OCT, KW, NP, NT>), lds);
   note_kernel("k_conv_rown<%d,%d,%d,%d,%d>", KS, OCT, KW, NP, NT);

@@ -23,7 +23,6 @@
 #include "srk_common.h"
 #include "conv_problem.h"
 #include <stdlib.h>
-#include <atomic>
 
 namespace srk {
 
@@ -103,14 +102,6 @@ struct WgBfParams {
                          // only its TH new rows instead of all TH + KH - 1 (2-row tiles: the X read halves).  CS is then
                          // the plane stride of the ring, and the dY tiles keep their two buffer sets behind it.
   int XP, XPL, YPL;      // k_wgrad_tr: pixels per ring row, bytes per X plane / dY plane of its pixel-major LDS image
-  // k_wgrad_tr, in-launch slab reduction (round 6): the LAST of the G blocks that share an output tile (layer, ci half, co
-  // block) sums the tile's G slabs in the fixed order of the reduce kernel it replaces and writes dw / db -- no reduce launch.
-  int red_on;            // 0: off (slabs only, a reduce kernel follows); 1: order of k_wgrad_reduce_grouped; 2: of k_wgrad_reduce
-  int red_cnt_base;      // first arrival counter of this launch in g_wg_cnt (one per output tile)
-  int red_ps_r;          // the slab's channel order is pixel-shuffle-major (out_ps_r of k_wgrad_reduce)
-  float red_beta;
-  float* red_dw;         // single-layer launches (grouped: WgLayer.dw / .db)
-  float* red_db;
 };
 
 // Grouped launch: the weight gradients of up to WB_MAXGROUP convolutions that share ONE geometry (the 33 body convs
@@ -124,8 +115,6 @@ struct WgLayer {
   const float* mask_y;
   float mask_slope;
   int pad_;
-  float* dw;   // in-launch reduction (WgBfParams.red_on): the layer's gradient tensors
-  float* db;
 };
 struct WgGroup {
   WgLayer L[WB_MAXGROUP];
@@ -1050,41 +1039,6 @@ __global__ __launch_bounds__(SPEC ? 64 * CIT * COW + WB_SST : 64 * CIT * COW,
 // Requirements (wt_eligible): 3x3, stride 1, Cin % 32 == 0, Cout % 64 == 0, 16-byte aligned tensors, pixel-shuffled dY
 // only with >= 64 channels per sub-pixel; everything else stays on k_wgrad_bf.
 // ---------------------------------------------------------------------------------------------
-// Arrival counters of the in-launch slab reduction: zero at module load, and every tile's last arriver puts its counter
-// back to zero, so no launch needs a memset node.  A launch takes a window of consecutive counters from a host-side cursor
-// (wt_counter_window): launches that can overlap in time (other streams, other graphs) never share one.
-constexpr int WG_CNT_N = 1 << 15;
-__device__ unsigned g_wg_cnt[WG_CNT_N];
-
-// sum over the G slabs of one float4 / one float, in EXACTLY the order of wgrad_reduce_body<WIDE> (conv_wgrad_mfma.hip) and
-// k_wgrad_reduce_grouped: four interleaved partial sums (the reduce kernels' four waves), each with 2 (4: WIDE)
-// accumulators, combined as (p0 + p1) + (p2 + p3) -- the in-launch reduction is bit-equal to the launch it replaces.
-template <bool WIDE, typename T>
-__device__ __forceinline__ T wt_ordered_sum(const T* __restrict__ p, size_t stride, int G) {
-  T part[4];
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    T s0 = T(0.f), s1 = T(0.f), s2 = T(0.f), s3 = T(0.f);
-    int g = w;
-    if (WIDE) {
-      for (; g + 12 < G; g += 16) {
-        s0 += p[(size_t)g * stride];
-        s1 += p[(size_t)(g + 4) * stride];
-        s2 += p[(size_t)(g + 8) * stride];
-        s3 += p[(size_t)(g + 12) * stride];
-      }
-    } else {
-      for (; g + 4 < G; g += 8) {
-        s0 += p[(size_t)g * stride];
-        s1 += p[(size_t)(g + 4) * stride];
-      }
-    }
-    for (; g < G; g += 4) s0 += p[(size_t)g * stride];
-    part[w] = WIDE ? (s0 + s1) + (s2 + s3) : s0 + s1;
-  }
-  return (part[0] + part[1]) + (part[2] + part[3]);
-}
-
 typedef short wt_s16x4 __attribute__((ext_vector_type(4)));
 typedef short wt_s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) wt_s16x4* wt_ldsp;
@@ -1096,75 +1050,6 @@ __device__ __forceinline__ void wt_split8(const f32x4& v0, const f32x4& v1, uint
   wb_split_pair(ev, od, h, l);
   hi = make_uint4(h[0], h[1], h[2], h[3]);
   lo = make_uint4(l[0], l[1], l[2], l[3]);
-}
-
-// In-launch slab reduction of k_wgrad_tr (cdna_hip_programming.md, split-K recipe in its counter form): every wave drains its
-// slab / bias-partial stores, ONE lane publishes them with an agent-scope release and draws the tile's ticket; the block
-// that draws G - 1 acquires, sums the tile's [9][32 ci][64 co] region over the G slabs in the reduce kernel's order and
-// writes dw (torch layout) and, on the ci-half-0 block, db.  Correct wherever the G blocks of a tile run (XCD, CU); the
-// last arriver zeroes the counter for the next launch that gets this window.
-template <bool GRP>
-__device__ __forceinline__ void wt_reduce_tail(const WgBfParams& P, const typename WgGroupArg<GRP>::type& GR, unsigned* flag,
-                                               int bxl, int byl, int cib, int cob) {
-  const int tid0 = threadIdx.x, nthr = blockDim.x;
-  int layer = 0;
-  float* dw = P.red_dw;
-  float* db = P.red_db;
-  if constexpr (GRP) {
-    layer = bxl / P.G;
-    dw = GR.L[layer].dw;
-    db = GR.L[layer].db;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid0 == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned* c = g_wg_cnt + P.red_cnt_base + (layer * (int)gridDim.y + byl) * (int)gridDim.z + (int)blockIdx.z;
-    const unsigned tk = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool last = tk == (unsigned)(P.G - 1);
-    if (last) {
-      __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    *flag = last ? 1u : 0u;
-  }
-  __syncthreads();
-  if (*flag == 0u) return;
-  const int G = P.G, Cin = P.Cin, Cout = P.Cout;
-  const size_t elems = (size_t)9 * Cin * Cout;
-  const float* __restrict__ ws0 = P.ws + (size_t)layer * G * elems;
-  const float beta = P.red_beta;
-  const int r2 = P.red_ps_r > 1 ? P.red_ps_r * P.red_ps_r : 1, Cps = Cout / r2;
-  // items: (tap t, ci, 4 consecutive co) of the tile's region -- 16 lanes read 256 contiguous bytes of every slab
-  for (int it = tid0; it < 9 * 32 * 16; it += nthr) {
-    const int c4 = it & 15, ci = cib + ((it >> 4) & 31), t = it >> 9;
-    const int co0 = cob + c4 * 4;
-    const f32x4* p = reinterpret_cast<const f32x4*>(ws0 + ((size_t)t * Cin + ci) * Cout + co0);
-    const f32x4 v = P.red_on == 2 ? wt_ordered_sum<true, f32x4>(p, elems / 4, G) : wt_ordered_sum<false, f32x4>(p, elems / 4, G);
-    const int kh = t / 3, kw = t - kh * 3;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      int co = co0 + e;
-      if (r2 > 1) {  // slab channel order (i, j, c) -> torch channel c*r*r + i*r + j
-        const int q = co / Cps, c = co - q * Cps;
-        co = c * r2 + q;
-      }
-      const size_t o = (((size_t)co * Cin + ci) * 3 + kh) * 3 + kw;
-      dw[o] = beta != 0.f ? beta * dw[o] + v[e] : v[e];
-    }
-  }
-  if (db && P.bias_partial && byl == 0 && tid0 < 64) {
-    const int co = cob + tid0;
-    const float* bp = P.bias_partial + (size_t)layer * G * Cout + co;
-    const float tsum = P.red_on == 2 ? wt_ordered_sum<true, float>(bp, (size_t)Cout, G) : wt_ordered_sum<false, float>(bp, (size_t)Cout, G);
-    int cot = co;
-    if (r2 > 1) {
-      const int q = co / Cps, c = co - q * Cps;
-      cot = c * r2 + q;
-    }
-    db[cot] = beta != 0.f ? beta * db[cot] + tsum : tsum;
-  }
 }
 
 // NTW = 2: four working waves (2 ci tiles x 2 pairs of co tiles, one per SIMD beside two stager waves; 168 VGPRs).
@@ -1413,7 +1298,6 @@ __global__ __launch_bounds__(NTW == 2 ? 768 : 1024, NTW == 2 ? 3 : 4) void k_wgr
       for (int t = g; t < NST; t += 8) s += bred[t * 9 + e];
       P.bias_partial[(size_t)bxl * P.Cout + cob + tid] = s;
     }
-    if (P.red_on) wt_reduce_tail<GRP>(P, GR, &oct_tw[0], bxl, byl, cib, cob);   // (every wave of the block takes part)
     return;
   }
 
@@ -1708,7 +1592,6 @@ __global__ __launch_bounds__(NTW == 2 ? 768 : 1024, NTW == 2 ? 3 : 4) void k_wgr
       for (int nt = 0; nt < NTW; ++nt)
         *reinterpret_cast<f32x4*>(slab + (size_t)t * P.Cin * P.Cout + nt * 16) = acc[u][v][nt];
     }
-  if (P.red_on) wt_reduce_tail<GRP>(P, GR, &oct_tw[0], bxl, byl, cib, cob);
 #ifdef SRK_EXPERIMENTS
   if (P.prof && tid0 == 0) {
     __builtin_amdgcn_s_waitcnt(0);   // (vmcnt(0): the slab stores have left)
@@ -2181,22 +2064,6 @@ static void wt_launch(const WgBfParams& P, const typename WgGroupArg<GRP>::type&
   hipLaunchKernelGGL((k_wgrad_tr<GRP, 2>), grid, dim3(768), lds, s, P, GR);
 }
 
-// A window of `n` consecutive arrival counters (g_wg_cnt) for one launch of the in-launch reduction; -1: switched off
-// (SRK_WGRAD_INRED=0: slabs + a reduce launch, the round-5 path).
-// Only for FEW slabs per tile: the last arriver reads all G of them alone (G x 73 KB at ~100 GB/s per block), where the
-// reduce launch spreads that read over hundreds of blocks -- measured with the tail on every launch: VDSR layer (G = 128)
-// 100 -> 205 us, c3 5.74 -> 7.63 ms; the grouped launches of a strong-scaled shard have G = 4 - 6.
-constexpr int WT_INRED_MAX_G = 8;
-static int wt_counter_window(int n, int G) {
-  if (!env_int("SRK_WGRAD_INRED", 1) || n < 1 || n > WG_CNT_N / 4 || G > env_int("SRK_WGRAD_INRED_MAXG", WT_INRED_MAX_G)) return -1;
-  static std::atomic<unsigned> cur{0};
-  unsigned c = cur.load(std::memory_order_relaxed);
-  for (;;) {
-    const unsigned base = c + (unsigned)n > (unsigned)WG_CNT_N ? 0u : c;
-    if (cur.compare_exchange_weak(c, base + (unsigned)n, std::memory_order_relaxed)) return (int)base;
-  }
-}
-
 bool conv_wgrad_bf_supported(const srk_conv_desc& d) { return wb_plan(d).ok; }
 
 size_t conv_wgrad_bf_ws(const srk_conv_desc& d) {
@@ -2392,17 +2259,7 @@ int conv_wgrad_bf(const srk_conv_desc& d, const float* x, const float* dy, const
       // experiment (SRK_WG_W8=1): eight working waves (2 ci tiles x 4 single-tile co columns) -- measured SLOWER: see k_wgrad_bf
       if (spec && wb_k33(P) && SRK_EXP_INT("SRK_WG_W8", 0)) { wb_launch<2, 4, 1>(P, grid, lds_half, spec, s); break; }
 #endif
-      if (wt_setup(P, d, pl, spec, tr_lds)) {
-        // the last of a tile's G blocks reduces the tile's slabs inside the launch (k_wgrad_reduce's order): no reduce launch
-        const int win = wt_counter_window((int)(grid.y * grid.z), G);
-        if (win >= 0) {
-          P.red_on = 2; P.red_cnt_base = win; P.red_ps_r = d.dy_ps_r > 1 ? d.dy_ps_r : 0; P.red_beta = beta;
-          P.red_dw = dw; P.red_db = db;
-        }
-        wt_launch<false>(P, WgNoGroup{0}, grid, tr_lds, s);
-        if (win >= 0) return check_launch("conv_wgrad_bf");
-        break;
-      }
+      if (wt_setup(P, d, pl, spec, tr_lds)) { wt_launch<false>(P, WgNoGroup{0}, grid, tr_lds, s); break; }
       wb_launch<2, 2, 2>(P, grid, lds_half, spec, s);
       break;
     case 1: wb_launch<4, 1, 2>(P, grid, lds_half, spec, s); break;
@@ -2525,19 +2382,7 @@ int conv_wgrad_bf_grouped(const srk_conv_desc& d, int n, const float* const* xs,
 #ifdef SRK_EXPERIMENTS
       if (spec && wb_k33(P) && SRK_EXP_INT("SRK_WG_W8", 0)) { wb_launch_grouped<2, 4, 1>(P, GR, grid, lds_half, spec, s); break; }
 #endif
-      if (wt_setup(P, d, pl, spec, tr_lds)) {
-        const int win = wt_counter_window((int)(n * grid.y * grid.z), G);   // (k_wgrad_reduce_grouped's order)
-        if (win >= 0) {
-          P.red_on = 1; P.red_cnt_base = win; P.red_ps_r = 0; P.red_beta = beta;
-          for (int l = 0; l < n; ++l) {
-            GR.L[l].dw = GO.L[l].dw;
-            GR.L[l].db = GO.L[l].db;
-          }
-        }
-        wt_launch<true>(P, GR, grid, tr_lds, s);
-        if (win >= 0) return check_launch("conv_wgrad_bf_grouped");
-        break;
-      }
+      if (wt_setup(P, d, pl, spec, tr_lds)) { wt_launch<true>(P, GR, grid, tr_lds, s); break; }
       wb_launch_grouped<2, 2, 2>(P, GR, grid, lds_half, spec, s);
       break;
     case 1: wb_launch_grouped<4, 1, 2>(P, GR, grid, lds_half, spec, s); break;

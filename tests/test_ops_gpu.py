@@ -129,7 +129,7 @@ def test_conv_few_output_channels(gpu, cin, cout, k, p, H, W, N, algo):
     (64, 3, 9, 4, 33, 64, 1, 32),    # ... 32-row tiles, the second one a single row; exactly one column tile
     (64, 3, 9, 0, 40, 90, 2, 16),    # no padding (output 32 x 82)
     (32, 3, 5, 0, 52, 52, 3, 0),     # SRCNN output conv (c1 size): one 32-channel step, one 16-column N tile
-    (32, 1, 5, 2, 20, 100, 2, 16),   # single output channel
+    (32, 2, 5, 2, 20, 100, 2, 16),   # two output channels, one N tile
     (64, 2, 7, 3, 31, 65, 2, 0),     # 7x7, two output channels; one column past the first tile
     (64, 3, 9, 4, 128, 128, 2, 0),   # c5 size per image
 ])
