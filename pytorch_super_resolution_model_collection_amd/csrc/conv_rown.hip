@@ -17,10 +17,11 @@
 //   * the K dimension is split over the 4 waves by (v, 32-channel step) pairs -- 18 pairs for 9 x 64: 5 / 5 / 4 / 4 -- so that
 //     a wave's filter fragments (its pairs x 2 column tiles x NP planes) stay in REGISTERS for the life of the block;
 //     every wave covers all four 16-pixel tiles of the row and leaves its partial Z in its own LDS slab;
-//   * the four partials are added in a fixed order (deterministic) straight into a ring of KH output-row accumulators in
-//     LDS -- thread (x, u, oc): first touch (u = 0) overwrites, so the ring is never cleared; the thread that adds the last
-//     term (u = KH - 1) runs the epilogue (bias / activation / residual / pixel shuffle) and stores the pixel;
-//   * two barriers per input row; two blocks per CU (61 - 77 KB of LDS) hide each other's staging and column sums.
+//   * thread (x, oc) adds the four partials in a fixed order (deterministic) into the KH running column sums of its output
+//     column, which live in its REGISTERS as a window that shifts by one row per input row; the oldest entry is complete
+//     after each row: bias / activation / residual (bias and slope read once per block -- a load inside the per-row
+//     epilogue was a global round trip per row: 3.0 of 5.5 us) and one coalesced 768-byte store per row;
+//   * two barriers per input row; two blocks per CU (57 - 68 KB of LDS) hide each other's staging and column sums.
 // Work beside the algorithmic FLOPs: N padding 27 -> 32, and the (TH + KH - 1) / TH halo rows (1.5x at TH = 16).
 // Arithmetic: bf16x3 (NP = 2) or the exact three-way split bf16x6 (NP = 3), products smallest-first, as k_conv_tapn.
 #include "srk_common.h"
@@ -32,9 +33,13 @@
 
 namespace srk {
 
+// constant-ablation builds (tools/tu_variant.sh RN<bits> conv_rown.hip -DRN_ABL=<bits>; 0 in the release library):
+// 1 no column sums, 2 no matrix phase, 4 no commit (split + LDS stores), 8 no global loads, 16 no z stores
+#ifndef RN_ABL
+#define RN_ABL 0
+#endif
 constexpr int RN_TW = 64;             // output columns per block
 constexpr int RN_ZS = 36;             // z row stride in floats (conflict-free C/D fragment writes, as TAPN_ZS)
-constexpr int RN_RS = RN_TW * 4 + 4;  // ring row stride in floats: rows u apart land 4 banks apart
 
 template <int I0, int I1, typename F>
 __device__ __forceinline__ void rn_static_for(F&& f) {
@@ -57,7 +62,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_rown(MfmaConvParams P) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   uint4* xs = smem4;                                                  // [NP][NG][XP]
   float* zs = reinterpret_cast<float*>(smem4 + NP * NG * XP);         // [4 waves][64 px][RN_ZS]
-  float* ring = zs + 4 * RN_TW * RN_ZS;                               // [KH][RN_RS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kq = lane >> 4;
   const int KH = P.KHv;
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_rown(MfmaConvParams P) {
       split8n<NP>(f, bw[qi][nt]);
     }
   }
-  __syncthreads();   // the filter image is dead: xs / zs / ring take its place
+  __syncthreads();   // the filter image is dead: xs / zs take its place
 
   // ---- staging items of this thread: 8 consecutive pixels x the groups of a pixel per 8 * NG consecutive items (a wave
   // reads whole pixels: 256-byte rows; 8 adjacent lanes store 8 adjacent slots of one group: conflict-free)
@@ -167,76 +171,104 @@ __global__ __launch_bounds__(256, 2) void k_conv_rown(MfmaConvParams P) {
   // rows of the input that lie outside the image contribute zeros: their staging and matrix phases are skipped
   auto row_in_image = [&](int hh) { return (unsigned)(r0 + hh + P.iy0) < (unsigned)P.IH; };
 
-  // column-sum items: i = tid + 256 k -> (x, nn) by an exact float reciprocal (i < 2048, NN <= 32), nn -> (u, oc)
-  const float inv_nn = 1.f / (float)NN, inv_oc = 1.f / (float)OCT;
-  GatherConv g{};
-  g.OH = P.OH; g.OW = P.OW; g.OC = P.OC;
+  // column-sum role of this thread: output column x = tid / OCT, channel oc = tid % OCT (the first 64 * OCT threads);
+  // bias / activation slope are read ONCE here -- a load inside the per-row epilogue is a global round trip per row
+  const bool cs_on = tid < RN_TW * OCT;
+  const int cs_x = cs_on ? tid / OCT : 0, cs_oc = cs_on ? tid - cs_x * OCT : 0;
+  const bool cs_px_ok = cs_on && c0 + cs_x < P.PW;
+  const float cs_bias = P.ep.bias ? P.ep.bias[cs_oc] : 0.f;
+  const float cs_slope = P.ep.act == SRK_ACT_PRELU ? P.ep.prelu_w[P.ep.prelu_n > 1 ? cs_oc : 0] : P.ep.slope;
+  float col[KW];
+#pragma unroll
+  for (int u = 0; u < KW; ++u) col[u] = 0.f;
   issue(0);
-  int hm = 0;   // hh mod KH
-  for (int hh = 0; hh < nrows; ++hh, hm = hm + 1 == KH ? 0 : hm + 1) {
+  for (int hh = 0; hh < nrows; ++hh) {
     const bool rok = row_in_image(hh);   // block-uniform
-    if (rok) commit();
-    issue(hh + 1);                       // in flight across the matrix phase and the column sums
+    if (rok && !(RN_ABL & 4)) commit();
+    if (!(RN_ABL & 8)) issue(hh + 1);    // in flight across the matrix phase and the column sums
     __syncthreads();
-    if (rok) {
+    if (rok && !(RN_ABL & 2)) {
       // ---- matrix phase: this wave's K pairs over the four 16-pixel tiles of the row
 #pragma unroll 1
-      for (int mt = 0; mt < RN_TW / 16; ++mt) {   // (not unrolled: the filter fragments already take 80 - 120 VGPRs)
-        f32x4 acc[NT];
+      for (int mh = 0; mh < RN_TW / 32; ++mh) {   // two 16-pixel tiles at a time: four independent accumulator chains
+        f32x4 acc[2][NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        rn_static_for<0, QW>([&](auto qic) {
-          constexpr int qi = decltype(qic)::value;
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // Every wave runs QW pairs: a pair past the end of K (waves 2, 3 of 18 pairs) multiplies zero filter fragments by the
+        // operand of pair 0 -- no branch in the stream, so the reads of pair qi + 1 are issued in front of the MFMAs of pair
+        // qi (with the wave-uniform `if (q < NQ)` of the first version every pair waited for its own reads: 28 clocks per
+        // MFMA); the block waits for its 5-pair waves either way.
+        uint4 a[2][2][NP];
+        auto aread = [&](int buf, int qi) {
           const int q = wave + 4 * qi;
-          if (q < NQ) {   // wave-uniform
-            const int v = q / KS, ks = q - v * KS;
-            uint4 a[NP];
+          const int qq = q < NQ ? q : 0;
+          const int v = qq / KS, ks = qq - v * KS;
 #pragma unroll
-            for (int p = 0; p < NP; ++p) a[p] = xs[(p * NG + ks * 4 + kq) * XP + mt * 16 + j + v];
-            // smallest products first (as k_conv_tapn / k_conv_bfd)
-#define SRK_ROWN_PASS(pa, pb) \
-  _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(a[pa], bw[qi][nt][pb], acc[nt]);
-            if constexpr (NP == 3) {
-              SRK_ROWN_PASS(2, 0)
-              SRK_ROWN_PASS(0, 2)
-              SRK_ROWN_PASS(1, 1)
-            }
-            SRK_ROWN_PASS(1, 0)
-            SRK_ROWN_PASS(0, 1)
-            SRK_ROWN_PASS(0, 0)
-#undef SRK_ROWN_PASS
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) a[buf][m][p] = xs[(p * NG + ks * 4 + kq) * XP + (mh * 2 + m) * 16 + j + v];
+        };
+        aread(0, 0);
+        rn_static_for<0, QW>([&](auto qic) {
+          constexpr int qi = decltype(qic)::value, cur = qi & 1;
+          if constexpr (qi + 1 < QW) aread(cur ^ 1, qi + 1);
+          // smallest products first (as k_conv_tapn / k_conv_bfd)
+#define SRK_ROWN_PASS(pa, pb)                                                    \
+  _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) \
+      acc[m][nt] = mfma16(a[cur][m][pa], bw[qi][nt][pb], acc[m][nt]);
+          if constexpr (NP == 3) {
+            SRK_ROWN_PASS(2, 0)
+            SRK_ROWN_PASS(0, 2)
+            SRK_ROWN_PASS(1, 1)
           }
+          SRK_ROWN_PASS(1, 0)
+          SRK_ROWN_PASS(0, 1)
+          SRK_ROWN_PASS(0, 0)
+#undef SRK_ROWN_PASS
         });
         // C/D layout: col = lane & 15 (nn), row = (lane >> 4) * 4 + reg (pixel of the tile)
-        float* zr = zs + (size_t)(wave * RN_TW + mt * 16 + kq * 4) * RN_ZS + j;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int m = 0; m < 2; ++m) {
+          float* zr = zs + (size_t)(wave * RN_TW + (mh * 2 + m) * 16 + kq * 4) * RN_ZS + j;
+          if (!(RN_ABL & 16)) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) zr[e * RN_ZS + nt * 16] = acc[nt][e];
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) zr[e * RN_ZS + nt * 16] = acc[m][nt][e];
+          } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(acc[m][nt]));
+          }
+        }
       }
     }
     __syncthreads();
-    // ---- column sums: item (x, nn = (u, oc)) adds Z[hh][x][nn] to output row hh - u of the tile
-#pragma unroll 1
-    for (int i = tid; i < RN_TW * NN; i += 256) {
-      const int x = (int)(((float)i + 0.5f) * inv_nn), nn = i - x * NN;
-      const int u = (int)(((float)nn + 0.5f) * inv_oc), oc = nn - u * OCT;
-      const int rr = hh - u;
-      if (rr < 0 || rr >= th) continue;
-      float zsum = 0.f;
+    // ---- column sums: thread (x, oc) keeps the KH running sums of its output column in REGISTERS -- col[u] belongs to
+    // output row hh - u; after this row's terms the oldest one (u = KH - 1) is complete, then the window shifts by one row
+    if (cs_on && !(RN_ABL & 1)) {
       if (rok) {
-        const float* z = zs + (size_t)x * RN_ZS + u * OCT + oc;
-        zsum = (z[0] + z[RN_TW * RN_ZS]) + (z[2 * RN_TW * RN_ZS] + z[3 * RN_TW * RN_ZS]);
+        const float* z = zs + (size_t)cs_x * RN_ZS + cs_oc;
+        float zv[KW][4];
+#pragma unroll
+        for (int u = 0; u < KW; ++u)
+#pragma unroll
+          for (int w = 0; w < 4; ++w) zv[u][w] = z[w * RN_TW * RN_ZS + u * OCT];
+#pragma unroll
+        for (int u = 0; u < KW; ++u) col[u] += (zv[u][0] + zv[u][1]) + (zv[u][2] + zv[u][3]);   // fixed order: deterministic
       }
-      const int slot = hm - u < 0 ? hm - u + KH : hm - u;   // (hh - u) mod KH
-      float* ra = ring + slot * RN_RS + x * 4 + oc;
-      const float acc = (u == 0 ? 0.f : *ra) + zsum;   // first touch overwrites: the ring is never cleared
-      if (u == KH - 1) {                               // last term: the pixel is complete
-        const int pr = r0 + rr, pc = c0 + x;
-        if (pc < P.PW) epi_store(P.ep, g, acc, n, P.oy0 + pr * P.os, P.ox0 + pc * P.os, oc, P.out);
-      } else {
-        *ra = acc;
+      const int rr = hh - (KW - 1);
+      if (rr >= 0 && cs_px_ok) {   // (rr < th by the loop bound)
+        float vout = col[KW - 1] + cs_bias;
+        if (P.ep.act != SRK_ACT_NONE) vout = act_apply(vout, P.ep.act, cs_slope);
+        const size_t o = (((size_t)n * P.OH + (P.oy0 + (r0 + rr) * P.os)) * P.OW + (P.ox0 + (c0 + cs_x) * P.os)) * P.OC + cs_oc;
+        if (P.ep.residual) vout += P.ep.residual[o];
+        P.out[o] = vout;
       }
+#pragma unroll
+      for (int u = KW - 1; u > 0; --u) col[u] = col[u - 1];
+      col[0] = 0.f;
     }
     // (no barrier here: the next commit writes xs, last read before the barrier above; the next matrix phase writes zs
     //  behind the next iteration's first barrier, which every thread reaches only after its column sums)
@@ -246,11 +278,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_rown(MfmaConvParams P) {
 // what the kernel covers: stride-1 gathers with <= 3 output channels whose taps do not fit one 32-column group (those stay
 // on k_conv_tapn's single pass), 32 or 64 input channels, a kernel of <= 32 / OC rows and 3 .. 9 columns
 bool conv_rown_gather_supported(const GatherConv& g, const float* in, const float* mask_y) {
-  if (env_int("SRK_ROWN", 1) == 0) return false;
+  const int mode = env_int("SRK_ROWN", 1);   // 0: never (k_conv_tapn's tap groups), 2: whenever the shape is covered (tests)
+  if (mode == 0) return false;
+  // small problems stay on k_conv_tapn: a 64-column tile per block leaves most CUs idle (SRCNN's 5x5 32 -> 3 layer on
+  // 16 x 48 x 48 outputs: 18.2 us here, 16.3 us there; SRGAN's 9x9 on 16 x 128 x 128: 69 - 95 us against 202 - 223)
+  if (mode != 2 && (long)g.N * g.OH * g.OW < 128L * 1024) return false;
   if (g.OC < 1 || g.OC > 3 || g.KH * g.KW * g.OC <= 32) return false;
   if (g.IC != 32 && g.IC != 64) return false;
   if (g.stride != 1 || mask_y || g.in_nchw || g.in_ps_r > 1) return false;
-  if (g.KH * g.OC > 32 || (g.KW != 9 && g.KW != 5 && g.KW != 7 && g.KW != 3)) return false;
+  if (g.KH != g.KW || g.KH * g.OC > 32 || (g.KW != 9 && g.KW != 5 && g.KW != 7)) return false;   // (square: KW is the template argument)
   if ((uintptr_t)in % 16 != 0) return false;
   if ((long)g.IH * g.IW * g.IC >= (1L << 30)) return false;
   return true;
@@ -259,7 +295,7 @@ bool conv_rown_gather_supported(const GatherConv& g, const float* in, const floa
 template <int KS, int OCT, int KW, int NP, int NT>
 static int rown_launch_t(MfmaConvParams P, hipStream_t s) {
   constexpr int NG = KS * 4, XP = ((RN_TW + KW - 1) + 15) & ~15;
-  size_t lds = (size_t)NP * NG * XP * 16 + (size_t)4 * RN_TW * RN_ZS * 4 + (size_t)P.KHv * RN_RS * 4;
+  size_t lds = (size_t)NP * NG * XP * 16 + (size_t)4 * RN_TW * RN_ZS * 4;
   const size_t flt = (size_t)P.KHv * P.KW_full * P.IC * OCT * 4;   // the fp32 filter passes through the same memory first
   if (lds < flt) lds = flt;
   static LdsLimit lim;

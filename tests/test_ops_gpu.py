@@ -101,7 +101,7 @@ def test_conv_infer_fused_epilogue(gpu, idx):
     (64, 2, 7, 3, 15, 17, 1),    # 16 taps per group, 49 taps
 ])
 @pytest.mark.parametrize("algo", ["auto", "bf16x6"])
-def test_conv_few_output_channels(gpu, cin, cout, k, p, H, W, N, algo):
+def test_conv_few_output_channels(gpu, monkeypatch, cin, cout, k, p, H, W, N, algo):
     """The taps-as-N kernel (KH*KW*Cout <= 32 columns, conv_tapn.hip) against torch fp64 on CPU, held to the
     exact-fp32 tolerance in every precision class (it always runs the exact 3-way split); bias + LeakyReLU +
     residual go through its scalar epilogue.  Kernels with more taps than one 32-column group (9x9, 5x5, 7x7) run
@@ -109,6 +109,7 @@ def test_conv_few_output_channels(gpu, cin, cout, k, p, H, W, N, algo):
     fp32-faithful mode of the suite resolves to the exact split)."""
     pkg = _pkg()
     ops = pkg.ops
+    monkeypatch.setenv("SRK_ROWN", "2")     # (k_conv_rown on problems of any size: by default small ones stay on k_conv_tapn)
     x = fill.randn((N, cin, H, W), 71)
     w = fill.randn((cout, cin, k, k), 72, (2.0 / (cin * k * k)) ** 0.5)
     b = fill.randn((cout,), 73, 0.1)
@@ -140,6 +141,7 @@ def test_conv_rows_on_n_kernel(gpu, monkeypatch, cin, cout, k, p, H, W, N, th, m
     the halo outside the image (skipped matrix phases), bias + LeakyReLU + residual through the epilogue; vs torch fp64."""
     pkg = _pkg()
     ops = pkg.ops
+    monkeypatch.setenv("SRK_ROWN", "2")
     if th:
         monkeypatch.setenv("SRK_ROWN_TH", str(th))
     x = fill.randn((N, cin, H, W), 171)

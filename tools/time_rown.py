@@ -15,11 +15,13 @@ x = torch.randn(N, cin, H, W, generator=g).to(dev).contiguous(memory_format=torc
 w = (torch.randn(cout, cin, k, k, generator=g) * 0.05).to(dev)
 b = torch.randn(cout, generator=g).to(dev)
 flop = 2.0 * N * (H + 2 * pad - k + 1) * (W + 2 * pad - k + 1) * cin * cout * k * k
-for algo, aname in ((4, "bf16x3"), (5, "bf16x6")):
+QUICK = bool(os.environ.get("ROWN_QUICK"))
+for algo, aname in (((4, "bf16x3"),) if QUICK else ((4, "bf16x3"), (5, "bf16x6"))):
     cfg = ops.ConvCfg(1, pad, False, 0, 0, 0.0, 0, algo)
     wp, bp = ops.pack_weight_fwd(w, False, 0), ops.pack_bias_ps(b, 0)
     ref = None
-    for env in ({"SRK_ROWN": "0"}, {"SRK_ROWN_TH": "8"}, {"SRK_ROWN_TH": "16"}, {"SRK_ROWN_TH": "32"}, {"SRK_ROWN_TH": "64"}, {}):
+    for env in (({"SRK_ROWN_TH": "8"}, {"SRK_ROWN_TH": "64"}) if QUICK else
+                ({"SRK_ROWN": "0"}, {"SRK_ROWN_TH": "8"}, {"SRK_ROWN_TH": "16"}, {"SRK_ROWN_TH": "32"}, {"SRK_ROWN_TH": "64"}, {})):
         for kk in ("SRK_ROWN", "SRK_ROWN_TH"):
             os.environ.pop(kk, None)
         os.environ.update(env)
