@@ -95,6 +95,8 @@ bool conv_bf3_rows_f16_supported(const GatherConv& g, const Epi& ep, const float
 int conv_bf3_rows_f16_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s);
 bool conv_tapk_gather_supported(const GatherConv& g, const Epi& ep, const float* out, const float* mask_y);
 int conv_tapk_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s);
+bool conv_tapkm_gather_supported(const GatherConv& g, const Epi& ep, const float* out, const float* mask_y);
+int conv_tapkm_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s);
 bool conv_wgrad_tapn_supported(const srk_conv_desc& d, const float* x, const srk_bwd_mask* mask);
 size_t conv_wgrad_tapn_ws(const srk_conv_desc& d);
 int conv_wgrad_tapn(const srk_conv_desc& d, const float* x, const float* dy, float* dw, float* db, float beta, void* ws,
@@ -230,6 +232,9 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
   // ... and their data gradients (<= 3 input channels, TRANS gather): taps-in-K bf16x3 kernel
   if ((algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3) && conv_tapk_gather_supported(g, ep, out, mask_y))
     return conv_tapk_gather(g, in, wp, out, ep, s);
+  // ... with more taps than one 32-slot K step holds (9x9 x 3 channels): one kernel row per step
+  if ((algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3) && conv_tapkm_gather_supported(g, ep, out, mask_y))
+    return conv_tapkm_gather(g, in, wp, out, ep, s);
   // the bfd kernels are compiled without the scalar store fallback
   const bool bfd_ok = conv_bfd_gather_supported(g, ep) && conv_epi_all_vector(g.OC, ep, out);
   if (algo == SRK_ALGO_MFMA_BF16X6) {  // fp32-faithful class: bf16x6 where it applies, else the exact fp32 kernels

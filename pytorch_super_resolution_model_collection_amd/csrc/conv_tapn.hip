@@ -30,6 +30,7 @@
 #include "conv_tile.h"
 #include "bf16_frag.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace srk {
 
@@ -552,5 +553,214 @@ int conv_tapk_gather(const GatherConv& g, const float* in, const float* wp, floa
     return check_launch("conv_tapk");
   });
 }
+
+// ---------------------------------------------------------------------------------------------
+// The same mirror case with MORE than 32 contraction slots: the data gradient of a many-tap few-channel output conv
+// (SRGAN-G's 9x9 64 -> 3, srgan.py:32: dx[64] from dy[3], a stride-1 TRANS gather with IC = 3, OC = 64, 81 taps).  It ran
+// the exact-fp32 k_conv_mfma_tg<4> -- one 128-pixel tile per block walking 81 taps: 118 - 127 us for 8.15 GFLOP.
+//
+// K is packed ONE KERNEL ROW PER STEP: slot k' = v * IC + c of step u (k' < KW * IC <= 32; the rest of the step is zero
+// filter) -- the KW * IC values of a row are CONTIGUOUS in an NHWC tensor with IC channels, so lane (pixel j, kq) gathers
+// the 8 consecutive floats k' = 8 kq .. 8 kq + 7 at (iy + u, ix) * IC + k'.  Transposed product as k_conv_tapk (M = oc in
+// 16-channel tiles, N = 16 consecutive pixels of a row; the C/D layout stores float4s of 4 channels per pixel, no LDS
+// epilogue).  The filter fragments [kernel row][channel tile][plane] (73 KB for 9 x 4 x 2) live in LDS: the fp32 filter is
+// copied there in whole lines, turned into fragments through registers, and read back as one ds_read_b128 per MFMA
+// operand; a wave keeps the gathered rows of TWO pixel groups in flight (the loads of step u + 1 are issued in front of the
+// MFMAs of step u).  bf16x3 arithmetic, products smallest-first; 9 steps x 4 tiles x 3 MFMAs per 16 pixels.
+// ---------------------------------------------------------------------------------------------
+template <int MTN>  // 16-channel output tiles (OC = 16 * MTN)
+__global__ __launch_bounds__(256, 2) void k_conv_tapkm(MfmaConvParams P, int groups_per_row, int units) {
+  extern __shared__ __attribute__((aligned(16))) uint4 fsm4[];   // fragments [KHv][MTN][2 planes][64 lanes]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int KH = P.KHv, RK = P.KWv * P.IC;     // K slots of a kernel row that carry filter values (<= 32)
+  // ---- filter: global fp32 [tap][IC][OC] -> LDS (coalesced) -> fragments through registers -> LDS
+  {
+    float* wsm = reinterpret_cast<float*>(fsm4);
+    const int nflt = P.KHv * P.KW_full * P.IC * P.OC;   // (stride-1 gather: KHv x KWv is the whole filter)
+    if ((nflt & 3) == 0 && (reinterpret_cast<uintptr_t>(P.wp) & 15) == 0) {
+      for (int i = tid; i < (nflt >> 2); i += 256) reinterpret_cast<f32x4*>(wsm)[i] = reinterpret_cast<const f32x4*>(P.wp)[i];
+    } else {
+      for (int i = tid; i < nflt; i += 256) wsm[i] = P.wp[i];
+    }
+    __syncthreads();
+    constexpr int MAXF = (9 * MTN * 64 + 255) / 256;   // fragments (u, tile, lane) per thread, KH <= 9
+    uint4 fr[MAXF][2];
+    const int nfrag = KH * MTN * 64;
+#pragma unroll
+    for (int r = 0; r < MAXF; ++r) {
+      const int f = tid + 256 * r;
+      const int fl = f & 63, fi = (f >> 6) % MTN, fu = (f >> 6) / MTN;
+      const int fj = fl & 15, fkq = fl >> 4;
+      float v8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = fkq * 8 + e;
+        const bool on = f < nfrag && k < RK;
+        const int kk = on ? k : 0, uu = f < nfrag ? fu : 0;
+        const int v = kk / P.IC, c = kk - v * P.IC;
+        const int tapw = (P.wh0 + P.wdh * uu) * P.KW_full + (P.ww0 + P.wdw * v);
+        const float w = wsm[((size_t)tapw * P.IC + c) * P.OC + 16 * fi + fj];
+        v8[e] = on ? w : 0.f;
+      }
+      split8n<2>(v8, fr[r]);
+    }
+    __syncthreads();   // every source value is in registers
+#pragma unroll
+    for (int r = 0; r < MAXF; ++r) {
+      const int f = tid + 256 * r;
+      if (f < nfrag) {
+        const int fl = f & 63, fq = f >> 6;   // fq = u * MTN + tile
+        fsm4[(size_t)(fq * 2 + 0) * 64 + fl] = fr[r][0];
+        fsm4[(size_t)(fq * 2 + 1) * 64 + fl] = fr[r][1];
+      }
+    }
+    __syncthreads();
+  }
+  // this lane's K slots: column shift and channel are the same for every step
+  int slot_v[8];
+  bool slot_on[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = kq * 8 + e;
+    slot_on[e] = k < RK;
+    slot_v[e] = (slot_on[e] ? k : 0) / P.IC;
+  }
+  constexpr int U = 2;
+  const int nw = gridDim.x * 4;
+  const float* __restrict__ res = P.ep.residual;
+  for (int unit0 = (blockIdx.x * 4 + wave) * U; unit0 < units; unit0 += nw * U) {
+    size_t ooff[U];
+    bool px_on[U];
+    int iyb[U], ixb[U];
+    const float* src[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int unit = unit0 + q < units ? unit0 + q : units - 1;
+      const int rr = unit / groups_per_row, gx = unit - rr * groups_per_row;
+      const int n = rr / P.PH, pr = rr - n * P.PH;
+      const int pc = gx * 16 + j;  // this lane's pixel (phase coordinates)
+      px_on[q] = pc < P.PW && unit0 + q < units;
+      iyb[q] = pr * P.is + P.iy0;
+      ixb[q] = pc * P.is + P.ix0;
+      src[q] = P.in + (size_t)n * P.IH * P.IW * P.IC + kq * 8;
+      const int oy = P.oy0 + pr * P.os, ox = P.ox0 + pc * P.os;
+      ooff[q] = (((size_t)n * P.OH + oy) * P.OW + ox) * P.OC + kq * 4;
+    }
+    f32x4 acc[MTN][U];
+#pragma unroll
+    for (int i = 0; i < MTN; ++i)
+#pragma unroll
+      for (int q = 0; q < U; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float raw[2][U][8];
+    unsigned okm[2][U];
+    auto gather = [&](int buf, int u) {   // the 8 floats of kernel row u for both pixel groups, from clamped addresses
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        const int iy = iyb[q] + u;
+        const bool rok = px_on[q] && u < KH && (unsigned)iy < (unsigned)P.IH;
+        const int iyc = rok ? iy : 0;
+        unsigned m = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int ix = ixb[q] + slot_v[e];
+          const bool ok = rok && slot_on[e] && (unsigned)ix < (unsigned)P.IW;
+          // element (iy, ixb, k' = 8 kq + e) = base + (iy * IW + ixb) * IC + k'; out of range: element 0 of the row pointer
+          const long off = ok ? ((long)iyc * P.IW + ixb[q]) * P.IC + e : -(long)(kq * 8);
+          raw[buf][q][e] = src[q][off];
+          m |= ok ? (1u << e) : 0u;
+        }
+        okm[buf][q] = m;
+      }
+    };
+    gather(0, 0);
+    for (int u = 0; u < KH; ++u) {
+      const int cur = u & 1;
+      // (dynamic buffer index would spill: two copies of the body, selected by the wave-uniform parity)
+      auto body = [&](auto curc) {
+        constexpr int cb = decltype(curc)::value;
+        gather(cb ^ 1, u + 1);
+        uint4 bf[U][2];
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+          float f8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f8[e] = ((okm[cb][q] >> e) & 1u) ? raw[cb][q][e] : 0.f;
+          split8n<2>(f8, bf[q]);
+        }
+#pragma unroll
+        for (int i = 0; i < MTN; ++i) {
+          const uint4 ah = fsm4[(size_t)((u * MTN + i) * 2 + 0) * 64 + lane];
+          const uint4 am = fsm4[(size_t)((u * MTN + i) * 2 + 1) * 64 + lane];
+#pragma unroll
+          for (int q = 0; q < U; ++q) acc[i][q] = mfma16(am, bf[q][0], acc[i][q]);
+#pragma unroll
+          for (int q = 0; q < U; ++q) acc[i][q] = mfma16(ah, bf[q][1], acc[i][q]);
+#pragma unroll
+          for (int q = 0; q < U; ++q) acc[i][q] = mfma16(ah, bf[q][0], acc[i][q]);
+        }
+      };
+      if (cur == 0) body(std::integral_constant<int, 0>{}); else body(std::integral_constant<int, 1>{});
+    }
+    // C/D layout: col = lane & 15 = pixel j, rows kq*4 + reg = channels 16 i + kq*4 .. +3
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      if (px_on[q]) {
+#pragma unroll
+        for (int i = 0; i < MTN; ++i) {
+          f32x4 v = acc[i][q];
+          if (res) v += *reinterpret_cast<const f32x4*>(res + ooff[q] + 16 * i);
+          *reinterpret_cast<f32x4*>(P.out + ooff[q] + 16 * i) = v;
+        }
+      }
+    }
+  }
+}
+
+// (epilogue: optional "+ residual" only -- what a data gradient needs)
+bool conv_tapkm_gather_supported(const GatherConv& g, const Epi& ep, const float* out, const float* mask_y) {
+  if (ep.bias || ep.act != SRK_ACT_NONE || ep.ps_r > 1 || (uintptr_t)out % 16 != 0 || (uintptr_t)ep.residual % 16 != 0)
+    return false;
+  if (env_int("SRK_TAPKM", 1) == 0) return false;
+  if (!g.trans || g.stride != 1) return false;
+  if (g.IC < 1 || g.IC > 4 || g.KH * g.KW * g.IC <= 32 || g.KW * g.IC > 32 || g.KH > 9) return false;
+  if (g.OC % 16 != 0 || g.OC > 64) return false;
+  if (mask_y || g.in_nchw || g.in_ps_r > 1) return false;
+  if ((long)g.IH * g.IW * g.IC >= (1L << 30) || (long)g.N * g.OH * ((g.OW + 15) / 16) >= (1L << 30)) return false;
+  return true;
+}
+
+template <int MTN>
+static int tapkm_launch(const MfmaConvParams& P, int gpr, int units, hipStream_t s) {
+  size_t lds = (size_t)P.KHv * MTN * 2 * 64 * 16;
+  const size_t flt = (size_t)P.KHv * P.KW_full * P.IC * P.OC * 4;
+  if (lds < flt) lds = flt;
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&k_conv_tapkm<MTN>), lds);
+  long nb = (units + 4 * 2 * 4 - 1) / (4 * 2 * 4);   // >= 4 pairs of pixel groups per wave (the filter prologue is per block)
+  if (nb > 2 * kNumCU) nb = 2 * kNumCU;
+  if (nb < 1) nb = 1;
+  note_kernel("k_conv_tapkm<%d>", MTN);
+  hipLaunchKernelGGL(k_conv_tapkm<MTN>, dim3((unsigned)nb), dim3(256), lds, s, P, gpr, units);
+  return check_launch("conv_tapkm");
+}
+
+int conv_tapkm_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, hipStream_t s) {
+  return for_each_phase(g, in, wp, out, ep, nullptr, 0.f, [&](const MfmaConvParams& P) {
+    if (P.is != 1 || P.KHv != g.KH || P.KWv != g.KW) {
+      set_error("conv_tapkm: strided gather");
+      return (int)SRK_ERR_UNSUPPORTED;
+    }
+    const int gpr = (P.PW + 15) / 16;
+    const int units = P.N * P.PH * gpr;
+    switch (P.OC / 16) {
+      case 1: return tapkm_launch<1>(P, gpr, units, s);
+      case 2: return tapkm_launch<2>(P, gpr, units, s);
+      case 3: return tapkm_launch<3>(P, gpr, units, s);
+      default: return tapkm_launch<4>(P, gpr, units, s);
+    }
+  });
+}
+
 
 }  // namespace srk

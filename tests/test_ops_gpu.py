@@ -189,6 +189,52 @@ def test_conv_few_output_channels_backward(gpu, cin, cout, k, p, H, W, N):
     assert rel_err(bg.grad, br.grad.float()) < 1e-4
 
 
+@pytest.mark.parametrize("cin,cout,k,p,H,W,N,resid", [
+    (64, 3, 9, 4, 30, 40, 2, False),    # SRGAN-G output conv: dx[64] from dy[3], 9 kernel rows of 27 K slots, 4 channel tiles
+    (64, 3, 9, 4, 17, 70, 1, True),     # ragged 16-pixel groups, an odd number of them; fused "+ residual" (gradient fan-in)
+    (32, 3, 5, 2, 20, 24, 2, False),    # SRCNN output conv: two channel tiles, 15 K slots per row
+    (64, 2, 7, 3, 15, 33, 1, False),    # two gradient channels: 14 slots per row
+    (48, 3, 9, 0, 24, 24, 1, False),    # no padding (dy smaller than dx), three channel tiles
+    (64, 3, 9, 4, 128, 128, 1, False),  # c5 image size
+])
+def test_conv_many_tap_data_gradient(gpu, cin, cout, k, p, H, W, N, resid):
+    """k_conv_tapkm (conv_tapn.hip): the data gradient of a few-output-channel conv with more than 32 / Cout taps -- a TRANS
+    gather with <= 4 input channels, one kernel row per K step, filter fragments in LDS.  Through the C ABI
+    (srk_conv2d_backward_data: the dispatch must pick it) and through autograd (whole layer: forward, dx, dw, db); bf16x3
+    arithmetic: 1e-4 of the tensor's maximum, 1e-3 element-wise; vs torch fp64."""
+    pkg = _pkg()
+    ops, L = pkg.ops, pkg._lib
+    lib = L.load()
+    x = fill.randn((N, cin, H, W), 181)
+    w = fill.randn((cout, cin, k, k), 182, (2.0 / (cin * k * k)) ** 0.5)
+    b = fill.randn((cout,), 183, 0.1)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    ref = torch.nn.functional.conv2d(xr, wr, br, 1, p)
+    g = fill.randn(tuple(ref.shape), 184)
+    ref.backward(g.double())
+    cfg = ops.ConvCfg(1, p, False, 0, 0, 0.0, 0, ALGOS["auto"])
+    # the C ABI call: dx = conv^T(dy) [+ add_to]
+    d = ops._make_desc(x.shape, w, cfg, "bwd")
+    dy = g.to(gpu).contiguous(memory_format=torch.channels_last)
+    wpb = ops.pack_weight_bwd(w.to(gpu), False, 0)
+    dx = torch.empty((N, cin, H, W), device=gpu).contiguous(memory_format=torch.channels_last)
+    add = fill.randn((N, cin, H, W), 185).to(gpu).contiguous(memory_format=torch.channels_last) if resid else None
+    assert lib.srk_conv2d_backward_data(ctypes.byref(d), L.ptr(dy), L.ptr(wpb), L.ptr(dx), None, L.ptr(add),
+                                        L.stream_ptr()) == 0
+    assert lib.srk_last_kernel_name().decode() == "k_conv_tapkm<%d>" % (cin // 16)
+    want = xr.grad.float() + (add.cpu() if resid else 0.0)
+    assert rel_err(dx, want) < 1e-4
+    assert_close_elementwise(dx, want, 1e-3, what="k_conv_tapkm")
+    # the layer through autograd
+    xg, wg, bg = (t.to(gpu).requires_grad_(True) for t in (x, w, b))
+    y = ops.conv2d(xg, wg, bg, None, cfg)
+    y.backward(g.to(gpu))
+    assert rel_err(y, ref.detach().float()) < TOL_TIGHT
+    assert rel_err(xg.grad, xr.grad.float()) < 1e-4
+    assert rel_err(wg.grad, wr.grad.float()) < 1e-4
+    assert rel_err(bg.grad, br.grad.float()) < 1e-4
+
+
 @pytest.mark.parametrize("cin,cout,k,p,H,W,N,act,ps", [
     (64, 32, 3, 0, 30, 41, 2, "relu", 0),     # c2 layer 2 shape class: two chunks, unrolled taps + deferred stores
     (32, 48, 3, 0, 21, 37, 2, None, 4),       # c2 layer 3: one chunk, fused pixel-shuffle store
