@@ -80,7 +80,7 @@ int conv_rown_gather(const GatherConv& g, const float* in, const float* wp, floa
 // conv_tapn.hip
 bool conv_tapn_gather_supported(const GatherConv& g, const float* in, const float* mask_y);
 int conv_tapn_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, bool x6,
-                     hipStream_t s);
+                     hipStream_t s, const float* mask_y = nullptr, float mask_slope = 0.f);
 // conv_c64.hip
 bool conv_c64_applicable(const GatherConv& g, const Epi& ep, const float* in, const float* out, const float* mask_y);
 int conv_c64_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, int planes,
@@ -228,7 +228,7 @@ static int run_gather(const GatherConv& g, int algo, const float* in, const floa
   // few-output-channel 3x3 convs (the 64 -> 3 reconstruction layers): taps-as-N bf16x6 kernel for every bf16 class
   if ((algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3 || algo == SRK_ALGO_MFMA_BF16X6) &&
       conv_tapn_gather_supported(g, in, mask_y))
-    return conv_tapn_gather(g, in, wp, out, ep, algo == SRK_ALGO_MFMA_BF16X6, s);
+    return conv_tapn_gather(g, in, wp, out, ep, algo == SRK_ALGO_MFMA_BF16X6, s, mask_y, mask_slope);
   // ... and their data gradients (<= 3 input channels, TRANS gather): taps-in-K bf16x3 kernel
   if ((algo == SRK_ALGO_AUTO || algo == SRK_ALGO_MFMA_BF16X3) && conv_tapk_gather_supported(g, ep, out, mask_y))
     return conv_tapk_gather(g, in, wp, out, ep, s);

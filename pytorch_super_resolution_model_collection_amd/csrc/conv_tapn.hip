@@ -40,7 +40,10 @@ constexpr int TAPN_MAXI = 6;   // pixel groups (16 pixels each) per wave: halo <
 // KS = IC / 32, OCT = output channels, MULTI = more than one tap group, NP = bf16 planes (3: bf16x6; 2: bf16x3, only for
 // MULTI kernels in the bf16x3 class -- there the GEMM runs once per tap group over a halo 2-3x the tile and the MFMAs
 // are no longer free)
-template <int KS, int OCT, bool MULTI, int NP>
+// MASK: activation-gradient prologue of a data gradient (srk_bwd_mask: x <- x * (mask_y > 0 ? 1 : slope) while loading;
+// the data gradient of SRGAN-D's first layer, 3 -> 64 3x3 + LeakyReLU, srgan.py:51, is a 64 -> 3 TRANS gather with a mask and
+// ran k_conv_direct<3> at 100 us)
+template <int KS, int OCT, bool MULTI, int NP, bool MASK = false>
 __global__ __launch_bounds__(256, MULTI ? 2 : 3) void k_conv_tapn(MfmaConvParams P) {
   extern __shared__ __attribute__((aligned(16))) float zbuf[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -87,6 +90,16 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void k_conv_tapn(MfmaConvParams
       for (int q = 0; q < KS * 2; ++q) {
         raw[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (ok) raw[i][q] = *reinterpret_cast<const f32x4*>(src + q * 16);
+      }
+      if constexpr (MASK) {
+        const float* msk = P.mask_y + (size_t)n * P.IH * P.IW * P.IC + kq * 4 + ((size_t)iy * P.IW + ix) * P.IC;
+#pragma unroll
+        for (int q = 0; q < KS * 2; ++q) {
+          f32x4 m = (f32x4){1.f, 1.f, 1.f, 1.f};
+          if (ok) m = *reinterpret_cast<const f32x4*>(msk + q * 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) raw[i][q][e] = m[e] > 0.f ? raw[i][q][e] : raw[i][q][e] * P.mask_slope;
+        }
       }
     }
     for (int tg = 0; tg < NG; ++tg) {
@@ -185,7 +198,8 @@ bool conv_tapn_gather_supported(const GatherConv& g, const float* in, const floa
   if (g.OC < 1 || g.OC > 3 || g.KH * g.KW > 121) return false;  // larger kernels: several 32-column tap groups
   if (g.IC != 32 && g.IC != 64) return false;
   if (!g.trans && g.stride != 1) return false;
-  if (mask_y || g.in_nchw || g.in_ps_r > 1) return false;
+  if (g.in_nchw || g.in_ps_r > 1) return false;
+  if (mask_y && (g.KH * g.KW * g.OC > 32 || (uintptr_t)mask_y % 16 != 0)) return false;   // mask prologue: single-pass kernel only
   if ((uintptr_t)in % 16 != 0) return false;
   return true;
 }
@@ -206,6 +220,9 @@ static int tapn_launch(MfmaConvParams P, bool x6, hipStream_t s) {
       hipLaunchKernelGGL((k_conv_tapn<KS, OCT, true, 3>), grid, dim3(256), lds, s, P);
     else
       hipLaunchKernelGGL((k_conv_tapn<KS, OCT, true, 2>), grid, dim3(256), lds, s, P);
+  } else if (P.mask_y) {
+    note_kernel("k_conv_tapn<%d,%d,mask>", KS, OCT);
+    hipLaunchKernelGGL((k_conv_tapn<KS, OCT, false, 3, true>), grid, dim3(256), lds, s, P);
   } else {
     note_kernel("k_conv_tapn<%d,%d>", KS, OCT);
     hipLaunchKernelGGL((k_conv_tapn<KS, OCT, false, 3>), grid, dim3(256), lds, s, P);
@@ -214,8 +231,8 @@ static int tapn_launch(MfmaConvParams P, bool x6, hipStream_t s) {
 }
 
 int conv_tapn_gather(const GatherConv& g, const float* in, const float* wp, float* out, const Epi& ep, bool x6,
-                     hipStream_t s) {
-  return for_each_phase(g, in, wp, out, ep, nullptr, 0.f, [&](const MfmaConvParams& P) {
+                     hipStream_t s, const float* mask_y, float mask_slope) {
+  return for_each_phase(g, in, wp, out, ep, mask_y, mask_slope, [&](const MfmaConvParams& P) {
     if (P.is != 1) {
       set_error("conv_tapn: strided gather");
       return (int)SRK_ERR_UNSUPPORTED;

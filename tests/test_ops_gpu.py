@@ -189,6 +189,38 @@ def test_conv_few_output_channels_backward(gpu, cin, cout, k, p, H, W, N):
     assert rel_err(bg.grad, br.grad.float()) < 1e-4
 
 
+@pytest.mark.parametrize("cin,cout,k,p,H,W,N,slope", [
+    (3, 64, 3, 1, 37, 29, 2, 0.2),     # SRGAN-D first layer (srgan.py:51): dx[3] from dy[64] under the LeakyReLU gradient
+    (3, 64, 3, 1, 16, 50, 1, 0.0),     # ReLU mask
+    (2, 32, 3, 0, 20, 21, 2, 0.2),     # one 32-channel step, two image channels, no padding
+    (1, 64, 5, 2, 18, 18, 1, 0.2),     # 25 taps x 1 channel
+])
+def test_conv_image_gradient_with_mask(gpu, cin, cout, k, p, H, W, N, slope):
+    """The data gradient of a FIRST layer (few image channels in, 32 / 64 out, activation behind it): a TRANS gather with 32 /
+    64 input and <= 3 output channels and the activation-gradient mask on its input -- k_conv_tapn's single pass with the mask
+    prologue (k_conv_direct until round 6).  Through the C ABI, exact three-way split: fp32 tolerance vs torch fp64."""
+    pkg = _pkg()
+    ops, L = pkg.ops, pkg._lib
+    lib = L.load()
+    x = fill.randn((N, cin, H, W), 191)
+    w = fill.randn((cout, cin, k, k), 192, (2.0 / (cin * k * k)) ** 0.5)
+    xr = x.double().requires_grad_(True)
+    y = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(xr, w.double(), None, 1, p), slope)
+    g = fill.randn(tuple(y.shape), 193)
+    y.backward(g.double())
+    cfg = ops.ConvCfg(1, p, False, 0, 0, 0.0, 0, ALGOS["auto"])
+    d = ops._make_desc(x.shape, w, cfg, "bwd")
+    dy = g.to(gpu).contiguous(memory_format=torch.channels_last)
+    yg = y.detach().float().to(gpu).contiguous(memory_format=torch.channels_last)
+    wpb = ops.pack_weight_bwd(w.to(gpu), False, 0)
+    dx = torch.empty((N, cin, H, W), device=gpu).contiguous(memory_format=torch.channels_last)
+    mask = L.BwdMask(L.ptr(yg), slope)
+    assert lib.srk_conv2d_backward_data(ctypes.byref(d), L.ptr(dy), L.ptr(wpb), L.ptr(dx), ctypes.byref(mask), None,
+                                        L.stream_ptr()) == 0
+    assert lib.srk_last_kernel_name().decode() == "k_conv_tapn<%d,%d,mask>" % (cout // 32, cin)
+    assert rel_err(dx, xr.grad.float()) < TOL_TIGHT
+
+
 @pytest.mark.parametrize("cin,cout,k,p,H,W,N,resid", [
     (64, 3, 9, 4, 30, 40, 2, False),    # SRGAN-G output conv: dx[64] from dy[3], 9 kernel rows of 27 K slots, 4 channel tiles
     (64, 3, 9, 4, 17, 70, 1, True),     # ragged 16-pixel groups, an odd number of them; fused "+ residual" (gradient fan-in)
