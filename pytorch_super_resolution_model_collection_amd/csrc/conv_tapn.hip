@@ -398,7 +398,135 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_tapn(WgTapnParams P) {
   }
 }
 
+// The same gradient for MORE than 32 columns (Cout <= 3 with up to 85 taps: SRGAN-G's 9x9 64 -> 3 output conv ran the
+// role-swapped exact-fp32 k_wgrad_mfma_smallcin<16> at 159 us): the columns are split over the 4 waves of a block -- wave w
+// owns columns [64 w, 64 w + 64), four 16-column tiles -- and all four walk the SAME K steps (the x fragments are loaded by
+// every wave: L1 hits; the dyc gathers differ).  Nothing is combined across waves: each stores its own columns of the slab.
+template <int OCT>
+__global__ __launch_bounds__(256, 2) void k_wgrad_tapnw(WgTapnParams P) {
+  __shared__ float bred[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int T = P.KH * P.KW, NN = T * OCT;
+  constexpr int NTW = 4;
+  bool on[NTW], centre[NTW];
+  int tu[NTW], tv[NTW], toc[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const int nn = (wave * NTW + nt) * 16 + j;
+    on[nt] = nn < NN;
+    const int t = on[nt] ? nn / OCT : 0;
+    toc[nt] = on[nt] ? nn - t * OCT : 0;
+    tu[nt] = t / P.KW;
+    tv[nt] = t - tu[nt] * P.KW;
+    centre[nt] = on[nt] && tu[nt] == P.pad && tv[nt] == P.pad;
+  }
+  const bool ch_on = 4 * j < P.Cin;
+  f32x4 acc[4][NTW];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[i][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;   // (at most one of this lane's columns is a centre-tap column)
+  for (int unit = blockIdx.x; unit < P.units; unit += gridDim.x) {
+    const int rr = unit / P.S, sg = unit - rr * P.S;
+    const int n = rr / P.H, r = rr - n * P.H;
+    const int cb = sg * 32 + kq * 8;  // first pixel column of this lane's 8
+    // x fragments: float4 = channels 4j..4j+3 of pixel cb + e (unconditional loads from clamped addresses, zeroed afterwards)
+    f32x4 araw[8];
+    const float* __restrict__ xs = P.x + ((size_t)(n * P.H + r) * P.W) * P.Cin + (ch_on ? 4 * j : 0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int cx = cb + e < P.W ? cb + e : P.W - 1;
+      araw[e] = *reinterpret_cast<const f32x4*>(xs + (size_t)cx * P.Cin);
+    }
+    // dyc fragments of this wave's columns (gather; zero outside dy), from clamped addresses as well
+    float braw[NTW][8];
+    bool bok[NTW][8];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int qy = r + P.pad - tu[nt];
+      const bool oky = on[nt] && (unsigned)qy < (unsigned)P.OH;
+      const int qyc = oky ? qy : 0;
+      const float* __restrict__ src = P.dy + ((size_t)(n * P.OH + qyc) * P.OW) * OCT + toc[nt];
+      const int qx0 = cb + P.pad - tv[nt];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int qx = qx0 + e;
+        bok[nt][e] = oky && (unsigned)qx < (unsigned)P.OW;
+        braw[nt][e] = src[(size_t)(bok[nt][e] ? qx : 0) * OCT];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (!(ch_on && cb + e < P.W)) araw[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint4 a[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = araw[e][i];
+      split8n<2>(f, a[i]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = bok[nt][e] ? braw[nt][e] : 0.f;
+      if (centre[nt]) {
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t += f[e];
+        bsum += t;
+      }
+      uint4 bfr[2];
+      split8n<2>(f, bfr);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][nt] = mfma16(a[i][1], bfr[0], acc[i][nt]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][nt] = mfma16(a[i][0], bfr[1], acc[i][nt]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][nt] = mfma16(a[i][0], bfr[0], acc[i][nt]);
+    }
+  }
+  // the block's slab [t][ci][oc]: C/D layout col = lane & 15 (nn), row = (lane >> 4) * 4 + reg; row m of tile i is channel 4m + i
+  float* slab = P.ws + (size_t)blockIdx.x * T * P.Cin * OCT;
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    if (!on[nt]) continue;
+    const int t = tu[nt] * P.KW + tv[nt];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ci = 4 * (kq * 4 + e) + i;
+        if (ci < P.Cin) slab[((size_t)t * P.Cin + ci) * OCT + toc[nt]] = acc[i][nt][e];
+      }
+  }
+  if (P.bias_partial) {   // the centre tap's dyc column IS dy: its K sums are the bias gradient partials
+    // a centre column (u = v = pad, channel oc) sits on the 4 lanes (j, kq = 0..3) of ONE wave: sum over kq through LDS
+    bred[wave][lane] = bsum;
+    __syncthreads();
+    if (tid < OCT) {
+      const int nn = (P.pad * P.KW + P.pad) * OCT + tid;
+      const int w = nn >> 6, jj = nn & 15;
+      // (which of the wave's four column tiles holds it does not matter: a lane has at most one centre column)
+      float t = 0.f;
+      for (int q = 0; q < 4; ++q) t += bred[w][jj + 16 * q];
+      P.bias_partial[(size_t)blockIdx.x * OCT + tid] = t;
+    }
+  }
+}
+
+static bool wgrad_tapn_wide(const srk_conv_desc& d) { return d.KH * d.KW * d.Cout > 32; }
+
 static int wgrad_tapn_blocks(const srk_conv_desc& d) {
+  if (wgrad_tapn_wide(d)) {   // all waves of a block walk the same K steps: >= 8 per block, two blocks per CU
+    const long units = (long)d.N * d.H * ((d.W + 31) / 32);
+    long g = (units + 7) / 8;
+    if (g > 2 * kNumCU) g = 2 * kNumCU;
+    return g < 1 ? 1 : (int)g;
+  }
   const long units = (long)d.N * d.H * ((d.W + 31) / 32);
   long g = (units + 15) / 16;  // >= 4 K steps per wave (measured: 2..4 equal, 8 slower on the 16-image shard)
   if (g > 4 * kNumCU) g = 4 * kNumCU;  // 4 blocks per CU resident (36 KB LDS, 123 VGPRs)
@@ -409,7 +537,11 @@ bool conv_wgrad_tapn_supported(const srk_conv_desc& d, const float* x, const srk
   const bool off = env_int("SRK_TAPN", 1) == 0;
   if (off) return false;
   if (d.transposed || d.stride != 1 || d.dy_ps_r > 1 || (mask && mask->y)) return false;
-  if (d.Cout < 1 || d.Cout > 3 || d.KH * d.KW * d.Cout > 32) return false;
+  if (d.Cout < 1 || d.Cout > 3 || d.KH * d.KW * d.Cout > 256) return false;
+  if (d.KH * d.KW * d.Cout > 32) {   // the column-split kernel: 0 never, 2 on problems of any size (tests); small ones keep the old path
+    const int mode = env_int("SRK_WGRAD_TAPNW", 1);
+    if (mode == 0 || (mode != 2 && (long)d.N * d.H * d.W < 64L * 1024)) return false;
+  }
   if (d.Cin < 8 || d.Cin > 64 || d.Cin % 4 != 0) return false;
   if (2 * d.pad > d.KH - 1 || 2 * d.pad > d.KW - 1) return false;
   if ((long)d.N * d.H * ((d.W + 31) / 32) >= (1L << 30)) return false;
@@ -436,10 +568,18 @@ int conv_wgrad_tapn(const srk_conv_desc& d, const float* x, const float* dy, flo
   P.N = d.N; P.H = d.H; P.W = d.W; P.Cin = d.Cin; P.OH = d.OH; P.OW = d.OW; P.pad = d.pad; P.KH = d.KH; P.KW = d.KW;
   P.S = (d.W + 31) / 32;
   P.units = d.N * d.H * P.S;
-  switch (d.Cout) {
-    case 1: hipLaunchKernelGGL(k_wgrad_tapn<1>, dim3(G), dim3(256), 0, s, P); break;
-    case 2: hipLaunchKernelGGL(k_wgrad_tapn<2>, dim3(G), dim3(256), 0, s, P); break;
-    default: hipLaunchKernelGGL(k_wgrad_tapn<3>, dim3(G), dim3(256), 0, s, P); break;
+  if (wgrad_tapn_wide(d)) {
+    switch (d.Cout) {
+      case 1: hipLaunchKernelGGL(k_wgrad_tapnw<1>, dim3(G), dim3(256), 0, s, P); break;
+      case 2: hipLaunchKernelGGL(k_wgrad_tapnw<2>, dim3(G), dim3(256), 0, s, P); break;
+      default: hipLaunchKernelGGL(k_wgrad_tapnw<3>, dim3(G), dim3(256), 0, s, P); break;
+    }
+  } else {
+    switch (d.Cout) {
+      case 1: hipLaunchKernelGGL(k_wgrad_tapn<1>, dim3(G), dim3(256), 0, s, P); break;
+      case 2: hipLaunchKernelGGL(k_wgrad_tapn<2>, dim3(G), dim3(256), 0, s, P); break;
+      default: hipLaunchKernelGGL(k_wgrad_tapn<3>, dim3(G), dim3(256), 0, s, P); break;
+    }
   }
   int rc = check_launch("conv_wgrad_tapn");
   if (rc) return rc;

@@ -229,7 +229,7 @@ def test_conv_image_gradient_with_mask(gpu, cin, cout, k, p, H, W, N, slope):
     (48, 3, 9, 0, 24, 24, 1, False),    # no padding (dy smaller than dx), three channel tiles
     (64, 3, 9, 4, 128, 128, 1, False),  # c5 image size
 ])
-def test_conv_many_tap_data_gradient(gpu, cin, cout, k, p, H, W, N, resid):
+def test_conv_many_tap_data_gradient(gpu, monkeypatch, cin, cout, k, p, H, W, N, resid):
     """k_conv_tapkm (conv_tapn.hip): the data gradient of a few-output-channel conv with more than 32 / Cout taps -- a TRANS
     gather with <= 4 input channels, one kernel row per K step, filter fragments in LDS.  Through the C ABI
     (srk_conv2d_backward_data: the dispatch must pick it) and through autograd (whole layer: forward, dx, dw, db); bf16x3
@@ -237,6 +237,8 @@ def test_conv_many_tap_data_gradient(gpu, cin, cout, k, p, H, W, N, resid):
     pkg = _pkg()
     ops, L = pkg.ops, pkg._lib
     lib = L.load()
+    monkeypatch.setenv("SRK_WGRAD_TAPNW", "2")   # the column-split weight gradient (k_wgrad_tapnw) on these small problems too
+    monkeypatch.setenv("SRK_ROWN", "2")
     x = fill.randn((N, cin, H, W), 181)
     w = fill.randn((cout, cin, k, k), 182, (2.0 / (cin * k * k)) ** 0.5)
     b = fill.randn((cout,), 183, 0.1)
@@ -265,6 +267,12 @@ def test_conv_many_tap_data_gradient(gpu, cin, cout, k, p, H, W, N, resid):
     assert rel_err(xg.grad, xr.grad.float()) < 1e-4
     assert rel_err(wg.grad, wr.grad.float()) < 1e-4
     assert rel_err(bg.grad, br.grad.float()) < 1e-4
+    assert_close_elementwise(wg.grad, wr.grad.float(), 1e-3, what="k_wgrad_tapnw dw")
+    # ... and the same weight gradient from the kernel this one replaces (role-swapped exact fp32): both are the layer's dw
+    monkeypatch.setenv("SRK_WGRAD_TAPNW", "0")
+    xg2, wg2, bg2 = (t.to(gpu).requires_grad_(True) for t in (x, w, b))
+    ops.conv2d(xg2, wg2, bg2, None, cfg).backward(g.to(gpu))
+    assert rel_err(wg.grad, wg2.grad) < 1e-4 and rel_err(bg.grad, bg2.grad) < 1e-4
 
 
 @pytest.mark.parametrize("cin,cout,k,p,H,W,N,act,ps", [
