@@ -722,8 +722,8 @@ int conv_tapk_gather(const GatherConv& g, const float* in, const float* wp, floa
 // 16-channel tiles, N = 16 consecutive pixels of a row; the C/D layout stores float4s of 4 channels per pixel, no LDS
 // epilogue).  The filter fragments [kernel row][channel tile][plane] (73 KB for 9 x 4 x 2) live in LDS: the fp32 filter is
 // copied there in whole lines, turned into fragments through registers, and read back as one ds_read_b128 per MFMA
-// operand; a wave keeps the gathered rows of TWO pixel groups in flight (the loads of step u + 1 are issued in front of the
-// MFMAs of step u).  bf16x3 arithmetic, products smallest-first; 9 steps x 4 tiles x 3 MFMAs per 16 pixels.
+// operand; a wave keeps the gathered rows of TWO pixel groups in flight (the loads of step u + 1 -- two 16-byte loads per
+// lane and group -- are issued in front of the MFMAs of step u).  bf16x3 arithmetic, products smallest-first; 9 steps x 4 tiles x 3 MFMAs per 16 pixels.
 // ---------------------------------------------------------------------------------------------
 template <int MTN>  // 16-channel output tiles (OC = 16 * MTN)
 __global__ __launch_bounds__(256, 2) void k_conv_tapkm(MfmaConvParams P, int groups_per_row, int units) {
@@ -811,7 +811,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_tapkm(MfmaConvParams P, int gro
       for (int q = 0; q < U; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float raw[2][U][8];
     unsigned okm[2][U];
-    auto gather = [&](int buf, int u) {   // the 8 floats of kernel row u for both pixel groups, from clamped addresses
+    // The 8 floats of kernel row u for both pixel groups.  They are CONTIGUOUS in memory (k' = v * IC + c), so a lane issues
+    // two 16-byte loads (4-byte aligned) instead of eight dword gathers -- with dword gathers the kernel was bound by the
+    // address path: 72 wave-loads of 64 scattered dwords per 16 pixels, 88 us.  The vector may start left of its row (image
+    // edge: those slots are masked, the bytes belong to the row above) -- only a vector that leaves the TENSOR falls back to
+    // clamped scalar loads (first / last rows of the batch).
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    const long in_elems = (long)P.N * P.IH * P.IW * P.IC;
+    auto gather = [&](int buf, int u) {
 #pragma unroll
       for (int q = 0; q < U; ++q) {
         const int iy = iyb[q] + u;
@@ -822,12 +829,24 @@ __global__ __launch_bounds__(256, 2) void k_conv_tapkm(MfmaConvParams P, int gro
         for (int e = 0; e < 8; ++e) {
           const int ix = ixb[q] + slot_v[e];
           const bool ok = rok && slot_on[e] && (unsigned)ix < (unsigned)P.IW;
-          // element (iy, ixb, k' = 8 kq + e) = base + (iy * IW + ixb) * IC + k'; out of range: element 0 of the row pointer
-          const long off = ok ? ((long)iyc * P.IW + ixb[q]) * P.IC + e : -(long)(kq * 8);
-          raw[buf][q][e] = src[q][off];
           m |= ok ? (1u << e) : 0u;
         }
         okm[buf][q] = m;
+        // element (iy, ixb, k' = 8 kq + e) = src + (iy * IW + ixb) * IC + e   (src already holds image n and + 8 kq)
+        const long start = ((long)iyc * P.IW + ixb[q]) * P.IC;
+        const long abs0 = (src[q] - P.in) + start;
+        if (m != 0u && abs0 >= 0 && abs0 + 8 <= in_elems) {
+          const f32x4u v0 = *reinterpret_cast<const f32x4u*>(src[q] + start);
+          const f32x4u v1 = *reinterpret_cast<const f32x4u*>(src[q] + start + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            raw[buf][q][e] = v0[e];
+            raw[buf][q][4 + e] = v1[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) raw[buf][q][e] = ((m >> e) & 1u) ? src[q][start + e] : 0.f;
+        }
       }
     };
     gather(0, 0);
