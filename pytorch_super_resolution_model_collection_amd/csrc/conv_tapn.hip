@@ -91,15 +91,26 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void k_conv_tapn(MfmaConvParams
         raw[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (ok) raw[i][q] = *reinterpret_cast<const f32x4*>(src + q * 16);
       }
-      if constexpr (MASK) {
-        const float* msk = P.mask_y + (size_t)n * P.IH * P.IW * P.IC + kq * 4 + ((size_t)iy * P.IW + ix) * P.IC;
+    }
+    if constexpr (MASK) {
+      // second pass, UNCONDITIONAL loads from clamped addresses (a load under the divergent `if (ok)` is followed by an
+      // s_waitcnt vmcnt(0) at the join: six serialised round trips -- the first version of this prologue ran at 96 us
+      // against 31 us for the same layer without a mask); outside the image raw is zero and stays zero
+      const float* __restrict__ mkb = P.mask_y + (size_t)n * P.IH * P.IW * P.IC + kq * 4;
 #pragma unroll
-        for (int q = 0; q < KS * 2; ++q) {
-          f32x4 m = (f32x4){1.f, 1.f, 1.f, 1.f};
-          if (ok) m = *reinterpret_cast<const f32x4*>(msk + q * 16);
+      for (int i = 0; i < TAPN_MAXI; ++i) {
+        const int hp = (wave + 4 * i) * 16 + j;
+        const int hy = hp / P.HW, hx = hp - hy * P.HW;
+        const int iy = iyb + hy, ix = ixb + hx;
+        const bool ok = hp < npix && (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW;
+        const float* msk = mkb + (ok ? ((size_t)iy * P.IW + ix) * P.IC : 0);
+        f32x4 m[KS * 2];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) raw[i][q][e] = m[e] > 0.f ? raw[i][q][e] : raw[i][q][e] * P.mask_slope;
-        }
+        for (int q = 0; q < KS * 2; ++q) m[q] = *reinterpret_cast<const f32x4*>(msk + q * 16);
+#pragma unroll
+        for (int q = 0; q < KS * 2; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) raw[i][q][e] = m[q][e] > 0.f ? raw[i][q][e] : raw[i][q][e] * P.mask_slope;
       }
     }
     for (int tg = 0; tg < NG; ++tg) {
