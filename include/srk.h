@@ -407,6 +407,32 @@ int srk_bn_backward_apply_act(const float* dy, const float* x, const float* mean
                               const float* beta, const double* dstats, double count, float* dx, size_t rows, int C,
                               int act, float slope, const float* prelu_weight, int prelu_n, void* stream);
 
+/* Round 6, "finalize-in-apply": the same BatchNorm in ONE launch less per direction.  The apply kernels finish the split
+ * reduction themselves (every block re-sums the partials of its own 16-channel slab in the reduce kernel's order: forward
+ * statistics are bit-equal to the calls above), so a training BatchNorm is
+ *   forward : [srk_bn_stats_partials |  a conv that left srk_epilogue.bn_partial]  ->  srk_bn_finalize_apply_act
+ *   backward:  srk_bn_backward_partials_act                                         ->  srk_bn_backward_finalize_apply_act
+ * Per-shard statistics only (SyncBN all-reduces the [2C] sums between the phases: use the calls above).
+ * srk_bn_fused_supported(C): C % 16 == 0 and C <= 512.  `partials`: [splits][2][C] doubles (backward with an activation:
+ * [splits][3][C]) in a workspace of srk_bn_workspace_bytes(C); *splits_out is a HOST int the partials call fills.
+ * What the separate calls return is still returned: stats / dstats [2C], save_mean / save_rstd, running statistics,
+ * num_batches_tracked, dgamma += / dbeta += / dprelu +=.  Tensors 16-byte aligned. */
+int srk_bn_fused_supported(int C);
+int srk_bn_stats_partials(const float* x, size_t rows, int C, void* workspace, int* splits_out, void* stream);
+int srk_bn_finalize_apply_act(const double* partials, int splits, double* stats, size_t rows, int C, float* save_mean,
+                              float* save_rstd, float* running_mean, float* running_var, float momentum, float eps,
+                              int64_t* num_batches_tracked, const float* x, float* y, const float* gamma, const float* beta,
+                              int act, float slope, const float* prelu_weight, int prelu_n, const float* residual,
+                              float* y_amax, void* stream);
+int srk_bn_backward_partials_act(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                 const float* beta, size_t rows, int C, int act, float slope, const float* prelu_weight,
+                                 int prelu_n, void* workspace, int* splits_out, void* stream);
+int srk_bn_backward_finalize_apply_act(const double* partials, int splits, double* dstats, double count, const float* dy,
+                                       const float* x, const float* mean, const float* rstd, const float* gamma,
+                                       const float* beta, float* dx, size_t rows, int C, float* dgamma, float* dbeta,
+                                       int act, float slope, const float* prelu_weight, int prelu_n, float* dprelu,
+                                       void* stream);
+
 /* ---- Linear (DenseBlock: base_networks.py:7; srgan.py:66-70) -------------------------------- */
 /* y[B,Out] = act(x[B,In] @ w[Out,In]^T + b) */
 int srk_linear_forward(const float* x, const float* w, const float* b, float* y, int B, int In, int Out, int act,

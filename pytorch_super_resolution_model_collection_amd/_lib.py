@@ -120,6 +120,14 @@ _PROTOTYPES = {
                                                  c_float, c_f, c_int, c_f, c_vp, c_vp]),
     "srk_bn_backward_apply_act": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_vp, ctypes.c_double, c_f, c_size, c_int, c_int,
                                            c_float, c_f, c_int, c_vp]),
+    "srk_bn_fused_supported": (c_int, [c_int]),
+    "srk_bn_stats_partials": (c_int, [c_f, c_size, c_int, c_vp, ctypes.POINTER(c_int), c_vp]),
+    "srk_bn_finalize_apply_act": (c_int, [c_vp, c_int, c_vp, c_size, c_int, c_f, c_f, c_f, c_f, c_float, c_float, c_vp,
+                                          c_f, c_f, c_f, c_f, c_int, c_float, c_f, c_int, c_f, c_f, c_vp]),
+    "srk_bn_backward_partials_act": (c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_size, c_int, c_int, c_float, c_f, c_int, c_vp,
+                                             ctypes.POINTER(c_int), c_vp]),
+    "srk_bn_backward_finalize_apply_act": (c_int, [c_vp, c_int, c_vp, ctypes.c_double, c_f, c_f, c_f, c_f, c_f, c_f, c_f,
+                                                   c_size, c_int, c_f, c_f, c_int, c_float, c_f, c_int, c_f, c_vp]),
     "srk_bn_eval_params": (c_int, [c_f, c_f, c_float, c_f, c_f, c_int, c_vp]),
     "srk_rownorm_forward": (c_int, [c_f, c_f, c_f, c_f, c_int, c_int, c_float, c_vp]),
     "srk_rownorm_backward": (c_int, [c_f, c_f, c_f, c_f, c_f, c_int, c_int, c_vp]),

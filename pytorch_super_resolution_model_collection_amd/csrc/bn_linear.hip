@@ -594,6 +594,257 @@ static bool bn_fp32_backward() {
   return env_int("SRK_BN_F32", 0) == 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the split reduction FINISHED INSIDE the apply kernel ("finalize-in-apply").
+// A BatchNorm call was column sums -> reduce -> apply (forward) and column sums -> reduce -> apply (backward): six launches,
+// each at the ~5 us per-node floor of a replayed hipGraph on the 4 MB tensors of the SRGAN step (458 of its 846 nodes).  An
+// in-kernel hand-off does not beat that floor -- but the reduce needs no hand-off at all if every block of the
+// apply kernel sums the partials of ITS OWN channels again: blocks own a slab of 16 channels x a range of rows, start with
+// k_bn_reduce16's summation (64 phases x 16 channels, the same order: forward statistics bit-equal to the two-launch path)
+// over the slab's [nsplit][16] partials -- 32 - 96 KB from L2 per block, no cross-block dependency -- and go straight on to
+// their rows.  The first row-range block of a slab also writes what the reduce kernel wrote (mean / rstd / running
+// statistics / the [2C] sums; dgamma / dbeta / dprelu).  One launch less per BatchNorm and direction.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int BNF_CS = 16;      // channels per slab
+constexpr int BNF_THR = 1024;   // 64 phases x 16 channels in the reduction, 256 rows x 4 float4 in the apply loop
+
+// totals of NQ sums for channel c (the thread's t & 15) over partial[k * kstride + q * qstride + c], k < nsplit; every thread
+// of the block returns the totals of ITS channel.  Order of k_bn_reduce16.
+template <int NQ>
+__device__ __forceinline__ void bn_slab_totals(const double* __restrict__ partial, int nsplit, size_t kstride, size_t qstride,
+                                               int c, double (*sm)[64][BNF_CS], double (&tot)[NQ]) {
+  const int t = threadIdx.x, cl = t & 15, ph = t >> 4;
+  double a0[NQ], a1[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) a0[q] = a1[q] = 0.0;
+  constexpr int U = 8;
+  for (int kb = ph; kb < nsplit; kb += 64 * U) {
+    double v[U][NQ];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = kb + 64 * u, kc = k < nsplit ? k : nsplit - 1;   // (clamped unconditional loads + select: see k_bn_colsum)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) v[u][q] = partial[(size_t)kc * kstride + q * qstride + c];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (kb + 64 * u >= nsplit) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v[u][q] = 0.0;
+      }
+#pragma unroll
+    for (int u = 0; u < U; u += 2)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        a0[q] += v[u][q];
+        a1[q] += v[u + 1][q];
+      }
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) sm[q][ph][cl] = a0[q] + a1[q];
+  __syncthreads();
+  double s[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) s[q] = 0.0;
+  if (ph < 8) {   // phases 8 ph .. 8 ph + 7
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) s[q] += sm[q][ph * 8 + j][cl];
+  }
+  __syncthreads();
+  if (ph < 8) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) sm[q][ph][cl] = s[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    double r = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r += sm[q][j][cl];
+    tot[q] = r;
+  }
+}
+
+// forward: statistics from [nsplit][2][C] partials + y = act(gamma * (x - mean) * rstd + beta) [+ residual]
+__global__ __launch_bounds__(BNF_THR) void k_bn_fin_apply_act(const double* __restrict__ partial, int nsplit, double count,
+                                                              const float* __restrict__ x, float* __restrict__ y, BnAct A,
+                                                              const float* __restrict__ residual, size_t rows, int C,
+                                                              size_t rows_per_block, float* __restrict__ save_mean,
+                                                              float* __restrict__ save_rstd, double* __restrict__ stats,
+                                                              float* __restrict__ rm, float* __restrict__ rv, float momentum,
+                                                              float eps, long long* __restrict__ nbt,
+                                                              float* __restrict__ y_amax) {
+  __shared__ double sm[2][64][BNF_CS];
+  __shared__ float prm[5][BNF_CS];   // mean, rstd, gamma, beta, negative-side slope of the slab's channels
+  __shared__ float sm_amax[BNF_THR / 64];
+  const int t = threadIdx.x, cl = t & 15, ph = t >> 4;
+  const int c0 = blockIdx.x * BNF_CS, c = c0 + cl;
+  double tot[2];
+  bn_slab_totals<2>(partial, nsplit, (size_t)2 * C, (size_t)C, c, sm, tot);
+  if (ph == 0) {   // (the arithmetic of k_bn_reduce16<0>)
+    const double mean = tot[0] / count;
+    double var = tot[1] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)eps));
+    prm[0][cl] = mf;
+    prm[1][cl] = rf;
+    prm[2][cl] = A.gamma ? A.gamma[c] : 1.f;
+    prm[3][cl] = A.beta ? A.beta[c] : 0.f;
+    prm[4][cl] = A.act == SRK_ACT_NONE ? 1.f : bn_act_slope(A, c);
+    if (blockIdx.y == 0) {
+      stats[c] = tot[0];
+      stats[C + c] = tot[1];
+      if (c == 0 && nbt) *nbt += 1;
+      save_mean[c] = mf;
+      save_rstd[c] = rf;
+      if (rm) rm[c] = (1.f - momentum) * rm[c] + momentum * mf;
+      if (rv) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unbiased;
+      }
+    }
+  }
+  __syncthreads();
+  const int q4 = t & 3, rr = t >> 2;
+  bn_f4 mu, rs, g, b, sl;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    mu[e] = prm[0][q4 * 4 + e];
+    rs[e] = prm[1][q4 * 4 + e];
+    g[e] = prm[2][q4 * 4 + e];
+    b[e] = prm[3][q4 * 4 + e];
+    sl[e] = prm[4][q4 * 4 + e];
+  }
+  float amax = 0.f;
+  const float peeked = amax_peek(y_amax, blockIdx.x + blockIdx.y);
+  const size_t r_begin = (size_t)blockIdx.y * rows_per_block;
+  size_t r_end = r_begin + rows_per_block;
+  if (r_end > rows) r_end = rows;
+  for (size_t r = r_begin + rr; r < r_end; r += BNF_THR / 4) {
+    const size_t off = r * (size_t)C + c0 + q4 * 4;
+    const bn_f4 xv = *reinterpret_cast<const bn_f4*>(x + off);
+    bn_f4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float z = bn_z(xv[e], mu[e], rs[e], g[e], b[e]);
+      v[e] = z > 0.f ? z : sl[e] * z;   // (no activation: slope 1)
+    }
+    if (residual) v += *reinterpret_cast<const bn_f4*>(residual + off);
+    *reinterpret_cast<bn_f4*>(y + off) = v;
+    if (y_amax) amax = abs_max4(amax, v);
+  }
+  if (y_amax) amax_commit_block(y_amax, amax, blockIdx.x + blockIdx.y, sm_amax, BNF_THR / 64, peeked);
+}
+
+// backward: (sum dz, sum dz * xhat[, sum_{z<=0} dy * z]) from [nsplit][NQ][C] partials, parameter gradients, and
+// dx = gamma * rstd * (dz - m1 - xhat * m2) with dz = dy * act'(z), z recomputed from x as in the forward
+template <int NQ, bool DBL>
+__global__ __launch_bounds__(BNF_THR) void k_bn_fin_bwd_apply_act(const double* __restrict__ partial, int nsplit, double count,
+                                                                  const float* __restrict__ dy, const float* __restrict__ x,
+                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  BnAct A, float* __restrict__ dx, size_t rows, int C,
+                                                                  size_t rows_per_block, double* __restrict__ dstats,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  float* __restrict__ dprelu) {
+  __shared__ double sm[NQ][64][BNF_CS];
+  __shared__ double mm[2][BNF_CS];
+  __shared__ float prm[5][BNF_CS];
+  __shared__ float psum[512];
+  const int t = threadIdx.x, cl = t & 15, ph = t >> 4;
+  const int c0 = blockIdx.x * BNF_CS, c = c0 + cl;
+  double tot[NQ];
+  bn_slab_totals<NQ>(partial, nsplit, (size_t)NQ * C, (size_t)C, c, sm, tot);
+  if (ph == 0) {
+    mm[0][cl] = tot[0] / count;
+    mm[1][cl] = tot[1] / count;
+    prm[0][cl] = mean[c];
+    prm[1][cl] = rstd[c];
+    prm[2][cl] = A.gamma ? A.gamma[c] : 1.f;
+    prm[3][cl] = A.beta ? A.beta[c] : 0.f;
+    prm[4][cl] = A.act == SRK_ACT_NONE ? 1.f : bn_act_slope(A, c);
+    if (blockIdx.y == 0) {   // (what k_bn_reduce_act / k_bn_reduce16<1> wrote)
+      dstats[c] = tot[0];
+      dstats[C + c] = tot[1];
+      if (dbeta) dbeta[c] += (float)tot[0];
+      if (dgamma) dgamma[c] += (float)tot[1];
+      if (NQ == 3 && dprelu && A.prelu_n > 1) dprelu[c] += (float)tot[NQ - 1];
+    }
+  }
+  __syncthreads();
+  const int q4 = t & 3, rr = t >> 2;
+  bn_f4 mu, rs, g, b, sl;
+  double m1[4], m2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    mu[e] = prm[0][q4 * 4 + e];
+    rs[e] = prm[1][q4 * 4 + e];
+    g[e] = prm[2][q4 * 4 + e];
+    b[e] = prm[3][q4 * 4 + e];
+    sl[e] = prm[4][q4 * 4 + e];
+    m1[e] = mm[0][q4 * 4 + e];
+    m2[e] = mm[1][q4 * 4 + e];
+  }
+  const bool has_act = A.act != SRK_ACT_NONE;
+  const size_t r_begin = (size_t)blockIdx.y * rows_per_block;
+  size_t r_end = r_begin + rows_per_block;
+  if (r_end > rows) r_end = rows;
+  for (size_t r = r_begin + rr; r < r_end; r += BNF_THR / 4) {
+    const size_t off = r * (size_t)C + c0 + q4 * 4;
+    const bn_f4 dv = *reinterpret_cast<const bn_f4*>(dy + off), xv = *reinterpret_cast<const bn_f4*>(x + off);
+    bn_f4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float dz = dv[e];
+      if (has_act) {
+        const float z = bn_z(xv[e], mu[e], rs[e], g[e], b[e]);
+        dz = z > 0.f ? dv[e] : dv[e] * sl[e];
+      }
+      if (DBL) {
+        const double xhat = ((double)xv[e] - (double)mu[e]) * (double)rs[e];
+        o[e] = (float)((double)g[e] * (double)rs[e] * ((double)dz - m1[e] - xhat * m2[e]));
+      } else {
+        const float xhat = (xv[e] - mu[e]) * rs[e];
+        o[e] = g[e] * rs[e] * (dz - (float)m1[e] - xhat * (float)m2[e]);
+      }
+    }
+    *reinterpret_cast<bn_f4*>(dx + off) = o;
+  }
+  // one PReLU slope for all channels: block (0, 0) sums sum_{z<=0} dy * z over every channel in channel order -- per group
+  // of 64 channels one add, in order, by one thread (k_bn_reduce_act: one atomic per 64-channel block; C = 64: the same sum)
+  if (NQ == 3 && dprelu && A.prelu_n == 1 && blockIdx.x == 0 && blockIdx.y == 0) {
+    for (int sl0 = 0; sl0 < C; sl0 += BNF_CS) {
+      __syncthreads();
+      double t2[1];
+      bn_slab_totals<1>(partial + (size_t)(NQ - 1) * C, nsplit, (size_t)NQ * C, (size_t)C, sl0 + cl, sm, t2);
+      if (ph == 0 && sl0 + cl < 512) psum[sl0 + cl] = (float)t2[0];
+    }
+    __syncthreads();
+    if (t == 0) {
+      for (int cb = 0; cb < C; cb += 64) {
+        double acc = 0.0;
+        for (int q = cb; q < cb + 64 && q < C; ++q) acc += (double)psum[q];
+        *dprelu += (float)acc;
+      }
+    }
+  }
+}
+
+static void bnf_grid(size_t rows, int C, dim3& grid, size_t& rows_per_block) {
+  const int slabs = C / BNF_CS;
+  size_t g = (rows + BNF_THR / 4 - 1) / (BNF_THR / 4);
+  size_t cap = (size_t)(2 * kNumCU / slabs);
+  if (cap < 1) cap = 1;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  size_t rpb = (rows + g - 1) / g;
+  rpb = (rpb + BNF_THR / 4 - 1) / (BNF_THR / 4) * (BNF_THR / 4);
+  g = (rows + rpb - 1) / rpb;
+  rows_per_block = rpb;
+  grid = dim3((unsigned)slabs, (unsigned)g);
+}
+
 struct BnFused {   // fused tail of bn_colsum: what the reduce kernel also computes
   int mode = -1;   // -1: plain reduce
   double count = 0.0;
@@ -1197,6 +1448,106 @@ extern "C" int srk_bn_backward_apply_act(const float* dy, const float* x, const 
     hipLaunchKernelGGL(k_bn_bwd_apply_act4<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, A,
                        dstats, count, dx, total / 4, C);
   return check_launch("bn_backward_apply_act");
+}
+
+// ---- finalize-in-apply entry points (round 6) ---------------------------------------------------------------------------
+extern "C" int srk_bn_fused_supported(int C) { return C > 0 && C % BNF_CS == 0 && C <= 512 && env_int("SRK_BN_FIN_APPLY", 1) != 0; }
+
+extern "C" int srk_bn_stats_partials(const float* x, size_t rows, int C, void* workspace, int* splits_out, void* stream) {
+  SRK_REQUIRE(x && workspace && splits_out && rows > 0 && C > 0, "bn_stats_partials: bad args");
+  int splits = (int)((rows + 63) / 64);
+  if (splits > kBnRowSplits) splits = kBnRowSplits;
+  if (splits < 1) splits = 1;
+  const size_t rps = (rows + splits - 1) / splits;
+  hipLaunchKernelGGL((k_bn_colsum<0, false>), dim3(cdiv(C, 64), splits), dim3(256), 0, (hipStream_t)stream, x, nullptr, nullptr,
+                     nullptr, (double*)workspace, rows, C, rps);
+  *splits_out = splits;
+  return check_launch("bn_stats_partials");
+}
+
+extern "C" int srk_bn_finalize_apply_act(const double* partials, int splits, double* stats, size_t rows, int C, float* save_mean,
+                                         float* save_rstd, float* running_mean, float* running_var, float momentum, float eps,
+                                         int64_t* num_batches_tracked, const float* x, float* y, const float* gamma,
+                                         const float* beta, int act, float slope, const float* prelu_weight, int prelu_n,
+                                         const float* residual, float* y_amax, void* stream) {
+  SRK_REQUIRE(partials && stats && save_mean && save_rstd && x && y && splits > 0 && rows > 0, "bn_finalize_apply_act: bad args");
+  SRK_REQUIRE(srk_bn_fused_supported(C), "bn_finalize_apply_act: C must be a multiple of 16, <= 512");
+  int rc = bn_act_check(act, prelu_weight, prelu_n, C, "bn_finalize_apply_act");
+  if (rc) return rc;
+  SRK_REQUIRE(bn_vec4(C, x, y, save_mean, save_rstd, gamma, beta) && ((uintptr_t)residual & 15) == 0,
+              "bn_finalize_apply_act: tensors must be 16-byte aligned");
+  dim3 grid;
+  size_t rpb;
+  bnf_grid(rows, C, grid, rpb);
+  BnAct A{gamma, beta, prelu_weight, act, prelu_n, slope};
+  hipLaunchKernelGGL(k_bn_fin_apply_act, grid, dim3(BNF_THR), 0, (hipStream_t)stream, partials, splits, (double)rows, x, y, A,
+                     residual, rows, C, rpb, save_mean, save_rstd, stats, running_mean, running_var, momentum, eps,
+                     (long long*)num_batches_tracked, y_amax);
+  return check_launch("bn_finalize_apply_act");
+}
+
+// column sums of the backward only: [splits][3][C] (act != NONE: sum dz, sum dz * xhat, sum_{z<=0} dy * z) or [splits][2][C]
+extern "C" int srk_bn_backward_partials_act(const float* dy, const float* x, const float* mean, const float* rstd,
+                                            const float* gamma, const float* beta, size_t rows, int C, int act, float slope,
+                                            const float* prelu_weight, int prelu_n, void* workspace, int* splits_out,
+                                            void* stream) {
+  SRK_REQUIRE(dy && x && mean && rstd && workspace && splits_out && rows > 0 && C > 0, "bn_backward_partials_act: bad args");
+  int rc = bn_act_check(act, prelu_weight, prelu_n, C, "bn_backward_partials_act");
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (act == SRK_ACT_NONE) {
+    int splits = (int)((rows + 63) / 64);
+    if (splits > kBnRowSplits) splits = kBnRowSplits;
+    if (splits < 1) splits = 1;
+    const size_t rps = (rows + splits - 1) / splits;
+    dim3 grid(cdiv(C, 64), splits);
+    if (bn_fp32_backward())
+      hipLaunchKernelGGL((k_bn_colsum<1, false>), grid, dim3(256), 0, s, dy, x, mean, rstd, (double*)workspace, rows, C, rps);
+    else
+      hipLaunchKernelGGL((k_bn_colsum<1, true>), grid, dim3(256), 0, s, dy, x, mean, rstd, (double*)workspace, rows, C, rps);
+    *splits_out = splits;
+    return check_launch("bn_backward_partials_act");
+  }
+  int splits = (int)((rows + 127) / 128);
+  if (splits > kBnRowSplits * 2 / 3) splits = kBnRowSplits * 2 / 3;  // three sums per split in the same workspace
+  if (splits < 1) splits = 1;
+  const size_t rps = (rows + splits - 1) / splits;
+  BnAct A{gamma, beta, prelu_weight, act, prelu_n, slope};
+  hipLaunchKernelGGL(k_bn_colsum_act, dim3(cdiv(C, 64), splits), dim3(256), 0, s, dy, x, mean, rstd, A, (double*)workspace, rows,
+                     C, rps);
+  *splits_out = splits;
+  return check_launch("bn_backward_partials_act");
+}
+
+extern "C" int srk_bn_backward_finalize_apply_act(const double* partials, int splits, double* dstats, double count,
+                                                  const float* dy, const float* x, const float* mean, const float* rstd,
+                                                  const float* gamma, const float* beta, float* dx, size_t rows, int C,
+                                                  float* dgamma, float* dbeta, int act, float slope,
+                                                  const float* prelu_weight, int prelu_n, float* dprelu, void* stream) {
+  SRK_REQUIRE(partials && dstats && dy && x && mean && rstd && dx && splits > 0 && rows > 0 && count > 0,
+              "bn_backward_finalize_apply_act: bad args");
+  SRK_REQUIRE(srk_bn_fused_supported(C), "bn_backward_finalize_apply_act: C must be a multiple of 16, <= 512");
+  int rc = bn_act_check(act, prelu_weight, prelu_n, C, "bn_backward_finalize_apply_act");
+  if (rc) return rc;
+  SRK_REQUIRE(bn_vec4(C, dy, x, mean, rstd, gamma, dx) && ((uintptr_t)beta & 15) == 0,
+              "bn_backward_finalize_apply_act: tensors must be 16-byte aligned");
+  dim3 grid;
+  size_t rpb;
+  bnf_grid(rows, C, grid, rpb);
+  BnAct A{gamma, beta, prelu_weight, act, prelu_n, slope};
+  hipStream_t s = (hipStream_t)stream;
+  const bool f32 = bn_fp32_backward();
+  float* dp = act == SRK_ACT_PRELU ? dprelu : nullptr;
+#define SRK_BNF_LAUNCH(NQ, DBL)                                                                                            \
+  hipLaunchKernelGGL((k_bn_fin_bwd_apply_act<NQ, DBL>), grid, dim3(BNF_THR), 0, s, partials, splits, count, dy, x, mean, rstd, A, \
+                     dx, rows, C, rpb, dstats, dgamma, dbeta, dp)
+  if (act == SRK_ACT_NONE) {
+    if (f32) SRK_BNF_LAUNCH(2, false); else SRK_BNF_LAUNCH(2, true);
+  } else {
+    if (f32) SRK_BNF_LAUNCH(3, false); else SRK_BNF_LAUNCH(3, true);
+  }
+#undef SRK_BNF_LAUNCH
+  return check_launch("bn_backward_finalize_apply_act");
 }
 
 extern "C" int srk_bn_param_grads(const double* dstats, float* dgamma, float* dbeta, int C, void* stream) {

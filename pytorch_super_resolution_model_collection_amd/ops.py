@@ -1169,6 +1169,7 @@ def bce_loss(pred, target):
 # ------------------------------------------------------------------------------------------------
 # BatchNorm2d / Linear (SRGAN)
 # ------------------------------------------------------------------------------------------------
+BN_FIN_APPLY = os.environ.get("SRK_BN_FIN_APPLY", "1") != "0"   # 0: split reductions as launches of their own (rounds 1 - 5)
 BN_FUSE_ACT = os.environ.get("SRK_BN_FUSE_ACT", "1") != "0"   # 0: activations / residual adds after a BatchNorm stay passes of their own
 
 
@@ -1211,7 +1212,18 @@ class _BatchNorm(torch.autograd.Function):
             part = getattr(x, "_srk_bn_partial", None)
             if part is not None and (part[2] != _ver(x) or part[0].shape[1] != 2 * c):
                 part = None
-            if sync_group is None and part is not None:
+            # finalize-in-apply (round 6): the apply kernel finishes the split reduction itself -- one launch less
+            fin = (BN_FIN_APPLY and sync_group is None and lib.srk_bn_fused_supported(c)
+                   and all(t is None or t.data_ptr() % 16 == 0 for t in (x, gamma, beta, residual)))
+            if fin:
+                if part is not None:      # column sums from the producing conv's epilogue (k_c64)
+                    fin_part, fin_splits = part[0], int(part[1])
+                else:
+                    sp = ctypes.c_int(0)
+                    check(lib.srk_bn_stats_partials(ptr(x), rows, c, ptr(ws), ctypes.byref(sp), stream_ptr()),
+                          "srk_bn_stats_partials")
+                    fin_part, fin_splits = ws, int(sp.value)
+            elif sync_group is None and part is not None:
                 # the conv that produced x left its column sums (k_c64's epilogue): reduce + finalize only
                 check(lib.srk_bn_finalize_partials(ptr(part[0]), part[1], ptr(stats), rows, c, ptr(mean), ptr(rstd),
                                                    ptr(running_mean), ptr(running_var), momentum, eps, nbt_p,
@@ -1228,6 +1240,7 @@ class _BatchNorm(torch.autograd.Function):
                 check(lib.srk_bn_finalize(ptr(stats), count, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
                                           momentum, eps, c, nbt_p, stream_ptr()), "srk_bn_finalize")
         else:
+            fin = False
             check(lib.srk_bn_eval_params(ptr(running_mean), ptr(running_var), eps, ptr(mean), ptr(rstd), c,
                                          stream_ptr()), "srk_bn_eval_params")
         y = torch.empty_like(x)
@@ -1240,11 +1253,17 @@ class _BatchNorm(torch.autograd.Function):
                                        and (F16X3_ALWAYS or rows * ((c + 63) // 64) >= F16X3_MIN_PIXELS)
                                        and _MODES[_PRECISION["mode"]]["train_fwd" if training else "infer"]
                                        in (_lib.ALGO_MFMA_BF16X6, _lib.ALGO_MFMA_F16X3)) else None
-        if fused:
-            if residual is not None:
-                residual = _dense(residual)
-                if tuple(residual.shape) != tuple(x.shape) or residual.stride() != x.stride():
-                    raise RuntimeError("batch_norm: residual must have the shape and layout of x")
+        if residual is not None:
+            residual = _dense(residual)
+            if tuple(residual.shape) != tuple(x.shape) or residual.stride() != x.stride():
+                raise RuntimeError("batch_norm: residual must have the shape and layout of x")
+        if fin:
+            check(lib.srk_bn_finalize_apply_act(ptr(fin_part), fin_splits, ptr(stats), rows, c, ptr(mean), ptr(rstd),
+                                                ptr(running_mean), ptr(running_var), momentum, eps, nbt_p, ptr(x), ptr(y),
+                                                ptr(gamma), ptr(beta), act, slope, ptr(prelu_w),
+                                                0 if prelu_w is None else prelu_w.numel(), ptr(residual), ptr(ya),
+                                                stream_ptr()), "srk_bn_finalize_apply_act")
+        elif fused:
             check(lib.srk_bn_apply_act(ptr(x), ptr(y), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), rows, c, act, slope,
                                        ptr(prelu_w), 0 if prelu_w is None else prelu_w.numel(), ptr(residual),
                                        ptr(ya), stream_ptr()), "srk_bn_apply_act")
@@ -1254,6 +1273,7 @@ class _BatchNorm(torch.autograd.Function):
         if ya is not None:
             _tag_amax(y, ya)    # the convolution behind a BatchNorm scales its fp16 planes by this (F16X3)
         ctx.training, ctx.count, ctx.sync_group = training, count, sync_group
+        ctx.fin = fin
         ctx.gamma_ref, ctx.beta_ref, ctx.prelu_ref = gamma, beta, prelu_w
         ctx.act, ctx.slope, ctx.has_res = act, slope, residual is not None
         ctx.save_for_backward(x, gamma, mean, rstd, beta if act != ACT_NONE else None, prelu_w)
@@ -1277,6 +1297,25 @@ class _BatchNorm(torch.autograd.Function):
         dres = dy if ctx.has_res else None   # the residual's gradient is dy itself
         if ctx.has_res and ctx.res_box is not None:
             ctx.res_box.g, dres = dy, None   # parked for the block's first conv, which adds it in its data-gradient kernel
+        if ctx.fin and ctx.training and dy.data_ptr() % 16 == 0:
+            # finalize-in-apply: column sums, then ONE kernel that reduces them (per 16-channel slab), adds the parameter
+            # gradients and writes dx
+            dprelu = None
+            pn = 0 if prelu_w is None else prelu_w.numel()
+            if ctx.act == ACT_PRELU:
+                dprelu = getattr(ctx.prelu_ref, "_srk_grad", None)
+                if dprelu is None:
+                    dprelu = ret_p = torch.zeros_like(prelu_w)
+            sp = ctypes.c_int(0)
+            check(lib.srk_bn_backward_partials_act(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), rows, c,
+                                                   ctx.act, ctx.slope, ptr(prelu_w), pn, ptr(ws), ctypes.byref(sp),
+                                                   stream_ptr()), "srk_bn_backward_partials_act")
+            dx = torch.empty_like(dy)
+            check(lib.srk_bn_backward_finalize_apply_act(ptr(ws), int(sp.value), ptr(dstats), ctx.count, ptr(dy), ptr(x),
+                                                         ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), rows, c,
+                                                         ptr(dgamma), ptr(dbeta), ctx.act, ctx.slope, ptr(prelu_w), pn,
+                                                         ptr(dprelu), stream_ptr()), "srk_bn_backward_finalize_apply_act")
+            return dx, ret_g, ret_b, None, None, None, None, None, None, None, None, None, ret_p, dres, None
         if ctx.act != ACT_NONE:
             dprelu = None
             pn = 0 if prelu_w is None else prelu_w.numel()

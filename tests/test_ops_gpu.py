@@ -859,6 +859,66 @@ def test_batchnorm_with_folded_activation_and_residual(gpu, act):
     assert rc != 0
 
 
+@pytest.mark.parametrize("shape", [(16, 64, 32, 32), (5, 16, 9, 11), (8, 512, 8, 8), (3, 128, 37, 20), (16, 64, 64, 64)])
+@pytest.mark.parametrize("act", ["none", "lrelu", "prelu1", "preluC", "none+res", "prelu1+res"])
+def test_batchnorm_finalize_in_apply(gpu, monkeypatch, shape, act):
+    """Round 6: the apply kernels finish the split reduction themselves (srk_bn_finalize_apply_act /
+    srk_bn_backward_finalize_apply_act: one launch less per BatchNorm and direction).  Against torch's float64 BatchNorm ->
+    activation -> add, and against the separate-launch path (SRK_BN_FIN_APPLY=0): the forward statistics and outputs of the two
+    paths must be bit-equal (same summation order, same z), the backward equal to fp32 rounding; one and several row ranges per
+    slab, 1 .. 32 slabs, ragged last range, 64 .. 512 row splits."""
+    import torch.nn.functional as F
+    pkg = _pkg()
+    ops = pkg.ops
+    n, c, h, w = shape
+    x = fill.randn((n, c, h, w), 281) * 1.7 + 0.3
+    res = fill.randn((n, c, h, w), 282) if act.endswith("+res") else None
+    dy = fill.randn((n, c, h, w), 283)
+    gamma, beta = fill.rand((c,), 284, 0.5, 1.5), fill.randn((c,), 285) * 0.3
+    kind = act.split("+")[0]
+    pw = fill.rand((1 if kind == "prelu1" else c,), 286, 0.1, 0.4) if kind.startswith("prelu") else None
+    code = {"lrelu": pkg._lib.ACT_LRELU, "prelu1": pkg._lib.ACT_PRELU, "preluC": pkg._lib.ACT_PRELU, "none": pkg._lib.ACT_NONE}[kind]
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    pr = pw.double().requires_grad_(True) if pw is not None else None
+    z = F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    yr = F.leaky_relu(z, 0.2) if kind == "lrelu" else (F.prelu(z, pr) if pw is not None else z)
+    if res is not None:
+        yr = yr + res.double()
+    yr.backward(dy.double())
+    assert pkg._lib.load().srk_bn_fused_supported(c) == 1
+    out = {}
+    for fin in (True, False):
+        monkeypatch.setattr(ops, "BN_FIN_APPLY", fin)
+        xg = x.to(gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        gg, bg = gamma.to(gpu).requires_grad_(True), beta.to(gpu).requires_grad_(True)
+        pg = pw.to(gpu).requires_grad_(True) if pw is not None else None
+        rg = res.to(gpu).contiguous(memory_format=torch.channels_last) if res is not None else None
+        rm, rv = torch.zeros(c, device=gpu), torch.ones(c, device=gpu)
+        nbt = torch.zeros((), dtype=torch.int64, device=gpu)
+        y = ops.batch_norm(xg, gg, bg, rm, rv, True, 0.1, 1e-5, None, nbt, code, 0.2, pg, rg)
+        y.backward(dy.to(gpu).contiguous(memory_format=torch.channels_last))
+        out[fin] = (y.detach(), rm, rv, xg.grad, gg.grad, bg.grad, None if pg is None else pg.grad)
+        assert int(nbt) == 1
+        assert_close_elementwise(y, yr.detach(), 4e-6, what="forward")
+        assert_close_elementwise(xg.grad, xr.grad, 5e-5, what="dx")
+        assert_close_elementwise(gg.grad, gr.grad, 1e-5, what="dgamma")
+        assert_close_elementwise(bg.grad, br.grad, 1e-5, what="dbeta")
+        if pw is not None:
+            assert_close_elementwise(pg.grad, pr.grad, 1e-5, what="dprelu")
+        m = x.double().mean((0, 2, 3))
+        v = x.double().var((0, 2, 3), unbiased=True)
+        assert_close_elementwise(rm, 0.1 * m, 2e-6, what="running_mean")
+        assert_close_elementwise(rv, 0.9 + 0.1 * v, 2e-6, what="running_var")
+    a, b = out[True], out[False]
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])          # statistics: the reduce kernel's summation order
+    if act != "none":                                                    # (the plain apply kernel writes its affine differently)
+        assert torch.equal(a[0], b[0])
+    for u, v_ in zip(a[3:], b[3:]):
+        if u is not None:
+            assert rel_err(u, v_) < 2e-6
+
+
 def test_layout_roundtrip_and_ragged(gpu):
     """NCHW<->NHWC copies at ragged sizes (non multiples of the 32x32 transpose tile)."""
     pkg = _pkg()
