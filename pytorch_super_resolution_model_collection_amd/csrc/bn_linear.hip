@@ -681,6 +681,17 @@ __global__ __launch_bounds__(BNF_THR) void k_bn_fin_apply_act(const double* __re
   __shared__ float sm_amax[BNF_THR / 64];
   const int t = threadIdx.x, cl = t & 15, ph = t >> 4;
   const int c0 = blockIdx.x * BNF_CS, c = c0 + cl;
+  // the thread's first row is requested BEFORE the reduction (it does not depend on the statistics): its latency hides
+  // behind the partial loads and the three barriers of the prologue -- most blocks have exactly one row per thread
+  const int q4 = t & 3, rr = t >> 2;
+  const size_t r_begin = (size_t)blockIdx.y * rows_per_block;
+  size_t r_end = r_begin + rows_per_block;
+  if (r_end > rows) r_end = rows;
+  const size_t r_first = r_begin + rr < r_end ? r_begin + rr : (r_end - 1);   // (clamped: unconditional loads)
+  const size_t off_first = r_first * (size_t)C + c0 + q4 * 4;
+  bn_f4 x_first = *reinterpret_cast<const bn_f4*>(x + off_first);
+  bn_f4 res_first = {0.f, 0.f, 0.f, 0.f};
+  if (residual) res_first = *reinterpret_cast<const bn_f4*>(residual + off_first);
   double tot[2];
   bn_slab_totals<2>(partial, nsplit, (size_t)2 * C, (size_t)C, c, sm, tot);
   if (ph == 0) {   // (the arithmetic of k_bn_reduce16<0>)
@@ -707,7 +718,6 @@ __global__ __launch_bounds__(BNF_THR) void k_bn_fin_apply_act(const double* __re
     }
   }
   __syncthreads();
-  const int q4 = t & 3, rr = t >> 2;
   bn_f4 mu, rs, g, b, sl;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -719,29 +729,34 @@ __global__ __launch_bounds__(BNF_THR) void k_bn_fin_apply_act(const double* __re
   }
   float amax = 0.f;
   const float peeked = amax_peek(y_amax, blockIdx.x + blockIdx.y);
-  const size_t r_begin = (size_t)blockIdx.y * rows_per_block;
-  size_t r_end = r_begin + rows_per_block;
-  if (r_end > rows) r_end = rows;
+  bn_f4 xv = x_first, rv4 = res_first;
   for (size_t r = r_begin + rr; r < r_end; r += BNF_THR / 4) {
     const size_t off = r * (size_t)C + c0 + q4 * 4;
-    const bn_f4 xv = *reinterpret_cast<const bn_f4*>(x + off);
     bn_f4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float z = bn_z(xv[e], mu[e], rs[e], g[e], b[e]);
       v[e] = z > 0.f ? z : sl[e] * z;   // (no activation: slope 1)
     }
-    if (residual) v += *reinterpret_cast<const bn_f4*>(residual + off);
+    if (residual) v += rv4;
     *reinterpret_cast<bn_f4*>(y + off) = v;
     if (y_amax) amax = abs_max4(amax, v);
+    const size_t rn = r + BNF_THR / 4;
+    if (rn < r_end) {
+      const size_t offn = rn * (size_t)C + c0 + q4 * 4;
+      xv = *reinterpret_cast<const bn_f4*>(x + offn);
+      if (residual) rv4 = *reinterpret_cast<const bn_f4*>(residual + offn);
+    }
   }
   if (y_amax) amax_commit_block(y_amax, amax, blockIdx.x + blockIdx.y, sm_amax, BNF_THR / 64, peeked);
 }
 
 // backward: (sum dz, sum dz * xhat[, sum_{z<=0} dy * z]) from [nsplit][NQ][C] partials, parameter gradients, and
 // dx = gamma * rstd * (dz - m1 - xhat * m2) with dz = dy * act'(z), z recomputed from x as in the forward
+// NQ sums are reduced per channel; `pq` = planes per split row of `partial` (3 behind k_bn_colsum_act even where the third --
+// PReLU's slope gradient -- is not wanted: NQ = 2 then reads two of the three)
 template <int NQ, bool DBL>
-__global__ __launch_bounds__(BNF_THR) void k_bn_fin_bwd_apply_act(const double* __restrict__ partial, int nsplit, double count,
+__global__ __launch_bounds__(BNF_THR) void k_bn_fin_bwd_apply_act(const double* __restrict__ partial, int nsplit, int pq, double count,
                                                                   const float* __restrict__ dy, const float* __restrict__ x,
                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                   BnAct A, float* __restrict__ dx, size_t rows, int C,
@@ -751,11 +766,18 @@ __global__ __launch_bounds__(BNF_THR) void k_bn_fin_bwd_apply_act(const double* 
   __shared__ double sm[NQ][64][BNF_CS];
   __shared__ double mm[2][BNF_CS];
   __shared__ float prm[5][BNF_CS];
-  __shared__ float psum[512];
   const int t = threadIdx.x, cl = t & 15, ph = t >> 4;
   const int c0 = blockIdx.x * BNF_CS, c = c0 + cl;
+  // (first row requested before the reduction: see k_bn_fin_apply_act)
+  const int q4 = t & 3, rr = t >> 2;
+  const size_t r_begin = (size_t)blockIdx.y * rows_per_block;
+  size_t r_end = r_begin + rows_per_block;
+  if (r_end > rows) r_end = rows;
+  const size_t r_first = r_begin + rr < r_end ? r_begin + rr : (r_end - 1);
+  const size_t off_first = r_first * (size_t)C + c0 + q4 * 4;
+  bn_f4 dv = *reinterpret_cast<const bn_f4*>(dy + off_first), xv = *reinterpret_cast<const bn_f4*>(x + off_first);
   double tot[NQ];
-  bn_slab_totals<NQ>(partial, nsplit, (size_t)NQ * C, (size_t)C, c, sm, tot);
+  bn_slab_totals<NQ>(partial, nsplit, (size_t)pq * C, (size_t)C, c, sm, tot);
   if (ph == 0) {
     mm[0][cl] = tot[0] / count;
     mm[1][cl] = tot[1] / count;
@@ -773,7 +795,6 @@ __global__ __launch_bounds__(BNF_THR) void k_bn_fin_bwd_apply_act(const double* 
     }
   }
   __syncthreads();
-  const int q4 = t & 3, rr = t >> 2;
   bn_f4 mu, rs, g, b, sl;
   double m1[4], m2[4];
 #pragma unroll
@@ -787,12 +808,8 @@ __global__ __launch_bounds__(BNF_THR) void k_bn_fin_bwd_apply_act(const double* 
     m2[e] = mm[1][q4 * 4 + e];
   }
   const bool has_act = A.act != SRK_ACT_NONE;
-  const size_t r_begin = (size_t)blockIdx.y * rows_per_block;
-  size_t r_end = r_begin + rows_per_block;
-  if (r_end > rows) r_end = rows;
   for (size_t r = r_begin + rr; r < r_end; r += BNF_THR / 4) {
     const size_t off = r * (size_t)C + c0 + q4 * 4;
-    const bn_f4 dv = *reinterpret_cast<const bn_f4*>(dy + off), xv = *reinterpret_cast<const bn_f4*>(x + off);
     bn_f4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -810,23 +827,35 @@ __global__ __launch_bounds__(BNF_THR) void k_bn_fin_bwd_apply_act(const double* 
       }
     }
     *reinterpret_cast<bn_f4*>(dx + off) = o;
+    const size_t rn = r + BNF_THR / 4;
+    if (rn < r_end) {
+      const size_t offn = rn * (size_t)C + c0 + q4 * 4;
+      dv = *reinterpret_cast<const bn_f4*>(dy + offn);
+      xv = *reinterpret_cast<const bn_f4*>(x + offn);
+    }
   }
-  // one PReLU slope for all channels: block (0, 0) sums sum_{z<=0} dy * z over every channel in channel order -- per group
-  // of 64 channels one add, in order, by one thread (k_bn_reduce_act: one atomic per 64-channel block; C = 64: the same sum)
+  // one PReLU slope for all channels: block (0, 0) sums the whole third plane (sum_{z<=0} dy * z: [nsplit][C] doubles) in a
+  // fixed order -- a strided pass per thread, then a sequential tree through LDS -- and adds it once.  (The first version
+  // re-ran the slab reduction for every slab here: C / 16 x four barriers behind the block's own rows, 17 us per launch.)
   if (NQ == 3 && dprelu && A.prelu_n == 1 && blockIdx.x == 0 && blockIdx.y == 0) {
-    for (int sl0 = 0; sl0 < C; sl0 += BNF_CS) {
-      __syncthreads();
-      double t2[1];
-      bn_slab_totals<1>(partial + (size_t)(NQ - 1) * C, nsplit, (size_t)NQ * C, (size_t)C, sl0 + cl, sm, t2);
-      if (ph == 0 && sl0 + cl < 512) psum[sl0 + cl] = (float)t2[0];
+    double acc = 0.0;
+    const int total = nsplit * C;
+    for (int idx = t; idx < total; idx += BNF_THR) {
+      const int k = idx / C, cc = idx - k * C;
+      acc += partial[(size_t)k * pq * C + (size_t)2 * C + cc];
     }
     __syncthreads();
+    double* red = &sm[0][0][0];   // 1024 doubles of the 3072
+    red[t] = acc;
+    __syncthreads();
+    for (int w = BNF_THR / 2; w >= 64; w >>= 1) {
+      if (t < w) red[t] += red[t + w];
+      __syncthreads();
+    }
     if (t == 0) {
-      for (int cb = 0; cb < C; cb += 64) {
-        double acc = 0.0;
-        for (int q = cb; q < cb + 64 && q < C; ++q) acc += (double)psum[q];
-        *dprelu += (float)acc;
-      }
+      double r = 0.0;
+      for (int q = 0; q < 64; ++q) r += red[q];
+      *dprelu += (float)r;
     }
   }
 }
@@ -1538,10 +1567,11 @@ extern "C" int srk_bn_backward_finalize_apply_act(const double* partials, int sp
   hipStream_t s = (hipStream_t)stream;
   const bool f32 = bn_fp32_backward();
   float* dp = act == SRK_ACT_PRELU ? dprelu : nullptr;
+  const int pq = act == SRK_ACT_NONE ? 2 : 3;   // planes per split row (srk_bn_backward_partials_act)
 #define SRK_BNF_LAUNCH(NQ, DBL)                                                                                            \
-  hipLaunchKernelGGL((k_bn_fin_bwd_apply_act<NQ, DBL>), grid, dim3(BNF_THR), 0, s, partials, splits, count, dy, x, mean, rstd, A, \
+  hipLaunchKernelGGL((k_bn_fin_bwd_apply_act<NQ, DBL>), grid, dim3(BNF_THR), 0, s, partials, splits, pq, count, dy, x, mean, rstd, A, \
                      dx, rows, C, rpb, dstats, dgamma, dbeta, dp)
-  if (act == SRK_ACT_NONE) {
+  if (!dp) {    // no PReLU slope gradient wanted: two sums
     if (f32) SRK_BNF_LAUNCH(2, false); else SRK_BNF_LAUNCH(2, true);
   } else {
     if (f32) SRK_BNF_LAUNCH(3, false); else SRK_BNF_LAUNCH(3, true);

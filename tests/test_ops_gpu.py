@@ -1500,15 +1500,17 @@ def test_conv_c64_leaves_batchnorm_column_sums(gpu, shape):
         ops.BN_PARTIAL = on
         # (the fused path must actually RUN in the `on` arm -- if the conv output lost its tag on the way to the BatchNorm,
         #  both arms would take the classic path and agree trivially: count the finalize calls)
-        real, calls = lib.srk_bn_finalize_partials, []
-        lib.srk_bn_finalize_partials = lambda *a: (calls.append(1), real(*a))[1]
+        #  round 6: the consumer of the sums is srk_bn_finalize_apply_act, and WITHOUT them that path first launches
+        #  srk_bn_stats_partials -- count those)
+        real, calls = lib.srk_bn_stats_partials, []
+        lib.srk_bn_stats_partials = lambda *a: (calls.append(1), real(*a))[1]
         try:
             out = blk(xin)
             out.square().mean().backward()
         finally:
             ops.BN_PARTIAL = old
-            lib.srk_bn_finalize_partials = real
-        assert len(calls) == (2 if on else 0), (on, len(calls))    # conv1 -> bn and conv2 -> bn (one shared BatchNorm)
+            lib.srk_bn_stats_partials = real
+        assert len(calls) == (0 if on else 2), (on, len(calls))    # conv1 -> bn and conv2 -> bn (one shared BatchNorm)
         outs[on] = (out.detach(), xin.grad, blk.bn.running_mean.clone(), blk.bn.running_var.clone(), blk.conv1.weight.grad)
     for a, bb in zip(outs[True], outs[False]):
         assert rel_err(a, bb) < 1e-5
