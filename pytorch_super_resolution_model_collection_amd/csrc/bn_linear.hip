@@ -667,6 +667,17 @@ __device__ __forceinline__ void bn_slab_totals(const double* __restrict__ partia
   }
 }
 
+// block -> (slab, row range): the slabs of ONE row range sit on consecutive blocks of one XCD (hardware deals block ids
+// round-robin over the 8 XCDs): a 128-byte line of the tensor holds two slabs' 64 bytes, and with slab = blockIdx.x the two
+// readers of a line were on different XCDs -- every line fetched into two L2s
+__device__ __forceinline__ void bnf_block(int slabs, int& slab, int& range) {
+  const int nb = gridDim.x, per = nb >> 3, rem = nb & 7;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int b = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
+  range = b / slabs;
+  slab = b - range * slabs;
+}
+
 // forward: statistics from [nsplit][2][C] partials + y = act(gamma * (x - mean) * rstd + beta) [+ residual]
 __global__ __launch_bounds__(BNF_THR) void k_bn_fin_apply_act(const double* __restrict__ partial, int nsplit, double count,
                                                               const float* __restrict__ x, float* __restrict__ y, BnAct A,
@@ -680,11 +691,13 @@ __global__ __launch_bounds__(BNF_THR) void k_bn_fin_apply_act(const double* __re
   __shared__ float prm[5][BNF_CS];   // mean, rstd, gamma, beta, negative-side slope of the slab's channels
   __shared__ float sm_amax[BNF_THR / 64];
   const int t = threadIdx.x, cl = t & 15, ph = t >> 4;
-  const int c0 = blockIdx.x * BNF_CS, c = c0 + cl;
+  int bslab, brange;
+  bnf_block(C / BNF_CS, bslab, brange);
+  const int c0 = bslab * BNF_CS, c = c0 + cl;
   // the thread's first row is requested BEFORE the reduction (it does not depend on the statistics): its latency hides
   // behind the partial loads and the three barriers of the prologue -- most blocks have exactly one row per thread
   const int q4 = t & 3, rr = t >> 2;
-  const size_t r_begin = (size_t)blockIdx.y * rows_per_block;
+  const size_t r_begin = (size_t)brange * rows_per_block;
   size_t r_end = r_begin + rows_per_block;
   if (r_end > rows) r_end = rows;
   const size_t r_first = r_begin + rr < r_end ? r_begin + rr : (r_end - 1);   // (clamped: unconditional loads)
@@ -704,7 +717,7 @@ __global__ __launch_bounds__(BNF_THR) void k_bn_fin_apply_act(const double* __re
     prm[2][cl] = A.gamma ? A.gamma[c] : 1.f;
     prm[3][cl] = A.beta ? A.beta[c] : 0.f;
     prm[4][cl] = A.act == SRK_ACT_NONE ? 1.f : bn_act_slope(A, c);
-    if (blockIdx.y == 0) {
+    if (brange == 0) {
       stats[c] = tot[0];
       stats[C + c] = tot[1];
       if (c == 0 && nbt) *nbt += 1;
@@ -728,7 +741,7 @@ __global__ __launch_bounds__(BNF_THR) void k_bn_fin_apply_act(const double* __re
     sl[e] = prm[4][q4 * 4 + e];
   }
   float amax = 0.f;
-  const float peeked = amax_peek(y_amax, blockIdx.x + blockIdx.y);
+  const float peeked = amax_peek(y_amax, blockIdx.x);
   bn_f4 xv = x_first, rv4 = res_first;
   for (size_t r = r_begin + rr; r < r_end; r += BNF_THR / 4) {
     const size_t off = r * (size_t)C + c0 + q4 * 4;
@@ -748,7 +761,7 @@ __global__ __launch_bounds__(BNF_THR) void k_bn_fin_apply_act(const double* __re
       if (residual) rv4 = *reinterpret_cast<const bn_f4*>(residual + offn);
     }
   }
-  if (y_amax) amax_commit_block(y_amax, amax, blockIdx.x + blockIdx.y, sm_amax, BNF_THR / 64, peeked);
+  if (y_amax) amax_commit_block(y_amax, amax, blockIdx.x, sm_amax, BNF_THR / 64, peeked);
 }
 
 // backward: (sum dz, sum dz * xhat[, sum_{z<=0} dy * z]) from [nsplit][NQ][C] partials, parameter gradients, and
@@ -767,10 +780,12 @@ __global__ __launch_bounds__(BNF_THR) void k_bn_fin_bwd_apply_act(const double* 
   __shared__ double mm[2][BNF_CS];
   __shared__ float prm[5][BNF_CS];
   const int t = threadIdx.x, cl = t & 15, ph = t >> 4;
-  const int c0 = blockIdx.x * BNF_CS, c = c0 + cl;
+  int bslab, brange;
+  bnf_block(C / BNF_CS, bslab, brange);
+  const int c0 = bslab * BNF_CS, c = c0 + cl;
   // (first row requested before the reduction: see k_bn_fin_apply_act)
   const int q4 = t & 3, rr = t >> 2;
-  const size_t r_begin = (size_t)blockIdx.y * rows_per_block;
+  const size_t r_begin = (size_t)brange * rows_per_block;
   size_t r_end = r_begin + rows_per_block;
   if (r_end > rows) r_end = rows;
   const size_t r_first = r_begin + rr < r_end ? r_begin + rr : (r_end - 1);
@@ -786,7 +801,7 @@ __global__ __launch_bounds__(BNF_THR) void k_bn_fin_bwd_apply_act(const double* 
     prm[2][cl] = A.gamma ? A.gamma[c] : 1.f;
     prm[3][cl] = A.beta ? A.beta[c] : 0.f;
     prm[4][cl] = A.act == SRK_ACT_NONE ? 1.f : bn_act_slope(A, c);
-    if (blockIdx.y == 0) {   // (what k_bn_reduce_act / k_bn_reduce16<1> wrote)
+    if (brange == 0) {   // (what k_bn_reduce_act / k_bn_reduce16<1> wrote)
       dstats[c] = tot[0];
       dstats[C + c] = tot[1];
       if (dbeta) dbeta[c] += (float)tot[0];
@@ -837,7 +852,7 @@ __global__ __launch_bounds__(BNF_THR) void k_bn_fin_bwd_apply_act(const double* 
   // one PReLU slope for all channels: block (0, 0) sums the whole third plane (sum_{z<=0} dy * z: [nsplit][C] doubles) in a
   // fixed order -- a strided pass per thread, then a sequential tree through LDS -- and adds it once.  (The first version
   // re-ran the slab reduction for every slab here: C / 16 x four barriers behind the block's own rows, 17 us per launch.)
-  if (NQ == 3 && dprelu && A.prelu_n == 1 && blockIdx.x == 0 && blockIdx.y == 0) {
+  if (NQ == 3 && dprelu && A.prelu_n == 1 && bslab == 0 && brange == 0) {
     double acc = 0.0;
     const int total = nsplit * C;
     for (int idx = t; idx < total; idx += BNF_THR) {
@@ -871,7 +886,7 @@ static void bnf_grid(size_t rows, int C, dim3& grid, size_t& rows_per_block) {
   rpb = (rpb + BNF_THR / 4 - 1) / (BNF_THR / 4) * (BNF_THR / 4);
   g = (rows + rpb - 1) / rpb;
   rows_per_block = rpb;
-  grid = dim3((unsigned)slabs, (unsigned)g);
+  grid = dim3((unsigned)(slabs * g));
 }
 
 struct BnFused {   // fused tail of bn_colsum: what the reduce kernel also computes
