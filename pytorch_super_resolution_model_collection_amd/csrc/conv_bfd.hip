@@ -256,9 +256,9 @@ constexpr int bfd_occ() {
   return 0;
 }
 
+// The kernel body; `bx` = the block's tile index (blockIdx.x of a single-phase launch).
 template <int NTW, int NPW, int NOW, int NP, int PF, int KS, bool F16 = false, int OCCX = 0>
-__global__ __launch_bounds__(64 * NPW * NOW * KS, OCCX ? OCCX : (bfd_occ<NTW, NPW, NOW, NP, PF, KS>() ? bfd_occ<NTW, NPW, NOW, NP, PF, KS>() : 2)) void k_conv_bfd(
-    BfdParams B) {
+__device__ __forceinline__ void bfd_body(const BfdParams& B, const int bx) {
   static_assert(!F16 || NP == 2, "f16x3 has two planes");
   constexpr int NTHR = 64 * NPW * NOW * KS;
   constexpr bool TEPI = NPW == 1;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, OCCX ? OCCX : (bfd_occ<NTW, NP
   const int pw = wave % NPW, ow = wave / NPW;
   const int col = lane & 15, kq = lane >> 4;
   const int j = (int)((B.perm >> (4 * col)) & 15);   // this lane's pixel within a 16-pixel M tile
-  int b = blockIdx.x;
+  int b = bx;
   const int txi = b % P.tiles_x;
   b /= P.tiles_x;
   const int tyi = b % P.tiles_y;
@@ -491,6 +491,34 @@ __global__ __launch_bounds__(64 * NPW * NOW * KS, OCCX ? OCCX : (bfd_occ<NTW, NP
     bfd_epilogue<NTW, NPW, NOW>(P, B.perm, reinterpret_cast<float*>(smem4), acc, n, r0, c0, ocb, pw, ow, lane, kgrp == 0);
 }
 
+template <int NTW, int NPW, int NOW, int NP, int PF, int KS, bool F16 = false, int OCCX = 0>
+__global__ __launch_bounds__(64 * NPW * NOW * KS, OCCX ? OCCX : (bfd_occ<NTW, NPW, NOW, NP, PF, KS>() ? bfd_occ<NTW, NPW, NOW, NP, PF, KS>() : 2)) void k_conv_bfd(
+    BfdParams B) {
+  bfd_body<NTW, NPW, NOW, NP, PF, KS, F16, OCCX>(B, (int)blockIdx.x);
+}
+
+// All phases of a strided TRANS gather in ONE launch (round 6).  for_each_phase turns a stride-s transposed gather (the data
+// gradient of a stride-s conv, a deconv forward) into s * s stride-1 problems with their own tap subsets; they used to be
+// s * s launches -- on the SRGAN discriminator's deep layers (512 -> 512 at 8 x 8 per phase, 16 patches) four latency chains
+// of 128 blocks each, back to back: 113 us.  Here the phases' parameter blocks travel together in the kernel arguments, a
+// block finds its phase from its index (wave-uniform: scalar loads with a register offset) and the chains run side by side.
+constexpr int BFD_MAXPH = 4;
+struct BfdMulti {
+  BfdParams ph[BFD_MAXPH];
+  int start[BFD_MAXPH + 1];   // first block of phase p
+  int nph;
+};
+template <int NTW, int NPW, int NOW, int NP, int PF, int KS, bool F16 = false, int OCCX = 0>
+__global__ __launch_bounds__(64 * NPW * NOW * KS, OCCX ? OCCX : (bfd_occ<NTW, NPW, NOW, NP, PF, KS>() ? bfd_occ<NTW, NPW, NOW, NP, PF, KS>() : 2)) void k_conv_bfd_mp(
+    BfdMulti M) {
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < BFD_MAXPH; ++q)
+    if (q < M.nph && (int)blockIdx.x >= M.start[q]) p = q;
+  p = __builtin_amdgcn_readfirstlane(p);
+  bfd_body<NTW, NPW, NOW, NP, PF, KS, F16, OCCX>(M.ph[p], (int)blockIdx.x - M.start[p]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host
 // ---------------------------------------------------------------------------------------------
@@ -671,6 +699,88 @@ static int bfd_launch(BfdParams B, int budget_bytes, hipStream_t s) {
   return check_launch("conv_bfd");
 }
 
+// The phases of a stride-2 TRANS gather as one launch of the small-problem block (64 pixels x NOW channel-waves): every
+// phase keeps the tile, LDS plan and staging mode bfd_launch would give it; the K-split decision is taken on the blocks of
+// the WHOLE launch.  -1: not taken (the caller launches the phases one by one).
+template <int NOW, int NP>
+static int bfd_launch_small_multi(const MfmaConvParams* phases, int nph, const BfdParams& base, hipStream_t s) {
+  constexpr int NTW = 1, NPW = 1, PF = 2;
+  constexpr int SMALL = 36 * 1024;
+  if (nph < 2 || nph > BFD_MAXPH) return -1;
+  BfdMulti M{};
+  M.nph = nph;
+  size_t lds_chunk[BFD_MAXPH], lds[BFD_MAXPH];
+  long total = 0;
+  const size_t epi_bytes = (size_t)NPW * 32 * BFD_EPI_STRIDE * sizeof(float);
+  for (int i = 0; i < nph; ++i) {
+    BfdParams B = base;
+    B.P = phases[i];
+    MfmaConvParams& P = B.P;
+    TilePick best{};
+    const int kh = P.KHv > 0 ? P.KHv : 1, kw = P.KWv > 0 ? P.KWv : 1;
+    bool ok = pick_tile(64 * NPW, P.PH, P.PW, P.is, kh, kw, NP * 16, SMALL / 4 - 16 * NP * 16, best);
+    if (!ok || best.eff < 0.6) {
+      TilePick big{};
+      if (pick_tile(64 * NPW, P.PH, P.PW, P.is, kh, kw, NP * 16, (156 * 1024) / 4 - 16 * NP * 16, big) &&
+          (!ok || big.eff > best.eff * 1.2)) {
+        best = big;
+        ok = true;
+      }
+    }
+    if (!ok) return -1;
+    P.TH = best.TH; P.TW = best.TW; P.tiles_y = best.tiles_y; P.tiles_x = best.tiles_x; P.HH = best.HH; P.HW = best.HW;
+    bfd_lds_plan(P.TW, P.is, P.HW, P.TH * P.TW, P.HH * P.HW, NPW, B.NPIXp, B.perm);
+    size_t l = (size_t)NP * (4 * B.NPIXp + 4) * 16;
+    B.allc = 0;
+    B.cpr = 1;
+    lds_chunk[i] = l;
+    if (B.ICc > 1 && l * B.ICc <= 64 * 1024) {
+      B.allc = 1;
+      B.cpr = B.ICc;
+      l *= B.ICc;
+    }
+    if (l < epi_bytes) l = epi_bytes;
+    lds[i] = l;
+    M.ph[i] = B;
+    M.start[i] = (int)total;
+    total += (long)P.tiles_x * P.tiles_y * P.N;
+    if (total >= (1L << 30)) return -1;
+  }
+  M.start[nph] = (int)total;
+  const int OCb = base.OCb;
+  // K split over two wave groups while the whole launch leaves the CUs with about one block each (as bfd_launch)
+  const int ksplit = env_int("SRK_BFD_KSPLIT", 1);
+  bool ks2 = ksplit && base.ICc >= 2 && (total * OCb <= kNumCU + kNumCU / 4 || ksplit > 1);
+  for (int i = 0; i < nph && ks2; ++i) ks2 = M.ph[i].allc || 2 * lds_chunk[i] <= (size_t)150 * 1024;
+  size_t lds_max = 0;
+  const size_t red_bytes = (size_t)NOW * 4 * NTW * 64 * 16;
+  for (int i = 0; i < nph; ++i) {
+    if (ks2) {
+      if (!M.ph[i].allc) {
+        M.ph[i].cpr = 2;
+        lds[i] = 2 * lds_chunk[i];
+        if (lds[i] < epi_bytes) lds[i] = epi_bytes;
+      }
+      if (lds[i] < red_bytes) lds[i] = red_bytes;
+    }
+    if (lds[i] > lds_max) lds_max = lds[i];
+  }
+  note_amax_written(base.P.ep.y_amax != nullptr);
+  dim3 grid((unsigned)total, (unsigned)OCb);
+  if (ks2) {
+    static LdsLimit lim2;
+    lim2.ensure(reinterpret_cast<const void*>(&k_conv_bfd_mp<NTW, NPW, NOW, NP, PF, 2>), lds_max);
+    note_kernel("k_conv_bfd_mp<%d,%d,%d,%d,%d,2>x%d", NTW, NPW, NOW, NP, PF, nph);
+    hipLaunchKernelGGL((k_conv_bfd_mp<NTW, NPW, NOW, NP, PF, 2>), grid, dim3(64 * NPW * NOW * 2), lds_max, s, M);
+  } else {
+    static LdsLimit lim;
+    lim.ensure(reinterpret_cast<const void*>(&k_conv_bfd_mp<NTW, NPW, NOW, NP, PF, 1>), lds_max);
+    note_kernel("k_conv_bfd_mp<%d,%d,%d,%d,%d,1>x%d", NTW, NPW, NOW, NP, PF, nph);
+    hipLaunchKernelGGL((k_conv_bfd_mp<NTW, NPW, NOW, NP, PF, 1>), grid, dim3(64 * NPW * NOW), lds_max, s, M);
+  }
+  return check_launch("conv_bfd_mp");
+}
+
 bool conv_bfd_gather_supported(const GatherConv& g, const Epi& ep) {
   (void)ep;
   if (g.OC < 8 || g.IC < 8) return false;
@@ -756,6 +866,28 @@ int conv_bfd_gather(const GatherConv& g, const float* in, const float* wp, float
     return for_each_phase(g, in, wp, out, ep, mask_y, mask_slope, [&](const MfmaConvParams& P) {
       return bfd_launch_phase<2, true>(P, wh, nullptr, small, s, trailer);
     });
+  }
+  // strided TRANS gathers on the small-problem block: every phase in ONE launch (k_conv_bfd_mp); SRK_BFD_MP=0: one by one
+  if (g.trans && g.stride == 2 && small && g.OC >= 64 && env_int("SRK_BFD_MP", 1) != 0) {
+    MfmaConvParams phases[BFD_MAXPH];
+    int nph = 0;
+    bool fits = true;
+    const int rc0 = for_each_phase(g, in, wp, out, ep, mask_y, mask_slope, [&](const MfmaConvParams& P) {
+      if (nph < BFD_MAXPH) phases[nph] = P; else fits = false;
+      ++nph;
+      return (int)SRK_OK;
+    });
+    if (rc0 == SRK_OK && fits && nph >= 2) {
+      BfdParams base{};
+      base.NB = 64;
+      base.ICc = (g.IC + 31) / 32;
+      base.OCb = (g.OC + 63) / 64;
+      base.wq = wq;
+      base.wq3 = wq3;
+      base.dbg = bfd_dbg();
+      const int rc = planes == 3 ? bfd_launch_small_multi<4, 3>(phases, nph, base, s) : bfd_launch_small_multi<4, 2>(phases, nph, base, s);
+      if (rc != -1) return rc;
+    }
   }
   return for_each_phase(g, in, wp, out, ep, mask_y, mask_slope, [&](const MfmaConvParams& P) {
     return planes == 3 ? bfd_launch_phase<3>(P, wq, wq3, small, s) : bfd_launch_phase<2>(P, wq, wq3, small, s);

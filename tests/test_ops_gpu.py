@@ -189,6 +189,59 @@ def test_conv_few_output_channels_backward(gpu, cin, cout, k, p, H, W, N):
     assert rel_err(bg.grad, br.grad.float()) < 1e-4
 
 
+@pytest.mark.parametrize("cin,cout,k,p,H,W,N,act", [
+    (64, 64, 3, 1, 32, 32, 4, None),       # SRGAN-D conv2 geometry at a small size: four phases of 16 x 16, taps 2x2 / 2x1 / 1x2 / 1x1
+    (512, 512, 3, 1, 16, 16, 16, None),    # the discriminator's last strided layer at c5 size: 16 chunks, K split over two wave groups
+    (128, 128, 3, 1, 15, 21, 3, "lrelu"),  # odd sizes: the phases differ in height and width; LeakyReLU mask on dy
+    (64, 128, 4, 1, 18, 18, 2, None),      # even kernel: every phase has 2x2 taps
+    (256, 256, 3, 0, 17, 17, 2, "lrelu"),  # no padding
+])
+def test_strided_data_gradient_phases_in_one_launch(gpu, monkeypatch, cin, cout, k, p, H, W, N, act):
+    """Round 6: the s x s phases of a stride-2 data gradient on the small-problem block run as ONE launch (k_conv_bfd_mp: a
+    block finds its phase's parameters from its index) instead of four.  Same tiles, same arithmetic, same order per output
+    element: bit-equal to the phase-by-phase launches (SRK_BFD_MP=0), and both against torch fp64."""
+    pkg = _pkg()
+    ops, L = pkg.ops, pkg._lib
+    lib = L.load()
+    x = fill.randn((N, cin, H, W), 381)
+    w = fill.randn((cout, cin, k, k), 382, (2.0 / (cin * k * k)) ** 0.5)
+    b = fill.randn((cout,), 383, 0.1)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, b.double(), 2, p)
+    if act:
+        yr = torch.nn.functional.leaky_relu(yr, 0.2)
+    g = fill.randn(tuple(yr.shape), 384)
+    yr.backward(g.double())
+    cfg = ops.ConvCfg(2, p, False, 0, 0, 0.0, 0, ALGOS["auto"])
+    d = ops._make_desc(x.shape, w, cfg, "bwd")
+    dy = g.to(gpu).contiguous(memory_format=torch.channels_last)
+    yg = yr.detach().float().to(gpu).contiguous(memory_format=torch.channels_last)
+    wpb = ops.pack_weight_bwd(w.to(gpu), False, 0)
+    mask = L.BwdMask(L.ptr(yg), 0.2) if act else None
+    dx = {}
+    for mp in ("1", "0"):
+        monkeypatch.setenv("SRK_BFD_MP", mp)
+        out = torch.full((N, cin, H, W), float("nan"), device=gpu).contiguous(memory_format=torch.channels_last)
+        assert lib.srk_conv2d_backward_data(ctypes.byref(d), L.ptr(dy), L.ptr(wpb), L.ptr(out),
+                                            ctypes.byref(mask) if mask is not None else None, None, L.stream_ptr()) == 0
+        name = lib.srk_last_kernel_name().decode()
+        if mp == "1":
+            assert name.startswith("k_conv_bfd_mp<1,1,4,2,2,") and name.endswith("x4"), name
+        else:
+            assert name.startswith("k_conv_bfd<1,1,4,2,2,"), name
+        dx[mp] = out
+        assert rel_err(out, xr.grad.float()) < 1e-4
+    assert torch.equal(dx["1"], dx["0"])
+    # ... and the layer through autograd (forward, dx, dw) on the merged path
+    monkeypatch.setenv("SRK_BFD_MP", "1")
+    xg, wg, bg = (t.to(gpu).requires_grad_(True) for t in (x, w, b))
+    cfg2 = ops.ConvCfg(2, p, False, 0, ACTS[act], 0.2 if act else 0.0, 0, ALGOS["auto"])
+    y = ops.conv2d(xg, wg, bg, None, cfg2)
+    y.backward(g.to(gpu))
+    assert rel_err(xg.grad, xr.grad.float()) < 1e-4
+    assert rel_err(wg.grad, wr.grad.float()) < 1e-4
+
+
 @pytest.mark.parametrize("cin,cout,k,p,H,W,N,slope", [
     (3, 64, 3, 1, 37, 29, 2, 0.2),     # SRGAN-D first layer (srgan.py:51): dx[3] from dy[64] under the LeakyReLU gradient
     (3, 64, 3, 1, 16, 50, 1, 0.0),     # ReLU mask
