@@ -229,9 +229,14 @@ def test_strided_data_gradient_phases_in_one_launch(gpu, monkeypatch, cin, cout,
             assert name.startswith("k_conv_bfd_mp<1,1,4,2,2,") and name.endswith("x4"), name
         else:
             assert name.startswith("k_conv_bfd<1,1,4,2,2,"), name
-        dx[mp] = out
+        dx[mp] = (out, name.split("x4")[0].rstrip(">").split(",")[-1])    # (output, K-split factor of the launch)
         assert rel_err(out, xr.grad.float()) < 1e-4
-    assert torch.equal(dx["1"], dx["0"])
+    # the K split over two wave groups is decided on the blocks of a LAUNCH (one phase: few blocks -> split; all phases
+    # together may fill the CUs without it): same split -> the same sums in the same order, bit for bit
+    if dx["1"][1] == dx["0"][1]:
+        assert torch.equal(dx["1"][0], dx["0"][0])
+    else:
+        assert rel_err(dx["1"][0], dx["0"][0]) < 2e-5
     # ... and the layer through autograd (forward, dx, dw) on the merged path
     monkeypatch.setenv("SRK_BFD_MP", "1")
     xg, wg, bg = (t.to(gpu).requires_grad_(True) for t in (x, w, b))
