@@ -709,7 +709,9 @@ int pack_weights_batched(const float* params, void* packed, const long long* tab
                          hipStream_t s, bool has_unscratched, const int* fast_blocks, int n_fast_blocks) {
   // layer maxima for the fp16 planes: parallel slices into the caller-zeroed scratch words (table column 11 >= 0), or
   // one block per layer for rows without one
-  const int slices = 16;
+  // (64 slices: the SRGAN discriminator's 512 x 512 x 9 filters are 9.4 MB each -- with 16 blocks per layer the pass took
+  //  39 us per step; blocks past a small layer's end exit at once)
+  const int slices = 64;
   hipLaunchKernelGGL(k_pack_batched_amax, dim3((unsigned)slices, (unsigned)n_layers), dim3(256), 0, s, params,
                      static_cast<char*>(packed), table, slices);
   if (has_unscratched)
