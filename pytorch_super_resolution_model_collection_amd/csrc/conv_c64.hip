@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void k_c64(C64Params R) {
   const int ow = wave & 3, kgrp = wave >> 2;
   const int col = lane & 15, kq = lane >> 4;
   const int j = lds_pix_p10(col);  // this lane's pixel within a 2 x 8 pixel tile
-  int b = blockIdx.x;
+  int b = xcd_tile_index((int)blockIdx.x, (int)gridDim.x);   // (contiguous tile ranges per XCD: the 10 x 10 halos overlap)
   const int txi = b % R.tiles_x;
   b /= R.tiles_x;
   const int tyi = b % R.tiles_y;

@@ -172,7 +172,11 @@ __global__ __launch_bounds__(512, 2) void k_res2(Res2Params R) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ow = wave & 3, kgrp = wave >> 2;
   const int col = lane & 15, kq = lane >> 4;
-  int b = blockIdx.x;
+  // XCD-aware block order (round 6): hardware deals consecutive block ids round-robin over the 8 XCDs, each with its own L2;
+  // a tile's 12 x 12 halo overlaps its eight neighbours' (2.25x the tile), and with b = blockIdx.x every neighbour sat on
+  // another XCD -- the overlap was fetched once per L2 (counter traffic 1.34x forward / 1.45x backward, the only large
+  // kernel that re-read).  Now every XCD walks a contiguous range of tiles (whole patches of the 16-patch shard).
+  int b = xcd_tile_index((int)blockIdx.x, (int)gridDim.x);
   const int txi = b % R.tiles_x;
   b /= R.tiles_x;
   const int tyi = b % R.tiles_y;

@@ -109,6 +109,15 @@ struct LdsLimit {
 
 inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
+// XCD-aware tile index: hardware deals consecutive block ids round-robin over the 8 XCDs (each with its own L2); this maps
+// block `bx` of `nb` to a tile index such that every XCD walks a CONTIGUOUS range of tiles -- neighbouring tiles share
+// their halo in ONE L2 instead of fetching it once per L2.  A bijection on [0, nb) for any nb.
+__device__ __forceinline__ int xcd_tile_index(int bx, int nb) {
+  const int per = nb >> 3, rem = nb & 7;
+  const int xcd = bx & 7, idx = bx >> 3;
+  return xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
+}
+
 // Activation forward on a scalar. `a` is the negative-side slope for PReLU / LeakyReLU.
 __device__ __forceinline__ float act_apply(float v, int act, float a) {
   switch (act) {
