@@ -169,6 +169,26 @@ def amax_of(x, compute=True):
     return slots
 
 
+_BOUND_SLOTS = {}   # (device index, bound) -> slots filled with the bound: no kernel runs for a declared maximum
+
+
+def declare_absmax(x, bound):
+    """The caller's promise that |x| <= bound everywhere (e.g. 1.0 for a ToTensor image batch, dataset.py:71): the
+    fp32-faithful f16x3 kernels then scale x by that bound and the srk_absmax pass over x is not run.  The C ABI asks for
+    slots whose maximum is >= max|x| (include/srk.h, srk_epilogue.x_amax), so a true bound is as good as the maximum (a loose
+    one costs mantissa bits of the 22 the two fp16 planes hold: 2^-k of them for a bound 2^k too large); a FALSE one lets the
+    scaled fp16 planes overflow to inf.  Returns x, tagged."""
+    require_cuda(x)
+    idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    key = (idx, float(bound))
+    slots = _BOUND_SLOTS.get(key)
+    if slots is None:
+        slots = _BOUND_SLOTS[key] = torch.full((_lib.AMAX_FLOATS,), float(bound), dtype=torch.float32,
+                                               device=torch.device("cuda", idx))
+    _tag_amax(x, slots)
+    return x
+
+
 def _empty_cl(n, c, h, w, like):
     return torch.empty((n, c, h, w), dtype=torch.float32, device=like.device, memory_format=CL)
 

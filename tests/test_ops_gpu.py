@@ -977,6 +977,31 @@ def test_batchnorm_finalize_in_apply(gpu, monkeypatch, shape, act):
             assert rel_err(u, v_) < 2e-6
 
 
+def test_declared_input_bound_replaces_the_absmax_pass(gpu):
+    """ops.declare_absmax(x, bound): a caller-declared upper bound of |x| stands in for the srk_absmax pass in front of an
+    fp32-faithful (f16x3) first layer -- the ABI only asks for slots >= max|x|.  ESPCN forward on a [0, 1) batch: same accuracy
+    against fp64 with the measured maximum, the tight bound 1.0 and a loose bound 8.0 (three bits of 22 given away)."""
+    from oracle import ref_modules as R
+    pkg = _pkg()
+    ops = pkg.ops
+    ops.set_precision("mixed")
+    ora = fill.fill_module(R.ESPCN(3, 64, 4))
+    net = pkg.ESPCNNet(3, 64, 4)
+    net.load_state_dict(ora.state_dict())
+    net.to(gpu).eval()
+    x = fill.rand((2, 3, 300, 260), 401)          # (large enough for the f16x3 class to be taken)
+    ref = ora.double()(x.double())
+    xg = x.to(gpu)
+    with torch.no_grad():
+        y0 = net(xg.view(xg.shape))
+        assert getattr(xg, "_srk_amax", None) is None
+        y1 = net(ops.declare_absmax(xg.view(xg.shape), 1.0))
+        y8 = net(ops.declare_absmax(xg.view(xg.shape), 8.0))
+    assert float(ops.declare_absmax(xg.view(xg.shape), 1.0)._srk_amax[0].max()) == 1.0
+    for y, bar in ((y0, 2e-6), (y1, 2e-6), (y8, 4e-6)):
+        assert rel_err(y, ref.float()) < bar
+
+
 def test_layout_roundtrip_and_ragged(gpu):
     """NCHW<->NHWC copies at ragged sizes (non multiples of the 32x32 transpose tile)."""
     pkg = _pkg()
