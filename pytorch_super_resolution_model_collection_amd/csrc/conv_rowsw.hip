@@ -395,9 +395,17 @@ __global__ __launch_bounds__(512, 2) void k_conv_rowsw(RowswParams B) {
 //     barrier.  Register budget per wave is the same 256 as with one 8-wave block.
 // Applies when the kernel row fits one K step (KW <= 8) and the 8 x 16 tile's halo fits one pixel per thread; anything
 // else stays with k_conv_rowsw.
-template <int KH, bool F16, bool RELU, int ICN>
+//
+// BAND (round 6, the "sliding window" of DESIGN 10.9 item 2): a block walks whole BANDS -- the tiles_x tiles of one tile
+// row, left to right -- and stages per stage ONE aligned chunk of 16 columns x (7 + KH) halo rows (chunk i = the columns of
+// tile i: one 64-byte line per row and plane) into a ring of four chunk slots; tile i reads chunks i - 1, i, i + 1 (a
+// lane's two pixels: slot and column fixed per lane, the slot index rotates with the stage).  The chunks left of a band's
+// first tile and right of its last are all padding: a fifth, zero slot.  Read requests per tile: 3 (7 + KH) = 36 lines
+// against ~60 - 70 for the 20-column halo segments that straddle three lines; the products and their order are unchanged.
+template <int KH, bool F16, bool RELU, int ICN, bool BAND = false>
 __global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
   constexpr int NTW = 2, MTW = 4, NTHR = 256, NR = KH + MTW - 1, TH = 8, TW = 16;
+  constexpr int BHH = 7 + KH, BSLOT = BHH * 16;  // BAND: halo rows, uint4 per chunk slot
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   const MfmaConvParams& P = B.P;
   uint4* hal0 = smem4;  // 2 buffers x NPIXp pixels x {h: 4 x 16 bit, l: 4 x 16 bit}
@@ -426,9 +434,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
       wreg[q][1][nt] = w[(4 + kq) * B.NBfull];
     }
   // pixels past the halo (the padded tap slots of the last row read them; they meet zero filter taps and must be finite)
-  for (int e = tid; e < 2 * (B.NPIXp - npix); e += NTHR) {
-    const int b = e / (B.NPIXp - npix), i = e - b * (B.NPIXp - npix);
-    hal0[(size_t)b * B.NPIXp + npix + i] = make_uint4(0, 0, 0, 0);
+  if constexpr (BAND) {
+    if (tid < BSLOT) hal0[4 * BSLOT + tid] = make_uint4(0, 0, 0, 0);  // the zero slot
+  } else {
+    for (int e = tid; e < 2 * (B.NPIXp - npix); e += NTHR) {
+      const int b = e / (B.NPIXp - npix), i = e - b * (B.NPIXp - npix);
+      hal0[(size_t)b * B.NPIXp + npix + i] = make_uint4(0, 0, 0, 0);
+    }
   }
   // tiles of this block: XCD-aware contiguous ranges (see k_conv_bfw)
   const int nblk = gridDim.x;
@@ -441,12 +453,36 @@ __global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
     first = start_x + bi;
     count = bi < tiles_x ? (tiles_x - bi + nb_x - 1) / nb_x : 0;
   }
-  const int S = count;
-  const int img_tiles = P.tiles_x * P.tiles_y;
-  const int st_n = nb_x / img_tiles, st_y = (nb_x - st_n * img_tiles) / P.tiles_x, st_x = nb_x - st_n * img_tiles - st_y * P.tiles_x;
+  // BAND: B.ntiles counts bands (image, tile row); the walk's x is the tile inside the band and steps by one
+  const int S = BAND ? count * P.tiles_x : count;
+  const int img_tiles = BAND ? P.tiles_y : P.tiles_x * P.tiles_y;
+  const int st_n = nb_x / img_tiles;
+  const int st_y = BAND ? nb_x - st_n * img_tiles : (nb_x - st_n * img_tiles) / P.tiles_x;
+  const int st_x = BAND ? 0 : nb_x - st_n * img_tiles - st_y * P.tiles_x;
   RowswWalk wi, wc;
-  wi.init(first, P.tiles_x, img_tiles);
+  if constexpr (BAND) {
+    wi.n = __builtin_amdgcn_readfirstlane(first / img_tiles);
+    wi.y = __builtin_amdgcn_readfirstlane(first - wi.n * img_tiles);
+    wi.x = 0;
+  } else {
+    wi.init(first, P.tiles_x, img_tiles);
+  }
   wc = wi;
+  auto walk = [&](RowswWalk& w) {
+    if constexpr (BAND) {
+      if (++w.x == P.tiles_x) {
+        w.x = 0;
+        w.y += st_y;
+        w.n += st_n;
+        if (w.y >= P.tiles_y) {
+          w.y -= P.tiles_y;
+          ++w.n;
+        }
+      }
+    } else {
+      w.advance(st_n, st_y, st_x, P.tiles_x, P.tiles_y);
+    }
+  };
 
   // ---- staging: thread tid owns halo pixel tid (npix <= 256).  Loads are unconditional and branch-free as in
   // k_conv_rowsw, and run TWO stages ahead of the LDS commit in two register sets (tile t in set t & 1): vmcnt retires in
@@ -459,7 +495,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
   // operation was not issued makes its s_waitcnt pass assume the smaller distance everywhere.
   float pv[2][4];
   bool vok[2] = {false, false};
-  const int hy0 = tid / P.HW, hx0 = tid - hy0 * P.HW;
+  const int hy0 = BAND ? tid >> 4 : tid / P.HW, hx0 = BAND ? tid & 15 : tid - hy0 * P.HW;
+  const int nstage = BAND ? BSLOT : npix;  // threads that stage a pixel
   const size_t plane = (size_t)P.IH * P.IW;
   const size_t est = P.in_nchw ? plane : 1;
   const size_t e1 = P.IC > 1 ? est : 0, e2 = P.IC > 2 ? 2 * est : 0, e3 = P.IC > 3 ? 3 * est : 0;
@@ -469,10 +506,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
     const bool live = issued < S;
     ++issued;
     const int n = live ? wi.n : 0, ty = live ? wi.y : 0, tx = live ? wi.x : 0;
-    const int iy = ty * TH + P.iy0 + hy0, ix = tx * TW + P.ix0 + hx0;
-    wi.advance(st_n, st_y, st_x, P.tiles_x, P.tiles_y);
+    const int iy = ty * TH + P.iy0 + hy0, ix = tx * TW + (BAND ? 0 : P.ix0) + hx0;
+    walk(wi);
     if (SRK_KDBG(B.dbg) & 1) return;
-    vok[st] = tid < npix && (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW;
+    vok[st] = (BAND ? live : true) && tid < nstage && (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW;
     const int cy = min(max(iy, 0), P.IH - 1), cx = min(max(ix, 0), P.IW - 1);
     const size_t pix = (size_t)cy * P.IW + cx;
     // (one load instruction per channel the input HAS: every VMEM instruction in the consumers' store stream costs issue
@@ -512,11 +549,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
       hu = __builtin_bit_cast(uint2, h);
       lu = __builtin_bit_cast(uint2, l);
     }
-    if (tid < npix) hal[tid] = make_uint4(hu.x, hu.y, lu.x, lu.y);  // (the wait for pv sits in front of the conversions)
+    if (tid < nstage) hal[tid] = make_uint4(hu.x, hu.y, lu.x, lu.y);  // (the wait for pv sits in front of the conversions)
   };
 
   // ---- MFMA side: halo slot of (row rg * 4 + R, column j, taps 2 kq, 2 kq + 1) = hp0 + R * HW
   const int hp0 = (rg * MTW) * P.HW + j + 2 * kq;
+  // BAND: the lane's two pixels as (chunk relative to the tile's own: -1 / 0 / +1, column inside the chunk)
+  const int bo0 = j + 2 * kq + P.ix0, bo1 = bo0 + 1;
+  const int bd0 = bo0 >> 4, bd1 = bo1 >> 4;
+  const int bc0 = (rg * MTW) * 16 + (bo0 & 15), bc1 = (rg * MTW) * 16 + (bo1 & 15);
   f32x4 bias4[NTW];
   int coff[NTW];
   const EpiTile e0 = epi_tile_setup(P, 0, 0, 0);
@@ -547,7 +588,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
   };
   using Set0 = std::integral_constant<int, 0>;
   using Set1 = std::integral_constant<int, 1>;
-  if (S > 0) {
+  if constexpr (BAND) {
+    if (S > 0) {  // chunks 0 and 1 committed, 2 and 3 in flight: stage s commits chunk s + 2 and issues chunk s + 4
+      issue(Set0{});
+      issue(Set1{});
+      commit(hal0, Set0{});
+      issue(Set0{});
+      commit(hal0 + BSLOT, Set1{});
+      rw_static_for<0, NST>([&](auto qc) { store_slot(qc); });  // (dropped: see below)
+      issue(Set1{});
+    }
+  } else if (S > 0) {
     issue(Set0{});                  // tile 0
     commit(hal0, Set0{});
     issue(Set1{});                  // tile 1
@@ -576,20 +627,30 @@ __global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
     const unsigned pt0 = RS_T();
     unsigned pt1 = 0, pt2 = 0, pt3 = 0;
     const int n = wc.n, r0 = wc.y * TH, c0 = wc.x * TW;
-    wc.advance(st_n, st_y, st_x, P.tiles_x, P.tiles_y);
+    const int bt = wc.x;
+    walk(wc);
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
       const uint4* hal = hal0 + (size_t)(s & 1) * B.NPIXp + hp0;
+      const uint4 *ha = hal, *hb = hal + 1;
+      int rstep = P.HW;
+      if constexpr (BAND) {
+        const bool z0 = (bd0 < 0 && bt == 0) || (bd0 > 0 && bt == P.tiles_x - 1);
+        const bool z1 = (bd1 < 0 && bt == 0) || (bd1 > 0 && bt == P.tiles_x - 1);
+        ha = hal0 + (z0 ? 4 : (s + bd0) & 3) * BSLOT + bc0;
+        hb = hal0 + (z1 ? 4 : (s + bd1) & 3) * BSLOT + bc1;
+        rstep = 16;
+      }
       uint4 fb[2][2];  // [buffer][plane]
       int roff = 0;
       auto load_row = [&](uint4 (&b)[2]) {
-        const uint4 p0 = hal[roff], p1 = hal[roff + 1];
+        const uint4 p0 = ha[roff], p1 = hb[roff];
         b[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
         b[1] = make_uint4(p0.z, p0.w, p1.z, p1.w);
-        roff += P.HW;
+        roff += rstep;
       };
       if (!(SRK_KDBG(B.dbg) & 4)) load_row(fb[0]);
       if (!(SRK_KDBG(B.dbg) & 4)) rw_static_for<0, NR>([&](auto rc) {
@@ -631,9 +692,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
 #endif
       });
       pt1 = RS_T();
-      commit(hal0 + (size_t)((s + 1) & 1) * B.NPIXp, nset);  // tile s + 1 (that buffer was last read in stage s - 1)
+      if constexpr (BAND) commit(hal0 + (size_t)((s + 2) & 3) * BSLOT, nset);  // chunk s + 2 (slot last read in stage s - 1)
+      else commit(hal0 + (size_t)((s + 1) & 1) * B.NPIXp, nset);  // tile s + 1 (that buffer was last read in stage s - 1)
       pt2 = RS_T();
-      issue(nset);                                            // tile s + 3
+      issue(nset);                                            // tile s + 3 (BAND: chunk s + 4)
       pt3 = RS_T();
       // tile finished: park it (C/D col = lane & 15 = pixel column, rows kq*4 + reg = 4 consecutive channels)
       const unsigned tile_off = 4u * (unsigned)epi_tile_setup(P, n, r0, c0).off0;
@@ -666,8 +728,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_rowsr(RowswParams B) {
     RS_ACC(0, pt0, pt1); RS_ACC(1, pt1, pt2); RS_ACC(2, pt2, pt3); RS_ACC(3, pt3, pt4); RS_ACC(4, pt4, pt5);
   };
   for (int s0 = 0; s0 < S; s0 += 2) {  // (an odd S ends with one dummy stage)
-    stage(s0, Set1{});
-    stage(s0 + 1, Set0{});
+    if constexpr (BAND) {
+      stage(s0, Set0{});
+      stage(s0 + 1, Set1{});
+    } else {
+      stage(s0, Set1{});
+      stage(s0 + 1, Set0{});
+    }
   }
   rw_static_for<0, NST>([&](auto qc) { store_slot(qc); });  // the last tile (S = 0: nothing parked, dropped)
   if (P.ep.y_amax) amax_commit(P.ep.y_amax, amax, blockIdx.x + wave, amax_peek(P.ep.y_amax, blockIdx.x + wave));
@@ -748,19 +815,19 @@ static int rowsw_launch(const RowswParams& B, size_t lds, int grid, hipStream_t 
   return check_launch("conv_rowsw");
 }
 
-template <int KH>
+template <int KH, bool BAND = false>
 static int rowsr_launch(const RowswParams& B, size_t lds, int grid, hipStream_t s) {
   note_amax_written(B.P.ep.y_amax != nullptr);
   const bool relu = B.P.ep.act == SRK_ACT_RELU;
   const bool f16 = B.w_descale != nullptr;
-  note_kernel("k_conv_rowsr<%d%s%s>", KH, f16 ? ",f16" : "", relu ? ",relu" : "");
+  note_kernel("k_conv_rowsr<%d%s%s%s>", KH, f16 ? ",f16" : "", relu ? ",relu" : "", BAND ? ",band" : "");
   auto go = [&](auto f16c, auto reluc) {
     constexpr bool F = decltype(f16c)::value, R = decltype(reluc)::value;
     switch (B.P.IC) {
-      case 1: hipLaunchKernelGGL((k_conv_rowsr<KH, F, R, 1>), dim3(grid), dim3(256), lds, s, B); break;
-      case 2: hipLaunchKernelGGL((k_conv_rowsr<KH, F, R, 2>), dim3(grid), dim3(256), lds, s, B); break;
-      case 3: hipLaunchKernelGGL((k_conv_rowsr<KH, F, R, 3>), dim3(grid), dim3(256), lds, s, B); break;
-      default: hipLaunchKernelGGL((k_conv_rowsr<KH, F, R, 4>), dim3(grid), dim3(256), lds, s, B); break;
+      case 1: hipLaunchKernelGGL((k_conv_rowsr<KH, F, R, 1, BAND>), dim3(grid), dim3(256), lds, s, B); break;
+      case 2: hipLaunchKernelGGL((k_conv_rowsr<KH, F, R, 2, BAND>), dim3(grid), dim3(256), lds, s, B); break;
+      case 3: hipLaunchKernelGGL((k_conv_rowsr<KH, F, R, 3, BAND>), dim3(grid), dim3(256), lds, s, B); break;
+      default: hipLaunchKernelGGL((k_conv_rowsr<KH, F, R, 4, BAND>), dim3(grid), dim3(256), lds, s, B); break;
     }
   };
   if (f16 && relu) go(std::true_type{}, std::true_type{});
@@ -803,6 +870,29 @@ int conv_rowsw_gather(const GatherConv& g, const float* in, const float* wp, flo
       B.NPIXp = P.HH * P.HW + 16;
       B.nsl = P.OC / 64;
       const long ntiles = (long)P.tiles_x * P.tiles_y * P.N;
+      // Whole bands per block with one aligned 16-column chunk staged per tile (k_conv_rowsr<.., band>): where the input is no
+      // wider than the tiles' columns (the chunks beside a band are all padding), the left overhang fits one chunk, and the
+      // bands divide evenly enough among the blocks.  SRK_ROWSB: 0 never, 2 whenever applicable, unset = that rule.
+      const int band_mode = env_int("SRK_ROWSB", 1);
+      const long nbands = (long)P.tiles_y * P.N;
+      if (band_mode != 0 && ntiles < (1L << 30) && P.IW <= 16 * P.tiles_x && P.ix0 <= 0 && P.ix0 >= -16 &&
+          P.ix0 + 15 + 7 < 32) {
+        int grid = 2 * kNumCU - (2 * kNumCU) % (8 * B.nsl);
+        const long want = ((nbands + 7) / 8) * 8 * B.nsl;
+        if (want < grid) grid = (int)want;
+        const long nblk = grid / B.nsl;
+        const long rounds = nblk > 0 ? (nbands + nblk - 1) / nblk : 0;
+        const bool even = nblk > 0 && rounds * nblk * 100 <= nbands * 107 && nbands >= 2 * nblk;
+        if (grid > 0 && (band_mode == 2 || even)) {
+          B.ntiles = (int)nbands;
+          B.out_bytes = (unsigned)((size_t)P.N * P.OH * P.OW * P.OC * sizeof(float));
+          const size_t lds = (size_t)5 * (7 + P.KHv) * 16 * 16;
+#ifdef SRK_ROWSR_PROF
+          B.prof = g_rowsr_prof;
+#endif
+          return Q == 3 ? rowsr_launch<3, true>(B, lds, grid, s) : rowsr_launch<5, true>(B, lds, grid, s);
+        }
+      }
       if (ntiles < (1L << 30)) {
         B.ntiles = (int)ntiles;
         B.out_bytes = (unsigned)((size_t)P.N * P.OH * P.OW * P.OC * sizeof(float));

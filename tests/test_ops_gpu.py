@@ -378,6 +378,9 @@ def test_conv_wave_specialized(gpu, monkeypatch, cin, cout, k, p, H, W, N, act, 
     (4, 128, 3, 1, 17, 23, 2, None, "bf16x3"),      # four channels, two 64-channel slices
     (3, 64, 5, 2, 8, 300, 1, None, "mixed"),        # fewer tiles than XCDs
     (2, 64, 3, 0, 33, 18, 5, "relu", "mixed"),      # two channels, no padding
+    (3, 64, 5, 2, 24, 16, 200, "relu", "mixed"),    # 600 one-tile bands on 512 blocks: one or two bands per block
+    (3, 64, 3, 1, 50, 100, 30, None, "bf16x3"),     # 210 bands of seven tiles, ragged last column chunk
+    (3, 64, 5, 0, 70, 64, 9, "relu", "mixed"),      # no padding: the input is as wide as the tiles' columns
 ])
 def test_conv_first_layer_wave_specialized(gpu, monkeypatch, cin, cout, k, p, H, W, N, act, mode):
     """k_conv_rowsw (persistent, producer / consumer waves, deferred stores) forced onto small problems, against the
@@ -399,19 +402,26 @@ def test_conv_first_layer_wave_specialized(gpu, monkeypatch, cin, cout, k, p, H,
     monkeypatch.setattr(ops, "F16X3_ALWAYS", True)   # (small problems: the size policy would keep the fp32 MFMA kernel)
     ops.set_precision(mode)
     try:
-        # "0": per-tile kernel; "1": 8-wave persistent kernel; "r": its row-reuse form (4-wave blocks, filter in registers)
-        for sw in ("0", "1", "r"):
+        # "0": per-tile kernel; "1": 8-wave persistent kernel; "r": its row-reuse form (4-wave blocks, filter in registers);
+        # "b": that kernel walking whole bands of tiles with one aligned 16-column chunk staged per tile (round 6) -- where
+        # the input is no wider than the tiles' columns, else the library stays with "r"
+        PW = W + 2 * p - k + 1
+        band_ok = W <= 16 * ((PW + 15) // 16)
+        for sw in ("0", "1", "r", "b"):
             monkeypatch.setenv("SRK_ROWSW", "0" if sw == "0" else "1")
-            monkeypatch.setenv("SRK_ROWSR", "1" if sw == "r" else "0")
+            monkeypatch.setenv("SRK_ROWSR", "1" if sw in "rb" else "0")
+            monkeypatch.setenv("SRK_ROWSB", "2" if sw == "b" else "0")
             with torch.no_grad():
                 outs[sw] = ops.conv2d_infer(x.to(gpu), w.to(gpu), b.to(gpu), None, cfg)
             name = pkg._lib.load().srk_last_kernel_name().decode()
-            assert name.startswith({"0": "k_conv_bf3_rows<", "1": "k_conv_rowsw<", "r": "k_conv_rowsr<"}[sw]), name
+            assert name.startswith({"0": "k_conv_bf3_rows<", "1": "k_conv_rowsw<", "r": "k_conv_rowsr<", "b": "k_conv_rowsr<"}[sw]), name
             assert ("f16" in name) == (mode == "mixed"), name
+            assert ("band" in name) == (sw == "b" and band_ok), name
     finally:
         ops.set_precision("mixed")
     assert torch.equal(outs["0"], outs["1"])
     assert torch.equal(outs["0"], outs["r"])
+    assert torch.equal(outs["0"], outs["b"])
     assert rel_err(outs["1"], ref.float()) < (2e-6 if mode == "mixed" else 1e-4)
 
 
