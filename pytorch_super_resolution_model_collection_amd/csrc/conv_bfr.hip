@@ -110,8 +110,19 @@ __device__ __forceinline__ void bfr_signal(bfr_cnt_t* p) {
 // (Round 5 carried a FUSE variant here -- the Cin <= 4 first layer computed by the producers straight into the ring,
 //  srk_conv2d_pair_forward.  Correct but slower than the two launches (0.93 vs 0.70 ms on the c2 pair: its producers carried
 //  ~930 instructions per tile against the consumers' ~365); retired in round 6, DESIGN 13.  The last tree with it: b92a5aa.)
-template <int NTW, int ICC, bool F16>
+//
+// CV ("canvas", round 6): the layers of VDSR -- 64 -> 64 on 41 x 41 patches -- as this kernel's fixed 8 x 16 tiles.  41 is
+// 2.6 tiles wide (8 x 16 tiles over one patch: 73 % full), so the tiles are laid over a CANVAS instead: the batch as a grid
+// of cells of (PH + 1) x (PW + 1) pixels, B.cv_kx patches side by side, each followed by one separator row and column that
+// reads as zero -- the 3x3 "same" convolution's own padding, shared by neighbouring patches -- and whose outputs are
+// dropped.  The host picks cv_kx for the fullest tiles (256 patches of 41 x 41: 8 across, 95 %).  Producers map a halo
+// pixel to (patch, row, column) or to an out-of-range offset, consumers map an output pixel the same way; nothing else
+// changes.  CV blocks also take output-channel SLICES (B.nsl, as k_conv_bfw does: the 147 KB filter of 64 -> 64 as two
+// 32-channel halves on neighbouring blocks of one XCD).  OMASK: ep.out_relu as in k_conv_bfw (the data gradient leaves
+// multiplied by the ReLU gradient of the layer below), requested when the tile starts, applied when it is parked.
+template <int NTW, int ICC, bool F16, bool CV = false, bool OMASK = false>
 __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
+  static_assert(CV || !OMASK, "the output mask comes with the canvas variant");
   constexpr int NB = 16 * NTW;
   constexpr int NCW = 4, NGW = 2, NPW = 4;  // consumer waves (two groups of NGW), producer waves
   constexpr int NPS = NPW;                  // producer waves that fill one slot
@@ -139,14 +150,25 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
   }
   (void)sx;
 
-  const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;  // (one slice: the whole filter is resident)
+  const int xcd = blockIdx.x & 7;
+  int bi = blockIdx.x >> 3, sl = 0;  // (not CV: one slice, the whole filter is resident)
+  if constexpr (CV) {
+    sl = bi % B.nsl;
+    bi = bi / B.nsl;
+  }
   for (int e = tid; e < 9 * ICC * WSLOT; e += NTHR) {
     const int slot = e / WSLOT, w = e - slot * WSLOT;
     const int t = slot / ICC, cc = slot - t * ICC;
     const int u = t / 3, v = t - u * 3;
     const int tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
     // packed layout [tap][chunk][64-channel block][plane][group][NBfull channels] with NBfull = NB here (OC <= 48)
-    wl[e] = B.wq[(size_t)(tapw * ICC + cc) * WSLOT + w];
+    if constexpr (CV) {
+      const int pg = w / NB, o = w - pg * NB;
+      const int oc = sl * NB + o, ocb = oc / B.NBfull;
+      wl[e] = B.wq[((size_t)(tapw * ICC + cc) * B.OCb + ocb) * (size_t)(8 * B.NBfull) + pg * B.NBfull + (oc - ocb * B.NBfull)];
+    } else {
+      wl[e] = B.wq[(size_t)(tapw * ICC + cc) * WSLOT + w];
+    }
   }
   if (tid < 2 * BFR_MAXBUF) cnt[tid] = 0u;
   // tiles of this block (XCD-aware contiguous ranges, as in k_conv_bfw): first, first + tstride, ... (count of them)
@@ -154,13 +176,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
   int first, count;
   {
     const int per_x = B.ntiles >> 3, rem_x = B.ntiles & 7;
-    const int nb_x = (nblk + 7 - xcd) >> 3;
+    const int nb_x = CV ? ((nblk + 7 - xcd) >> 3) / B.nsl : (nblk + 7 - xcd) >> 3;
     const int tiles_x = per_x + (xcd < rem_x ? 1 : 0);
     const int start_x = xcd * per_x + (xcd < rem_x ? xcd : rem_x);
     first = start_x + bi;
     count = bi < tiles_x ? (tiles_x - bi + nb_x - 1) / nb_x : 0;
   }
-  const int tstride = (nblk + 7 - xcd) >> 3;
+  const int tstride = CV ? ((nblk + 7 - xcd) >> 3) / B.nsl : (nblk + 7 - xcd) >> 3;
+  // CV: the tile coordinates below are those of the canvas (one "image" of tiles_y x tiles_x tiles)
+  const int cvH = P.PH + 1, cvW = P.PW + 1, cvK = CV ? B.cv_kx : 1;
   count = __builtin_amdgcn_readfirstlane(count);
 
   // Tile coordinates (image, tile row, tile column) of the two tiles of a pair, advanced by TWO list steps per pair:
@@ -204,15 +228,17 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
     const int ptid = tid - 64 * NCW;
     const int g = ptid & 3, hp0 = ptid >> 2;
     f32x4 pv[NSET][PIT][2];
-    int it_rel[PIT], it_hx[PIT];
+    int it_rel[PIT], it_hx[PIT], it_hy[PIT];
 #pragma unroll
     for (int k = 0; k < PIT; ++k) {
       const int hq = hp0 + PSTEP * k;
       const int hy = hq / HW, hx = hq - hy * HW;
       it_rel[k] = hq < NPIX ? ((hy * P.IW + hx) * P.IC + g * 8) * 4 : -1;
       it_hx[k] = hx;
+      it_hy[k] = hy;
     }
     const unsigned img_bytes = (unsigned)((size_t)P.IH * P.IW * P.IC * 4);
+    const unsigned in_bytes = (unsigned)((size_t)P.N * P.IH * P.IW * P.IC * 4);  // (CV; host: below 2 GiB)
     auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
       return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
     };
@@ -245,13 +271,34 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
       constexpr unsigned OOB = 0x80000000u;
       const int iyb = r0 + P.iy0, ixb = c0 + P.ix0;
       const bool ch_on = valid && cc * 32 + g * 8 + 7 < P.IC;
-      const size_t img = (size_t)n * P.IH * P.IW * P.IC;
-      const __amdgpu_buffer_rsrc_t rin = rsrc_of(P.in + img, img_bytes);
+      const size_t img = CV ? 0 : (size_t)n * P.IH * P.IW * P.IC;
+      const __amdgpu_buffer_rsrc_t rin = rsrc_of(P.in + img, CV ? in_bytes : img_bytes);
       const int obase = ((iyb * P.IW + ixb) * P.IC + cc * 32) * 4;  // may be negative: rows above the image wrap out of range
+      // CV: cell and in-cell position of the halo's first row / column (one cell above / left of the canvas: the separator)
+      const int cy0 = (iyb + cvH) / cvH - 1, ry0 = iyb + cvH - (cy0 + 1) * cvH;
+      const int cx0 = (ixb + cvW) / cvW - 1, rx0 = ixb + cvW - (cx0 + 1) * cvW;
 #pragma unroll
       for (int k = 0; k < PIT; ++k) {
-        const bool ok = it_rel[k] >= 0 && ch_on && (unsigned)(ixb + it_hx[k]) < (unsigned)P.IW;
-        const unsigned o = ok ? (unsigned)(obase + it_rel[k]) : OOB;
+        bool ok;
+        unsigned o;
+        if constexpr (CV) {
+          int ry = ry0 + it_hy[k], cy = cy0, rx = rx0 + it_hx[k], cx = cx0;
+          if (ry >= cvH) {
+            ry -= cvH;
+            ++cy;
+          }
+          if (rx >= cvW) {
+            rx -= cvW;
+            ++cx;
+          }
+          const int pn = cy * cvK + cx;
+          ok = it_rel[k] >= 0 && ch_on && ry < P.PH && rx < P.PW && (unsigned)cx < (unsigned)cvK && cy >= 0 &&
+               (unsigned)pn < (unsigned)P.N;
+          o = ok ? (unsigned)((((pn * P.IH + ry) * P.IW + rx) * P.IC + cc * 32 + g * 8) * 4) : OOB;
+        } else {
+          ok = it_rel[k] >= 0 && ch_on && (unsigned)(ixb + it_hx[k]) < (unsigned)P.IW;
+          o = ok ? (unsigned)(obase + it_rel[k]) : OOB;
+        }
         if constexpr (BFR_ABL & 1) {
           v[k][0] = v[k][1] = (f32x4){(float)o, 1.f, 2.f, 3.f};
         } else {
@@ -351,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
     for (int r = 0; r < MR; ++r) poff[r] = (MR * gw + r) * e0.RS + pj * e0.CS;
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-      const EpiCol cl = epi_col_setup(P.ep, P.OW, P.OC, nt * 16 + kq * 4);
+      const EpiCol cl = epi_col_setup(P.ep, P.OW, P.OC, sl * NB + nt * 16 + kq * 4);
       coff[nt] = (int)cl.off_oc;
       bias4[nt] = cl.bias;
     }
@@ -371,6 +418,43 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
   unsigned pend_voff[MR];  // (kDrop: the buffer unit drops the store -- before the first tile, and pixels beyond the image)
 #pragma unroll
   for (int r = 0; r < MR; ++r) pend_voff[r] = kDrop;
+  // CV: byte offsets of the lane's output pixels of the tile being computed (kDrop: separator / beyond the batch), set when
+  // the tile starts; OMASK: the mask tensor's values there, requested at that moment through the same offsets
+  unsigned cur_voff[CV ? MR : 1];
+  f32x4 om[OMASK ? NTW : 1][OMASK ? MR : 1];
+  auto cv_offsets = [&](int r0, int c0) {
+    if constexpr (CV) {
+      const int cy0 = r0 / cvH, ry0 = r0 - cy0 * cvH;
+      const int cx0 = c0 / cvW, rx0 = c0 - cx0 * cvW;
+      int rx = rx0 + pj, cx = cx0;
+      if (rx >= cvW) {
+        rx -= cvW;
+        ++cx;
+      }
+      const bool col_ok = rx < P.PW && cx < cvK;
+#pragma unroll
+      for (int r = 0; r < MR; ++r) {
+        int ry = ry0 + MR * gw + r, cy = cy0;
+        if (ry >= cvH) {
+          ry -= cvH;
+          ++cy;
+        }
+        const int pn = cy * cvK + cx;
+        const bool pok = col_ok && ry < P.PH && pn < P.N;
+        cur_voff[r] = pok ? 4u * (unsigned)(((pn * P.OH + ry) * P.OW + rx) * P.OC) : kDrop;
+      }
+      if constexpr (OMASK) {
+        const __amdgpu_buffer_rsrc_t mrsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.ep.out_relu), 0, B.out_bytes, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < MR; ++r)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt)
+            om[nt][r] = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, (int)(cur_voff[r] + 4u * (unsigned)coff[nt]), 0, 0));
+      }
+    }
+  };
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
@@ -392,12 +476,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
   // max; none = nothing; leaky / PReLU = max + min + fma), the running maximum as max3 with |.| modifiers
   auto park_kind = [&](auto kind_c, int n, int r0, int c0) {
     constexpr int KIND = decltype(kind_c)::value;
-    const unsigned tile_off = 4u * (unsigned)epi_tile_setup(P, n, r0, c0).off0;
+    const unsigned tile_off = CV ? 0u : 4u * (unsigned)epi_tile_setup(P, n, r0, c0).off0;
     const bool col_ok = c0 + pj < P.PW;
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
-      const bool pok = col_ok && r0 + MR * gw + r < P.PH;
-      pend_voff[r] = pok ? tile_off + 4u * (unsigned)poff[r] : kDrop;
+      bool pok;
+      if constexpr (CV) {
+        pok = cur_voff[r] != kDrop;
+        pend_voff[r] = cur_voff[r];
+      } else {
+        pok = col_ok && r0 + MR * gw + r < P.PH;
+        pend_voff[r] = pok ? tile_off + 4u * (unsigned)poff[r] : kDrop;
+      }
       float rmax = 0.f;
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
@@ -410,6 +500,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
           } else if constexpr (KIND == 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(act_slope, fminf(v[e], 0.f), fmaxf(v[e], 0.f));
+          }
+          if constexpr (OMASK) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = om[nt][r][e] > 0.f ? v[e] : 0.f;
           }
           rmax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), rmax);
           rmax = fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), rmax);
@@ -501,6 +595,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
   for (int ti = grp; ti < count; ti += 2) {
     const int ng = (ti | 1) < count ? 2 : 1;
     const int n = o_n, r0 = o_y * TH, c0 = o_x * TW;
+    cv_offsets(r0, c0);
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
@@ -599,6 +694,24 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
   if (dead) bfr_fail(lane);
 }
 
+// the canvas variant (64 input channels -> 32-channel slices): f16x3 forward, bf16x3 with or without the output mask
+static int bfr_launch_cv(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
+  note_amax_written(B.P.ep.y_amax != nullptr);
+  const dim3 blk(512);
+  const bool omask = B.P.ep.out_relu != nullptr;
+  auto go = [&](auto f16c, auto omc) {
+    constexpr bool F = decltype(f16c)::value, O = decltype(omc)::value;
+    static LdsLimit lim;
+    lim.ensure(reinterpret_cast<const void*>(&k_conv_bfr<2, 2, F, true, O>), lds);
+    note_kernel("k_conv_bfr<2,2%s,canvas%s>", F ? ",f16" : "", O ? ",relu" : "");
+    hipLaunchKernelGGL((k_conv_bfr<2, 2, F, true, O>), dim3(grid), blk, lds, s, B);
+  };
+  if (B.w_descale) go(std::true_type{}, std::false_type{});
+  else if (omask) go(std::false_type{}, std::true_type{});
+  else go(std::false_type{}, std::false_type{});
+  return check_launch("conv_bfr");
+}
+
 template <int NTW, int ICC>
 static int bfr_launch_t(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
   note_amax_written(B.P.ep.y_amax != nullptr);
@@ -617,6 +730,73 @@ static int bfr_launch_t(const BfwParams& B, size_t lds, int grid, hipStream_t s)
   return check_launch("conv_bfr");
 }
 
+// The canvas variant: 3x3 "same" gathers (stride 1, pad 1, output as large as the input), 64 input channels in two chunks,
+// 32-channel output slices, plain NHWC stores, no input mask, f16x3 without / bf16x3 with or without the output mask;
+// in- and output below 2 GiB.  SRK_BFR_CV: 0 never, 2 whenever applicable, unset = where the plain 8 x 16 tiling would be
+// less than 90 % full (or the layer needs slices), the canvas is at least 88 % full and has four tiles per CU.
+static int conv_bfr_canvas(const BfwParams& B0, hipStream_t s) {
+  const int mode = env_int("SRK_BFR_CV", 1);
+  if (mode == 0) return -1;
+  BfwParams B = B0;
+  MfmaConvParams& P = B.P;
+  if (P.KHv != 3 || P.KWv != 3 || P.is != 1 || P.os != 1 || B.NB != 32 || B.ICc != 2 || P.IC != 64) return -1;
+  if (P.IH != P.PH || P.IW != P.PW || P.OH != P.PH || P.OW != P.PW || P.iy0 != -1 || P.ix0 != -1 || P.oy0 != 0 || P.ox0 != 0)
+    return -1;
+  if (P.mask_y || P.ep.ps_r > 1 || P.PH < 9 || P.PW < 17) return -1;
+  if (P.ep.out_relu && B.w_descale) return -1;
+  const size_t in_bytes = (size_t)P.N * P.IH * P.IW * P.IC * 4, out_bytes = (size_t)P.N * P.OH * P.OW * P.OC * 4;
+  if (in_bytes >= (1ull << 31) || out_bytes >= (1ull << 31)) return -1;
+  const int cvH = P.PH + 1, cvW = P.PW + 1;
+  long best_tiles = 0;
+  int best_kx = 0;
+  for (int kx = 1; kx <= P.N && kx * cvW <= 4096; ++kx) {
+    const long tx = (kx * cvW - 1 + BFR_TW - 1) / BFR_TW;
+    const long ky = (P.N + kx - 1) / kx;
+    const long ty = (ky * cvH - 1 + BFR_TH - 1) / BFR_TH;
+    if (best_kx == 0 || tx * ty < best_tiles) {
+      best_tiles = tx * ty;
+      best_kx = kx;
+    }
+  }
+  if (best_kx == 0 || best_tiles >= (1L << 29)) return -1;
+  if (mode != 2) {
+    const double px = (double)P.N * P.PH * P.PW;
+    const long plain = (long)((P.PH + BFR_TH - 1) / BFR_TH) * ((P.PW + BFR_TW - 1) / BFR_TW) * P.N;
+    const bool plain_ok = B.nsl == 1 && px >= 0.9 * (double)plain * (BFR_TH * BFR_TW);
+    if (plain_ok || px < 0.88 * (double)best_tiles * (BFR_TH * BFR_TW) || best_tiles * B.nsl < 4L * kNumCU) return -1;
+  }
+  B.cv_kx = best_kx;
+  P.TH = BFR_TH; P.TW = BFR_TW; P.HH = BFR_HH; P.HW = BFR_HW;
+  P.tiles_x = (best_kx * cvW - 1 + BFR_TW - 1) / BFR_TW;
+  P.tiles_y = (int)(best_tiles / P.tiles_x);
+  const size_t wbytes = (size_t)9 * B.ICc * 8 * B.NB * 16;
+  const size_t slot_bytes = (size_t)8 * BFR_NPIXP * 16;
+  const long lds_cap = 160L * 1024 - 512 - BFR_CNT_BYTES;
+  long nbuf = (lds_cap - (long)wbytes) / (long)slot_bytes;
+  const int want_buf = env_int("SRK_BFR_NBUF", 0);
+  if (want_buf >= 3 && want_buf < nbuf) nbuf = want_buf;
+  if (nbuf > BFR_MAXBUF) nbuf = BFR_MAXBUF;
+  if (nbuf < 3) return -1;
+  B.nbuf = (int)nbuf;
+  B.perm = 1;
+  B.NPIXp = BFR_NPIXP;
+  B.late = env_int("SRK_BFR_PRIO", 2);
+  const size_t lds = wbytes + (size_t)nbuf * slot_bytes + BFR_CNT_BYTES;
+  B.ntiles = (int)best_tiles;
+#ifdef BFR_PROF
+  B.prof = g_bfr_prof;
+#endif
+  B.out_bytes = (unsigned)out_bytes;
+  int grid = kNumCU - kNumCU % (8 * B.nsl);
+  const long want = ((best_tiles + 7) / 8) * 8 * B.nsl;
+  if (grid == 0) return -1;
+  if (want < grid) grid = (int)want;
+  if (B.dbg & 32)
+    fprintf(stderr, "[srk] k_conv_bfr<2,2,canvas>: %d patches across, %d x %d tiles, %d slices, ring %d, grid %d\n", best_kx,
+            P.tiles_y, P.tiles_x, B.nsl, B.nbuf, grid);
+  return bfr_launch_cv(B, lds, grid, s);
+}
+
 // B: the launch as conv_bfw_gather prepared it up to the tile choice (P, wq, ICc, NB, nsl, ...).  -1 when the layer is not
 // one of the ring kernel's: a stride-1 3x3 gather with 32 or 48 output channels in one slice and 32 or 64 input
 // channels, no gradient masks, an output whose 8 x 16 tiles are mostly full, a ring of at least three slots beside the
@@ -627,6 +807,10 @@ int conv_bfr_launch(const BfwParams& B0, hipStream_t s) {
   BfwParams B = B0;
   MfmaConvParams& P = B.P;
   const int ntw = B.NB / 16;
+  {
+    const int rc = conv_bfr_canvas(B0, s);
+    if (rc != -1) return rc;
+  }
   if (P.KHv != 3 || P.KWv != 3 || P.is != 1 || B.nsl != 1 || (ntw != 2 && ntw != 3) || B.NB != P.OC) return -1;
   if ((B.ICc != 1 && B.ICc != 2) || P.IC % 8 != 0) return -1;
   if (ntw == 3 && B.ICc != 1) return -1;  // (48 channels from 64: the instantiation spills; no net has that layer)

@@ -562,6 +562,85 @@ def test_conv_wave_specialized_ring(gpu, monkeypatch, cin, cout, H, W, N, act, p
     assert rel_err(outs["1"], ref.float()) < (2e-6 if mode == "mixed" else 1e-4)
 
 
+@pytest.mark.parametrize("cout,H,W,N,mode", [
+    (64, 41, 41, 7, "mixed"),      # VDSR body layer: two 32-channel slices, 7 patches on a canvas, f16x3
+    (64, 41, 41, 19, "bf16x3"),    # ... more patches than one canvas row holds
+    (32, 20, 33, 5, "mixed"),      # one slice
+    (64, 9, 17, 40, "bf16x3"),     # the smallest patches the canvas takes
+    (64, 48, 50, 3, "mixed"),      # patches larger than a tile row of the canvas is tall
+])
+def test_conv_ring_on_a_canvas(gpu, monkeypatch, cout, H, W, N, mode):
+    """k_conv_bfr<2,2,..,canvas> (round 6): the ring kernel's fixed 8 x 16 tiles laid over the batch as a grid of
+    (H + 1) x (W + 1) cells -- separator rows / columns read as the convolution's zero padding and are never stored -- with
+    32-channel output slices.  Forward (f16x3 / bf16x3) against k_conv_bfw (same products, another summation order) and
+    torch fp64; then the data gradient of a two-layer ReLU chain under ops.premasked_gradients() -- plain for the first
+    layer, multiplied by the ReLU gradient of the layer below (ep.out_relu) for the second -- against k_conv_bfw's."""
+    monkeypatch.setenv("SRK_BFW", "1")
+    monkeypatch.setenv("SRK_BF3_DIRECT", "0")
+    pkg = _pkg()
+    ops = pkg.ops
+    lib = pkg._lib.load()
+    x = fill.randn((N, 64, H, W), 491)
+    w = fill.randn((cout, 64, 3, 3), 492, (2.0 / (64 * 9)) ** 0.5)
+    b = fill.randn((cout,), 493, 0.1)
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 1, 1))
+    cfg = ops.ConvCfg(1, 1, False, 0, 1, 0.0, 0, ALGOS["auto"])
+    lib.srk_ring_timeouts(1)
+    outs = {}
+    monkeypatch.setattr(ops, "F16X3_ALWAYS", mode == "mixed")
+    ops.set_precision(mode)
+    try:
+        for cv in ("2", "0"):
+            monkeypatch.setenv("SRK_BFR_CV", cv)
+            monkeypatch.setenv("SRK_BFR", "1" if cv == "2" else "0")
+            with torch.no_grad():
+                outs[cv] = ops.conv2d_infer(x.to(gpu), w.to(gpu), b.to(gpu), None, cfg)
+            name = lib.srk_last_kernel_name().decode()
+            assert name.startswith("k_conv_bfr<2,2" if cv == "2" else "k_conv_bfw<"), name
+            assert ("canvas" in name) == (cv == "2") and ("f16" in name) == (mode == "mixed"), name
+    finally:
+        ops.set_precision("mixed")
+    assert lib.srk_ring_timeouts(1) == 0
+    assert rel_err(outs["2"], outs["0"]) < 2e-6
+    assert rel_err(outs["2"], ref.float()) < (2e-6 if mode == "mixed" else 1e-4)
+    if cout != 64:
+        return
+    # data gradients: x -> three conv + ReLU layers, 64 -> 64.  The top layer masks its own dy (k_conv_bfw: the canvas takes
+    # no input mask), the middle one gets it pre-masked and masks its dx (canvas, relu), the first one is plain
+    w2 = fill.randn((64, 64, 3, 3), 494, (2.0 / (64 * 9)) ** 0.5)
+    w3 = fill.randn((64, 64, 3, 3), 496, (2.0 / (64 * 9)) ** 0.5)
+    g = fill.randn((N, 64, H, W), 495)
+    xr = x.double().requires_grad_(True)
+    h = torch.relu(torch.nn.functional.conv2d(xr, w.double(), None, 1, 1))
+    h = torch.relu(torch.nn.functional.conv2d(h, w2.double(), None, 1, 1))
+    torch.relu(torch.nn.functional.conv2d(h, w3.double(), None, 1, 1)).backward(g.double())
+    grads, names = {}, {}
+    real = lib.srk_conv2d_backward_data_relu
+    cfg2 = ops.ConvCfg(1, 1, False, 0, 1, 0.0, 0)
+    try:
+        for cv in ("2", "0"):
+            monkeypatch.setenv("SRK_BFR_CV", cv)
+            monkeypatch.setenv("SRK_BFR", "1" if cv == "2" else "0")
+            seen = []
+            lib.srk_conv2d_backward_data_relu = lambda *a: (real(*a), seen.append(lib.srk_last_kernel_name().decode()))[0]
+            xg = x.to(gpu).requires_grad_(True)
+            h1 = ops.conv2d(xg, w.to(gpu), None, None, cfg2)
+            h2 = ops.conv2d(h1, w2.to(gpu), None, None, cfg2)
+            out = ops.conv2d(h2, w3.to(gpu), None, None, cfg2)
+            with ops.premasked_gradients():
+                out.backward(g.to(gpu))
+            names[cv] = (seen, lib.srk_last_kernel_name().decode())
+            grads[cv] = xg.grad.clone()
+    finally:
+        lib.srk_conv2d_backward_data_relu = real
+    assert lib.srk_ring_timeouts(1) == 0
+    assert names["2"][0] == ["k_conv_bfw<2,9,2,mask,relu>", "k_conv_bfr<2,2,canvas,relu>"], names
+    assert names["2"][1].startswith("k_conv_bfr<2,2") and "canvas" in names["2"][1], names
+    assert all(n.startswith("k_conv_bfw<") for n in names["0"][0] + [names["0"][1]]), names
+    assert rel_err(grads["2"], grads["0"]) < 2e-5
+    assert rel_err(grads["2"], xr.grad.float()) < 1e-4
+
+
 @pytest.mark.parametrize("fan_out", [False, True])
 def test_premasked_gradients(gpu, monkeypatch, fan_out):
     """Chain of conv + ReLU layers whose data gradients run on k_conv_bfw: each dx leaves multiplied by the ReLU gradient
