@@ -185,6 +185,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
   const int tstride = CV ? ((nblk + 7 - xcd) >> 3) / B.nsl : (nblk + 7 - xcd) >> 3;
   // CV: the tile coordinates below are those of the canvas (one "image" of tiles_y x tiles_x tiles)
   const int cvH = P.PH + 1, cvW = P.PW + 1, cvK = CV ? B.cv_kx : 1;
+  // v / cvH and v / cvW for the small non-negative v below: one multiply-high by ceil(2^32 / d) (host: exact for v d < 2^32)
+  auto div_h = [&](int v) { return (int)__umulhi((unsigned)v, B.cv_mh); };
+  auto div_w = [&](int v) { return (int)__umulhi((unsigned)v, B.cv_mw); };
   count = __builtin_amdgcn_readfirstlane(count);
 
   // Tile coordinates (image, tile row, tile column) of the two tiles of a pair, advanced by TWO list steps per pair:
@@ -237,6 +240,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
       it_hx[k] = hx;
       it_hy[k] = hy;
     }
+    // CV: byte strides of an input row / pixel / patch, and what a step into the next cell adds to an offset
+    const int cv_row = P.IW * P.IC * 4, cv_px = P.IC * 4, cv_img = P.IH * cv_row;
+    const int cv_wrap_y = cvK * cv_img - cvH * cv_row, cv_wrap_x = cv_img - cvW * cv_px;
+    int cv_rel[PIT];
+#pragma unroll
+    for (int k = 0; k < PIT; ++k) cv_rel[k] = it_hy[k] * cv_row + it_hx[k] * cv_px + g * 32;
     const unsigned img_bytes = (unsigned)((size_t)P.IH * P.IW * P.IC * 4);
     const unsigned in_bytes = (unsigned)((size_t)P.N * P.IH * P.IW * P.IC * 4);  // (CV; host: below 2 GiB)
     auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
@@ -274,27 +283,28 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
       const size_t img = CV ? 0 : (size_t)n * P.IH * P.IW * P.IC;
       const __amdgpu_buffer_rsrc_t rin = rsrc_of(P.in + img, CV ? in_bytes : img_bytes);
       const int obase = ((iyb * P.IW + ixb) * P.IC + cc * 32) * 4;  // may be negative: rows above the image wrap out of range
-      // CV: cell and in-cell position of the halo's first row / column (one cell above / left of the canvas: the separator)
-      const int cy0 = (iyb + cvH) / cvH - 1, ry0 = iyb + cvH - (cy0 + 1) * cvH;
-      const int cx0 = (ixb + cvW) / cvW - 1, rx0 = ixb + cvW - (cx0 + 1) * cvW;
+      // CV: cell (cy0, cx0) and in-cell position (ry0, rx0) of the halo's first row / column -- cell -1 with the position of
+      // the separator for the row above / the column left of the canvas.  A halo pixel (hy, hx) lies in that cell or, from
+      // hy >= ty / hx >= tx on, in the next one; hy == ty - 1 / hx == tx - 1 is the separator; one cell past the last of a
+      // canvas row is padding too.  Patches below the batch's last lie beyond the buffer: the descriptor returns zeros.
+      int ty = 0, tx = 0, cv_base = 0;
+      bool x_last = false;
+      if constexpr (CV) {
+        const int cy0 = div_h(iyb + cvH) - 1, ry0 = iyb + cvH - (cy0 + 1) * cvH;
+        const int cx0 = div_w(ixb + cvW) - 1, rx0 = ixb + cvW - (cx0 + 1) * cvW;
+        ty = cvH - ry0;
+        tx = cvW - rx0;
+        x_last = cx0 == cvK - 1;
+        cv_base = (cy0 * cvK + cx0) * cv_img + ry0 * cv_row + rx0 * cv_px + cc * 128;
+      }
 #pragma unroll
       for (int k = 0; k < PIT; ++k) {
         bool ok;
         unsigned o;
         if constexpr (CV) {
-          int ry = ry0 + it_hy[k], cy = cy0, rx = rx0 + it_hx[k], cx = cx0;
-          if (ry >= cvH) {
-            ry -= cvH;
-            ++cy;
-          }
-          if (rx >= cvW) {
-            rx -= cvW;
-            ++cx;
-          }
-          const int pn = cy * cvK + cx;
-          ok = it_rel[k] >= 0 && ch_on && ry < P.PH && rx < P.PW && (unsigned)cx < (unsigned)cvK && cy >= 0 &&
-               (unsigned)pn < (unsigned)P.N;
-          o = ok ? (unsigned)((((pn * P.IH + ry) * P.IW + rx) * P.IC + cc * 32 + g * 8) * 4) : OOB;
+          const bool wy = it_hy[k] >= ty, wx = it_hx[k] >= tx;
+          ok = it_rel[k] >= 0 && ch_on && it_hy[k] != ty - 1 && it_hx[k] != tx - 1 && !(wx && x_last);
+          o = ok ? (unsigned)(cv_base + cv_rel[k] + (wy ? cv_wrap_y : 0) + (wx ? cv_wrap_x : 0)) : OOB;
         } else {
           ok = it_rel[k] >= 0 && ch_on && (unsigned)(ixb + it_hx[k]) < (unsigned)P.IW;
           o = ok ? (unsigned)(obase + it_rel[k]) : OOB;
@@ -424,8 +434,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
   f32x4 om[OMASK ? NTW : 1][OMASK ? MR : 1];
   auto cv_offsets = [&](int r0, int c0) {
     if constexpr (CV) {
-      const int cy0 = r0 / cvH, ry0 = r0 - cy0 * cvH;
-      const int cx0 = c0 / cvW, rx0 = c0 - cx0 * cvW;
+      const int cy0 = div_h(r0), ry0 = r0 - cy0 * cvH;
+      const int cx0 = div_w(c0), rx0 = c0 - cx0 * cvW;
       int rx = rx0 + pj, cx = cx0;
       if (rx >= cvW) {
         rx -= cvW;
@@ -759,6 +769,7 @@ static int conv_bfr_canvas(const BfwParams& B0, hipStream_t s) {
     }
   }
   if (best_kx == 0 || best_tiles >= (1L << 29)) return -1;
+  if (((double)P.N * cvH + 64.0) * cvH >= 4.0e9 || ((double)best_kx * cvW + 64.0) * cvW >= 4.0e9) return -1;  // (div_h / div_w exact)
   if (mode != 2) {
     const double px = (double)P.N * P.PH * P.PW;
     const long plain = (long)((P.PH + BFR_TH - 1) / BFR_TH) * ((P.PW + BFR_TW - 1) / BFR_TW) * P.N;
@@ -766,6 +777,8 @@ static int conv_bfr_canvas(const BfwParams& B0, hipStream_t s) {
     if (plain_ok || px < 0.88 * (double)best_tiles * (BFR_TH * BFR_TW) || best_tiles * B.nsl < 4L * kNumCU) return -1;
   }
   B.cv_kx = best_kx;
+  B.cv_mh = (unsigned)(((1ull << 32) + cvH - 1) / cvH);
+  B.cv_mw = (unsigned)(((1ull << 32) + cvW - 1) / cvW);
   P.TH = BFR_TH; P.TW = BFR_TW; P.HH = BFR_HH; P.HW = BFR_HW;
   P.tiles_x = (best_kx * cvW - 1 + BFR_TW - 1) / BFR_TW;
   P.tiles_y = (int)(best_tiles / P.tiles_x);

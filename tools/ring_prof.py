@@ -16,11 +16,16 @@ lib.srk_debug_ring_prof.restype = None
 prof = torch.zeros(4096 * 16, dtype=torch.int64, device=dev)
 net = pkg.ESPCNNet(3, 64, 4); net.weight_init(); net.to(dev).eval()
 x = torch.rand(64, 3, 256, 256, device=dev)
+vdsr = len(sys.argv) > 1 and sys.argv[1] == "vdsr"   # a VDSR body layer (64 -> 64 on 256 patches of 41 x 41: the canvas variant)
 with torch.no_grad():
     hs, h = [], x
     for l in net.layers:
         hs.append(h); h = l(h)
-    for i in (1, 2):
+    if vdsr:
+        vnet = pkg.VDSRNet(3, 64, 18); vnet.weight_init(); vnet.to(dev).train()   # (the training forward: all 18 body layers;
+        hs = {1: torch.rand(256, 3, 41, 41, device=dev)}                           #  the sums below are over their launches)
+        net = type("N", (), {"layers": {1: vnet}})
+    for i in ((1,) if vdsr else (1, 2)):
         l = net.layers[i]
         for _ in range(3): l(hs[i])
         torch.cuda.synchronize()
