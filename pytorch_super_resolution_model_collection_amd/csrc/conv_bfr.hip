@@ -134,6 +134,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
   constexpr int HBUF = 8 * NPIXP;       // uint4 per halo slot: [plane 2][group 4][NPIXP]
   constexpr int PLANE_B = 4 * NPIXP, PLANE_A = 4 * NB;
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
+#ifdef BFR_PROF
+  const long long cw_entry = wall_clock64();
+#endif
   const MfmaConvParams& P = B.P;
   uint4* wl = smem4;
   uint4* hal0 = smem4 + 9 * ICC * WSLOT;
@@ -150,27 +153,53 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
   }
   (void)sx;
 
+#ifdef BFR_PROF
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const long long cw_p1 = wall_clock64();   // arguments, input maximum, descale read
+#endif
   const int xcd = blockIdx.x & 7;
   int bi = blockIdx.x >> 3, sl = 0;  // (not CV: one slice, the whole filter is resident)
   if constexpr (CV) {
     sl = bi % B.nsl;
     bi = bi / B.nsl;
   }
-  for (int e = tid; e < 9 * ICC * WSLOT; e += NTHR) {
-    const int slot = e / WSLOT, w = e - slot * WSLOT;
-    const int t = slot / ICC, cc = slot - t * ICC;
-    const int u = t / 3, v = t - u * 3;
-    const int tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
-    // packed layout [tap][chunk][64-channel block][plane][group][NBfull channels] with NBfull = NB here (OC <= 48)
-    if constexpr (CV) {
-      const int pg = w / NB, o = w - pg * NB;
-      const int oc = sl * NB + o, ocb = oc / B.NBfull;
-      wl[e] = B.wq[((size_t)(tapw * ICC + cc) * B.OCb + ocb) * (size_t)(8 * B.NBfull) + pg * B.NBfull + (oc - ocb * B.NBfull)];
-    } else {
-      wl[e] = B.wq[(size_t)(tapw * ICC + cc) * WSLOT + w];
-    }
+  // The filter into LDS: every load of a thread in flight before its first LDS store.  (As a plain loop the compiler waits for
+  // each 16-byte load in turn -- global_load; s_waitcnt vmcnt(0); ds_write -- nine L2 round trips in a row, 4.1 - 4.7 us of the
+  // 6.5 - 8.5 us between a block's first instruction and its first tile: tools/ring_prof.py, round 6.  Native vectors: an
+  // array of HIP's uint4 structs ends up in scratch memory here.)
+  {
+    constexpr int FW = 9 * ICC * WSLOT, NLD = (FW + NTHR - 1) / NTHR;
+    typedef unsigned fv4 __attribute__((ext_vector_type(4)));
+    fv4 wv[NLD];
+    srk_static_for<0, NLD>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int e = tid + i * NTHR;
+      const int ec = e < FW ? e : FW - 1;
+      const int slot = ec / WSLOT, w = ec - slot * WSLOT;
+      const int t = slot / ICC, cc = slot - t * ICC;
+      const int u = t / 3, v = t - u * 3;
+      const int tapw = (P.wh0 + P.wdh * u) * P.KW_full + (P.ww0 + P.wdw * v);
+      // packed layout [tap][chunk][64-channel block][plane][group][NBfull channels] with NBfull = NB where OC <= 48
+      if constexpr (CV) {
+        const int pg = w / NB, o = w - pg * NB;
+        const int oc = sl * NB + o, ocb = oc / B.NBfull;
+        wv[i] = *reinterpret_cast<const fv4*>(B.wq + ((size_t)(tapw * ICC + cc) * B.OCb + ocb) * (size_t)(8 * B.NBfull) + pg * B.NBfull +
+                                              (oc - ocb * B.NBfull));
+      } else {
+        wv[i] = *reinterpret_cast<const fv4*>(B.wq + (size_t)(tapw * ICC + cc) * WSLOT + w);
+      }
+    });
+    srk_static_for<0, NLD>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int e = tid + i * NTHR;
+      if (e < FW) *reinterpret_cast<fv4*>(wl + e) = wv[i];
+    });
   }
   if (tid < 2 * BFR_MAXBUF) cnt[tid] = 0u;
+#ifdef BFR_PROF
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const long long cw_p2 = wall_clock64();   // filter in LDS
+#endif
   // tiles of this block (XCD-aware contiguous ranges, as in k_conv_bfw): first, first + tstride, ... (count of them)
   const int nblk = gridDim.x;
   int first, count;
@@ -532,6 +561,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) asm volatile("" ::"v"(bias4[nt]));
   asm volatile("" ::"v"(act_slope));
+#ifdef BFR_PROF
+  const long long cw_p3 = wall_clock64();   // consumer set-up (bias, offsets) done, before the barrier
+#endif
   __syncthreads();  // filter and counters visible
 
   // own tiles: list entries grp, grp + 2, ...; stage (entry i, chunk cc) is number (i >> 1) * 2 ICC + cc * ng + (i & 1) of
@@ -697,10 +729,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
     pr[4] = BFR_CLK_TOTAL() - ct_begin;
     pr[5] = ct[5];
     pr[6] = wall_clock64() - cw_begin;   // 100 MHz: the loop in wall time
+    pr[-2] = cw_begin - cw_entry;        // ... from the block's first instruction to the loop (filter copy, set-up, barrier)
+    B.prof[(size_t)(2048 + blockIdx.x) * 16 + 0] = cw_p1 - cw_entry;   // (the prologue split: rows 2048 .. of the buffer)
+    B.prof[(size_t)(2048 + blockIdx.x) * 16 + 1] = cw_p2 - cw_p1;
+    B.prof[(size_t)(2048 + blockIdx.x) * 16 + 2] = cw_p3 - cw_p2;
+    pr[-1] = cw_entry;                   // ... when the block started (absolute)
   }
 #endif
   (void)ct; (void)ct_begin;
   if (P.ep.y_amax) amax_commit(P.ep.y_amax, amax, blockIdx.x + wave, amax_peek(P.ep.y_amax, blockIdx.x + wave));
+#ifdef BFR_PROF
+  if (B.prof && tid == 0) B.prof[(size_t)blockIdx.x * 16 + 15] = wall_clock64();   // ... when consumer wave 0 left (absolute)
+#endif
   if (dead) bfr_fail(lane);
 }
 

@@ -39,6 +39,14 @@ with torch.no_grad():
         t = t[t[:, 13] > 0]
         st = t[:, 13].mean()      # own stages of consumer wave 0 (half of the block's)
         print("layer %d %s: %.1f us with stamps, %d blocks, %.0f stages per group" % (i, lib.srk_last_kernel_name().decode(), e0.elapsed_time(e1) * 1e3, t.shape[0], st))
+        ent, ext = t[:, 7], t[:, 15]      # block entry / consumer wave 0 exit, 100 MHz wall clock
+        print("   wall clock (us): first block in -> last out %.1f; block start spread %.1f; entry -> loop %.1f (max %.1f); loop %.1f (max %.1f); loop end -> exit %.1f; last out - mean out %.1f"
+              % ((ext.max() - ent.min()) / 100, (ent.max() - ent.min()) / 100, t[:, 6].mean() / 100, t[:, 6].max() / 100, t[:, 14].mean() / 100, t[:, 14].max() / 100,
+                 (ext - ent - t[:, 6] - t[:, 14]).mean() / 100, (ext.max() - ext.mean()) / 100))
+        q = prof.view(-1, 16)[2048:2048 + 256].cpu().double()
+        q = q[q[:, 1] > 0]
+        print("   prologue split (us): arguments + input maximum %.2f, filter copy %.2f, consumer set-up %.2f, barrier %.2f"
+              % (q[:, 0].mean() / 100, q[:, 1].mean() / 100, q[:, 2].mean() / 100, t[:, 6].mean() / 100 - q[:, :3].sum(1).mean() / 100))
         tp, tc = t[:, 5].mean(), t[:, 12].mean()
         names = ["wait free", "wait loads", "split+commit", "signal", "issue"]
         print("   producer (ticks per stage, %% of its loop): " + "  ".join("%s %.0f (%.0f %%)" % (n, t[:, j].mean() / (2 * st), 100 * t[:, j].mean() / tp) for j, n in enumerate(names)) + "   loop %.0f" % tp)
