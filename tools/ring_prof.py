@@ -43,6 +43,12 @@ with torch.no_grad():
         print("   wall clock (us): first block in -> last out %.1f; block start spread %.1f; entry -> loop %.1f (max %.1f); loop %.1f (max %.1f); loop end -> exit %.1f; last out - mean out %.1f"
               % ((ext.max() - ent.min()) / 100, (ent.max() - ent.min()) / 100, t[:, 6].mean() / 100, t[:, 6].max() / 100, t[:, 14].mean() / 100, t[:, 14].max() / 100,
                  (ext - ent - t[:, 6] - t[:, 14]).mean() / 100, (ext.max() - ext.mean()) / 100))
+        full = prof.view(-1, 16)[:256].cpu().double()
+        if full[:, 13].min() > 0:   # tile loop (wall us) by XCD (block & 7) and by position inside the XCD (block >> 3)
+            lp = full[:, 14] / 100
+            print("   tile loop by XCD: " + " ".join("%.1f" % lp[x::8].mean() for x in range(8)) +
+                  "; by quarter of the XCD's blocks: " + " ".join("%.1f" % lp.view(32, 8)[i * 8:(i + 1) * 8].mean() for i in range(4)) +
+                  "; sd inside an XCD %.1f" % lp.view(32, 8).std(0).mean())
         q = prof.view(-1, 16)[2048:2048 + 256].cpu().double()
         q = q[q[:, 1] > 0]
         print("   prologue split (us): arguments + input maximum %.2f, filter copy %.2f, consumer set-up %.2f, barrier %.2f"
