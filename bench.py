@@ -229,7 +229,7 @@ def training_roofline(tag, px, layer_px_note, layers_per_step=1, steps=5):
     flop = 2.0 * px * 64 * 64 * 9
     # (role, kernel-name keys, algorithmic bytes per LAYER, operands, layers' worth of FLOPs per launch or None = from calls)
     # (k_conv_bfr<2, 2, F16, true, OMASK>: the ring kernel's canvas variant, round 6 -- VDSR's body layers)
-    roles = [("forward", ("k_conv_bfr<2, 2, true, true, false>", "k_conv_bfw<2, 9, 2, true, false", "k_conv_bfd<2, 2, 2, 2", "k_conv_bfd<2, 2, 2, 3",
+    roles = [("forward", ("k_conv_bfr<2, 2, true, true, false", "k_conv_bfw<2, 9, 2, true, false", "k_conv_bfd<2, 2, 2, 2", "k_conv_bfd<2, 2, 2, 3",
                           "k_conv_bfd<4, 4, 1, 2"),
               2 * t, "x, y", 1.0),
              ("data_gradient", ("k_conv_bfr<2, 2, false, true, ", "k_conv_bfw<2, 9, 2, false, ", "k_conv_bf3<4, 4, true>"), 3 * t,
@@ -238,7 +238,7 @@ def training_roofline(tag, px, layer_px_note, layers_per_step=1, steps=5):
              # residual blocks fused per tile (conv -> ReLU -> conv -> + skip in one launch): useful work of two layers
              ("fused_block_forward", ("k_res2<2, false", "k_res2<3, false"), 3 * t, "x, intermediate, y", 2.0),
              ("fused_block_data_gradient", ("k_res2<2, true",), 4 * t, "dy, saved intermediate, its gradient, dx", 2.0)]
-    if any("k_conv_bfw<2, 9, 2, false, false, true" in r["Name"] or "k_conv_bfr<2, 2, false, true, true>" in r["Name"] for r in rows):
+    if any("k_conv_bfw<2, 9, 2, false, false, true" in r["Name"] or "k_conv_bfr<2, 2, false, true, true" in r["Name"] for r in rows):
         # pre-masked gradients (ops.PREMASK): dy arrives already multiplied by this layer's ReLU gradient
         roles[2] = ("weight_gradient", ("k_wgrad_tr<", "k_wgrad_bf<2, 2, 2, true"), 2 * t, "x, dy (pre-masked by the data gradient above)", None)
     if any("k_res2<" in r["Name"] for r in rows):   # body layers run fused per block: no stand-alone forward / data gradient

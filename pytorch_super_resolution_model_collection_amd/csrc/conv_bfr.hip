@@ -120,9 +120,12 @@ __device__ __forceinline__ void bfr_signal(bfr_cnt_t* p) {
 // changes.  CV blocks also take output-channel SLICES (B.nsl, as k_conv_bfw does: the 147 KB filter of 64 -> 64 as two
 // 32-channel halves on neighbouring blocks of one XCD).  OMASK: ep.out_relu as in k_conv_bfw (the data gradient leaves
 // multiplied by the ReLU gradient of the layer below), requested when the tile starts, applied when it is parked.
-template <int NTW, int ICC, bool F16, bool CV = false, bool OMASK = false>
+// RES: ep.residual (conv + skip of a residual block, `/root/reference/base_networks.py:148`; the gradient fan-in of its first
+// conv's data gradient) is requested the same way and added after the activation, the epilogue order of every other kernel.
+template <int NTW, int ICC, bool F16, bool CV = false, bool OMASK = false, bool RES = false>
 __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
-  static_assert(CV || !OMASK, "the output mask comes with the canvas variant");
+  static_assert(CV || !(OMASK || RES), "the output mask and the residual come with the canvas variant");
+  static_assert(!(OMASK && RES), "one tensor read per output tile");
   constexpr int NB = 16 * NTW;
   constexpr int NCW = 4, NGW = 2, NPW = 4;  // consumer waves (two groups of NGW), producer waves
   constexpr int NPS = NPW;                  // producer waves that fill one slot
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
   // CV: byte offsets of the lane's output pixels of the tile being computed (kDrop: separator / beyond the batch), set when
   // the tile starts; OMASK: the mask tensor's values there, requested at that moment through the same offsets
   unsigned cur_voff[CV ? MR : 1];
-  f32x4 om[OMASK ? NTW : 1][OMASK ? MR : 1];
+  f32x4 om[(OMASK || RES) ? NTW : 1][(OMASK || RES) ? MR : 1];   // (RES: the residual's values)
   auto cv_offsets = [&](int r0, int c0) {
     if constexpr (CV) {
       const int cy0 = div_h(r0), ry0 = r0 - cy0 * cvH;
@@ -482,9 +485,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
         const bool pok = col_ok && ry < P.PH && pn < P.N;
         cur_voff[r] = pok ? 4u * (unsigned)(((pn * P.OH + ry) * P.OW + rx) * P.OC) : kDrop;
       }
-      if constexpr (OMASK) {
+      if constexpr (OMASK || RES) {
         const __amdgpu_buffer_rsrc_t mrsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.ep.out_relu), 0, B.out_bytes, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RES ? P.ep.residual : P.ep.out_relu), 0, B.out_bytes, 0x00020000);
 #pragma unroll
         for (int r = 0; r < MR; ++r)
 #pragma unroll
@@ -544,6 +547,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = om[nt][r][e] > 0.f ? v[e] : 0.f;
           }
+          if constexpr (RES) v += om[nt][r];
           rmax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), rmax);
           rmax = fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), rmax);
         }
@@ -748,17 +752,19 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
 static int bfr_launch_cv(const BfwParams& B, size_t lds, int grid, hipStream_t s) {
   note_amax_written(B.P.ep.y_amax != nullptr);
   const dim3 blk(512);
-  const bool omask = B.P.ep.out_relu != nullptr;
-  auto go = [&](auto f16c, auto omc) {
-    constexpr bool F = decltype(f16c)::value, O = decltype(omc)::value;
+  const bool omask = B.P.ep.out_relu != nullptr, res = B.P.ep.residual != nullptr;
+  auto go = [&](auto f16c, auto omc, auto resc) {
+    constexpr bool F = decltype(f16c)::value, O = decltype(omc)::value, R = decltype(resc)::value;
     static LdsLimit lim;
-    lim.ensure(reinterpret_cast<const void*>(&k_conv_bfr<2, 2, F, true, O>), lds);
-    note_kernel("k_conv_bfr<2,2%s,canvas%s>", F ? ",f16" : "", O ? ",relu" : "");
-    hipLaunchKernelGGL((k_conv_bfr<2, 2, F, true, O>), dim3(grid), blk, lds, s, B);
+    lim.ensure(reinterpret_cast<const void*>(&k_conv_bfr<2, 2, F, true, O, R>), lds);
+    note_kernel("k_conv_bfr<2,2%s,canvas%s%s>", F ? ",f16" : "", O ? ",relu" : "", R ? ",res" : "");
+    hipLaunchKernelGGL((k_conv_bfr<2, 2, F, true, O, R>), dim3(grid), blk, lds, s, B);
   };
-  if (B.w_descale) go(std::true_type{}, std::false_type{});
-  else if (omask) go(std::false_type{}, std::true_type{});
-  else go(std::false_type{}, std::false_type{});
+  if (B.w_descale && res) go(std::true_type{}, std::false_type{}, std::true_type{});
+  else if (B.w_descale) go(std::true_type{}, std::false_type{}, std::false_type{});
+  else if (res) go(std::false_type{}, std::false_type{}, std::true_type{});
+  else if (omask) go(std::false_type{}, std::true_type{}, std::false_type{});
+  else go(std::false_type{}, std::false_type{}, std::false_type{});
   return check_launch("conv_bfr");
 }
 
@@ -793,7 +799,8 @@ static int conv_bfr_canvas(const BfwParams& B0, hipStream_t s) {
   if (P.IH != P.PH || P.IW != P.PW || P.OH != P.PH || P.OW != P.PW || P.iy0 != -1 || P.ix0 != -1 || P.oy0 != 0 || P.ox0 != 0)
     return -1;
   if (P.mask_y || P.ep.ps_r > 1 || P.PH < 9 || P.PW < 17) return -1;
-  if (P.ep.out_relu && B.w_descale) return -1;
+  if (P.ep.out_relu && (B.w_descale || P.ep.residual)) return -1;
+  if (P.ep.residual && (uintptr_t)P.ep.residual % 16 != 0) return -1;
   const size_t in_bytes = (size_t)P.N * P.IH * P.IW * P.IC * 4, out_bytes = (size_t)P.N * P.OH * P.OW * P.OC * 4;
   if (in_bytes >= (1ull << 31) || out_bytes >= (1ull << 31)) return -1;
   const int cvH = P.PH + 1, cvW = P.PW + 1;
@@ -864,6 +871,7 @@ int conv_bfr_launch(const BfwParams& B0, hipStream_t s) {
     const int rc = conv_bfr_canvas(B0, s);
     if (rc != -1) return rc;
   }
+  if (P.ep.residual) return -1;   // (only the canvas variant above adds a residual)
   if (P.KHv != 3 || P.KWv != 3 || P.is != 1 || B.nsl != 1 || (ntw != 2 && ntw != 3) || B.NB != P.OC) return -1;
   if ((B.ICc != 1 && B.ICc != 2) || P.IC % 8 != 0) return -1;
   if (ntw == 3 && B.ICc != 1) return -1;  // (48 channels from 64: the instantiation spills; no net has that layer)

@@ -539,7 +539,11 @@ bool conv_bfw_applicable(const GatherConv& g, const Epi& ep, const float* in, co
   if (mask_y && (NB != 32 || T != 9 || (uintptr_t)mask_y % 16 != 0)) return false;
   if (ep.out_relu && (NB != 32 || T != 9 || ep.ps_r > 1 || ep.act != SRK_ACT_NONE || (uintptr_t)ep.out_relu % 16 != 0)) return false;
   if (!conv_epi_all_vector(g.OC, ep, out)) return false;
-  if (ep.residual || (ep.act == SRK_ACT_PRELU && ep.prelu_n > 1)) return false;
+  if (ep.act == SRK_ACT_PRELU && ep.prelu_n > 1) return false;
+  // a residual / gradient fan-in: only the ring kernel's canvas variant adds one (conv_bfr.hip: 3x3 pad-1 layers with 64 input
+  // channels and 32-channel slices, no mask, plain stores); conv_bfw_gather returns -1 where that variant declines
+  if (ep.residual && (T != 9 || NB != 32 || g.IC != 64 || mask_y || ep.out_relu || ep.ps_r > 1 || (uintptr_t)ep.residual % 16 != 0))
+    return false;
   if (ep.act != SRK_ACT_NONE && ep.act != SRK_ACT_RELU && ep.act != SRK_ACT_LRELU && ep.act != SRK_ACT_PRELU) return false;
   if ((long)g.N * g.OH * g.OW * g.OC >= (1L << 29)) return false;  // 32-bit byte offsets into an output below 2 GiB (kDrop)
   const size_t wbytes = (size_t)T * ((g.IC + 31) / 32) * 8 * NB * 16;
@@ -648,6 +652,7 @@ int conv_bfw_gather(const GatherConv& g, const float* in, const float* wp, float
       const int rc = conv_bfr_launch(B, s);
       if (rc != -1) return rc;
     }
+    if (P.ep.residual) return -1;   // (this kernel's epilogue has no residual: the caller's other kernels)
     TilePick best{};
     if (px_cap < 64 || P.is != 1) return -1;
     if (!bfw_pick_tile(256, P.PH, P.PW, P.KHv, P.KWv, px_cap, perm, w16 ? 16 : 1, best)) return -1;

@@ -512,8 +512,11 @@ static int r2_dbg() {
 // x4 train step (tools/shard_step.py, fused vs separate): 16 patches 1.36 vs 1.63 ms, 32: 2.27 vs 2.56, 64: 4.04 vs
 // 4.57, 128 (8 tiles per CU): 7.57 vs 7.08 -> the limit sits at 5 tiles per CU.
 bool conv_res2_supported(int N, int H, int W, int C) {
-  // (round 3: with the f16x3 forward the fused block also wins at 8 tiles per CU: EDSR batch 128 6.46 -> 6.33 ms)
-  const int max_tiles = env_int("SRK_RES2_MAX_TILES", 10 * kNumCU);
+  // (round 3: with the f16x3 forward the fused block also won at 8 tiles per CU: EDSR batch 128 6.46 -> 6.33 ms.  Round 6: from
+  //  the size at which the wave-specialised family takes a 64 -> 64 layer -- 512 pixels per CU, conv_bfw_applicable -- the block's
+  //  two convs run faster as two launches of the ring kernel's canvas variant, which adds the skip / the gradient fan-in itself:
+  //  EDSR batch 128 5.56 -> 5.40 ms same-box; at batch 64 those kernels do not apply and the fused block stays 16 % ahead)
+  const int max_tiles = env_int("SRK_RES2_MAX_TILES", 8 * kNumCU - 1);
   if (C != R2_C || N < 1 || H < 1 || W < 1) return false;
   if ((long)H * W * R2_C >= (1L << 29)) return false;  // 32-bit element offsets inside an image
   const long tiles = (long)N * ((H + R2_TS - 1) / R2_TS) * ((W + R2_TS - 1) / R2_TS);

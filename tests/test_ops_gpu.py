@@ -604,6 +604,28 @@ def test_conv_ring_on_a_canvas(gpu, monkeypatch, cout, H, W, N, mode):
     assert lib.srk_ring_timeouts(1) == 0
     assert rel_err(outs["2"], outs["0"]) < 2e-6
     assert rel_err(outs["2"], ref.float()) < (2e-6 if mode == "mixed" else 1e-4)
+    # conv + residual (the second conv of a residual block, no activation): the canvas variant adds it when a tile is parked;
+    # without the canvas the layer leaves the wave-specialised family (k_conv_bfw has no residual)
+    res = fill.randn((N, cout, H, W), 497)
+    ref_r = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 1, 1) + res.double()
+    cfg_r = ops.ConvCfg(1, 1, False, 0, 0, 0.0, 0, ALGOS["auto"])
+    outs_r = {}
+    monkeypatch.setenv("SRK_C64", "0")   # (small activation-free 64 -> 64 problems would take the per-tile k_c64)
+    ops.set_precision(mode)
+    try:
+        for cv in ("2", "0"):
+            monkeypatch.setenv("SRK_BFR_CV", cv)
+            monkeypatch.setenv("SRK_BFR", "1" if cv == "2" else "0")
+            with torch.no_grad():
+                outs_r[cv] = ops.conv2d_infer(x.to(gpu), w.to(gpu), b.to(gpu), res.to(gpu), cfg_r)
+            name = lib.srk_last_kernel_name().decode()
+            assert (name == "k_conv_bfr<2,2%s,canvas,res>" % (",f16" if mode == "mixed" else "")) == (cv == "2"), name
+            assert not name.startswith("k_conv_bfw<"), name
+    finally:
+        ops.set_precision("mixed")
+    assert lib.srk_ring_timeouts(1) == 0
+    assert rel_err(outs_r["2"], outs_r["0"]) < (2e-6 if mode == "mixed" else 2e-5)
+    assert rel_err(outs_r["2"], ref_r.float()) < (2e-6 if mode == "mixed" else 1e-4)
     if cout != 64:
         return
     # data gradients: x -> three conv + ReLU layers, 64 -> 64.  The top layer masks its own dy (k_conv_bfw: the canvas takes

@@ -128,7 +128,8 @@ def test_resblock2_only_for_small_problems(gpu):
     pkg = _pkg()
     lib = pkg._lib.load()
     assert lib.srk_resblock2_supported(16, 32, 32, 64) == 1
-    assert lib.srk_resblock2_supported(128, 32, 32, 64) == 1      # 8 tiles per CU: still fused (round 3, f16x3 forward)
+    assert lib.srk_resblock2_supported(127, 32, 32, 64) == 1
+    assert lib.srk_resblock2_supported(128, 32, 32, 64) == 0      # 8 tiles per CU: two launches of the canvas ring kernel (round 6)
     assert lib.srk_resblock2_supported(256, 32, 32, 64) == 0
     assert lib.srk_resblock2_supported(16, 32, 32, 32) == 0
     blk = pkg.base_networks.ResnetBlock(64, activation='relu', norm=None).to(gpu)
