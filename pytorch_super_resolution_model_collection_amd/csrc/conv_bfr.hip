@@ -216,7 +216,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
   }
   const int tstride = CV ? ((nblk + 7 - xcd) >> 3) / B.nsl : (nblk + 7 - xcd) >> 3;
   // CV: the tile coordinates below are those of the canvas (one "image" of tiles_y x tiles_x tiles)
-  const int cvH = P.PH + 1, cvW = P.PW + 1, cvK = CV ? B.cv_kx : 1;
+  const int cvS = CV ? B.cv_sep : 1;
+  const int cvH = P.PH + cvS, cvW = P.PW + cvS, cvK = CV ? B.cv_kx : 1;
   // v / cvH and v / cvW for the small non-negative v below: one multiply-high by ceil(2^32 / d) (host: exact for v d < 2^32)
   auto div_h = [&](int v) { return (int)__umulhi((unsigned)v, B.cv_mh); };
   auto div_w = [&](int v) { return (int)__umulhi((unsigned)v, B.cv_mw); };
@@ -319,14 +320,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
       // the separator for the row above / the column left of the canvas.  A halo pixel (hy, hx) lies in that cell or, from
       // hy >= ty / hx >= tx on, in the next one; hy == ty - 1 / hx == tx - 1 is the separator; one cell past the last of a
       // canvas row is padding too.  Patches below the batch's last lie beyond the buffer: the descriptor returns zeros.
+      // Without separators (cvS == 0: patches of whole tiles) the tile lies inside ONE cell and a halo pixel of another cell is
+      // padding: valid where "one cell on" equals "the halo's first row / column lies one cell before the tile's".
       int ty = 0, tx = 0, cv_base = 0;
-      bool x_last = false;
+      bool x_last = false, y_prev = false, x_prev = false;
       if constexpr (CV) {
         const int cy0 = div_h(iyb + cvH) - 1, ry0 = iyb + cvH - (cy0 + 1) * cvH;
         const int cx0 = div_w(ixb + cvW) - 1, rx0 = ixb + cvW - (cx0 + 1) * cvW;
         ty = cvH - ry0;
         tx = cvW - rx0;
         x_last = cx0 == cvK - 1;
+        y_prev = ty == 1;   // (the halo's first row is the last row of the cell above the tile's)
+        x_prev = tx == 1;
         cv_base = (cy0 * cvK + cx0) * cv_img + ry0 * cv_row + rx0 * cv_px + cc * 128;
       }
 #pragma unroll
@@ -335,7 +340,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_bfr(BfwParams B) {
         unsigned o;
         if constexpr (CV) {
           const bool wy = it_hy[k] >= ty, wx = it_hx[k] >= tx;
-          ok = it_rel[k] >= 0 && ch_on && it_hy[k] != ty - 1 && it_hx[k] != tx - 1 && !(wx && x_last);
+          ok = it_rel[k] >= 0 && ch_on &&
+               (cvS ? it_hy[k] != ty - 1 && it_hx[k] != tx - 1 && !(wx && x_last) : wy == y_prev && wx == x_prev);
           o = ok ? (unsigned)(cv_base + cv_rel[k] + (wy ? cv_wrap_y : 0) + (wx ? cv_wrap_x : 0)) : OOB;
         } else {
           ok = it_rel[k] >= 0 && ch_on && (unsigned)(ixb + it_hx[k]) < (unsigned)P.IW;
@@ -757,7 +763,7 @@ static int bfr_launch_cv(const BfwParams& B, size_t lds, int grid, hipStream_t s
     constexpr bool F = decltype(f16c)::value, O = decltype(omc)::value, R = decltype(resc)::value;
     static LdsLimit lim;
     lim.ensure(reinterpret_cast<const void*>(&k_conv_bfr<2, 2, F, true, O, R>), lds);
-    note_kernel("k_conv_bfr<2,2%s,canvas%s%s>", F ? ",f16" : "", O ? ",relu" : "", R ? ",res" : "");
+    note_kernel("k_conv_bfr<2,2%s,canvas%s%s%s>", F ? ",f16" : "", B.cv_sep ? "" : "0", O ? ",relu" : "", R ? ",res" : "");   // (canvas0: no separators)
     hipLaunchKernelGGL((k_conv_bfr<2, 2, F, true, O, R>), dim3(grid), blk, lds, s, B);
   };
   if (B.w_descale && res) go(std::true_type{}, std::false_type{}, std::true_type{});
@@ -798,15 +804,21 @@ static int conv_bfr_canvas(const BfwParams& B0, hipStream_t s) {
   if (P.KHv != 3 || P.KWv != 3 || P.is != 1 || P.os != 1 || B.NB != 32 || B.ICc != 2 || P.IC != 64) return -1;
   if (P.IH != P.PH || P.IW != P.PW || P.OH != P.PH || P.OW != P.PW || P.iy0 != -1 || P.ix0 != -1 || P.oy0 != 0 || P.ox0 != 0)
     return -1;
-  if (P.mask_y || P.ep.ps_r > 1 || P.PH < 9 || P.PW < 17) return -1;
+  // patches of whole tiles: no separators, one patch per canvas row of cells -- every tile full (SRK_BFR_CV_EXACT=0: separators)
+  const bool exact = P.PH % BFR_TH == 0 && P.PW % BFR_TW == 0 && env_int("SRK_BFR_CV_EXACT", 1) != 0;
+  if (P.mask_y || P.ep.ps_r > 1 || P.PH < 9 + (exact ? 7 : 0) || P.PW < 17 + (exact ? 15 : 0)) return -1;
   if (P.ep.out_relu && (B.w_descale || P.ep.residual)) return -1;
   if (P.ep.residual && (uintptr_t)P.ep.residual % 16 != 0) return -1;
   const size_t in_bytes = (size_t)P.N * P.IH * P.IW * P.IC * 4, out_bytes = (size_t)P.N * P.OH * P.OW * P.OC * 4;
   if (in_bytes >= (1ull << 31) || out_bytes >= (1ull << 31)) return -1;
-  const int cvH = P.PH + 1, cvW = P.PW + 1;
+  const int cvH = P.PH + (exact ? 0 : 1), cvW = P.PW + (exact ? 0 : 1);
   long best_tiles = 0;
   int best_kx = 0;
-  for (int kx = 1; kx <= P.N && kx * cvW <= 4096; ++kx) {
+  if (exact) {
+    best_kx = 1;
+    best_tiles = (long)P.N * (P.PH / BFR_TH) * (P.PW / BFR_TW);
+  }
+  for (int kx = 1; !exact && kx <= P.N && kx * cvW <= 4096; ++kx) {
     const long tx = (kx * cvW - 1 + BFR_TW - 1) / BFR_TW;
     const long ky = (P.N + kx - 1) / kx;
     const long ty = (ky * cvH - 1 + BFR_TH - 1) / BFR_TH;
@@ -824,10 +836,11 @@ static int conv_bfr_canvas(const BfwParams& B0, hipStream_t s) {
     if (plain_ok || px < 0.88 * (double)best_tiles * (BFR_TH * BFR_TW) || best_tiles * B.nsl < 4L * kNumCU) return -1;
   }
   B.cv_kx = best_kx;
+  B.cv_sep = exact ? 0 : 1;
   B.cv_mh = (unsigned)(((1ull << 32) + cvH - 1) / cvH);
   B.cv_mw = (unsigned)(((1ull << 32) + cvW - 1) / cvW);
   P.TH = BFR_TH; P.TW = BFR_TW; P.HH = BFR_HH; P.HW = BFR_HW;
-  P.tiles_x = (best_kx * cvW - 1 + BFR_TW - 1) / BFR_TW;
+  P.tiles_x = exact ? P.PW / BFR_TW : (best_kx * cvW - 1 + BFR_TW - 1) / BFR_TW;
   P.tiles_y = (int)(best_tiles / P.tiles_x);
   const size_t wbytes = (size_t)9 * B.ICc * 8 * B.NB * 16;
   const size_t slot_bytes = (size_t)8 * BFR_NPIXP * 16;

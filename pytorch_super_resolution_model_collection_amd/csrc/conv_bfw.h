@@ -37,6 +37,8 @@ struct BfwParams {
   int dbg;  // ablation (SRK_DBG): 1 no global loads, 2 no epilogue, 4 no MFMA loop, 16 no LDS commit, 1024 no deferred stores
   int nbuf;  // k_conv_bfr: halo buffers of the ring (3 .. BFR_MAXBUF)
   int cv_kx;  // k_conv_bfr<.., canvas>: patches side by side on the canvas
+  int cv_sep;  // ... 1: every cell ends with a separator row / column; 0: patches of whole tiles (H % 8 == 0, W % 16 == 0) stacked
+              // without separators -- a halo pixel outside the tile's own patch is padding
   unsigned cv_mh, cv_mw;  // ... ceil(2^32 / (PH + 1)), ceil(2^32 / (PW + 1))
   long long* prof;  // experiments build only (srk_debug_bfw_prof): per block 16 int64 -- clock64() sums of the first producer
                     // wave {commit, issue, barrier wait, stages} and of consumer wave 0 {tap loop, park, barrier wait, stages}

@@ -569,6 +569,8 @@ def test_conv_wave_specialized_ring(gpu, monkeypatch, cin, cout, H, W, N, act, p
     (64, 9, 17, 40, "bf16x3"),     # the smallest patches the canvas takes
     (64, 48, 50, 3, "mixed"),      # patches larger than a tile row of the canvas is tall
     (64, 130, 200, 1, "mixed"),    # one large image (VDSR's test() forward): a canvas of one cell, for the slices
+    (64, 32, 32, 6, "mixed"),      # patches of whole tiles (EDSR's residual blocks): stacked without separators ("canvas0")
+    (64, 16, 48, 9, "bf16x3"),     # ... the smallest such patches
 ])
 def test_conv_ring_on_a_canvas(gpu, monkeypatch, cout, H, W, N, mode):
     """k_conv_bfr<2,2,..,canvas> (round 6): the ring kernel's fixed 8 x 16 tiles laid over the batch as a grid of
@@ -599,11 +601,26 @@ def test_conv_ring_on_a_canvas(gpu, monkeypatch, cout, H, W, N, mode):
             name = lib.srk_last_kernel_name().decode()
             assert name.startswith("k_conv_bfr<2,2" if cv == "2" else "k_conv_bfw<"), name
             assert ("canvas" in name) == (cv == "2") and ("f16" in name) == (mode == "mixed"), name
+            assert ("canvas0" in name) == (cv == "2" and H % 8 == 0 and W % 16 == 0), name
     finally:
         ops.set_precision("mixed")
     assert lib.srk_ring_timeouts(1) == 0
     assert rel_err(outs["2"], outs["0"]) < 2e-6
     assert rel_err(outs["2"], ref.float()) < (2e-6 if mode == "mixed" else 1e-4)
+    if H % 8 == 0 and W % 16 == 0:   # the same layer on the canvas WITH separators: same products, same order -> equal outputs
+        monkeypatch.setenv("SRK_BFR_CV", "2")
+        monkeypatch.setenv("SRK_BFR", "1")
+        monkeypatch.setenv("SRK_BFR_CV_EXACT", "0")
+        ops.set_precision(mode)
+        try:
+            with torch.no_grad():
+                sep = ops.conv2d_infer(x.to(gpu), w.to(gpu), b.to(gpu), None, cfg)
+            name = lib.srk_last_kernel_name().decode()
+            assert "canvas" in name and "canvas0" not in name, name
+        finally:
+            ops.set_precision("mixed")
+            monkeypatch.setenv("SRK_BFR_CV_EXACT", "1")
+        assert torch.equal(sep, outs["2"])
     # conv + residual (the second conv of a residual block, no activation): the canvas variant adds it when a tile is parked;
     # without the canvas the layer leaves the wave-specialised family (k_conv_bfw has no residual)
     res = fill.randn((N, cout, H, W), 497)
@@ -619,7 +636,8 @@ def test_conv_ring_on_a_canvas(gpu, monkeypatch, cout, H, W, N, mode):
             with torch.no_grad():
                 outs_r[cv] = ops.conv2d_infer(x.to(gpu), w.to(gpu), b.to(gpu), res.to(gpu), cfg_r)
             name = lib.srk_last_kernel_name().decode()
-            assert (name == "k_conv_bfr<2,2%s,canvas,res>" % (",f16" if mode == "mixed" else "")) == (cv == "2"), name
+            tag = "canvas0" if (H % 8 == 0 and W % 16 == 0) else "canvas"
+            assert (name == "k_conv_bfr<2,2%s,%s,res>" % (",f16" if mode == "mixed" else "", tag)) == (cv == "2"), name
             assert not name.startswith("k_conv_bfw<"), name
     finally:
         ops.set_precision("mixed")
@@ -657,7 +675,7 @@ def test_conv_ring_on_a_canvas(gpu, monkeypatch, cout, H, W, N, mode):
     finally:
         lib.srk_conv2d_backward_data_relu = real
     assert lib.srk_ring_timeouts(1) == 0
-    assert names["2"][0] == ["k_conv_bfw<2,9,2,mask,relu>", "k_conv_bfr<2,2,canvas,relu>"], names
+    assert names["2"][0] == ["k_conv_bfw<2,9,2,mask,relu>", "k_conv_bfr<2,2,%s,relu>" % tag], names
     assert all(n.startswith("k_conv_bfw<") for n in names["0"][0]), names   # (the first layer's plain gradient: whatever the
                                                                            #  dispatch takes in this precision mode)
     # (a ReLU whose pre-activation is within rounding of zero may decide differently under another summation order, and flips
